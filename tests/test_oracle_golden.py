@@ -1,0 +1,118 @@
+"""CPU: pins oracle/dccrn_oracle.py against vectors produced by the imported reference
+(oracle/gen_golden.py).  Tolerances are fp32 round-off of two different op orders."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccrn_oracle as O
+from util import load_golden, sub, json_entry, rel_err, max_abs
+
+TINY = dict(rnn_units=16, kernel_num=[4, 4, 8, 8, 16, 16], length=4000)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return load_golden("dccrn_tiny_fwd_bwd.npz")
+
+
+def test_stft_bases_match_reference_rows():
+    g = load_golden("stft_bases_rows.npz")
+    a, s, w = O.stft_bases(400, 512)
+    rows = g["rows"]
+    assert max_abs(a[rows], g["stft"]) < 1e-6
+    assert max_abs(s[rows], g["istft"]) < 1e-6
+    assert max_abs(w, g["window"]) < 1e-7
+
+
+def test_sisnr_cases():
+    g = load_golden("sisnr_cases.npz")
+    for k in ("a", "b", "zero_target", "equal"):
+        v = O.si_snr(torch.from_numpy(g[k + "/est"]), torch.from_numpy(g[k + "/ref"]))
+        assert abs(float(v) - float(g[k + "/si_snr"])) < 2e-4 * max(1.0, abs(float(g[k + "/si_snr"]))), k
+
+
+def test_forward_activations(fx):
+    cfg = O.DCCRNConfig(**TINY)
+    p = sub(fx, "state")
+    cap, stats = {}, {}
+    est = O.dccrn_forward(p, torch.from_numpy(fx["noisy"]), cfg, training=True, capture=cap, stats_out=stats)
+    acts = sub(fx, "act")
+    assert rel_err(cap["stft"], acts["stft"]) < 1e-5
+    for i in range(6):
+        assert rel_err(cap[f"enc{i}.conv"], acts[f"enc{i}.conv"]) < 2e-5, i
+        assert rel_err(cap[f"enc{i}"], acts[f"enc{i}"]) < 2e-5, i
+        assert rel_err(cap[f"dec{i}"], acts[f"dec{i}.full"][..., 1:]) < 5e-5, i
+    assert rel_err(cap["lstm0.r"], acts["lstm0.r"]) < 2e-5
+    assert rel_err(cap["lstm1.i"], acts["lstm1.r.i"]) < 2e-5
+    assert rel_err(cap["istft"], acts["istft"]) < 5e-5
+    assert rel_err(est, fx["est"]) < 5e-5
+    for k, v in sub(fx, "state_after").items():
+        assert rel_err(stats[k].float(), v.float()) < 1e-5, k
+
+
+def test_loss_and_gradients(fx):
+    cfg = O.DCCRNConfig(**TINY)
+    p = sub(fx, "state")
+    names = [k for k in p if O.is_trainable(k)]
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    est = O.dccrn_forward(work, torch.from_numpy(fx["noisy"]), cfg, training=True)
+    loss = O.loss_sisdr(est, torch.from_numpy(fx["clean"])[:, 0])
+    assert abs(float(loss.detach()) - float(fx["loss"])) < 1e-4
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    ref = sub(fx, "grad")
+    assert set(ref) == set(names)
+    for k, g in zip(names, grads):
+        # conv biases that feed a BatchNorm have an analytically zero gradient: both sides are
+        # round-off noise there, hence the absolute floor.
+        err = float((g - ref[k]).norm())
+        assert err < 2e-3 * float(ref[k].norm()) + 2e-6 * g.numel() ** 0.5, (k, err, float(ref[k].norm()))
+
+
+def test_eval_mode(fx):
+    cfg = O.DCCRNConfig(**TINY)
+    p = sub(fx, "state")
+    p.update(sub(fx, "state_after"))
+    est = O.dccrn_forward(p, torch.from_numpy(fx["noisy"]), cfg, training=False)
+    assert rel_err(est, fx["est_eval"]) < 5e-5
+
+
+def test_two_solver_steps():
+    """Oracle train_step x2 vs the real Solver.train() (loss log, grad_norm metric, weights, Adam state)."""
+    g = load_golden("dccrn_tiny_solver.npz")
+    cfg = O.DCCRNConfig(**TINY)
+    p = sub(g, "state0")
+    adam = O.AdamState({k: v for k, v in p.items() if O.is_trainable(k)}, lr=3e-4, betas=(0.9, 0.999))
+    log = json_entry(g, "log_json")
+    losses = [v for (tag, v, _s) in log if tag == "Train/Loss_step"]
+    gnorms = [v for (tag, v, _s) in log if tag == "Train/grad_norm_step"]
+    for s in range(2):
+        loss, metric, _ = O.train_step(p, torch.from_numpy(g[f"noisy{s}"]),
+                                       torch.from_numpy(g[f"clean{s}"])[:, 0], cfg, adam, clip_grad=5)
+        assert abs(loss - losses[s]) < 2e-3 * abs(losses[s]), (s, loss, losses[s])
+        assert abs(metric - gnorms[s]) < 2e-2 * abs(gnorms[s]), (s, metric, gnorms[s])
+    ref = sub(g, "state2")
+    for k, v in ref.items():
+        if v.dtype == torch.int64:
+            assert int(p[k]) == int(v), k
+        else:
+            # a conv bias in front of a BatchNorm has zero true gradient; Adam turns the round-off
+            # noise into +-lr steps of arbitrary sign, so those entries may differ by 2*steps*lr.
+            noise_bias = k.endswith("conv.bias") and not k.startswith("decoder.5.")
+            assert max_abs(p[k], v) < (1.3e-3 if noise_bias else 2e-4), (k, max_abs(p[k], v))
+    for k, v in sub(g, "adam_m").items():
+        if k.endswith("conv.bias") and not k.startswith("decoder.5."):
+            continue
+        assert rel_err(adam.m[k], v) < 5e-3, k
+    keys = json_entry(g, "ckpt_keys_json")
+    assert keys["top"] == ["best_score", "epoch", "model", "optimizer"]
+    assert len(keys["model"]) == 204
+
+
+def test_param_init_shapes_match_reference_schema():
+    g = load_golden("dccrn_tiny_solver.npz")
+    ref = sub(g, "state0")
+    mine = O.init_params(O.DCCRNConfig(**TINY))
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert tuple(mine[k].shape) == tuple(ref[k].shape), k
