@@ -1,0 +1,106 @@
+"""ctypes binding of libsehip.so -- the C-ABI boundary (include/sehip.h).
+
+There is no fallback: if the shared library is missing or a call fails, a SehipError is raised.
+All device pointers are borrowed from torch tensors that the caller keeps alive; every call is
+asynchronous on the caller's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsehip.so")
+
+
+class SehipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+
+# name -> argtypes (all return int status unless listed in _RESTYPE)
+_PROTOS = {
+    "sehip_version": [],
+    "sehip_check_device": [I],
+    "sehip_stft_frames": [I, I, I],
+    "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
+    "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
+    "sehip_grad_sumsq": [P, L, P, P],
+    "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, F, I, P],
+    "sehip_grad_metric": [P, P, I, P, P, P, P],
+    "sehip_stft_fwd": [P, P, I, I, I, I, I, P, P, P],
+    "sehip_istft_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P],
+    "sehip_istft_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
+    "sehip_gemm": [P, P],
+    "sehip_wgrad": [P, P],
+    "sehip_gemm_desc_size": [],
+    "sehip_pack_conv": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "sehip_unpack_conv_grad": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "sehip_cbn_stats": [P, L, I, I, I, I, P, P],
+    "sehip_cbn_finalize": [P, P, P, P, P, L, I, F, F, I, P, P, P],
+    "sehip_cbn_apply": [P, P, P, P, L, I, I, I, I, P],
+    "sehip_cbn_bwd_reduce": [P, P, P, P, P, L, I, I, I, I, P, P],
+    "sehip_cbn_bwd_finalize": [P, P, P, P, P, P, L, I, P],
+    "sehip_cbn_bwd_apply": [P, P, P, P, P, P, P, L, I, I, I, I, P],
+    "sehip_lstm_fwd": [P, P],
+    "sehip_lstm_bwd": [P, P],
+    "sehip_cast_f32_bf16": [P, P, L, P],
+    "sehip_colsum_bf16": [P, L, I, P, P],
+}
+_RESTYPE = {}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SehipError(
+                f"{LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the HIP path.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sehip_last_error.restype = C.c_char_p
+        for name, args in _PROTOS.items():
+            fn = getattr(_lib, name, None)
+            if fn is None:
+                continue
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, C.c_int)
+    return _lib
+
+
+def declared_symbols():
+    return ["sehip_last_error"] + list(_PROTOS)
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().sehip_last_error().decode()
+        raise SehipError(f"{what}: status {status}: {msg}")
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    check(fn(*args), name)
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libsehip needs contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise SehipError(f"{what}: tensor is on {t.device}; the HIP path needs a gfx950 GPU (no CPU fallback)")

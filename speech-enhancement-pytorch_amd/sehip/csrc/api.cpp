@@ -1,0 +1,29 @@
+// libsehip C ABI plumbing: error string, version, device probe.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+int sehip_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* sehip_last_error(void) { return g_err; }
+extern "C" int sehip_version(void) { return 100; }
+
+// Returns 0 when device `dev` is a gfx950 part this library was built for.
+extern "C" int sehip_check_device(int dev) {
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return sehip_set_error(-3, "check_device: %s", hipGetErrorString(e));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return sehip_set_error(-3, "check_device: libsehip is built for gfx950 only, device %d is %s", dev, p.gcnArchName);
+    return 0;
+}

@@ -1,0 +1,107 @@
+// SI-SNR loss forward/backward (reference: src/loss.py:14-29 -- l2_norm, si_snr, loss_sisdr).
+//
+//   s_t   = <x,s>/(<s,s>+eps) * s          (no zero-mean, as in the reference)
+//   e     = x - s_t
+//   l_row = 10*log10( |s_t|^2 / (|e|^2 + eps) + eps )
+//   loss  = -mean_rows(l_row)
+//
+// HBM-bound: one 256-thread workgroup per utterance row; the row is read twice (dot products, then the
+// exact residual energy -- the second read hits L2), the backward is one fused a*x+b*s pass whose two row
+// coefficients were produced by the forward.
+#include "common.h"
+
+#define EPS 1e-8f
+
+// rowstat[r] = {a, b, l_row, unused}; d loss / d x_j = upstream * (a*x_j + b*s_j)
+__global__ __launch_bounds__(256) void sisnr_fwd_kernel(const float* __restrict__ est, const float* __restrict__ ref,
+                                                        int n, int rows, float4* __restrict__ rowstat) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const float* x = est + (size_t)r * n;
+    const float* s = ref + (size_t)r * n;
+    float xs = 0.f, ss = 0.f;
+    const int n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    const bool vec = ((n & 3) == 0) && ((((uintptr_t)x | (uintptr_t)s) & 15) == 0);
+    if (vec) {
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float4 a = x4[i], b = s4[i];
+            xs += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            ss += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) { xs += x[i] * s[i]; ss += s[i] * s[i]; }
+    }
+    xs = block_sum<4>(xs, red);
+    ss = block_sum<4>(ss, red);
+    const float alpha = xs / (ss + EPS);
+    float et = 0.f, en = 0.f, es = 0.f;
+    if (vec) {
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float4 a = x4[i], b = s4[i];
+            float t0 = alpha * b.x, t1 = alpha * b.y, t2 = alpha * b.z, t3 = alpha * b.w;
+            float e0 = a.x - t0, e1 = a.y - t1, e2 = a.z - t2, e3 = a.w - t3;
+            et += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+            en += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+            es += e0 * b.x + e1 * b.y + e2 * b.z + e3 * b.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float t = alpha * s[i], e = x[i] - t;
+            et += t * t; en += e * e; es += e * s[i];
+        }
+    }
+    et = block_sum<4>(et, red);
+    en = block_sum<4>(en, red);
+    es = block_sum<4>(es, red);
+    if (threadIdx.x == 0) {
+        const float ratio = et / (en + EPS);
+        const float l = 10.f * log10f(ratio + EPS);
+        // d l / d ratio, with the -1/rows of loss = -mean folded in
+        const float c = -(1.0f / rows) * 10.f / (2.302585092994046f * (ratio + EPS));
+        const float q = et / ((en + EPS) * (en + EPS));
+        const float a = c * (-2.f * q);
+        const float b = c * (2.f * alpha * ss / ((ss + EPS) * (en + EPS)) + 2.f * q * alpha + 2.f * q * es / (ss + EPS));
+        rowstat[r] = make_float4(a, b, l, alpha);
+    }
+}
+
+__global__ void sisnr_finalize_kernel(const float4* __restrict__ rowstat, int rows, float* __restrict__ loss) {
+    // single wave, deterministic order
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 64) acc += rowstat[i].z;
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[0] = -acc / rows;
+}
+
+__global__ __launch_bounds__(256) void sisnr_bwd_kernel(const float* __restrict__ est, const float* __restrict__ ref,
+                                                        const float4* __restrict__ rowstat, const float* __restrict__ upstream,
+                                                        int n, float* __restrict__ dest) {
+    const int r = blockIdx.y;
+    const float4 st = rowstat[r];
+    const float up = upstream ? upstream[0] : 1.f;
+    const float a = st.x * up, b = st.y * up;
+    const size_t base = (size_t)r * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        dest[base + i] = a * est[base + i] + b * ref[base + i];
+}
+
+extern "C" int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* rowstat, float* loss,
+                               void* stream) {
+    SEHIP_REQUIRE(rows > 0 && n > 0, "sisnr_fwd: empty input (rows=%d n=%d)", rows, n);
+    hipStream_t st = (hipStream_t)stream;
+    sisnr_fwd_kernel<<<rows, 256, 0, st>>>(est, ref, n, rows, (float4*)rowstat);
+    sisnr_finalize_kernel<<<1, 64, 0, st>>>((const float4*)rowstat, rows, loss);
+    SEHIP_CHECK_LAUNCH("sisnr_fwd");
+    return 0;
+}
+
+extern "C" int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, const float* upstream, int rows,
+                               int n, float* dest, void* stream) {
+    SEHIP_REQUIRE(rows > 0 && n > 0, "sisnr_bwd: empty input (rows=%d n=%d)", rows, n);
+    dim3 grid(cdiv(n, 256 * 8), rows);
+    sisnr_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(est, ref, (const float4*)rowstat, upstream, n, dest);
+    SEHIP_CHECK_LAUNCH("sisnr_bwd");
+    return 0;
+}

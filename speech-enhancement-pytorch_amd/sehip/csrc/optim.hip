@@ -1,0 +1,121 @@
+// Optimizer path on ONE flat fp32 parameter / gradient buffer
+// (reference: src/solver.py:487-498 clip_grad_norm_ + optimizer.step + the sum-based grad_norm metric,
+//  src/distrib.py:244-261 Adam/SGD construction).
+//
+//   1. sumsq:   total = sum g^2                         (double accumulator in HBM, no host sync)
+//   2. adam:    coef = min(1, max_norm/(sqrt(total)+1e-6)); g *= coef (written back: the reference's
+//               p.grad is the clipped gradient afterwards); m,v,p update with torch.optim.Adam's formula.
+//   3. tensor_sums: per-parameter-tensor sum(g) for the reference's grad_norm metric
+//               sqrt(sum_p (sum g_p)^2).
+// All HBM-bound single passes over 2.07 M floats (DCCRN); nothing here touches the host.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        float4 v = g4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += g[i] * g[i];
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, (double)acc);
+}
+
+// mode 0: Adam (torch.optim.Adam, amsgrad False, weight_decay wd added to g as L2);
+// mode 1: SGD with momentum (torch.optim.SGD, dampening 0, nesterov False), m = momentum buffer.
+__global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, const double* __restrict__ sumsq,
+                                                       float max_norm, float lr, float b1, float b2, float eps, float bc1,
+                                                       float sqrt_bc2, float wd, int mode, int first_step) {
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        const float total = (float)sqrt(sumsq[0]);
+        coef = fminf(1.f, max_norm / (total + 1e-6f));
+    }
+    const float step_size = lr / bc1;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        float gi = g[i] * coef;
+        g[i] = gi;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        if (mode == 0) {
+            float mi = m[i] * b1 + (1.f - b1) * gi;
+            float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+            p[i] = pi - step_size * (mi / denom);
+        } else {
+            float mi = first_step ? gi : (m[i] * b1 + gi);
+            m[i] = mi;
+            p[i] = pi - lr * (b1 != 0.f ? mi : gi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tensor_sums_kernel(const float* __restrict__ g, const long* __restrict__ offsets,
+                                                          int ntensors, float* __restrict__ sums) {
+    __shared__ float red[4];
+    const int t = blockIdx.x;
+    const long lo = offsets[t], hi = offsets[t + 1];
+    float acc = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) acc += g[i];
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) sums[t] = acc;
+}
+
+// metric[0] = sqrt(sum_t sums[t]^2)  (src/solver.py:494-498); metric[1] = sqrt(sumsq) (pre-clip L2 norm)
+__global__ void grad_metric_kernel(const float* __restrict__ sums, int ntensors, const double* __restrict__ sumsq,
+                                   float* __restrict__ metric) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < ntensors; i += 64) acc += sums[i] * sums[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+        metric[0] = sqrtf(acc);
+        metric[1] = sumsq ? (float)sqrt(sumsq[0]) : 0.f;
+    }
+}
+
+extern "C" int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream) {
+    SEHIP_REQUIRE(n >= 0, "grad_sumsq: negative size");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sumsq_out, 0, sizeof(double), st);
+    SEHIP_REQUIRE(e == hipSuccess, "grad_sumsq: memset failed: %s", hipGetErrorString(e));
+    if (n == 0) return 0;
+    SEHIP_REQUIRE((((uintptr_t)grads) & 15) == 0, "grad_sumsq: gradient buffer must be 16-byte aligned");
+    int grid = cdiv(n, 256 * 16);
+    if (grid > 1024) grid = 1024;
+    sumsq_kernel<<<grid, 256, 0, st>>>(grads, n, sumsq_out);
+    SEHIP_CHECK_LAUNCH("grad_sumsq");
+    return 0;
+}
+
+extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
+                              float max_norm, float lr, float beta1, float beta2, float eps, int step, float weight_decay,
+                              int mode, void* stream) {
+    SEHIP_REQUIRE(n >= 0 && step >= 1, "opt_step: bad n/step (n=%ld step=%d)", n, step);
+    SEHIP_REQUIRE(mode == 0 || mode == 1, "opt_step: mode must be 0 (adam) or 1 (sgd)");
+    SEHIP_REQUIRE(max_norm <= 0.f || sumsq != nullptr, "opt_step: clipping needs the sumsq buffer");
+    if (n == 0) return 0;
+    const double bc1 = mode == 0 ? 1.0 - pow((double)beta1, step) : 1.0;
+    const double bc2 = mode == 0 ? 1.0 - pow((double)beta2, step) : 1.0;
+    int grid = cdiv(n, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
+                                                           (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1);
+    SEHIP_CHECK_LAUNCH("opt_step");
+    return 0;
+}
+
+extern "C" int sehip_grad_metric(const float* grads, const long* offsets, int ntensors, const double* sumsq,
+                                 float* tensor_sums, float* metric, void* stream) {
+    SEHIP_REQUIRE(ntensors > 0, "grad_metric: no tensors");
+    hipStream_t st = (hipStream_t)stream;
+    tensor_sums_kernel<<<ntensors, 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
+    grad_metric_kernel<<<1, 64, 0, st>>>(tensor_sums, ntensors, sumsq, metric);
+    SEHIP_CHECK_LAUNCH("grad_metric");
+    return 0;
+}

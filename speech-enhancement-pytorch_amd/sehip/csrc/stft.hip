@@ -1,0 +1,368 @@
+// Conv-STFT / conv-iSTFT front-end of DCCRN as wave64 FFTs
+// (reference: src/model/dccrn.py:649-747 init_kernels/ConvSTFT/ConviSTFT, and the glue of
+//  DCCRN.forward src/model/dccrn.py:145-154 (mag/phase/DC drop) and :198-229 (mask, istft, clamp)).
+//
+// The reference multiplies every frame by a dense [514 x 400] basis.  That basis is
+//   analysis : rows = (cos, -sin)(2 pi k n / 512) * hann[n]      == 512-point FFT of the windowed frame
+//   synthesis: pinv(K)^T * hann,  K = un-windowed analysis; K^T K = 256 I + (11^T + ss^T)/2, s_n = (-1)^n
+//              => pinv(K) = (1/256) (I - c (11^T + ss^T)) K^T,  c = 1/(512 + win_len)   (win_len even)
+// so both directions are one 512-point complex FFT per frame plus a rank-2 correction.
+//
+// One wavefront owns one frame: lane l holds points l + 64 r (r = 0..7) in registers, does the radix-8
+// part in registers, one twiddle multiply, and the 64-point part across lanes with six __shfl_xor
+// butterfly stages.  Outputs land 8 consecutive bins (or samples) per lane, in bit-reversed lane order,
+// so every store is a full 32/64-byte segment.  HBM-bound; no LDS.
+#include "common.h"
+
+#define FFT_N 512
+#define NBIN 257
+
+struct FftTw {
+    float tr[8], ti[8];  // W512^(lane * k2)
+    float sr[5], si[5];  // stage twiddles W_(2h)^(lane mod h), h = 32,16,8,4,2
+};
+
+template <int SIGN>
+__device__ __forceinline__ void fft_twiddles(FftTw& w, int lane) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float s, c;
+        sincospif((float)(lane * k) * (1.0f / 256.0f), &s, &c);
+        w.tr[k] = c; w.ti[k] = SIGN * s;
+    }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int h = 32 >> st;
+        float s, c;
+        sincospif((float)(lane & (h - 1)) / (float)h, &s, &c);
+        w.sr[st] = c; w.si[st] = SIGN * s;
+    }
+}
+
+// in : lane l, register r  <->  element l + 64 r
+// out: lane l, register j  <->  element 8*brev6(l) + brev3(j)
+template <int SIGN>
+__device__ __forceinline__ void fft512_wave(float (&re)[8], float (&im)[8], const FftTw& w, int lane) {
+    const float h = 0.70710678118654752f;
+    // ---- radix-8 DIF over the register index ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ar = re[i], ai = im[i], br = re[i + 4], bi = im[i + 4];
+        re[i] = ar + br; im[i] = ai + bi;
+        float dr = ar - br, di = ai - bi;
+        // * W8^i : (1), (h, s*h), (0, s), (-h, s*h)  with s = SIGN
+        if (i == 0) { re[4] = dr; im[4] = di; }
+        if (i == 1) { re[5] = h * (dr - SIGN * di); im[5] = h * (di + SIGN * dr); }
+        if (i == 2) { re[6] = -SIGN * di; im[6] = SIGN * dr; }
+        if (i == 3) { re[7] = h * (-dr - SIGN * di); im[7] = h * (-di + SIGN * dr); }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b += 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float ar = re[b + i], ai = im[b + i], br = re[b + i + 2], bi = im[b + i + 2];
+            re[b + i] = ar + br; im[b + i] = ai + bi;
+            float dr = ar - br, di = ai - bi;
+            if (i == 0) { re[b + 2] = dr; im[b + 2] = di; }
+            else        { re[b + 3] = -SIGN * di; im[b + 3] = SIGN * dr; }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) {
+        float ar = re[b], ai = im[b], br = re[b + 1], bi = im[b + 1];
+        re[b] = ar + br; im[b] = ai + bi;
+        re[b + 1] = ar - br; im[b + 1] = ai - bi;
+    }
+    // register j now holds k2 = brev3(j); twiddle by W512^(lane*k2)
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        const float tr = w.tr[brev3[j]], ti = w.ti[brev3[j]];
+        const float xr = re[j], xi = im[j];
+        re[j] = xr * tr - xi * ti;
+        im[j] = xr * ti + xi * tr;
+    }
+    // ---- 64-point DIF across lanes ----
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int hh = 32 >> st;
+        const bool upper = (lane & hh) != 0;
+        const float sr = st < 5 ? w.sr[st] : 1.f, si = st < 5 ? w.si[st] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float pr = __shfl_xor(re[j], hh, 64), pi = __shfl_xor(im[j], hh, 64);
+            if (!upper) { re[j] += pr; im[j] += pi; }
+            else {
+                const float dr = pr - re[j], di = pi - im[j];
+                re[j] = dr * sr - di * si;
+                im[j] = dr * si + di * sr;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int brev6(int l) { return (int)(__brev((unsigned)l) >> 26); }
+
+// ------------------------------------------------------------------------------------------------
+// STFT forward: wav [B][N] fp32 -> spec [B][T][257] float2 (re, im) and the encoder input
+// [B][T][256][2] bf16 (bins 1..256, channels-last real|imag).       src/model/dccrn.py:687-694,147-154
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                       int B, int N, int T, int win, int hop,
+                                                       float2* __restrict__ spec, unsigned* __restrict__ enc_in) {
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= B * T) return;
+    const int b = frame / T, t = frame - b * T;
+    FftTw tw;
+    fft_twiddles<-1>(tw, lane);
+    float re[8], im[8];
+    const int pad = win - hop;
+    const float* x = wav + (size_t)b * N;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
+        const int s = t * hop + n - pad;
+        float v = 0.f;
+        if (n < win && s >= 0 && s < N) v = x[s] * window[n];
+        re[r] = v; im[r] = 0.f;
+    }
+    fft512_wave<-1>(re, im, tw, lane);
+    const int k0 = 8 * brev6(lane);
+    if (k0 > 256) return;
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    float2* so = spec + (size_t)frame * NBIN;
+    unsigned* eo = enc_in + (size_t)frame * 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + brev3[j];
+        if (k <= 256) {
+            so[k] = make_float2(re[j], im[j]);
+            if (k >= 1) eo[k - 1] = pack_bf2(re[j], im[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask ('E' polar / 'C' complex / 'R' real) + inverse transform to windowed frames.
+//   spec [B][T][257] float2, mask [B][T][256][2] fp32 (bins 1..256) -> frames [B][T][win] fp32
+// 'E' without trigonometry: cos(phase)=re/|z|, cos(mask_phase)=m_r/|m| (atan2(0,0)=0 conventions kept).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void apply_mask(int mode, float re, float im, float mr, float mi, float& er, float& ei) {
+    if (mode == 0) {  // E
+        const float z2 = re * re + im * im;
+        const float mags = sqrtf(z2 + 1e-8f);
+        const float zabs = sqrtf(z2);
+        const float cp = zabs > 0.f ? re / zabs : 1.f, sp = zabs > 0.f ? im / zabs : 0.f;
+        const float rho = sqrtf(mr * mr + mi * mi);
+        const float cm = rho > 0.f ? mr / rho : 1.f, sm = rho > 0.f ? mi / rho : 0.f;
+        const float a = tanhf(rho) * mags;
+        er = a * (cp * cm - sp * sm);
+        ei = a * (sp * cm + cp * sm);
+    } else if (mode == 1) {  // C
+        er = re * mr - im * mi;
+        ei = re * mi + im * mr;
+    } else {  // R
+        er = re * mr;
+        ei = im * mi;
+    }
+}
+
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float2* __restrict__ spec, const float2* __restrict__ mask,
+                                                           const float* __restrict__ window, int nframes, int win, int mode,
+                                                           float* __restrict__ frames) {
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= nframes) return;
+    FftTw tw;
+    fft_twiddles<1>(tw, lane);
+    float re[8], im[8];
+    const float2* sp = spec + (size_t)frame * NBIN;
+    const float2* mk = mask + (size_t)frame * 256;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        float er = 0.f, ei = 0.f;
+        if (k >= 1 && k <= 256) {  // DC: the mask row is zero padding -> estimate is exactly 0
+            const float2 z = sp[k];
+            const float2 m = mk[k - 1];
+            apply_mask(mode, z.x, z.y, m.x, m.y, er, ei);
+        }
+        re[r] = er; im[r] = ei;
+    }
+    fft512_wave<1>(re, im, tw, lane);
+    // u[n] = Re(ifft), n = n0 + brev3(j)
+    const int n0 = 8 * brev6(lane);
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    float u[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + brev3[j];
+        u[brev3[j]] = re[j];
+        if (n < win) { s1 += re[j]; s2 += (n & 1) ? -re[j] : re[j]; }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float c = 1.0f / (float)(FFT_N + win);
+    float* fo = frames + (size_t)frame * win;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int n = n0 + q;
+        if (n < win) {
+            const float corr = c * (s1 + ((n & 1) ? -s2 : s2));
+            fo[n] = window[n] * (1.0f / 256.0f) * (u[q] - corr);
+        }
+    }
+}
+
+// overlap-add / window energy, trim, [:length], clamp   (src/model/dccrn.py:733-745, :228)
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ inv_coff,
+                                                        int T, int win, int hop, int length, float* __restrict__ wav) {
+    const int b = blockIdx.y;
+    const int pad = win - hop;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < length; i += gridDim.x * 256) {
+        const int s = i + pad;
+        int t_hi = s / hop;
+        int t_lo = (s - win + hop) / hop;  // ceil((s - win + 1)/hop) for s >= win-1
+        if (s - win + 1 <= 0) t_lo = 0;
+        if (t_hi > T - 1) t_hi = T - 1;
+        float acc = 0.f;
+        for (int t = t_lo; t <= t_hi; ++t) acc += frames[((size_t)b * T + t) * win + (s - t * hop)];
+        acc *= inv_coff[i];
+        wav[(size_t)b * length + i] = fminf(1.f, fmaxf(-1.f, acc));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of clamp + OLA + synthesis + mask:  d wav -> d mask  ([B][T][256][2], bf16 for the dgrad
+// GEMM of the last decoder layer and fp32 copy optional).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void istft_bwd_kernel(const float* __restrict__ dwav, const float* __restrict__ wav,
+                                                        const float* __restrict__ inv_coff, const float* __restrict__ window,
+                                                        const float2* __restrict__ spec, const float2* __restrict__ mask,
+                                                        int B, int T, int win, int hop, int length, int mode,
+                                                        unsigned* __restrict__ dmask_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= B * T) return;
+    const int b = frame / T, t = frame - b * T;
+    FftTw tw;
+    fft_twiddles<-1>(tw, lane);
+    const int pad = win - hop;
+    float re[8], im[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
+        const int i = t * hop + n - pad;
+        float v = 0.f;
+        if (n < win && i >= 0 && i < length) {
+            const size_t o = (size_t)b * length + i;
+            const float y = wav[o];
+            if (y > -1.f && y < 1.f) v = dwav[o] * inv_coff[i] * window[n] * (1.0f / 256.0f);
+        }
+        re[r] = v; im[r] = 0.f;
+        s1 += v; s2 += (n & 1) ? -v : v;   // n parity == lane parity (64 r is even)
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float c = 1.0f / (float)(FFT_N + win);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
+        if (n < win) re[r] -= c * (s1 + ((n & 1) ? -s2 : s2));
+    }
+    fft512_wave<-1>(re, im, tw, lane);
+    const int k0 = 8 * brev6(lane);
+    if (k0 > 256) return;
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    const float2* sp = spec + (size_t)frame * NBIN;
+    const float2* mk = mask + (size_t)frame * 256;
+    unsigned* dm = dmask_bf16 + (size_t)frame * 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + brev3[j];
+        if (k < 1 || k > 256) continue;
+        const float dr = re[j], di = im[j];  // d loss / d est_real[k], d est_imag[k]
+        const float2 z = sp[k];
+        const float2 m = mk[k - 1];
+        float gmr, gmi;
+        if (mode == 0) {
+            const float z2 = z.x * z.x + z.y * z.y;
+            const float mags = sqrtf(z2 + 1e-8f);
+            const float zabs = sqrtf(z2);
+            const float cp = zabs > 0.f ? z.x / zabs : 1.f, sp_ = zabs > 0.f ? z.y / zabs : 0.f;
+            const float rho = sqrtf(m.x * m.x + m.y * m.y);
+            if (rho > 0.f) {
+                const float cm = m.x / rho, sm = m.y / rho;
+                const float ce = cp * cm - sp_ * sm, se = sp_ * cm + cp * sm;  // cos/sin(phase + mask phase)
+                const float th = tanhf(rho);
+                const float g_rho = (dr * ce + di * se) * mags * (1.f - th * th);
+                const float g_mu = th * mags * (-dr * se + di * ce);
+                gmr = g_rho * cm - g_mu * sm / rho;
+                gmi = g_rho * sm + g_mu * cm / rho;
+            } else { gmr = 0.f; gmi = 0.f; }
+        } else if (mode == 1) {
+            gmr = dr * z.x + di * z.y;
+            gmi = -dr * z.y + di * z.x;
+        } else {
+            gmr = dr * z.x;
+            gmi = di * z.y;
+        }
+        dm[k - 1] = pack_bf2(gmr, gmi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int check_stft_cfg(const char* who, int win, int hop, int fft) {
+    SEHIP_REQUIRE(fft == FFT_N, "%s: only fft_len 512 is built (got %d)", who, fft);
+    SEHIP_REQUIRE(win > 0 && win <= FFT_N && (win % 2) == 0, "%s: win_len must be even and <= 512 (got %d)", who, win);
+    SEHIP_REQUIRE(hop > 0 && hop <= win, "%s: bad hop %d", who, hop);
+    return 0;
+}
+
+extern "C" int sehip_stft_frames(int n_samples, int win, int hop) { return (n_samples + 2 * (win - hop) - win) / hop + 1; }
+
+extern "C" int sehip_stft_fwd(const float* wav, const float* window, int B, int N, int win, int hop, int fft, float* spec,
+                              void* enc_in_bf16, void* stream) {
+    if (int e = check_stft_cfg("stft_fwd", win, hop, fft)) return e;
+    SEHIP_REQUIRE(B > 0 && N > 0, "stft_fwd: empty input");
+    const int T = sehip_stft_frames(N, win, hop);
+    SEHIP_REQUIRE(T > 0, "stft_fwd: input shorter than one frame");
+    stft_fwd_kernel<<<cdiv((long)B * T, 4), 256, 0, (hipStream_t)stream>>>(wav, window, B, N, T, win, hop, (float2*)spec,
+                                                                           (unsigned*)enc_in_bf16);
+    SEHIP_CHECK_LAUNCH("stft_fwd");
+    return 0;
+}
+
+extern "C" int sehip_istft_fwd(const float* spec, const float* mask, const float* window, const float* inv_coff, int B,
+                               int T, int win, int hop, int fft, int length, int mode, float* frames_ws, float* wav,
+                               void* stream) {
+    if (int e = check_stft_cfg("istft_fwd", win, hop, fft)) return e;
+    SEHIP_REQUIRE(B > 0 && T > 0 && length > 0, "istft_fwd: empty input");
+    SEHIP_REQUIRE(mode >= 0 && mode <= 2, "istft_fwd: masking mode must be 0(E) 1(C) 2(R)");
+    SEHIP_REQUIRE(length <= (T - 1) * hop + win - (win - hop), "istft_fwd: length %d exceeds the synthesised signal", length);
+    hipStream_t st = (hipStream_t)stream;
+    istft_frames_kernel<<<cdiv((long)B * T, 4), 256, 0, st>>>((const float2*)spec, (const float2*)mask, window, B * T, win,
+                                                             mode, frames_ws);
+    dim3 grid(cdiv(length, 256 * 4), B);
+    istft_ola_kernel<<<grid, 256, 0, st>>>(frames_ws, inv_coff, T, win, hop, length, wav);
+    SEHIP_CHECK_LAUNCH("istft_fwd");
+    return 0;
+}
+
+extern "C" int sehip_istft_bwd(const float* dwav, const float* wav, const float* spec, const float* mask,
+                               const float* window, const float* inv_coff, int B, int T, int win, int hop, int fft,
+                               int length, int mode, void* dmask_bf16, void* stream) {
+    if (int e = check_stft_cfg("istft_bwd", win, hop, fft)) return e;
+    SEHIP_REQUIRE(B > 0 && T > 0 && length > 0, "istft_bwd: empty input");
+    SEHIP_REQUIRE(mode >= 0 && mode <= 2, "istft_bwd: masking mode must be 0(E) 1(C) 2(R)");
+    istft_bwd_kernel<<<cdiv((long)B * T, 4), 256, 0, (hipStream_t)stream>>>(dwav, wav, inv_coff, window, (const float2*)spec,
+                                                                            (const float2*)mask, B, T, win, hop, length, mode,
+                                                                            (unsigned*)dmask_bf16);
+    SEHIP_CHECK_LAUNCH("istft_bwd");
+    return 0;
+}
