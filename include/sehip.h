@@ -1,0 +1,119 @@
+/* libsehip -- C ABI of the MI355X-native (gfx950) train-step path for ooshyun/Speech-Enhancement-Pytorch.
+ *
+ * The reference has no FFI/plugin interface (pure PyTorch); the seam it offers is the Python contract
+ * between `Solver` and the model registry (src/solver.py:388-532, src/distrib.py:226-275).  This header is the
+ * operator-level boundary below that seam: one entry point per op of the DCCRN train step, each citing the
+ * reference code it replaces.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on error (never throws / aborts);
+ *     sehip_last_error() returns the thread-local message of the last failing call;
+ *   - pointers are BORROWED device pointers (hipMalloc / torch CUDA tensors kept alive by the caller);
+ *     the library never allocates, frees or synchronises;
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - "bf16" buffers hold raw bfloat16 bit patterns (uint16_t); activations are CHANNELS-LAST
+ *     [B][T][F][C] with C = real half | imag half.
+ */
+#ifndef SEHIP_H
+#define SEHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sehip_last_error(void);
+int sehip_version(void);
+int sehip_check_device(int device);
+
+/* ---- STFT / iSTFT front-end: src/model/dccrn.py:649-747 (init_kernels, ConvSTFT, ConviSTFT) fused with the
+ *      glue of DCCRN.forward src/model/dccrn.py:145-154 and :198-229 (mask E/C/R, clamp).  fft_len must be 512. */
+int sehip_stft_frames(int n_samples, int win_len, int hop);
+int sehip_stft_fwd(const float* wav /*[B][N]*/, const float* window /*[win]*/, int B, int N, int win_len, int hop,
+                   int fft_len, float* spec /*[B][T][257][2]*/, void* enc_in_bf16 /*[B][T][256][2]*/, void* stream);
+int sehip_istft_fwd(const float* spec, const float* mask /*[B][T][256][2] fp32*/, const float* window,
+                    const float* inv_coff /*[length]*/, int B, int T, int win_len, int hop, int fft_len, int length,
+                    int masking_mode /*0=E 1=C 2=R*/, float* frames_ws /*[B][T][win]*/, float* wav /*[B][length]*/,
+                    void* stream);
+int sehip_istft_bwd(const float* dwav, const float* wav, const float* spec, const float* mask, const float* window,
+                    const float* inv_coff, int B, int T, int win_len, int hop, int fft_len, int length,
+                    int masking_mode, void* dmask_bf16 /*[B][T][256][2]*/, void* stream);
+
+/* ---- SI-SNR loss: src/loss.py:14-29 (si_snr, loss_sisdr).  rowstat is [rows][4] fp32 scratch kept for bwd. */
+int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* rowstat, float* loss, void* stream);
+int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, const float* upstream /*scalar or NULL*/,
+                    int rows, int n, float* dest, void* stream);
+
+/* ---- optimizer path on one flat fp32 buffer: src/solver.py:487-498 (clip_grad_norm_, optimizer.step, grad_norm
+ *      metric) and src/distrib.py:244-261 (Adam / SGD).  mode 0 = Adam, 1 = SGD(momentum=beta1). */
+int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream);
+int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
+                   float lr, float beta1, float beta2, float eps, int step, float weight_decay, int mode, void* stream);
+int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, int ntensors, const double* sumsq,
+                      float* tensor_sums /*[ntensors]*/, float* metric /*[2]: sum-metric, L2 norm*/, void* stream);
+
+/* ---- implicit-GEMM engine (bf16 MFMA, fp32 accumulate) used for
+ *        ComplexConv2d            src/model/dccrn.py:316-384      (fwd, dgrad, wgrad)
+ *        ComplexConvTranspose2d   src/model/dccrn.py:387-450      (fwd incl. complex_cat :304-314 and the frame
+ *                                                                  drop :193-196, dgrad, wgrad)
+ *        nn.LSTM input GEMMs + Linear projections of NavieComplexLSTM  src/model/dccrn.py:264-302
+ *      out[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]);  row m <-> (b, t, j): m = (b*TT + t)*J + j.
+ *      A is never materialised: element (m, 8*c .. 8*c+7) is gathered through ktab[c] from up to 4 channels-last
+ *      source tensors:   src[s][ ((b*T_s + t + toff) * F_s + j*fmul + fadd) * C_s + coff .. +7 ]
+ *      (zero outside [tlo,thi) x [0,F_s)).  C_s == 2 sources use "narrow" chunks: 4 consecutive rows x 2 channels.
+ *      Output columns are scattered 4 at a time through ntab into up to 2 destination tensors. */
+typedef struct {
+    const void* ptr; /* bf16 */
+    int32_t T;       /* frames stored per batch item */
+    int32_t tlo, thi;/* valid stored-frame range */
+    int32_t F;       /* rows per frame */
+    int32_t C;       /* elements per row */
+    int32_t pad_;
+} sehip_src;
+
+typedef struct {
+    int32_t src;  /* source index, -1 = zero chunk */
+    int32_t toff; /* added to the row's t */
+    int32_t fadd; /* added to j*fmul */
+    int32_t coff; /* wide: channel offset (multiple of 8); narrow (C==2): number of valid rows (1..4) */
+} sehip_kchunk;
+
+typedef struct {
+    void* ptr;
+    int32_t T, F, C;      /* destination geometry [B][T][F][C] */
+    int32_t toff;         /* row (b,t,j) -> ((b*T + t + toff)*F + j*fmul + fadd)*C */
+    int32_t fmul, fadd;
+    int32_t is_f32;       /* 0: bf16, 1: fp32 */
+} sehip_dst;
+
+typedef struct {
+    int32_t dst;    /* destination index */
+    int32_t coff;   /* first column inside the destination row */
+    int32_t nvalid; /* 0..4 valid columns of this group of 4 */
+    int32_t pad_;
+} sehip_nchunk;
+
+typedef struct {
+    sehip_src src[4];
+    sehip_dst dst[2];
+    const sehip_kchunk* ktab; /* K/8 entries, device */
+    const sehip_nchunk* ntab; /* Npad/4 entries, device */
+    const void* W;            /* bf16 [Npad][K] */
+    const float* bias;        /* fp32 [Npad] or NULL */
+    float* dW;                /* wgrad only: fp32 [Npad][K], accumulated with atomics (caller zeroes) */
+    float* dbias;             /* wgrad only: fp32 [Npad] column sums of dOut, or NULL */
+    int32_t M, N, Npad, K;    /* K multiple of 64, Npad multiple of 16 */
+    int32_t TT, J, fmul;
+    int32_t pad_;
+} sehip_gemm_desc;
+
+int sehip_gemm_desc_size(void);
+/* forward / dgrad style product */
+int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
+/* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */
+int sehip_wgrad(const sehip_gemm_desc* desc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEHIP_H */

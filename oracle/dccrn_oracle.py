@@ -58,6 +58,44 @@ class DCCRNConfig:
 
 
 # --------------------------------------------------------------------------------------
+# optional bf16 storage simulation (used by the GPU parity tests to separate rounding from logic:
+# the HIP path stores activations / activation gradients in bf16 and feeds bf16 operands to the MFMA)
+# --------------------------------------------------------------------------------------
+class _RoundAct(torch.autograd.Function):
+    """bf16 round-trip of an activation; its gradient is stored in bf16 too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundWeight(torch.autograd.Function):
+    """bf16 round-trip of a GEMM weight; the weight gradient is accumulated in fp32 (straight-through)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class Bf16Sim:
+    act = staticmethod(_RoundAct.apply)
+    weight = staticmethod(_RoundWeight.apply)
+
+
+class NoSim:
+    act = staticmethod(lambda x: x)
+    weight = staticmethod(lambda x: x)
+
+
+# --------------------------------------------------------------------------------------
 # STFT bases (src/model/dccrn.py:649-666)
 # --------------------------------------------------------------------------------------
 def hann_periodic(n: int) -> np.ndarray:
@@ -184,7 +222,7 @@ def complex_batchnorm(x, p, prefix, training, eps=1e-5, momentum=0.1, stats_out=
     return torch.cat([yr, yi], 1)
 
 
-def lstm_single(x, w_ih, w_hh, b_ih, b_hh):
+def lstm_single(x, w_ih, w_hh, b_ih, b_hh, sim=NoSim):
     """One-layer unidirectional nn.LSTM with zero initial state; x [T,B,I] -> [T,B,H].
 
     Gate order i,f,g,o (PyTorch).  Written as an explicit recurrence so that the HIP
@@ -192,6 +230,7 @@ def lstm_single(x, w_ih, w_hh, b_ih, b_hh):
     """
     steps, batch, _ = x.shape
     hidden = w_hh.shape[1]
+    w_ih, w_hh = sim.weight(w_ih), sim.weight(w_hh)
     pre = x @ w_ih.t() + (b_ih + b_hh)
     h = x.new_zeros(batch, hidden)
     c = x.new_zeros(batch, hidden)
@@ -200,17 +239,17 @@ def lstm_single(x, w_ih, w_hh, b_ih, b_hh):
         gates = pre[t] + h @ w_hh.t()
         i, f, g, o = gates.chunk(4, 1)
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-        h = torch.sigmoid(o) * torch.tanh(c)
+        h = sim.act(torch.sigmoid(o) * torch.tanh(c))
         outs.append(h)
     return torch.stack(outs, 0)
 
 
-def complex_lstm(real, imag, p, prefix, has_projection):
+def complex_lstm(real, imag, p, prefix, has_projection, sim=NoSim):
     """src/model/dccrn.py:283-298: four LSTM passes + optional 2 Linear projections."""
     def run(which, x):
         q = prefix + which + "."
         return lstm_single(x, p[q + "weight_ih_l0"], p[q + "weight_hh_l0"],
-                           p[q + "bias_ih_l0"], p[q + "bias_hh_l0"])
+                           p[q + "bias_ih_l0"], p[q + "bias_hh_l0"], sim)
     r2r = run("real_lstm", real)
     r2i = run("imag_lstm", real)
     i2r = run("real_lstm", imag)
@@ -218,8 +257,8 @@ def complex_lstm(real, imag, p, prefix, has_projection):
     out_r = r2r - i2i
     out_i = i2r + r2i
     if has_projection:
-        out_r = F.linear(out_r, p[prefix + "r_trans.weight"], p[prefix + "r_trans.bias"])
-        out_i = F.linear(out_i, p[prefix + "i_trans.weight"], p[prefix + "i_trans.bias"])
+        out_r = F.linear(out_r, sim.weight(p[prefix + "r_trans.weight"]), p[prefix + "r_trans.bias"])
+        out_i = F.linear(out_i, sim.weight(p[prefix + "i_trans.weight"]), p[prefix + "i_trans.bias"])
     return out_r, out_i
 
 
@@ -227,7 +266,7 @@ def complex_lstm(real, imag, p, prefix, has_projection):
 # DCCRN forward (src/model/dccrn.py:145-229)
 # --------------------------------------------------------------------------------------
 def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_out=None,
-                  bases=None):
+                  bases=None, sim=NoSim):
     """p: dict name->tensor with the reference's state_dict keys.  wav [B,1,N] -> [B,1,length].
 
     ``capture`` (dict) receives named intermediates; ``stats_out`` the updated BN buffers.
@@ -243,16 +282,17 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
     real, imag = spec[:, :nbin], spec[:, nbin:]
     mags = torch.sqrt(real ** 2 + imag ** 2 + 1e-8)
     phase = torch.atan2(imag, real)
-    out = torch.stack([real, imag], 1)[:, :, 1:]  # drop DC bin
+    out = sim.act(torch.stack([real, imag], 1)[:, :, 1:])  # drop DC bin
 
     skips = []
     for i in range(cfg.n_layers):
         pre = f"encoder.{i}."
-        out = complex_conv2d(out, p[pre + "0.real_conv.weight"], p[pre + "0.real_conv.bias"],
-                             p[pre + "0.imag_conv.weight"], p[pre + "0.imag_conv.bias"])
+        out = complex_conv2d(out, sim.weight(p[pre + "0.real_conv.weight"]), p[pre + "0.real_conv.bias"],
+                             sim.weight(p[pre + "0.imag_conv.weight"]), p[pre + "0.imag_conv.bias"])
+        out = sim.act(out)
         cap[f"enc{i}.conv"] = out
         out = complex_batchnorm(out, p, pre + "1.", training, stats_out=stats_out)
-        out = F.prelu(out, p[pre + "2.weight"])
+        out = sim.act(F.prelu(out, p[pre + "2.weight"]))
         cap[f"enc{i}"] = out
         skips.append(out)
 
@@ -262,7 +302,9 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
     i_in = seq[:, :, ch // 2:].reshape(t, b, ch // 2 * d)
     for layer in range(cfg.rnn_layers):
         r_in, i_in = complex_lstm(r_in, i_in, p, f"enhance.{layer}.",
-                                  has_projection=(layer == cfg.rnn_layers - 1))
+                                  has_projection=(layer == cfg.rnn_layers - 1), sim=sim)
+        if layer == cfg.rnn_layers - 1:
+            r_in, i_in = sim.act(r_in), sim.act(i_in)
         cap[f"lstm{layer}.r"] = r_in
         cap[f"lstm{layer}.i"] = i_in
     r_in = r_in.reshape(t, b, ch // 2, d)
@@ -272,12 +314,13 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
     for i in range(cfg.n_layers):
         pre = f"decoder.{i}."
         out = complex_cat(out, skips[-1 - i])
-        out = complex_deconv2d(out, p[pre + "0.real_conv.weight"], p[pre + "0.real_conv.bias"],
-                               p[pre + "0.imag_conv.weight"], p[pre + "0.imag_conv.bias"])
+        out = complex_deconv2d(out, sim.weight(p[pre + "0.real_conv.weight"]), p[pre + "0.real_conv.bias"],
+                               sim.weight(p[pre + "0.imag_conv.weight"]), p[pre + "0.imag_conv.bias"])
         if i != cfg.n_layers - 1:
+            out = sim.act(out)
             cap[f"dec{i}.conv"] = out[..., 1:]
             out = complex_batchnorm(out, p, pre + "1.", training, stats_out=stats_out)
-            out = F.prelu(out, p[pre + "2.weight"])
+            out = sim.act(F.prelu(out, p[pre + "2.weight"]))
         out = out[..., 1:]  # drop the first frame (src/model/dccrn.py:196)
         cap[f"dec{i}"] = out
 

@@ -40,18 +40,17 @@ _PROTOS = {
     "sehip_gemm": [P, P],
     "sehip_wgrad": [P, P],
     "sehip_gemm_desc_size": [],
-    "sehip_pack_conv": [P, P, P, P, P, P, I, I, I, I, I, P],
-    "sehip_unpack_conv_grad": [P, P, P, P, P, P, I, I, I, I, I, P],
-    "sehip_cbn_stats": [P, L, I, I, I, I, P, P],
-    "sehip_cbn_finalize": [P, P, P, P, P, L, I, F, F, I, P, P, P],
-    "sehip_cbn_apply": [P, P, P, P, L, I, I, I, I, P],
+    "sehip_pack_bf16": [P, P, L, P, P],
+    "sehip_pack_f32": [P, P, L, P, P],
+    "sehip_unpack_grad": [P, P, L, P, P],
+    "sehip_cbn_stats": [P, L, I, P, P],
+    "sehip_cbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],
+    "sehip_cbn_apply": [P, P, P, L, I, P, P],
     "sehip_cbn_bwd_reduce": [P, P, P, P, P, L, I, I, I, I, P, P],
-    "sehip_cbn_bwd_finalize": [P, P, P, P, P, P, L, I, P],
-    "sehip_cbn_bwd_apply": [P, P, P, P, P, P, P, L, I, I, I, I, P],
-    "sehip_lstm_fwd": [P, P],
-    "sehip_lstm_bwd": [P, P],
-    "sehip_cast_f32_bf16": [P, P, L, P],
-    "sehip_colsum_bf16": [P, L, I, P, P],
+    "sehip_cbn_bwd_finalize": [P, P, P, P, P, L, I, P, P, P, P, P, P, P, P],
+    "sehip_cbn_bwd_apply": [P, P, P, P, P, P, L, I, I, I, I, P, P],
+    "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
+    "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
 }
 _RESTYPE = {}
 

@@ -1,0 +1,400 @@
+// ComplexBatchNorm (2x2 whitening) + single-slope PReLU, forward and backward, on channels-last bf16
+// activations [rows][C], C = 2*Cr (real half | imag half).
+// Reference: src/model/dccrn.py:457-634 (ComplexBatchNorm; training branch :549-611, whitening :593-602,
+// running-stat lerp :555-556,577-579) and nn.PReLU() at :79,122.  The reference spends ~15 elementwise passes and
+// 10 chained .mean() reductions per call; here the layer is
+//   forward : stats (1 read)  -> per-channel finalize -> apply+PReLU (1 read, 1 write)
+//   backward: reduce (2 reads) -> per-channel finalize -> apply (2 reads, 1 write)
+// all HBM-bound with 16-byte loads: one thread owns 8 complex channels (a real chunk and its imag chunk).
+//
+// Backward derivation (c = y - M, xh = U c, o = Wm xh + B, z = prelu(o)):
+//   d = dz * (o > 0 ? 1 : a);  da = sum dz*o*[o<=0];  dB = sum d;  dWm from  P = Q U  (Q = sum d c^T)
+//   dxh = Wm d;  dU from H = Wm Q;  dV by reverse mode through the closed-form inverse square root;
+//   dy = A d + E c - A mean(d),  A = U Wm,  E = (1/N) [[2 dVrr, dVri],[dVri, 2 dVii]].
+#include "common.h"
+
+#define COEF_STRIDE 16  // floats per channel in the coefficient records
+
+// fwd coef record: 0 Zrr 1 Zri 2 Zir 3 Zii 4 Mr 5 Mi 6 Br 7 Bi 8 Urr 9 Uri 10 Uii 11 vrr(+eps) 12 vri 13 vii(+eps)
+// bwd coef record: 0 Arr 1 Ari 2 Air 3 Aii 4 Err 5 Eri 6 Eii 7 kr 8 ki
+
+struct Chunk8 { float v[8]; };
+__device__ __forceinline__ Chunk8 unpack8(uint4 u) {
+    Chunk8 c;
+    c.v[0] = bf2f((bf16_raw)(u.x & 0xffff)); c.v[1] = bf2f((bf16_raw)(u.x >> 16));
+    c.v[2] = bf2f((bf16_raw)(u.y & 0xffff)); c.v[3] = bf2f((bf16_raw)(u.y >> 16));
+    c.v[4] = bf2f((bf16_raw)(u.z & 0xffff)); c.v[5] = bf2f((bf16_raw)(u.z >> 16));
+    c.v[6] = bf2f((bf16_raw)(u.w & 0xffff)); c.v[7] = bf2f((bf16_raw)(u.w >> 16));
+    return c;
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// Reduce NS per-thread sums (for 8 channels each) over the threads of the block that share a chunk column q,
+// then add them to the double accumulators acc[s*Cr + channel].
+template <int NS>
+__device__ __forceinline__ void block_accumulate(float (&s)[NS][8], int q, int nq, int Cr, double* __restrict__ acc,
+                                                 float* lds /* 256 floats */) {
+    const int tid = threadIdx.x;
+    const int groups = 256 / nq;  // threads per chunk column
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __syncthreads();
+            lds[tid] = s[a][j];
+            __syncthreads();
+            if (tid < nq) {  // thread tid sums column tid
+                float t = 0.f;
+                for (int g = 0; g < groups; ++g) t += lds[g * nq + tid];
+                atomicAdd(&acc[(size_t)a * Cr + tid * 8 + j], (double)t);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restrict__ y, long rows, int Cr,
+                                                        double* __restrict__ acc /* [5][Cr] */) {
+    __shared__ float lds[256];
+    const int nq = Cr >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    float s[5][8];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[a][j] = 0.f;
+    const int C = 2 * Cr;
+    if (rl < rpb)
+        for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
+            const Chunk8 a = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
+            const Chunk8 b = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[0][j] += a.v[j]; s[1][j] += b.v[j];
+                s[2][j] += a.v[j] * a.v[j]; s[3][j] += a.v[j] * b.v[j]; s[4][j] += b.v[j] * b.v[j];
+            }
+        }
+    block_accumulate<5>(s, q, nq, Cr, acc, lds);
+}
+
+// one thread per complex channel
+__global__ void cbn_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ Wrr, const float* __restrict__ Wri,
+                                    const float* __restrict__ Wii, const float* __restrict__ Br, const float* __restrict__ Bi,
+                                    float* __restrict__ RMr, float* __restrict__ RMi, float* __restrict__ RVrr,
+                                    float* __restrict__ RVri, float* __restrict__ RVii, long* __restrict__ nbt, long rows,
+                                    int Cr, float eps, float momentum, int training, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cr) return;
+    float mr, mi, vrr, vri, vii;
+    if (training) {
+        const double n = (double)rows;
+        const double dmr = acc[c] / n, dmi = acc[Cr + c] / n;
+        mr = (float)dmr; mi = (float)dmi;
+        vrr = (float)(acc[2 * Cr + c] / n - dmr * dmr);
+        vri = (float)(acc[3 * Cr + c] / n - dmr * dmi);
+        vii = (float)(acc[4 * Cr + c] / n - dmi * dmi);
+        RMr[c] += momentum * (mr - RMr[c]);
+        RMi[c] += momentum * (mi - RMi[c]);
+        RVrr[c] += momentum * (vrr - RVrr[c]);
+        RVri[c] += momentum * (vri - RVri[c]);
+        RVii[c] += momentum * (vii - RVii[c]);
+        if (c == 0 && nbt) nbt[0] += 1;
+    } else {
+        mr = RMr[c]; mi = RMi[c]; vrr = RVrr[c]; vri = RVri[c]; vii = RVii[c];
+    }
+    vrr += eps; vii += eps;
+    const float tau = vrr + vii;
+    const float delta = vrr * vii - vri * vri;
+    const float s = sqrtf(delta);
+    const float t = sqrtf(tau + 2.f * s);
+    const float rst = 1.f / (s * t);
+    const float urr = (s + vii) * rst, uii = (s + vrr) * rst, uri = -vri * rst;
+    const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
+    float* o = coef + (size_t)c * COEF_STRIDE;
+    o[0] = wrr * urr + wri * uri;
+    o[1] = wrr * uri + wri * uii;
+    o[2] = wri * urr + wii * uri;
+    o[3] = wri * uri + wii * uii;
+    o[4] = mr; o[5] = mi; o[6] = Br[c]; o[7] = Bi[c];
+    o[8] = urr; o[9] = uri; o[10] = uii; o[11] = vrr; o[12] = vri; o[13] = vii;
+}
+
+__global__ __launch_bounds__(256) void cbn_apply_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                        const float* __restrict__ slope, long rows, int Cr,
+                                                        bf16_raw* __restrict__ z) {
+    const int nq = Cr >> 3;
+    const int C = 2 * Cr;
+    const long total = rows * nq;
+    const float a = slope[0];
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const long r = id / nq;
+        const int q = (int)(id - r * nq);
+        const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
+        const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
+        float orr[8], oii[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
+            const float4 zc = *reinterpret_cast<const float4*>(k);
+            const float4 mb = *reinterpret_cast<const float4*>(k + 4);
+            const float cr = xr.v[j] - mb.x, ci = xi.v[j] - mb.y;
+            float vr = zc.x * cr + zc.y * ci + mb.z;
+            float vi = zc.z * cr + zc.w * ci + mb.w;
+            orr[j] = vr > 0.f ? vr : a * vr;
+            oii[j] = vi > 0.f ? vi : a * vi;
+        }
+        *reinterpret_cast<uint4*>(z + r * C + q * 8) = pack8(orr);
+        *reinterpret_cast<uint4*>(z + r * C + Cr + q * 8) = pack8(oii);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward pass 1: per-channel sums  0 sum d_r  1 sum d_i  2 Qrr  3 Qri  4 Qir  5 Qii ; slope grad -> acc[6*Cr]
+// rows whose stored frame index (row / F) % Tst is < tfirst carry dz == 0 (dropped decoder frame).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
+                                                             const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                             const float* __restrict__ slope, long rows, int Cr, int F,
+                                                             int Tst, int tfirst, double* __restrict__ acc) {
+    __shared__ float lds[256];
+    const int nq = Cr >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    const int C = 2 * Cr;
+    const float a = slope[0];
+    float s[6][8];
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[u][j] = 0.f;
+    float da = 0.f;
+    float4 zc[8], mb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
+        zc[j] = *reinterpret_cast<const float4*>(k);
+        mb[j] = *reinterpret_cast<const float4*>(k + 4);
+    }
+    if (rl < rpb)
+        for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
+            if (tfirst > 0 && (int)((r / F) % Tst) < tfirst) continue;
+            const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
+            const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
+            Chunk8 gr = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + q * 8));
+            Chunk8 gi = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + Cr + q * 8));
+            if (dz2) {
+                const Chunk8 hr = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + q * 8));
+                const Chunk8 hi = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + Cr + q * 8));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
+                const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
+                const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
+                float dr = gr.v[j], di = gi.v[j];
+                if (!(vr > 0.f)) { da += dr * vr; dr *= a; }
+                if (!(vi > 0.f)) { da += di * vi; di *= a; }
+                s[0][j] += dr; s[1][j] += di;
+                s[2][j] += dr * cr; s[3][j] += dr * ci; s[4][j] += di * cr; s[5][j] += di * ci;
+            }
+        }
+    block_accumulate<6>(s, q, nq, Cr, acc, lds);
+    da = wave_sum(da);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = da;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&acc[(size_t)6 * Cr], (double)(lds[0] + lds[1] + lds[2] + lds[3]));
+}
+
+// one thread per channel: parameter gradients + coefficients of the apply pass
+__global__ void cbn_bwd_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ coef,
+                                        const float* __restrict__ Wrr, const float* __restrict__ Wri,
+                                        const float* __restrict__ Wii, long rows, int Cr, float* __restrict__ gWrr,
+                                        float* __restrict__ gWri, float* __restrict__ gWii, float* __restrict__ gBr,
+                                        float* __restrict__ gBi, float* __restrict__ gslope, float* __restrict__ bcoef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) gslope[0] = (float)acc[(size_t)6 * Cr];
+    if (c >= Cr) return;
+    const float* k = coef + (size_t)c * COEF_STRIDE;
+    const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
+    const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
+    const float n = (float)rows;
+    const float sdr = (float)acc[c], sdi = (float)acc[Cr + c];
+    const float qrr = (float)acc[2 * Cr + c], qri = (float)acc[3 * Cr + c];
+    const float qir = (float)acc[4 * Cr + c], qii = (float)acc[5 * Cr + c];
+    // P = Q U  (sum d xh^T)
+    const float prr = qrr * urr + qri * uri, pri = qrr * uri + qri * uii;
+    const float pir = qir * urr + qii * uri, pii = qir * uri + qii * uii;
+    gWrr[c] = prr;
+    gWri[c] = pri + pir;
+    gWii[c] = pii;
+    gBr[c] = sdr;
+    gBi[c] = sdi;
+    // H = Wm Q  (sum dxh c^T)
+    const float hrr = wrr * qrr + wri * qir, hri = wrr * qri + wri * qii;
+    const float hir = wri * qrr + wii * qir, hii = wri * qri + wii * qii;
+    const float dUrr = hrr, dUri = hri + hir, dUii = hii;
+    // reverse mode through the closed-form V^(-1/2)
+    const float tau = vrr + vii;
+    const float delta = vrr * vii - vri * vri;
+    const float s = sqrtf(delta);
+    const float t = sqrtf(tau + 2.f * s);
+    const float rst = 1.f / (s * t);
+    const float d_rst = dUrr * (s + vii) - dUri * vri + dUii * (s + vrr);
+    float d_s = (dUrr + dUii) * rst;
+    float d_vii = dUrr * rst, d_vrr = dUii * rst, d_vri = -dUri * rst;
+    d_s += d_rst * (-rst / s);
+    const float d_t = d_rst * (-rst / t);
+    const float d_tau = d_t / (2.f * t);
+    d_s += d_t / t;
+    const float d_delta = d_s / (2.f * s);
+    d_vrr += d_delta * vii + d_tau;
+    d_vii += d_delta * vrr + d_tau;
+    d_vri += d_delta * (-2.f * vri);
+    // A = U Wm
+    const float arr = urr * wrr + uri * wri, ari = urr * wri + uri * wii;
+    const float air = uri * wrr + uii * wri, aii = uri * wri + uii * wii;
+    float* o = bcoef + (size_t)c * COEF_STRIDE;
+    o[0] = arr; o[1] = ari; o[2] = air; o[3] = aii;
+    o[4] = 2.f * d_vrr / n; o[5] = d_vri / n; o[6] = 2.f * d_vii / n;
+    o[7] = -(arr * sdr + ari * sdi) / n;
+    o[8] = -(air * sdr + aii * sdi) / n;
+}
+
+__global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
+                                                            const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                            const float* __restrict__ bcoef, const float* __restrict__ slope,
+                                                            long rows, int Cr, int F, int Tst, int tfirst,
+                                                            bf16_raw* __restrict__ dy) {
+    const int nq = Cr >> 3;
+    const int C = 2 * Cr;
+    const long total = rows * nq;
+    const float a = slope[0];
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const long r = id / nq;
+        const int q = (int)(id - r * nq);
+        const bool dropped = tfirst > 0 && (int)((r / F) % Tst) < tfirst;
+        const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
+        const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
+        Chunk8 gr, gi;
+        if (dropped) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gr.v[j] = 0.f; gi.v[j] = 0.f; }
+        } else {
+            gr = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + q * 8));
+            gi = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + Cr + q * 8));
+            if (dz2) {
+                const Chunk8 hr = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + q * 8));
+                const Chunk8 hi = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + Cr + q * 8));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
+            }
+        }
+        float orr[8], oii[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
+            const float* kb = bcoef + (size_t)(q * 8 + j) * COEF_STRIDE;
+            const float4 zc = *reinterpret_cast<const float4*>(k);
+            const float4 mb = *reinterpret_cast<const float4*>(k + 4);
+            const float4 A = *reinterpret_cast<const float4*>(kb);
+            const float4 E = *reinterpret_cast<const float4*>(kb + 4);  // Err Eri Eii kr
+            const float ki = kb[8];
+            const float cr = xr.v[j] - mb.x, ci = xi.v[j] - mb.y;
+            const float vr = zc.x * cr + zc.y * ci + mb.z;
+            const float vi = zc.z * cr + zc.w * ci + mb.w;
+            float dr = gr.v[j], di = gi.v[j];
+            if (!(vr > 0.f)) dr *= a;
+            if (!(vi > 0.f)) di *= a;
+            orr[j] = A.x * dr + A.y * di + E.x * cr + E.y * ci + E.w;
+            oii[j] = A.z * dr + A.w * di + E.y * cr + E.z * ci + ki;
+        }
+        *reinterpret_cast<uint4*>(dy + r * C + q * 8) = pack8(orr);
+        *reinterpret_cast<uint4*>(dy + r * C + Cr + q * 8) = pack8(oii);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_cbn(const char* who, long rows, int Cr) {
+    SEHIP_REQUIRE(rows > 0, "%s: empty input", who);
+    SEHIP_REQUIRE(Cr >= 8 && (Cr & 7) == 0 && Cr <= 2048 && (256 % (Cr >> 3) == 0 || (Cr >> 3) > 256),
+                  "%s: complex channels Cr=%d must be 8,16,32,...,2048 (power-of-two multiples of 8)", who, Cr);
+    SEHIP_REQUIRE((Cr >> 3) <= 256, "%s: Cr=%d too large", who, Cr);
+    return 0;
+}
+static int grid_for(long work_items) {
+    long g = (work_items + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// acc must hold 7*Cr+1 doubles; zeroed here.
+extern "C" int sehip_cbn_stats(const void* y, long rows, int Cr, double* acc, void* stream) {
+    if (int e = check_cbn("cbn_stats", rows, Cr)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t he = hipMemsetAsync(acc, 0, sizeof(double) * (5 * (size_t)Cr), st);
+    SEHIP_REQUIRE(he == hipSuccess, "cbn_stats: memset failed: %s", hipGetErrorString(he));
+    const int rpb = 256 / (Cr >> 3);
+    long g = (rows + (long)rpb * 16 - 1) / ((long)rpb * 16);
+    if (g > 2048) g = 2048;
+    cbn_stats_kernel<<<(int)g, 256, 0, st>>>((const bf16_raw*)y, rows, Cr, acc);
+    SEHIP_CHECK_LAUNCH("cbn_stats");
+    return 0;
+}
+
+// params: Wrr,Wri,Wii,Br,Bi [Cr] fp32; buffers RMr,RMi,RVrr,RVri,RVii [Cr] fp32 (updated in training), nbt int64[1]
+extern "C" int sehip_cbn_finalize(const double* acc, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
+                                  const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
+                                  long rows, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
+    if (int e = check_cbn("cbn_finalize", rows, Cr)) return e;
+    cbn_finalize_kernel<<<cdiv(Cr, 64), 64, 0, (hipStream_t)stream>>>(acc, Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr, RVri, RVii,
+                                                                      nbt, rows, Cr, eps, momentum, training, coef);
+    SEHIP_CHECK_LAUNCH("cbn_finalize");
+    return 0;
+}
+
+extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream) {
+    if (int e = check_cbn("cbn_apply", rows, Cr)) return e;
+    cbn_apply_kernel<<<grid_for(rows * (Cr >> 3)), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, coef, slope, rows, Cr,
+                                                                                 (bf16_raw*)z);
+    SEHIP_CHECK_LAUNCH("cbn_apply");
+    return 0;
+}
+
+extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
+                                    long rows, int Cr, int F, int Tst, int tfirst, double* acc, void* stream) {
+    if (int e = check_cbn("cbn_bwd_reduce", rows, Cr)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t he = hipMemsetAsync(acc, 0, sizeof(double) * (6 * (size_t)Cr + 1), st);
+    SEHIP_REQUIRE(he == hipSuccess, "cbn_bwd_reduce: memset failed: %s", hipGetErrorString(he));
+    const int rpb = 256 / (Cr >> 3);
+    long g = (rows + (long)rpb * 16 - 1) / ((long)rpb * 16);
+    if (g > 2048) g = 2048;
+    cbn_bwd_reduce_kernel<<<(int)g, 256, 0, st>>>((const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope,
+                                                  rows, Cr, F, Tst, tfirst, acc);
+    SEHIP_CHECK_LAUNCH("cbn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int sehip_cbn_bwd_finalize(const double* acc, const float* coef, const float* Wrr, const float* Wri,
+                                      const float* Wii, long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr,
+                                      float* gBi, float* gslope, float* bcoef, void* stream) {
+    if (int e = check_cbn("cbn_bwd_finalize", rows, Cr)) return e;
+    cbn_bwd_finalize_kernel<<<cdiv(Cr, 64), 64, 0, (hipStream_t)stream>>>(acc, coef, Wrr, Wri, Wii, rows, Cr, gWrr, gWri, gWii,
+                                                                          gBr, gBi, gslope, bcoef);
+    SEHIP_CHECK_LAUNCH("cbn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
+                                   const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream) {
+    if (int e = check_cbn("cbn_bwd_apply", rows, Cr)) return e;
+    cbn_bwd_apply_kernel<<<grid_for(rows * (Cr >> 3)), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, bcoef, slope, rows, Cr, F, Tst, tfirst,
+        (bf16_raw*)dy);
+    SEHIP_CHECK_LAUNCH("cbn_bwd_apply");
+    return 0;
+}

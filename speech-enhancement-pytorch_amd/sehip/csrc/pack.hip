@@ -1,0 +1,62 @@
+// Table-driven weight packing / gradient un-packing between the reference's parameter tensors (one flat fp32
+// buffer holding every tensor of the state_dict, src/model/dccrn.py:62-137) and the GEMM-side layouts:
+//   - packed bf16 weights  W[n][k]  (complex block matrix [[Wr,-Wi],[Wi,Wr]], tap/channel order of the K table,
+//     LSTM column permutations, [W|-W] sign-folded concatenations)
+//   - packed fp32 biases   (ComplexConv2d adds each real conv's bias twice-signed: real b_r-b_i, imag b_r+b_i,
+//     src/model/dccrn.py:374-382; LSTM b_ih+b_hh)
+//   - parameter gradients  g[j] = sum of up to 4 signed entries of the packed-gradient buffer.
+// An entry e encodes (index << 1) | negate, -1 = absent.  The tables are built once on the host.
+#include "common.h"
+
+__device__ __forceinline__ float term(const float* __restrict__ src, int e) {
+    if (e < 0) return 0.f;
+    const float v = src[e >> 1];
+    return (e & 1) ? -v : v;
+}
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ params, const int* __restrict__ tab, long n,
+                                                        bf16_raw* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = f2bf(term(params, tab[i]));
+}
+
+__global__ __launch_bounds__(256) void pack_f32_kernel(const float* __restrict__ params, const int2* __restrict__ tab, long n,
+                                                       float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int2 e = tab[i];
+        out[i] = term(params, e.x) + term(params, e.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restrict__ packed, const int4* __restrict__ tab, long n,
+                                                          float* __restrict__ grads) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int4 e = tab[i];
+        grads[i] = term(packed, e.x) + term(packed, e.y) + term(packed, e.z) + term(packed, e.w);
+    }
+}
+
+static int grid_of(long n) { long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
+
+extern "C" int sehip_pack_bf16(const float* params, const int* table, long n, void* out_bf16, void* stream) {
+    SEHIP_REQUIRE(n >= 0, "pack_bf16: negative size");
+    if (n == 0) return 0;
+    pack_bf16_kernel<<<grid_of(n), 256, 0, (hipStream_t)stream>>>(params, table, n, (bf16_raw*)out_bf16);
+    SEHIP_CHECK_LAUNCH("pack_bf16");
+    return 0;
+}
+
+extern "C" int sehip_pack_f32(const float* params, const int* table2, long n, float* out, void* stream) {
+    SEHIP_REQUIRE(n >= 0, "pack_f32: negative size");
+    if (n == 0) return 0;
+    pack_f32_kernel<<<grid_of(n), 256, 0, (hipStream_t)stream>>>(params, (const int2*)table2, n, out);
+    SEHIP_CHECK_LAUNCH("pack_f32");
+    return 0;
+}
+
+extern "C" int sehip_unpack_grad(const float* packed, const int* table4, long n, float* grads, void* stream) {
+    SEHIP_REQUIRE(n >= 0, "unpack_grad: negative size");
+    if (n == 0) return 0;
+    unpack_grad_kernel<<<grid_of(n), 256, 0, (hipStream_t)stream>>>(packed, (const int4*)table4, n, grads);
+    SEHIP_CHECK_LAUNCH("unpack_grad");
+    return 0;
+}

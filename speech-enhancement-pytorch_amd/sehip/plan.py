@@ -1,0 +1,811 @@
+"""Host-side plan of the DCCRN train step on libsehip: parameter layout, packing tables, implicit-GEMM
+descriptors and the launch sequences of forward and backward.
+
+Everything numeric runs in libsehip (HIP); this module only does bookkeeping with numpy at construction time:
+  * ParamLayout  -- the reference's state_dict schema (src/model/dccrn.py:62-137) laid out in
+                    ONE flat fp32 buffer (parameters) + one flat fp32 buffer (BatchNorm running statistics).
+  * pack tables  -- how the GEMM-side bf16 weights / fp32 biases are gathered from the flat parameters and how the
+                    packed gradients fold back (complex block matrix, tap order, skip-concat order, LSTM permutations).
+  * descriptors  -- sehip_gemm_desc instances (include/sehip.h) for every conv / deconv / linear product,
+                    its dgrad and its wgrad.
+Channel-last layout [B][T][F][C]; decoder tensors that feed a BatchNorm keep the extra first frame the reference
+drops after the BatchNorm (src/model/dccrn.py:193-196), i.e. they store T+1 frames and logical frame t lives at t+1.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream, SehipError
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------------------------------
+# ctypes mirrors of include/sehip.h
+# --------------------------------------------------------------------------------------------------
+class CSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("T", C.c_int32), ("tlo", C.c_int32), ("thi", C.c_int32), ("F", C.c_int32),
+                ("C", C.c_int32), ("pad_", C.c_int32)]
+
+
+class CDst(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("T", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("toff", C.c_int32),
+                ("fmul", C.c_int32), ("fadd", C.c_int32), ("is_f32", C.c_int32)]
+
+
+class CGemmDesc(C.Structure):
+    _fields_ = [("src", CSrc * 4), ("dst", CDst * 2), ("ktab", C.c_void_p), ("ntab", C.c_void_p), ("W", C.c_void_p),
+                ("bias", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32),
+                ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+def npad_of(n):
+    if n <= 16:
+        return 16
+    if n <= 32:
+        return 32
+    if n <= 64:
+        return 64
+    return (n + 127) // 128 * 128
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------------------
+# configuration / parameter layout
+# --------------------------------------------------------------------------------------------------
+class DCCRNConfig:
+    """Constructor arguments of the reference model (src/model/dccrn.py:12-27)."""
+
+    def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512, length=16384,
+                 win_type="hann", masking_mode="E", use_clstm=True, use_cbn=True, kernel_size=5,
+                 kernel_num=(16, 32, 64, 128, 256, 256), **_ignored):
+        if not use_clstm or not use_cbn:
+            raise SehipError("sehip DCCRN implements the reference defaults use_clstm=True, use_cbn=True only")
+        if win_type != "hann":
+            raise SehipError("sehip DCCRN: only win_type='hann' is built")
+        if kernel_size != 5:
+            raise SehipError("sehip DCCRN: only kernel_size=5 is built")
+        if rnn_layers != 2:
+            raise SehipError("sehip DCCRN: only rnn_layers=2 is built")
+        if rnn_units != 128:
+            raise SehipError("sehip DCCRN: only rnn_units=128 (LSTM hidden 64) is built")
+        if masking_mode not in ("E", "C", "R"):
+            raise SehipError(f"unknown masking_mode {masking_mode}")
+        self.rnn_layers, self.rnn_units = rnn_layers, rnn_units
+        self.win_len, self.win_inc, self.fft_len, self.length = win_len, win_inc, fft_len, length
+        self.masking_mode = masking_mode
+        self.kernel_size = kernel_size
+        self.kernel_num = [2] + list(kernel_num)
+        self.n_layers = len(self.kernel_num) - 1
+        if self.n_layers != 6:
+            raise SehipError("sehip DCCRN: six encoder/decoder layers are built (len(kernel_num) == 6)")
+        self.hidden_dim = fft_len // (2 ** len(self.kernel_num))
+        for c in self.kernel_num[1:]:
+            if c % 16 or (c & (c - 1)):
+                raise SehipError(f"sehip DCCRN: channel counts must be powers of two >= 16, got {kernel_num}")
+        self.hid = rnn_units // 2
+        self.lstm_in = self.hidden_dim * self.kernel_num[-1] // 2  # per real/imag part
+
+    def param_specs(self):
+        """[(name, shape, kind)] in the reference's state_dict order; kind in param|buffer|nbt."""
+        kn = self.kernel_num
+        out = []
+
+        def conv(pre, wshape, nb):
+            for part in ("real_conv", "imag_conv"):
+                out.append((f"{pre}0.{part}.weight", wshape, "param"))
+                out.append((f"{pre}0.{part}.bias", (nb,), "param"))
+
+        def bn(pre, n):
+            for k in ("Wrr", "Wri", "Wii", "Br", "Bi"):
+                out.append((f"{pre}1.{k}", (n,), "param"))
+            for k in ("RMr", "RMi", "RVrr", "RVri", "RVii"):
+                out.append((f"{pre}1.{k}", (n,), "buffer"))
+            out.append((f"{pre}1.num_batches_tracked", (), "nbt"))
+            out.append((f"{pre}2.weight", (1,), "param"))
+
+        for i in range(self.n_layers):
+            cin, cout = kn[i] // 2, kn[i + 1] // 2
+            conv(f"encoder.{i}.", (cout, cin, self.kernel_size, 2), cout)
+            bn(f"encoder.{i}.", cout)
+        for j, idx in enumerate(range(self.n_layers, 0, -1)):
+            cin, cout = kn[idx], kn[idx - 1] // 2
+            conv(f"decoder.{j}.", (cin, cout, self.kernel_size, 2), cout)
+            if idx != 1:
+                bn(f"decoder.{j}.", cout)
+        h = self.hid
+        for layer in range(self.rnn_layers):
+            nin = self.lstm_in if layer == 0 else h
+            for part in ("real_lstm", "imag_lstm"):
+                q = f"enhance.{layer}.{part}."
+                out.append((q + "weight_ih_l0", (4 * h, nin), "param"))
+                out.append((q + "weight_hh_l0", (4 * h, h), "param"))
+                out.append((q + "bias_ih_l0", (4 * h,), "param"))
+                out.append((q + "bias_hh_l0", (4 * h,), "param"))
+            if layer == self.rnn_layers - 1:
+                for part in ("r_trans", "i_trans"):
+                    out.append((f"enhance.{layer}.{part}.weight", (self.lstm_in, h), "param"))
+                    out.append((f"enhance.{layer}.{part}.bias", (self.lstm_in,), "param"))
+        return out
+
+
+class ParamLayout:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.specs = cfg.param_specs()
+        self.param_off, self.buffer_off, self.nbt_idx = {}, {}, {}
+        po = bo = 0
+        self.param_names, self.buffer_names, self.nbt_names = [], [], []
+        for name, shape, kind in self.specs:
+            n = int(np.prod(shape)) if len(shape) else 1
+            if kind == "param":
+                self.param_off[name] = (po, shape)
+                self.param_names.append(name)
+                po += round_up(n, 4)
+            elif kind == "buffer":
+                self.buffer_off[name] = (bo, shape)
+                self.buffer_names.append(name)
+                bo += round_up(n, 4)
+            else:
+                self.nbt_idx[name] = len(self.nbt_names)
+                self.nbt_names.append(name)
+        self.n_params = po
+        self.n_buffers = bo
+        # tensor boundaries for the reference's per-tensor grad_norm metric (src/solver.py:494-498)
+        offs = [self.param_off[n][0] for n in self.param_names] + [po]
+        self.tensor_offsets = np.asarray(offs, dtype=np.int64)
+
+    def index_array(self, name):
+        off, shape = self.param_off[name]
+        n = int(np.prod(shape))
+        return (off + np.arange(n, dtype=np.int64)).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------------------
+# table helpers
+# --------------------------------------------------------------------------------------------------
+def enc_entry(idx, neg):
+    """(index<<1)|neg, -1 where idx < 0."""
+    idx = np.asarray(idx, dtype=np.int64)
+    neg = np.broadcast_to(np.asarray(neg, dtype=np.int64), idx.shape)
+    e = (idx << 1) | neg
+    return np.where(idx < 0, -1, e).astype(np.int32)
+
+
+def complex_block(wr, wi, transposed):
+    """Index/sign arrays of the real block matrix of a complex conv.
+
+    conv   (transposed=False): w [Co_r, Ci_r, kf, kt] -> full [Co, Ci, kf, kt]:  [[Wr, -Wi], [Wi, Wr]]
+    deconv (transposed=True) : w [Ci_r, Co_r, kf, kt] -> full [Ci, Co, kf, kt]:  [[Wr, Wi], [-Wi, Wr]]
+    """
+    a, b = wr.shape[0], wr.shape[1]
+    idx = np.empty((2 * a, 2 * b) + wr.shape[2:], dtype=np.int64)
+    neg = np.zeros_like(idx)
+    idx[:a, :b], idx[a:, b:] = wr, wr
+    if not transposed:
+        idx[:a, b:], idx[a:, :b] = wi, wi
+        neg[:a, b:] = 1
+    else:
+        idx[:a, b:], idx[a:, :b] = wi, wi
+        neg[a:, :b] = 1
+    return idx, neg
+
+
+class Arena:
+    """Grows a list of numpy pieces that end up as one flat device buffer; returns element offsets."""
+
+    def __init__(self, align):
+        self.pieces, self.size, self.align = [], 0, align
+
+    def add(self, arr):
+        off = self.size
+        self.pieces.append((off, arr))
+        self.size += round_up(arr.shape[0], self.align)
+        return off
+
+    def reserve(self, n):
+        off = self.size
+        self.size += round_up(n, self.align)
+        return off
+
+    def build(self, dtype, width=None, fill=-1):
+        shape = (self.size,) if width is None else (self.size, width)
+        out = np.full(shape, fill, dtype=dtype)
+        for off, arr in self.pieces:
+            out[off:off + arr.shape[0]] = arr
+        return out
+
+
+class Gemm:
+    """One implicit-GEMM problem: descriptor + the pieces needed to (re)bind pointers."""
+
+    def __init__(self, name):
+        self.name = name
+        self.desc = CGemmDesc()
+        self.w_off = None      # offset in packed bf16 weights
+        self.b_off = None      # offset in packed fp32 bias
+        self.dw_off = None     # offset in packed-gradient buffer
+        self.db_off = None
+        self.ktab = None
+        self.ntab = None
+
+
+def dense_ntab(n, npad, dst=0, base=0):
+    t = np.zeros((npad // 4, 4), dtype=np.int32)
+    for q in range(npad // 4):
+        t[q] = (dst, base + 4 * q, max(0, min(4, n - 4 * q)), 0)
+    return t
+
+
+def wide_chunks(src, toff, fadd, c0, cn):
+    """chunks covering channels [c0, c0+cn) of one source row."""
+    assert cn % 8 == 0 and c0 % 8 == 0
+    return [(src, toff, fadd, c0 + 8 * q) for q in range(cn // 8)]
+
+
+def pad_ktab(rows):
+    k = len(rows) * 8
+    kp = round_up(k, 64)
+    rows = rows + [(-1, 0, 0, 0)] * ((kp - k) // 8)
+    return np.asarray(rows, dtype=np.int32).reshape(-1, 4), kp
+
+
+# --------------------------------------------------------------------------------------------------
+# static (batch-independent) part: tables + packed layouts
+# --------------------------------------------------------------------------------------------------
+class GemmSpec:
+    """Batch-independent description of one product (see sehip_gemm_desc)."""
+
+    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd"):
+        self.name = name
+        self.ktab, self.K = pad_ktab(rows)
+        self.N = n
+        self.Npad = npad_of(n)
+        k0 = widx.shape[1]
+        wi = np.full((self.Npad, self.K), -1, dtype=np.int64)
+        wn = np.zeros((self.Npad, self.K), dtype=np.int64)
+        wi[:n, :k0] = widx
+        wn[:n, :k0] = wneg
+        self.widx, self.wneg = wi, wn
+        self.bias_pairs = None
+        if bias_pairs is not None:
+            bp = np.full((self.Npad, 2), -1, dtype=np.int32)
+            bp[:n] = bias_pairs
+            self.bias_pairs = bp
+        self.tt, self.J, self.fmul = tt, j, fmul      # tt: "T" or "T+1"
+        self.srcs = srcs   # list of (buffer name, tlo_mode) ; geometry comes from the buffer
+        self.dsts = dsts   # list of (buffer name, toff, fmul, fadd)
+        self.ntab = ntab if ntab is not None else dense_ntab(n, self.Npad)
+        self.kind = kind
+        self.w_off = self.b_off = self.dw_off = self.db_off = None
+        self.kt_off = self.nt_off = None
+
+
+class DCCRNStatic:
+    def __init__(self, cfg: DCCRNConfig):
+        self.cfg = cfg
+        self.layout = L = ParamLayout(cfg)
+        kn = cfg.kernel_num
+        self.specs = {}
+        self.bn = []  # (prefix, Cr)
+        ia = L.index_array
+        self.F0 = cfg.fft_len // 2  # 256 bins after dropping DC
+
+        def eff_bias(pre, cr):
+            br, bi = ia(pre + "0.real_conv.bias"), ia(pre + "0.imag_conv.bias")
+            pairs = np.empty((2 * cr, 2), dtype=np.int32)
+            pairs[:cr, 0] = enc_entry(br, 0); pairs[:cr, 1] = enc_entry(bi, 1)
+            pairs[cr:, 0] = enc_entry(br, 0); pairs[cr:, 1] = enc_entry(bi, 0)
+            return pairs
+
+        # ---------------- encoder ----------------
+        for i in range(6):
+            ci, co = kn[i], kn[i + 1]
+            pre = f"encoder.{i}."
+            full, neg = complex_block(ia(pre + "0.real_conv.weight"), ia(pre + "0.imag_conv.weight"), False)  # [co,ci,5,2]
+            src = "enc_in" if i == 0 else f"z{i - 1}"
+            if ci >= 8:
+                rows = []
+                for kt in (0, 1):
+                    for kf in range(5):
+                        rows += wide_chunks(0, kt - 1, kf - 2, 0, ci)
+                widx = full.transpose(0, 3, 2, 1).reshape(co, -1)
+                wneg = neg.transpose(0, 3, 2, 1).reshape(co, -1)
+            else:
+                assert ci == 2
+                rows, widx, wneg = [], np.full((co, 32), -1, np.int64), np.zeros((co, 32), np.int64)
+                for kt in (0, 1):
+                    rows += [(0, kt - 1, -2, 4), (0, kt - 1, 2, 1)]
+                    for kf in range(5):
+                        for c in range(2):
+                            widx[:, kt * 16 + kf * 2 + c] = full[:, c, kf, kt]
+                            wneg[:, kt * 16 + kf * 2 + c] = neg[:, c, kf, kt]
+            self.specs[f"enc{i}.fwd"] = GemmSpec(f"enc{i}.fwd", rows, widx, wneg, co, eff_bias(pre, co // 2), "T",
+                                                  self.F0 >> (i + 1), 2, [(src, "all")], [(f"y{i}", 0, 1, 0)])
+            self.bn.append((pre, co // 2))
+            if i >= 1:
+                # dgrad by output-row parity: dX[b,t,2j+p,ci] = sum dY[b,t+1-kt,j+d,co] * full[co,ci,kf,kt], kf = p+2-2d
+                for p in (0, 1):
+                    ds = (-1, 0, 1) if p == 0 else (0, 1)
+                    rows = []
+                    for kt in (0, 1):
+                        for d in ds:
+                            rows += wide_chunks(0, 1 - kt, d, 0, co)
+                    w = np.empty((ci, 2, len(ds), co), dtype=np.int64)
+                    wn = np.empty_like(w)
+                    for kt in (0, 1):
+                        for q, d in enumerate(ds):
+                            kf = p + 2 - 2 * d
+                            w[:, kt, q, :] = full[:, :, kf, kt].T
+                            wn[:, kt, q, :] = neg[:, :, kf, kt].T
+                    self.specs[f"enc{i}.dg{p}"] = GemmSpec(f"enc{i}.dg{p}", rows, w.reshape(ci, -1), wn.reshape(ci, -1), ci,
+                                                           None, "T", self.F0 >> (i + 1), 1, [(f"dye{i}", "all")],
+                                                           [(f"dz{i - 1}", 0, 2, p)], kind="dgrad")
+
+        # ---------------- decoder ----------------
+        for j in range(6):
+            idx = 6 - j
+            c1 = c2 = kn[idx]
+            co = kn[idx - 1]
+            f_in = self.F0 >> idx
+            pre = f"decoder.{j}."
+            full, neg = complex_block(ia(pre + "0.real_conv.weight"), ia(pre + "0.imag_conv.weight"), True)  # [cin,co,5,2]
+            crt = (c1 + c2) // 2
+            # concatenated-channel index of (source s, channel c)   (complex_cat: [a_r, b_r, a_i, b_i])
+            cat1 = np.concatenate([np.arange(c1 // 2), crt + np.arange(c1 // 2)])
+            cat2 = np.concatenate([c1 // 2 + np.arange(c2 // 2), crt + c1 // 2 + np.arange(c2 // 2)])
+            s1 = "P" if j == 0 else f"zd{j - 1}"
+            s2 = f"z{5 - j}"
+            s1_mode = "all" if j == 0 else "drop1"  # logical frame t lives at stored t+1
+            last = j == 5
+            for p in (0, 1):
+                ds = (-1, 0, 1) if p == 0 else (0, 1)
+                rows = []
+                cols_i, cols_n = [], []
+                for kt in (0, 1):
+                    for d in ds:
+                        kf = p + 2 - 2 * d
+                        base_t = (1 if last else 0) - kt  # last layer produces only frames 1..T of the T+1
+                        rows += wide_chunks(0, base_t + (0 if j == 0 else 1), d, 0, c1)
+                        rows += wide_chunks(1, base_t, d, 0, c2)
+                        cols_i += [full[cat1, :, kf, kt].T, full[cat2, :, kf, kt].T]
+                        cols_n += [neg[cat1, :, kf, kt].T, neg[cat2, :, kf, kt].T]
+                widx, wneg = np.concatenate(cols_i, 1), np.concatenate(cols_n, 1)
+                if last:
+                    nt = np.zeros((4, 4), dtype=np.int32)
+                    nt[0] = (0, 0, 2, 0)
+                    dst = [("mask", 0, 2, p)]
+                    tt = "T"
+                else:
+                    nt = None
+                    dst = [(f"yd{j}", 0, 2, p)]
+                    tt = "T+1"
+                self.specs[f"dec{j}.fwd{p}"] = GemmSpec(f"dec{j}.fwd{p}", rows, widx, wneg, co, eff_bias(pre, co // 2), tt,
+                                                        f_in, 1, [(s1, s1_mode), (s2, "all")], dst, ntab=nt)
+            if not last:
+                self.bn.append((pre, co // 2))
+            # dgrad: dIn[b,t,fi,(s,c)] = sum dOut'[b,t+kt,2fi-2+kf,co] * full[cin,co,kf,kt]
+            gsrc = "dmask" if last else f"dyd{j}"
+            if co >= 8:
+                rows = []
+                for kt in (0, 1):
+                    for kf in range(5):
+                        rows += wide_chunks(0, kt, kf - 2, 0, co)
+                w = full.transpose(0, 3, 2, 1).reshape(c1 + c2, -1)   # [cin, (kt,kf,co)]
+                wn = neg.transpose(0, 3, 2, 1).reshape(c1 + c2, -1)
+            else:
+                assert co == 2
+                rows, w, wn = [], np.full((c1 + c2, 32), -1, np.int64), np.zeros((c1 + c2, 32), np.int64)
+                for kt in (0, 1):
+                    rows += [(0, kt - 1, -2, 4), (0, kt - 1, 2, 1)]  # dmask stores logical frame t' at t'-1
+                    for kf in range(5):
+                        for c in range(2):
+                            w[:, kt * 16 + kf * 2 + c] = full[:, c, kf, kt]
+                            wn[:, kt * 16 + kf * 2 + c] = neg[:, c, kf, kt]
+            order = np.concatenate([cat1, cat2])
+            d1 = ("dP", 0, 1, 0) if j == 0 else (f"dzd{j - 1}", 1, 1, 0)
+            nt = np.concatenate([dense_ntab(c1, c1, 0, 0), dense_ntab(c2, c2, 1, 0)])
+            assert npad_of(c1 + c2) == c1 + c2
+            self.specs[f"dec{j}.dg"] = GemmSpec(f"dec{j}.dg", rows, w[order], wn[order], c1 + c2, None, "T", f_in, 2,
+                                                [(gsrc, "all")], [d1, (f"dskip{5 - j}", 0, 1, 0)], ntab=nt, kind="dgrad")
+
+        # ---------------- complex LSTM ----------------
+        c5 = kn[6]
+        cp = c5 // 2
+        h = cfg.hid
+        lstm = ("real_lstm", "imag_lstm")
+
+        def ih(layer, l):
+            return ia(f"enhance.{layer}.{lstm[l]}.weight_ih_l0")
+
+        def bias_pairs_lstm(layer):
+            bp = np.empty((2 * 4 * h, 2), dtype=np.int32)
+            for l in (0, 1):
+                bp[l * 4 * h:(l + 1) * 4 * h, 0] = enc_entry(ia(f"enhance.{layer}.{lstm[l]}.bias_ih_l0"), 0)
+                bp[l * 4 * h:(l + 1) * 4 * h, 1] = enc_entry(ia(f"enhance.{layer}.{lstm[l]}.bias_hh_l0"), 0)
+            return bp
+
+        zero = lambda a: np.zeros_like(a)
+        # layer 1 input products: x[(f,c)] with reference feature index c*4+f  (src/model/dccrn.py:170-176)
+        w1 = np.concatenate([ih(0, l).reshape(4 * h, cp, 4).transpose(0, 2, 1).reshape(4 * h, -1) for l in (0, 1)])  # [512,(f,c)]
+        for q, tag in enumerate("ri"):
+            rows = []
+            for f in range(4):
+                rows += wide_chunks(0, 0, f, q * cp, cp)
+            self.specs[f"ih1_{tag}"] = GemmSpec(f"ih1_{tag}", rows, w1, zero(w1), 8 * h, bias_pairs_lstm(0), "T", 1, 1,
+                                                [("z5", "all")], [(f"pre1_{tag}", 0, 1, 0)])
+            # dx1: d z5[b,t,f,q*cp+c] = dpre1_q @ W
+            nt = np.zeros((4 * cp // 4, 4), dtype=np.int32)
+            for n4 in range(4 * cp // 4):
+                f, c = divmod(4 * n4, cp)
+                nt[n4] = (0, f * c5 + q * cp + c, 4, 0)
+            self.specs[f"dx1_{tag}"] = GemmSpec(f"dx1_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w1.T.copy(), zero(w1.T), 4 * cp,
+                                                None, "T", 1, 1, [(f"dpre1_{tag}", "all")], [("dz5l", 0, 1, 0)], ntab=nt,
+                                                kind="dgrad")
+        # layer 2 input products and the projection: x2_r = h1[r,real] - h1[i,imag]; x2_i = h1[i,real] + h1[r,imag]
+        combos = {"r": (0, 3, 1), "i": (2, 1, 0)}  # (first combo, second combo, negate second)
+        w2 = np.concatenate([ih(1, l) for l in (0, 1)])  # [512, 64]
+        for tag, (ca, cb, ng) in combos.items():
+            rows = wide_chunks(0, 0, 0, 0, h) + wide_chunks(1, 0, 0, 0, h)
+            wi = np.concatenate([w2, w2], 1)
+            wn = np.concatenate([zero(w2), zero(w2) + ng], 1)
+            self.specs[f"ih2_{tag}"] = GemmSpec(f"ih2_{tag}", rows, wi, wn, 8 * h, bias_pairs_lstm(1), "T", 1, 1,
+                                                [(f"h1_{ca}", "all"), (f"h1_{cb}", "all")], [(f"pre2_{tag}", 0, 1, 0)])
+            self.specs[f"dx2_{tag}"] = GemmSpec(f"dx2_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w2.T.copy(), zero(w2.T), h, None,
+                                                "T", 1, 1, [(f"dpre2_{tag}", "all")], [(f"dx2_{tag}", 0, 1, 0)], kind="dgrad")
+            q = 0 if tag == "r" else 1
+            tr = ia(f"enhance.1.{tag}_trans.weight")        # [cp*4, h], row c*4+d
+            trb = ia(f"enhance.1.{tag}_trans.bias")
+            wt = tr.reshape(cp, 4, h).transpose(1, 0, 2).reshape(4 * cp, h)   # row n' = d*cp + c
+            bt = trb.reshape(cp, 4).T.reshape(-1)
+            bp = np.full((4 * cp, 2), -1, dtype=np.int32)
+            bp[:, 0] = enc_entry(bt, 0)
+            nt = np.zeros((4 * cp // 4, 4), dtype=np.int32)
+            for n4 in range(4 * cp // 4):
+                d, c = divmod(4 * n4, cp)
+                nt[n4] = (0, d * c5 + q * cp + c, 4, 0)
+            self.specs[f"proj_{tag}"] = GemmSpec(f"proj_{tag}", rows, np.concatenate([wt, wt], 1),
+                                                 np.concatenate([zero(wt), zero(wt) + ng], 1), 4 * cp, bp, "T", 1, 1,
+                                                 [(f"h2_{ca}", "all"), (f"h2_{cb}", "all")], [("P", 0, 1, 0)], ntab=nt)
+            rows = []
+            for d in range(4):
+                rows += wide_chunks(0, 0, d, q * cp, cp)
+            self.specs[f"dproj_{tag}"] = GemmSpec(f"dproj_{tag}", rows, wt.T.copy(), zero(wt.T), h, None, "T", 1, 1,
+                                                  [("dP", "all")], [(f"dxo_{tag}", 0, 1, 0)], kind="dgrad")
+        # recurrent weight gradients: dW_hh[n,k] = sum dpre[b,t,n] h[b,t-1,k]
+        for layer in (1, 2):
+            for combo in range(4):
+                part, l = combo >> 1, combo & 1
+                hh = ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0")
+                nt = dense_ntab(4 * h, 4 * h, 0, l * 4 * h)
+                self.specs[f"hh{layer}_{combo}"] = GemmSpec(f"hh{layer}_{combo}", wide_chunks(0, -1, 0, 0, h), hh, zero(hh),
+                                                            4 * h, None, "T", 1, 1, [(f"h{layer}_{combo}", "all")],
+                                                            [(f"dpre{layer}_{'ri'[part]}", 0, 1, 0)], ntab=nt, kind="wgrad_only")
+
+        # ---------------- arenas: packed weights / biases / gradient regions / tables ----------------
+        wa, ba, ga = Arena(64), Arena(16), Arena(16)
+        kta, nta = Arena(1), Arena(1)
+        self.wgrad_of = {}
+        for name, s in self.specs.items():
+            s.kt_off = kta.add(s.ktab)
+            s.nt_off = nta.add(s.ntab)
+            if s.kind != "wgrad_only":
+                s.w_off = wa.add(enc_entry(s.widx, s.wneg).reshape(-1))
+            if s.bias_pairs is not None:
+                s.b_off = ba.add(s.bias_pairs)
+            if s.kind in ("fwd", "wgrad_only"):
+                s.dw_off = ga.reserve(s.Npad * s.K)
+                if s.bias_pairs is not None:
+                    s.db_off = ga.reserve(s.Npad)
+        # recurrent weights for the LSTM kernels: whh [layer][lstm][256][64], whhT [layer][lstm][64][256]
+        self.whh_off, self.whhT_off = {}, {}
+        for layer in (1, 2):
+            hh = np.stack([ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0") for l in (0, 1)])
+            self.whh_off[layer] = wa.add(enc_entry(hh, 0).reshape(-1))
+            self.whhT_off[layer] = wa.add(enc_entry(hh.transpose(0, 2, 1), 0).reshape(-1))
+        # BatchNorm / PReLU gradients land in the packed-gradient buffer too
+        self.bn_g_off = {}
+        for pre, cr in self.bn:
+            self.bn_g_off[pre] = {k: ga.reserve(cr) for k in ("Wrr", "Wri", "Wii", "Br", "Bi")}
+            self.bn_g_off[pre]["slope"] = ga.reserve(1)
+        self.n_wpack, self.n_bpack, self.n_gpack = wa.size, ba.size, ga.size
+        self.wtab = wa.build(np.int32)
+        self.btab = ba.build(np.int32, 2)
+        self.ktab = kta.build(np.int32, 4)
+        self.ntab = nta.build(np.int32, 4, fill=0)
+        self.utab = self._build_unpack_table()
+
+    def _build_unpack_table(self):
+        L = self.layout
+        ps, gs, ns = [], [], []
+        for s in self.specs.values():
+            if s.dw_off is None:
+                continue
+            m = s.widx >= 0
+            ps.append(s.widx[m]); ns.append(s.wneg[m])
+            gs.append(s.dw_off + np.flatnonzero(m.reshape(-1)))
+            if s.db_off is not None:
+                for col in (0, 1):
+                    e = s.bias_pairs[:, col].astype(np.int64)
+                    mm = e >= 0
+                    ps.append(e[mm] >> 1); ns.append(e[mm] & 1)
+                    gs.append(s.db_off + np.flatnonzero(mm))
+        for pre, cr in self.bn:
+            for k in ("Wrr", "Wri", "Wii", "Br", "Bi"):
+                ps.append(L.index_array(pre + "1." + k)); ns.append(np.zeros(cr, np.int64))
+                gs.append(self.bn_g_off[pre][k] + np.arange(cr))
+            ps.append(L.index_array(pre + "2.weight")); ns.append(np.zeros(1, np.int64))
+            gs.append(np.asarray([self.bn_g_off[pre]["slope"]]))
+        p = np.concatenate([a.reshape(-1) for a in ps]).astype(np.int64)
+        g = np.concatenate([a.reshape(-1) for a in gs]).astype(np.int64)
+        n = np.concatenate([a.reshape(-1) for a in ns]).astype(np.int64)
+        order = np.argsort(p, kind="stable")
+        p, g, n = p[order], g[order], n[order]
+        first = np.searchsorted(p, p, side="left")
+        slot = np.arange(p.shape[0]) - first
+        assert slot.max() < 4, "a parameter feeds more than 4 packed-gradient entries"
+        tab = np.full((L.n_params, 4), -1, dtype=np.int32)
+        tab[p, slot] = ((g << 1) | n).astype(np.int32)
+        return tab
+
+
+# --------------------------------------------------------------------------------------------------
+# dynamic part: buffers for one (batch, length), bound descriptors, launch sequences
+# --------------------------------------------------------------------------------------------------
+class Buf:
+    def __init__(self, t, tst, f, c, t0):
+        self.t, self.Tst, self.F, self.C, self.t0 = t, tst, f, c, t0
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+class DeviceTables:
+    """Device copies of the static tables (shared by every workspace of a model on one device)."""
+
+    def __init__(self, st: DCCRNStatic, device):
+        f = lambda a: torch.from_numpy(a).to(device)
+        self.wtab, self.btab, self.utab = f(st.wtab), f(st.btab), f(st.utab)
+        self.ktab, self.ntab = f(st.ktab), f(st.ntab)
+        self.tensor_offsets = f(st.layout.tensor_offsets)
+        cfg = st.cfg
+        self.window = f(ops.hann_periodic(cfg.win_len))
+        self.wpack = torch.zeros(st.n_wpack, dtype=BF16, device=device)
+        self.bpack = torch.zeros(max(st.n_bpack, 4), dtype=torch.float32, device=device)
+
+
+class DCCRNWorkspace:
+    def __init__(self, st: DCCRNStatic, tables: DeviceTables, B, N, device):
+        cfg = st.cfg
+        self.st, self.tb, self.B, self.N, self.device = st, tables, B, N, device
+        self.T = T = ops.stft_frames(N, cfg.win_len, cfg.win_inc)
+        if T < 1:
+            raise SehipError(f"input of {N} samples is shorter than one frame")
+        max_len = (T - 1) * cfg.win_inc + cfg.win_len - (cfg.win_len - cfg.win_inc)
+        self.length = min(cfg.length, max_len)  # the reference's [..., :length] slice simply truncates
+        kn = cfg.kernel_num
+        F0 = st.F0
+        self.bufs = {}
+
+        def add(name, tst, f, c, t0=0, dtype=BF16, lead=None):
+            shape = (B, tst, f, c) if lead is None else (lead, B, tst, f, c)
+            t = torch.zeros(shape, dtype=dtype, device=device)
+            if lead is None:
+                self.bufs[name] = Buf(t, tst, f, c, t0)
+            else:
+                for q in range(lead):
+                    self.bufs[f"{name}_{q}"] = Buf(t[q], tst, f, c, t0)
+                self.bufs[name] = Buf(t, tst, f, c, t0)
+            return t
+
+        add("enc_in", T, F0, 2)
+        for i in range(6):
+            f, c = F0 >> (i + 1), kn[i + 1]
+            add(f"y{i}", T, f, c); add(f"z{i}", T, f, c)
+            add(f"dye{i}", T, f, c); add(f"dskip{i}", T, f, c)
+            if i < 5:
+                add(f"dz{i}", T, f, c)
+        c5, h = kn[6], cfg.hid
+        add("dz5l", T, 4, c5); add("P", T, 4, c5); add("dP", T, 4, c5)
+        for layer in (1, 2):
+            for tag in "ri":
+                add(f"pre{layer}_{tag}", T, 1, 8 * h, dtype=torch.float32)
+                add(f"dpre{layer}_{tag}", T, 1, 8 * h)
+            add(f"h{layer}", T, 1, h, lead=4)
+            add(f"gates{layer}", T, 1, 4 * h, lead=4)
+            add(f"c{layer}", T, 1, h, dtype=torch.float32, lead=4)
+        for tag in "ri":
+            add(f"dx2_{tag}", T, 1, h); add(f"dxo_{tag}", T, 1, h)
+        for j in range(5):
+            idx = 6 - j
+            f, c = (F0 >> idx) * 2, kn[idx - 1]
+            add(f"yd{j}", T + 1, f, c, 1); add(f"zd{j}", T + 1, f, c, 1)
+            add(f"dyd{j}", T + 1, f, c, 1); add(f"dzd{j}", T + 1, f, c, 1)
+        add("mask", T, F0, 2, dtype=torch.float32)
+        add("dmask", T, F0, 2)
+        self.spec = torch.empty(B, T, 257, 2, dtype=torch.float32, device=device)
+        self.frames = torch.empty(B, T, cfg.win_len, dtype=torch.float32, device=device)
+        self.wav = torch.empty(B, self.length, dtype=torch.float32, device=device)
+        self.inv_coff = torch.from_numpy(ops.inv_window_energy(cfg.win_len, cfg.win_inc, T, self.length)).to(device)
+        self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
+        maxcr = max(cr for _, cr in st.bn)
+        self.bn_acc = torch.zeros(7 * maxcr + 8, dtype=torch.float64, device=device)
+        self.bn_coef = {pre: torch.zeros(cr, 16, dtype=torch.float32, device=device) for pre, cr in st.bn}
+        self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
+        self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
+        self._bind()
+
+    # ---- descriptors ---------------------------------------------------------------------------
+    def _bind(self):
+        st, tb, B, T = self.st, self.tb, self.B, self.T
+        self.desc = {}
+        for name, s in st.specs.items():
+            d = CGemmDesc()
+            tt = T if s.tt == "T" else T + 1
+            for q, (bname, mode) in enumerate(s.srcs):
+                b = self.bufs[bname]
+                d.src[q].ptr = b.ptr
+                d.src[q].T, d.src[q].F, d.src[q].C = b.Tst, b.F, b.C
+                if mode == "drop1":
+                    d.src[q].tlo, d.src[q].thi = 1, T + 1
+                else:
+                    d.src[q].tlo, d.src[q].thi = 0, b.Tst
+            for q, (bname, toff, fmul, fadd) in enumerate(s.dsts):
+                b = self.bufs[bname]
+                d.dst[q].ptr = b.ptr
+                d.dst[q].T, d.dst[q].F, d.dst[q].C = b.Tst, b.F, b.C
+                d.dst[q].toff, d.dst[q].fmul, d.dst[q].fadd = toff, fmul, fadd
+                d.dst[q].is_f32 = 1 if b.t.dtype == torch.float32 else 0
+                if s.J == 1:  # dense rows: view the destination as one row per (b,t)
+                    d.dst[q].F, d.dst[q].C = 1, b.F * b.C
+            d.ktab = tb.ktab.data_ptr() + 16 * s.kt_off
+            d.ntab = tb.ntab.data_ptr() + 16 * s.nt_off
+            if s.w_off is not None:
+                d.W = tb.wpack.data_ptr() + 2 * s.w_off
+            if s.b_off is not None:
+                d.bias = tb.bpack.data_ptr() + 4 * s.b_off
+            d.M, d.N, d.Npad, d.K = B * tt * s.J, s.N, s.Npad, s.K
+            d.TT, d.J, d.fmul = tt, s.J, s.fmul
+            self.desc[name] = d
+            if s.dw_off is not None:  # weight-gradient twin: dOut replaces the destination
+                w = CGemmDesc.from_buffer_copy(d)
+                w.dW = self.gpack.data_ptr() + 4 * s.dw_off
+                w.dbias = self.gpack.data_ptr() + 4 * s.db_off if s.db_off is not None else None
+                if s.kind == "fwd":
+                    gname = self._grad_buffer_of(s.dsts[0][0])
+                    gb = self.bufs[gname]
+                    w.dst[0].ptr = gb.ptr
+                    w.dst[0].is_f32 = 0
+                self.desc[name + ".wg"] = w
+
+    @staticmethod
+    def _grad_buffer_of(out_name):
+        if out_name.startswith("yd"):
+            return "dyd" + out_name[2:]
+        if out_name.startswith("y"):
+            return "dye" + out_name[1:]
+        if out_name == "mask":
+            return "dmask"
+        if out_name.startswith("pre"):
+            return "d" + out_name
+        if out_name == "P":
+            return "dP"
+        raise KeyError(out_name)
+
+    def gemm(self, name):
+        call("sehip_gemm", C.byref(self.desc[name]), stream())
+
+    def wgrad(self, name):
+        call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), stream())
+
+    # ---- BatchNorm helpers ---------------------------------------------------------------------
+    def _bn_ptrs(self, pre, params, buffers, nbt):
+        L = self.st.layout
+        pp = lambda k: params.data_ptr() + 4 * L.param_off[pre + k][0]
+        bp = lambda k: buffers.data_ptr() + 4 * L.buffer_off[pre + k][0]
+        return pp, bp, nbt.data_ptr() + 8 * L.nbt_idx[pre + "1.num_batches_tracked"]
+
+    def bn_forward(self, pre, cr, y, z, params, buffers, nbt, training):
+        rows = y.t.numel() // (2 * cr)
+        pp, bp, nb = self._bn_ptrs(pre, params, buffers, nbt)
+        coef = self.bn_coef[pre]
+        if training:
+            call("sehip_cbn_stats", y.ptr, rows, cr, ptr(self.bn_acc), stream())
+        call("sehip_cbn_finalize", ptr(self.bn_acc), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
+             bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
+             1 if training else 0, ptr(coef), stream())
+        call("sehip_cbn_apply", y.ptr, ptr(coef), pp("2.weight"), rows, cr, z.ptr, stream())
+
+    def bn_backward(self, pre, cr, dz, dz2, y, dy, params, tfirst):
+        rows = y.t.numel() // (2 * cr)
+        L, st = self.st.layout, self.st
+        pp = lambda k: params.data_ptr() + 4 * L.param_off[pre + k][0]
+        g = lambda k: self.gpack.data_ptr() + 4 * st.bn_g_off[pre][k]
+        coef = self.bn_coef[pre]
+        dz2p = dz2.ptr if dz2 is not None else None
+        call("sehip_cbn_bwd_reduce", dz.ptr, dz2p, y.ptr, ptr(coef), pp("2.weight"), rows, cr, y.F, y.Tst, tfirst,
+             ptr(self.bn_acc), stream())
+        call("sehip_cbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
+             g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
+        call("sehip_cbn_bwd_apply", dz.ptr, dz2p, y.ptr, ptr(coef), ptr(self.bn_bcoef), pp("2.weight"), rows, cr, y.F,
+             y.Tst, tfirst, dy.ptr, stream())
+
+    # ---- forward / backward --------------------------------------------------------------------
+    def pack_weights(self, params):
+        st, tb = self.st, self.tb
+        call("sehip_pack_bf16", ptr(params), ptr(tb.wtab), st.n_wpack, ptr(tb.wpack), stream())
+        call("sehip_pack_f32", ptr(params), ptr(tb.btab), st.n_bpack, ptr(tb.bpack), stream())
+
+    def forward(self, wav_in, params, buffers, nbt, training=True):
+        """wav_in [B,N] fp32 on device -> self.wav [B,length]."""
+        st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
+        B, T, h = self.B, self.T, cfg.hid
+        self.pack_weights(params)
+        call("sehip_stft_fwd", ptr(wav_in), ptr(tb.window), B, self.N, cfg.win_len, cfg.win_inc, cfg.fft_len,
+             ptr(self.spec), b["enc_in"].ptr, stream())
+        for i in range(6):
+            self.gemm(f"enc{i}.fwd")
+            self.bn_forward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, b[f"y{i}"], b[f"z{i}"], params, buffers, nbt, training)
+        for layer in (1, 2):
+            for tag in "ri":
+                self.gemm(f"ih{layer}_{tag}")
+            whh = tb.wpack.data_ptr() + 2 * st.whh_off[layer]
+            call("sehip_lstm_fwd", b[f"pre{layer}_r"].ptr, b[f"pre{layer}_i"].ptr, whh, B, T, h, b[f"h{layer}"].ptr,
+                 b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, stream())
+        for tag in "ri":
+            self.gemm(f"proj_{tag}")
+        for j in range(6):
+            self.gemm(f"dec{j}.fwd0")
+            self.gemm(f"dec{j}.fwd1")
+            if j < 5:
+                self.bn_forward(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"yd{j}"], b[f"zd{j}"], params, buffers, nbt,
+                                training)
+        call("sehip_istft_fwd", ptr(self.spec), b["mask"].ptr, ptr(tb.window), ptr(self.inv_coff), B, T, cfg.win_len,
+             cfg.win_inc, cfg.fft_len, self.length, self.mode, ptr(self.frames), ptr(self.wav), stream())
+        return self.wav
+
+    def backward(self, dwav, params, grads):
+        """dwav [B,length] fp32 -> flat parameter gradients (overwritten)."""
+        st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
+        B, T, h = self.B, self.T, cfg.hid
+        self.gpack.zero_()
+        call("sehip_istft_bwd", ptr(dwav), ptr(self.wav), ptr(self.spec), b["mask"].ptr, ptr(tb.window), ptr(self.inv_coff),
+             B, T, cfg.win_len, cfg.win_inc, cfg.fft_len, self.length, self.mode, b["dmask"].ptr, stream())
+        for j in range(5, -1, -1):
+            if j < 5:
+                self.bn_backward(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"dzd{j}"], None, b[f"yd{j}"], b[f"dyd{j}"],
+                                 params, 1)
+            self.wgrad(f"dec{j}.fwd0")
+            self.wgrad(f"dec{j}.fwd1")
+            self.gemm(f"dec{j}.dg")
+        for tag in "ri":
+            self.wgrad(f"proj_{tag}")
+            self.gemm(f"dproj_{tag}")
+        for layer in (2, 1):
+            dha, dhb = (b["dxo_r"], b["dxo_i"]) if layer == 2 else (b["dx2_r"], b["dx2_i"])
+            whhT = tb.wpack.data_ptr() + 2 * st.whhT_off[layer]
+            call("sehip_lstm_bwd", dha.ptr, dhb.ptr, whhT, b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, B, T, h,
+                 b[f"dpre{layer}_r"].ptr, b[f"dpre{layer}_i"].ptr, stream())
+            for tag in "ri":
+                self.wgrad(f"ih{layer}_{tag}")
+                self.gemm(f"dx{layer}_{tag}")
+            for combo in range(4):
+                self.wgrad(f"hh{layer}_{combo}")
+        for i in range(5, -1, -1):
+            dz = b["dz5l"] if i == 5 else b[f"dz{i}"]
+            self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, b[f"dskip{i}"], b[f"y{i}"], b[f"dye{i}"], params, 0)
+            self.wgrad(f"enc{i}.fwd")
+            if i > 0:
+                self.gemm(f"enc{i}.dg0")
+                self.gemm(f"enc{i}.dg1")
+        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
+        return grads

@@ -1,0 +1,147 @@
+"""GPU parity of the whole DCCRN forward/backward (libsehip kernels driven by sehip.plan) against the CPU oracle,
+stage by stage.  bf16 MFMA operands / bf16 activation storage with fp32 accumulation: tolerances are bf16-level."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccrn_oracle as O
+from util import rel_err, max_abs
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(kernel_num=[16, 32, 32, 64, 64, 128], rnn_units=128, length=4000)
+
+
+def cl(x, t0=0):
+    """oracle [B,C,F,T] -> channels-last [B,T,F,C]"""
+    return x.permute(0, 3, 2, 1)
+
+
+def flat_params(layout, p):
+    flat = torch.zeros(layout.n_params)
+    for name in layout.param_names:
+        off, shape = layout.param_off[name]
+        flat[off:off + p[name].numel()] = p[name].reshape(-1)
+    return flat
+
+
+def flat_buffers(layout, p):
+    flat = torch.zeros(layout.n_buffers)
+    for name in layout.buffer_names:
+        off, shape = layout.buffer_off[name]
+        flat[off:off + p[name].numel()] = p[name].reshape(-1)
+    return flat
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from sehip import plan
+    dev = torch.device("cuda:0")
+    cfg_o = O.DCCRNConfig(**SMALL)
+    p = O.init_params(cfg_o, seed=3)
+    g = torch.Generator().manual_seed(11)
+    for k in p:  # non-trivial biases / BN affine / PReLU so every term is exercised
+        if k.endswith(".bias") or k.endswith((".Br", ".Bi")):
+            p[k] = 0.1 * torch.randn(p[k].shape, generator=g)
+        if k.endswith((".Wrr", ".Wii")):
+            p[k] = 1.0 + 0.2 * torch.randn(p[k].shape, generator=g)
+        if k.endswith("2.weight"):
+            p[k] = 0.25 + 0.1 * torch.randn(p[k].shape, generator=g)
+    B, N = 3, 4000
+    clean = 0.1 * torch.randn(B, 1, N, generator=g)
+    noisy = clean + 0.05 * torch.randn(B, 1, N, generator=g)
+    cfg = plan.DCCRNConfig(**SMALL)
+    st = plan.DCCRNStatic(cfg)
+    tb = plan.DeviceTables(st, dev)
+    ws = plan.DCCRNWorkspace(st, tb, B, N, dev)
+    params = flat_params(st.layout, p).to(dev)
+    buffers = flat_buffers(st.layout, p).to(dev)
+    nbt = torch.zeros(len(st.layout.nbt_names), dtype=torch.int64, device=dev)
+    return dict(cfg_o=cfg_o, p=p, noisy=noisy, clean=clean, st=st, ws=ws, params=params, buffers=buffers, nbt=nbt, dev=dev)
+
+
+def test_forward_stages(setup):
+    s = setup
+    ws, cfg_o = s["ws"], s["cfg_o"]
+    cap, stats = {}, {}
+    est = O.dccrn_forward(s["p"], s["noisy"], cfg_o, training=True, capture=cap, stats_out=stats, sim=O.Bf16Sim)
+    est32 = O.dccrn_forward(s["p"], s["noisy"], cfg_o, training=True)
+    print("bf16-sim oracle vs fp32 oracle, waveform rel err:", rel_err(est, est32))
+    out = ws.forward(s["noisy"][:, 0].contiguous().to(s["dev"]), s["params"], s["buffers"], s["nbt"], training=True)
+    torch.cuda.synchronize()
+    b = ws.bufs
+    errs = {}
+    for i in range(6):
+        errs[f"enc{i}.conv"] = rel_err(b[f"y{i}"].t.float().cpu(), cl(cap[f"enc{i}.conv"]))
+        errs[f"enc{i}"] = rel_err(b[f"z{i}"].t.float().cpu(), cl(cap[f"enc{i}"]))
+    T = ws.T
+    for layer in (0, 1):
+        # oracle capture after layer: r/i [T,B,*]; layer 0 gives the combined hidden outputs
+        h = b[f"h{layer + 1}"].t.float().cpu()[:, :, :, 0]  # [4,B,T,64]
+        if layer == 0:
+            errs["lstm0.r"] = rel_err((h[0] - h[3]).permute(1, 0, 2), cap["lstm0.r"])
+            errs["lstm0.i"] = rel_err((h[2] + h[1]).permute(1, 0, 2), cap["lstm0.i"])
+    P = b["P"].t.float().cpu()  # [B,T,4,C5]
+    c5 = P.shape[-1]
+    ref_r = cap["lstm1.r"].reshape(T, -1, c5 // 2, 4).permute(1, 0, 3, 2)
+    ref_i = cap["lstm1.i"].reshape(T, -1, c5 // 2, 4).permute(1, 0, 3, 2)
+    errs["lstm1"] = rel_err(P, torch.cat([ref_r, ref_i], -1))
+    for j in range(5):
+        errs[f"dec{j}"] = rel_err(b[f"zd{j}"].t.float().cpu()[:, 1:], cl(cap[f"dec{j}"]))
+    errs["mask"] = rel_err(b["mask"].t.cpu(), cl(cap["dec5"]))
+    errs["wav"] = rel_err(out.cpu(), est[:, 0])
+    print("\n".join(f"{k:12s} {v:.3e}" for k, v in errs.items()))
+    # against the bf16-storage simulation of the oracle the only differences are accumulation order and rare
+    # one-ulp flips at bf16 rounding boundaries
+    bad = {k: v for k, v in errs.items() if not v < 1e-2}
+    assert not bad, bad
+    assert rel_err(out.cpu(), est32[:, 0]) < 3e-2   # vs the fp32 reference path: bf16 storage noise
+    # running statistics (updated in place)
+    L = s["st"].layout
+    bufs = s["buffers"].cpu()
+    for name in L.buffer_names:
+        off, shape = L.buffer_off[name]
+        got = bufs[off:off + stats[name].numel()].reshape(stats[name].shape)
+        assert rel_err(got, stats[name]) < 2e-2, name
+    assert int(s["nbt"].min()) == 1 and int(s["nbt"].max()) == 1
+
+
+def test_backward_param_grads(setup):
+    s = setup
+    ws, cfg_o, p = s["ws"], s["cfg_o"], s["p"]
+    names = [k for k in p if O.is_trainable(k)]
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    est = O.dccrn_forward(work, s["noisy"], cfg_o, training=True, sim=O.Bf16Sim)
+    loss = O.loss_sisdr(est, s["clean"])
+    grads_ref = torch.autograd.grad(loss, [leaves[k] for k in names])
+    dev = s["dev"]
+    from sehip import ops
+    buffers = s["buffers"].clone(); nbt = s["nbt"].clone()
+    out = ws.forward(s["noisy"][:, 0].contiguous().to(dev), s["params"], buffers, nbt, training=True)
+    lossd, rowstat = ops.sisnr_fwd(out, s["clean"][:, 0].contiguous().to(dev))
+    assert abs(float(lossd) - float(loss)) < 0.05, (float(lossd), float(loss))
+    dwav = ops.sisnr_bwd(out, s["clean"][:, 0].contiguous().to(dev), rowstat)
+    grads = torch.zeros_like(s["params"])
+    ws.backward(dwav, s["params"], grads)
+    torch.cuda.synchronize()
+    g = grads.cpu()
+    L = s["st"].layout
+    errs = {}
+    for k, gr in zip(names, grads_ref):
+        off, shape = L.param_off[k]
+        got = g[off:off + gr.numel()].reshape(gr.shape)
+        errs[k] = (float((got - gr).norm()), float(gr.norm()))
+    for k, (e, n) in errs.items():
+        print(f"{k:45s} err {e:.3e} norm {n:.3e} rel {e / (n + 1e-30):.3e}")
+    bad = {}
+    for k, (e, n) in errs.items():
+        noise_bias = k.endswith("conv.bias") and not k.startswith("decoder.5.")  # zero true gradient (BatchNorm follows)
+        # Whole-chain comparison of two bf16 pipelines: one-ulp rounding flips in the forward activations are
+        # amplified chaotically through 11 BatchNorms (the bf16-simulated oracle itself sits 2-15 % from the fp32
+        # oracle on these gradients), so this is a coarse bound; tests/test_gpu_ops_local.py pins every op tightly
+        # on shared inputs.
+        tol = 0.2 * n + (3e-3 if noise_bias else 1e-5)
+        if not e < tol:
+            bad[k] = (e, n)
+    assert not bad, bad
