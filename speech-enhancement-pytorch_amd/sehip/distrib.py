@@ -1,0 +1,77 @@
+"""Factories with the reference's names and argument meaning (src/distrib.py:226-275):
+get_model / get_optimizer / get_loss_function, plus the data-parallel helpers the reference lacks
+(it wraps the model in single-process nn.DataParallel, src/solver.py:144-145): one process per GPU,
+gradient all-reduce of the flat buffer over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" on CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from ._lib import SehipError
+from .loss import loss_sisdr
+from .model.dccrn import DCCRN
+from .optim import FlatOptimizer
+from .utils import obj2dict
+
+MODEL_REGISTRY = {"dccrn": DCCRN}
+_REFERENCE_NAMES = ("dnn", "mel-rnn", "unet", "dccrn", "dcunet", "demucs", "wav-unet", "conv-tasnet", "crn", "rnn-stft-mask")
+
+
+def get_model(config):
+    if config.name not in MODEL_REGISTRY:
+        if config.name in _REFERENCE_NAMES:
+            raise SehipError(f"model '{config.name}' is in the reference registry but has no HIP path yet (built: "
+                             f"{sorted(MODEL_REGISTRY)})")
+        raise KeyError(config.name)
+    return MODEL_REGISTRY[config.name](**obj2dict(config))
+
+
+def get_optimizer(config, model):
+    if config.optim == "sgd":
+        return FlatOptimizer(model, lr=config.lr, kind="sgd", momentum=config.momentum)
+    if config.optim == "adam":
+        return FlatOptimizer(model, lr=config.lr, kind="adam", betas=(config.beta1, config.beta2))
+    raise ValueError(f"Optimizer {config.optim} cannot use...")
+
+
+def get_loss_function(config):
+    if config.loss == "si-sdr":
+        return loss_sisdr
+    if config.loss in ("l1", "mse", "psa"):
+        raise SehipError(f"loss '{config.loss}' has no HIP path yet (built: si-sdr)")
+    raise ValueError(f"Loss function {config.loss} cannot use...")
+
+
+# ---- data parallel over utterances -----------------------------------------------------------------
+def init_distributed(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, 0
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_parameters(flat_params, flat_buffers=None, src=0):
+    """Every replica starts from rank 0's weights (DataParallel replicates module 0 each step)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_params, src)
+        if flat_buffers is not None:
+            dist.broadcast(flat_buffers, src)
+
+
+def allreduce_gradients(flat_grads):
+    """ONE all-reduce(sum) of the flat fp32 gradient buffer, then x 1/world: the mean over the global batch
+    (equal shards), i.e. what DataParallel's gather + loss mean + backward reduce produces on GPU 0.
+    Clipping happens after this (src/solver.py:487-490 clips the reduced gradients)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        flat_grads.mul_(1.0 / dist.get_world_size())
+    return flat_grads

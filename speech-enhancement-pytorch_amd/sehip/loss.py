@@ -1,0 +1,35 @@
+"""Loss functions of the train step (reference: src/loss.py:14-29 si_snr / loss_sisdr; l1 / mse are
+torch.nn.functional in the reference, src/distrib.py:263-275)."""
+import torch
+
+from . import ops
+from ._lib import SehipError
+
+
+class _SiSdrLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, ref):
+        n = est.shape[-1]
+        e2 = est.reshape(-1, n).contiguous().float()
+        r2 = ref.reshape(-1, n).contiguous().float()
+        loss, rowstat = ops.sisnr_fwd(e2, r2)
+        ctx.save_for_backward(e2, r2, rowstat)
+        ctx.shape = est.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        e2, r2, rowstat = ctx.saved_tensors
+        d = ops.sisnr_bwd(e2, r2, rowstat, g.reshape(1).contiguous().float())
+        return d.view(ctx.shape), None
+
+
+def loss_sisdr(inputs, targets):
+    """-mean(si_snr(inputs, targets)) over all leading dims (src/loss.py:25-29)."""
+    if inputs.shape != targets.shape:
+        raise SehipError(f"loss_sisdr: shape mismatch {tuple(inputs.shape)} vs {tuple(targets.shape)}")
+    return _SiSdrLoss.apply(inputs, targets)
+
+
+def si_snr(s1, s2):
+    return -loss_sisdr(s1, s2)

@@ -1,0 +1,251 @@
+"""Drop-in DCCRN module on libsehip (reference: src/model/dccrn.py:10-246).
+
+Same constructor arguments, same `forward(x[B,1,N]) -> [B,1,length]`, same state_dict keys/shapes (204 entries incl.
+the persistent stft/istft buffers), so checkpoints of the reference load here and vice versa.  Differences by design:
+  * all parameters are views into ONE flat fp32 buffer (`flat_params`), gradients into one flat buffer
+    (`flat_grads`) -- one RCCL all-reduce, one fused clip+Adam launch;
+  * forward/backward run the hand-written HIP kernels through the C ABI; there is no PyTorch/CPU fallback:
+    calling forward on a CPU tensor raises SehipError.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import plan, ops
+from .._lib import SehipError
+
+_STATIC_CACHE = {}
+
+
+def _static_for(cfg):
+    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode)
+    if key not in _STATIC_CACHE:
+        _STATIC_CACHE[key] = plan.DCCRNStatic(cfg)
+    return _STATIC_CACHE[key]
+
+
+class _Node(nn.Module):
+    """Plain container; the tree of these reproduces the reference's module/parameter names."""
+
+    def __getitem__(self, idx):  # encoder[i][0] style access like the reference's nn.Sequential
+        return getattr(self, str(idx))
+
+
+class _DCCRNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, wav, anchor):
+        ctx.model = model
+        ctx.ws = model._run_forward(wav)
+        return ctx.ws.wav.view(wav.shape[0], 1, -1).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._run_backward(ctx.ws, grad_out)
+        return None, None, None
+
+
+class DCCRN(nn.Module):
+    def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512, length=16384, win_type="hann",
+                 masking_mode="E", use_clstm=True, use_cbn=True, kernel_size=5, kernel_num=[16, 32, 64, 128, 256, 256],
+                 *args, **kwargs):
+        super().__init__()
+        self.cfg = cfg = plan.DCCRNConfig(rnn_layers=rnn_layers, rnn_units=rnn_units, win_len=win_len, win_inc=win_inc,
+                                          fft_len=fft_len, length=length, win_type=win_type, masking_mode=masking_mode,
+                                          use_clstm=use_clstm, use_cbn=use_cbn, kernel_size=kernel_size,
+                                          kernel_num=list(kernel_num))
+        self.win_len, self.win_inc, self.fft_len, self.rnn_units = win_len, win_inc, fft_len, rnn_units
+        self.masking_mode, self.kernel_num = masking_mode, cfg.kernel_num
+        self.static = _static_for(cfg)
+        L = self.static.layout
+        self._flat = torch.zeros(L.n_params)
+        self._gflat = None
+        self._bflat = torch.zeros(max(L.n_buffers, 1))
+        self._nbt = torch.zeros(len(L.nbt_names), dtype=torch.int64)
+        self._tables = None
+        self._ws = {}
+        self._anchor = None
+        self._grads_live = False
+
+        # persistent STFT buffers (checkpoint compatibility; the FFT kernels do not read them)
+        an, sy, win = _stft_bases(win_len, fft_len)
+        self.stft = _Node()
+        self.stft.register_buffer("weight", torch.from_numpy(an[:, None, :]))
+        self.istft = _Node()
+        self.istft.register_buffer("weight", torch.from_numpy(sy[:, None, :]))
+        self.istft.register_buffer("window", torch.from_numpy(win[None, :, None]))
+        self.istft.register_buffer("enframe", torch.eye(win_len)[:, None, :])
+        self.encoder, self.decoder, self.enhance = nn.ModuleList(), nn.ModuleList(), _Node()
+        self._params, self._buffers_named, self._nbt_named = [], [], []
+        for name, shape, kind in L.specs:
+            parts = name.split(".")
+            node = self._descend(parts[:-1])
+            if kind == "param":
+                off, _ = L.param_off[name]
+                p = nn.Parameter(self._flat[off:off + int(np.prod(shape))].view(shape))
+                node.register_parameter(parts[-1], p)
+                self._params.append((name, p))
+            elif kind == "buffer":
+                off, _ = L.buffer_off[name]
+                node.register_buffer(parts[-1], self._bflat[off:off + int(np.prod(shape))].view(shape))
+                self._buffers_named.append((name, node, parts[-1]))
+            else:
+                node.register_buffer(parts[-1], self._nbt[L.nbt_idx[name]])
+                self._nbt_named.append((name, node, parts[-1]))
+        self.reset_parameters()
+        self._register_state_dict_hook(_clone_state_hook)
+
+    # ---- construction helpers ----------------------------------------------------------------------
+    def _descend(self, parts):
+        node = self
+        for q, key in enumerate(parts):
+            if isinstance(node, nn.ModuleList):
+                while len(node) <= int(key):
+                    node.append(_Node())
+                node = node[int(key)]
+            else:
+                if not hasattr(node, key):
+                    node.add_module(key, _Node())
+                node = getattr(node, key)
+        return node
+
+    def reset_parameters(self):
+        """Same distributions as the reference constructors: conv N(0,0.05)/bias 0 (src/model/dccrn.py:352-355,
+        :417-420), CBN Wrr=Wii=1, Wri~U(-.9,.9), B=0, running stats (0,0,1,0,1) (:497-514), PReLU 0.25,
+        LSTM/Linear U(-1/sqrt(fan),1/sqrt(fan))."""
+        h = self.cfg.hid
+        with torch.no_grad():
+            for name, p in self._params:
+                leaf = name.split(".")[-1]
+                if "conv.weight" in name:
+                    p.normal_(0.0, 0.05)
+                elif "conv.bias" in name or leaf in ("Br", "Bi"):
+                    p.zero_()
+                elif leaf in ("Wrr", "Wii"):
+                    p.fill_(1.0)
+                elif leaf == "Wri":
+                    p.uniform_(-0.9, 0.9)
+                elif name.endswith("2.weight"):
+                    p.fill_(0.25)
+                elif "lstm" in name:
+                    p.uniform_(-1.0 / h ** 0.5, 1.0 / h ** 0.5)
+                elif "trans" in name:
+                    p.uniform_(-1.0 / h ** 0.5, 1.0 / h ** 0.5)
+                else:
+                    raise KeyError(name)
+            for name, node, leaf in self._buffers_named:
+                getattr(node, leaf).fill_(1.0 if leaf in ("RVrr", "RVii") else 0.0)
+            self._nbt.zero_()
+
+    # ---- flat storage follows the module across devices ---------------------------------------------
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        L = self.static.layout
+        dev = self._params[0][1].device
+        flat = torch.zeros(L.n_params, device=dev)
+        for name, p in self._params:
+            off, shape = L.param_off[name]
+            v = flat[off:off + p.numel()].view(shape)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = None
+        bflat = torch.zeros(max(L.n_buffers, 1), device=dev)
+        for name, node, leaf in self._buffers_named:
+            off, shape = L.buffer_off[name]
+            v = bflat[off:off + int(np.prod(shape))].view(shape)
+            v.copy_(getattr(node, leaf))
+            node._buffers[leaf] = v
+        nbt = torch.zeros(len(L.nbt_names), dtype=torch.int64, device=dev)
+        for name, node, leaf in self._nbt_named:
+            i = L.nbt_idx[name]
+            nbt[i] = getattr(node, leaf).to(torch.int64)
+            node._buffers[leaf] = nbt[i]
+        self._flat, self._bflat, self._nbt = flat, bflat, nbt
+        self._gflat, self._tables, self._ws, self._anchor, self._grads_live = None, None, {}, None, False
+        return self
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        if self._gflat is None or self._gflat.device != self._flat.device:
+            self._gflat = torch.zeros_like(self._flat)
+        return self._gflat
+
+    def bind_grads(self):
+        """Make every p.grad a view into flat_grads (what the fused optimizer and the all-reduce operate on)."""
+        L = self.static.layout
+        g = self.flat_grads
+        for name, p in self._params:
+            off, shape = L.param_off[name]
+            p.grad = g[off:off + p.numel()].view(shape)
+
+    # ---- HIP path -------------------------------------------------------------------------------------
+    def workspace(self, batch, nsample):
+        dev = self._flat.device
+        if dev.type != "cuda":
+            raise SehipError(f"DCCRN parameters are on {dev}: the HIP path needs a gfx950 GPU (no CPU fallback); "
+                             "call model.to('cuda') first")
+        if self._tables is None:
+            self._tables = plan.DeviceTables(self.static, dev)
+        key = (batch, nsample)
+        if key not in self._ws:
+            self._ws[key] = plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev)
+        return self._ws[key]
+
+    def _run_forward(self, wav):
+        ws = self.workspace(wav.shape[0], wav.shape[-1])
+        x = wav.reshape(wav.shape[0], wav.shape[-1]).contiguous().float()
+        ws.forward(x, self._flat, self._bflat, self._nbt, training=self.training)
+        return ws
+
+    def _run_backward(self, ws, grad_out):
+        if not self.training:
+            raise SehipError("DCCRN.backward in eval mode (running-statistics BatchNorm) is not built")
+        g = grad_out.reshape(ws.B, ws.length).contiguous().float()
+        accumulate = self._grads_live and self._params[0][1].grad is not None
+        if accumulate:
+            tmp = torch.empty_like(self.flat_grads)
+            ws.backward(g, self._flat, tmp)
+            self.flat_grads.add_(tmp)
+        else:
+            ws.backward(g, self._flat, self.flat_grads)
+        self.bind_grads()
+        self._grads_live = True
+
+    def forward(self, inputs, lens=None):
+        if inputs.dim() == 2:
+            inputs = inputs.unsqueeze(1)
+        if not inputs.is_cuda:
+            raise SehipError("DCCRN.forward got a CPU tensor: the HIP path needs a gfx950 GPU (no CPU fallback)")
+        if torch.is_grad_enabled() and self.training:
+            if self._anchor is None or self._anchor.device != inputs.device:
+                self._anchor = torch.zeros(1, device=inputs.device, requires_grad=True)
+            return _DCCRNFunction.apply(self, inputs, self._anchor)
+        ws = self._run_forward(inputs)
+        return ws.wav.view(inputs.shape[0], 1, -1).clone()
+
+    def get_params(self, weight_decay=0.0):
+        """Same grouping helper as the reference (src/model/dccrn.py:231-246)."""
+        weights, biases = [], []
+        for name, p in self.named_parameters():
+            (biases if "bias" in name else weights).append(p)
+        return [{"params": weights, "weight_decay": weight_decay}, {"params": biases, "weight_decay": 0.0}]
+
+
+def _clone_state_hook(module, state_dict, prefix, local_metadata):
+    # parameters are views of one flat buffer; give every checkpoint entry its own storage like the reference's
+    for k in list(state_dict.keys()):
+        state_dict[k] = state_dict[k].detach().clone()
+    return state_dict
+
+
+def _stft_bases(win_len, fft_len):
+    """init_kernels (src/model/dccrn.py:649-666): analysis = [cos; -sin] * hann, synthesis = pinv(basis).T * hann."""
+    n = np.arange(win_len, dtype=np.float64)[None, :]
+    k = np.arange(fft_len // 2 + 1, dtype=np.float64)[:, None]
+    ang = 2.0 * np.pi * k * n / fft_len
+    basis = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0)
+    win = ops.hann_periodic(win_len).astype(np.float64)
+    return ((basis * win).astype(np.float32), (np.linalg.pinv(basis).T * win).astype(np.float32), win.astype(np.float32))

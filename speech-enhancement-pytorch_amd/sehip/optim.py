@@ -1,0 +1,121 @@
+"""Fused optimizer on the model's flat parameter / gradient buffers
+(reference: src/distrib.py:244-261 builds torch.optim.Adam / SGD; src/solver.py:487-498 clips, steps and
+computes the sum-based grad_norm metric with one Python loop over 134 tensors).
+
+`FlatOptimizer` keeps torch.optim.Optimizer's interface and state_dict format (per-parameter `step`, `exp_avg`,
+`exp_avg_sq` / `momentum_buffer`, so checkpoints interchange with the reference), but the state tensors are views
+into two flat fp32 buffers and `step()` is ONE HIP launch (plus one reduction when clipping).
+"""
+import torch
+
+from ._lib import call, ptr, stream, SehipError
+
+
+class FlatOptimizer(torch.optim.Optimizer):
+    def __init__(self, model, lr, kind="adam", betas=(0.9, 0.999), eps=1e-8, momentum=0.0, weight_decay=0.0):
+        if not hasattr(model, "flat_params"):
+            raise SehipError("FlatOptimizer needs a sehip model (flat_params / flat_grads)")
+        self.model = model
+        self.kind = kind
+        defaults = dict(lr=lr, betas=betas, eps=eps, momentum=momentum, weight_decay=weight_decay)
+        super().__init__(list(model.parameters()), defaults)
+        self._m = self._v = None
+        self._step = 0
+        self._scratch = None
+        self.max_norm = 0.0  # set by clip_grad_norm_() for the next step only
+
+    # ---- flat state -------------------------------------------------------------------------------
+    def _ensure_state(self):
+        flat = self.model.flat_params
+        if self._m is None or self._m.device != flat.device or self._m.numel() != flat.numel():
+            old_m, old_v = self._m, self._v
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+            if old_m is not None and old_m.numel() == flat.numel():
+                self._m.copy_(old_m); self._v.copy_(old_v)
+            self._scratch = dict(sumsq=torch.zeros(1, dtype=torch.float64, device=flat.device),
+                                 tsums=torch.zeros(len(self.model._params), device=flat.device),
+                                 metric=torch.zeros(2, device=flat.device),
+                                 offsets=torch.from_numpy(self.model.static.layout.tensor_offsets).to(flat.device))
+            self._publish_state()
+
+    def _publish_state(self):
+        L = self.model.static.layout
+        for name, p in self.model._params:
+            off, shape = L.param_off[name]
+            sl = slice(off, off + p.numel())
+            st = self.state[p]
+            st["step"] = torch.tensor(float(self._step))
+            if self.kind == "adam":
+                st["exp_avg"] = self._m[sl].view(shape)
+                st["exp_avg_sq"] = self._v[sl].view(shape)
+            else:
+                st["momentum_buffer"] = self._m[sl].view(shape)
+
+    def clip_grad_norm_(self, max_norm):
+        """Arms global-norm clipping (torch.nn.utils.clip_grad_norm_ semantics) for the next step();
+        the norm is computed on device and never read back."""
+        self.max_norm = float(max_norm) if max_norm else 0.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise SehipError("FlatOptimizer.step: closures are not supported")
+        self._ensure_state()
+        model = self.model
+        params, grads = model.flat_params, model.flat_grads
+        g = self.param_groups[0]
+        self._step += 1
+        s = self._scratch
+        if self.max_norm > 0:
+            call("sehip_grad_sumsq", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
+        if self.kind == "adam":
+            b1, b2 = g["betas"]
+            mode = 0
+        else:
+            b1, b2, mode = g["momentum"], 0.0, 1
+        call("sehip_opt_step", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq"]),
+             self.max_norm, g["lr"], b1, b2, g["eps"], self._step, g["weight_decay"], mode, stream())
+        self.max_norm = 0.0
+
+    def grad_metric(self):
+        """Device tensor [2]: the reference's sqrt(sum_p (p.grad.sum())^2) (src/solver.py:494-498) and the L2 norm."""
+        self._ensure_state()
+        s = self._scratch
+        grads = self.model.flat_grads
+        call("sehip_grad_metric", ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), ptr(s["sumsq"]), ptr(s["tsums"]),
+             ptr(s["metric"]), stream())
+        return s["metric"]
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=True)
+        self.model._grads_live = False
+
+    # ---- checkpoint format of torch.optim ----------------------------------------------------------
+    def state_dict(self):
+        self._ensure_state()
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._ensure_state()
+        L = self.model.static.layout
+        states = state_dict["state"]
+        for idx, (name, p) in enumerate(self.model._params):
+            st = states.get(idx, states.get(str(idx)))
+            if st is None:
+                continue
+            off, shape = L.param_off[name]
+            sl = slice(off, off + p.numel())
+            if self.kind == "adam":
+                self._m[sl].copy_(st["exp_avg"].reshape(-1))
+                self._v[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            elif "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                self._m[sl].copy_(st["momentum_buffer"].reshape(-1))
+            self._step = int(float(st["step"]))
+        for g, saved in zip(self.param_groups, state_dict["param_groups"]):
+            for k in ("lr", "betas", "eps", "momentum", "weight_decay"):
+                if k in saved:
+                    g[k] = saved[k]
+        self._publish_state()

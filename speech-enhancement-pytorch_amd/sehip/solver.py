@@ -1,0 +1,277 @@
+"""Solver: the train loop of the reference (src/solver.py:109-532) on the HIP path.
+
+Kept from the reference: constructor signature, train() / _run_one_epoch() control flow (step caps, asserts on
+channels and speakers, MONARCH reshape, model.train()/eval(), the overwritten PIT loss, zero_grad / backward /
+clip / step, the sum-based grad_norm metric, tag names of the logged scalars, score dict incl. the
+'validation metric loss returns the TRAIN loss' quirk), checkpoint files and their keys (latest_model.tar,
+model_<epoch>_<metric>_<best>.pth, best_model.tar, state.json), resume / preload.
+Changed by design: one process per GPU with an RCCL all-reduce of the flat gradient buffer instead of
+nn.DataParallel (src/solver.py:144-145); clip + optimizer are one fused launch; per-step `.item()` syncs happen
+every `config.solver.log_interval` steps (default 1 = the reference's cadence); no CUDA_LAUNCH_BLOCKING.
+Out of scope: inference / metrics / plots (src/solver.py:534-746).
+"""
+import datetime
+import json
+import os
+import time
+from pathlib import Path
+from shutil import copyfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import distrib
+from ._lib import SehipError
+from .model.types import MONARCH_SPEECH_SEPARTAION_MODELS, MULTI_SPEECH_SEPERATION_MODELS, STFT_MODELS
+from .optim import FlatOptimizer
+from .utils import obj2dict
+
+try:  # tensorboard is optional in this image
+    from torch.utils.tensorboard import SummaryWriter as _TBWriter
+except Exception:  # pragma: no cover
+    _TBWriter = None
+
+
+class ScalarLog:
+    """SummaryWriter stand-in that keeps the scalars in memory (used when tensorboard is absent)."""
+
+    def __init__(self, *a, **k):
+        self.scalars = []
+
+    def add_text(self, *a, **k):
+        pass
+
+    def add_scalar(self, tag, value, step=None, *a, **k):
+        self.scalars.append((tag, float(value), -1 if step is None else int(step)))
+
+    def add_scalars(self, *a, **k):
+        pass
+
+    def add_figure(self, *a, **k):
+        pass
+
+
+def _cfg(obj, name, default):
+    return getattr(obj, name, default)
+
+
+class Solver(object):
+    def __init__(self, config, model, optimizer=None, loss_function=None, train_dataloader=None,
+                 validation_dataloader=None, test_dataloader=None, device="gpu", writer=None):
+        self.train_dataloader = train_dataloader
+        self.validation_dataloader = validation_dataloader
+        self.test_dataloader = test_dataloader
+        self.audiogram_dataloader = None  # hearing-aid post-processing is outside the train step
+
+        self.rank, self.world_size, self.local_rank = distrib.init_distributed() if device == "gpu" else (0, 1, 0)
+        self.n_gpu = torch.cuda.device_count()
+        if device == "gpu":
+            if self.n_gpu == 0:
+                raise SehipError("Solver(device='gpu'): no GPU visible and the HIP path has no CPU fallback")
+            self.device = torch.device(f"cuda:{self.local_rank}")
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.is_main = self.rank == 0
+
+        self.optimizer = optimizer
+        self.loss_function = loss_function
+        self.model = model.to(self.device)
+        if self.world_size > 1:
+            distrib.broadcast_parameters(self.model.flat_params, self.model._bflat)
+
+        self.epochs = config.solver.epochs
+        self.save_checkpoint_interval = config.solver.save_checkpoint_interval
+        self.validation_interval = config.solver.validation.interval
+        self.test_interval = config.solver.test.interval
+        self.log_interval = int(_cfg(config.solver, "log_interval", 1))
+
+        self.find_max = config.solver.validation.metric in ("stoi", "pesq", "sisdr", "haspi", "hasqi")
+        self.score = {"best_score": -np.inf if self.find_max else np.inf, "loss": 0, "loss_valid": 0, "grad_norm": 0,
+                      "stoi": [], "pesq": [], "sisdr": [], "haspi": [], "hasqi": []}
+
+        self.root_dir = Path(config.solver.root) / "result" / config.model.name / datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
+        self.checkpoints_dir = self.root_dir / "checkpoints"
+        self.logs_dir = self.root_dir / "logs"
+        if self.is_main:
+            for d in (self.checkpoints_dir, self.logs_dir):
+                d.mkdir(parents=True, exist_ok=True)
+        if writer is not None:
+            self.writer = writer
+        elif _TBWriter is not None and self.is_main:
+            self.writer = _TBWriter(log_dir=self.logs_dir.as_posix(), max_queue=5, flush_secs=30)
+        else:
+            self.writer = ScalarLog()
+        self.writer.add_text(tag="Configuration",
+                             text_string=f"<pre>  \n{json.dumps(obj2dict(config), indent=4, sort_keys=False)}  \n</pre>",
+                             global_step=1)
+        self.config = config
+        if config.solver.preloaded_model:
+            self._preload_model()
+        elif config.solver.resume:
+            self._resume_checkpoint()
+        if self.is_main and getattr(config, "root", None) and os.path.exists(config.root):
+            copyfile(config.root, (self.root_dir / "config.yaml").as_posix())
+        self._print_networks([self.model])
+
+    # ---- checkpoints (src/solver.py:233-341) ---------------------------------------------------------
+    def _resume_checkpoint(self):
+        latest = Path(self.config.solver.resume) / "checkpoints/latest_model.tar"
+        assert latest.exists(), f"{latest} does not exist, can not load latest checkpoint."
+        checkpoint = torch.load(latest.as_posix(), map_location=self.device, weights_only=False)
+        self.best_score = checkpoint["best_score"]
+        if self.config.optim.load:
+            self.optimizer.load_state_dict(checkpoint["optimizer"])
+        self.model.load_state_dict(checkpoint["model"])
+        print(f"\tModel checkpoint loaded, {latest.as_posix()}")
+
+    def _preload_model(self):
+        path = Path(self.config.solver.preloaded_model)
+        assert path.exists(), f"Preloaded *.pth file is not exist. Please check the file path: {path.as_posix()}"
+        self.model.load_state_dict(torch.load(path, map_location=self.device, weights_only=False), strict=False)
+        print(f"\tModel preloaded successfully from {path.as_posix()}.")
+
+    @staticmethod
+    def _print_networks(nets):
+        total = 0
+        for i, net in enumerate(nets, start=1):
+            n = sum(p.numel() for p in net.parameters())
+            print(f"\tNetwork {i}: {n / 1e6} million.")
+            total += n
+        print(f"The amount of parameters in the project is {total / 1e6} million.")
+
+    def _save_checkpoint(self, epoch, is_best=False):
+        if not self.is_main:
+            return
+        state_dict = {"epoch": epoch, "best_score": self.score["best_score"], "optimizer": self.optimizer.state_dict()}
+        state_dict["model"] = {k: v.cpu() for k, v in self.model.state_dict().items()}
+        torch.save(state_dict, (self.checkpoints_dir / "latest_model.tar").as_posix())
+        torch.save(state_dict["model"], (self.checkpoints_dir /
+                   f"model_{str(epoch).zfill(4)}_{self.config.solver.validation.metric}_{self.score['best_score']:2.8f}.pth").as_posix())
+        with open(self.checkpoints_dir / "state.json", "w") as tmp:
+            json.dump(self.score, tmp, indent=4)
+        if is_best:
+            torch.save(state_dict, (self.checkpoints_dir / "best_model.tar").as_posix())
+
+    def _is_best(self, score, find_max=True):
+        if find_max and score >= self.score["best_score"]:
+            self.score["best_score"] = score
+            return True
+        if not find_max and score <= self.score["best_score"]:
+            self.score["best_score"] = score
+            return True
+        return False
+
+    # ---- train loop (src/solver.py:355-532) ------------------------------------------------------------
+    def train(self):
+        patience = self.config.solver.patience
+        early_stopping = 0
+        for epoch in range(self.epochs):
+            start_time = time.time()
+            score = self._run_one_epoch(epoch, self.epochs, train=True)
+            if epoch % self.save_checkpoint_interval == 0:
+                self._save_checkpoint(epoch)
+            if epoch % self.validation_interval == 0:
+                score = self._run_one_epoch(epoch, self.epochs, train=False)
+                if self._is_best(score, find_max=self.find_max):
+                    self._save_checkpoint(epoch, is_best=True)
+                    early_stopping = 0
+                else:
+                    early_stopping += 1
+            if early_stopping > patience:
+                break
+            print(f"[{int(time.time() - start_time)} seconds] End this epoch.")
+
+    def _prepare_batch(self, mixture, sources):
+        cfg = self.config
+        mixture = mixture.to(self.device, non_blocking=True)
+        sources = sources.to(self.device, non_blocking=True)
+        batch, nchannel, nsample = mixture.shape
+        num_spk = sources.shape[1]
+        assert cfg.model.audio_channels == nchannel, f"Channel between {cfg.dset.name} and {cfg.model.name} did not match..."
+        assert cfg.model.num_spk == num_spk, f"number of speakers between {cfg.dset.name} and {cfg.model.name} did not match..."
+        if cfg.model.name in MULTI_SPEECH_SEPERATION_MODELS:
+            assert num_spk == len(cfg.model.sources)
+        if cfg.model.name in MONARCH_SPEECH_SEPARTAION_MODELS:
+            sources = torch.squeeze(sources, dim=1)
+            mixture = torch.reshape(mixture, shape=(batch * nchannel, 1, nsample))
+            sources = torch.reshape(sources, shape=(batch * num_spk * nchannel, 1, nsample))
+        if cfg.model.name in STFT_MODELS:
+            raise SehipError(f"STFT-domain model '{cfg.model.name}' has no HIP path yet")
+        return mixture, sources
+
+    def train_step(self, mixture, sources):
+        """One optimisation step on device tensors; returns (loss, grad_metric[2]) as DEVICE tensors (no sync)."""
+        self.model.train()
+        enhanced = self.model(mixture)
+        # (the reference computes a PIT loss here and then overwrites it, src/solver.py:469-480)
+        loss = self.loss_function(enhanced, sources)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.world_size > 1:
+            distrib.allreduce_gradients(self.model.flat_grads)
+        fused = isinstance(self.optimizer, FlatOptimizer)
+        if self.config.optim.clip_grad:
+            if fused:
+                self.optimizer.clip_grad_norm_(self.config.optim.clip_grad)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.config.optim.clip_grad)
+        self.optimizer.step()
+        metric = self.optimizer.grad_metric() if fused else None
+        return loss.detach(), metric
+
+    def _run_one_epoch(self, epoch, total_epoch, train=False):
+        cfg = self.config
+        loss_total = 0.0
+        grad_norm_total = 0.0
+        dataloader = self.train_dataloader if train else self.validation_dataloader
+        total_step = len(dataloader)
+        if not cfg.solver.all_steps:
+            if train and total_step > cfg.solver.total_steps:
+                total_step = cfg.solver.total_steps
+            elif not train and total_step > cfg.solver.validation.total_steps:
+                total_step = cfg.solver.validation.total_steps
+        pending = []  # device scalars waiting for the next logging point
+
+        def flush():
+            nonlocal loss_total, grad_norm_total
+            for step_, loss_t, metric_t in pending:
+                loss = float(loss_t)
+                loss_total += loss
+                if train:
+                    grad_norm = float(metric_t[0]) if metric_t is not None else 0.0
+                    grad_norm_total += grad_norm
+                    self.writer.add_scalar("Train/Loss_step", loss, epoch * total_step + step_)
+                    self.writer.add_scalar("Train/grad_norm_step", grad_norm, epoch * total_step + step_)
+                else:
+                    self.writer.add_scalar("Validation/Loss_step", loss, epoch * total_step + step_)
+            pending.clear()
+
+        for step, batch in enumerate(dataloader):
+            if step >= total_step:
+                break
+            mixture, sources = batch[0], batch[1]
+            mixture, sources = self._prepare_batch(mixture, sources)
+            if train:
+                loss_t, metric_t = self.train_step(mixture, sources)
+                pending.append((step, loss_t.clone(), metric_t.clone() if metric_t is not None else None))
+            else:
+                self.model.eval()
+                with torch.no_grad():
+                    enhanced = self.model(mixture)
+                    loss_t = self.loss_function(enhanced, sources)
+                pending.append((step, loss_t.detach().clone(), None))
+            if (step + 1) % self.log_interval == 0:
+                flush()
+        flush()
+        if train:
+            self.score["loss"] = loss_total / total_step
+            self.score["grad_norm"] = grad_norm_total / total_step
+            self.writer.add_scalar("Train/Loss", self.score["loss"], epoch)
+            self.writer.add_scalar("Train/Grad_norm", self.score["grad_norm"], epoch)
+        else:
+            self.score["loss_valid"] = loss_total / total_step
+            self.writer.add_scalar("Validation/Loss", self.score["loss_valid"], epoch)
+        # NB: with validation metric 'loss' this returns the TRAIN loss, exactly like src/solver.py:532
+        return self.score["loss"] if train else self.score[cfg.solver.validation.metric]

@@ -1,0 +1,106 @@
+"""GPU: the drop-in module / fused optimizer / Solver loop against two oracle train steps (same weights, same batches)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccrn_oracle as O
+from util import rel_err, max_abs
+
+pytestmark = pytest.mark.gpu
+KW = dict(kernel_num=[16, 16, 32, 32, 64, 64], rnn_units=128, length=4000)
+
+
+def make_batch(seed, b, n):
+    g = torch.Generator().manual_seed(seed)
+    clean = 0.1 * torch.randn(b, 1, 1, n, generator=g)
+    noisy = clean[:, 0] + 0.05 * torch.randn(b, 1, n, generator=g)
+    return noisy, clean
+
+
+def solver_config(tmp, clip=5):
+    from sehip.utils import dict2obj
+    return dict2obj({
+        "seed": 10, "root": None, "ha": None,
+        "model": dict(name="dccrn", audio_channels=1, num_spk=1, **KW),
+        "optim": {"optim": "adam", "lr": 3e-4, "beta1": 0.9, "beta2": 0.999, "loss": "si-sdr", "clip_grad": clip,
+                  "pit": False, "load": True},
+        "dset": {"name": "synthetic"},
+        "solver": {"epochs": 1, "save_checkpoint_interval": 1, "all_steps": True, "total_steps": 0, "patience": 0,
+                   "root": str(tmp), "resume": None, "preloaded_model": None,
+                   "validation": {"interval": 1, "metric": "loss", "total_steps": 0}, "test": {"interval": 1}},
+    })
+
+
+def test_two_solver_steps_match_oracle(tmp_path):
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    cfg = solver_config(tmp_path)
+    torch.manual_seed(cfg.seed)
+    model = distrib.get_model(cfg.model)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith(("stft.", "istft."))}
+    opt = distrib.get_optimizer(cfg.optim, model)
+    batches = []
+    for s in range(2):
+        noisy, clean = make_batch(100 + s, 2, 4000)
+        batches.append((noisy, clean, [None], [None], ["x"], [s]))
+    log = ScalarLog()
+    solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), train_dataloader=batches,
+                    validation_dataloader=[batches[0]], device="gpu", writer=log)
+    solver.train()
+    losses = [v for (t, v, _s) in log.scalars if t == "Train/Loss_step"]
+    gnorms = [v for (t, v, _s) in log.scalars if t == "Train/grad_norm_step"]
+
+    cfg_o = O.DCCRNConfig(**KW)
+    adam = O.AdamState({k: v for k, v in p.items() if O.is_trainable(k)}, lr=3e-4)
+    for s in range(2):
+        loss, metric, _ = O.train_step(p, batches[s][0], batches[s][1][:, 0], cfg_o, adam, clip_grad=5)
+        assert abs(loss - losses[s]) < 0.1, (s, loss, losses[s])          # dB; bf16 activations vs fp32 oracle
+        assert abs(metric - gnorms[s]) < 0.15 * abs(metric) + 1e-3, (s, metric, gnorms[s])
+    sd = {k: v.cpu() for k, v in solver.model.state_dict().items()}
+    for k, v in p.items():
+        if v.dtype == torch.int64:
+            assert int(sd[k]) == int(v), k
+        elif O.is_trainable(k):
+            # two Adam steps move every weight by at most ~2*lr; direction agreement is what is checked
+            assert max_abs(sd[k], v) < 1.3e-3, (k, max_abs(sd[k], v))
+        elif k.endswith(("RMr", "RMi", "RVri")):
+            # running means / cross-covariances are ~1e3x smaller than the channel scale: absolute bound
+            assert max_abs(sd[k], v) < 3e-3, (k, max_abs(sd[k], v))
+        else:
+            assert rel_err(sd[k], v) < 3e-2, k
+    # checkpoint files and keys (src/solver.py:295-341)
+    ck = list((solver.checkpoints_dir).glob("*"))
+    names = sorted(f.name for f in ck)
+    assert "latest_model.tar" in names and "best_model.tar" in names and "state.json" in names
+    tar = torch.load(solver.checkpoints_dir / "latest_model.tar", weights_only=False)
+    assert sorted(tar.keys()) == ["best_score", "epoch", "model", "optimizer"]
+    assert len(tar["model"]) == 204
+    # resume into a fresh model + optimizer
+    cfg2 = solver_config(tmp_path)
+    cfg2.solver.resume = str(solver.root_dir)
+    model2 = distrib.get_model(cfg2.model)
+    opt2 = distrib.get_optimizer(cfg2.optim, model2)
+    s2 = Solver(cfg2, model2, opt2, distrib.get_loss_function(cfg2.optim), train_dataloader=batches,
+                validation_dataloader=[batches[0]], device="gpu", writer=ScalarLog())
+    assert torch.equal(s2.model.flat_params.cpu(), solver.model.flat_params.cpu())
+    assert opt2._step == 2 and torch.equal(opt2._m.cpu(), opt._m.cpu())
+
+
+def test_eval_forward_and_cpu_rejection():
+    from sehip.model import DCCRN
+    from sehip import SehipError
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model = DCCRN(**KW).to(dev)
+    noisy, _ = make_batch(5, 2, 4000)
+    model.train()
+    with torch.no_grad():
+        model(noisy.to(dev))  # updates running statistics
+    model.eval()
+    with torch.no_grad():
+        out = model(noisy.to(dev))
+    p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if not k.startswith(("stft.", "istft."))}
+    ref = O.dccrn_forward(p, noisy, O.DCCRNConfig(**KW), training=False)
+    assert rel_err(out.cpu(), ref) < 3e-2
+    with pytest.raises(SehipError):
+        model(noisy)  # CPU tensor: no fallback
