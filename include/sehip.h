@@ -49,7 +49,8 @@ int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, co
 int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream);
 int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
                    float lr, float beta1, float beta2, float eps, int step, float weight_decay, int mode, void* stream);
-int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, int ntensors, const double* sumsq,
+int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, int ntensors, long max_tensor_numel,
+                      const double* sumsq,
                       float* tensor_sums /*[ntensors]*/, float* metric /*[2]: sum-metric, L2 norm*/, void* stream);
 
 /* ---- implicit-GEMM engine (bf16 MFMA, fp32 accumulate) used for
@@ -58,7 +59,7 @@ int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, 
  *                                                                  drop :193-196, dgrad, wgrad)
  *        nn.LSTM input GEMMs + Linear projections of NavieComplexLSTM  src/model/dccrn.py:264-302
  *      out[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]);  row m <-> (b, t, j): m = (b*TT + t)*J + j.
- *      A is never materialised: element (m, 8*c .. 8*c+7) is gathered through ktab[c] from up to 4 channels-last
+ *      A is never materialised: element (m, 8*c .. 8*c+7) is gathered through ktab[c] from up to 2 channels-last
  *      source tensors:   src[s][ ((b*T_s + t + toff) * F_s + j*fmul + fadd) * C_s + coff .. +7 ]
  *      (zero outside [tlo,thi) x [0,F_s)).  C_s == 2 sources use "narrow" chunks: 4 consecutive rows x 2 channels.
  *      Output columns are scattered 4 at a time through ntab into up to 2 destination tensors. */
@@ -72,10 +73,10 @@ typedef struct {
 } sehip_src;
 
 typedef struct {
-    int32_t src;  /* source index, -1 = zero chunk */
-    int32_t toff; /* added to the row's t */
-    int32_t fadd; /* added to j*fmul */
-    int32_t coff; /* wide: channel offset (multiple of 8); narrow (C==2): number of valid rows (1..4) */
+    int32_t src;  /* source index (0 or 1), -1 = zero chunk */
+    int32_t toff; /* (frame offset << 16) | (row offset & 0xffff): added to the row's t / to j*fmul, for the bounds */
+    int32_t fadd; /* element delta (frame_off*F_s + row_off)*C_s + channel_off added to the row's base offset */
+    int32_t coff; /* narrow (C_s == 2) chunks: number of valid rows (1..4); unused otherwise */
 } sehip_kchunk;
 
 typedef struct {

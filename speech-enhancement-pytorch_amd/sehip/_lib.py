@@ -33,7 +33,8 @@ _PROTOS = {
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
     "sehip_grad_sumsq": [P, L, P, P],
     "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, F, I, P],
-    "sehip_grad_metric": [P, P, I, P, P, P, P],
+    "sehip_grad_metric": [P, P, I, L, P, P, P, P],
+    "sehip_cbn_scratch_floats": [L, I],
     "sehip_stft_fwd": [P, P, I, I, I, I, I, P, P, P],
     "sehip_istft_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P],
     "sehip_istft_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
@@ -52,7 +53,7 @@ _PROTOS = {
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
 }
-_RESTYPE = {}
+_RESTYPE = {"sehip_cbn_scratch_floats": C.c_long}
 
 
 def lib():

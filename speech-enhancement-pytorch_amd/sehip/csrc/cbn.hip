@@ -31,31 +31,44 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
     return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
 
-// Reduce NS per-thread sums (for 8 channels each) over the threads of the block that share a chunk column q,
-// then add them to the double accumulators acc[s*Cr + channel].
+// Reduce NS per-thread sums (for 8 channels each) over the threads of the block that share a chunk column q and
+// store the block's partial sums at part[blockIdx.x][a*Cr + channel] (no atomics: a later per-channel wave adds the
+// partials of all blocks in double precision).
 template <int NS>
-__device__ __forceinline__ void block_accumulate(float (&s)[NS][8], int q, int nq, int Cr, double* __restrict__ acc,
-                                                 float* lds /* 256 floats */) {
+__device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr, float* __restrict__ part, int stride,
+                                               float* lds /* 256 floats */) {
     const int tid = threadIdx.x;
     const int groups = 256 / nq;  // threads per chunk column
+    float* out = part + (size_t)blockIdx.x * stride;
 #pragma unroll
     for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // first fold the lanes of a wave that share a column (nq divides 64), then across waves through LDS
+            float v = s[a][j];
+            for (int o = 32; o >= nq; o >>= 1) v += __shfl_xor(v, o, 64);
             __syncthreads();
-            lds[tid] = s[a][j];
+            if ((tid & 63) < nq) lds[(tid >> 6) * nq + (tid & 63)] = v;
             __syncthreads();
-            if (tid < nq) {  // thread tid sums column tid
+            if (tid < nq) {
                 float t = 0.f;
-                for (int g = 0; g < groups; ++g) t += lds[g * nq + tid];
-                atomicAdd(&acc[(size_t)a * Cr + tid * 8 + j], (double)t);
+                const int nw = groups >= 4 ? 4 : 4;  // 4 waves always
+                for (int w = 0; w < nw; ++w) t += lds[w * nq + tid];
+                out[(size_t)a * Cr + tid * 8 + j] = t;
             }
         }
 }
 
+// sum of part[b][idx] over the blocks, by one wave
+__device__ __forceinline__ double wave_reduce_partials(const float* __restrict__ part, int nblk, int stride, int idx) {
+    double acc = 0.0;
+    for (int b = threadIdx.x & 63; b < nblk; b += 64) acc += (double)part[(size_t)b * stride + idx];
+    return wave_sum_d(acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restrict__ y, long rows, int Cr,
-                                                        double* __restrict__ acc /* [5][Cr] */) {
+                                                        float* __restrict__ part /* [nblk][5*Cr] */) {
     __shared__ float lds[256];
     const int nq = Cr >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
@@ -75,25 +88,29 @@ __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restri
                 s[2][j] += a.v[j] * a.v[j]; s[3][j] += a.v[j] * b.v[j]; s[4][j] += b.v[j] * b.v[j];
             }
         }
-    block_accumulate<5>(s, q, nq, Cr, acc, lds);
+    block_partials<5>(s, nq, Cr, part, 5 * Cr, lds);
 }
 
-// one thread per complex channel
-__global__ void cbn_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ Wrr, const float* __restrict__ Wri,
+// one wave per complex channel
+__global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ Wrr, const float* __restrict__ Wri,
                                     const float* __restrict__ Wii, const float* __restrict__ Br, const float* __restrict__ Bi,
                                     float* __restrict__ RMr, float* __restrict__ RMi, float* __restrict__ RVrr,
                                     float* __restrict__ RVri, float* __restrict__ RVii, long* __restrict__ nbt, long rows,
                                     int Cr, float eps, float momentum, int training, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cr) return;
+    const int c = blockIdx.x;
     float mr, mi, vrr, vri, vii;
     if (training) {
         const double n = (double)rows;
-        const double dmr = acc[c] / n, dmi = acc[Cr + c] / n;
+        const double a0 = wave_reduce_partials(part, nblk, 5 * Cr, c), a1 = wave_reduce_partials(part, nblk, 5 * Cr, Cr + c);
+        const double a2 = wave_reduce_partials(part, nblk, 5 * Cr, 2 * Cr + c);
+        const double a3 = wave_reduce_partials(part, nblk, 5 * Cr, 3 * Cr + c);
+        const double a4 = wave_reduce_partials(part, nblk, 5 * Cr, 4 * Cr + c);
+        if (threadIdx.x != 0) return;
+        const double dmr = a0 / n, dmi = a1 / n;
         mr = (float)dmr; mi = (float)dmi;
-        vrr = (float)(acc[2 * Cr + c] / n - dmr * dmr);
-        vri = (float)(acc[3 * Cr + c] / n - dmr * dmi);
-        vii = (float)(acc[4 * Cr + c] / n - dmi * dmi);
+        vrr = (float)(a2 / n - dmr * dmr);
+        vri = (float)(a3 / n - dmr * dmi);
+        vii = (float)(a4 / n - dmi * dmi);
         RMr[c] += momentum * (mr - RMr[c]);
         RMi[c] += momentum * (mi - RMi[c]);
         RVrr[c] += momentum * (vrr - RVrr[c]);
@@ -101,6 +118,7 @@ __global__ void cbn_finalize_kernel(const double* __restrict__ acc, const float*
         RVii[c] += momentum * (vii - RVii[c]);
         if (c == 0 && nbt) nbt[0] += 1;
     } else {
+        if (threadIdx.x != 0) return;
         mr = RMr[c]; mi = RMi[c]; vrr = RVrr[c]; vri = RVri[c]; vii = RVii[c];
     }
     vrr += eps; vii += eps;
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(256) void cbn_apply_kernel(const bf16_raw* __restri
 __global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
                                                              const bf16_raw* __restrict__ y, const float* __restrict__ coef,
                                                              const float* __restrict__ slope, long rows, int Cr, int F,
-                                                             int Tst, int tfirst, double* __restrict__ acc) {
+                                                             int Tst, int tfirst, float* __restrict__ part) {
     __shared__ float lds[256];
     const int nq = Cr >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
@@ -200,30 +218,36 @@ __global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const bf16_raw* __r
                 s[2][j] += dr * cr; s[3][j] += dr * ci; s[4][j] += di * cr; s[5][j] += di * ci;
             }
         }
-    block_accumulate<6>(s, q, nq, Cr, acc, lds);
+    block_partials<6>(s, nq, Cr, part, 6 * Cr + 1, lds);
     da = wave_sum(da);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = da;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&acc[(size_t)6 * Cr], (double)(lds[0] + lds[1] + lds[2] + lds[3]));
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * (6 * Cr + 1) + 6 * Cr] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-// one thread per channel: parameter gradients + coefficients of the apply pass
-__global__ void cbn_bwd_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ coef,
+// one wave per channel: parameter gradients + coefficients of the apply pass
+__global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ coef,
                                         const float* __restrict__ Wrr, const float* __restrict__ Wri,
                                         const float* __restrict__ Wii, long rows, int Cr, float* __restrict__ gWrr,
                                         float* __restrict__ gWri, float* __restrict__ gWii, float* __restrict__ gBr,
                                         float* __restrict__ gBi, float* __restrict__ gslope, float* __restrict__ bcoef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) gslope[0] = (float)acc[(size_t)6 * Cr];
-    if (c >= Cr) return;
+    const int c = blockIdx.x;
+    const int st = 6 * Cr + 1;
+    const float sdr = (float)wave_reduce_partials(part, nblk, st, c), sdi = (float)wave_reduce_partials(part, nblk, st, Cr + c);
+    const float qrr = (float)wave_reduce_partials(part, nblk, st, 2 * Cr + c);
+    const float qri = (float)wave_reduce_partials(part, nblk, st, 3 * Cr + c);
+    const float qir = (float)wave_reduce_partials(part, nblk, st, 4 * Cr + c);
+    const float qii = (float)wave_reduce_partials(part, nblk, st, 5 * Cr + c);
+    if (c == 0) {
+        const float ds = (float)wave_reduce_partials(part, nblk, st, 6 * Cr);
+        if (threadIdx.x == 0) gslope[0] = ds;
+    }
+    if (threadIdx.x != 0) return;
     const float* k = coef + (size_t)c * COEF_STRIDE;
     const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
     const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
     const float n = (float)rows;
-    const float sdr = (float)acc[c], sdi = (float)acc[Cr + c];
-    const float qrr = (float)acc[2 * Cr + c], qri = (float)acc[3 * Cr + c];
-    const float qir = (float)acc[4 * Cr + c], qii = (float)acc[5 * Cr + c];
     // P = Q U  (sum d xh^T)
     const float prr = qrr * urr + qri * uri, pri = qrr * uri + qri * uii;
     const float pir = qir * urr + qii * uri, pii = qir * uri + qii * uii;
@@ -319,9 +343,8 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const bf16_raw* __re
 // ---------------------------------------------------------------------------------------------
 static int check_cbn(const char* who, long rows, int Cr) {
     SEHIP_REQUIRE(rows > 0, "%s: empty input", who);
-    SEHIP_REQUIRE(Cr >= 8 && (Cr & 7) == 0 && Cr <= 2048 && (256 % (Cr >> 3) == 0 || (Cr >> 3) > 256),
-                  "%s: complex channels Cr=%d must be 8,16,32,...,2048 (power-of-two multiples of 8)", who, Cr);
-    SEHIP_REQUIRE((Cr >> 3) <= 256, "%s: Cr=%d too large", who, Cr);
+    SEHIP_REQUIRE(Cr >= 8 && Cr <= 512 && (Cr & (Cr - 1)) == 0,
+                  "%s: complex channels Cr=%d must be a power of two in [8, 512]", who, Cr);
     return 0;
 }
 static int grid_for(long work_items) {
@@ -331,27 +354,31 @@ static int grid_for(long work_items) {
     return (int)g;
 }
 
-// acc must hold 7*Cr+1 doubles; zeroed here.
-extern "C" int sehip_cbn_stats(const void* y, long rows, int Cr, double* acc, void* stream) {
-    if (int e = check_cbn("cbn_stats", rows, Cr)) return e;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t he = hipMemsetAsync(acc, 0, sizeof(double) * (5 * (size_t)Cr), st);
-    SEHIP_REQUIRE(he == hipSuccess, "cbn_stats: memset failed: %s", hipGetErrorString(he));
+static int stat_blocks(long rows, int Cr) {
     const int rpb = 256 / (Cr >> 3);
-    long g = (rows + (long)rpb * 16 - 1) / ((long)rpb * 16);
-    if (g > 2048) g = 2048;
-    cbn_stats_kernel<<<(int)g, 256, 0, st>>>((const bf16_raw*)y, rows, Cr, acc);
+    long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// number of floats the partial-sum scratch must hold (forward stats and backward reduce share it)
+extern "C" long sehip_cbn_scratch_floats(long rows, int Cr) { return (long)stat_blocks(rows, Cr) * (6L * Cr + 1); }
+
+extern "C" int sehip_cbn_stats(const void* y, long rows, int Cr, float* part, void* stream) {
+    if (int e = check_cbn("cbn_stats", rows, Cr)) return e;
+    cbn_stats_kernel<<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, rows, Cr, part);
     SEHIP_CHECK_LAUNCH("cbn_stats");
     return 0;
 }
 
 // params: Wrr,Wri,Wii,Br,Bi [Cr] fp32; buffers RMr,RMi,RVrr,RVri,RVii [Cr] fp32 (updated in training), nbt int64[1]
-extern "C" int sehip_cbn_finalize(const double* acc, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
+extern "C" int sehip_cbn_finalize(const float* part, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
                                   const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
                                   long rows, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
     if (int e = check_cbn("cbn_finalize", rows, Cr)) return e;
-    cbn_finalize_kernel<<<cdiv(Cr, 64), 64, 0, (hipStream_t)stream>>>(acc, Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr, RVri, RVii,
-                                                                      nbt, rows, Cr, eps, momentum, training, coef);
+    cbn_finalize_kernel<<<Cr, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr,
+                                                            RVri, RVii, nbt, rows, Cr, eps, momentum, training, coef);
     SEHIP_CHECK_LAUNCH("cbn_finalize");
     return 0;
 }
@@ -365,26 +392,20 @@ extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* sl
 }
 
 extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
-                                    long rows, int Cr, int F, int Tst, int tfirst, double* acc, void* stream) {
+                                    long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream) {
     if (int e = check_cbn("cbn_bwd_reduce", rows, Cr)) return e;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t he = hipMemsetAsync(acc, 0, sizeof(double) * (6 * (size_t)Cr + 1), st);
-    SEHIP_REQUIRE(he == hipSuccess, "cbn_bwd_reduce: memset failed: %s", hipGetErrorString(he));
-    const int rpb = 256 / (Cr >> 3);
-    long g = (rows + (long)rpb * 16 - 1) / ((long)rpb * 16);
-    if (g > 2048) g = 2048;
-    cbn_bwd_reduce_kernel<<<(int)g, 256, 0, st>>>((const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope,
-                                                  rows, Cr, F, Tst, tfirst, acc);
+    cbn_bwd_reduce_kernel<<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part);
     SEHIP_CHECK_LAUNCH("cbn_bwd_reduce");
     return 0;
 }
 
-extern "C" int sehip_cbn_bwd_finalize(const double* acc, const float* coef, const float* Wrr, const float* Wri,
+extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri,
                                       const float* Wii, long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr,
                                       float* gBi, float* gslope, float* bcoef, void* stream) {
     if (int e = check_cbn("cbn_bwd_finalize", rows, Cr)) return e;
-    cbn_bwd_finalize_kernel<<<cdiv(Cr, 64), 64, 0, (hipStream_t)stream>>>(acc, coef, Wrr, Wri, Wii, rows, Cr, gWrr, gWri, gWii,
-                                                                          gBr, gBi, gslope, bcoef);
+    cbn_bwd_finalize_kernel<<<Cr, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), coef, Wrr, Wri, Wii, rows, Cr, gWrr,
+                                                                gWri, gWii, gBr, gBi, gslope, bcoef);
     SEHIP_CHECK_LAUNCH("cbn_bwd_finalize");
     return 0;
 }

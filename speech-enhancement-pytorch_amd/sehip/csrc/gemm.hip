@@ -32,27 +32,38 @@ __device__ __forceinline__ RowPos row_pos(int m, int M, int TT, int J, int fmul)
     return r;
 }
 
-__device__ __forceinline__ uint4 gather_chunk(const sehip_src* ssrc, const sehip_kchunk e, const RowPos r) {
+// element offset of (b, t, jf) in source s, before the per-chunk delta
+__device__ __forceinline__ long row_base(const sehip_src& s, const RowPos r) {
+    return (((long)r.b * s.T + r.t) * s.F + r.jf) * s.C;
+}
+
+// One 16-byte chunk (8 consecutive k) of the implicit A matrix.  The chunk table carries the precomputed element
+// delta (toff*F + fadd)*C + coff, so the address is row_base + delta; toff/fadd are only needed for the bounds.
+__device__ __forceinline__ uint4 gather_chunk(const sehip_src& s0, const sehip_src& s1, const sehip_kchunk e, const RowPos r,
+                                              long rb0, long rb1) {
     uint4 z = make_uint4(0u, 0u, 0u, 0u);
     if (!r.valid || e.src < 0) return z;
-    const sehip_src s = ssrc[e.src];
-    const int ts = r.t + e.toff;
-    const int f = r.jf + e.fadd;
-    if (ts < s.tlo || ts >= s.thi) return z;
-    const size_t frame = (size_t)r.b * s.T + ts;
-    if (s.C == 2) {  // narrow source: 4 consecutive rows x (re, im)
-        const unsigned* p = reinterpret_cast<const unsigned*>(s.ptr) + frame * s.F;
+    const bool second = e.src != 0;
+    const int toff = e.toff >> 16, fadd = (int)(short)(e.toff & 0xffff);
+    const int ts = r.t + toff;
+    const int f = r.jf + fadd;
+    const int tlo = second ? s1.tlo : s0.tlo, thi = second ? s1.thi : s0.thi, F = second ? s1.F : s0.F;
+    if (ts < tlo || ts >= thi) return z;
+    const bf16_raw* base = reinterpret_cast<const bf16_raw*>(second ? s1.ptr : s0.ptr);
+    const long off = (second ? rb1 : rb0) + e.fadd;  // e.fadd holds the element delta
+    const int C = second ? s1.C : s0.C;
+    if (C == 2) {  // narrow source: up to 4 consecutive rows x (re, im); e.coff = number of valid rows
+        const unsigned* p = reinterpret_cast<const unsigned*>(base + off);
         unsigned v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int fr = f + q;
-            v[q] = (q < e.coff && fr >= 0 && fr < s.F) ? p[fr] : 0u;
+            v[q] = (q < e.coff && fr >= 0 && fr < F) ? p[q] : 0u;
         }
         return make_uint4(v[0], v[1], v[2], v[3]);
     }
-    if (f < 0 || f >= s.F) return z;
-    const bf16_raw* p = reinterpret_cast<const bf16_raw*>(s.ptr) + (frame * s.F + f) * s.C + e.coff;
-    return *reinterpret_cast<const uint4*>(p);
+    if ((unsigned)f >= (unsigned)F) return z;
+    return *reinterpret_cast<const uint4*>(base + off);
 }
 
 __device__ __forceinline__ size_t dst_row_offset(const sehip_dst& d, const RowPos r, int fmul_row) {
@@ -69,18 +80,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
     constexpr int NRW = (BN + 31) / 32;
     __shared__ uint4 sW[BN * 8];
     __shared__ uint4 sA[BM * 8];
-    __shared__ sehip_src ssrc[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    if (tid < 4) ssrc[tid] = d.src[tid];
-    __syncthreads();
 
     const int kc = tid & 7, r0 = tid >> 3;
     RowPos rp[NRA];
+    long rb0[NRA], rb1[NRA];
 #pragma unroll
-    for (int i = 0; i < NRA; ++i) rp[i] = row_pos(m0 + r0 + 32 * i, d.M, d.TT, d.J, d.fmul);
+    for (int i = 0; i < NRA; ++i) {
+        rp[i] = row_pos(m0 + r0 + 32 * i, d.M, d.TT, d.J, d.fmul);
+        rb0[i] = row_base(d.src[0], rp[i]);
+        rb1[i] = row_base(d.src[1], rp[i]);
+    }
 
     const int nk = d.K >> 6;
     const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
     auto issue = [&](int kt) {
         const sehip_kchunk e = d.ktab[kt * 8 + kc];
 #pragma unroll
-        for (int i = 0; i < NRA; ++i) ra[i] = gather_chunk(ssrc, e, rp[i]);
+        for (int i = 0; i < NRA; ++i) ra[i] = gather_chunk(d.src[0], d.src[1], e, rp[i], rb0[i], rb1[i]);
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
             const int rw_row = r0 + 32 * i;
@@ -188,7 +201,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
     constexpr int GPT = (64 * GCH + 255) / 256;  // dOut chunks per thread
     __shared__ __attribute__((aligned(16))) bf16_raw sG[64 * PG];
     __shared__ __attribute__((aligned(16))) bf16_raw sX[64 * PX];
-    __shared__ sehip_src ssrc[4];
     __shared__ sehip_dst sdst[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -196,7 +208,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
     const int n0 = blockIdx.x * BNW, k0 = blockIdx.y * 64;
     const int m_begin = blockIdx.z * m_per_block;
     const int m_end = min(d.M, m_begin + m_per_block);
-    if (tid < 4) ssrc[tid] = d.src[tid];
     if (tid < 2) sdst[tid] = d.dst[tid];
     __syncthreads();
 
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
             const int r = r0 + 32 * i;
             const int m = mb + r;
             RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul);
-            const uint4 v = gather_chunk(ssrc, e, rp);
+            const uint4 v = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
             *reinterpret_cast<uint4*>(&sX[r * PX + kc * 8]) = v;
         }
         // ---- stage dOut chunks: 64 rows x GCH chunks
@@ -311,6 +322,7 @@ static int check_desc(const char* who, const sehip_gemm_desc* d) {
     SEHIP_REQUIRE(d->TT > 0 && d->J > 0 && d->fmul > 0, "%s: bad row decomposition", who);
     SEHIP_REQUIRE(d->ktab && d->ntab && d->dst[0].ptr, "%s: missing table / destination", who);
     SEHIP_REQUIRE(d->M % d->J == 0 && (d->M / d->J) % d->TT == 0, "%s: M=%d is not B*TT*J", who, d->M);
+    SEHIP_REQUIRE(d->src[2].ptr == nullptr && d->src[3].ptr == nullptr, "%s: at most two sources are built", who);
     for (int s = 0; s < 4; ++s)
         if (d->src[s].ptr) {
             SEHIP_REQUIRE(d->src[s].C == 2 || (d->src[s].C & 7) == 0, "%s: source %d has C=%d (need 2 or a multiple of 8)", who, s, d->src[s].C);

@@ -15,6 +15,14 @@
 #define HP 72    // LDS pitch of the h tile (bf16 elements)
 #define DGP 264  // LDS pitch of the dgate tile
 
+// Workgroup barrier that only waits for this wave's LDS traffic: the per-step global stores / prefetch loads stay in
+// flight across it (__syncthreads() would also drain vmcnt and expose a full HBM round trip on every time step).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
 
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
             *reinterpret_cast<uint2*>(gp + 2 * H) = make_uint2(pack_bf2(gg[0], gg[1]), pack_bf2(gg[2], gg[3]));
             *reinterpret_cast<uint2*>(gp + 3 * H) = make_uint2(pack_bf2(go[0], go[1]), pack_bf2(go[2], go[3]));
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
@@ -123,23 +131,35 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
 
     float dc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 dhrec = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // software pipeline: the (gates, dh) of step t-1 and the cell state of step t-2 are requested while step t runs
+    struct StepIn { uint2 gi, gf, gg, go, dh; };
+    auto load_step = [&](int t) {
+        StepIn v;
+        const bf16_raw* gp = gates + (sbase + t) * G4 + uo;
+        v.gi = *reinterpret_cast<const uint2*>(gp);
+        v.gf = *reinterpret_cast<const uint2*>(gp + H);
+        v.gg = *reinterpret_cast<const uint2*>(gp + 2 * H);
+        v.go = *reinterpret_cast<const uint2*>(gp + 3 * H);
+        v.dh = *reinterpret_cast<const uint2*>(dhp + (size_t)t * H);
+        return v;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 c_t = *reinterpret_cast<const float4*>(cst + (sbase + T - 1) * H + uo);
+    float4 c_m1 = T > 1 ? *reinterpret_cast<const float4*>(cst + (sbase + T - 2) * H + uo) : zero4;
+    StepIn in = load_step(T - 1);
     int cur = 0;
     for (int t = T - 1; t >= 0; --t) {
-        const size_t o = sbase + t;
-        float4 c_prev = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t > 0) c_prev = *reinterpret_cast<const float4*>(cst + (o - 1) * H + uo);
-        const bf16_raw* gp = gates + o * G4 + uo;
-        const uint2 ri = *reinterpret_cast<const uint2*>(gp), rf = *reinterpret_cast<const uint2*>(gp + H);
-        const uint2 rg = *reinterpret_cast<const uint2*>(gp + 2 * H), ro = *reinterpret_cast<const uint2*>(gp + 3 * H);
-        const uint2 rdh = *reinterpret_cast<const uint2*>(dhp + (size_t)t * H);
-        const float gi[4] = {bf2f(ri.x & 0xffff), bf2f(ri.x >> 16), bf2f(ri.y & 0xffff), bf2f(ri.y >> 16)};
-        const float gf[4] = {bf2f(rf.x & 0xffff), bf2f(rf.x >> 16), bf2f(rf.y & 0xffff), bf2f(rf.y >> 16)};
-        const float gg[4] = {bf2f(rg.x & 0xffff), bf2f(rg.x >> 16), bf2f(rg.y & 0xffff), bf2f(rg.y >> 16)};
-        const float go[4] = {bf2f(ro.x & 0xffff), bf2f(ro.x >> 16), bf2f(ro.y & 0xffff), bf2f(ro.y >> 16)};
-        const float dho[4] = {bf2f(rdh.x & 0xffff), bf2f(rdh.x >> 16), bf2f(rdh.y & 0xffff), bf2f(rdh.y >> 16)};
+        StepIn nxt = in;
+        if (t > 0) nxt = load_step(t - 1);
+        float4 c_m2 = zero4;
+        if (t > 1) c_m2 = *reinterpret_cast<const float4*>(cst + (sbase + t - 2) * H + uo);
+        const float gi[4] = {bf2f(in.gi.x & 0xffff), bf2f(in.gi.x >> 16), bf2f(in.gi.y & 0xffff), bf2f(in.gi.y >> 16)};
+        const float gf[4] = {bf2f(in.gf.x & 0xffff), bf2f(in.gf.x >> 16), bf2f(in.gf.y & 0xffff), bf2f(in.gf.y >> 16)};
+        const float gg[4] = {bf2f(in.gg.x & 0xffff), bf2f(in.gg.x >> 16), bf2f(in.gg.y & 0xffff), bf2f(in.gg.y >> 16)};
+        const float go[4] = {bf2f(in.go.x & 0xffff), bf2f(in.go.x >> 16), bf2f(in.go.y & 0xffff), bf2f(in.go.y >> 16)};
+        const float dho[4] = {bf2f(in.dh.x & 0xffff), bf2f(in.dh.x >> 16), bf2f(in.dh.y & 0xffff), bf2f(in.dh.y >> 16)};
         const float cc[4] = {c_t.x, c_t.y, c_t.z, c_t.w};
-        const float cp[4] = {c_prev.x, c_prev.y, c_prev.z, c_prev.w};
+        const float cp[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w};
         float di[4], df[4], dg[4], dob[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
             *reinterpret_cast<uint2*>(dp + 2 * H) = pg;
             *reinterpret_cast<uint2*>(dp + 3 * H) = po;
         }
-        __syncthreads();
+        lds_barrier();
         dhrec = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -177,7 +197,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
             dhrec = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], gfrag, dhrec, 0, 0, 0);
         }
         cur ^= 1;
-        c_t = c_prev;
+        in = nxt;
+        c_t = c_m1;
+        c_m1 = c_m2;
     }
 }
 

@@ -56,15 +56,18 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, fl
     }
 }
 
+#define TS_CHUNK 8192
 __global__ __launch_bounds__(256) void tensor_sums_kernel(const float* __restrict__ g, const long* __restrict__ offsets,
                                                           int ntensors, float* __restrict__ sums) {
     __shared__ float red[4];
     const int t = blockIdx.x;
-    const long lo = offsets[t], hi = offsets[t + 1];
+    const long lo = offsets[t] + (long)blockIdx.y * TS_CHUNK;
+    const long hi = min(offsets[t + 1], lo + TS_CHUNK);
+    if (lo >= hi) return;
     float acc = 0.f;
     for (long i = lo + threadIdx.x; i < hi; i += 256) acc += g[i];
     acc = block_sum<4>(acc, red);
-    if (threadIdx.x == 0) sums[t] = acc;
+    if (threadIdx.x == 0) atomicAdd(&sums[t], acc);
 }
 
 // metric[0] = sqrt(sum_t sums[t]^2)  (src/solver.py:494-498); metric[1] = sqrt(sumsq) (pre-clip L2 norm)
@@ -110,11 +113,13 @@ extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, l
     return 0;
 }
 
-extern "C" int sehip_grad_metric(const float* grads, const long* offsets, int ntensors, const double* sumsq,
+extern "C" int sehip_grad_metric(const float* grads, const long* offsets, int ntensors, long max_tensor, const double* sumsq,
                                  float* tensor_sums, float* metric, void* stream) {
-    SEHIP_REQUIRE(ntensors > 0, "grad_metric: no tensors");
+    SEHIP_REQUIRE(ntensors > 0 && max_tensor > 0, "grad_metric: no tensors");
     hipStream_t st = (hipStream_t)stream;
-    tensor_sums_kernel<<<ntensors, 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
+    hipError_t e = hipMemsetAsync(tensor_sums, 0, sizeof(float) * ntensors, st);
+    SEHIP_REQUIRE(e == hipSuccess, "grad_metric: memset failed: %s", hipGetErrorString(e));
+    tensor_sums_kernel<<<dim3(ntensors, cdiv(max_tensor, TS_CHUNK)), 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
     grad_metric_kernel<<<1, 64, 0, st>>>(tensor_sums, ntensors, sumsq, metric);
     SEHIP_CHECK_LAUNCH("grad_metric");
     return 0;

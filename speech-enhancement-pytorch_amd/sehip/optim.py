@@ -83,8 +83,9 @@ class FlatOptimizer(torch.optim.Optimizer):
         self._ensure_state()
         s = self._scratch
         grads = self.model.flat_grads
-        call("sehip_grad_metric", ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), ptr(s["sumsq"]), ptr(s["tsums"]),
-             ptr(s["metric"]), stream())
+        offs = self.model.static.layout.tensor_offsets
+        call("sehip_grad_metric", ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), int((offs[1:] - offs[:-1]).max()),
+             ptr(s["sumsq"]), ptr(s["tsums"]), ptr(s["metric"]), stream())
         return s["metric"]
 
     def zero_grad(self, set_to_none=True):

@@ -638,7 +638,12 @@ class DCCRNWorkspace:
         self.inv_coff = torch.from_numpy(ops.inv_window_energy(cfg.win_len, cfg.win_inc, T, self.length)).to(device)
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
         maxcr = max(cr for _, cr in st.bn)
-        self.bn_acc = torch.zeros(7 * maxcr + 8, dtype=torch.float64, device=device)
+        lib = _lib.lib()
+        need = 16
+        for pre, cr in st.bn:
+            src = self.bufs[("y" if pre.startswith("encoder") else "yd") + pre.split(".")[1]]
+            need = max(need, int(lib.sehip_cbn_scratch_floats(src.t.numel() // (2 * cr), cr)))
+        self.bn_acc = torch.zeros(need, dtype=torch.float32, device=device)
         self.bn_coef = {pre: torch.zeros(cr, 16, dtype=torch.float32, device=device) for pre, cr in st.bn}
         self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
@@ -648,6 +653,23 @@ class DCCRNWorkspace:
     def _bind(self):
         st, tb, B, T = self.st, self.tb, self.B, self.T
         self.desc = {}
+        # chunk table bound to this workspace's source geometry: [src, (toff<<16)|(fadd&0xffff), element delta, npieces]
+        kt = st.ktab.copy()
+        for name, s in st.specs.items():
+            rows = st.ktab[s.kt_off:s.kt_off + s.K // 8]
+            out = kt[s.kt_off:s.kt_off + s.K // 8]
+            for q, (bname, mode) in enumerate(s.srcs):
+                b = self.bufs[bname]
+                m = rows[:, 0] == q
+                toff, fadd, coff = rows[m, 1].astype(np.int64), rows[m, 2].astype(np.int64), rows[m, 3].astype(np.int64)
+                narrow = b.C == 2
+                delta = (toff * b.F + fadd) * b.C + (0 if narrow else coff)
+                assert np.abs(delta).max() < 2 ** 31 and np.abs(toff).max() < 2 ** 15 and np.abs(fadd).max() < 2 ** 15
+                out[m, 1] = ((toff << 16) | (fadd & 0xffff)).astype(np.int64).astype(np.uint32).view(np.int32) if False else \
+                    (((toff << 16) | (fadd & 0xffff)) & 0xffffffff).astype(np.uint32).view(np.int32)
+                out[m, 2] = delta.astype(np.int32)
+                out[m, 3] = coff.astype(np.int32) if narrow else 0
+        self.ktab_dev = torch.from_numpy(kt).to(self.device)
         for name, s in st.specs.items():
             d = CGemmDesc()
             tt = T if s.tt == "T" else T + 1
@@ -667,7 +689,7 @@ class DCCRNWorkspace:
                 d.dst[q].is_f32 = 1 if b.t.dtype == torch.float32 else 0
                 if s.J == 1:  # dense rows: view the destination as one row per (b,t)
                     d.dst[q].F, d.dst[q].C = 1, b.F * b.C
-            d.ktab = tb.ktab.data_ptr() + 16 * s.kt_off
+            d.ktab = self.ktab_dev.data_ptr() + 16 * s.kt_off
             d.ntab = tb.ntab.data_ptr() + 16 * s.nt_off
             if s.w_off is not None:
                 d.W = tb.wpack.data_ptr() + 2 * s.w_off

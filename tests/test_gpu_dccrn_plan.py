@@ -141,7 +141,10 @@ def test_backward_param_grads(setup):
         # amplified chaotically through 11 BatchNorms (the bf16-simulated oracle itself sits 2-15 % from the fp32
         # oracle on these gradients), so this is a coarse bound; tests/test_gpu_ops_local.py pins every op tightly
         # on shared inputs.
-        tol = 0.2 * n + (3e-3 if noise_bias else 1e-5)
+        # (a conv bias in front of a BatchNorm has an analytically zero gradient: what is left is the rounding noise
+        # of the column sums of dY, which scales with the layer's gradient magnitude)
+        wn = errs.get(k.replace(".bias", ".weight"), (0.0, 0.0))[1]
+        tol = 0.2 * n + (2e-3 * wn + 3e-3 if noise_bias else 1e-5)
         if not e < tol:
             bad[k] = (e, n)
     assert not bad, bad

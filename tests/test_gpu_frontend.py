@@ -119,7 +119,7 @@ def test_clip_adam_matches_oracle(dev):
         call("sehip_grad_sumsq", ptr(gdev), n, ptr(sumsq), stream())
         call("sehip_opt_step", ptr(p), ptr(gdev), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 3e-4, 0.9, 0.999, 1e-8, step, 0.0,
              0, stream())
-        call("sehip_grad_metric", ptr(gdev), ptr(offs_d), len(sizes), ptr(sumsq), ptr(tsum), ptr(metric), stream())
+        call("sehip_grad_metric", ptr(gdev), ptr(offs_d), len(sizes), max(sizes), ptr(sumsq), ptr(tsum), ptr(metric), stream())
         assert abs(float(metric[1]) - float(total)) < 1e-4 * float(total)
         assert abs(float(metric[0]) - want_metric) < 1e-3 * max(1.0, want_metric)
         ref_p = torch.cat([params[str(i)] for i in range(len(sizes))])
