@@ -106,6 +106,12 @@ typedef struct {
     int32_t M, N, Npad, K;    /* K multiple of 64, Npad multiple of 16 */
     int32_t TT, J, fmul;
     int32_t pad_;
+    /* Optional: the product is a regular convolution over (frame, row) -- K ordered (kt, tap, source, channel),
+     * kt in {0,1}, taps at rows j*fmul + cv_fadd + 0..cv_nf-1, frame offsets cv_toff[source][kt].  Lets the library
+     * stage each input element once per tile in LDS instead of once per tap.  cv_nf == 0: not described. */
+    int32_t cv_nf, cv_fadd;
+    int32_t cv_toff[2][2];
+    int32_t cv_pad_[2];
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);

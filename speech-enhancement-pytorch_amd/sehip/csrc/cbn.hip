@@ -38,7 +38,6 @@ template <int NS>
 __device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr, float* __restrict__ part, int stride,
                                                float* lds /* 256 floats */) {
     const int tid = threadIdx.x;
-    const int groups = 256 / nq;  // threads per chunk column
     float* out = part + (size_t)blockIdx.x * stride;
 #pragma unroll
     for (int a = 0; a < NS; ++a)
@@ -52,8 +51,7 @@ __device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr
             __syncthreads();
             if (tid < nq) {
                 float t = 0.f;
-                const int nw = groups >= 4 ? 4 : 4;  // 4 waves always
-                for (int w = 0; w < nw; ++w) t += lds[w * nq + tid];
+                for (int w = 0; w < 4; ++w) t += lds[w * nq + tid];
                 out[(size_t)a * Cr + tid * 8 + j] = t;
             }
         }
@@ -357,7 +355,7 @@ static int grid_for(long work_items) {
 static int stat_blocks(long rows, int Cr) {
     const int rpb = 256 / (Cr >> 3);
     long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
-    if (g > 1024) g = 1024;
+    if (g > 256) g = 256;
     if (g < 1) g = 1;
     return (int)g;
 }

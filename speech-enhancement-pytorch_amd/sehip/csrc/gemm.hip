@@ -13,6 +13,7 @@
 //   writes), register-staged prefetch of the next K tile while the MFMAs of the current one run.
 // wgrad_kernel  dW[n][k] += sum_m dOut[m][n] A[m][k]  (split over m, fp32 atomics)
 //   both operands are staged row-major in m and fed to the MFMA through ds_read_b64_tr_b16 transposed reads.
+#include <stdlib.h>
 #include "common.h"
 #include "../../../include/sehip.h"
 
@@ -73,6 +74,54 @@ __device__ __forceinline__ size_t dst_row_offset(const sehip_dst& d, const RowPo
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int N>
+struct RegTile { uint4 v[N]; };
+
+// Scatter of one lane's 4 consecutive output channels (shared by both product kernels).
+__device__ __forceinline__ void store_out4(const sehip_gemm_desc& d, const sehip_nchunk nc, f32x4 v, size_t ro0, size_t ro1,
+                                           int n) {
+    if (d.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(d.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    const size_t off = (nc.dst ? ro1 : ro0) + nc.coff;
+    void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
+    const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+    if (is_f32) {
+        float* p = reinterpret_cast<float*>(dptr) + off;
+        if (nc.nvalid == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int q = 0; q < nc.nvalid; ++q) p[q] = v[q];
+    } else {
+        bf16_raw* p = reinterpret_cast<bf16_raw*>(dptr) + off;
+        if (nc.nvalid == 4) *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        else
+            for (int q = 0; q < nc.nvalid; ++q) p[q] = f2bf(v[q]);
+    }
+}
+
+template <int NRA>
+__device__ __forceinline__ RegTile<NRA> fetch_a_tile(const sehip_gemm_desc& d, int kt, int kc, const RowPos (&rp)[NRA],
+                                                     const long (&rb0)[NRA], const long (&rb1)[NRA]) {
+    RegTile<NRA> t;
+    const sehip_kchunk e = d.ktab[kt * 8 + kc];
+#pragma unroll
+    for (int i = 0; i < NRA; ++i) t.v[i] = gather_chunk(d.src[0], d.src[1], e, rp[i], rb0[i], rb1[i]);
+    return t;
+}
+
+template <int NRW, int BN>
+__device__ __forceinline__ RegTile<NRW> fetch_w_tile(const bf16_raw* Wb, int K, int n0, int r0, int kcol) {
+    RegTile<NRW> t;
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        const int row = r0 + 32 * i;
+        t.v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (row < BN) t.v[i] = *reinterpret_cast<const uint4*>(Wb + (size_t)(n0 + row) * K + kcol);
+    }
+    return t;
+}
+
 template <int BN, int BM, int WN, int WM>
 __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
     constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
@@ -83,7 +132,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give every XCD a contiguous range of
+    // the (m-tile, n-tile) space with the n-tiles of one m-tile adjacent, so the gathered activation rows (shared by
+    // all n-tiles and, through the conv halo, by neighbouring m-tiles) are re-read from that XCD's L2.
+    const int ntn = d.Npad / BN;
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
 
     const int kc = tid & 7, r0 = tid >> 3;
     RowPos rp[NRA];
@@ -97,19 +154,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
 
     const int nk = d.K >> 6;
     const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
-    uint4 ra[NRA], rw[NRW];
-
-    auto issue = [&](int kt) {
-        const sehip_kchunk e = d.ktab[kt * 8 + kc];
-#pragma unroll
-        for (int i = 0; i < NRA; ++i) ra[i] = gather_chunk(d.src[0], d.src[1], e, rp[i], rb0[i], rb1[i]);
-#pragma unroll
-        for (int i = 0; i < NRW; ++i) {
-            const int rw_row = r0 + 32 * i;
-            if (rw_row < BN)
-                rw[i] = *reinterpret_cast<const uint4*>(Wb + (size_t)(n0 + rw_row) * d.K + kt * 64 + kc * 8);
-        }
-    };
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -117,20 +161,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
+    RegTile<NRA> ra = fetch_a_tile<NRA>(d, 0, kc, rp, rb0, rb1);
+    RegTile<NRW> rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, kc * 8);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
             const int r = r0 + 32 * i;
-            sA[r * 8 + (kc ^ (r & 7))] = ra[i];
+            sA[r * 8 + (kc ^ (r & 7))] = ra.v[i];
         }
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
             const int r = r0 + 32 * i;
-            if (r < BN) sW[r * 8 + (kc ^ (r & 7))] = rw[i];
+            if (r < BN) sW[r * 8 + (kc ^ (r & 7))] = rw.v[i];
         }
         __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1);
+        if (kt + 1 < nk) {  // next K tile in flight behind this tile's MFMAs
+            ra = fetch_a_tile<NRA>(d, kt + 1, kc, rp, rb0, rb1);
+            rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, (kt + 1) * 64 + kc * 8);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + (lane >> 4);
@@ -167,26 +215,211 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
             const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * (lane >> 4);
             const sehip_nchunk nc = d.ntab[n >> 2];
             if (nc.nvalid <= 0) continue;
-            f32x4 v = acc[ni][mi];
-            if (d.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(d.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            const sehip_dst& ds = nc.dst ? d.dst[1] : d.dst[0];
-            const size_t off = (nc.dst ? ro1 : ro0) + nc.coff;
-            if (ds.is_f32) {
-                float* p = reinterpret_cast<float*>(ds.ptr) + off;
-                if (nc.nvalid == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int q = 0; q < nc.nvalid; ++q) p[q] = v[q];
-            } else {
-                bf16_raw* p = reinterpret_cast<bf16_raw*>(ds.ptr) + off;
-                if (nc.nvalid == 4) *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                else
-                    for (int q = 0; q < nc.nvalid; ++q) p[q] = f2bf(v[q]);
-            }
+            store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_kernel: same product for descriptors that carry the regular-convolution description (cv_*).
+// The generic kernel re-gathers every input element once per tap from L2/HBM (10x for a 5x2 kernel) and that
+// stream, not the MFMA, bounds it.  Here a workgroup owns 128 output rows = TB frames x JB rows of ONE utterance
+// and, per 64-channel chunk, stages the input PATCH ((TB+1) frames x ((JB-1)*fmul+NF) rows x 64 ch) in LDS once;
+// all 2*NF taps read their MFMA operand fragments straight from that patch (row pitch 144 B).  Only the weight
+// tile is staged per K step.  The next patch chunk is prefetched into registers a few 16-byte pieces per K step.
+// ------------------------------------------------------------------------------------------------
+#define CV_PITCH 72   // bf16 elements per patch row (64 + 8 pad)
+#define CV_MAXP 12    // 16-byte patch pieces per thread (patch <= 48 KB)
+
+template <int BN, int WN, int WM, int NF>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d, int TB, int JB, int FR) {
+    constexpr int BM = 128;
+    constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
+    constexpr int NRW = BN / 32;
+    constexpr int NIT = 2 * NF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* sW = reinterpret_cast<uint4*>(smem);
+    bf16_raw* patch = reinterpret_cast<bf16_raw*>(sW + BN * 8);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const int ntn = d.Npad / BN;
+    const int tblocks = (d.TT + TB - 1) / TB, jblocks = d.J / JB;
+    // XCD-contiguous order, n-tile fastest (see gemm_kernel)
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = logical % ntn;
+    int rest = logical / ntn;
+    const int jb = rest % jblocks; rest /= jblocks;
+    const int tb = rest % tblocks;
+    const int b = rest / tblocks;
+    const int t0 = tb * TB, j0 = jb * JB, n0 = nt * BN;
+    const int f0 = j0 * d.fmul + d.cv_fadd;
+
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int Ctot = C0 + C1;
+    const int ncc = Ctot >> 6;
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const int NP = (TB + 1) * FR * 8;
+
+    auto fetch_piece = [&](int cc, int i) -> uint4 {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const int idx = tid + 256 * i;
+        if (idx < NP) {
+            const int p = idx / (FR * 8), rem = idx - p * (FR * 8);
+            const int r = rem >> 3, c8 = rem & 7;
+            const bool second = cc * 64 >= C0;
+            const int sT = second ? d.src[1].T : d.src[0].T, sF = second ? d.src[1].F : d.src[0].F;
+            const int sC = second ? C1 : C0;
+            const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+            const bf16_raw* base = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr);
+            const int ts = t0 + p + (second ? tmin1 : tmin0);
+            const int f = f0 + r;
+            if (ts >= tlo && ts < thi && f >= 0 && f < sF) {
+                const bf16_raw* g = base + ((((long)b * sT + ts) * sF + f) * sC + (cc * 64 - (second ? C0 : 0)) + c8 * 8);
+                v = *reinterpret_cast<const uint4*>(g);
+            }
+        }
+        return v;
+    };
+    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
+    const int kc = tid & 7, r0 = tid >> 3;
+
+    // per-lane patch offsets of its TM activation rows (element units, k-chunk of the lane included)
+    int abase[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * (BM / WM) + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        abase[mi] = (tl * FR + jl * d.fmul) * CV_PITCH + 8 * (lane >> 4);
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    RegTile<NRW> rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, kc * 8);
+
+    for (int cc = 0; cc < ncc; ++cc) {
+        // stage the patch of this channel chunk (all reads of the previous one ended at the last barrier); the second
+        // workgroup resident on the CU computes meanwhile
+#pragma unroll
+        for (int i0 = 0; i0 < CV_MAXP; i0 += 4) {
+            uint4 pr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pr[q] = fetch_piece(cc, i0 + q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * (i0 + q);
+                if (idx < NP) {
+                    const int p = idx / (FR * 8), rem = idx - p * (FR * 8);
+                    *reinterpret_cast<uint4*>(&patch[(p * FR + (rem >> 3)) * CV_PITCH + (rem & 7) * 8]) = pr[q];
+                }
+            }
+        }
+        const bool second = cc * 64 >= C0;
+        const int dt0 = (second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0);
+        const int dt1 = (second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) {
+                const int r = r0 + 32 * i;
+                sW[r * 8 + (kc ^ (r & 7))] = rw.v[i];
+            }
+            __syncthreads();
+            // next weight tile goes in flight behind this step's MFMAs
+            if (it + 1 < NIT) rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, (it + 1) * Ctot + cc * 64 + kc * 8);
+            else if (cc + 1 < ncc) rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, (cc + 1) * 64 + kc * 8);
+            const int kt = it / NF, tap = it - kt * NF;
+            const int toff_e = ((kt ? dt1 : dt0) * FR + tap) * CV_PITCH;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = ks * 4 + (lane >> 4);
+                bf16x8 wf[TN], af[TM];
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int r = wn * (BN / WN) + ni * 16 + (lane & 15);
+                    wf[ni] = __builtin_bit_cast(bf16x8, sW[r * 8 + (c ^ (r & 7))]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + toff_e + 32 * ks]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue (same scatter as gemm_kernel)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int rr = wm * (BM / WM) + mi * 16 + (lane & 15);
+        const int tl = rr / JB, jl = rr - tl * JB;
+        RowPos r;
+        r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
+        if (!r.valid) continue;
+        const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
+        const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * (lane >> 4);
+            const sehip_nchunk nc = d.ntab[n >> 2];
+            if (nc.nvalid <= 0) continue;
+            store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
+        }
+    }
+}
+
+template <int BN, int WN, int WM>
+static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int grid, size_t lds, hipStream_t st) {
+#define CV_CASE(NF_)                                                                                                  \
+    case NF_: {                                                                                                       \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BN, WN, WM, NF_>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        conv_gemm_kernel<BN, WN, WM, NF_><<<grid, 256, lds, st>>>(d, TB, JB, FR);                                     \
+        return 1;                                                                                                     \
+    }
+    switch (d.cv_nf) {
+        CV_CASE(2)
+        CV_CASE(3)
+        CV_CASE(5)
+        default: return 0;
+    }
+#undef CV_CASE
+}
+
+// returns 1 if the LDS-patch kernel was launched, 0 if the descriptor does not qualify
+static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr;
+    if (disabled || d.cv_nf <= 0) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.J > 64 || (128 % d.J)) return 0;
+    if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
+    const int JB = d.J, TB = 128 / JB;
+    const int FR = (JB - 1) * d.fmul + d.cv_nf;
+    const size_t patch_bytes = (size_t)(TB + 1) * FR * CV_PITCH * 2;
+    if ((TB + 1) * FR * 8 > CV_MAXP * 256) return 0;
+    const int B = d.M / (d.TT * d.J);
+    const int tblocks = (d.TT + TB - 1) / TB;
+    if ((d.Npad & 127) == 0) {
+        const int grid = B * tblocks * (d.Npad / 128);
+        return launch_conv<128, 2, 2>(d, TB, JB, FR, grid, 128 * 128 + patch_bytes, st);
+    }
+    const int grid = B * tblocks * (d.Npad / 64);
+    return launch_conv<64, 1, 4>(d, TB, JB, FR, grid, 64 * 128 + patch_bytes, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,25 +455,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
     float colsum = 0.f;
     const bool do_bias = d.dbias != nullptr && blockIdx.y == 0;
 
-    for (int mb = m_begin; mb < m_end; mb += 64) {
-        // ---- stage A chunks: 64 rows x 8 chunks
+    uint4 xa[2], ga[GPT];
+    auto fetch = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = r0 + 32 * i;
-            const int m = mb + r;
+            const int m = mb + r0 + 32 * i;
             RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul);
-            const uint4 v = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
-            *reinterpret_cast<uint4*>(&sX[r * PX + kc * 8]) = v;
+            xa[i] = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
         }
-        // ---- stage dOut chunks: 64 rows x GCH chunks
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int id = tid + 256 * i;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (id < 64 * GCH) {
                 const int r = id / GCH, gc = id - r * GCH;
                 const int m = mb + r;
                 RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul);
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (rp.valid) {
                     const int n = n0 + gc * 8;
                     const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
@@ -262,10 +492,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
                                        tmp[4] | ((unsigned)tmp[5] << 16), tmp[6] | ((unsigned)tmp[7] << 16));
                     }
                 }
-                *reinterpret_cast<uint4*>(&sG[r * PG + gc * 8]) = v;
+            }
+            ga[i] = v;
+        }
+    };
+    fetch(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += 64) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(&sX[(r0 + 32 * i) * PX + kc * 8]) = xa[i];
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int id = tid + 256 * i;
+            if (id < 64 * GCH) {
+                const int r = id / GCH, gc = id - r * GCH;
+                *reinterpret_cast<uint4*>(&sG[r * PG + gc * 8]) = ga[i];
             }
         }
         __syncthreads();
+        if (mb + 64 < m_end) fetch(mb + 64);  // next slab in flight while this one is multiplied
         if (do_bias && tid < BNW) {
             float s = 0.f;
 #pragma unroll 8
@@ -337,15 +581,19 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("gemm", d)) return e;
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
+    if (try_conv_gemm(*d, st)) {
+        SEHIP_CHECK_LAUNCH("gemm(conv)");
+        return 0;
+    }
     if (d->Npad == 16) {
-        gemm_kernel<16, 256, 1, 4><<<dim3(cdiv(d->M, 256), 1), 256, 0, st>>>(*d);
+        gemm_kernel<16, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
     } else if (d->Npad == 32) {
-        gemm_kernel<32, 256, 1, 4><<<dim3(cdiv(d->M, 256), 1), 256, 0, st>>>(*d);
+        gemm_kernel<32, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
     } else if (d->Npad == 64) {
-        gemm_kernel<64, 256, 1, 4><<<dim3(cdiv(d->M, 256), 1), 256, 0, st>>>(*d);
+        gemm_kernel<64, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
     } else {
         SEHIP_REQUIRE(d->Npad % 128 == 0, "gemm: Npad=%d must be 16, 32, 64 or a multiple of 128", d->Npad);
-        gemm_kernel<128, 128, 2, 2><<<dim3(cdiv(d->M, 128), d->Npad / 128), 256, 0, st>>>(*d);
+        gemm_kernel<128, 128, 2, 2><<<cdiv(d->M, 128) * (d->Npad / 128), 256, 0, st>>>(*d);
     }
     SEHIP_CHECK_LAUNCH("gemm");
     return 0;

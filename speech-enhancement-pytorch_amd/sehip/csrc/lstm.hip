@@ -23,8 +23,9 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the cell update sits on the serial path
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ pre0, const float* __restrict__ pre1,
                                                        const bf16_raw* __restrict__ whh, int B, int T,

@@ -41,7 +41,8 @@ class CGemmDesc(C.Structure):
     _fields_ = [("src", CSrc * 4), ("dst", CDst * 2), ("ktab", C.c_void_p), ("ntab", C.c_void_p), ("W", C.c_void_p),
                 ("bias", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32),
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("pad_", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
+                ("cv_pad_", C.c_int32 * 2)]
 
 
 def npad_of(n):
@@ -264,8 +265,9 @@ def pad_ktab(rows):
 class GemmSpec:
     """Batch-independent description of one product (see sehip_gemm_desc)."""
 
-    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd"):
+    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd", conv=None):
         self.name = name
+        self.conv = conv  # (nf, fadd, [[toff(s0,kt0), toff(s0,kt1)], [toff(s1,kt0), toff(s1,kt1)]]) or None
         self.ktab, self.K = pad_ktab(rows)
         self.N = n
         self.Npad = npad_of(n)
@@ -329,7 +331,8 @@ class DCCRNStatic:
                             widx[:, kt * 16 + kf * 2 + c] = full[:, c, kf, kt]
                             wneg[:, kt * 16 + kf * 2 + c] = neg[:, c, kf, kt]
             self.specs[f"enc{i}.fwd"] = GemmSpec(f"enc{i}.fwd", rows, widx, wneg, co, eff_bias(pre, co // 2), "T",
-                                                  self.F0 >> (i + 1), 2, [(src, "all")], [(f"y{i}", 0, 1, 0)])
+                                                  self.F0 >> (i + 1), 2, [(src, "all")], [(f"y{i}", 0, 1, 0)],
+                                                  conv=(5, -2, [[-1, 0], [0, 0]]) if ci >= 8 else None)
             self.bn.append((pre, co // 2))
             if i >= 1:
                 # dgrad by output-row parity: dX[b,t,2j+p,ci] = sum dY[b,t+1-kt,j+d,co] * full[co,ci,kf,kt], kf = p+2-2d
@@ -348,7 +351,8 @@ class DCCRNStatic:
                             wn[:, kt, q, :] = neg[:, :, kf, kt].T
                     self.specs[f"enc{i}.dg{p}"] = GemmSpec(f"enc{i}.dg{p}", rows, w.reshape(ci, -1), wn.reshape(ci, -1), ci,
                                                            None, "T", self.F0 >> (i + 1), 1, [(f"dye{i}", "all")],
-                                                           [(f"dz{i - 1}", 0, 2, p)], kind="dgrad")
+                                                           [(f"dz{i - 1}", 0, 2, p)], kind="dgrad",
+                                                           conv=(len(ds), ds[0], [[1, 0], [0, 0]]))
 
         # ---------------- decoder ----------------
         for j in range(6):
@@ -388,8 +392,11 @@ class DCCRNStatic:
                     nt = None
                     dst = [(f"yd{j}", 0, 2, p)]
                     tt = "T+1"
+                bt = 1 if last else 0
                 self.specs[f"dec{j}.fwd{p}"] = GemmSpec(f"dec{j}.fwd{p}", rows, widx, wneg, co, eff_bias(pre, co // 2), tt,
-                                                        f_in, 1, [(s1, s1_mode), (s2, "all")], dst, ntab=nt)
+                                                        f_in, 1, [(s1, s1_mode), (s2, "all")], dst, ntab=nt,
+                                                        conv=(len(ds), ds[0], [[bt + (0 if j == 0 else 1), bt - 1 + (0 if j == 0 else 1)],
+                                                                               [bt, bt - 1]]))
             if not last:
                 self.bn.append((pre, co // 2))
             # dgrad: dIn[b,t,fi,(s,c)] = sum dOut'[b,t+kt,2fi-2+kf,co] * full[cin,co,kf,kt]
@@ -415,7 +422,8 @@ class DCCRNStatic:
             nt = np.concatenate([dense_ntab(c1, c1, 0, 0), dense_ntab(c2, c2, 1, 0)])
             assert npad_of(c1 + c2) == c1 + c2
             self.specs[f"dec{j}.dg"] = GemmSpec(f"dec{j}.dg", rows, w[order], wn[order], c1 + c2, None, "T", f_in, 2,
-                                                [(gsrc, "all")], [d1, (f"dskip{5 - j}", 0, 1, 0)], ntab=nt, kind="dgrad")
+                                                [(gsrc, "all")], [d1, (f"dskip{5 - j}", 0, 1, 0)], ntab=nt, kind="dgrad",
+                                                conv=(5, -2, [[0, 1], [0, 0]]) if co >= 8 else None)
 
         # ---------------- complex LSTM ----------------
         c5 = kn[6]
@@ -697,6 +705,11 @@ class DCCRNWorkspace:
                 d.bias = tb.bpack.data_ptr() + 4 * s.b_off
             d.M, d.N, d.Npad, d.K = B * tt * s.J, s.N, s.Npad, s.K
             d.TT, d.J, d.fmul = tt, s.J, s.fmul
+            if s.conv is not None:
+                d.cv_nf, d.cv_fadd = s.conv[0], s.conv[1]
+                for q in range(2):
+                    for kt in range(2):
+                        d.cv_toff[q][kt] = s.conv[2][q][kt]
             self.desc[name] = d
             if s.dw_off is not None:  # weight-gradient twin: dOut replaces the destination
                 w = CGemmDesc.from_buffer_copy(d)

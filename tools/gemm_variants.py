@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""A/B of gemm launch variants in ONE process (SEHIP_GEMM_FLAGS is read once per process, so each variant runs in a
+child process on the same device, interleaved)."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    sys.path.insert(0, os.path.join(ROOT, "speech-enhancement-pytorch_amd")); sys.path.insert(0, ROOT)
+    import torch, ctypes as C
+    from sehip.model import DCCRN
+    from sehip._lib import call, stream
+    names = sys.argv[2:]
+    dev = torch.device("cuda:0"); torch.manual_seed(0)
+    model = DCCRN(length=32000).to(dev).train()
+    x = (0.1 * torch.randn(32, 1, 32000)).to(dev)
+    out = model(x); out.backward(torch.randn_like(out) * 1e-3); torch.cuda.synchronize()
+    ws = model.workspace(32, 32000)
+    res = {}
+    for name in names:
+        fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
+        d = ws.desc[name]
+        for _ in range(3): call(fn, C.byref(d), stream())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): call(fn, C.byref(d), stream())
+        e1.record(); torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 20
+    print("RES " + json.dumps(res))
+else:
+    names = ["dec1.dg", "dec0.fwd0", "dec1.fwd0", "enc5.fwd", "enc3.fwd", "dec3.fwd0", "enc2.dg0", "ih1_r", "dec4.dg", "dec0.fwd0.wg", "enc4.fwd.wg"]
+    for flags in sys.argv[1:]:
+        env = dict(os.environ)
+        if flags == "nopatch":
+            env["SEHIP_NO_PATCH"] = "1"
+        r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RES ")]
+        print(flags, {k: round(v * 1e3) for k, v in json.loads(line[0][4:]).items()} if line else r.stderr[-500:])
