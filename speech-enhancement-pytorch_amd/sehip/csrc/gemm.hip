@@ -385,7 +385,7 @@ static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int gri
     case NF_: {                                                                                                       \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BN, WN, WM, NF_>),                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BN, WN, WM, NF_>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
             attr_set = true;                                                                                          \
         }                                                                                                             \
@@ -599,11 +599,209 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad_kernel: weight gradient for descriptors with the regular-convolution description.
+// A workgroup owns 64 output channels (n) x ONE 64-channel input chunk x ALL 2*NF taps and walks over 128-row
+// m-tiles: per tile it stages the input patch and the dOut tile [128 m][64 n] in LDS once and every tap reuses them
+// (the generic wgrad_kernel re-reads dOut once per 64 k-columns and the inputs once per tap).  Wave w accumulates
+// dW[64 n][taps][16 channels (16w..)] in registers: 4 x 2NF MFMA tiles; both operands come from transposed LDS reads.
+// ------------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
+    constexpr int NIT = 2 * NF;
+    constexpr int GP = 72;  // pitch of the dOut tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_raw* sG = reinterpret_cast<bf16_raw*>(smem);  // [128][GP]
+    bf16_raw* patch = sG + 128 * GP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = wv & 3, nh = wv >> 2;  // wave -> 16-channel subtile w, 32-wide half nh of the 64 output channels
+    const int ntn = d.Npad >> 6;
+    const int nt = blockIdx.x % ntn, cc = blockIdx.x / ntn;
+    const int n0 = nt * 64;
+    const int tblocks = (d.TT + TB - 1) / TB;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * tblocks;
+    const int mt_begin = blockIdx.y * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int Ctot = C0 + C1;
+    const bool second = cc * 64 >= C0;
+    const int sT = second ? d.src[1].T : d.src[0].T, sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+    const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+    const bf16_raw* sbase = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) + (cc * 64 - (second ? C0 : 0));
+    const int tmin = second ? min(d.cv_toff[1][0], d.cv_toff[1][1]) : min(d.cv_toff[0][0], d.cv_toff[0][1]);
+    const int dt0 = (second ? d.cv_toff[1][0] : d.cv_toff[0][0]) - tmin, dt1 = (second ? d.cv_toff[1][1] : d.cv_toff[0][1]) - tmin;
+    const int NP = (TB + 1) * FR * 8;
+    const int f0 = d.cv_fadd;  // JB == J: the tile starts at row 0
+
+    // transposed-read addresses: lane supplies row (8g + q [+4]) of each 32-row k-step, columns 4p..4p+3
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = 4 * (i16 & 3);
+    int pbase[4][2], gbase[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ks * 32 + 8 * g + q + 4 * h;
+            const int tl = m / JB, jl = m - tl * JB;
+            pbase[ks][h] = (tl * FR + jl * d.fmul) * CV_PITCH + 16 * w + p4;
+            gbase[ks][h] = m * GP + p4 + 32 * nh;
+        }
+
+    f32x4 acc[2][NIT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.f;
+    const bool do_bias = d.dbias != nullptr && cc == 0;
+
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        const int b = mt / tblocks, t0 = (mt - b * tblocks) * TB;
+        // ---- stage the input patch chunk
+#pragma unroll
+        for (int i0 = 0; i0 < CV_MAXP / 2; i0 += 3) {
+            uint4 pr[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                pr[u] = make_uint4(0u, 0u, 0u, 0u);
+                const int idx = tid + 512 * (i0 + u);
+                if (idx < NP) {
+                    const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
+                    const int ts = t0 + pp + tmin, f = f0 + (rem >> 3);
+                    if (ts >= tlo && ts < thi && f >= 0 && f < sF)
+                        pr[u] = *reinterpret_cast<const uint4*>(sbase + (((long)b * sT + ts) * sF + f) * sC + (rem & 7) * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int idx = tid + 512 * (i0 + u);
+                if (idx < NP) {
+                    const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
+                    *reinterpret_cast<uint4*>(&patch[(pp * FR + (rem >> 3)) * CV_PITCH + (rem & 7) * 8]) = pr[u];
+                }
+            }
+        }
+        // ---- stage the dOut tile: 128 rows x 8 chunks
+        {
+            uint4 gr[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 512 * u;
+                const int r = idx >> 3, gc = idx & 7;
+                const int tl = r / JB, jl = r - tl * JB;
+                RowPos rp;
+                rp.b = b; rp.t = t0 + tl; rp.jf = jl * d.fmul; rp.valid = rp.t < d.TT;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (rp.valid) {
+                    const int n = n0 + gc * 8;
+                    const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
+                    if (c0.nvalid == 4 && c1.nvalid == 4 && c1.dst == c0.dst && c1.coff == c0.coff + 4) {
+                        const bf16_raw* gp = reinterpret_cast<const bf16_raw*>(c0.dst ? d.dst[1].ptr : d.dst[0].ptr) +
+                                             (c0.dst ? dst_row_offset(d.dst[1], rp, d.fmul) : dst_row_offset(d.dst[0], rp, d.fmul)) + c0.coff;
+                        v = *reinterpret_cast<const uint4*>(gp);
+                    }
+                }
+                gr[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 512 * u;
+                *reinterpret_cast<uint4*>(&sG[(idx >> 3) * GP + (idx & 7) * 8]) = gr[u];
+            }
+        }
+        __syncthreads();
+        if (do_bias && tid < 64) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 128; ++r) sacc += bf2f(sG[r * GP + tid]);
+            colsum += sacc;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 gf[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][0] + ni * 16]);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][1] + ni * 16]);
+                gf[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int toff_e = ((it < NF ? dt0 : dt1) * FR + (it < NF ? it : it - NF)) * CV_PITCH;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][0] + toff_e]);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][1] + toff_e]);
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[ni][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], xf, acc[ni][it], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // D rows = n (4*(lane>>4)+u), cols = channel (lane&15)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = n0 + 32 * nh + ni * 16 + 4 * (lane >> 4);
+            const int k = it * Ctot + cc * 64 + 16 * w + (lane & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][it][u]);
+        }
+    if (do_bias && tid < 64) atomicAdd(&d.dbias[n0 + tid], colsum);
+}
+
+static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr;
+    if (disabled || d.cv_nf <= 0) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.J > 64 || (128 % d.J)) return 0;
+    if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
+    // the dOut tile loader handles dense 8-column groups only
+    const int JB = d.J, TB = 128 / JB;
+    const int FR = (JB - 1) * d.fmul + d.cv_nf;
+    if ((TB + 1) * FR * 8 > CV_MAXP * 256) return 0;
+    const size_t lds = (size_t)128 * 72 * 2 + (size_t)(TB + 1) * FR * CV_PITCH * 2;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * ((d.TT + TB - 1) / TB);
+    const int gx = (d.Npad >> 6) * ((C0 + C1) >> 6);
+    int splits = 512 / gx;
+    if (splits < 1) splits = 1;
+    if (splits > MT) splits = MT;
+    const int tiles_per_wg = (MT + splits - 1) / splits;
+    splits = (MT + tiles_per_wg - 1) / tiles_per_wg;
+    dim3 grid(gx, splits);
+#define CW_CASE(NF_)                                                                                              \
+    case NF_: {                                                                                                   \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NF_>),                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        conv_wgrad_kernel<NF_><<<grid, 512, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                              \
+        return 1;                                                                                                 \
+    }
+    switch (d.cv_nf) {
+        CW_CASE(2)
+        CW_CASE(3)
+        CW_CASE(5)
+        default: return 0;
+    }
+#undef CW_CASE
+}
+
 extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("wgrad", d)) return e;
     SEHIP_REQUIRE(d->dW != nullptr, "wgrad: missing dW");
     SEHIP_REQUIRE(!d->dst[0].is_f32 && !(d->dst[1].ptr && d->dst[1].is_f32), "wgrad: dOut must be bf16");
     hipStream_t st = (hipStream_t)stream;
+    if (try_conv_wgrad(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(conv)");
+        return 0;
+    }
     const int ktiles = d->K / 64;
     int ntiles, bnw;
     if (d->Npad == 16) bnw = 16; else if (d->Npad == 32) bnw = 32; else if (d->Npad == 64) bnw = 64; else bnw = 128;
