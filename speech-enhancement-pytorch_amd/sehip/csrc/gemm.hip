@@ -423,6 +423,194 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small-channel layers (<= 64 output channels, <= 128 concatenated input channels: the outer encoder/decoder
+// layers, HBM-bound).  The whole packed weight [BN][K] lives in LDS for the lifetime of the workgroup, which
+// walks over 128-row m-tiles: stage the input patch (every element read once), then run all K/32 MFMA steps
+// straight from LDS -- no per-step staging and no barrier inside the K loop.
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void conv_small_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
+    constexpr int TN = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int CT = C0 + C1;
+    const int NIT = 2 * d.cv_nf;
+    const int KR = NIT * CT;          // real K
+    const int KP = d.K + 8;           // LDS pitch of a weight row
+    const int PP = CT + 8;            // LDS pitch of a patch row
+    bf16_raw* sW = reinterpret_cast<bf16_raw*>(smem);
+    bf16_raw* patch = sW + BN * KP;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4;
+    // weights -> LDS (once)
+    {
+        const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
+        const int cpr = d.K >> 3;
+        for (int idx = tid; idx < BN * cpr; idx += 256) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            *reinterpret_cast<uint4*>(&sW[r * KP + c * 8]) = *reinterpret_cast<const uint4*>(Wb + (size_t)r * d.K + c * 8);
+        }
+    }
+    const int tblocks = (d.TT + TB - 1) / TB, jblocks = d.J / JB;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * tblocks * jblocks;
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const int cp8 = CT >> 3;
+    const int NP = (TB + 1) * FR * cp8;
+
+    // per-lane constants of the two 16-row activation tiles of this wave
+    int abase[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = 32 * w + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        abase[mi] = (tl * FR + jl * d.fmul) * PP;
+    }
+    const int ksteps = KR >> 5;
+    const int nf = d.cv_nf;
+    const int lgct = 31 - __clz(CT);
+
+    // tile-invariant description of the patch pieces this thread stages: LDS offset, global offset relative to the
+    // tile's first frame, patch frame (or -1 when the piece does not exist / its row is outside the source)
+    constexpr int MAXPC = 12;
+    int p_lds[MAXPC], p_g[MAXPC], p_pp[MAXPC];
+    const int f0c = d.cv_fadd;  // JB == J: tiles start at row 0
+#pragma unroll
+    for (int u = 0; u < MAXPC; ++u) {
+        const int idx = tid + 256 * u;
+        p_pp[u] = -1; p_lds[u] = 0; p_g[u] = 0;
+        if (idx < NP) {
+            const int pp = idx / (FR * cp8), rem = idx - pp * (FR * cp8);
+            const int r = rem / cp8, c8 = rem - r * cp8;
+            const bool second = c8 * 8 >= C0;
+            const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+            const int f = f0c + r;
+            p_lds[u] = (pp * FR + r) * PP + c8 * 8;
+            if (f >= 0 && f < sF) {
+                p_pp[u] = pp | (second ? 0x10000 : 0);
+                p_g[u] = (pp * sF + f) * sC + (c8 * 8 - (second ? C0 : 0));
+            }
+        }
+    }
+
+    const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        int rest = mt;
+        const int jb = rest % jblocks; rest /= jblocks;
+        const int tb = rest % tblocks;
+        const int b = rest / tblocks;
+        const int t0 = tb * TB, j0 = jb * JB;
+        __syncthreads();  // previous tile's reads of the patch are done (also orders the weight fill)
+#pragma unroll
+        for (int u0 = 0; u0 < MAXPC; u0 += 4) {
+            if (u0 * 256 >= NP) break;
+            uint4 pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pr[u] = make_uint4(0u, 0u, 0u, 0u);
+                const int e = p_pp[u0 + u];
+                if (e >= 0) {
+                    const bool second = (e & 0x10000) != 0;
+                    const int ts = t0 + (e & 0xffff) + (second ? tmin1 : tmin0);
+                    const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+                    if (ts >= tlo && ts < thi) {
+                        const bf16_raw* base = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr);
+                        const long frame0 = ((long)b * (second ? d.src[1].T : d.src[0].T) + t0 + (second ? tmin1 : tmin0)) *
+                                            (second ? d.src[1].F : d.src[0].F) * (second ? C1 : C0);
+                        pr[u] = *reinterpret_cast<const uint4*>(base + frame0 + p_g[u0 + u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (tid + 256 * (u0 + u) < NP) *reinterpret_cast<uint4*>(&patch[p_lds[u0 + u]]) = pr[u];
+        }
+        __syncthreads();
+
+        f32x4 acc[TN][2];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int s = 0; s < ksteps; ++s) {
+            const int k = 32 * s + 8 * g;
+            const int it = k >> lgct, c = k & (CT - 1);
+            const bool second = c >= C0;
+            const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
+            const int dt = (second ? d.cv_toff[1][kt] - tmin1 : d.cv_toff[0][kt] - tmin0);
+            const int poff = (dt * FR + tap) * PP + c;
+            bf16x8 af[2], wf[TN];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[(ni * 16 + (lane & 15)) * KP + k]));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int rr = 32 * w + mi * 16 + (lane & 15);
+            const int tl = rr / JB, jl = rr - tl * JB;
+            RowPos r;
+            r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
+            if (!r.valid) continue;
+            const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
+            const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = ni * 16 + 4 * (lane >> 4);
+                const sehip_nchunk nc = d.ntab[n >> 2];
+                if (nc.nvalid <= 0) continue;
+                store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
+            }
+        }
+    }
+}
+
+static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_SMALL") != nullptr;
+    if (disabled || d.cv_nf <= 0) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int CT = C0 + C1;
+    if ((C0 & 7) || (C1 & 7) || CT > 128 || (CT & (CT - 1)) || d.Npad > 64 || CT < 16) return 0;
+    if (d.Npad == 64 && CT >= 32) return 0;  // measured: the generic tile kernel is faster there
+    if (d.J > 128 || (128 % d.J)) return 0;
+    const int KR = 2 * d.cv_nf * CT;
+    if ((128 / d.J + 1) * ((d.J - 1) * d.fmul + d.cv_nf) * (CT >> 3) > 12 * 256) return 0;
+    if ((KR & 31) || KR > d.K) return 0;
+    const int JB = d.J, TB = 128 / JB;
+    const int FR = (JB - 1) * d.fmul + d.cv_nf;
+    const size_t lds = (size_t)d.Npad * (d.K + 8) * 2 + (size_t)(TB + 1) * FR * (CT + 8) * 2;
+    if (lds > 120 * 1024) return 0;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * ((d.TT + TB - 1) / TB);
+    int wgs = lds > 64 * 1024 ? 256 : (lds > 40 * 1024 ? 512 : 1024);
+    if (wgs > MT) wgs = MT;
+    const int tiles_per_wg = (MT + wgs - 1) / wgs;
+    const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
+#define CS_CASE(BN_)                                                                                                \
+    {                                                                                                               \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<BN_>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);                      \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        conv_small_kernel<BN_><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                                \
+        return 1;                                                                                                   \
+    }
+    if (d.Npad == 16) CS_CASE(16)
+    if (d.Npad == 32) CS_CASE(32)
+    if (d.Npad == 64) CS_CASE(64)
+#undef CS_CASE
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: tile BNW (n) x 64 (k), m consumed 64 rows per step
 // ------------------------------------------------------------------------------------------------
 template <int BNW, int WNN, int WNK>
@@ -583,6 +771,10 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (try_conv_gemm(*d, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv)");
+        return 0;
+    }
+    if (try_conv_small(*d, st)) {
+        SEHIP_CHECK_LAUNCH("gemm(conv-small)");
         return 0;
     }
     if (d->Npad == 16) {

@@ -27,11 +27,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         res[name] = e0.elapsed_time(e1) / 20
     print("RES " + json.dumps(res))
 else:
-    names = ["dec1.dg", "dec0.fwd0", "dec1.fwd0", "enc5.fwd", "enc3.fwd", "dec3.fwd0", "enc2.dg0", "ih1_r", "dec4.dg", "dec0.fwd0.wg", "enc4.fwd.wg"]
+    names = ["dec1.dg", "dec0.fwd0", "enc5.fwd", "dec0.fwd0.wg", "enc4.fwd.wg", "enc1.fwd", "enc2.fwd", "enc1.dg0", "enc2.dg0", "dec3.fwd0", "dec4.fwd0", "dec5.fwd0", "dec4.dg", "enc0.fwd", "dec5.dg", "enc1.fwd.wg", "enc2.fwd.wg", "dec4.fwd0.wg", "dec3.fwd0.wg", "dec5.fwd0.wg", "enc0.fwd.wg"]
     for flags in sys.argv[1:]:
         env = dict(os.environ)
         if flags == "nopatch":
             env["SEHIP_NO_PATCH"] = "1"
+        if flags == "nosmall":
+            env["SEHIP_NO_SMALL"] = "1"
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RES ")]
         print(flags, {k: round(v * 1e3) for k, v in json.loads(line[0][4:]).items()} if line else r.stderr[-500:])
