@@ -120,6 +120,42 @@ int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
 /* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */
 int sehip_wgrad(const sehip_gemm_desc* desc, void* stream);
 
+/* ---- table-driven packing between the reference's parameter tensors (one flat fp32 buffer in state_dict order,
+ *      src/model/dccrn.py:62-137) and the GEMM-side layouts; entries are (index << 1) | negate, -1 = absent.
+ *      pack_bf16: out[i] = +-params[e]            (complex block weights [[Wr,-Wi],[Wi,Wr]], LSTM permutations)
+ *      pack_f32 : out[i] = +-params[e0] +- params[e1]   (ComplexConv2d's twice-signed bias src/model/dccrn.py:374-382,
+ *                                                        LSTM b_ih + b_hh)
+ *      unpack_grad: grads[j] = sum of up to 4 signed entries of the packed-gradient buffer. */
+int sehip_pack_bf16(const float* params, const int* table, long n, void* out_bf16, void* stream);
+int sehip_pack_f32(const float* params, const int* table2 /*[n][2]*/, long n, float* out, void* stream);
+int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n, float* grads, void* stream);
+
+/* ---- ComplexBatchNorm + PReLU: src/model/dccrn.py:457-634 (training branch :549-611, whitening :593-602,
+ *      running statistics :555-556,577-579) fused with nn.PReLU() (:79,122).  Activations are [rows][2*Cr] bf16.
+ *      `part` is scratch of sehip_cbn_scratch_floats() floats shared by stats / bwd_reduce and their finalize. */
+long sehip_cbn_scratch_floats(long rows, int Cr);
+int sehip_cbn_stats(const void* y, long rows, int Cr, float* part, void* stream);
+int sehip_cbn_finalize(const float* part, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
+                       const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
+                       long rows, int Cr, float eps, float momentum, int training, float* coef /*[Cr][16]*/, void* stream);
+int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream);
+int sehip_cbn_bwd_reduce(const void* dz, const void* dz2 /*or NULL*/, const void* y, const float* coef, const float* slope,
+                         long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream);
+int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri, const float* Wii,
+                           long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope,
+                           float* bcoef /*[Cr][16]*/, void* stream);
+int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
+                        const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream);
+
+/* ---- recurrent part of NavieComplexLSTM: src/model/dccrn.py:264-302 (four nn.LSTM passes of one complex layer in one
+ *      persistent launch; hidden size 64).  pre*: [B][T][2 lstm * 256] gates from the input GEMMs (fp32);
+ *      h/gates/c: [4 combos][B][T][64|256|64]; combo = part*2 + lstm. */
+int sehip_lstm_fwd(const float* pre_r, const float* pre_i, const void* whh_bf16 /*[2][256][64]*/, int B, int T, int hidden,
+                   void* h_bf16, void* gates_bf16, float* c, void* stream);
+int sehip_lstm_bwd(const void* dh_a_bf16, const void* dh_b_bf16, const void* whhT_bf16 /*[2][64][256]*/,
+                   const void* gates_bf16, const float* c, int B, int T, int hidden, void* dpre_r_bf16, void* dpre_i_bf16,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
