@@ -985,6 +985,238 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
 #undef CW_CASE
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_small_wgrad_kernel: weight gradient of the small-channel layers.  The WHOLE dW[BN][K] of the layer lives in
+// the registers of one workgroup (wave w owns the 16-column k-tiles w, w+4, ...), which streams over 128-row m-tiles:
+// dOut and the input patch are each read from HBM exactly once per workgroup pass; one atomic flush at the end.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int KPW>
+__global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
+    constexpr int TN = BN / 16;
+    constexpr int GP = BN + 8;
+    constexpr int GCH = BN / 8;
+    constexpr int GPT = (128 * GCH + 255) / 256;
+    constexpr int MAXPC = 12;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int CT = C0 + C1;
+    const int KR = 2 * d.cv_nf * CT;
+    const int PP = CT + 8;
+    bf16_raw* sG = reinterpret_cast<bf16_raw*>(smem);
+    bf16_raw* patch = sG + 128 * GP;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tblocks = (d.TT + TB - 1) / TB;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * tblocks;
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const int cp8 = CT >> 3;
+    const int NP = (TB + 1) * FR * cp8;
+    const int lgct = 31 - __clz(CT);
+    const int nf = d.cv_nf;
+
+    int p_lds[MAXPC], p_g[MAXPC], p_pp[MAXPC];
+#pragma unroll
+    for (int u = 0; u < MAXPC; ++u) {
+        const int idx = tid + 256 * u;
+        p_pp[u] = -1; p_lds[u] = 0; p_g[u] = 0;
+        if (idx < NP) {
+            const int pp = idx / (FR * cp8), rem = idx - pp * (FR * cp8);
+            const int r = rem / cp8, c8 = rem - r * cp8;
+            const bool second = c8 * 8 >= C0;
+            const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+            const int f = d.cv_fadd + r;
+            p_lds[u] = (pp * FR + r) * PP + c8 * 8;
+            if (f >= 0 && f < sF) {
+                p_pp[u] = pp | (second ? 0x10000 : 0);
+                p_g[u] = (pp * sF + f) * sC + (c8 * 8 - (second ? C0 : 0));
+            }
+        }
+    }
+    // transposed-read rows of this lane, and the patch offset of each owned k-tile
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = 4 * (i16 & 3);
+    int pbase[4][2], gbase[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ks * 32 + 8 * g + q + 4 * h;
+            const int tl = m / JB, jl = m - tl * JB;
+            pbase[ks][h] = (tl * FR + jl * d.fmul) * PP + p4;
+            gbase[ks][h] = m * GP + p4;
+        }
+    int koff[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int k0 = 16 * (w + 4 * i);
+        koff[i] = -1;
+        if (k0 < KR) {
+            const int it = k0 >> lgct, c = k0 & (CT - 1);
+            const bool second = c >= C0;
+            const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
+            const int dt = second ? d.cv_toff[1][kt] - tmin1 : d.cv_toff[0][kt] - tmin0;
+            koff[i] = (dt * FR + tap) * PP + c;
+        }
+    }
+
+    f32x4 acc[TN][KPW];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < KPW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.f;
+    const bool do_bias = d.dbias != nullptr;
+
+    const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        const int b = mt / tblocks, t0 = (mt - b * tblocks) * TB;
+#pragma unroll
+        for (int u0 = 0; u0 < MAXPC; u0 += 4) {
+            if (u0 * 256 >= NP) break;
+            uint4 pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pr[u] = make_uint4(0u, 0u, 0u, 0u);
+                const int e = p_pp[u0 + u];
+                if (e >= 0) {
+                    const bool second = (e & 0x10000) != 0;
+                    const int ts = t0 + (e & 0xffff) + (second ? tmin1 : tmin0);
+                    const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+                    if (ts >= tlo && ts < thi) {
+                        const bf16_raw* base = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr);
+                        const long frame0 = ((long)b * (second ? d.src[1].T : d.src[0].T) + t0 + (second ? tmin1 : tmin0)) *
+                                            (second ? d.src[1].F : d.src[0].F) * (second ? C1 : C0);
+                        pr[u] = *reinterpret_cast<const uint4*>(base + frame0 + p_g[u0 + u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (tid + 256 * (u0 + u) < NP) *reinterpret_cast<uint4*>(&patch[p_lds[u0 + u]]) = pr[u];
+        }
+        // dOut tile: 128 rows x GCH chunks
+        {
+            uint4 gr[GPT];
+#pragma unroll
+            for (int u = 0; u < GPT; ++u) {
+                const int idx = tid + 256 * u;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < 128 * GCH) {
+                    const int r = idx / GCH, gc = idx - r * GCH;
+                    const int tl = r / JB, jl = r - tl * JB;
+                    RowPos rp;
+                    rp.b = b; rp.t = t0 + tl; rp.jf = jl * d.fmul; rp.valid = rp.t < d.TT;
+                    if (rp.valid) {
+                        const int n = gc * 8;
+                        const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
+                        const size_t ro = dst_row_offset(d.dst[0], rp, d.fmul);
+                        const bf16_raw* gb = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr) + ro;
+                        if (c0.nvalid == 4 && c1.nvalid == 4 && c1.coff == c0.coff + 4) {
+                            v = *reinterpret_cast<const uint4*>(gb + c0.coff);
+                        } else {
+                            bf16_raw tmp[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                tmp[e] = e < c0.nvalid ? gb[c0.coff + e] : (bf16_raw)0;
+                                tmp[4 + e] = e < c1.nvalid ? gb[c1.coff + e] : (bf16_raw)0;
+                            }
+                            v = make_uint4(tmp[0] | ((unsigned)tmp[1] << 16), tmp[2] | ((unsigned)tmp[3] << 16),
+                                           tmp[4] | ((unsigned)tmp[5] << 16), tmp[6] | ((unsigned)tmp[7] << 16));
+                        }
+                    }
+                }
+                gr[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < GPT; ++u) {
+                const int idx = tid + 256 * u;
+                if (idx < 128 * GCH) *reinterpret_cast<uint4*>(&sG[(idx / GCH) * GP + (idx % GCH) * 8]) = gr[u];
+            }
+        }
+        __syncthreads();
+        if (do_bias && tid < BN) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 128; ++r) sacc += bf2f(sG[r * GP + tid]);
+            colsum += sacc;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 gf[TN];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][0] + ni * 16]);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][1] + ni * 16]);
+                gf[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int ko = koff[i] < 0 ? 0 : koff[i];  // padded k-tiles read a valid address and are discarded
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][0] + ko]);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][1] + ko]);
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[ni][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], xf, acc[ni][i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            if (koff[i] < 0) continue;
+            const int n = ni * 16 + 4 * (lane >> 4);
+            const int k = 16 * (w + 4 * i) + (lane & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][i][u]);
+        }
+    if (do_bias && tid < BN) atomicAdd(&d.dbias[tid], colsum);
+}
+
+template <int BN, int KPW>
+static int launch_small_wgrad(const sehip_gemm_desc& d, int TB, int JB, int FR, int tiles_per_wg, int grid, size_t lds,
+                              hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_wgrad_kernel<BN, KPW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        attr_set = true;
+    }
+    conv_small_wgrad_kernel<BN, KPW><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);
+    return 1;
+}
+
+static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_SMALL") != nullptr;
+    if (disabled || d.cv_nf <= 0 || d.dst[1].ptr) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int CT = C0 + C1;
+    if ((C0 & 15) || (C1 & 15) || CT > 128 || (CT & (CT - 1)) || d.Npad > 64 || CT < 16) return 0;
+    if (d.J > 128 || (128 % d.J)) return 0;
+    const int KR = 2 * d.cv_nf * CT;
+    if (KR > d.K) return 0;
+    const int JB = d.J, TB = 128 / JB;
+    const int FR = (JB - 1) * d.fmul + d.cv_nf;
+    if ((TB + 1) * FR * (CT >> 3) > 12 * 256) return 0;
+    const size_t lds = (size_t)128 * (d.Npad + 8) * 2 + (size_t)(TB + 1) * FR * (CT + 8) * 2;
+    if (lds > 120 * 1024) return 0;
+    const int kpw = d.K / 64;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * ((d.TT + TB - 1) / TB);
+    int wgs = 512;
+    if (wgs > MT) wgs = MT;
+    const int tiles_per_wg = (MT + wgs - 1) / wgs;
+    const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
+#define SW(BN_, KPW_) if (d.Npad == BN_ && kpw == KPW_) return launch_small_wgrad<BN_, KPW_>(d, TB, JB, FR, tiles_per_wg, grid, lds, st);
+    SW(16, 1) SW(16, 2) SW(16, 3) SW(16, 4) SW(16, 5) SW(16, 6) SW(16, 8) SW(16, 12)
+    SW(32, 1) SW(32, 2) SW(32, 3) SW(32, 4) SW(32, 5) SW(32, 6) SW(32, 8) SW(32, 12)
+    SW(64, 1) SW(64, 2) SW(64, 3)  // wider 64-row tiles: the generic kernel measured faster
+#undef SW
+    return 0;
+}
+
 extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("wgrad", d)) return e;
     SEHIP_REQUIRE(d->dW != nullptr, "wgrad: missing dW");
@@ -992,6 +1224,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (try_conv_wgrad(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv)");
+        return 0;
+    }
+    if (try_conv_small_wgrad(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(conv-small)");
         return 0;
     }
     const int ktiles = d->K / 64;
