@@ -76,16 +76,31 @@ __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[a][j] = 0.f;
     const int C = 2 * Cr;
-    if (rl < rpb)
-        for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
-            const Chunk8 a = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
-            const Chunk8 b = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
+    if (rl < rpb) {
+        // four rows per trip: 8 independent 16-byte loads in flight per thread (one workgroup per CU must cover HBM latency)
+        const long stride = (long)gridDim.x * rpb;
+        for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 4 * stride) {
+            uint4 ua[4], ub[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                s[0][j] += a.v[j]; s[1][j] += b.v[j];
-                s[2][j] += a.v[j] * a.v[j]; s[3][j] += a.v[j] * b.v[j]; s[4][j] += b.v[j] * b.v[j];
+            for (int u = 0; u < 4; ++u) {
+                const long r = r0 + u * stride;
+                ua[u] = make_uint4(0u, 0u, 0u, 0u); ub[u] = ua[u];
+                if (r < rows) {
+                    ua[u] = *reinterpret_cast<const uint4*>(y + r * C + q * 8);
+                    ub[u] = *reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const Chunk8 a = unpack8(ua[u]), b = unpack8(ub[u]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s[0][j] += a.v[j]; s[1][j] += b.v[j];
+                    s[2][j] += a.v[j] * a.v[j]; s[3][j] += a.v[j] * b.v[j]; s[4][j] += b.v[j] * b.v[j];
+                }
             }
         }
+    }
     block_partials<5>(s, nq, Cr, part, 5 * Cr, lds);
 }
 
@@ -139,24 +154,28 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
 __global__ __launch_bounds__(256) void cbn_apply_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ coef,
                                                         const float* __restrict__ slope, long rows, int Cr,
                                                         bf16_raw* __restrict__ z) {
+    // a thread owns ONE chunk of 8 complex channels for all its rows: the 64 coefficient floats stay in registers
+    // (re-loading them per row made the kernel TA-issue bound: 16 coefficient loads per 2 data loads)
     const int nq = Cr >> 3;
     const int C = 2 * Cr;
-    const long total = rows * nq;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     const float a = slope[0];
-    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
-        const long r = id / nq;
-        const int q = (int)(id - r * nq);
+    float4 zc[8], mb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
+        zc[j] = *reinterpret_cast<const float4*>(k);
+        mb[j] = *reinterpret_cast<const float4*>(k + 4);
+    }
+    for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
         const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
         const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
         float orr[8], oii[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
-            const float4 zc = *reinterpret_cast<const float4*>(k);
-            const float4 mb = *reinterpret_cast<const float4*>(k + 4);
-            const float cr = xr.v[j] - mb.x, ci = xi.v[j] - mb.y;
-            float vr = zc.x * cr + zc.y * ci + mb.z;
-            float vi = zc.z * cr + zc.w * ci + mb.w;
+            const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
+            const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
+            const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
             orr[j] = vr > 0.f ? vr : a * vr;
             oii[j] = vi > 0.f ? vi : a * vi;
         }
@@ -292,11 +311,22 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const bf16_raw* __re
                                                             bf16_raw* __restrict__ dy) {
     const int nq = Cr >> 3;
     const int C = 2 * Cr;
-    const long total = rows * nq;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     const float a = slope[0];
-    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
-        const long r = id / nq;
-        const int q = (int)(id - r * nq);
+    // per-channel coefficients of this thread's 8 complex channels, in registers for the whole pass
+    float4 zc[8], mb[8], A[8], E[8];
+    float ki[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
+        const float* kb = bcoef + (size_t)(q * 8 + j) * COEF_STRIDE;
+        zc[j] = *reinterpret_cast<const float4*>(k);
+        mb[j] = *reinterpret_cast<const float4*>(k + 4);
+        A[j] = *reinterpret_cast<const float4*>(kb);
+        E[j] = *reinterpret_cast<const float4*>(kb + 4);  // Err Eri Eii kr
+        ki[j] = kb[8];
+    }
+    for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
         const bool dropped = tfirst > 0 && (int)((r / F) % Tst) < tfirst;
         const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
         const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
@@ -317,21 +347,14 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const bf16_raw* __re
         float orr[8], oii[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
-            const float* kb = bcoef + (size_t)(q * 8 + j) * COEF_STRIDE;
-            const float4 zc = *reinterpret_cast<const float4*>(k);
-            const float4 mb = *reinterpret_cast<const float4*>(k + 4);
-            const float4 A = *reinterpret_cast<const float4*>(kb);
-            const float4 E = *reinterpret_cast<const float4*>(kb + 4);  // Err Eri Eii kr
-            const float ki = kb[8];
-            const float cr = xr.v[j] - mb.x, ci = xi.v[j] - mb.y;
-            const float vr = zc.x * cr + zc.y * ci + mb.z;
-            const float vi = zc.z * cr + zc.w * ci + mb.w;
+            const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
+            const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
+            const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
             float dr = gr.v[j], di = gi.v[j];
             if (!(vr > 0.f)) dr *= a;
             if (!(vi > 0.f)) di *= a;
-            orr[j] = A.x * dr + A.y * di + E.x * cr + E.y * ci + E.w;
-            oii[j] = A.z * dr + A.w * di + E.y * cr + E.z * ci + ki;
+            orr[j] = A[j].x * dr + A[j].y * di + E[j].x * cr + E[j].y * ci + E[j].w;
+            oii[j] = A[j].z * dr + A[j].w * di + E[j].y * cr + E[j].z * ci + ki[j];
         }
         *reinterpret_cast<uint4*>(dy + r * C + q * 8) = pack8(orr);
         *reinterpret_cast<uint4*>(dy + r * C + Cr + q * 8) = pack8(oii);
@@ -348,6 +371,14 @@ static int check_cbn(const char* who, long rows, int Cr) {
 static int grid_for(long work_items) {
     long g = (work_items + 255) / 256;
     if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int apply_blocks(long rows, int Cr) {
+    const int rpb = 256 / (Cr >> 3);
+    long g = (rows + (long)rpb * 4 - 1) / ((long)rpb * 4);
+    if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -383,8 +414,8 @@ extern "C" int sehip_cbn_finalize(const float* part, const float* Wrr, const flo
 
 extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream) {
     if (int e = check_cbn("cbn_apply", rows, Cr)) return e;
-    cbn_apply_kernel<<<grid_for(rows * (Cr >> 3)), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, coef, slope, rows, Cr,
-                                                                                 (bf16_raw*)z);
+    cbn_apply_kernel<<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, coef, slope, rows, Cr,
+                                                                              (bf16_raw*)z);
     SEHIP_CHECK_LAUNCH("cbn_apply");
     return 0;
 }
@@ -411,7 +442,7 @@ extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, cons
 extern "C" int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
                                    const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream) {
     if (int e = check_cbn("cbn_bwd_apply", rows, Cr)) return e;
-    cbn_bwd_apply_kernel<<<grid_for(rows * (Cr >> 3)), 256, 0, (hipStream_t)stream>>>(
+    cbn_bwd_apply_kernel<<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(
         (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, bcoef, slope, rows, Cr, F, Tst, tfirst,
         (bf16_raw*)dy);
     SEHIP_CHECK_LAUNCH("cbn_bwd_apply");
