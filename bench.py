@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraphs")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -156,13 +157,14 @@ def main():
         torch.cuda.synchronize()
 
     note(f"model built, batch staged on {dev}; warm-up {args.warmup} steps")
+    step_fn = solver.train_step if args.eager else solver.train_step_graphed
     for _ in range(args.warmup):
-        solver.train_step(mixture, sources)
+        step_fn(mixture, sources)
     sync()
-    note(f"timing {args.steps} steps")
+    note(f"timing {args.steps} steps ({'eager launches' if args.eager else 'hipGraph replay'})")
     t0 = time.time()
     for _ in range(args.steps):
-        loss, metric = solver.train_step(mixture, sources)
+        loss, metric = step_fn(mixture, sources)
     sync()
     dt = time.time() - t0
     if world > 1:
@@ -179,7 +181,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
                                "clips, SI-SNR, Adam 3e-4, clip 5", "per_gpu_batch": args.batch,
-                   "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}"},
+                   "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
+                   "launch": "eager" if args.eager else "hipGraph"},
         "final_loss": float(loss),
     }
     if rank == 0 and not args.no_roofline:

@@ -48,7 +48,11 @@ int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, co
  *      metric) and src/distrib.py:244-261 (Adam / SGD).  mode 0 = Adam, 1 = SGD(momentum=beta1). */
 int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream);
 int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
-                   float lr, float beta1, float beta2, float eps, int step, float weight_decay, int mode, void* stream);
+                   float lr, float beta1, float beta2, float eps, int step, const int* step_dev /*device counter or NULL*/,
+                   float weight_decay, int mode, void* stream);
+int sehip_counter_add(int* counter, int value, void* stream);
+/* sets the dynamic-LDS attributes of every kernel up front (call once before capturing a hipGraph) */
+int sehip_init(void);
 int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, int ntensors, long max_tensor_numel,
                       const double* sumsq,
                       float* tensor_sums /*[ntensors]*/, float* metric /*[2]: sum-metric, L2 norm*/, void* stream);

@@ -32,7 +32,9 @@ _PROTOS = {
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
     "sehip_grad_sumsq": [P, L, P, P],
-    "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, F, I, P],
+    "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, P],
+    "sehip_counter_add": [P, I, P],
+    "sehip_init": [],
     "sehip_grad_metric": [P, P, I, L, P, P, P, P],
     "sehip_cbn_scratch_floats": [L, I],
     "sehip_stft_fwd": [P, P, I, I, I, I, I, P, P, P],

@@ -1249,3 +1249,29 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     SEHIP_CHECK_LAUNCH("wgrad");
     return 0;
 }
+
+template <typename K>
+static void set_lds(K kernel, int bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+extern "C" int sehip_init(void) {
+#define INIT_CONV(NF_)                                           \
+    set_lds(&conv_gemm_kernel<128, 2, 2, NF_>, 96 * 1024);      \
+    set_lds(&conv_gemm_kernel<64, 1, 4, NF_>, 96 * 1024);       \
+    set_lds(&conv_wgrad_kernel<NF_>, 96 * 1024);
+    INIT_CONV(2) INIT_CONV(3) INIT_CONV(5)
+#undef INIT_CONV
+    set_lds(&conv_small_kernel<16>, 120 * 1024);
+    set_lds(&conv_small_kernel<32>, 120 * 1024);
+    set_lds(&conv_small_kernel<64>, 120 * 1024);
+#define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_>, 120 * 1024);
+    INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)
+    INIT_SW(32, 1) INIT_SW(32, 2) INIT_SW(32, 3) INIT_SW(32, 4) INIT_SW(32, 5) INIT_SW(32, 6) INIT_SW(32, 8) INIT_SW(32, 12)
+    INIT_SW(64, 1) INIT_SW(64, 2) INIT_SW(64, 3)
+#undef INIT_SW
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sehip_set_error(-2, "init: %s", hipGetErrorString(e));
+    return 0;
+}
+

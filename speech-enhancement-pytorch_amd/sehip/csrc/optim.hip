@@ -30,7 +30,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, const double* __restrict__ sumsq,
                                                        float max_norm, float lr, float b1, float b2, float eps, float bc1,
-                                                       float sqrt_bc2, float wd, int mode, int first_step) {
+                                                       float sqrt_bc2, float wd, int mode, int first_step,
+                                                       const int* __restrict__ step_dev) {
+    if (step_dev) {  // step counter lives on the device (graph replay): bias corrections computed here
+        const int step = step_dev[0];
+        first_step = step == 1;
+        if (mode == 0) {
+            bc1 = (float)(1.0 - pow((double)b1, (double)step));
+            sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, (double)step));
+        }
+    }
     float coef = 1.f;
     if (max_norm > 0.f) {
         const float total = (float)sqrt(sumsq[0]);
@@ -96,10 +105,20 @@ extern "C" int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, v
     return 0;
 }
 
+__global__ void counter_add_kernel(int* p, int v) { p[0] += v; }
+
+extern "C" int sehip_counter_add(int* counter, int value, void* stream) {
+    SEHIP_REQUIRE(counter != nullptr, "counter_add: null counter");
+    counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter, value);
+    SEHIP_CHECK_LAUNCH("counter_add");
+    return 0;
+}
+
 extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
-                              float max_norm, float lr, float beta1, float beta2, float eps, int step, float weight_decay,
-                              int mode, void* stream) {
-    SEHIP_REQUIRE(n >= 0 && step >= 1, "opt_step: bad n/step (n=%ld step=%d)", n, step);
+                              float max_norm, float lr, float beta1, float beta2, float eps, int step, const int* step_dev,
+                              float weight_decay, int mode, void* stream) {
+    SEHIP_REQUIRE(n >= 0 && (step >= 1 || step_dev != nullptr), "opt_step: bad n/step (n=%ld step=%d)", n, step);
+    if (step < 1) step = 1;
     SEHIP_REQUIRE(mode == 0 || mode == 1, "opt_step: mode must be 0 (adam) or 1 (sgd)");
     SEHIP_REQUIRE(max_norm <= 0.f || sumsq != nullptr, "opt_step: clipping needs the sumsq buffer");
     if (n == 0) return 0;
@@ -108,7 +127,7 @@ extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, l
     int grid = cdiv(n, 256 * 4);
     if (grid > 2048) grid = 2048;
     opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
-                                                           (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1);
+                                                           (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev);
     SEHIP_CHECK_LAUNCH("opt_step");
     return 0;
 }

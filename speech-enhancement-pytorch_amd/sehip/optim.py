@@ -21,6 +21,7 @@ class FlatOptimizer(torch.optim.Optimizer):
         super().__init__(list(model.parameters()), defaults)
         self._m = self._v = None
         self._step = 0
+        self._step_dev = None
         self._scratch = None
         self.max_norm = 0.0  # set by clip_grad_norm_() for the next step only
 
@@ -33,6 +34,7 @@ class FlatOptimizer(torch.optim.Optimizer):
             self._v = torch.zeros_like(flat)
             if old_m is not None and old_m.numel() == flat.numel():
                 self._m.copy_(old_m); self._v.copy_(old_v)
+            self._step_dev = torch.full((1,), int(self._step), dtype=torch.int32, device=flat.device)
             self._scratch = dict(sumsq=torch.zeros(1, dtype=torch.float64, device=flat.device),
                                  tsums=torch.zeros(len(self.model._params), device=flat.device),
                                  metric=torch.zeros(2, device=flat.device),
@@ -65,7 +67,8 @@ class FlatOptimizer(torch.optim.Optimizer):
         model = self.model
         params, grads = model.flat_params, model.flat_grads
         g = self.param_groups[0]
-        self._step += 1
+        self._step += 1  # host mirror; the kernel reads the device counter (valid under hipGraph replay)
+        call("sehip_counter_add", ptr(self._step_dev), 1, stream())
         s = self._scratch
         if self.max_norm > 0:
             call("sehip_grad_sumsq", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
@@ -75,7 +78,7 @@ class FlatOptimizer(torch.optim.Optimizer):
         else:
             b1, b2, mode = g["momentum"], 0.0, 1
         call("sehip_opt_step", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq"]),
-             self.max_norm, g["lr"], b1, b2, g["eps"], self._step, g["weight_decay"], mode, stream())
+             self.max_norm, g["lr"], b1, b2, g["eps"], self._step, ptr(self._step_dev), g["weight_decay"], mode, stream())
         self.max_norm = 0.0
 
     def grad_metric(self):
@@ -93,8 +96,15 @@ class FlatOptimizer(torch.optim.Optimizer):
         self.model._grads_live = False
 
     # ---- checkpoint format of torch.optim ----------------------------------------------------------
+    def sync_step(self):
+        """Refresh the host mirror of the step counter from the device (after graph replays)."""
+        if getattr(self, "_step_dev", None) is not None and self._step_dev.is_cuda:
+            self._step = int(self._step_dev.item())
+        return self._step
+
     def state_dict(self):
         self._ensure_state()
+        self.sync_step()
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
         return super().state_dict()
@@ -115,6 +125,7 @@ class FlatOptimizer(torch.optim.Optimizer):
             elif "momentum_buffer" in st and st["momentum_buffer"] is not None:
                 self._m[sl].copy_(st["momentum_buffer"].reshape(-1))
             self._step = int(float(st["step"]))
+        self._step_dev.fill_(int(self._step))
         for g, saved in zip(self.param_groups, state_dict["param_groups"]):
             for k in ("lr", "betas", "eps", "momentum", "weight_decay"):
                 if k in saved:

@@ -221,6 +221,54 @@ class Solver(object):
         metric = self.optimizer.grad_metric() if fused else None
         return loss.detach(), metric
 
+    # ---- hipGraph replay of the step (config.solver.use_graph) ------------------------------------------
+    def train_step_graphed(self, mixture, sources):
+        """Same step as train_step(), captured once per batch shape into two hipGraphs (forward+loss+backward, and
+        clip+optimizer+metric; the RCCL all-reduce runs between them) and replayed: ~330 launches become 2.
+        Inputs are copied into static buffers; returns the static (loss, metric) device tensors."""
+        key = (tuple(mixture.shape), tuple(sources.shape))
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture_step(mixture, sources)
+        g["mix"].copy_(mixture)
+        g["src"].copy_(sources)
+        g["fb"].replay()
+        if self.world_size > 1:
+            distrib.allreduce_gradients(self.model.flat_grads)
+        g["upd"].replay()
+        return g["loss"], g["metric"]
+
+    def _capture_step(self, mixture, sources):
+        from ._lib import call
+        if not isinstance(self.optimizer, FlatOptimizer):
+            raise SehipError("train_step_graphed needs the fused FlatOptimizer")
+        call("sehip_init")
+        self.model.train()
+        self.model.workspace(mixture.shape[0], mixture.shape[-1])  # all buffers exist before capture
+        self.optimizer._ensure_state()
+        self.model.flat_grads
+        if self.model._anchor is None or self.model._anchor.device != mixture.device:
+            self.model._anchor = torch.zeros(1, device=mixture.device, requires_grad=True)
+        mix, src = mixture.clone(), sources.clone()
+        torch.cuda.synchronize()
+        fb, upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(fb):
+            enhanced = self.model(mix)
+            loss = self.loss_function(enhanced, src)
+            self.optimizer.zero_grad()
+            loss.backward()
+            loss_out = loss.detach().clone()
+        with torch.cuda.graph(upd, pool=fb.pool()):
+            if self.config.optim.clip_grad:
+                self.optimizer.clip_grad_norm_(self.config.optim.clip_grad)
+            self.optimizer.step()
+            metric_out = self.optimizer.grad_metric().clone()
+        # capture executed nothing: undo the host-side step increment made while recording
+        self.optimizer._step -= 1
+        return dict(fb=fb, upd=upd, mix=mix, src=src, loss=loss_out, metric=metric_out)
+
     def _run_one_epoch(self, epoch, total_epoch, train=False):
         cfg = self.config
         loss_total = 0.0
@@ -254,7 +302,8 @@ class Solver(object):
             mixture, sources = batch[0], batch[1]
             mixture, sources = self._prepare_batch(mixture, sources)
             if train:
-                loss_t, metric_t = self.train_step(mixture, sources)
+                step_fn = self.train_step_graphed if _cfg(cfg.solver, "use_graph", False) else self.train_step
+                loss_t, metric_t = step_fn(mixture, sources)
                 pending.append((step, loss_t.clone(), metric_t.clone() if metric_t is not None else None))
             else:
                 self.model.eval()

@@ -117,8 +117,8 @@ def test_clip_adam_matches_oracle(dev):
         want_metric = math.sqrt(sum(float(x.sum()) ** 2 for x in gd.values()))
         gdev = grads.to(dev)
         call("sehip_grad_sumsq", ptr(gdev), n, ptr(sumsq), stream())
-        call("sehip_opt_step", ptr(p), ptr(gdev), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 3e-4, 0.9, 0.999, 1e-8, step, 0.0,
-             0, stream())
+        call("sehip_opt_step", ptr(p), ptr(gdev), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 3e-4, 0.9, 0.999, 1e-8, step, None,
+             0.0, 0, stream())
         call("sehip_grad_metric", ptr(gdev), ptr(offs_d), len(sizes), max(sizes), ptr(sumsq), ptr(tsum), ptr(metric), stream())
         assert abs(float(metric[1]) - float(total)) < 1e-4 * float(total)
         assert abs(float(metric[0]) - want_metric) < 1e-3 * max(1.0, want_metric)

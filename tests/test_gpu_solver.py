@@ -104,3 +104,34 @@ def test_eval_forward_and_cpu_rejection():
     assert rel_err(out.cpu(), ref) < 3e-2
     with pytest.raises(SehipError):
         model(noisy)  # CPU tensor: no fallback
+
+
+def test_graph_replay_matches_eager_steps(tmp_path):
+    """Three optimisation steps through the captured hipGraphs == three eager steps (same kernels, same order)."""
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    batches = [make_batch(300 + s, 2, 4000) for s in range(3)]
+    finals = []
+    for use_graph in (False, True):
+        cfg = solver_config(tmp_path)
+        torch.manual_seed(cfg.seed)
+        model = distrib.get_model(cfg.model)
+        opt = distrib.get_optimizer(cfg.optim, model)
+        solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+        losses = []
+        for noisy, clean in batches:
+            mix, src = solver._prepare_batch(noisy, clean)
+            fn = solver.train_step_graphed if use_graph else solver.train_step
+            loss, metric = fn(mix, src)
+            losses.append((float(loss), float(metric[0])))
+        finals.append((losses, solver.model.flat_params.cpu().clone(), opt.sync_step()))
+    (l0, p0, s0), (l1, p1, s1) = finals
+    assert s0 == s1 == 3
+    # step 0 starts from identical weights: forward + backward are the same kernels -> same loss / metric
+    assert abs(l0[0][0] - l1[0][0]) < 1e-5 and abs(l0[0][1] - l1[0][1]) < 1e-3 * abs(l0[0][1])
+    # later steps: the fp32 atomics of the weight-gradient kernels make gradients differ in the last bits from run to run
+    # (eager-vs-eager too); Adam's first steps turn that into +-lr moves of the parameters whose true gradient is zero
+    # (conv biases in front of a BatchNorm), hence the loose bounds
+    for a, b in zip(l0[1:], l1[1:]):
+        assert abs(a[0] - b[0]) < 0.03 and abs(a[1] - b[1]) < 1e-2 * max(1.0, abs(a[1]))
+    assert max_abs(p0, p1) < 3 * 2 * 3e-4
