@@ -801,20 +801,28 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
 template <int NF>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
     constexpr int NIT = 2 * NF;
-    constexpr int GP = 72;  // pitch of the dOut tile
+    constexpr int GP = 80;  // pitch of the dOut tile: 160 B, so 8 consecutive rows sit on 8 disjoint 32-byte bank slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_raw* sG = reinterpret_cast<bf16_raw*>(smem);  // [128][GP]
     bf16_raw* patch = sG + 128 * GP;
+    // patch pitch: consecutive m are consecutive patch rows (fmul 1) or every other row (fmul 2); 160 B / 144 B make
+    // the 8 rows a 32-lane half reads in one transposed read conflict-free in both cases
+    const int PPW = d.fmul == 2 ? 72 : 80;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int w = wv & 3, nh = wv >> 2;  // wave -> 16-channel subtile w, 32-wide half nh of the 64 output channels
+    // All (n-tile, channel-chunk) workgroups of one m-split read the same dOut tiles and patches at the same time:
+    // put them on ONE XCD (blocks are dealt round-robin over the 8 XCDs) so that those re-reads hit its L2.
     const int ntn = d.Npad >> 6;
-    const int nt = blockIdx.x % ntn, cc = blockIdx.x / ntn;
+    const int gx = ntn * ((d.src[0].C + (d.src[1].ptr ? d.src[1].C : 0)) >> 6);
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int xi = rr % gx, split = (rr / gx) * 8 + xcd;
+    const int nt = xi % ntn, cc = xi / ntn;
     const int n0 = nt * 64;
     const int tblocks = (d.TT + TB - 1) / TB;
     const int B = d.M / (d.TT * d.J);
     const int MT = B * tblocks;
-    const int mt_begin = blockIdx.y * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    const int mt_begin = split * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
 
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int Ctot = C0 + C1;
@@ -834,9 +842,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int m = ks * 32 + 8 * g + q + 4 * h;
+            // MFMA k index j of lane group g  <->  tile row m = 32 ks + 16 (j>>2) + 4 g + (j&3): the two groups of a
+            // 32-lane half then read 8 CONSECUTIVE rows (the reduction order is free as long as both operands agree)
+            const int m = ks * 32 + 16 * h + 4 * g + q;
             const int tl = m / JB, jl = m - tl * JB;
-            pbase[ks][h] = (tl * FR + jl * d.fmul) * CV_PITCH + 16 * w + p4;
+            pbase[ks][h] = (tl * FR + jl * d.fmul) * PPW + 16 * w + p4;
             gbase[ks][h] = m * GP + p4 + 32 * nh;
         }
 
@@ -870,7 +880,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
                 const int idx = tid + 512 * (i0 + u);
                 if (idx < NP) {
                     const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
-                    *reinterpret_cast<uint4*>(&patch[(pp * FR + (rem >> 3)) * CV_PITCH + (rem & 7) * 8]) = pr[u];
+                    *reinterpret_cast<uint4*>(&patch[(pp * FR + (rem >> 3)) * PPW + (rem & 7) * 8]) = pr[u];
                 }
             }
         }
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int toff_e = ((it < NF ? dt0 : dt1) * FR + (it < NF ? it : it - NF)) * CV_PITCH;
+                const int toff_e = ((it < NF ? dt0 : dt1) * FR + (it < NF ? it : it - NF)) * PPW;
                 s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][0] + toff_e]);
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][1] + toff_e]);
                 const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -955,16 +965,14 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     const int JB = d.J, TB = 128 / JB;
     const int FR = (JB - 1) * d.fmul + d.cv_nf;
     if ((TB + 1) * FR * 8 > CV_MAXP * 256) return 0;
-    const size_t lds = (size_t)128 * 72 * 2 + (size_t)(TB + 1) * FR * CV_PITCH * 2;
+    const size_t lds = (size_t)128 * 80 * 2 + (size_t)(TB + 1) * FR * 80 * 2;
     const int B = d.M / (d.TT * d.J);
     const int MT = B * ((d.TT + TB - 1) / TB);
     const int gx = (d.Npad >> 6) * ((C0 + C1) >> 6);
-    int splits = 512 / gx;
-    if (splits < 1) splits = 1;
-    if (splits > MT) splits = MT;
+    int splits = (512 / gx + 7) / 8 * 8;  // a multiple of 8: one group of splits per XCD
+    if (splits < 8) splits = 8;
     const int tiles_per_wg = (MT + splits - 1) / splits;
-    splits = (MT + tiles_per_wg - 1) / tiles_per_wg;
-    dim3 grid(gx, splits);
+    const int grid = gx * splits;  // splits beyond the data simply find an empty m range
 #define CW_CASE(NF_)                                                                                              \
     case NF_: {                                                                                                   \
         static bool attr_set = false;                                                                             \
@@ -993,7 +1001,7 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
 template <int BN, int KPW>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
     constexpr int TN = BN / 16;
-    constexpr int GP = BN + 8;
+    constexpr int GP = BN == 16 ? 16 : BN + 16;  // row offsets = distinct multiples of 32 B for 8 consecutive rows
     constexpr int GCH = BN / 8;
     constexpr int GPT = (128 * GCH + 255) / 256;
     constexpr int MAXPC = 12;
@@ -1001,7 +1009,8 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int CT = C0 + C1;
     const int KR = 2 * d.cv_nf * CT;
-    const int PP = CT + 8;
+    // patch pitch in elements: 8 consecutive (fmul 1) / alternate (fmul 2) rows on disjoint 32-byte bank slots
+    const int PP = d.fmul == 2 ? (CT == 64 ? 72 : CT + 8) : (CT == 16 ? 16 : CT + 16);
     bf16_raw* sG = reinterpret_cast<bf16_raw*>(smem);
     bf16_raw* patch = sG + 128 * GP;
 
@@ -1040,7 +1049,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int m = ks * 32 + 8 * g + q + 4 * h;
+            const int m = ks * 32 + 16 * h + 4 * g + q;  // see conv_wgrad_kernel
             const int tl = m / JB, jl = m - tl * JB;
             pbase[ks][h] = (tl * FR + jl * d.fmul) * PP + p4;
             gbase[ks][h] = m * GP + p4;
@@ -1200,7 +1209,7 @@ static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     const int JB = d.J, TB = 128 / JB;
     const int FR = (JB - 1) * d.fmul + d.cv_nf;
     if ((TB + 1) * FR * (CT >> 3) > 12 * 256) return 0;
-    const size_t lds = (size_t)128 * (d.Npad + 8) * 2 + (size_t)(TB + 1) * FR * (CT + 8) * 2;
+    const size_t lds = (size_t)128 * (d.Npad + 16) * 2 + (size_t)(TB + 1) * FR * (CT + 16) * 2;
     if (lds > 120 * 1024) return 0;
     const int kpw = d.K / 64;
     const int B = d.M / (d.TT * d.J);
