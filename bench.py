@@ -51,17 +51,19 @@ def bench_config(length):
 
 
 def gemm_roofline(ws, reps=10):
-    """Times every implicit-GEMM launch of the step separately (HIP events on the launch stream) and returns the
-    per-kernel table plus the entry that costs the most time per step."""
+    """Times every product launch of the step separately (HIP events on the launch stream, `reps` back-to-back launches
+    each), groups them by the kernel instantiation libsehip picked, and returns the per-class table: launches per step,
+    average launch duration (comparable with rocprofv3 --stats AverageNs of that symbol) and algorithmic TFLOP/s."""
     import ctypes as C
-    from sehip._lib import call, stream
-    rows = []
+    from sehip._lib import call, stream, lib
+    per = {}
     for name, d in ws.desc.items():
         if not name.endswith(".wg") and not d.W:
             continue  # recurrent-weight gradients exist only as wgrad launches
         fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
         flops = 2.0 * d.M * d.N * _real_k(ws, name)
         call(fn, C.byref(d), stream())
+        kname = lib().sehip_last_kernel().decode()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -70,8 +72,12 @@ def gemm_roofline(ws, reps=10):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        rows.append({"name": name, "ms": ms, "gflop": flops / 1e9, "tflops": flops / ms / 1e9})
-    rows.sort(key=lambda r: -r["ms"])
+        r = per.setdefault(kname, {"kernel": kname, "launches": 0, "ms": 0.0, "gflop": 0.0, "layers": []})
+        r["launches"] += 1; r["ms"] += ms; r["gflop"] += flops / 1e9; r["layers"].append(name)
+    rows = sorted(per.values(), key=lambda r: -r["ms"])
+    for r in rows:
+        r["avg_us"] = r["ms"] / r["launches"] * 1e3
+        r["tflops"] = r["gflop"] / r["ms"]
     return rows
 
 
@@ -84,7 +90,8 @@ def cpu_baseline_worker():
     """Child process: the oracle (fp32 PyTorch-CPU restatement of the reference step) on a bounded sample:
     B=4 clips, 1 warm-up + up to 5 timed steps.  Prints one JSON object."""
     from oracle import dccrn_oracle as O
-    cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0)))
+    # torch CPU ops stop scaling (and then slow down) beyond a few dozen threads on these small tensors
+    cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
     cfg = O.DCCRNConfig(length=int(SR * CLIP_S))
     p = O.init_params(cfg, seed=10)
@@ -192,12 +199,19 @@ def main():
         top = rows[0]
         total_ms = sum(r["ms"] for r in rows)
         total_gf = sum(r["gflop"] for r in rows)
-        out["roofline"] = {"bound": "mfma", "kernel": top["name"], "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                           "kernel_ms": top["ms"], "all_gemm_ms": total_ms, "all_gemm_tflops": total_gf / total_ms,
-                           "all_gemm_frac": total_gf / total_ms / PEAK_BF16_TFLOPS}
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")  # PMC passes (FETCH_SIZE / WRITE_SIZE), tools/collect_traffic.sh
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                           "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
+                           "gflop_per_launch": top["gflop"] / top["launches"],
+                           "all_product_kernels": {"ms_per_step": total_ms, "tflops": total_gf / total_ms,
+                                                   "frac": total_gf / total_ms / PEAK_BF16_TFLOPS}}
         out["step_tflops"] = 45.96e9 * args.batch / (ms * 1e-3) / 1e12
-        out["top_kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]]
+        out["kernel_classes"] = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["avg_us"], 1),
+                                  "tflops": round(r["tflops"], 1)} for r in rows[:10]]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("cpu baseline (oracle)")
         out["cpu_baseline"] = cpu_baseline()

@@ -23,6 +23,7 @@ extern "C" {
 #endif
 
 const char* sehip_last_error(void);
+const char* sehip_last_kernel(void); /* instantiation chosen by the last sehip_gemm / sehip_wgrad call (profiling aid) */
 int sehip_version(void);
 int sehip_check_device(int device);
 

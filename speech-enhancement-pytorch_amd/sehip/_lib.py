@@ -67,6 +67,7 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the HIP path.")
         _lib = C.CDLL(LIB_PATH)
         _lib.sehip_last_error.restype = C.c_char_p
+        _lib.sehip_last_kernel.restype = C.c_char_p
         for name, args in _PROTOS.items():
             fn = getattr(_lib, name, None)
             if fn is None:
@@ -77,7 +78,7 @@ def lib():
 
 
 def declared_symbols():
-    return ["sehip_last_error"] + list(_PROTOS)
+    return ["sehip_last_error", "sehip_last_kernel"] + list(_PROTOS)
 
 
 def check(status, what=""):

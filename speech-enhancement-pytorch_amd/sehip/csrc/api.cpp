@@ -15,7 +15,17 @@ int sehip_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+static thread_local char g_kernel[128] = "";
+
+void sehip_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 extern "C" const char* sehip_last_error(void) { return g_err; }
+extern "C" const char* sehip_last_kernel(void) { return g_kernel; }
 extern "C" int sehip_version(void) { return 100; }
 
 // Returns 0 when device `dev` is a gfx950 part this library was built for.

@@ -389,6 +389,7 @@ static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int gri
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
             attr_set = true;                                                                                          \
         }                                                                                                             \
+        sehip_note_kernel("conv_gemm_kernel<%d, %d, %d, %d>", BN, WN, WM, NF_);                                        \
         conv_gemm_kernel<BN, WN, WM, NF_><<<grid, 256, lds, st>>>(d, TB, JB, FR);                                     \
         return 1;                                                                                                     \
     }
@@ -600,6 +601,7 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);                      \
             attr_set = true;                                                                                        \
         }                                                                                                           \
+        sehip_note_kernel("conv_small_kernel<%d>", BN_);                                                           \
         conv_small_kernel<BN_><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                                \
         return 1;                                                                                                   \
     }
@@ -777,6 +779,8 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("gemm(conv-small)");
         return 0;
     }
+    sehip_note_kernel("gemm_kernel<%d, %d, %d, %d>", d->Npad <= 64 ? d->Npad : 128, d->Npad <= 64 ? 256 : 128,
+                      d->Npad <= 64 ? 1 : 2, d->Npad <= 64 ? 4 : 2);
     if (d->Npad == 16) {
         gemm_kernel<16, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
     } else if (d->Npad == 32) {
@@ -981,6 +985,7 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
             attr_set = true;                                                                                      \
         }                                                                                                         \
+        sehip_note_kernel("conv_wgrad_kernel<%d>", NF_);                                                         \
         conv_wgrad_kernel<NF_><<<grid, 512, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                              \
         return 1;                                                                                                 \
     }
@@ -1193,6 +1198,7 @@ static int launch_small_wgrad(const sehip_gemm_desc& d, int TB, int JB, int FR, 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
         attr_set = true;
     }
+    sehip_note_kernel("conv_small_wgrad_kernel<%d, %d>", BN, KPW);
     conv_small_wgrad_kernel<BN, KPW><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);
     return 1;
 }
@@ -1251,6 +1257,7 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     if (mpb < 256) mpb = 256;
     const int splits = cdiv(d->M, mpb);
     dim3 grid(ntiles, ktiles, splits);
+    sehip_note_kernel("wgrad_kernel<%d, %d, %d>", bnw, bnw >= 64 ? 2 : 1, bnw >= 64 ? 2 : 4);
     if (bnw == 16) wgrad_kernel<16, 1, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
     else if (bnw == 32) wgrad_kernel<32, 1, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
     else if (bnw == 64) wgrad_kernel<64, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
