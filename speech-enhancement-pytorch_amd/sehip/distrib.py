@@ -50,10 +50,14 @@ def init_distributed(backend=None):
     if world == 1:
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: several ranks on ONE GPU (RCCL refuses duplicate devices, gloo moves CUDA tensors through the host)
+    backend = backend or os.environ.get("SEHIP_DIST_BACKEND")
+    if "SEHIP_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["SEHIP_LOCAL_DEVICE"])
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

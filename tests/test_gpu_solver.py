@@ -135,3 +135,21 @@ def test_graph_replay_matches_eager_steps(tmp_path):
     for a, b in zip(l0[1:], l1[1:]):
         assert abs(a[0] - b[0]) < 0.03 and abs(a[1] - b[1]) < 1e-2 * max(1.0, abs(a[1]))
     assert max_abs(p0, p1) < 3 * 2 * 3e-4
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 path of bench.py / Solver (rank-0 broadcast, flat-gradient all-reduce between the two hipGraphs, max-over-
+    ranks timing) with two processes sharing cuda:0 over gloo (RCCL refuses two ranks on one device)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SEHIP_DIST_BACKEND="gloo", SEHIP_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "4", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+    assert out["final_loss"] == out["final_loss"]  # not NaN
