@@ -137,7 +137,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraphs")
+    ap.add_argument("--graph", action="store_true", help="replay the step as two captured hipGraphs instead of launching "
+                    "every kernel from Python (measured slower: graph replay serialises the side-stream weight gradients)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -164,6 +165,7 @@ def main():
         torch.cuda.synchronize()
 
     note(f"model built, batch staged on {dev}; warm-up {args.warmup} steps")
+    args.eager = not args.graph
     step_fn = solver.train_step if args.eager else solver.train_step_graphed
     for _ in range(args.warmup):
         step_fn(mixture, sources)

@@ -655,6 +655,8 @@ class DCCRNWorkspace:
         self.bn_coef = {pre: torch.zeros(cr, 16, dtype=torch.float32, device=device) for pre, cr in st.bn}
         self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
+        import os
+        self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self._bind()
 
     # ---- descriptors ---------------------------------------------------------------------------
@@ -740,7 +742,16 @@ class DCCRNWorkspace:
         call("sehip_gemm", C.byref(self.desc[name]), stream())
 
     def wgrad(self, name):
-        call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), stream())
+        """Weight gradients are side work (nothing in the backward chain consumes them): they go to a second HIP stream
+        and fill the ~248 CUs the persistent LSTM kernels (8 workgroups) and the latency-bound BatchNorm passes leave
+        idle.  The side stream waits for everything enqueued so far on the main stream (which includes the producer of
+        dOut); backward() joins the two streams before the gradients are un-packed."""
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), main.cuda_stream)
+            return
+        self.side.wait_stream(main)
+        call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), self.side.cuda_stream)
 
     # ---- BatchNorm helpers ---------------------------------------------------------------------
     def _bn_ptrs(self, pre, params, buffers, nbt):
@@ -842,5 +853,7 @@ class DCCRNWorkspace:
             if i > 0:
                 self.gemm(f"enc{i}.dg0")
                 self.gemm(f"enc{i}.dg1")
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
         return grads
