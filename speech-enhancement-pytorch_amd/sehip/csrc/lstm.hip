@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     const int bc = bvalid ? b : B - 1;
     const float* pre = (part ? pre1 : pre0) + ((size_t)bc * T) * (2 * G4) + lstm * G4 + 16 * w + 4 * ug;
     const size_t obase = ((size_t)combo * B + bc) * T;
+    const int ntiles = gridDim.x >> 2;
 
     // W_hh fragments: gate g, k-step s: rows g*64 + 16w + (lane&15), cols 32 s + 8 (lane>>4) ..
     bf16x8 wf[4][2];
@@ -90,12 +91,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         if (bvalid) {
             const size_t o = obase + t;
             *reinterpret_cast<uint2*>(hout + o * H + 16 * w + 4 * ug) = hp;
-            *reinterpret_cast<float4*>(cout + o * H + 16 * w + 4 * ug) = make_float4(c[0], c[1], c[2], c[3]);
-            bf16_raw* gp = gates + o * G4 + 16 * w + 4 * ug;
+        }
+        {   // gates / cell state are private to lstm_bwd_kernel: stored tile-major so that every store instruction of a
+            // wave is one contiguous 512 B / 1 KB run ([combo][tile][t][wave][gate][lane]) instead of 16 partial lines
+            const size_t rec = ((size_t)(combo * ntiles + tile) * T + t);
+            *reinterpret_cast<float4*>(cout + rec * 1024 + w * 256 + lane * 4) = make_float4(c[0], c[1], c[2], c[3]);
+            bf16_raw* gp = gates + rec * 4096 + w * 1024 + lane * 4;
             *reinterpret_cast<uint2*>(gp) = make_uint2(pack_bf2(gi[0], gi[1]), pack_bf2(gi[2], gi[3]));
-            *reinterpret_cast<uint2*>(gp + H) = make_uint2(pack_bf2(gf[0], gf[1]), pack_bf2(gf[2], gf[3]));
-            *reinterpret_cast<uint2*>(gp + 2 * H) = make_uint2(pack_bf2(gg[0], gg[1]), pack_bf2(gg[2], gg[3]));
-            *reinterpret_cast<uint2*>(gp + 3 * H) = make_uint2(pack_bf2(go[0], go[1]), pack_bf2(go[2], go[3]));
+            *reinterpret_cast<uint2*>(gp + 256) = make_uint2(pack_bf2(gf[0], gf[1]), pack_bf2(gf[2], gf[3]));
+            *reinterpret_cast<uint2*>(gp + 512) = make_uint2(pack_bf2(gg[0], gg[1]), pack_bf2(gg[2], gg[3]));
+            *reinterpret_cast<uint2*>(gp + 768) = make_uint2(pack_bf2(go[0], go[1]), pack_bf2(go[2], go[3]));
         }
         lds_barrier();
         cur ^= 1;
@@ -134,26 +139,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
     f32x4 dhrec = (f32x4){0.f, 0.f, 0.f, 0.f};
     // software pipeline: the (gates, dh) of step t-1 and the cell state of step t-2 are requested while step t runs
     struct StepIn { uint2 gi, gf, gg, go, dh; };
+    const int ntiles = gridDim.x >> 2;
+    const size_t rbase = (size_t)(combo * ntiles + tile) * T;  // tile-major records written by lstm_fwd_kernel
+    const float* cbase = cst + w * 256 + lane * 4;
     auto load_step = [&](int t) {
         StepIn v;
-        const bf16_raw* gp = gates + (sbase + t) * G4 + uo;
+        const bf16_raw* gp = gates + (rbase + t) * 4096 + w * 1024 + lane * 4;
         v.gi = *reinterpret_cast<const uint2*>(gp);
-        v.gf = *reinterpret_cast<const uint2*>(gp + H);
-        v.gg = *reinterpret_cast<const uint2*>(gp + 2 * H);
-        v.go = *reinterpret_cast<const uint2*>(gp + 3 * H);
+        v.gf = *reinterpret_cast<const uint2*>(gp + 256);
+        v.gg = *reinterpret_cast<const uint2*>(gp + 512);
+        v.go = *reinterpret_cast<const uint2*>(gp + 768);
         v.dh = *reinterpret_cast<const uint2*>(dhp + (size_t)t * H);
         return v;
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 c_t = *reinterpret_cast<const float4*>(cst + (sbase + T - 1) * H + uo);
-    float4 c_m1 = T > 1 ? *reinterpret_cast<const float4*>(cst + (sbase + T - 2) * H + uo) : zero4;
+    float4 c_t = *reinterpret_cast<const float4*>(cbase + (rbase + T - 1) * 1024);
+    float4 c_m1 = T > 1 ? *reinterpret_cast<const float4*>(cbase + (rbase + T - 2) * 1024) : zero4;
     StepIn in = load_step(T - 1);
     int cur = 0;
     for (int t = T - 1; t >= 0; --t) {
         StepIn nxt = in;
         if (t > 0) nxt = load_step(t - 1);
         float4 c_m2 = zero4;
-        if (t > 1) c_m2 = *reinterpret_cast<const float4*>(cst + (sbase + t - 2) * H + uo);
+        if (t > 1) c_m2 = *reinterpret_cast<const float4*>(cbase + (rbase + t - 2) * 1024);
         const float gi[4] = {bf2f(in.gi.x & 0xffff), bf2f(in.gi.x >> 16), bf2f(in.gi.y & 0xffff), bf2f(in.gi.y >> 16)};
         const float gf[4] = {bf2f(in.gf.x & 0xffff), bf2f(in.gf.x >> 16), bf2f(in.gf.y & 0xffff), bf2f(in.gf.y >> 16)};
         const float gg[4] = {bf2f(in.gg.x & 0xffff), bf2f(in.gg.x >> 16), bf2f(in.gg.y & 0xffff), bf2f(in.gg.y >> 16)};

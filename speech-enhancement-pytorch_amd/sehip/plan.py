@@ -604,8 +604,11 @@ class DCCRNWorkspace:
         F0 = st.F0
         self.bufs = {}
 
-        def add(name, tst, f, c, t0=0, dtype=BF16, lead=None):
-            shape = (B, tst, f, c) if lead is None else (lead, B, tst, f, c)
+        Bp = round_up(B, 16)  # gate / cell-state records of the LSTM kernels are stored per 16-row batch tile
+
+        def add(name, tst, f, c, t0=0, dtype=BF16, lead=None, batch=None):
+            bb = B if batch is None else batch
+            shape = (bb, tst, f, c) if lead is None else (lead, bb, tst, f, c)
             t = torch.zeros(shape, dtype=dtype, device=device)
             if lead is None:
                 self.bufs[name] = Buf(t, tst, f, c, t0)
@@ -629,8 +632,8 @@ class DCCRNWorkspace:
                 add(f"pre{layer}_{tag}", T, 1, 8 * h, dtype=torch.float32)
                 add(f"dpre{layer}_{tag}", T, 1, 8 * h)
             add(f"h{layer}", T, 1, h, lead=4)
-            add(f"gates{layer}", T, 1, 4 * h, lead=4)
-            add(f"c{layer}", T, 1, h, dtype=torch.float32, lead=4)
+            add(f"gates{layer}", T, 1, 4 * h, lead=4, batch=Bp)
+            add(f"c{layer}", T, 1, h, dtype=torch.float32, lead=4, batch=Bp)
         for tag in "ri":
             add(f"dx2_{tag}", T, 1, h); add(f"dxo_{tag}", T, 1, h)
         for j in range(5):
