@@ -36,25 +36,25 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 // partials of all blocks in double precision).
 template <int NS>
 __device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr, float* __restrict__ part, int stride,
-                                               float* lds /* 256 floats */) {
-    const int tid = threadIdx.x;
+                                               float* lds /* [4][NS*8][nq] floats */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* out = part + (size_t)blockIdx.x * stride;
+    // fold the lanes of a wave that share a chunk column (nq divides 64), park the wave partials in LDS, ONE barrier,
+    // then NS*8*nq threads add the four waves
 #pragma unroll
     for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // first fold the lanes of a wave that share a column (nq divides 64), then across waves through LDS
             float v = s[a][j];
             for (int o = 32; o >= nq; o >>= 1) v += __shfl_xor(v, o, 64);
-            __syncthreads();
-            if ((tid & 63) < nq) lds[(tid >> 6) * nq + (tid & 63)] = v;
-            __syncthreads();
-            if (tid < nq) {
-                float t = 0.f;
-                for (int w = 0; w < 4; ++w) t += lds[w * nq + tid];
-                out[(size_t)a * Cr + tid * 8 + j] = t;
-            }
+            if (lane < nq) lds[(w * NS * 8 + a * 8 + j) * nq + lane] = v;
         }
+    __syncthreads();
+    for (int i = tid; i < NS * 8 * nq; i += 256) {
+        const float t = lds[i] + lds[NS * 8 * nq + i] + lds[2 * NS * 8 * nq + i] + lds[3 * NS * 8 * nq + i];
+        const int aj = i / nq, q = i - aj * nq;
+        out[(size_t)(aj >> 3) * Cr + q * 8 + (aj & 7)] = t;
+    }
 }
 
 // sum of part[b][idx] over the blocks, by one wave
@@ -67,7 +67,7 @@ __device__ __forceinline__ double wave_reduce_partials(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restrict__ y, long rows, int Cr,
                                                         float* __restrict__ part /* [nblk][5*Cr] */) {
-    __shared__ float lds[256];
+    __shared__ float lds[4 * 5 * 8 * 32];
     const int nq = Cr >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     float s[5][8];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const bf16_raw* __r
                                                              const bf16_raw* __restrict__ y, const float* __restrict__ coef,
                                                              const float* __restrict__ slope, long rows, int Cr, int F,
                                                              int Tst, int tfirst, float* __restrict__ part) {
-    __shared__ float lds[256];
+    __shared__ float lds[4 * 6 * 8 * 32];
     const int nq = Cr >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     const int C = 2 * Cr;
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const bf16_raw* __re
 // ---------------------------------------------------------------------------------------------
 static int check_cbn(const char* who, long rows, int Cr) {
     SEHIP_REQUIRE(rows > 0, "%s: empty input", who);
-    SEHIP_REQUIRE(Cr >= 8 && Cr <= 512 && (Cr & (Cr - 1)) == 0,
-                  "%s: complex channels Cr=%d must be a power of two in [8, 512]", who, Cr);
+    SEHIP_REQUIRE(Cr >= 8 && Cr <= 256 && (Cr & (Cr - 1)) == 0,
+                  "%s: complex channels Cr=%d must be a power of two in [8, 256]", who, Cr);
     return 0;
 }
 static int grid_for(long work_items) {
@@ -386,7 +386,7 @@ static int apply_blocks(long rows, int Cr) {
 static int stat_blocks(long rows, int Cr) {
     const int rpb = 256 / (Cr >> 3);
     long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
-    if (g > 256) g = 256;
+    if (g > 512) g = 512;
     if (g < 1) g = 1;
     return (int)g;
 }
