@@ -57,11 +57,23 @@ __device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr
     }
 }
 
-// sum of part[b][idx] over the blocks, by one wave
-__device__ __forceinline__ double wave_reduce_partials(const float* __restrict__ part, int nblk, int stride, int idx) {
-    double acc = 0.0;
-    for (int b = threadIdx.x & 63; b < nblk; b += 64) acc += (double)part[(size_t)b * stride + idx];
-    return wave_sum_d(acc);
+// sums of part[b][idx0 + k*Cr] (k < NS) over the blocks, by one wave, in ONE pass (all NS loads of a trip in flight)
+template <int NS>
+__device__ __forceinline__ void wave_reduce_partials(const float* __restrict__ part, int nblk, int stride, int idx0, int Cr,
+                                                     double (&out)[NS]) {
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x & 63; b < nblk; b += 64) {
+        const float* p = part + (size_t)b * stride + idx0;
+        float v[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = p[(size_t)k * Cr];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += (double)v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) out[k] = wave_sum_d(acc[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -114,10 +126,9 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
     float mr, mi, vrr, vri, vii;
     if (training) {
         const double n = (double)rows;
-        const double a0 = wave_reduce_partials(part, nblk, 5 * Cr, c), a1 = wave_reduce_partials(part, nblk, 5 * Cr, Cr + c);
-        const double a2 = wave_reduce_partials(part, nblk, 5 * Cr, 2 * Cr + c);
-        const double a3 = wave_reduce_partials(part, nblk, 5 * Cr, 3 * Cr + c);
-        const double a4 = wave_reduce_partials(part, nblk, 5 * Cr, 4 * Cr + c);
+        double a[5];
+        wave_reduce_partials<5>(part, nblk, 5 * Cr, c, Cr, a);
+        const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
         if (threadIdx.x != 0) return;
         const double dmr = a0 / n, dmi = a1 / n;
         mr = (float)dmr; mi = (float)dmi;
@@ -251,14 +262,13 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
                                         float* __restrict__ gBi, float* __restrict__ gslope, float* __restrict__ bcoef) {
     const int c = blockIdx.x;
     const int st = 6 * Cr + 1;
-    const float sdr = (float)wave_reduce_partials(part, nblk, st, c), sdi = (float)wave_reduce_partials(part, nblk, st, Cr + c);
-    const float qrr = (float)wave_reduce_partials(part, nblk, st, 2 * Cr + c);
-    const float qri = (float)wave_reduce_partials(part, nblk, st, 3 * Cr + c);
-    const float qir = (float)wave_reduce_partials(part, nblk, st, 4 * Cr + c);
-    const float qii = (float)wave_reduce_partials(part, nblk, st, 5 * Cr + c);
+    double a[6];
+    wave_reduce_partials<6>(part, nblk, st, c, Cr, a);
+    const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
     if (c == 0) {
-        const float ds = (float)wave_reduce_partials(part, nblk, st, 6 * Cr);
-        if (threadIdx.x == 0) gslope[0] = ds;
+        double ds[1];
+        wave_reduce_partials<1>(part, nblk, st, 6 * Cr, Cr, ds);
+        if (threadIdx.x == 0) gslope[0] = (float)ds[0];
     }
     if (threadIdx.x != 0) return;
     const float* k = coef + (size_t)c * COEF_STRIDE;

@@ -304,7 +304,8 @@ class Solver(object):
             if train:
                 step_fn = self.train_step_graphed if _cfg(cfg.solver, "use_graph", False) else self.train_step
                 loss_t, metric_t = step_fn(mixture, sources)
-                pending.append((step, loss_t.clone(), metric_t.clone() if metric_t is not None else None))
+                # (loss / metric live in per-step tensors: no copy needed before the deferred read-back)
+                pending.append((step, loss_t, metric_t.clone() if metric_t is not None else None))
             else:
                 self.model.eval()
                 with torch.no_grad():
