@@ -45,6 +45,10 @@ int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* 
 int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, const float* upstream /*scalar or NULL*/,
                     int rows, int n, float* dest, void* stream);
 
+/* ---- l1 / mse with reduction 'mean' (torch.nn.functional.l1_loss / mse_loss in src/distrib.py:263-268); mode 0 = l1, 1 = mse */
+int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, int mode, double* acc_scratch, float* loss, void* stream);
+int sehip_pointwise_loss_bwd(const float* x, const float* y, long n, int mode, const float* upstream, float* dx, void* stream);
+
 /* ---- optimizer path on one flat fp32 buffer: src/solver.py:487-498 (clip_grad_norm_, optimizer.step, grad_norm
  *      metric) and src/distrib.py:244-261 (Adam / SGD).  mode 0 = Adam, 1 = SGD(momentum=beta1). */
 int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream);

@@ -31,6 +31,8 @@ _PROTOS = {
     "sehip_stft_frames": [I, I, I],
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
+    "sehip_pointwise_loss_fwd": [P, P, L, I, P, P, P],
+    "sehip_pointwise_loss_bwd": [P, P, L, I, P, P, P],
     "sehip_grad_sumsq": [P, L, P, P],
     "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, P],
     "sehip_counter_add": [P, I, P],

@@ -105,3 +105,57 @@ extern "C" int sehip_sisnr_bwd(const float* est, const float* ref, const float* 
     SEHIP_CHECK_LAUNCH("sisnr_bwd");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// l1 / mse (the reference uses torch.nn.functional.l1_loss / mse_loss with reduction 'mean', src/distrib.py:263-268)
+// mode 0: mean |x - y|     mode 1: mean (x - y)^2
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointwise_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long n,
+                                                                 int mode, double* __restrict__ acc) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const float d = x[i] - y[i];
+        a += mode == 0 ? fabsf(d) : d * d;
+    }
+    a = block_sum<4>(a, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)a);
+}
+
+__global__ void pointwise_loss_finalize_kernel(const double* __restrict__ acc, long n, float* __restrict__ loss) {
+    loss[0] = (float)(acc[0] / (double)n);
+}
+
+__global__ __launch_bounds__(256) void pointwise_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long n,
+                                                                 int mode, const float* __restrict__ upstream,
+                                                                 float* __restrict__ dx) {
+    const float up = (upstream ? upstream[0] : 1.f) / (float)n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const float d = x[i] - y[i];
+        dx[i] = mode == 0 ? (d > 0.f ? up : (d < 0.f ? -up : 0.f)) : 2.f * d * up;
+    }
+}
+
+extern "C" int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, int mode, double* acc, float* loss,
+                                        void* stream) {
+    SEHIP_REQUIRE(n > 0 && (mode == 0 || mode == 1), "pointwise_loss_fwd: bad arguments (n=%ld mode=%d)", n, mode);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(double), st);
+    SEHIP_REQUIRE(e == hipSuccess, "pointwise_loss_fwd: memset failed: %s", hipGetErrorString(e));
+    int grid = cdiv(n, 256 * 16);
+    if (grid > 1024) grid = 1024;
+    pointwise_loss_fwd_kernel<<<grid, 256, 0, st>>>(x, y, n, mode, acc);
+    pointwise_loss_finalize_kernel<<<1, 1, 0, st>>>(acc, n, loss);
+    SEHIP_CHECK_LAUNCH("pointwise_loss_fwd");
+    return 0;
+}
+
+extern "C" int sehip_pointwise_loss_bwd(const float* x, const float* y, long n, int mode, const float* upstream, float* dx,
+                                        void* stream) {
+    SEHIP_REQUIRE(n > 0 && (mode == 0 || mode == 1), "pointwise_loss_bwd: bad arguments (n=%ld mode=%d)", n, mode);
+    int grid = cdiv(n, 256 * 8);
+    if (grid > 2048) grid = 2048;
+    pointwise_loss_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, n, mode, upstream, dx);
+    SEHIP_CHECK_LAUNCH("pointwise_loss_bwd");
+    return 0;
+}

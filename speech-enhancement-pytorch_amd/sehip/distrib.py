@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import SehipError
-from .loss import loss_sisdr
+from .loss import loss_sisdr, l1_loss, mse_loss
 from .model.dccrn import DCCRN
 from .optim import FlatOptimizer
 from .utils import obj2dict
@@ -36,10 +36,14 @@ def get_optimizer(config, model):
 
 
 def get_loss_function(config):
+    if config.loss == "l1":  # mae
+        return l1_loss
+    if config.loss == "mse":
+        return mse_loss
     if config.loss == "si-sdr":
         return loss_sisdr
-    if config.loss in ("l1", "mse", "psa"):
-        raise SehipError(f"loss '{config.loss}' has no HIP path yet (built: si-sdr)")
+    if config.loss == "psa":
+        raise SehipError("loss 'psa' (phase-sensitive spectral approximation, STFT-domain models) has no HIP path yet")
     raise ValueError(f"Loss function {config.loss} cannot use...")
 
 

@@ -33,3 +33,40 @@ def loss_sisdr(inputs, targets):
 
 def si_snr(s1, s2):
     return -loss_sisdr(s1, s2)
+
+
+class _PointwiseLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, mode):
+        from ._lib import call, ptr, stream, require_gpu
+        require_gpu(x, "l1/mse loss")
+        xf, yf = x.contiguous().float(), y.contiguous().float()
+        acc = torch.zeros(1, dtype=torch.float64, device=x.device)
+        loss = torch.empty(1, device=x.device)
+        call("sehip_pointwise_loss_fwd", ptr(xf), ptr(yf), xf.numel(), mode, ptr(acc), ptr(loss), stream())
+        ctx.save_for_backward(xf, yf)
+        ctx.mode, ctx.shape = mode, x.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import call, ptr, stream
+        xf, yf = ctx.saved_tensors
+        dx = torch.empty_like(xf)
+        call("sehip_pointwise_loss_bwd", ptr(xf), ptr(yf), xf.numel(), ctx.mode, ptr(g.reshape(1).contiguous().float()), ptr(dx),
+             stream())
+        return dx.view(ctx.shape), None, None
+
+
+def l1_loss(inputs, targets):
+    """torch.nn.functional.l1_loss(reduction='mean') as used by src/distrib.py:264-265."""
+    if inputs.shape != targets.shape:
+        raise SehipError(f"l1_loss: shape mismatch {tuple(inputs.shape)} vs {tuple(targets.shape)}")
+    return _PointwiseLoss.apply(inputs, targets, 0)
+
+
+def mse_loss(inputs, targets):
+    """torch.nn.functional.mse_loss(reduction='mean') as used by src/distrib.py:266-267."""
+    if inputs.shape != targets.shape:
+        raise SehipError(f"mse_loss: shape mismatch {tuple(inputs.shape)} vs {tuple(targets.shape)}")
+    return _PointwiseLoss.apply(inputs, targets, 1)

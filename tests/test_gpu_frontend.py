@@ -124,3 +124,20 @@ def test_clip_adam_matches_oracle(dev):
         assert abs(float(metric[0]) - want_metric) < 1e-3 * max(1.0, want_metric)
         ref_p = torch.cat([params[str(i)] for i in range(len(sizes))])
         assert max_abs(p.cpu(), ref_p) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["l1", "mse"])
+def test_l1_mse_losses(dev, name):
+    from sehip import distrib, utils
+    fn = distrib.get_loss_function(utils.dict2obj({"loss": name}))
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 1, 5000, generator=g)
+    y = torch.randn(3, 1, 5000, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = (torch.nn.functional.l1_loss if name == "l1" else torch.nn.functional.mse_loss)(xr, y)
+    ref.backward()
+    xd = x.to(dev).requires_grad_(True)
+    out = fn(xd, y.to(dev))
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    assert rel_err(xd.grad.cpu(), xr.grad) < 1e-6
