@@ -167,6 +167,12 @@ def main():
     note(f"model built, batch staged on {dev}; warm-up {args.warmup} steps")
     args.eager = not args.graph
     step_fn = solver.train_step if args.eager else solver.train_step_graphed
+    # the dependent chain of the step runs on a high-priority stream; the weight gradients (side stream, default
+    # priority) then only take the CUs the chain leaves idle
+    lo, hi = torch.cuda.Stream.priority_range()
+    main_stream = torch.cuda.Stream(device=dev, priority=hi) if os.environ.get("SEHIP_BENCH_PRIO", "1") == "1" else torch.cuda.current_stream()
+    main_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(main_stream)
     for _ in range(args.warmup):
         step_fn(mixture, sources)
     sync()
