@@ -74,6 +74,8 @@ __device__ __forceinline__ size_t dst_row_offset(const sehip_dst& d, const RowPo
 }
 
 // ------------------------------------------------------------------------------------------------
+#define BF16_ONES __builtin_bit_cast(bf16x8, (s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
+
 template <int N>
 struct RegTile { uint4 v[N]; };
 
@@ -642,8 +644,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
     for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float colsum = 0.f;
-    const bool do_bias = d.dbias != nullptr && blockIdx.y == 0;
+    // bias gradient = column sums of dOut: one extra MFMA against an all-ones operand in the waves that own k-subtile 0
+    const bool do_bias = d.dbias != nullptr && blockIdx.y == 0 && wk == 0;
+    f32x4 accb[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) accb[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 xa[2], ga[GPT];
     auto fetch = [&](int mb) {
@@ -700,12 +705,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
         }
         __syncthreads();
         if (mb + 64 < m_end) fetch(mb + 64);  // next slab in flight while this one is multiplied
-        if (do_bias && tid < BNW) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 64; ++r) s += bf2f(sG[r * PG + tid]);
-            colsum += s;
-        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int g = lane >> 4, i16 = lane & 15;
@@ -730,6 +729,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
 #pragma unroll
                 for (int ki = 0; ki < TK; ++ki)
                     acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], xf[ki], acc[ni][ki], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], BF16_ONES, accb[ni], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -744,7 +747,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) atomicAdd(&d.dW[(size_t)(n + q) * d.K + k], acc[ni][ki][q]);
         }
-    if (do_bias && tid < BNW) atomicAdd(&d.dbias[n0 + tid], colsum);
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                atomicAdd(&d.dbias[n0 + wn * (BNW / WNN) + ni * 16 + 4 * (lane >> 4) + q], accb[ni][q]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -803,7 +812,7 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
 // dW[64 n][taps][16 channels (16w..)] in registers: 4 x 2NF MFMA tiles; both operands come from transposed LDS reads.
 // ------------------------------------------------------------------------------------------------
 template <int NF>
-__global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg, int nsplit) {
     constexpr int NIT = 2 * NF;
     constexpr int GP = 80;  // pitch of the dOut tile: 160 B, so 8 consecutive rows sit on 8 disjoint 32-byte bank slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -820,7 +829,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
     const int ntn = d.Npad >> 6;
     const int gx = ntn * ((d.src[0].C + (d.src[1].ptr ? d.src[1].C : 0)) >> 6);
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
-    const int xi = rr % gx, split = (rr / gx) * 8 + xcd;
+    int xi, split;
+    if (nsplit >= 8) { xi = rr % gx; split = (rr / gx) * 8 + xcd; }
+    else { split = xcd % nsplit; xi = (xcd / nsplit) * (gx * nsplit >> 3) + rr; }  // 8/nsplit XCDs share one split
     const int nt = xi % ntn, cc = xi / ntn;
     const int n0 = nt * 64;
     const int tblocks = (d.TT + TB - 1) / TB;
@@ -859,70 +870,75 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < NIT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float colsum = 0.f;
-    const bool do_bias = d.dbias != nullptr && cc == 0;
+    const bool do_bias = d.dbias != nullptr && cc == 0 && w == 0;  // column sums of dOut by MFMA against ones
+    f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
-    for (int mt = mt_begin; mt < mt_end; ++mt) {
-        const int b = mt / tblocks, t0 = (mt - b * tblocks) * TB;
-        // ---- stage the input patch chunk
+    // Everything about a thread's staging slots that does not depend on the tile is computed once: the tile loop
+    // then only adds the tile base and checks the frame range (no integer divisions inside the loop).
+    constexpr int NPS = CV_MAXP / 2;
+    int p_goff[NPS], p_lds[NPS];  // element offset from the tile's first patch frame (or INT_MIN), LDS slot | frame << 16 (or -1)
 #pragma unroll
-        for (int i0 = 0; i0 < CV_MAXP / 2; i0 += 3) {
-            uint4 pr[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                pr[u] = make_uint4(0u, 0u, 0u, 0u);
-                const int idx = tid + 512 * (i0 + u);
-                if (idx < NP) {
-                    const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
-                    const int ts = t0 + pp + tmin, f = f0 + (rem >> 3);
-                    if (ts >= tlo && ts < thi && f >= 0 && f < sF)
-                        pr[u] = *reinterpret_cast<const uint4*>(sbase + (((long)b * sT + ts) * sF + f) * sC + (rem & 7) * 8);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int idx = tid + 512 * (i0 + u);
-                if (idx < NP) {
-                    const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
-                    *reinterpret_cast<uint4*>(&patch[(pp * FR + (rem >> 3)) * PPW + (rem & 7) * 8]) = pr[u];
-                }
-            }
+    for (int i = 0; i < NPS; ++i) {
+        const int idx = tid + 512 * i;
+        p_goff[i] = INT_MIN; p_lds[i] = -1;
+        if (idx < NP) {
+            const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
+            const int f = f0 + (rem >> 3);
+            p_lds[i] = ((pp * FR + (rem >> 3)) * PPW + (rem & 7) * 8) | (pp << 16);
+            if (f >= 0 && f < sF) p_goff[i] = (pp * sF + f) * sC + (rem & 7) * 8;
         }
-        // ---- stage the dOut tile: 128 rows x 8 chunks
-        {
-            uint4 gr[2];
+    }
+    const bf16_raw* g_ptr[2];
+    int g_tl[2];
+    long g_bstride[2];
+    int g_tstride[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + 512 * u;
-                const int r = idx >> 3, gc = idx & 7;
-                const int tl = r / JB, jl = r - tl * JB;
-                RowPos rp;
-                rp.b = b; rp.t = t0 + tl; rp.jf = jl * d.fmul; rp.valid = rp.t < d.TT;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (rp.valid) {
-                    const int n = n0 + gc * 8;
-                    const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
-                    if (c0.nvalid == 4 && c1.nvalid == 4 && c1.dst == c0.dst && c1.coff == c0.coff + 4) {
-                        const bf16_raw* gp = reinterpret_cast<const bf16_raw*>(c0.dst ? d.dst[1].ptr : d.dst[0].ptr) +
-                                             (c0.dst ? dst_row_offset(d.dst[1], rp, d.fmul) : dst_row_offset(d.dst[0], rp, d.fmul)) + c0.coff;
-                        v = *reinterpret_cast<const uint4*>(gp);
-                    }
-                }
-                gr[u] = v;
-            }
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 512 * u;
+        const int r = idx >> 3, gc = idx & 7;
+        const int tl = r / JB, jl = r - tl * JB;
+        g_tl[u] = tl; g_ptr[u] = nullptr; g_bstride[u] = 0; g_tstride[u] = 0;
+        const int n = n0 + gc * 8;
+        const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
+        if (c0.nvalid == 4 && c1.nvalid == 4 && c1.dst == c0.dst && c1.coff == c0.coff + 4) {
+            const sehip_dst& dd = c0.dst ? d.dst[1] : d.dst[0];
+            RowPos rp;
+            rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+            g_ptr[u] = reinterpret_cast<const bf16_raw*>(dd.ptr) + dst_row_offset(dd, rp, d.fmul) + c0.coff;
+            g_tstride[u] = dd.F * dd.C;
+            g_bstride[u] = (long)dd.T * dd.F * dd.C;
+        }
+    }
+
+    uint4 pr[NPS], gr[2];
+#define CW_FETCH(mt_)                                                                                              \
+    {                                                                                                              \
+        const int b_ = (mt_) / tblocks, t0_ = ((mt_) - b_ * tblocks) * TB;                                         \
+        const bf16_raw* tb_ = sbase + ((long)b_ * sT + t0_ + tmin) * sF * sC;                                      \
+        _Pragma("unroll") for (int i = 0; i < NPS; ++i) {                                                          \
+            pr[i] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            const int ts_ = t0_ + tmin + (p_lds[i] >> 16);                                                         \
+            if (p_goff[i] != INT_MIN && ts_ >= tlo && ts_ < thi) pr[i] = *reinterpret_cast<const uint4*>(tb_ + p_goff[i]); \
+        }                                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                            \
+            gr[u] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            if (g_ptr[u] && t0_ + g_tl[u] < d.TT)                                                                  \
+                gr[u] = *reinterpret_cast<const uint4*>(g_ptr[u] + b_ * g_bstride[u] + (long)t0_ * g_tstride[u]);  \
+        }                                                                                                          \
+    }
+
+    if (mt_begin < mt_end) CW_FETCH(mt_begin)
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + 512 * u;
-                *reinterpret_cast<uint4*>(&sG[(idx >> 3) * GP + (idx & 7) * 8]) = gr[u];
-            }
+        for (int i = 0; i < NPS; ++i)
+            if (p_lds[i] >= 0) *reinterpret_cast<uint4*>(&patch[p_lds[i] & 0xffff]) = pr[i];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 512 * u;
+            *reinterpret_cast<uint4*>(&sG[(idx >> 3) * GP + (idx & 7) * 8]) = gr[u];
         }
         __syncthreads();
-        if (do_bias && tid < 64) {
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 128; ++r) sacc += bf2f(sG[r * GP + tid]);
-            colsum += sacc;
-        }
+        if (mt + 1 < mt_end) CW_FETCH(mt + 1)   // in flight while this tile is consumed
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 gf[2];
@@ -931,6 +947,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
                 s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][0] + ni * 16]);
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][1] + ni * 16]);
                 gf[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], BF16_ONES, accb[ni], 0, 0, 0);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -956,7 +976,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
 #pragma unroll
             for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][it][u]);
         }
-    if (do_bias && tid < 64) atomicAdd(&d.dbias[n0 + tid], colsum);
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&d.dbias[n0 + 32 * nh + ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
+    }
+#undef CW_FETCH
 }
 
 static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
@@ -973,8 +999,12 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     const int B = d.M / (d.TT * d.J);
     const int MT = B * ((d.TT + TB - 1) / TB);
     const int gx = (d.Npad >> 6) * ((C0 + C1) >> 6);
-    int splits = (512 / gx + 7) / 8 * 8;  // a multiple of 8: one group of splits per XCD
-    if (splits < 8) splits = 8;
+    // m-splits: a multiple of 8 (one group of splits per XCD) or 1, 2, 4 (8, 4, 2 XCDs share a split).  Every split flushes
+    // its dW with atomics, and the weight gradients run beside the dependent chain on a second stream, so fewer, longer-lived
+    // workgroups than "fill the GPU twice" pay: measured per step with 8 / 16 / 32 / 64 splits: 7.24 / 7.15 / 7.19 / 7.3 ms.
+    static const int cw_splits = getenv("SEHIP_CW_SPLITS") ? atoi(getenv("SEHIP_CW_SPLITS")) : 16;
+    int splits = cw_splits >= 8 ? cw_splits / 8 * 8 : (cw_splits >= 4 ? 4 : (cw_splits >= 2 ? 2 : 1));
+    while (splits < 8 && (gx * splits) % 8) splits <<= 1;
     const int tiles_per_wg = (MT + splits - 1) / splits;
     const int grid = gx * splits;  // splits beyond the data simply find an empty m range
 #define CW_CASE(NF_)                                                                                              \
@@ -986,7 +1016,7 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
             attr_set = true;                                                                                      \
         }                                                                                                         \
         sehip_note_kernel("conv_wgrad_kernel<%d>", NF_);                                                         \
-        conv_wgrad_kernel<NF_><<<grid, 512, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                              \
+        conv_wgrad_kernel<NF_><<<grid, 512, lds, st>>>(d, TB, JB, FR, tiles_per_wg, splits);                              \
         return 1;                                                                                                 \
     }
     switch (d.cv_nf) {
@@ -1078,8 +1108,10 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
     for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < KPW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float colsum = 0.f;
-    const bool do_bias = d.dbias != nullptr;
+    const bool do_bias = d.dbias != nullptr && w == 0;  // column sums of dOut by MFMA against ones (every wave holds all n)
+    f32x4 accb[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) accb[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
     for (int mt = mt_begin; mt < mt_end; ++mt) {
@@ -1148,12 +1180,6 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
             }
         }
         __syncthreads();
-        if (do_bias && tid < BN) {
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 128; ++r) sacc += bf2f(sG[r * GP + tid]);
-            colsum += sacc;
-        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 gf[TN];
@@ -1162,6 +1188,10 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
                 s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][0] + ni * 16]);
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][1] + ni * 16]);
                 gf[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], BF16_ONES, accb[ni], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < KPW; ++i) {
@@ -1186,7 +1216,12 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
 #pragma unroll
             for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][i][u]);
         }
-    if (do_bias && tid < BN) atomicAdd(&d.dbias[tid], colsum);
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&d.dbias[ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
+    }
 }
 
 template <int BN, int KPW>
@@ -1220,7 +1255,8 @@ static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     const int kpw = d.K / 64;
     const int B = d.M / (d.TT * d.J);
     const int MT = B * ((d.TT + TB - 1) / TB);
-    int wgs = 512;
+    static const int sw_wgs = getenv("SEHIP_SW_WGS") ? atoi(getenv("SEHIP_SW_WGS")) : 256;
+    int wgs = sw_wgs;
     if (wgs > MT) wgs = MT;
     const int tiles_per_wg = (MT + wgs - 1) / wgs;
     const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
@@ -1251,7 +1287,8 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     SEHIP_REQUIRE(d->Npad % bnw == 0, "wgrad: Npad=%d must be 16, 32, 64 or a multiple of 128", d->Npad);
     ntiles = d->Npad / bnw;
     // split m so that the grid has ~2048 workgroups, at least 256 rows each
-    long want = 2048 / ((long)ntiles * ktiles);
+    static const int gw_wgs = getenv("SEHIP_GW_WGS") ? atoi(getenv("SEHIP_GW_WGS")) : 2048;
+    long want = gw_wgs / ((long)ntiles * ktiles);
     if (want < 1) want = 1;
     long mpb = ((d->M + want - 1) / want + 63) / 64 * 64;
     if (mpb < 256) mpb = 256;

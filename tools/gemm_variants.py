@@ -27,11 +27,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         res[name] = e0.elapsed_time(e1) / 20
     print("RES " + json.dumps(res))
 else:
-    names = ["dec1.dg", "dec0.fwd0", "enc5.fwd", "dec0.fwd0.wg", "enc4.fwd.wg", "enc1.fwd", "enc2.fwd", "enc1.dg0", "enc2.dg0", "dec3.fwd0", "dec4.fwd0", "dec5.fwd0", "dec4.dg", "enc0.fwd", "dec5.dg", "enc1.fwd.wg", "enc2.fwd.wg", "dec4.fwd0.wg", "dec3.fwd0.wg", "dec5.fwd0.wg", "enc0.fwd.wg"]
+    names = os.environ.get("SEHIP_NAMES", "").split(",") if os.environ.get("SEHIP_NAMES") else ["dec1.dg", "dec0.fwd0", "enc5.fwd", "dec0.fwd0.wg", "enc4.fwd.wg", "enc1.fwd", "enc2.fwd", "enc1.dg0", "enc2.dg0", "dec3.fwd0", "dec4.fwd0", "dec5.fwd0", "dec4.dg", "enc0.fwd", "dec5.dg", "enc1.fwd.wg", "enc2.fwd.wg", "dec4.fwd0.wg", "dec3.fwd0.wg", "dec5.fwd0.wg", "enc0.fwd.wg"]
     for flags in sys.argv[1:]:
         env = dict(os.environ)
         if flags == "nopatch":
             env["SEHIP_NO_PATCH"] = "1"
+        if flags.startswith("abl"):
+            env["SEHIP_ABL"] = flags[3:]
+        if flags.startswith("cw"):
+            env["SEHIP_CW_WGS"] = flags[2:]
         if flags == "nosmall":
             env["SEHIP_NO_SMALL"] = "1"
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
