@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsehip.so")
+LIB_PATH = os.environ.get("SEHIP_LIB") or os.path.join(_HERE, "libsehip.so")   # SEHIP_LIB: A/B of two builds in tools/
 
 
 class SehipError(RuntimeError):

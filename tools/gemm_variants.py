@@ -36,6 +36,8 @@ else:
             env["SEHIP_ABL"] = flags[3:]
         if flags.startswith("cw"):
             env["SEHIP_CW_WGS"] = flags[2:]
+        if flags.startswith("lib:"):
+            env["SEHIP_LIB"] = os.path.join(ROOT, flags[4:])
         if flags == "nosmall":
             env["SEHIP_NO_SMALL"] = "1"
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
