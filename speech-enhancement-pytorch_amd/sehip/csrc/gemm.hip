@@ -74,6 +74,9 @@ __device__ __forceinline__ size_t dst_row_offset(const sehip_dst& d, const RowPo
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16 zero bytes in device memory: staging loads of padded / out-of-range pieces read this instead of branching
+__device__ uint4 sehip_zero16 = {0u, 0u, 0u, 0u};
+
 #define BF16_ONES __builtin_bit_cast(bf16x8, (s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
 
 template <int N>
@@ -381,6 +384,176 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_direct_kernel: conv_gemm_kernel without the weight tile in LDS.  Staging W per K step costs 4 ds_write_b128
+// (13 cycles each on the store path) and two barriers per step, which together took as long as the step's MFMAs.  Here
+// every lane loads its MFMA A-operand fragment (16 consecutive k of one weight row) straight from global memory (the
+// packed weights are L2-resident, 64-byte segments), one step ahead of use; LDS holds only the input patch, and the
+// only barriers are the two around the patch staging of each 64-channel chunk.
+// ------------------------------------------------------------------------------------------------
+template <int TN>
+struct WFrag { uint4 v[2][TN]; };
+
+template <int TN>
+__device__ __forceinline__ WFrag<TN> load_wfrag(const bf16_raw* const (&wp)[TN], int kcol) {
+    WFrag<TN> f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) f.v[ks][ni] = *reinterpret_cast<const uint4*>(wp[ni] + kcol + 32 * ks);
+    return f;
+}
+
+template <int BN, int WN, int WM, int NF>
+__global__ __launch_bounds__(256, 2) void conv_direct_kernel(const sehip_gemm_desc d, int TB, int JB, int FR) {
+    constexpr int BM = 128;
+    constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
+    constexpr int NIT = 2 * NF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_raw* patch = reinterpret_cast<bf16_raw*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const int ntn = d.Npad / BN;
+    const int tblocks = (d.TT + TB - 1) / TB, jblocks = d.J / JB;
+    // XCD-contiguous order, n-tile fastest (see gemm_kernel)
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = logical % ntn;
+    int rest = logical / ntn;
+    const int jb = rest % jblocks; rest /= jblocks;
+    const int tb = rest % tblocks;
+    const int b = rest / tblocks;
+    const int t0 = tb * TB, j0 = jb * JB, n0 = nt * BN;
+    const int f0 = j0 * d.fmul + d.cv_fadd;
+
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int Ctot = C0 + C1;
+    const int ncc = Ctot >> 6;
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const int NP = (TB + 1) * FR * 8;
+
+    const bf16_raw* wp[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+        wp[ni] = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)(n0 + wn * (BN / WN) + ni * 16 + (lane & 15)) * d.K + 8 * (lane >> 4);
+
+    int abase[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * (BM / WM) + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        abase[mi] = (tl * FR + jl * d.fmul) * CV_PITCH + 8 * (lane >> 4);
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    WFrag<TN> cur = load_wfrag<TN>(wp, 0);
+
+    for (int cc = 0; cc < ncc; ++cc) {
+        const bool second = cc * 64 >= C0;
+        {
+            const int sT = second ? d.src[1].T : d.src[0].T, sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+            const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+            const int tfirst = t0 + (second ? tmin1 : tmin0);
+            const bf16_raw* cbase = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) +
+                                    (((long)b * sT + tfirst) * sF + f0) * sC + (cc * 64 - (second ? C0 : 0));
+#pragma unroll
+            for (int i0 = 0; i0 < CV_MAXP; i0 += 4) {
+                uint4 pr[4];
+                int lds_off[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pr[q] = make_uint4(0u, 0u, 0u, 0u);
+                    const int idx = tid + 256 * (i0 + q);
+                    const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
+                    const int r = rem >> 3, c8 = rem & 7;
+                    const int ts = tfirst + pp, f = f0 + r;
+                    lds_off[q] = idx < NP ? (pp * FR + r) * CV_PITCH + c8 * 8 : -1;
+                    if (idx < NP && ts >= tlo && ts < thi && f >= 0 && f < sF)
+                        pr[q] = *reinterpret_cast<const uint4*>(cbase + (pp * sF + r) * sC + c8 * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lds_off[q] >= 0) *reinterpret_cast<uint4*>(&patch[lds_off[q]]) = pr[q];
+            }
+        }
+        __syncthreads();
+        const int dt0 = (second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0);
+        const int dt1 = (second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            WFrag<TN> nxt = cur;
+            if (it + 1 < NIT) nxt = load_wfrag<TN>(wp, (it + 1) * Ctot + cc * 64);
+            else if (cc + 1 < ncc) nxt = load_wfrag<TN>(wp, (cc + 1) * 64);
+            const int kt = it / NF, tap = it - kt * NF;
+            const int toff_e = ((kt ? dt1 : dt0) * FR + tap) * CV_PITCH;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[TM];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + toff_e + 32 * ks]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.v[ks][ni]), af[mi],
+                                                                              acc[ni][mi], 0, 0, 0);
+            }
+            cur = nxt;
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int rr = wm * (BM / WM) + mi * 16 + (lane & 15);
+        const int tl = rr / JB, jl = rr - tl * JB;
+        RowPos r;
+        r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
+        if (!r.valid) continue;
+        const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
+        const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * (lane >> 4);
+            const sehip_nchunk nc = d.ntab[n >> 2];
+            if (nc.nvalid <= 0) continue;
+            store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
+        }
+    }
+}
+
+template <int BN, int WN, int WM>
+static int launch_conv_direct(const sehip_gemm_desc& d, int TB, int JB, int FR, int grid, size_t lds, hipStream_t st) {
+#define CD_CASE(NF_)                                                                                                  \
+    case NF_: {                                                                                                       \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<BN, WN, WM, NF_>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        sehip_note_kernel("conv_direct_kernel<%d, %d, %d, %d>", BN, WN, WM, NF_);                                     \
+        conv_direct_kernel<BN, WN, WM, NF_><<<grid, 256, lds, st>>>(d, TB, JB, FR);                                   \
+        return 1;                                                                                                     \
+    }
+    switch (d.cv_nf) {
+        CD_CASE(2)
+        CD_CASE(3)
+        CD_CASE(5)
+        default: return 0;
+    }
+#undef CD_CASE
+}
+
 template <int BN, int WN, int WM>
 static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int grid, size_t lds, hipStream_t st) {
 #define CV_CASE(NF_)                                                                                                  \
@@ -417,11 +590,16 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
     if ((TB + 1) * FR * 8 > CV_MAXP * 256) return 0;
     const int B = d.M / (d.TT * d.J);
     const int tblocks = (d.TT + TB - 1) / TB;
+    static const int direct = getenv("SEHIP_DIRECT") ? atoi(getenv("SEHIP_DIRECT")) : 0;
     if ((d.Npad & 127) == 0) {
         const int grid = B * tblocks * (d.Npad / 128);
+        if (direct == 1) return launch_conv_direct<128, 4, 1>(d, TB, JB, FR, grid, patch_bytes, st);
+        if (direct == 2) return launch_conv_direct<128, 2, 2>(d, TB, JB, FR, grid, patch_bytes, st);
         return launch_conv<128, 2, 2>(d, TB, JB, FR, grid, 128 * 128 + patch_bytes, st);
     }
     const int grid = B * tblocks * (d.Npad / 64);
+    if (direct == 1) return launch_conv_direct<64, 2, 2>(d, TB, JB, FR, grid, patch_bytes, st);
+    if (direct == 2) return launch_conv_direct<64, 1, 4>(d, TB, JB, FR, grid, patch_bytes, st);
     return launch_conv<64, 1, 4>(d, TB, JB, FR, grid, 64 * 128 + patch_bytes, st);
 }
 
@@ -1004,6 +1182,8 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     // workgroups than "fill the GPU twice" pay: measured per step with 8 / 16 / 32 / 64 splits: 7.24 / 7.15 / 7.19 / 7.3 ms.
     static const int cw_splits = getenv("SEHIP_CW_SPLITS") ? atoi(getenv("SEHIP_CW_SPLITS")) : 16;
     int splits = cw_splits >= 8 ? cw_splits / 8 * 8 : (cw_splits >= 4 ? 4 : (cw_splits >= 2 ? 2 : 1));
+    static const int cw_minwg = getenv("SEHIP_CW_MINWG") ? atoi(getenv("SEHIP_CW_MINWG")) : 0;
+    if (gx * splits < cw_minwg) splits = (cw_minwg / gx + 7) / 8 * 8;  // (off: see above)
     while (splits < 8 && (gx * splits) % 8) splits <<= 1;
     const int tiles_per_wg = (MT + splits - 1) / splits;
     const int grid = gx * splits;  // splits beyond the data simply find an empty m range
@@ -1028,18 +1208,68 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
 #undef CW_CASE
 }
 
+template <int NPC>
+__device__ __forceinline__ RegTile<NPC> sw_fetch_patch(const bf16_raw* const (&p_ptr)[NPC], const int (&p_pp)[NPC], long off0, long off1,
+                                                       int lo0, int span0, int lo1, int span1, const bf16_raw* zero_page) {
+    RegTile<NPC> t;
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+        const int e = p_pp[u];
+        const int sec = (e >> 16) & 1;
+        const unsigned rel = (unsigned)((e & 0xffff) - (sec ? lo1 : lo0));
+        const int ok = (int)(e >= 0) & (int)(rel < (unsigned)(sec ? span1 : span0));
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) u32x4_t* gvec_ptr;
+        const bf16_raw* q = p_ptr[u] + (sec ? off1 : off0);
+        q = ok ? q : zero_page;
+        const u32x4_t x = *(gvec_ptr)(q);
+        t.v[u] = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    return t;
+}
+
+// dOut pieces: mode 1 = eight dense channels, 2 = the two channels of a narrow layer as one dword, 3 = element by element
+template <int GPT>
+__device__ __forceinline__ RegTile<GPT> sw_fetch_dout(const sehip_gemm_desc& d, const bf16_raw* const (&g_ptr)[GPT], const int (&g_mode)[GPT],
+                                                      const int (&g_tl)[GPT], long tile_off, int t0) {
+    RegTile<GPT> t;
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (g_mode[u] && t0 + g_tl[u] < d.TT) {
+            const bf16_raw* gp = g_ptr[u] + tile_off;
+            const int mode = g_mode[u] & 0xff;
+            if (mode == 1) v = *reinterpret_cast<const uint4*>(gp);
+            else if (mode == 2) v.x = *reinterpret_cast<const unsigned*>(gp);
+            else {
+                const int gc = g_mode[u] >> 8;
+                const sehip_nchunk c0 = d.ntab[(gc * 8) >> 2], c1 = d.ntab[((gc * 8) >> 2) + 1];
+                unsigned h[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = e < c0.nvalid ? (unsigned)gp[e] : 0u;
+                    h[4 + e] = e < c1.nvalid ? (unsigned)gp[c1.coff - c0.coff + e] : 0u;
+                }
+                v = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            }
+        }
+        t.v[u] = v;
+    }
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv_small_wgrad_kernel: weight gradient of the small-channel layers.  The WHOLE dW[BN][K] of the layer lives in
 // the registers of one workgroup (wave w owns the 16-column k-tiles w, w+4, ...), which streams over 128-row m-tiles:
 // dOut and the input patch are each read from HBM exactly once per workgroup pass; one atomic flush at the end.
 // ------------------------------------------------------------------------------------------------
-template <int BN, int KPW>
+template <int BN, int KPW, int NPC>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
     constexpr int TN = BN / 16;
     constexpr int GP = BN == 16 ? 16 : BN + 16;  // row offsets = distinct multiples of 32 B for 8 consecutive rows
     constexpr int GCH = BN / 8;
     constexpr int GPT = (128 * GCH + 255) / 256;
-    constexpr int MAXPC = 12;
+    constexpr int MAXPC = NPC;  // 16-byte patch pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int CT = C0 + C1;
@@ -1059,11 +1289,17 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
     const int lgct = 31 - __clz(CT);
     const int nf = d.cv_nf;
 
-    int p_lds[MAXPC], p_g[MAXPC], p_pp[MAXPC];
+    // Staging slots of this thread.  p_ptr: address of the piece for (b 0, first patch frame at t 0); p_pp: patch frame |
+    // source << 16, or -1 for a piece that is always zero (frequency padding, beyond NP).  The tile loop adds one
+    // per-source offset, checks the frame range with one unsigned compare and reads sehip_zero16 for anything invalid,
+    // so it contains no divergent branch (with one wave per SIMD every branch and dependent instruction is exposed).
+    const bf16_raw* p_ptr[MAXPC];
+    int p_lds[MAXPC], p_pp[MAXPC];
+    const int lds_dump = (TB + 1) * FR * PP;  // 16 spare bytes behind the patch take the stores of idx >= NP
 #pragma unroll
     for (int u = 0; u < MAXPC; ++u) {
         const int idx = tid + 256 * u;
-        p_pp[u] = -1; p_lds[u] = 0; p_g[u] = 0;
+        p_pp[u] = -1; p_lds[u] = lds_dump; p_ptr[u] = nullptr;
         if (idx < NP) {
             const int pp = idx / (FR * cp8), rem = idx - pp * (FR * cp8);
             const int r = rem / cp8, c8 = rem - r * cp8;
@@ -1073,7 +1309,8 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
             p_lds[u] = (pp * FR + r) * PP + c8 * 8;
             if (f >= 0 && f < sF) {
                 p_pp[u] = pp | (second ? 0x10000 : 0);
-                p_g[u] = (pp * sF + f) * sC + (c8 * 8 - (second ? C0 : 0));
+                p_ptr[u] = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) +
+                           ((long)((second ? tmin1 : tmin0) + pp) * sF + f) * sC + (c8 * 8 - (second ? C0 : 0));
             }
         }
     }
@@ -1113,73 +1350,54 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) accb[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // dOut staging slots of this thread: row / column chunk, source pointer of (b 0, t tl) and how to read it
+    // (1: eight dense channels, 2: the two channels of a narrow layer as one dword, 3: element by element)
+    const bf16_raw* g_ptr[GPT];
+    int g_tl[GPT], g_mode[GPT], g_lds[GPT];
+    const long g_bstride = (long)d.dst[0].T * d.dst[0].F * d.dst[0].C;
+    const int g_tstride = d.dst[0].F * d.dst[0].C;
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        const int idx = tid + 256 * u;
+        g_ptr[u] = nullptr; g_tl[u] = 0; g_mode[u] = 0; g_lds[u] = -1;
+        if (idx < 128 * GCH) {
+            const int r = idx / GCH, gc = idx - r * GCH;
+            const int tl = r / JB, jl = r - tl * JB;
+            RowPos rp;
+            rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+            const sehip_nchunk c0 = d.ntab[(gc * 8) >> 2], c1 = d.ntab[((gc * 8) >> 2) + 1];
+            g_ptr[u] = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr) + dst_row_offset(d.dst[0], rp, d.fmul) + c0.coff;
+            g_tl[u] = tl; g_lds[u] = r * GP + gc * 8;
+            if (c0.nvalid == 4 && c1.nvalid == 4 && c1.coff == c0.coff + 4) g_mode[u] = 1;
+            else if (c0.nvalid == 2 && c1.nvalid <= 0 && ((dst_row_offset(d.dst[0], rp, d.fmul) + c0.coff) & 1) == 0 &&
+                     (g_tstride & 1) == 0 && (g_bstride & 1) == 0) g_mode[u] = 2;
+            else if (c0.nvalid > 0 || c1.nvalid > 0) g_mode[u] = 3 | (gc << 8);
+        }
+    }
+
+    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&sehip_zero16);
+    RegTile<NPC> pr;
+    RegTile<GPT> gr;
+#define SW_FETCH(mt_)                                                                                             \
+    {                                                                                                             \
+        const int b_ = (mt_) / tblocks, t0_ = ((mt_) - b_ * tblocks) * TB;                                        \
+        const long off0_ = ((long)b_ * d.src[0].T + t0_) * d.src[0].F * C0;                                       \
+        const long off1_ = C1 ? ((long)b_ * d.src[1].T + t0_) * d.src[1].F * C1 : 0;                              \
+        pr = sw_fetch_patch<NPC>(p_ptr, p_pp, off0_, off1_, d.src[0].tlo - t0_ - tmin0, d.src[0].thi - d.src[0].tlo, \
+                                 d.src[1].tlo - t0_ - tmin1, d.src[1].thi - d.src[1].tlo, zero_page);             \
+        gr = sw_fetch_dout<GPT>(d, g_ptr, g_mode, g_tl, b_ * g_bstride + (long)t0_ * g_tstride, t0_);             \
+    }
+
     const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    if (mt_begin < mt_end) SW_FETCH(mt_begin)
     for (int mt = mt_begin; mt < mt_end; ++mt) {
-        const int b = mt / tblocks, t0 = (mt - b * tblocks) * TB;
 #pragma unroll
-        for (int u0 = 0; u0 < MAXPC; u0 += 4) {
-            if (u0 * 256 >= NP) break;
-            uint4 pr[4];
+        for (int u = 0; u < NPC; ++u) *reinterpret_cast<uint4*>(&patch[p_lds[u]]) = pr.v[u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                pr[u] = make_uint4(0u, 0u, 0u, 0u);
-                const int e = p_pp[u0 + u];
-                if (e >= 0) {
-                    const bool second = (e & 0x10000) != 0;
-                    const int ts = t0 + (e & 0xffff) + (second ? tmin1 : tmin0);
-                    const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
-                    if (ts >= tlo && ts < thi) {
-                        const bf16_raw* base = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr);
-                        const long frame0 = ((long)b * (second ? d.src[1].T : d.src[0].T) + t0 + (second ? tmin1 : tmin0)) *
-                                            (second ? d.src[1].F : d.src[0].F) * (second ? C1 : C0);
-                        pr[u] = *reinterpret_cast<const uint4*>(base + frame0 + p_g[u0 + u]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (tid + 256 * (u0 + u) < NP) *reinterpret_cast<uint4*>(&patch[p_lds[u0 + u]]) = pr[u];
-        }
-        // dOut tile: 128 rows x GCH chunks
-        {
-            uint4 gr[GPT];
-#pragma unroll
-            for (int u = 0; u < GPT; ++u) {
-                const int idx = tid + 256 * u;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (idx < 128 * GCH) {
-                    const int r = idx / GCH, gc = idx - r * GCH;
-                    const int tl = r / JB, jl = r - tl * JB;
-                    RowPos rp;
-                    rp.b = b; rp.t = t0 + tl; rp.jf = jl * d.fmul; rp.valid = rp.t < d.TT;
-                    if (rp.valid) {
-                        const int n = gc * 8;
-                        const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
-                        const size_t ro = dst_row_offset(d.dst[0], rp, d.fmul);
-                        const bf16_raw* gb = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr) + ro;
-                        if (c0.nvalid == 4 && c1.nvalid == 4 && c1.coff == c0.coff + 4) {
-                            v = *reinterpret_cast<const uint4*>(gb + c0.coff);
-                        } else {
-                            bf16_raw tmp[8];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                tmp[e] = e < c0.nvalid ? gb[c0.coff + e] : (bf16_raw)0;
-                                tmp[4 + e] = e < c1.nvalid ? gb[c1.coff + e] : (bf16_raw)0;
-                            }
-                            v = make_uint4(tmp[0] | ((unsigned)tmp[1] << 16), tmp[2] | ((unsigned)tmp[3] << 16),
-                                           tmp[4] | ((unsigned)tmp[5] << 16), tmp[6] | ((unsigned)tmp[7] << 16));
-                        }
-                    }
-                }
-                gr[u] = v;
-            }
-#pragma unroll
-            for (int u = 0; u < GPT; ++u) {
-                const int idx = tid + 256 * u;
-                if (idx < 128 * GCH) *reinterpret_cast<uint4*>(&sG[(idx / GCH) * GP + (idx % GCH) * 8]) = gr[u];
-            }
-        }
+        for (int u = 0; u < GPT; ++u)
+            if (g_lds[u] >= 0) *reinterpret_cast<uint4*>(&sG[g_lds[u]]) = gr.v[u];
         __syncthreads();
+        if (mt + 1 < mt_end) SW_FETCH(mt + 1)   // next tile in flight while this one is multiplied
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 gf[TN];
@@ -1222,19 +1440,20 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
 #pragma unroll
             for (int u = 0; u < 4; ++u) atomicAdd(&d.dbias[ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
     }
+#undef SW_FETCH
 }
 
-template <int BN, int KPW>
+template <int BN, int KPW, int NPC>
 static int launch_small_wgrad(const sehip_gemm_desc& d, int TB, int JB, int FR, int tiles_per_wg, int grid, size_t lds,
                               hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_wgrad_kernel<BN, KPW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_wgrad_kernel<BN, KPW, NPC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
         attr_set = true;
     }
-    sehip_note_kernel("conv_small_wgrad_kernel<%d, %d>", BN, KPW);
-    conv_small_wgrad_kernel<BN, KPW><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);
+    sehip_note_kernel("conv_small_wgrad_kernel<%d, %d, %d>", BN, KPW, NPC);
+    conv_small_wgrad_kernel<BN, KPW, NPC><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);
     return 1;
 }
 
@@ -1250,7 +1469,7 @@ static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     const int JB = d.J, TB = 128 / JB;
     const int FR = (JB - 1) * d.fmul + d.cv_nf;
     if ((TB + 1) * FR * (CT >> 3) > 12 * 256) return 0;
-    const size_t lds = (size_t)128 * (d.Npad + 16) * 2 + (size_t)(TB + 1) * FR * (CT + 16) * 2;
+    const size_t lds = (size_t)128 * (d.Npad + 16) * 2 + (size_t)(TB + 1) * FR * (CT + 16) * 2 + 16;  // + dump slot
     if (lds > 120 * 1024) return 0;
     const int kpw = d.K / 64;
     const int B = d.M / (d.TT * d.J);
@@ -1260,7 +1479,11 @@ static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     if (wgs > MT) wgs = MT;
     const int tiles_per_wg = (MT + wgs - 1) / wgs;
     const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
-#define SW(BN_, KPW_) if (d.Npad == BN_ && kpw == KPW_) return launch_small_wgrad<BN_, KPW_>(d, TB, JB, FR, tiles_per_wg, grid, lds, st);
+    const bool few = (TB + 1) * FR * (CT >> 3) <= 6 * 256;  // 16-byte patch pieces per thread: 6 or 12
+#define SW(BN_, KPW_)                                                                                           \
+    if (d.Npad == BN_ && kpw == KPW_)                                                                           \
+        return few ? launch_small_wgrad<BN_, KPW_, 6>(d, TB, JB, FR, tiles_per_wg, grid, lds, st)               \
+                   : launch_small_wgrad<BN_, KPW_, 12>(d, TB, JB, FR, tiles_per_wg, grid, lds, st);
     SW(16, 1) SW(16, 2) SW(16, 3) SW(16, 4) SW(16, 5) SW(16, 6) SW(16, 8) SW(16, 12)
     SW(32, 1) SW(32, 2) SW(32, 3) SW(32, 4) SW(32, 5) SW(32, 6) SW(32, 8) SW(32, 12)
     SW(64, 1) SW(64, 2) SW(64, 3)  // wider 64-row tiles: the generic kernel measured faster
@@ -1318,7 +1541,7 @@ extern "C" int sehip_init(void) {
     set_lds(&conv_small_kernel<16>, 120 * 1024);
     set_lds(&conv_small_kernel<32>, 120 * 1024);
     set_lds(&conv_small_kernel<64>, 120 * 1024);
-#define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_>, 120 * 1024);
+#define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 6>, 120 * 1024); set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 12>, 120 * 1024);
     INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)
     INIT_SW(32, 1) INIT_SW(32, 2) INIT_SW(32, 3) INIT_SW(32, 4) INIT_SW(32, 5) INIT_SW(32, 6) INIT_SW(32, 8) INIT_SW(32, 12)
     INIT_SW(64, 1) INIT_SW(64, 2) INIT_SW(64, 3)

@@ -38,6 +38,10 @@ else:
             env["SEHIP_CW_WGS"] = flags[2:]
         if flags.startswith("lib:"):
             env["SEHIP_LIB"] = os.path.join(ROOT, flags[4:])
+        if flags.startswith("direct"):
+            env["SEHIP_DIRECT"] = flags[6:]
+        if flags.startswith("minwg"):
+            env["SEHIP_CW_MINWG"] = flags[5:]
         if flags == "nosmall":
             env["SEHIP_NO_SMALL"] = "1"
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
