@@ -82,6 +82,33 @@ __device__ uint4 sehip_zero16 = {0u, 0u, 0u, 0u};
 template <int N>
 struct RegTile { uint4 v[N]; };
 
+// Staging fetch shared by the small-channel kernels: piece u of this thread lives at p_ptr[u] (address for batch 0, tile
+// frame 0) + a per-source tile offset; p_pp[u] = patch frame | source << 16, or -1 for a piece that is always zero.  A
+// piece outside the source's frame range reads sehip_zero16 instead of branching (one wave per SIMD: every branch and
+// every dependent instruction is exposed).  The loads are explicit global-address-space loads: a select between
+// pointers of unknown provenance becomes a flat load, which may alias private memory and forced the prefetch
+// registers into scratch.
+template <int NPC>
+__device__ __forceinline__ RegTile<NPC> sw_fetch_patch(const bf16_raw* const (&p_ptr)[NPC], const int (&p_pp)[NPC], long off0, long off1,
+                                                       int lo0, int span0, int lo1, int span1, const bf16_raw* zero_page) {
+    RegTile<NPC> t;
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+        const int e = p_pp[u];
+        const int sec = (e >> 16) & 1;
+        const unsigned rel = (unsigned)((e & 0xffff) - (sec ? lo1 : lo0));
+        const int ok = (int)(e >= 0) & (int)(rel < (unsigned)(sec ? span1 : span0));
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) u32x4_t* gvec_ptr;
+        const bf16_raw* q = p_ptr[u] + (sec ? off1 : off0);
+        q = ok ? q : zero_page;
+        const u32x4_t x = *(gvec_ptr)(q);
+        t.v[u] = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    return t;
+}
+
+
 // Scatter of one lane's 4 consecutive output channels (shared by both product kernels).
 __device__ __forceinline__ void store_out4(const sehip_gemm_desc& d, const sehip_nchunk nc, f32x4 v, size_t ro0, size_t ro1,
                                            int n) {
@@ -752,6 +779,193 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const sehip_gemm_desc d
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_small2_kernel: conv_small_kernel with the tile loop pipelined for one wave per SIMD.  In the first version the
+// phases of a tile ran one after the other (stage, barrier, multiply, store) and 30-45 % of its time was the
+// instruction stream of the staging and store addressing alone.  Here the next tile's patch is fetched into registers
+// (branch-free, see sw_fetch_patch) while the current one is multiplied and stored, the store addressing (row
+// offsets, n-chunk table entries, bias) is computed once per workgroup, and the K loop walks taps with scalar offsets.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int NPC>
+__global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
+    constexpr int TN = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int CT = C0 + C1;
+    const int NIT = 2 * d.cv_nf;
+    const int KR = NIT * CT;          // real K
+    const int KP = d.K + 8;           // LDS pitch of a weight row
+    const int PP = CT + 8;            // LDS pitch of a patch row
+    bf16_raw* sW = reinterpret_cast<bf16_raw*>(smem);
+    bf16_raw* patch = sW + BN * KP;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4;
+    {
+        const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
+        const int cpr = d.K >> 3;
+        for (int idx = tid; idx < BN * cpr; idx += 256) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            *reinterpret_cast<uint4*>(&sW[r * KP + c * 8]) = *reinterpret_cast<const uint4*>(Wb + (size_t)r * d.K + c * 8);
+        }
+    }
+    const int tblocks = (d.TT + TB - 1) / TB;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * tblocks;       // JB == J
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const int cp8 = CT >> 3;
+    const int NP = (TB + 1) * FR * cp8;
+    const int nf = d.cv_nf;
+    const int lgct = 31 - __clz(CT);
+
+    // ---- staging slots (see sw_fetch_patch)
+    const bf16_raw* p_ptr[NPC];
+    int p_lds[NPC], p_pp[NPC];
+    const int lds_dump = (TB + 1) * FR * PP;
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+        const int idx = tid + 256 * u;
+        p_pp[u] = -1; p_lds[u] = lds_dump; p_ptr[u] = nullptr;
+        if (idx < NP) {
+            const int pp = idx / (FR * cp8), rem = idx - pp * (FR * cp8);
+            const int r = rem / cp8, c8 = rem - r * cp8;
+            const bool second = c8 * 8 >= C0;
+            const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+            const int f = d.cv_fadd + r;
+            p_lds[u] = (pp * FR + r) * PP + c8 * 8;
+            if (f >= 0 && f < sF) {
+                p_pp[u] = pp | (second ? 0x10000 : 0);
+                p_ptr[u] = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) +
+                           ((long)((second ? tmin1 : tmin0) + pp) * sF + f) * sC + (c8 * 8 - (second ? C0 : 0));
+            }
+        }
+    }
+    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&sehip_zero16);
+
+    // ---- MFMA operand rows of this lane and its store addressing (all tile-invariant)
+    int abase[2], e_tl[2];
+    long e_off0[2], e_off1[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = 32 * w + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        abase[mi] = (tl * FR + jl * d.fmul) * PP;
+        e_tl[mi] = tl;
+        RowPos rp;
+        rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+        e_off0[mi] = (long)dst_row_offset(d.dst[0], rp, d.fmul);
+        e_off1[mi] = d.dst[1].ptr ? (long)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
+    }
+    const long bs0 = (long)d.dst[0].T * d.dst[0].F * d.dst[0].C, bs1 = (long)d.dst[1].T * d.dst[1].F * d.dst[1].C;
+    const int ts0 = d.dst[0].F * d.dst[0].C, ts1 = d.dst[1].F * d.dst[1].C;
+    sehip_nchunk nck[TN];
+    float4 bias4[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = ni * 16 + 4 * g;
+        nck[ni] = d.ntab[n >> 2];
+        bias4[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int wrow = (lane & 15) * KP + 8 * g;  // this lane's weight fragment: row (lane & 15) of each 16-row tile, k chunk g
+
+    const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    RegTile<NPC> pr;
+#define CS_FETCH(mt_)                                                                                             \
+    {                                                                                                             \
+        const int b_ = (mt_) / tblocks, t0_ = ((mt_) - b_ * tblocks) * TB;                                        \
+        const long off0_ = ((long)b_ * d.src[0].T + t0_) * d.src[0].F * C0;                                       \
+        const long off1_ = C1 ? ((long)b_ * d.src[1].T + t0_) * d.src[1].F * C1 : 0;                              \
+        pr = sw_fetch_patch<NPC>(p_ptr, p_pp, off0_, off1_, d.src[0].tlo - t0_ - tmin0, d.src[0].thi - d.src[0].tlo, \
+                                 d.src[1].tlo - t0_ - tmin1, d.src[1].thi - d.src[1].tlo, zero_page);             \
+    }
+    if (mt_begin < mt_end) CS_FETCH(mt_begin)
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        const int b = mt / tblocks, t0 = (mt - b * tblocks) * TB;
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) *reinterpret_cast<uint4*>(&patch[p_lds[u]]) = pr.v[u];
+        __syncthreads();
+        if (mt + 1 < mt_end) CS_FETCH(mt + 1)   // in flight while this tile is multiplied and stored
+
+        f32x4 acc[TN][2];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (CT >= 32) {
+            const int cs_n = CT >> 5;
+            for (int it = 0; it < NIT; ++it) {
+                const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
+                const int po0 = ((d.cv_toff[0][kt] - tmin0) * FR + tap) * PP, po1 = ((d.cv_toff[1][kt] - tmin1) * FR + tap) * PP;
+                for (int cs = 0; cs < cs_n; ++cs) {
+                    const int c = 32 * cs + 8 * g;
+                    const int poff = (c >= C0 ? po1 : po0) + c;
+                    bf16x8 af[2], wf[TN];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[ni * 16 * KP + wrow + it * CT + 32 * cs]));
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                }
+            }
+        } else {
+            const int ksteps = KR >> 5;
+            for (int s = 0; s < ksteps; ++s) {
+                const int k = 32 * s + 8 * g;
+                const int it = k >> lgct, c = k & (CT - 1);
+                const bool second = c >= C0;
+                const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
+                const int dt = (second ? d.cv_toff[1][kt] - tmin1 : d.cv_toff[0][kt] - tmin0);
+                const int poff = (dt * FR + tap) * PP + c;
+                bf16x8 af[2], wf[TN];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[ni * 16 * KP + wrow + 32 * s]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if (t0 + e_tl[mi] >= d.TT) continue;
+            const long ro0 = e_off0[mi] + b * bs0 + (long)t0 * ts0;
+            const long ro1 = e_off1[mi] + b * bs1 + (long)t0 * ts1;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const sehip_nchunk nc = nck[ni];
+                if (nc.nvalid <= 0) continue;
+                f32x4 v = acc[ni][mi];
+                v[0] += bias4[ni].x; v[1] += bias4[ni].y; v[2] += bias4[ni].z; v[3] += bias4[ni].w;
+                const long off = (nc.dst ? ro1 : ro0) + nc.coff;
+                void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
+                const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+                if (is_f32) {
+                    float* q = reinterpret_cast<float*>(dptr) + off;
+                    if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        for (int e = 0; e < nc.nvalid; ++e) q[e] = v[e];
+                } else {
+                    bf16_raw* q = reinterpret_cast<bf16_raw*>(dptr) + off;
+                    if (nc.nvalid == 4) *reinterpret_cast<uint2*>(q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    else
+                        for (int e = 0; e < nc.nvalid; ++e) q[e] = f2bf(v[e]);
+                }
+            }
+        }
+        __syncthreads();  // every read of this tile's patch is done before the next one is written
+    }
+#undef CS_FETCH
+}
+
 static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_SMALL") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
@@ -773,6 +987,27 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
     if (wgs > MT) wgs = MT;
     const int tiles_per_wg = (MT + wgs - 1) / wgs;
     const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
+    static const bool v1 = getenv("SEHIP_SMALL_V1") != nullptr;
+    const size_t lds2 = lds + 16;  // + dump slot
+    const bool few = (TB + 1) * FR * (CT >> 3) <= 6 * 256;
+#define CS2_CASE(BN_, NPC_)                                                                                         \
+    {                                                                                                               \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small2_kernel<BN_, NPC_>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024 + 16);                 \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        sehip_note_kernel("conv_small2_kernel<%d, %d>", BN_, NPC_);                                                \
+        conv_small2_kernel<BN_, NPC_><<<grid, 256, lds2, st>>>(d, TB, JB, FR, tiles_per_wg);                        \
+        return 1;                                                                                                   \
+    }
+    if (!v1) {
+        if (d.Npad == 16) { if (few) CS2_CASE(16, 6) else CS2_CASE(16, 12) }
+        if (d.Npad == 32) { if (few) CS2_CASE(32, 6) else CS2_CASE(32, 12) }
+        if (d.Npad == 64) { if (few) CS2_CASE(64, 6) else CS2_CASE(64, 12) }
+    }
+#undef CS2_CASE
 #define CS_CASE(BN_)                                                                                                \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
@@ -1208,26 +1443,6 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
 #undef CW_CASE
 }
 
-template <int NPC>
-__device__ __forceinline__ RegTile<NPC> sw_fetch_patch(const bf16_raw* const (&p_ptr)[NPC], const int (&p_pp)[NPC], long off0, long off1,
-                                                       int lo0, int span0, int lo1, int span1, const bf16_raw* zero_page) {
-    RegTile<NPC> t;
-#pragma unroll
-    for (int u = 0; u < NPC; ++u) {
-        const int e = p_pp[u];
-        const int sec = (e >> 16) & 1;
-        const unsigned rel = (unsigned)((e & 0xffff) - (sec ? lo1 : lo0));
-        const int ok = (int)(e >= 0) & (int)(rel < (unsigned)(sec ? span1 : span0));
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(1))) u32x4_t* gvec_ptr;
-        const bf16_raw* q = p_ptr[u] + (sec ? off1 : off0);
-        q = ok ? q : zero_page;
-        const u32x4_t x = *(gvec_ptr)(q);
-        t.v[u] = make_uint4(x[0], x[1], x[2], x[3]);
-    }
-    return t;
-}
-
 // dOut pieces: mode 1 = eight dense channels, 2 = the two channels of a narrow layer as one dword, 3 = element by element
 template <int GPT>
 __device__ __forceinline__ RegTile<GPT> sw_fetch_dout(const sehip_gemm_desc& d, const bf16_raw* const (&g_ptr)[GPT], const int (&g_mode)[GPT],
@@ -1541,6 +1756,9 @@ extern "C" int sehip_init(void) {
     set_lds(&conv_small_kernel<16>, 120 * 1024);
     set_lds(&conv_small_kernel<32>, 120 * 1024);
     set_lds(&conv_small_kernel<64>, 120 * 1024);
+#define INIT_CS2(BN_) set_lds(&conv_small2_kernel<BN_, 6>, 120 * 1024 + 16); set_lds(&conv_small2_kernel<BN_, 12>, 120 * 1024 + 16);
+    INIT_CS2(16) INIT_CS2(32) INIT_CS2(64)
+#undef INIT_CS2
 #define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 6>, 120 * 1024); set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 12>, 120 * 1024);
     INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)
     INIT_SW(32, 1) INIT_SW(32, 2) INIT_SW(32, 3) INIT_SW(32, 4) INIT_SW(32, 5) INIT_SW(32, 6) INIT_SW(32, 8) INIT_SW(32, 12)
