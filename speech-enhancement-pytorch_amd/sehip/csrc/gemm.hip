@@ -971,8 +971,7 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
     if (disabled || d.cv_nf <= 0) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int CT = C0 + C1;
-    if ((C0 & 7) || (C1 & 7) || CT > 128 || (CT & (CT - 1)) || d.Npad > 64 || CT < 16) return 0;
-    if (d.Npad == 64 && CT >= 32) return 0;  // measured: the generic tile kernel is faster there
+    if ((C0 & 7) || (C1 & 7) || CT > 128 || (CT & (CT - 1)) || d.Npad > 128 || CT < 16) return 0;
     if (d.J > 128 || (128 % d.J)) return 0;
     const int KR = 2 * d.cv_nf * CT;
     if ((128 / d.J + 1) * ((d.J - 1) * d.fmul + d.cv_nf) * (CT >> 3) > 12 * 256) return 0;
@@ -1006,6 +1005,7 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
         if (d.Npad == 16) { if (few) CS2_CASE(16, 6) else CS2_CASE(16, 12) }
         if (d.Npad == 32) { if (few) CS2_CASE(32, 6) else CS2_CASE(32, 12) }
         if (d.Npad == 64) { if (few) CS2_CASE(64, 6) else CS2_CASE(64, 12) }
+        if (d.Npad == 128) { if (few) CS2_CASE(128, 6) else CS2_CASE(128, 12) }
     }
 #undef CS2_CASE
 #define CS_CASE(BN_)                                                                                                \
@@ -1757,7 +1757,7 @@ extern "C" int sehip_init(void) {
     set_lds(&conv_small_kernel<32>, 120 * 1024);
     set_lds(&conv_small_kernel<64>, 120 * 1024);
 #define INIT_CS2(BN_) set_lds(&conv_small2_kernel<BN_, 6>, 120 * 1024 + 16); set_lds(&conv_small2_kernel<BN_, 12>, 120 * 1024 + 16);
-    INIT_CS2(16) INIT_CS2(32) INIT_CS2(64)
+    INIT_CS2(16) INIT_CS2(32) INIT_CS2(64) INIT_CS2(128)
 #undef INIT_CS2
 #define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 6>, 120 * 1024); set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 12>, 120 * 1024);
     INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)

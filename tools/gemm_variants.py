@@ -44,6 +44,8 @@ else:
             env["SEHIP_CW_MINWG"] = flags[5:]
         if flags == "smallv1":
             env["SEHIP_SMALL_V1"] = "1"
+        if flags == "small128":
+            env["SEHIP_SMALL128"] = "1"
         if flags == "nosmall":
             env["SEHIP_NO_SMALL"] = "1"
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
