@@ -631,162 +631,15 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small-channel layers (<= 64 output channels, <= 128 concatenated input channels: the outer encoder/decoder
-// layers, HBM-bound).  The whole packed weight [BN][K] lives in LDS for the lifetime of the workgroup, which
-// walks over 128-row m-tiles: stage the input patch (every element read once), then run all K/32 MFMA steps
-// straight from LDS -- no per-step staging and no barrier inside the K loop.
-// ------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(256) void conv_small_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
-    constexpr int TN = BN / 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
-    const int CT = C0 + C1;
-    const int NIT = 2 * d.cv_nf;
-    const int KR = NIT * CT;          // real K
-    const int KP = d.K + 8;           // LDS pitch of a weight row
-    const int PP = CT + 8;            // LDS pitch of a patch row
-    bf16_raw* sW = reinterpret_cast<bf16_raw*>(smem);
-    bf16_raw* patch = sW + BN * KP;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane >> 4;
-    // weights -> LDS (once)
-    {
-        const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
-        const int cpr = d.K >> 3;
-        for (int idx = tid; idx < BN * cpr; idx += 256) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            *reinterpret_cast<uint4*>(&sW[r * KP + c * 8]) = *reinterpret_cast<const uint4*>(Wb + (size_t)r * d.K + c * 8);
-        }
-    }
-    const int tblocks = (d.TT + TB - 1) / TB, jblocks = d.J / JB;
-    const int B = d.M / (d.TT * d.J);
-    const int MT = B * tblocks * jblocks;
-    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
-    const int cp8 = CT >> 3;
-    const int NP = (TB + 1) * FR * cp8;
-
-    // per-lane constants of the two 16-row activation tiles of this wave
-    int abase[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int r = 32 * w + mi * 16 + (lane & 15);
-        const int tl = r / JB, jl = r - tl * JB;
-        abase[mi] = (tl * FR + jl * d.fmul) * PP;
-    }
-    const int ksteps = KR >> 5;
-    const int nf = d.cv_nf;
-    const int lgct = 31 - __clz(CT);
-
-    // tile-invariant description of the patch pieces this thread stages: LDS offset, global offset relative to the
-    // tile's first frame, patch frame (or -1 when the piece does not exist / its row is outside the source)
-    constexpr int MAXPC = 12;
-    int p_lds[MAXPC], p_g[MAXPC], p_pp[MAXPC];
-    const int f0c = d.cv_fadd;  // JB == J: tiles start at row 0
-#pragma unroll
-    for (int u = 0; u < MAXPC; ++u) {
-        const int idx = tid + 256 * u;
-        p_pp[u] = -1; p_lds[u] = 0; p_g[u] = 0;
-        if (idx < NP) {
-            const int pp = idx / (FR * cp8), rem = idx - pp * (FR * cp8);
-            const int r = rem / cp8, c8 = rem - r * cp8;
-            const bool second = c8 * 8 >= C0;
-            const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
-            const int f = f0c + r;
-            p_lds[u] = (pp * FR + r) * PP + c8 * 8;
-            if (f >= 0 && f < sF) {
-                p_pp[u] = pp | (second ? 0x10000 : 0);
-                p_g[u] = (pp * sF + f) * sC + (c8 * 8 - (second ? C0 : 0));
-            }
-        }
-    }
-
-    const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
-    for (int mt = mt_begin; mt < mt_end; ++mt) {
-        int rest = mt;
-        const int jb = rest % jblocks; rest /= jblocks;
-        const int tb = rest % tblocks;
-        const int b = rest / tblocks;
-        const int t0 = tb * TB, j0 = jb * JB;
-        __syncthreads();  // previous tile's reads of the patch are done (also orders the weight fill)
-#pragma unroll
-        for (int u0 = 0; u0 < MAXPC; u0 += 4) {
-            if (u0 * 256 >= NP) break;
-            uint4 pr[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                pr[u] = make_uint4(0u, 0u, 0u, 0u);
-                const int e = p_pp[u0 + u];
-                if (e >= 0) {
-                    const bool second = (e & 0x10000) != 0;
-                    const int ts = t0 + (e & 0xffff) + (second ? tmin1 : tmin0);
-                    const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
-                    if (ts >= tlo && ts < thi) {
-                        const bf16_raw* base = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr);
-                        const long frame0 = ((long)b * (second ? d.src[1].T : d.src[0].T) + t0 + (second ? tmin1 : tmin0)) *
-                                            (second ? d.src[1].F : d.src[0].F) * (second ? C1 : C0);
-                        pr[u] = *reinterpret_cast<const uint4*>(base + frame0 + p_g[u0 + u]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (tid + 256 * (u0 + u) < NP) *reinterpret_cast<uint4*>(&patch[p_lds[u0 + u]]) = pr[u];
-        }
-        __syncthreads();
-
-        f32x4 acc[TN][2];
-#pragma unroll
-        for (int a = 0; a < TN; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        for (int s = 0; s < ksteps; ++s) {
-            const int k = 32 * s + 8 * g;
-            const int it = k >> lgct, c = k & (CT - 1);
-            const bool second = c >= C0;
-            const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
-            const int dt = (second ? d.cv_toff[1][kt] - tmin1 : d.cv_toff[0][kt] - tmin0);
-            const int poff = (dt * FR + tap) * PP + c;
-            bf16x8 af[2], wf[TN];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[(ni * 16 + (lane & 15)) * KP + k]));
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int rr = 32 * w + mi * 16 + (lane & 15);
-            const int tl = rr / JB, jl = rr - tl * JB;
-            RowPos r;
-            r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
-            if (!r.valid) continue;
-            const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
-            const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int n = ni * 16 + 4 * (lane >> 4);
-                const sehip_nchunk nc = d.ntab[n >> 2];
-                if (nc.nvalid <= 0) continue;
-                store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// conv_small2_kernel: conv_small_kernel with the tile loop pipelined for one wave per SIMD.  In the first version the
-// phases of a tile ran one after the other (stage, barrier, multiply, store) and 30-45 % of its time was the
-// instruction stream of the staging and store addressing alone.  Here the next tile's patch is fetched into registers
+// conv_small2_kernel: small-channel layers (<= 128 output channels, <= 128 concatenated input channels: the outer
+// encoder/decoder layers, HBM-bound).  The whole packed weight [BN][K] lives in LDS for the lifetime of the workgroup,
+// which walks over tiles of 64 MI rows: stage the input patch (every element read once), run all K/32 MFMA steps
+// straight from LDS, store.  A first version ran the phases of a tile one after the other with divergent staging code;
+// 30-45 % of its time was that instruction stream.  Here the next tile's patch is fetched into registers
 // (branch-free, see sw_fetch_patch) while the current one is multiplied and stored, the store addressing (row
 // offsets, n-chunk table entries, bias) is computed once per workgroup, and the K loop walks taps with scalar offsets.
 // ------------------------------------------------------------------------------------------------
-template <int BN, int NPC>
+template <int BN, int NPC, int MI>
 __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
     constexpr int TN = BN / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -843,18 +696,18 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
     const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&sehip_zero16);
 
     // ---- MFMA operand rows of this lane and its store addressing (all tile-invariant)
-    int abase[2], e_tl[2];
-    long e_off0[2], e_off1[2];
+    // wave w owns rows [16 MI w, 16 MI (w + 1)) of the 64 MI-row tile
+    int abase[MI], e_tl[MI], e_off0[MI], e_off1[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int r = 32 * w + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = 16 * MI * w + mi * 16 + (lane & 15);
         const int tl = r / JB, jl = r - tl * JB;
         abase[mi] = (tl * FR + jl * d.fmul) * PP;
         e_tl[mi] = tl;
         RowPos rp;
         rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
-        e_off0[mi] = (long)dst_row_offset(d.dst[0], rp, d.fmul);
-        e_off1[mi] = d.dst[1].ptr ? (long)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
+        e_off0[mi] = (int)dst_row_offset(d.dst[0], rp, d.fmul);
+        e_off1[mi] = d.dst[1].ptr ? (int)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
     }
     const long bs0 = (long)d.dst[0].T * d.dst[0].F * d.dst[0].C, bs1 = (long)d.dst[1].T * d.dst[1].F * d.dst[1].C;
     const int ts0 = d.dst[0].F * d.dst[0].C, ts1 = d.dst[1].F * d.dst[1].C;
@@ -886,20 +739,23 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
         __syncthreads();
         if (mt + 1 < mt_end) CS_FETCH(mt + 1)   // in flight while this tile is multiplied and stored
 
-        f32x4 acc[TN][2];
+        f32x4 acc[TN][MI];
 #pragma unroll
-        for (int a = 0; a < TN; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[a][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (CT >= 32) {
             const int cs_n = CT >> 5;
+#pragma unroll 2
             for (int it = 0; it < NIT; ++it) {
                 const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
                 const int po0 = ((d.cv_toff[0][kt] - tmin0) * FR + tap) * PP, po1 = ((d.cv_toff[1][kt] - tmin1) * FR + tap) * PP;
                 for (int cs = 0; cs < cs_n; ++cs) {
                     const int c = 32 * cs + 8 * g;
                     const int poff = (c >= C0 ? po1 : po0) + c;
-                    bf16x8 af[2], wf[TN];
+                    bf16x8 af[MI], wf[TN];
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
                         af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
@@ -907,7 +763,7 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
+                        for (int mi = 0; mi < MI; ++mi)
                             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
                 }
             }
@@ -920,9 +776,9 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
                 const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
                 const int dt = (second ? d.cv_toff[1][kt] - tmin1 : d.cv_toff[0][kt] - tmin0);
                 const int poff = (dt * FR + tap) * PP + c;
-                bf16x8 af[2], wf[TN];
+                bf16x8 af[MI], wf[TN];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
@@ -930,12 +786,12 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             if (t0 + e_tl[mi] >= d.TT) continue;
             const long ro0 = e_off0[mi] + b * bs0 + (long)t0 * ts0;
             const long ro1 = e_off1[mi] + b * bs1 + (long)t0 * ts1;
@@ -974,58 +830,53 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
     if ((C0 & 7) || (C1 & 7) || CT > 128 || (CT & (CT - 1)) || d.Npad > 128 || CT < 16) return 0;
     if (d.J > 128 || (128 % d.J)) return 0;
     const int KR = 2 * d.cv_nf * CT;
-    if ((128 / d.J + 1) * ((d.J - 1) * d.fmul + d.cv_nf) * (CT >> 3) > 12 * 256) return 0;
     if ((KR & 31) || KR > d.K) return 0;
-    const int JB = d.J, TB = 128 / JB;
+    const int JB = d.J;
     const int FR = (JB - 1) * d.fmul + d.cv_nf;
-    const size_t lds = (size_t)d.Npad * (d.K + 8) * 2 + (size_t)(TB + 1) * FR * (CT + 8) * 2;
-    if (lds > 120 * 1024) return 0;
+    // rows per tile = 64 MI.  Larger tiles amortise the per-tile instruction stream and the weight-fragment reads (every wave
+    // reads all of W per K step) but cost registers and LDS, i.e. resident workgroups; measured per layer (B=32, us, MI 2 / 4):
+    // enc1.fwd 35/31, enc1.dg 27/27, enc2.fwd 56/48, enc2.dg0 29/33, dec4.fwd 42/37, dec4.dg 46/63, dec5.fwd 42/53.
+    // Rule that reproduces the winners: 4 when the pieces-per-thread class (6 / 12) does not grow, for 64 outputs when K >= 256.
+    static const int mi_force = getenv("SEHIP_SMALL_MI") ? atoi(getenv("SEHIP_SMALL_MI")) : 0;
+    auto pieces = [&](int mi) { return (64 * mi / JB + 1) * FR * (CT >> 3); };
+    auto lds_of = [&](int mi) { return (size_t)d.Npad * (d.K + 8) * 2 + (size_t)(64 * mi / JB + 1) * FR * (CT + 8) * 2 + 16; };
+    auto fits = [&](int mi) { return pieces(mi) <= 12 * 256 && lds_of(mi) <= 120 * 1024; };
+    int MI = 2;
+    if (d.Npad <= 32 && fits(4) && (pieces(2) <= 6 * 256) == (pieces(4) <= 6 * 256)) MI = 4;
+    if (d.Npad == 64 && fits(4) && d.K >= 256) MI = 4;
+    if (mi_force == 2 || (mi_force == 4 && fits(4) && d.Npad <= 64)) MI = mi_force;
+    if (!fits(MI)) return 0;
+    const int TB = 64 * MI / JB;
+    const size_t lds = lds_of(MI);  // includes the 16-byte dump slot
     const int B = d.M / (d.TT * d.J);
     const int MT = B * ((d.TT + TB - 1) / TB);
     int wgs = lds > 64 * 1024 ? 256 : (lds > 40 * 1024 ? 512 : 1024);
     if (wgs > MT) wgs = MT;
     const int tiles_per_wg = (MT + wgs - 1) / wgs;
     const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
-    static const bool v1 = getenv("SEHIP_SMALL_V1") != nullptr;
-    const size_t lds2 = lds + 16;  // + dump slot
     const bool few = (TB + 1) * FR * (CT >> 3) <= 6 * 256;
-#define CS2_CASE(BN_, NPC_)                                                                                         \
-    {                                                                                                               \
+#define CS2_CASE(BN_, NPC_, MI_)                                                                                    \
+    if (d.Npad == BN_ && MI == MI_ && few == (NPC_ == 6)) {                                                         \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small2_kernel<BN_, NPC_>),                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024 + 16);                 \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        sehip_note_kernel("conv_small2_kernel<%d, %d>", BN_, NPC_);                                                \
-        conv_small2_kernel<BN_, NPC_><<<grid, 256, lds2, st>>>(d, TB, JB, FR, tiles_per_wg);                        \
-        return 1;                                                                                                   \
-    }
-    if (!v1) {
-        if (d.Npad == 16) { if (few) CS2_CASE(16, 6) else CS2_CASE(16, 12) }
-        if (d.Npad == 32) { if (few) CS2_CASE(32, 6) else CS2_CASE(32, 12) }
-        if (d.Npad == 64) { if (few) CS2_CASE(64, 6) else CS2_CASE(64, 12) }
-        if (d.Npad == 128) { if (few) CS2_CASE(128, 6) else CS2_CASE(128, 12) }
-    }
-#undef CS2_CASE
-#define CS_CASE(BN_)                                                                                                \
-    {                                                                                                               \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<BN_>),                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small2_kernel<BN_, NPC_, MI_>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);                      \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        sehip_note_kernel("conv_small_kernel<%d>", BN_);                                                           \
-        conv_small_kernel<BN_><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                                \
+        sehip_note_kernel("conv_small2_kernel<%d, %d, %d>", BN_, NPC_, MI_);                                       \
+        conv_small2_kernel<BN_, NPC_, MI_><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                    \
         return 1;                                                                                                   \
     }
-    if (d.Npad == 16) CS_CASE(16)
-    if (d.Npad == 32) CS_CASE(32)
-    if (d.Npad == 64) CS_CASE(64)
-#undef CS_CASE
+#define CS2_BOTH(BN_, MI_) CS2_CASE(BN_, 6, MI_) CS2_CASE(BN_, 12, MI_)
+    CS2_BOTH(16, 4) CS2_BOTH(16, 2)
+    CS2_BOTH(32, 4) CS2_BOTH(32, 2)
+    CS2_BOTH(64, 4) CS2_BOTH(64, 2)
+    CS2_BOTH(128, 2)
+#undef CS2_BOTH
+#undef CS2_CASE
     return 0;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: tile BNW (n) x 64 (k), m consumed 64 rows per step
@@ -1753,11 +1604,8 @@ extern "C" int sehip_init(void) {
     set_lds(&conv_wgrad_kernel<NF_>, 96 * 1024);
     INIT_CONV(2) INIT_CONV(3) INIT_CONV(5)
 #undef INIT_CONV
-    set_lds(&conv_small_kernel<16>, 120 * 1024);
-    set_lds(&conv_small_kernel<32>, 120 * 1024);
-    set_lds(&conv_small_kernel<64>, 120 * 1024);
-#define INIT_CS2(BN_) set_lds(&conv_small2_kernel<BN_, 6>, 120 * 1024 + 16); set_lds(&conv_small2_kernel<BN_, 12>, 120 * 1024 + 16);
-    INIT_CS2(16) INIT_CS2(32) INIT_CS2(64) INIT_CS2(128)
+#define INIT_CS2(BN_, MI_) set_lds(&conv_small2_kernel<BN_, 6, MI_>, 120 * 1024); set_lds(&conv_small2_kernel<BN_, 12, MI_>, 120 * 1024);
+    INIT_CS2(16, 4) INIT_CS2(16, 2) INIT_CS2(32, 4) INIT_CS2(32, 2) INIT_CS2(64, 4) INIT_CS2(64, 2) INIT_CS2(128, 2)
 #undef INIT_CS2
 #define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 6>, 120 * 1024); set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 12>, 120 * 1024);
     INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)

@@ -42,8 +42,8 @@ else:
             env["SEHIP_DIRECT"] = flags[6:]
         if flags.startswith("minwg"):
             env["SEHIP_CW_MINWG"] = flags[5:]
-        if flags == "smallv1":
-            env["SEHIP_SMALL_V1"] = "1"
+        if flags.startswith("mi"):
+            env["SEHIP_SMALL_MI"] = flags[2:]
         if flags == "small128":
             env["SEHIP_SMALL128"] = "1"
         if flags == "nosmall":
