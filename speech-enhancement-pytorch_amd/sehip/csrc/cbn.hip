@@ -57,20 +57,29 @@ __device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr
     }
 }
 
-// sums of part[b][idx0 + k*Cr] (k < NS) over the blocks, by one wave, in ONE pass (all NS loads of a trip in flight)
+// sums of part[b][idx0 + k*Cr] (k < NS) over the blocks, by one wave.  The partials were written by other CUs moments
+// ago, so every load is a round trip to memory: ALL of a lane's loads (8 blocks x NS values; nblk <= 512) are issued before
+// the first add -- a trip-by-trip loop took 8 serial round trips, 14 of this kernel's 19 us, on the dependent chain.
+#define CBN_MAX_BLOCKS 512
 template <int NS>
 __device__ __forceinline__ void wave_reduce_partials(const float* __restrict__ part, int nblk, int stride, int idx0, int Cr,
                                                      double (&out)[NS]) {
+    float v[CBN_MAX_BLOCKS / 64][NS];
+#pragma unroll
+    for (int t = 0; t < CBN_MAX_BLOCKS / 64; ++t) {
+        const int b = (threadIdx.x & 63) + 64 * t;
+        const float* p = part + (size_t)(b < nblk ? b : 0) * stride + idx0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[t][k] = p[(size_t)k * Cr];  // unconditional (block 0 for b >= nblk): a predicated
+    }                                                                 // load is followed by vmcnt(0) and serialises them all
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    for (int b = threadIdx.x & 63; b < nblk; b += 64) {
-        const float* p = part + (size_t)b * stride + idx0;
-        float v[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) v[k] = p[(size_t)k * Cr];
+    for (int t = 0; t < CBN_MAX_BLOCKS / 64; ++t) {
+        const bool live = (int)(threadIdx.x & 63) + 64 * t < nblk;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] += (double)v[k];
+        for (int k = 0; k < NS; ++k) acc[k] += live ? (double)v[t][k] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) out[k] = wave_sum_d(acc[k]);
@@ -396,7 +405,7 @@ static int apply_blocks(long rows, int Cr) {
 static int stat_blocks(long rows, int Cr) {
     const int rpb = 256 / (Cr >> 3);
     long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
-    if (g > 512) g = 512;
+    if (g > CBN_MAX_BLOCKS) g = CBN_MAX_BLOCKS;
     if (g < 1) g = 1;
     return (int)g;
 }
