@@ -1058,11 +1058,19 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         gemm_kernel<16, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
     } else if (d->Npad == 32) {
         gemm_kernel<32, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
+    } else if (d->Npad == 64 && d->M < 256 * 192) {  // too few 256-row tiles to fill the GPU (LSTM input gradients)
+        sehip_note_kernel("gemm_kernel<64, 64, 2, 2>");
+        gemm_kernel<64, 64, 2, 2><<<cdiv(d->M, 64), 256, 0, st>>>(*d);
     } else if (d->Npad == 64) {
         gemm_kernel<64, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
     } else {
         SEHIP_REQUIRE(d->Npad % 128 == 0, "gemm: Npad=%d must be 16, 32, 64 or a multiple of 128", d->Npad);
-        gemm_kernel<128, 128, 2, 2><<<cdiv(d->M, 128) * (d->Npad / 128), 256, 0, st>>>(*d);
+        static const bool no64 = getenv("SEHIP_NO_BM64") != nullptr;
+        if (!no64 && (long)cdiv(d->M, 128) * (d->Npad / 128) < 512) {  // under one round of 2 workgroups per CU: halve the tile
+            sehip_note_kernel("gemm_kernel<128, 64, 2, 2>");
+            gemm_kernel<128, 64, 2, 2><<<cdiv(d->M, 64) * (d->Npad / 128), 256, 0, st>>>(*d);
+        } else
+            gemm_kernel<128, 128, 2, 2><<<cdiv(d->M, 128) * (d->Npad / 128), 256, 0, st>>>(*d);
     }
     SEHIP_CHECK_LAUNCH("gemm");
     return 0;

@@ -46,6 +46,8 @@ else:
             env["SEHIP_SMALL_MI"] = flags[2:]
         if flags == "small128":
             env["SEHIP_SMALL128"] = "1"
+        if flags == "nobm64":
+            env["SEHIP_NO_BM64"] = "1"
         if flags == "nosmall":
             env["SEHIP_NO_SMALL"] = "1"
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
