@@ -27,6 +27,14 @@ const char* sehip_last_kernel(void); /* instantiation chosen by the last sehip_g
 int sehip_version(void);
 int sehip_check_device(int device);
 
+/* ---- two-stream schedule of the backward pass (no reference counterpart: autograd runs one stream).  The weight
+ *      gradients run on a second stream; `from`'s work so far becomes a dependency of `to` through an event created
+ *      without timing and without the system-scope fence (hipEventDisableSystemFence): a default event record drains
+ *      and flushes the recording queue, 6-12 us of idle chain per record. */
+void* sehip_event_create(void);
+int sehip_event_destroy(void* event);
+int sehip_stream_depend(void* to_stream, void* from_stream, void* event);
+
 /* ---- STFT / iSTFT front-end: src/model/dccrn.py:649-747 (init_kernels, ConvSTFT, ConviSTFT) fused with the
  *      glue of DCCRN.forward src/model/dccrn.py:145-154 and :198-229 (mask E/C/R, clamp).  fft_len must be 512. */
 int sehip_stft_frames(int n_samples, int win_len, int hop);

@@ -28,6 +28,9 @@ F = C.c_float
 _PROTOS = {
     "sehip_version": [],
     "sehip_check_device": [I],
+    "sehip_event_create": [],
+    "sehip_event_destroy": [P],
+    "sehip_stream_depend": [P, P, P],
     "sehip_stft_frames": [I, I, I],
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
@@ -57,7 +60,7 @@ _PROTOS = {
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
 }
-_RESTYPE = {"sehip_cbn_scratch_floats": C.c_long}
+_RESTYPE = {"sehip_cbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
 
 
 def lib():

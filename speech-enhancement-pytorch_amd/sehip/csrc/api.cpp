@@ -37,3 +37,30 @@ extern "C" int sehip_check_device(int dev) {
         return sehip_set_error(-3, "check_device: libsehip is built for gfx950 only, device %d is %s", dev, p.gcnArchName);
     return 0;
 }
+
+// ---- cheap cross-stream dependency (see include/sehip.h)
+extern "C" void* sehip_event_create(void) {
+    hipEvent_t e = nullptr;
+    hipError_t st = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (st != hipSuccess) {
+        sehip_set_error(-2, "event_create: %s", hipGetErrorString(st));
+        return nullptr;
+    }
+    return (void*)e;
+}
+
+extern "C" int sehip_event_destroy(void* event) {
+    if (!event) return 0;
+    hipError_t st = hipEventDestroy((hipEvent_t)event);
+    if (st != hipSuccess) return sehip_set_error(-2, "event_destroy: %s", hipGetErrorString(st));
+    return 0;
+}
+
+extern "C" int sehip_stream_depend(void* to_stream, void* from_stream, void* event) {
+    if (!event) return sehip_set_error(-1, "stream_depend: null event");
+    hipError_t st = hipEventRecord((hipEvent_t)event, (hipStream_t)from_stream);
+    if (st != hipSuccess) return sehip_set_error(-2, "stream_depend: record: %s", hipGetErrorString(st));
+    st = hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)event, 0);
+    if (st != hipSuccess) return sehip_set_error(-2, "stream_depend: wait: %s", hipGetErrorString(st));
+    return 0;
+}

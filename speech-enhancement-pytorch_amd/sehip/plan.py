@@ -660,6 +660,7 @@ class DCCRNWorkspace:
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
         import os
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        self._events, self._event_i, self._chain_dirty = [], 0, True
         self._bind()
 
     # ---- descriptors ---------------------------------------------------------------------------
@@ -742,18 +743,34 @@ class DCCRNWorkspace:
         raise KeyError(out_name)
 
     def gemm(self, name):
+        self._chain_dirty = True
         call("sehip_gemm", C.byref(self.desc[name]), stream())
+
+    def _event(self):
+        """Round-robin pool of fence-free events (sehip_stream_depend)."""
+        if not self._events:
+            for _ in range(8):
+                e = _lib.lib().sehip_event_create()
+                if not e:
+                    raise SehipError("sehip_event_create: " + _lib.lib().sehip_last_error().decode())
+                self._events.append(e)
+        self._event_i = (self._event_i + 1) % len(self._events)
+        return self._events[self._event_i]
 
     def wgrad(self, name):
         """Weight gradients are side work (nothing in the backward chain consumes them): they go to a second HIP stream
         and fill the ~248 CUs the persistent LSTM kernels (8 workgroups) and the latency-bound BatchNorm passes leave
         idle.  The side stream waits for everything enqueued so far on the main stream (which includes the producer of
-        dOut); backward() joins the two streams before the gradients are un-packed."""
+        dOut) -- once per group of weight gradients: nothing new has been put on the chain between dec.fwd0 / fwd1 or the
+        four hh products, and every event record costs the chain a bubble; backward() joins the two streams before the
+        gradients are un-packed."""
         main = torch.cuda.current_stream()
         if self.side is None:
             call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), main.cuda_stream)
             return
-        self.side.wait_stream(main)
+        if self._chain_dirty:
+            call("sehip_stream_depend", self.side.cuda_stream, main.cuda_stream, self._event())
+            self._chain_dirty = False
         call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), self.side.cuda_stream)
 
     # ---- BatchNorm helpers ---------------------------------------------------------------------
@@ -781,6 +798,7 @@ class DCCRNWorkspace:
         g = lambda k: self.gpack.data_ptr() + 4 * st.bn_g_off[pre][k]
         coef = self.bn_coef[pre]
         dz2p = dz2.ptr if dz2 is not None else None
+        self._chain_dirty = True
         call("sehip_cbn_bwd_reduce", dz.ptr, dz2p, y.ptr, ptr(coef), pp("2.weight"), rows, cr, y.F, y.Tst, tfirst,
              ptr(self.bn_acc), stream())
         call("sehip_cbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
@@ -827,6 +845,7 @@ class DCCRNWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, T, h = self.B, self.T, cfg.hid
         self.gpack.zero_()
+        self._chain_dirty = True
         call("sehip_istft_bwd", ptr(dwav), ptr(self.wav), ptr(self.spec), b["mask"].ptr, ptr(tb.window), ptr(self.inv_coff),
              B, T, cfg.win_len, cfg.win_inc, cfg.fft_len, self.length, self.mode, b["dmask"].ptr, stream())
         for j in range(5, -1, -1):
@@ -838,17 +857,20 @@ class DCCRNWorkspace:
             self.gemm(f"dec{j}.dg")
         for tag in "ri":
             self.wgrad(f"proj_{tag}")
+        for tag in "ri":
             self.gemm(f"dproj_{tag}")
         for layer in (2, 1):
             dha, dhb = (b["dxo_r"], b["dxo_i"]) if layer == 2 else (b["dx2_r"], b["dx2_i"])
             whhT = tb.wpack.data_ptr() + 2 * st.whhT_off[layer]
+            self._chain_dirty = True
             call("sehip_lstm_bwd", dha.ptr, dhb.ptr, whhT, b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, B, T, h,
                  b[f"dpre{layer}_r"].ptr, b[f"dpre{layer}_i"].ptr, stream())
             for tag in "ri":
                 self.wgrad(f"ih{layer}_{tag}")
-                self.gemm(f"dx{layer}_{tag}")
             for combo in range(4):
                 self.wgrad(f"hh{layer}_{combo}")
+            for tag in "ri":
+                self.gemm(f"dx{layer}_{tag}")
         for i in range(5, -1, -1):
             dz = b["dz5l"] if i == 5 else b[f"dz{i}"]
             self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, b[f"dskip{i}"], b[f"y{i}"], b[f"dye{i}"], params, 0)
@@ -857,6 +879,6 @@ class DCCRNWorkspace:
                 self.gemm(f"enc{i}.dg0")
                 self.gemm(f"enc{i}.dg1")
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
         call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
         return grads
