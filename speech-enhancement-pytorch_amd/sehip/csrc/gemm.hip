@@ -1276,8 +1276,8 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     // workgroups than "fill the GPU twice" pay: measured per step with 8 / 16 / 32 / 64 splits: 7.24 / 7.15 / 7.19 / 7.3 ms.
     static const int cw_splits = getenv("SEHIP_CW_SPLITS") ? atoi(getenv("SEHIP_CW_SPLITS")) : 16;
     int splits = cw_splits >= 8 ? cw_splits / 8 * 8 : (cw_splits >= 4 ? 4 : (cw_splits >= 2 ? 2 : 1));
-    static const int cw_minwg = getenv("SEHIP_CW_MINWG") ? atoi(getenv("SEHIP_CW_MINWG")) : 0;
-    if (gx * splits < cw_minwg) splits = (cw_minwg / gx + 7) / 8 * 8;  // (off: see above)
+    static const int cw_minwg = getenv("SEHIP_CW_MINWG") ? atoi(getenv("SEHIP_CW_MINWG")) : 128;
+    if (gx * splits < cw_minwg) splits = (cw_minwg / gx + 7) / 8 * 8;  // few (n, channel) tiles (enc3, dec2): 16 splits would leave 32-64 workgroups
     while (splits < 8 && (gx * splits) % 8) splits <<= 1;
     const int tiles_per_wg = (MT + splits - 1) / splits;
     const int grid = gx * splits;  // splits beyond the data simply find an empty m range
@@ -1560,9 +1560,152 @@ static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
                    : launch_small_wgrad<BN_, KPW_, 12>(d, TB, JB, FR, tiles_per_wg, grid, lds, st);
     SW(16, 1) SW(16, 2) SW(16, 3) SW(16, 4) SW(16, 5) SW(16, 6) SW(16, 8) SW(16, 12)
     SW(32, 1) SW(32, 2) SW(32, 3) SW(32, 4) SW(32, 5) SW(32, 6) SW(32, 8) SW(32, 12)
-    SW(64, 1) SW(64, 2) SW(64, 3)  // wider 64-row tiles: the generic kernel measured faster
+    SW(64, 1) SW(64, 2) SW(64, 3) SW(64, 4) SW(64, 5)
 #undef SW
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrow_wgrad_kernel: weight gradient of the FIRST encoder layer (2 input channels = re | im of the spectrogram, 16
+// output channels): dW[16][2 x NF x 2].  320 numbers reduced over 1.3 M rows is VALU work, not MFMA work, and it is the
+// tail of every step: it can only start when the last kernel of the backward chain has produced dOut and nothing is
+// left to overlap it with (the table-gathered generic kernel took 110-150 us there).  A wave stages one frame (its 128
+// dOut rows and the two input frames it touches) in a private LDS region -- no workgroup barrier in the frame loop --
+// and lane (n, kt, c) accumulates the NF taps of dW[n][kt][.][c] over the frame's rows with a sliding window over the
+// input column; the next frame's loads are in flight meanwhile.  Workgroups reduce over their waves through LDS before
+// the atomics.
+// ------------------------------------------------------------------------------------------------
+#define NW_WAVES 8
+template <int NF>
+__global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip_gemm_desc d, int FRA /* staged input rows, multiple of 4 */,
+                                                                      int fa /* first staged row (multiple of 4, <= cv_fadd) */,
+                                                                      int frames_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int J = d.J, fmul = d.fmul;
+    const int gbytes = J * 16 * 2, xbytes = 2 * FRA * 2 * 2;
+    unsigned char* wbase = smem + (size_t)w * (gbytes + xbytes);
+    bf16_raw* sG = reinterpret_cast<bf16_raw*>(wbase);             // [J][16]
+    bf16_raw* sX = reinterpret_cast<bf16_raw*>(wbase + gbytes);    // [2 (kt)][FRA][2]
+    const int n = lane & 15, kg = lane >> 4, kt = kg >> 1, c = kg & 1;
+    const int gch = d.ntab[n >> 2].coff + (n & 3);  // channel of dOut that packed row n of dW belongs to
+
+    const int sT = d.src[0].T, sF = d.src[0].F;
+    const bf16_raw* xsrc = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
+    const bf16_raw* gsrc = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr);
+    const int gpieces = J * 2;              // 16-byte pieces of a dOut frame (8 channels each)
+    const int xpieces = FRA >> 2;           // 16-byte pieces (4 rows x 2 ch) of one input frame
+    constexpr int GPL = 4, XPL = 2;         // pieces per lane: J <= 128, FRA <= 512
+
+    float acc[NF], accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+
+    const int wave_id = blockIdx.x * NW_WAVES + w, nwaves = gridDim.x * NW_WAVES;
+    uint4 gr[GPL], xr[2][XPL];
+#define NW_FETCH(fr_)                                                                                              \
+    {                                                                                                              \
+        const int b_ = (fr_) / d.TT, t_ = (fr_) - b_ * d.TT;                                                       \
+        _Pragma("unroll") for (int u = 0; u < GPL; ++u) {                                                          \
+            const int idx = lane + 64 * u;                                                                         \
+            gr[u] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            if (idx < gpieces) {                                                                                   \
+                const int j = idx >> 1, h = idx & 1;                                                               \
+                const long off = (((long)b_ * d.dst[0].T + t_ + d.dst[0].toff) * d.dst[0].F + (long)j * d.dst[0].fmul + d.dst[0].fadd) * d.dst[0].C; \
+                gr[u] = *reinterpret_cast<const uint4*>(gsrc + off + 8 * h);                                       \
+            }                                                                                                      \
+        }                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                            \
+            const int ts = t_ + d.cv_toff[0][k];                                                                   \
+            const bool tok = ts >= d.src[0].tlo && ts < d.src[0].thi;                                              \
+            _Pragma("unroll") for (int u = 0; u < XPL; ++u) {                                                      \
+                const int idx = lane + 64 * u;                                                                     \
+                const int f = fa + 4 * idx;                                                                        \
+                xr[k][u] = make_uint4(0u, 0u, 0u, 0u);                                                             \
+                if (tok && idx < xpieces && f >= 0 && f + 3 < sF)                                                  \
+                    xr[k][u] = *reinterpret_cast<const uint4*>(xsrc + (((long)b_ * sT + ts) * sF + f) * 2);        \
+                else if (tok && idx < xpieces && f + 3 >= 0 && f < sF) {  /* piece straddles the edge: row by row */ \
+                    unsigned q[4];                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                        q[r] = (f + r >= 0 && f + r < sF) ? *reinterpret_cast<const unsigned*>(xsrc + (((long)b_ * sT + ts) * sF + f + r) * 2) : 0u; \
+                    xr[k][u] = make_uint4(q[0], q[1], q[2], q[3]);                                                 \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+
+    int fr = wave_id;
+    if (fr < frames_total) NW_FETCH(fr)
+    for (; fr < frames_total; fr += nwaves) {
+        // registers -> this wave's LDS region (only this wave reads it: no barrier, the LDS pipe is in order per wave)
+#pragma unroll
+        for (int u = 0; u < GPL; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < gpieces) *reinterpret_cast<uint4*>(&sG[(idx >> 1) * 16 + 8 * (idx & 1)]) = gr[u];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int u = 0; u < XPL; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < xpieces) *reinterpret_cast<uint4*>(&sX[(k * FRA + 4 * idx) * 2]) = xr[k][u];
+            }
+        if (fr + nwaves < frames_total) NW_FETCH(fr + nwaves)
+
+        // row j of the frame reads input rows j*fmul + tap + (cv_fadd - fa), tap < NF
+        const bf16_raw* xcol = sX + (kt * FRA + (d.cv_fadd - fa)) * 2 + c;
+        const bf16_raw* gcol = sG + gch;
+#pragma unroll 8
+        for (int j = 0; j < J; ++j) {
+            const float g = bf2f(gcol[j * 16]);
+            accb += g;
+#pragma unroll
+            for (int tap = 0; tap < NF; ++tap) acc[tap] += g * bf2f(xcol[(j * fmul + tap) * 2]);
+        }
+    }
+#undef NW_FETCH
+
+    // reduce the waves of the workgroup through LDS, then one atomic per dW entry and workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [NW_WAVES][64][NF + 1]
+#pragma unroll
+    for (int i = 0; i < NF; ++i) red[(w * 64 + lane) * (NF + 1) + i] = acc[i];
+    red[(w * 64 + lane) * (NF + 1) + NF] = accb;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int i = 0; i <= NF; ++i) {
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW_WAVES; ++ww) v += red[(ww * 64 + lane) * (NF + 1) + i];
+            if (i < NF) atomicAdd(&d.dW[(size_t)n * d.K + kt * 16 + i * 2 + c], v);  // K order of a 2-channel source: kt*16 + tap*2 + c
+            else if (kg == 0 && d.dbias) atomicAdd(&d.dbias[n], v);
+        }
+    }
+}
+
+static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
+    if (disabled || d.cv_nf <= 0 || d.src[0].C != 2 || d.src[1].ptr || d.dst[1].ptr) return 0;
+    if (d.N != 16 || d.Npad != 16 || d.J > 128 || d.K < 32 || d.cv_nf > 8) return 0;
+    if (d.dst[0].is_f32 || (d.dst[0].C & 7)) return 0;
+    const int FR = (d.J - 1) * d.fmul + d.cv_nf;
+    const int fa = (d.cv_fadd >= 0 ? d.cv_fadd / 4 : -((-d.cv_fadd + 3) / 4)) * 4;
+    const int FRA = ((d.cv_fadd - fa) + FR + 3) / 4 * 4;
+    if (FRA > 512 || (d.src[0].F & 3)) return 0;
+    const int B = d.M / (d.TT * d.J);
+    const int frames = B * d.TT;
+    const size_t per_wave = (size_t)d.J * 16 * 2 + (size_t)2 * FRA * 2 * 2;
+    size_t lds = per_wave * NW_WAVES;
+    const size_t red = (size_t)NW_WAVES * 64 * 6 * 4;
+    if (lds < red) lds = red;
+    if (lds > 64 * 1024) return 0;
+    int grid = (frames + NW_WAVES - 1) / NW_WAVES;
+    if (grid > 256) grid = 256;
+    sehip_note_kernel("narrow_wgrad_kernel<%d>", d.cv_nf);
+    if (d.cv_nf == 5) narrow_wgrad_kernel<5><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
+    else return 0;
+    return 1;
 }
 
 extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
@@ -1570,6 +1713,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     SEHIP_REQUIRE(d->dW != nullptr, "wgrad: missing dW");
     SEHIP_REQUIRE(!d->dst[0].is_f32 && !(d->dst[1].ptr && d->dst[1].is_f32), "wgrad: dOut must be bf16");
     hipStream_t st = (hipStream_t)stream;
+    if (try_narrow_wgrad(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(narrow)");
+        return 0;
+    }
     if (try_conv_wgrad(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv)");
         return 0;
@@ -1618,7 +1765,7 @@ extern "C" int sehip_init(void) {
 #define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 6>, 120 * 1024); set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 12>, 120 * 1024);
     INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)
     INIT_SW(32, 1) INIT_SW(32, 2) INIT_SW(32, 3) INIT_SW(32, 4) INIT_SW(32, 5) INIT_SW(32, 6) INIT_SW(32, 8) INIT_SW(32, 12)
-    INIT_SW(64, 1) INIT_SW(64, 2) INIT_SW(64, 3)
+    INIT_SW(64, 1) INIT_SW(64, 2) INIT_SW(64, 3) INIT_SW(64, 4) INIT_SW(64, 5)
 #undef INIT_SW
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sehip_set_error(-2, "init: %s", hipGetErrorString(e));

@@ -332,7 +332,7 @@ class DCCRNStatic:
                             wneg[:, kt * 16 + kf * 2 + c] = neg[:, c, kf, kt]
             self.specs[f"enc{i}.fwd"] = GemmSpec(f"enc{i}.fwd", rows, widx, wneg, co, eff_bias(pre, co // 2), "T",
                                                   self.F0 >> (i + 1), 2, [(src, "all")], [(f"y{i}", 0, 1, 0)],
-                                                  conv=(5, -2, [[-1, 0], [0, 0]]) if ci >= 8 else None)
+                                                  conv=(5, -2, [[-1, 0], [0, 0]]))  # ci == 2: read by the narrow wgrad only
             self.bn.append((pre, co // 2))
             if i >= 1:
                 # dgrad by output-row parity: dX[b,t,2j+p,ci] = sum dY[b,t+1-kt,j+d,co] * full[co,ci,kf,kt], kf = p+2-2d
