@@ -1576,7 +1576,7 @@ static int try_conv_small_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
 // the atomics.
 // ------------------------------------------------------------------------------------------------
 #define NW_WAVES 8
-template <int NF>
+template <int NF, int FMUL>
 __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip_gemm_desc d, int FRA /* staged input rows, multiple of 4 */,
                                                                       int fa /* first staged row (multiple of 4, <= cv_fadd) */,
                                                                       int frames_total) {
@@ -1587,7 +1587,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
     unsigned char* wbase = smem + (size_t)w * (gbytes + xbytes);
     bf16_raw* sG = reinterpret_cast<bf16_raw*>(wbase);             // [J][16]
     bf16_raw* sX = reinterpret_cast<bf16_raw*>(wbase + gbytes);    // [2 (kt)][FRA][2]
-    const int n = lane & 15, kg = lane >> 4, kt = kg >> 1, c = kg & 1;
+    // lane = n + 16 kt + 32 half: both input channels of (n, kt), rows [half J/2, (half + 1) J/2) of the frame
+    const int n = lane & 15, kt = (lane >> 4) & 1, half = lane >> 5;
     const int gch = d.ntab[n >> 2].coff + (n & 3);  // channel of dOut that packed row n of dW belongs to
 
     const int sT = d.src[0].T, sF = d.src[0].F;
@@ -1597,9 +1598,9 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
     const int xpieces = FRA >> 2;           // 16-byte pieces (4 rows x 2 ch) of one input frame
     constexpr int GPL = 4, XPL = 2;         // pieces per lane: J <= 128, FRA <= 512
 
-    float acc[NF], accb = 0.f;
+    float acc[NF][2], accb = 0.f;
 #pragma unroll
-    for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+    for (int i = 0; i < NF; ++i) acc[i][0] = acc[i][1] = 0.f;
 
     const int wave_id = blockIdx.x * NW_WAVES + w, nwaves = gridDim.x * NW_WAVES;
     uint4 gr[GPL], xr[2][XPL];
@@ -1652,34 +1653,50 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
             }
         if (fr + nwaves < frames_total) NW_FETCH(fr + nwaves)
 
-        // row j of the frame reads input rows j*fmul + tap + (cv_fadd - fa), tap < NF
-        const bf16_raw* xcol = sX + (kt * FRA + (d.cv_fadd - fa)) * 2 + c;
+        // row j of the frame reads input rows j*FMUL + tap + (cv_fadd - fa), tap < NF; one dword = both channels of a row.
+        // Consecutive rows of a lane shift the tap window by FMUL rows: only FMUL new dwords per row.
+        const unsigned* xcol = reinterpret_cast<const unsigned*>(sX) + kt * FRA + (d.cv_fadd - fa);
         const bf16_raw* gcol = sG + gch;
+        const int j0 = half * (J >> 1), j1 = j0 + (J >> 1);
+        float xw[NF][2];
+#pragma unroll
+        for (int tap = 0; tap < NF; ++tap) {
+            const unsigned q = xcol[j0 * FMUL + tap];
+            xw[tap][0] = __uint_as_float(q << 16); xw[tap][1] = __uint_as_float(q & 0xffff0000u);
+        }
 #pragma unroll 8
-        for (int j = 0; j < J; ++j) {
+        for (int j = j0; j < j1; ++j) {
             const float g = bf2f(gcol[j * 16]);
             accb += g;
 #pragma unroll
-            for (int tap = 0; tap < NF; ++tap) acc[tap] += g * bf2f(xcol[(j * fmul + tap) * 2]);
+            for (int tap = 0; tap < NF; ++tap) { acc[tap][0] += g * xw[tap][0]; acc[tap][1] += g * xw[tap][1]; }
+#pragma unroll
+            for (int tap = 0; tap + FMUL < NF; ++tap) { xw[tap][0] = xw[tap + FMUL][0]; xw[tap][1] = xw[tap + FMUL][1]; }
+#pragma unroll
+            for (int tap = (NF > FMUL ? NF - FMUL : 0); tap < NF; ++tap) {
+                const unsigned q = xcol[(j + 1) * FMUL + tap];   // the row after the last one reads staged padding
+                xw[tap][0] = __uint_as_float(q << 16); xw[tap][1] = __uint_as_float(q & 0xffff0000u);
+            }
         }
     }
 #undef NW_FETCH
 
-    // reduce the waves of the workgroup through LDS, then one atomic per dW entry and workgroup
+    // reduce the waves (and the two row halves) of the workgroup through LDS, then one atomic per dW entry and workgroup
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [NW_WAVES][64][NF + 1]
+    constexpr int NR = 2 * NF + 1;
+    float* red = reinterpret_cast<float*>(smem);  // [NW_WAVES][64][NR]
 #pragma unroll
-    for (int i = 0; i < NF; ++i) red[(w * 64 + lane) * (NF + 1) + i] = acc[i];
-    red[(w * 64 + lane) * (NF + 1) + NF] = accb;
+    for (int i = 0; i < NF; ++i) { red[(w * 64 + lane) * NR + 2 * i] = acc[i][0]; red[(w * 64 + lane) * NR + 2 * i + 1] = acc[i][1]; }
+    red[(w * 64 + lane) * NR + 2 * NF] = accb;
     __syncthreads();
-    if (w == 0) {
+    if (w == 0 && lane < 32) {
 #pragma unroll
-        for (int i = 0; i <= NF; ++i) {
+        for (int i = 0; i < NR; ++i) {
             float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < NW_WAVES; ++ww) v += red[(ww * 64 + lane) * (NF + 1) + i];
-            if (i < NF) atomicAdd(&d.dW[(size_t)n * d.K + kt * 16 + i * 2 + c], v);  // K order of a 2-channel source: kt*16 + tap*2 + c
-            else if (kg == 0 && d.dbias) atomicAdd(&d.dbias[n], v);
+            for (int ww = 0; ww < NW_WAVES; ++ww) v += red[(ww * 64 + lane) * NR + i] + red[(ww * 64 + lane + 32) * NR + i];
+            if (i < 2 * NF) atomicAdd(&d.dW[(size_t)n * d.K + kt * 16 + i], v);  // K order of a 2-channel source: kt*16 + tap*2 + c
+            else if (kt == 0 && d.dbias) atomicAdd(&d.dbias[n], v);
         }
     }
 }
@@ -1691,19 +1708,19 @@ static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     if (d.dst[0].is_f32 || (d.dst[0].C & 7)) return 0;
     const int FR = (d.J - 1) * d.fmul + d.cv_nf;
     const int fa = (d.cv_fadd >= 0 ? d.cv_fadd / 4 : -((-d.cv_fadd + 3) / 4)) * 4;
-    const int FRA = ((d.cv_fadd - fa) + FR + 3) / 4 * 4;
+    const int FRA = ((d.cv_fadd - fa) + FR + d.fmul + 3) / 4 * 4;  // + fmul: the window refill after a lane's last row stays inside
     if (FRA > 512 || (d.src[0].F & 3)) return 0;
     const int B = d.M / (d.TT * d.J);
     const int frames = B * d.TT;
     const size_t per_wave = (size_t)d.J * 16 * 2 + (size_t)2 * FRA * 2 * 2;
     size_t lds = per_wave * NW_WAVES;
-    const size_t red = (size_t)NW_WAVES * 64 * 6 * 4;
+    const size_t red = (size_t)NW_WAVES * 64 * (2 * 8 + 1) * 4;
     if (lds < red) lds = red;
     if (lds > 64 * 1024) return 0;
     int grid = (frames + NW_WAVES - 1) / NW_WAVES;
     if (grid > 256) grid = 256;
     sehip_note_kernel("narrow_wgrad_kernel<%d>", d.cv_nf);
-    if (d.cv_nf == 5) narrow_wgrad_kernel<5><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
+    if (d.cv_nf == 5 && d.fmul == 2 && !(d.J & 1)) narrow_wgrad_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
     else return 0;
     return 1;
 }
