@@ -1040,6 +1040,167 @@ static int check_desc(const char* who, const sehip_gemm_desc* d) {
 
 extern "C" int sehip_gemm_desc_size(void) { return (int)sizeof(sehip_gemm_desc); }
 
+// ------------------------------------------------------------------------------------------------
+// conv_narrow_kernel: forward / dgrad product whose SOURCE has 2 channels (the first encoder layer reads the
+// spectrogram, the last decoder layer's input gradient reads d(mask)): K = 2 frames x 5 taps x 2 channels in the
+// layout k = kt*16 + tap*2 + c (K = 32 with the padding), so the whole reduction is ONE MFMA step and the layer is a
+// pure stream: 5 MB in, 42-85 MB out.  The table-gathered generic kernel spent its time on 4-byte gathers (60-71 us).
+// Here the weights live in registers, the input frames of a tile are staged in LDS as they lie in memory (4 bytes per
+// row), and a lane's 8 consecutive k are 16 contiguous bytes of that image (4 taps x 2 channels; the taps beyond the
+// fifth meet zero weights).  Tile loop and store addressing as in conv_small2_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int MI>
+__global__ __launch_bounds__(256) void conv_narrow_kernel(const sehip_gemm_desc d, int TB, int FRA, int fa, int tiles_per_wg) {
+    constexpr int TN = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* sX = reinterpret_cast<unsigned*>(smem);  // [(TB + 1) frames][FRA rows] dwords (re | im)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4;
+    const int JB = d.J;
+    const int tblocks = (d.TT + TB - 1) / TB;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * tblocks;
+    const int tmin = min(d.cv_toff[0][0], d.cv_toff[0][1]);
+    const int sT = d.src[0].T, sF = d.src[0].F;
+    const unsigned* xsrc = reinterpret_cast<const unsigned*>(d.src[0].ptr);
+
+    // weights: row (lane & 15) of each 16-row tile, k chunk g
+    bf16x8 wf[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+        wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(d.W) +
+                                                                              (size_t)(ni * 16 + (lane & 15)) * d.K + 8 * g));
+    // staging: piece = 4 rows of one frame; (TB + 1) * FRA / 4 pieces, NPL per thread
+    constexpr int NPL = 4;
+    const int ppf = FRA >> 2;                 // pieces per frame
+    const int NP = (TB + 1) * ppf;
+    int p_fr[NPL], p_row[NPL];
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) {
+        const int idx = tid + 256 * u;
+        p_fr[u] = -1; p_row[u] = 0;
+        if (idx < NP) { p_fr[u] = idx / ppf; p_row[u] = (idx - p_fr[u] * ppf) * 4; }
+    }
+    // operand rows / store addressing of this lane
+    const int kt = g >> 1, hf = g & 1;
+    int abase[MI], e_tl[MI], e_off0[MI], e_off1[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = 16 * MI * w + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        abase[mi] = (tl + d.cv_toff[0][kt] - tmin) * FRA + jl * d.fmul + 4 * hf + (d.cv_fadd - fa);
+        e_tl[mi] = tl;
+        RowPos rp;
+        rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+        e_off0[mi] = (int)dst_row_offset(d.dst[0], rp, d.fmul);
+        e_off1[mi] = d.dst[1].ptr ? (int)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
+    }
+    const long bs0 = (long)d.dst[0].T * d.dst[0].F * d.dst[0].C, bs1 = (long)d.dst[1].T * d.dst[1].F * d.dst[1].C;
+    const int ts0 = d.dst[0].F * d.dst[0].C, ts1 = d.dst[1].F * d.dst[1].C;
+    sehip_nchunk nck[TN];
+    float4 bias4[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = ni * 16 + 4 * g;
+        nck[ni] = d.ntab[n >> 2];
+        bias4[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    uint4 pr[NPL];
+#define CN_FETCH(mt_)                                                                                              \
+    {                                                                                                              \
+        const int b_ = (mt_) / tblocks, t0_ = ((mt_) - b_ * tblocks) * TB;                                         \
+        _Pragma("unroll") for (int u = 0; u < NPL; ++u) {                                                          \
+            pr[u] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            const int ts = t0_ + tmin + p_fr[u], f = fa + p_row[u];                                                \
+            if (p_fr[u] >= 0 && ts >= d.src[0].tlo && ts < d.src[0].thi) {                                         \
+                const unsigned* q = xsrc + ((long)b_ * sT + ts) * sF + f;                                          \
+                if (f >= 0 && f + 3 < sF) pr[u] = *reinterpret_cast<const uint4*>(q);                              \
+                else {                                                                                             \
+                    unsigned v[4];                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = (f + r >= 0 && f + r < sF) ? q[r] : 0u;   \
+                    pr[u] = make_uint4(v[0], v[1], v[2], v[3]);                                                    \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    if (mt_begin < mt_end) CN_FETCH(mt_begin)
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        const int b = mt / tblocks, t0 = (mt - b * tblocks) * TB;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u)
+            if (p_fr[u] >= 0) *reinterpret_cast<uint4*>(&sX[p_fr[u] * FRA + p_row[u]]) = pr[u];
+        __syncthreads();
+        if (mt + 1 < mt_end) CN_FETCH(mt + 1)
+
+        f32x4 acc[TN][MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            // 16 contiguous bytes at an 8-byte aligned address: two ds_read_b64
+            const uint2 lo = *reinterpret_cast<const uint2*>(&sX[abase[mi]]), hi = *reinterpret_cast<const uint2*>(&sX[abase[mi] + 2]);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (t0 + e_tl[mi] >= d.TT) continue;
+            const long ro0 = e_off0[mi] + b * bs0 + (long)t0 * ts0;
+            const long ro1 = e_off1[mi] + b * bs1 + (long)t0 * ts1;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const sehip_nchunk nc = nck[ni];
+                if (nc.nvalid <= 0) continue;
+                f32x4 v = acc[ni][mi];
+                v[0] += bias4[ni].x; v[1] += bias4[ni].y; v[2] += bias4[ni].z; v[3] += bias4[ni].w;
+                const long off = (nc.dst ? ro1 : ro0) + nc.coff;
+                void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
+                const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+                if (is_f32) {
+                    float* q = reinterpret_cast<float*>(dptr) + off;
+                    if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        for (int e = 0; e < nc.nvalid; ++e) q[e] = v[e];
+                } else {
+                    bf16_raw* q = reinterpret_cast<bf16_raw*>(dptr) + off;
+                    if (nc.nvalid == 4) *reinterpret_cast<uint2*>(q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    else
+                        for (int e = 0; e < nc.nvalid; ++e) q[e] = f2bf(v[e]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef CN_FETCH
+}
+
+static int try_conv_narrow(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
+    if (disabled || d.cv_nf <= 0 || d.cv_nf > 5 || d.src[0].C != 2 || d.src[1].ptr) return 0;
+    if ((d.Npad != 16 && d.Npad != 32) || d.K < 32 || d.J > 128 || (128 % d.J)) return 0;
+    const int fa = (d.cv_fadd >= 0 ? d.cv_fadd / 4 : -((-d.cv_fadd + 3) / 4)) * 4;
+    if ((d.cv_fadd - fa) & 1) return 0;  // 8-byte aligned operand reads
+    constexpr int MI = 4;
+    const int TB = 64 * MI / d.J;
+    if (TB < 1) return 0;
+    // staged rows per frame: the lane of the last row reads taps 4..7 as well (zero weights): (J-1)*fmul + 8 rows
+    const int FRA = ((d.cv_fadd - fa) + (d.J - 1) * d.fmul + 8 + 3) / 4 * 4;
+    if ((TB + 1) * (FRA >> 2) > 4 * 256 || (d.src[0].F & 3)) return 0;
+    const size_t lds = (size_t)(TB + 1) * FRA * 4;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * ((d.TT + TB - 1) / TB);
+    int wgs = 1024;
+    if (wgs > MT) wgs = MT;
+    const int tiles_per_wg = (MT + wgs - 1) / wgs;
+    const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
+    sehip_note_kernel("conv_narrow_kernel<%d, %d>", d.Npad, MI);
+    if (d.Npad == 16) conv_narrow_kernel<16, MI><<<grid, 256, lds, st>>>(d, TB, FRA, fa, tiles_per_wg);
+    else conv_narrow_kernel<32, MI><<<grid, 256, lds, st>>>(d, TB, FRA, fa, tiles_per_wg);
+    return 1;
+}
+
 extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("gemm", d)) return e;
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
@@ -1050,6 +1211,10 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     }
     if (try_conv_small(*d, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv-small)");
+        return 0;
+    }
+    if (try_conv_narrow(*d, st)) {
+        SEHIP_CHECK_LAUNCH("gemm(conv-narrow)");
         return 0;
     }
     sehip_note_kernel("gemm_kernel<%d, %d, %d, %d>", d->Npad <= 64 ? d->Npad : 128, d->Npad <= 64 ? 256 : 128,

@@ -423,7 +423,7 @@ class DCCRNStatic:
             assert npad_of(c1 + c2) == c1 + c2
             self.specs[f"dec{j}.dg"] = GemmSpec(f"dec{j}.dg", rows, w[order], wn[order], c1 + c2, None, "T", f_in, 2,
                                                 [(gsrc, "all")], [d1, (f"dskip{5 - j}", 0, 1, 0)], ntab=nt, kind="dgrad",
-                                                conv=(5, -2, [[0, 1], [0, 0]]) if co >= 8 else None)
+                                                conv=(5, -2, [[0, 1], [0, 0]]) if co >= 8 else (5, -2, [[-1, 0], [0, 0]]))
 
         # ---------------- complex LSTM ----------------
         c5 = kn[6]
