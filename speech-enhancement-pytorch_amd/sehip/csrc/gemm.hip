@@ -411,176 +411,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv_direct_kernel: conv_gemm_kernel without the weight tile in LDS.  Staging W per K step costs 4 ds_write_b128
-// (13 cycles each on the store path) and two barriers per step, which together took as long as the step's MFMAs.  Here
-// every lane loads its MFMA A-operand fragment (16 consecutive k of one weight row) straight from global memory (the
-// packed weights are L2-resident, 64-byte segments), one step ahead of use; LDS holds only the input patch, and the
-// only barriers are the two around the patch staging of each 64-channel chunk.
-// ------------------------------------------------------------------------------------------------
-template <int TN>
-struct WFrag { uint4 v[2][TN]; };
-
-template <int TN>
-__device__ __forceinline__ WFrag<TN> load_wfrag(const bf16_raw* const (&wp)[TN], int kcol) {
-    WFrag<TN> f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) f.v[ks][ni] = *reinterpret_cast<const uint4*>(wp[ni] + kcol + 32 * ks);
-    return f;
-}
-
-template <int BN, int WN, int WM, int NF>
-__global__ __launch_bounds__(256, 2) void conv_direct_kernel(const sehip_gemm_desc d, int TB, int JB, int FR) {
-    constexpr int BM = 128;
-    constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
-    constexpr int NIT = 2 * NF;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_raw* patch = reinterpret_cast<bf16_raw*>(smem);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave / WM, wm = wave % WM;
-    const int ntn = d.Npad / BN;
-    const int tblocks = (d.TT + TB - 1) / TB, jblocks = d.J / JB;
-    // XCD-contiguous order, n-tile fastest (see gemm_kernel)
-    const int nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const int nt = logical % ntn;
-    int rest = logical / ntn;
-    const int jb = rest % jblocks; rest /= jblocks;
-    const int tb = rest % tblocks;
-    const int b = rest / tblocks;
-    const int t0 = tb * TB, j0 = jb * JB, n0 = nt * BN;
-    const int f0 = j0 * d.fmul + d.cv_fadd;
-
-    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
-    const int Ctot = C0 + C1;
-    const int ncc = Ctot >> 6;
-    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
-    const int NP = (TB + 1) * FR * 8;
-
-    const bf16_raw* wp[TN];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-        wp[ni] = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)(n0 + wn * (BN / WN) + ni * 16 + (lane & 15)) * d.K + 8 * (lane >> 4);
-
-    int abase[TM];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int r = wm * (BM / WM) + mi * 16 + (lane & 15);
-        const int tl = r / JB, jl = r - tl * JB;
-        abase[mi] = (tl * FR + jl * d.fmul) * CV_PITCH + 8 * (lane >> 4);
-    }
-
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    WFrag<TN> cur = load_wfrag<TN>(wp, 0);
-
-    for (int cc = 0; cc < ncc; ++cc) {
-        const bool second = cc * 64 >= C0;
-        {
-            const int sT = second ? d.src[1].T : d.src[0].T, sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
-            const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
-            const int tfirst = t0 + (second ? tmin1 : tmin0);
-            const bf16_raw* cbase = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) +
-                                    (((long)b * sT + tfirst) * sF + f0) * sC + (cc * 64 - (second ? C0 : 0));
-#pragma unroll
-            for (int i0 = 0; i0 < CV_MAXP; i0 += 4) {
-                uint4 pr[4];
-                int lds_off[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    pr[q] = make_uint4(0u, 0u, 0u, 0u);
-                    const int idx = tid + 256 * (i0 + q);
-                    const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
-                    const int r = rem >> 3, c8 = rem & 7;
-                    const int ts = tfirst + pp, f = f0 + r;
-                    lds_off[q] = idx < NP ? (pp * FR + r) * CV_PITCH + c8 * 8 : -1;
-                    if (idx < NP && ts >= tlo && ts < thi && f >= 0 && f < sF)
-                        pr[q] = *reinterpret_cast<const uint4*>(cbase + (pp * sF + r) * sC + c8 * 8);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (lds_off[q] >= 0) *reinterpret_cast<uint4*>(&patch[lds_off[q]]) = pr[q];
-            }
-        }
-        __syncthreads();
-        const int dt0 = (second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0);
-        const int dt1 = (second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            WFrag<TN> nxt = cur;
-            if (it + 1 < NIT) nxt = load_wfrag<TN>(wp, (it + 1) * Ctot + cc * 64);
-            else if (cc + 1 < ncc) nxt = load_wfrag<TN>(wp, (cc + 1) * 64);
-            const int kt = it / NF, tap = it - kt * NF;
-            const int toff_e = ((kt ? dt1 : dt0) * FR + tap) * CV_PITCH;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[TM];
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + toff_e + 32 * ks]));
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.v[ks][ni]), af[mi],
-                                                                              acc[ni][mi], 0, 0, 0);
-            }
-            cur = nxt;
-        }
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int rr = wm * (BM / WM) + mi * 16 + (lane & 15);
-        const int tl = rr / JB, jl = rr - tl * JB;
-        RowPos r;
-        r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
-        if (!r.valid) continue;
-        const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
-        const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * (lane >> 4);
-            const sehip_nchunk nc = d.ntab[n >> 2];
-            if (nc.nvalid <= 0) continue;
-            store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
-        }
-    }
-}
-
-template <int BN, int WN, int WM>
-static int launch_conv_direct(const sehip_gemm_desc& d, int TB, int JB, int FR, int grid, size_t lds, hipStream_t st) {
-#define CD_CASE(NF_)                                                                                                  \
-    case NF_: {                                                                                                       \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<BN, WN, WM, NF_>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
-            attr_set = true;                                                                                          \
-        }                                                                                                             \
-        sehip_note_kernel("conv_direct_kernel<%d, %d, %d, %d>", BN, WN, WM, NF_);                                     \
-        conv_direct_kernel<BN, WN, WM, NF_><<<grid, 256, lds, st>>>(d, TB, JB, FR);                                   \
-        return 1;                                                                                                     \
-    }
-    switch (d.cv_nf) {
-        CD_CASE(2)
-        CD_CASE(3)
-        CD_CASE(5)
-        default: return 0;
-    }
-#undef CD_CASE
-}
-
 template <int BN, int WN, int WM>
 static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int grid, size_t lds, hipStream_t st) {
 #define CV_CASE(NF_)                                                                                                  \
@@ -617,16 +447,11 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
     if ((TB + 1) * FR * 8 > CV_MAXP * 256) return 0;
     const int B = d.M / (d.TT * d.J);
     const int tblocks = (d.TT + TB - 1) / TB;
-    static const int direct = getenv("SEHIP_DIRECT") ? atoi(getenv("SEHIP_DIRECT")) : 0;
     if ((d.Npad & 127) == 0) {
         const int grid = B * tblocks * (d.Npad / 128);
-        if (direct == 1) return launch_conv_direct<128, 4, 1>(d, TB, JB, FR, grid, patch_bytes, st);
-        if (direct == 2) return launch_conv_direct<128, 2, 2>(d, TB, JB, FR, grid, patch_bytes, st);
         return launch_conv<128, 2, 2>(d, TB, JB, FR, grid, 128 * 128 + patch_bytes, st);
     }
     const int grid = B * tblocks * (d.Npad / 64);
-    if (direct == 1) return launch_conv_direct<64, 2, 2>(d, TB, JB, FR, grid, patch_bytes, st);
-    if (direct == 2) return launch_conv_direct<64, 1, 4>(d, TB, JB, FR, grid, patch_bytes, st);
     return launch_conv<64, 1, 4>(d, TB, JB, FR, grid, 64 * 128 + patch_bytes, st);
 }
 
