@@ -48,6 +48,16 @@ int sehip_istft_bwd(const float* dwav, const float* wav, const float* spec, cons
                     const float* inv_coff, int B, int T, int win_len, int hop, int fft_len, int length,
                     int masking_mode, void* dmask_bf16 /*[B][T][256][2]*/, void* stream);
 
+/* ---- stft_custom / istft_custom: src/evaluate.py:101-128 and :130-162 (torch.stft / torch.istft with a periodic hann
+ *      window of win_length centred in n_fft, center -> reflect padding, one-sided, and the reference's own / and * by
+ *      win_length).  wav [rows][n_samples] fp32, spec [rows][n_fft/2+1][n_frames][2] fp32 (time innermost, as the
+ *      reference returns it), frames_ws [rows][n_frames][n_fft] fp32 scratch.  n_fft must be 512. */
+int sehip_stft_custom_frames(int n_samples, int n_fft, int hop, int center);
+int sehip_stft_custom_fwd(const float* wav, int rows, int n_samples, int n_fft, int hop, int win_length, int center,
+                          float* spec, void* stream);
+int sehip_istft_custom_fwd(const float* spec, int rows, int n_frames, int n_fft, int hop, int win_length, int center,
+                           int length, float* frames_ws, float* wav, void* stream);
+
 /* ---- SI-SNR loss: src/loss.py:14-29 (si_snr, loss_sisdr).  rowstat is [rows][4] fp32 scratch kept for bwd. */
 int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* rowstat, float* loss, void* stream);
 int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, const float* upstream /*scalar or NULL*/,

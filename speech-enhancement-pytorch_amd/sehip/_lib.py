@@ -32,6 +32,9 @@ _PROTOS = {
     "sehip_event_destroy": [P],
     "sehip_stream_depend": [P, P, P],
     "sehip_stft_frames": [I, I, I],
+    "sehip_stft_custom_frames": [I, I, I, I],
+    "sehip_stft_custom_fwd": [P, I, I, I, I, I, I, P, P],
+    "sehip_istft_custom_fwd": [P, I, I, I, I, I, I, I, P, P, P],
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
     "sehip_pointwise_loss_fwd": [P, P, L, I, P, P, P],

@@ -14,94 +14,7 @@
 // so every store is a full 32/64-byte segment.  HBM-bound; no LDS.
 #include "common.h"
 
-#define FFT_N 512
-#define NBIN 257
-
-struct FftTw {
-    float tr[8], ti[8];  // W512^(lane * k2)
-    float sr[5], si[5];  // stage twiddles W_(2h)^(lane mod h), h = 32,16,8,4,2
-};
-
-template <int SIGN>
-__device__ __forceinline__ void fft_twiddles(FftTw& w, int lane) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float s, c;
-        sincospif((float)(lane * k) * (1.0f / 256.0f), &s, &c);
-        w.tr[k] = c; w.ti[k] = SIGN * s;
-    }
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-        const int h = 32 >> st;
-        float s, c;
-        sincospif((float)(lane & (h - 1)) / (float)h, &s, &c);
-        w.sr[st] = c; w.si[st] = SIGN * s;
-    }
-}
-
-// in : lane l, register r  <->  element l + 64 r
-// out: lane l, register j  <->  element 8*brev6(l) + brev3(j)
-template <int SIGN>
-__device__ __forceinline__ void fft512_wave(float (&re)[8], float (&im)[8], const FftTw& w, int lane) {
-    const float h = 0.70710678118654752f;
-    // ---- radix-8 DIF over the register index ----
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float ar = re[i], ai = im[i], br = re[i + 4], bi = im[i + 4];
-        re[i] = ar + br; im[i] = ai + bi;
-        float dr = ar - br, di = ai - bi;
-        // * W8^i : (1), (h, s*h), (0, s), (-h, s*h)  with s = SIGN
-        if (i == 0) { re[4] = dr; im[4] = di; }
-        if (i == 1) { re[5] = h * (dr - SIGN * di); im[5] = h * (di + SIGN * dr); }
-        if (i == 2) { re[6] = -SIGN * di; im[6] = SIGN * dr; }
-        if (i == 3) { re[7] = h * (-dr - SIGN * di); im[7] = h * (-di + SIGN * dr); }
-    }
-#pragma unroll
-    for (int b = 0; b < 8; b += 4) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float ar = re[b + i], ai = im[b + i], br = re[b + i + 2], bi = im[b + i + 2];
-            re[b + i] = ar + br; im[b + i] = ai + bi;
-            float dr = ar - br, di = ai - bi;
-            if (i == 0) { re[b + 2] = dr; im[b + 2] = di; }
-            else        { re[b + 3] = -SIGN * di; im[b + 3] = SIGN * dr; }
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 8; b += 2) {
-        float ar = re[b], ai = im[b], br = re[b + 1], bi = im[b + 1];
-        re[b] = ar + br; im[b] = ai + bi;
-        re[b + 1] = ar - br; im[b + 1] = ai - bi;
-    }
-    // register j now holds k2 = brev3(j); twiddle by W512^(lane*k2)
-    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-        const float tr = w.tr[brev3[j]], ti = w.ti[brev3[j]];
-        const float xr = re[j], xi = im[j];
-        re[j] = xr * tr - xi * ti;
-        im[j] = xr * ti + xi * tr;
-    }
-    // ---- 64-point DIF across lanes ----
-#pragma unroll
-    for (int st = 0; st < 6; ++st) {
-        const int hh = 32 >> st;
-        const bool upper = (lane & hh) != 0;
-        const float sr = st < 5 ? w.sr[st] : 1.f, si = st < 5 ? w.si[st] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float pr = __shfl_xor(re[j], hh, 64), pi = __shfl_xor(im[j], hh, 64);
-            if (!upper) { re[j] += pr; im[j] += pi; }
-            else {
-                const float dr = pr - re[j], di = pi - im[j];
-                re[j] = dr * sr - di * si;
-                im[j] = dr * si + di * sr;
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ int brev6(int l) { return (int)(__brev((unsigned)l) >> 26); }
+#include "fft512.h"
 
 // ------------------------------------------------------------------------------------------------
 // STFT forward: wav [B][N] fp32 -> spec [B][T][257] float2 (re, im) and the encoder input

@@ -1,0 +1,197 @@
+// stft_custom / istft_custom of the STFT-domain models (reference: src/evaluate.py:101-128 and :130-162; called twice per
+// train step from src/solver.py:457-458 for DCUNet / DNN / ...).  The reference calls torch.stft / torch.istft with a
+// periodic hann window of win_length (zero-padded, centred, to n_fft), center=True -> reflect padding by n_fft/2,
+// one-sided output [rows][n_fft/2+1][T][2], and divides / multiplies by win_length itself.  n_fft must be 512 (both shipped
+// configurations: 512/128/512 and 512/256/512).
+//
+// One wavefront transforms one frame (fft512.h).  The reference's layout puts TIME innermost, so a frame's 257 bins are
+// 257 strided 8-byte elements: a workgroup therefore owns 16 consecutive frames of one row and passes its results
+// through an LDS tile [16 frames][257 bins], so that global memory sees 128-byte runs (16 frames of one bin) in both
+// directions.  HBM-bound: 4 B/sample in, 8.03 B/sample x n_fft/hop out.
+#include "fft512.h"
+
+#define SC_TF 16          // frames per workgroup
+#define SC_PITCH 258      // float2 per frame row of the tile (257 + 1: odd pitch in 8-byte words)
+
+// window value of sample n of a frame: periodic hann of win_length centred in n_fft
+__device__ __forceinline__ float sc_window(int n, int left, int win_length) {
+    const int m = n - left;
+    if (m < 0 || m >= win_length) return 0.f;
+    return 0.5f - 0.5f * cospif(2.0f * (float)m / (float)win_length);
+}
+
+__global__ __launch_bounds__(256) void stft_custom_kernel(const float* __restrict__ wav, int N, int T, int hop, int win_length,
+                                                          int center, float2* __restrict__ spec) {
+    __shared__ float2 tile[SC_TF * SC_PITCH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.y, t0 = blockIdx.x * SC_TF;
+    const float* x = wav + (size_t)row * N;
+    FftTw tw;
+    fft_twiddles<-1>(tw, lane);
+    const int left = (FFT_N - win_length) >> 1;
+    const float scale = 1.0f / (float)win_length;          // the reference's  tensor_stft /= win_length
+    float wv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wv[r] = sc_window(lane + 64 * r, left, win_length) * scale;
+    const int pad = center ? FFT_N / 2 : 0;
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    for (int tl = w; tl < SC_TF; tl += 4) {
+        const int t = t0 + tl;
+        if (t >= T) break;
+        float re[8], im[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int s = t * hop + lane + 64 * r - pad;
+            if (s < 0) s = -s;                              // reflect (no edge repeat), as torch's pad_mode="reflect"
+            if (s >= N) s = 2 * (N - 1) - s;
+            re[r] = x[s] * wv[r];
+            im[r] = 0.f;
+        }
+        fft512_wave<-1>(re, im, tw, lane);
+        const int k0 = 8 * brev6(lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + brev3[j];
+            if (k <= 256) tile[tl * SC_PITCH + k] = make_float2(re[j], im[j]);
+        }
+    }
+    __syncthreads();
+    const int nt = min(SC_TF, T - t0);
+    float2* out = spec + (size_t)row * NBIN * T + t0;
+    for (int idx = threadIdx.x; idx < NBIN * SC_TF; idx += 256) {
+        const int f = idx >> 4, tl = idx & (SC_TF - 1);
+        if (tl < nt) out[(size_t)f * T + tl] = tile[tl * SC_PITCH + f];
+    }
+}
+
+// spectrum tile -> windowed synthesis frames [rows][T][512]
+__global__ __launch_bounds__(256) void istft_custom_frames_kernel(const float2* __restrict__ spec, int T, int win_length,
+                                                                  float* __restrict__ frames) {
+    __shared__ float2 tile[SC_TF * SC_PITCH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.y, t0 = blockIdx.x * SC_TF;
+    const int nt = min(SC_TF, T - t0);
+    const float2* in = spec + (size_t)row * NBIN * T + t0;
+    for (int idx = threadIdx.x; idx < NBIN * SC_TF; idx += 256) {
+        const int f = idx >> 4, tl = idx & (SC_TF - 1);
+        if (tl < nt) tile[tl * SC_PITCH + f] = in[(size_t)f * T + tl];
+    }
+    __syncthreads();
+    FftTw tw;
+    fft_twiddles<1>(tw, lane);
+    const int left = (FFT_N - win_length) >> 1;
+    // tensor * win_length (src/evaluate.py:131), the 1/n_fft of the inverse transform, and the synthesis window
+    const float scale = (float)win_length / (float)FFT_N;
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    for (int tl = w; tl < nt; tl += 4) {
+        float re[8], im[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = lane + 64 * r;
+            // Hermitian extension of the one-sided spectrum; a c2r transform ignores Im of DC and Nyquist
+            const float2 z = tile[tl * SC_PITCH + (k <= 256 ? k : FFT_N - k)];
+            re[r] = z.x;
+            im[r] = (k == 0 || k == 256) ? 0.f : (k < 256 ? z.y : -z.y);
+        }
+        fft512_wave<1>(re, im, tw, lane);
+        const int n0 = 8 * brev6(lane);
+        float u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[brev3[j]] = re[j];
+        float* fo = frames + ((size_t)row * T + t0 + tl) * FFT_N + n0;
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = u[q] * scale * sc_window(n0 + q, left, win_length);
+        *reinterpret_cast<float4*>(fo) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(fo + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// overlap-add, divide by the overlap-added squared window, drop the leading centre padding, keep `length` samples
+// (zero beyond the overlap-added signal) -- what torch.istft does with an explicit length
+__global__ __launch_bounds__(256) void istft_custom_ola_kernel(const float* __restrict__ frames, int T, int hop, int win_length,
+                                                               int center, int length, float* __restrict__ wav) {
+    const int row = blockIdx.y;
+    const int left = (FFT_N - win_length) >> 1;
+    const int start = center ? FFT_N / 2 : 0;
+    const int total = FFT_N + hop * (T - 1);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < length; i += gridDim.x * 256) {
+        const int pos = i + start;
+        float v = 0.f;
+        if (pos < total) {
+            int t_hi = pos / hop;
+            if (t_hi > T - 1) t_hi = T - 1;
+            int t_lo = pos - FFT_N + 1 <= 0 ? 0 : (pos - FFT_N + hop) / hop;   // ceil((pos - n_fft + 1) / hop)
+            float acc = 0.f, env = 0.f;
+            for (int t = t_lo; t <= t_hi; ++t) {
+                const int n = pos - t * hop;
+                const float wn = sc_window(n, left, win_length);
+                acc += frames[((size_t)row * T + t) * FFT_N + n];
+                env += wn * wn;
+            }
+            v = acc / env;
+        }
+        wav[(size_t)row * length + i] = v;
+    }
+}
+
+static int sc_check(const char* who, int n_fft, int hop, int win_length) {
+    SEHIP_REQUIRE(n_fft == FFT_N, "%s: only n_fft 512 is built, got %d", who, n_fft);
+    SEHIP_REQUIRE(hop >= 1 && win_length >= 1 && win_length <= n_fft, "%s: bad hop_length %d / win_length %d", who, hop, win_length);
+    return 0;
+}
+
+extern "C" int sehip_stft_custom_frames(int n_samples, int n_fft, int hop, int center) {
+    if (hop < 1) return 0;
+    return center ? 1 + n_samples / hop : (n_samples >= n_fft ? 1 + (n_samples - n_fft) / hop : 0);
+}
+
+extern "C" int sehip_stft_custom_fwd(const float* wav, int rows, int n_samples, int n_fft, int hop, int win_length, int center,
+                                     float* spec, void* stream) {
+    if (int e = sc_check("stft_custom", n_fft, hop, win_length)) return e;
+    SEHIP_REQUIRE(rows > 0 && n_samples > 0, "stft_custom: empty input");
+    // torch.stft: reflect padding needs n_fft/2 < n_samples; without centring the signal must hold one frame
+    SEHIP_REQUIRE(center ? n_samples > n_fft / 2 : n_samples >= n_fft, "stft_custom: %d samples are too few for n_fft %d",
+                  n_samples, n_fft);
+    const int T = sehip_stft_custom_frames(n_samples, n_fft, hop, center);
+    dim3 grid(cdiv(T, SC_TF), rows);
+    stft_custom_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(wav, n_samples, T, hop, win_length, center, (float2*)spec);
+    SEHIP_CHECK_LAUNCH("stft_custom");
+    return 0;
+}
+
+extern "C" int sehip_istft_custom_fwd(const float* spec, int rows, int n_frames, int n_fft, int hop, int win_length, int center,
+                                      int length, float* frames_ws, float* wav, void* stream) {
+    if (int e = sc_check("istft_custom", n_fft, hop, win_length)) return e;
+    SEHIP_REQUIRE(rows > 0 && n_frames > 0 && length > 0, "istft_custom: empty input");
+    // NOLA, as torch.istft checks it: the overlap-added squared window must not vanish on the kept interval
+    {
+        const int left = (n_fft - win_length) / 2, start = center ? n_fft / 2 : 0;
+        const long total = n_fft + (long)hop * (n_frames - 1);
+        const long end = start + (long)length < total ? start + (long)length : total;
+        // the envelope is periodic in hop away from the two ends: checking the first and last n_fft positions covers it
+        for (long pos = start; pos < end; ++pos) {
+            if (pos >= start + n_fft && pos < end - n_fft) { pos = end - n_fft - 1; continue; }
+            double env = 0.0;
+            long t_hi = pos / hop; if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+            long t_lo = pos - n_fft + 1 <= 0 ? 0 : (pos - n_fft + hop) / hop;
+            for (long t = t_lo; t <= t_hi; ++t) {
+                const long m = pos - t * hop - left;
+                if (m >= 0 && m < win_length) {
+                    const double wv = 0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * (double)m / win_length);
+                    env += wv * wv;
+                }
+            }
+            SEHIP_REQUIRE(env > 1e-11, "istft_custom: window overlap-add is zero at sample %ld (torch.istft raises here as well)",
+                          pos - start);
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(n_frames, SC_TF), rows);
+    istft_custom_frames_kernel<<<grid, 256, 0, st>>>((const float2*)spec, n_frames, win_length, frames_ws);
+    int gx = cdiv(length, 256 * 4);
+    if (gx < 1) gx = 1;
+    istft_custom_ola_kernel<<<dim3(gx, rows), 256, 0, st>>>(frames_ws, n_frames, hop, win_length, center, length, wav);
+    SEHIP_CHECK_LAUNCH("istft_custom");
+    return 0;
+}

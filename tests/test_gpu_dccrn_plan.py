@@ -145,6 +145,12 @@ def test_backward_param_grads(setup):
         # of the column sums of dY, which scales with the layer's gradient magnitude)
         wn = errs.get(k.replace(".bias", ".weight"), (0.0, 0.0))[1]
         tol = 0.2 * n + (2e-3 * wn + 3e-3 if noise_bias else 1e-5)
+        if k.endswith(".2.weight"):
+            # PReLU slope: ONE scalar = a signed sum over the whole activation tensor (20 M terms).  Its absolute error is
+            # ~0.01-0.02 in every layer while its value happens to be anywhere between 0.05 and 30: bound the error by the
+            # scale of the layer's other per-channel gradients instead of by its own (possibly cancelled) value.
+            pre = k[:-len("2.weight")]
+            tol += 0.08 * max(errs[pre + "1.Wrr"][1], errs[pre + "1.Wii"][1])
         if not e < tol:
             bad[k] = (e, n)
     assert not bad, bad

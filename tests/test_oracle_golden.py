@@ -116,3 +116,23 @@ def test_param_init_shapes_match_reference_schema():
     assert set(mine) == set(ref)
     for k in ref:
         assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+
+
+# ---- stft_custom / istft_custom: oracle/stft_oracle.py vs the reference's outputs
+def test_stft_custom_oracle_matches_reference():
+    from oracle import stft_oracle as S
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stft_custom.npz"))
+    names = sorted({k.split(".")[0] for k in g.files})
+    assert len(names) == 5
+    for name in names:
+        n_fft, hop, win, length = [int(v) for v in g[name + ".cfg"]]
+        s = S.stft_custom(g[name + ".x"], n_fft, hop, win)
+        assert s.shape == g[name + ".stft"].shape
+        assert np.abs(s - g[name + ".stft"]).max() < 5e-8
+        y = S.istft_custom(g[name + ".z"], length, n_fft, hop, win)
+        ref = g[name + ".istft"]
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < 1e-6 * np.abs(ref).max()
+        rt = S.istft_custom(g[name + ".stft"], length, n_fft, hop, win)
+        assert np.abs(rt - g[name + ".roundtrip"]).max() < 1e-6
