@@ -144,6 +144,9 @@ typedef struct {
 int sehip_gemm_desc_size(void);
 /* forward / dgrad style product */
 int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
+/* two products over the same sources (the output-row parities of ComplexConvTranspose2d, src/model/dccrn.py:387-450):
+ * one launch that stages the input once where the library can, otherwise the two launches */
+int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream);
 /* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */
 int sehip_wgrad(const sehip_gemm_desc* desc, void* stream);
 

@@ -49,6 +49,7 @@ _PROTOS = {
     "sehip_istft_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P],
     "sehip_istft_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "sehip_gemm": [P, P],
+    "sehip_gemm_pair": [P, P, P],
     "sehip_wgrad": [P, P],
     "sehip_gemm_desc_size": [],
     "sehip_pack_bf16": [P, P, L, P, P],

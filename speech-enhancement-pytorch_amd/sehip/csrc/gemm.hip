@@ -14,6 +14,7 @@
 // wgrad_kernel  dW[n][k] += sum_m dOut[m][n] A[m][k]  (split over m, fp32 atomics)
 //   both operands are staged row-major in m and fed to the MFMA through ds_read_b64_tr_b16 transposed reads.
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 #include "../../../include/sehip.h"
 
@@ -464,37 +465,178 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
 // (branch-free, see sw_fetch_patch) while the current one is multiplied and stored, the store addressing (row
 // offsets, n-chunk table entries, bias) is computed once per workgroup, and the K loop walks taps with scalar offsets.
 // ------------------------------------------------------------------------------------------------
-template <int BN, int NPC, int MI>
-__global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg) {
+// Everything of one product over a staged patch that depends on the descriptor: weights in LDS, tap geometry, store
+// addressing.  A launch carries one side, or two (the two output-row parities of a transposed convolution read the same
+// input: staged once, multiplied by both weight sets -- see sehip_gemm_pair).
+template <int TN, int MI>
+struct Cs2Side {
+    const bf16_raw* sW;
+    int KP, NIT, nf, KR;
+    int dt00, dt01, dt10, dt11;  // patch frame of (source, kt); scalars: a dynamically indexed member array lives in scratch
+    int fshift;            // rows between the patch's first row and this side's first tap
+    int e_off0[MI], e_off1[MI];
+    long bs0, bs1;
+    int ts0, ts1;
+    sehip_nchunk nck[TN];
+    float4 bias4[TN];
+};
+
+template <int TN, int MI>
+__device__ __forceinline__ Cs2Side<TN, MI> cs2_side_init(const sehip_gemm_desc& d, const bf16_raw* sW, int tmin0, int tmin1,
+                                                          int fadd_u, int JB, int w, int lane) {
+    Cs2Side<TN, MI> sd;  // returned by value: filled through a reference it stayed in scratch
+    sd.sW = sW;
+    sd.KP = d.K + 8;
+    sd.nf = d.cv_nf;
+    sd.NIT = 2 * d.cv_nf;
+    sd.KR = sd.NIT * (d.src[0].C + (d.src[1].ptr ? d.src[1].C : 0));
+    sd.dt00 = d.cv_toff[0][0] - tmin0; sd.dt01 = d.cv_toff[0][1] - tmin0;
+    sd.dt10 = d.cv_toff[1][0] - tmin1; sd.dt11 = d.cv_toff[1][1] - tmin1;
+    sd.fshift = d.cv_fadd - fadd_u;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = 16 * MI * w + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        RowPos rp;
+        rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+        sd.e_off0[mi] = (int)dst_row_offset(d.dst[0], rp, d.fmul);
+        sd.e_off1[mi] = d.dst[1].ptr ? (int)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
+    }
+    sd.bs0 = (long)d.dst[0].T * d.dst[0].F * d.dst[0].C; sd.bs1 = (long)d.dst[1].T * d.dst[1].F * d.dst[1].C;
+    sd.ts0 = d.dst[0].F * d.dst[0].C; sd.ts1 = d.dst[1].F * d.dst[1].C;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = ni * 16 + 4 * (lane >> 4);
+        sd.nck[ni] = d.ntab[n >> 2];
+        sd.bias4[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return sd;
+}
+
+// weights -> LDS (once per workgroup)
+template <int BN>
+__device__ __forceinline__ void cs2_load_weights(const sehip_gemm_desc& d, bf16_raw* sW, int tid) {
+    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
+    const int cpr = d.K >> 3, KP = d.K + 8;
+    for (int idx = tid; idx < BN * cpr; idx += 256) {
+        const int r = idx / cpr, c = idx - r * cpr;
+        *reinterpret_cast<uint4*>(&sW[r * KP + c * 8]) = *reinterpret_cast<const uint4*>(Wb + (size_t)r * d.K + c * 8);
+    }
+}
+
+// all K steps of one side over the staged patch, then its stores
+template <int TN, int MI>
+__device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, const sehip_gemm_desc& d, const bf16_raw* patch,
+                                                   const int (&abase)[MI], const int (&e_tl)[MI], int FR, int PP, int CT, int C0,
+                                                   int b, int t0, int lane) {
+    const int g = lane >> 4;
+    const int wrow = (lane & 15) * sd.KP + 8 * g;  // this lane's weight fragment: row (lane & 15) of each 16-row tile, k chunk g
+    f32x4 acc[TN][MI];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[a][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (CT >= 32) {
+        const int cs_n = CT >> 5;
+#pragma unroll 2
+        for (int it = 0; it < sd.NIT; ++it) {
+            const int kt = it >= sd.nf ? 1 : 0, tap = it - kt * sd.nf;
+            const int po0 = ((kt ? sd.dt01 : sd.dt00) * FR + tap + sd.fshift) * PP, po1 = ((kt ? sd.dt11 : sd.dt10) * FR + tap + sd.fshift) * PP;
+            for (int cs = 0; cs < cs_n; ++cs) {
+                const int c = 32 * cs + 8 * g;
+                const int poff = (c >= C0 ? po1 : po0) + c;
+                bf16x8 af[MI], wf[TN];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sd.sW[ni * 16 * sd.KP + wrow + it * CT + 32 * cs]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+    } else {
+        const int ksteps = sd.KR >> 5;
+        const int lgct = 31 - __clz(CT);
+        for (int s = 0; s < ksteps; ++s) {
+            const int k = 32 * s + 8 * g;
+            const int it = k >> lgct, c = k & (CT - 1);
+            const int kt = it >= sd.nf ? 1 : 0, tap = it - kt * sd.nf;
+            const int dtv = c >= C0 ? (kt ? sd.dt11 : sd.dt10) : (kt ? sd.dt01 : sd.dt00);
+            const int poff = (dtv * FR + tap + sd.fshift) * PP + c;
+            bf16x8 af[MI], wf[TN];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sd.sW[ni * 16 * sd.KP + wrow + 32 * s]));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (t0 + e_tl[mi] >= d.TT) continue;
+        const long ro0 = sd.e_off0[mi] + b * sd.bs0 + (long)t0 * sd.ts0;
+        const long ro1 = sd.e_off1[mi] + b * sd.bs1 + (long)t0 * sd.ts1;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const sehip_nchunk nc = sd.nck[ni];
+            if (nc.nvalid <= 0) continue;
+            f32x4 v = acc[ni][mi];
+            v[0] += sd.bias4[ni].x; v[1] += sd.bias4[ni].y; v[2] += sd.bias4[ni].z; v[3] += sd.bias4[ni].w;
+            const long off = (nc.dst ? ro1 : ro0) + nc.coff;
+            void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
+            const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+            if (is_f32) {
+                float* q = reinterpret_cast<float*>(dptr) + off;
+                if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nc.nvalid; ++e) q[e] = v[e];
+            } else {
+                bf16_raw* q = reinterpret_cast<bf16_raw*>(dptr) + off;
+                if (nc.nvalid == 4) *reinterpret_cast<uint2*>(q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else
+                    for (int e = 0; e < nc.nvalid; ++e) q[e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+// d2 is read only when PAIR; fadd_u = first input row of the patch relative to row j*fmul (min of the sides' cv_fadd)
+template <int BN, int NPC, int MI, bool PAIR>
+__global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc d, const sehip_gemm_desc d2, int TB, int JB, int FR,
+                                                          int fadd_u, int tiles_per_wg) {
     constexpr int TN = BN / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int CT = C0 + C1;
-    const int NIT = 2 * d.cv_nf;
-    const int KR = NIT * CT;          // real K
-    const int KP = d.K + 8;           // LDS pitch of a weight row
     const int PP = CT + 8;            // LDS pitch of a patch row
     bf16_raw* sW = reinterpret_cast<bf16_raw*>(smem);
-    bf16_raw* patch = sW + BN * KP;
+    bf16_raw* sW2 = sW + BN * (d.K + 8);
+    bf16_raw* patch = PAIR ? sW2 + BN * (d2.K + 8) : sW2;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane >> 4;
-    {
-        const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
-        const int cpr = d.K >> 3;
-        for (int idx = tid; idx < BN * cpr; idx += 256) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            *reinterpret_cast<uint4*>(&sW[r * KP + c * 8]) = *reinterpret_cast<const uint4*>(Wb + (size_t)r * d.K + c * 8);
-        }
-    }
+    cs2_load_weights<BN>(d, sW, tid);
+    if (PAIR) cs2_load_weights<BN>(d2, sW2, tid);
     const int tblocks = (d.TT + TB - 1) / TB;
     const int B = d.M / (d.TT * d.J);
     const int MT = B * tblocks;       // JB == J
-    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    if (PAIR) {
+        tmin0 = min(tmin0, min(d2.cv_toff[0][0], d2.cv_toff[0][1]));
+        tmin1 = min(tmin1, min(d2.cv_toff[1][0], d2.cv_toff[1][1]));
+    }
     const int cp8 = CT >> 3;
     const int NP = (TB + 1) * FR * cp8;
-    const int nf = d.cv_nf;
-    const int lgct = 31 - __clz(CT);
 
     // ---- staging slots (see sw_fetch_patch)
     const bf16_raw* p_ptr[NPC];
@@ -509,7 +651,7 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
             const int r = rem / cp8, c8 = rem - r * cp8;
             const bool second = c8 * 8 >= C0;
             const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
-            const int f = d.cv_fadd + r;
+            const int f = fadd_u + r;
             p_lds[u] = (pp * FR + r) * PP + c8 * 8;
             if (f >= 0 && f < sF) {
                 p_pp[u] = pp | (second ? 0x10000 : 0);
@@ -520,31 +662,17 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
     }
     const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&sehip_zero16);
 
-    // ---- MFMA operand rows of this lane and its store addressing (all tile-invariant)
-    // wave w owns rows [16 MI w, 16 MI (w + 1)) of the 64 MI-row tile
-    int abase[MI], e_tl[MI], e_off0[MI], e_off1[MI];
+    // ---- MFMA operand rows of this lane (wave w owns rows [16 MI w, 16 MI (w + 1)) of the 64 MI-row tile) and the sides
+    int abase[MI], e_tl[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int r = 16 * MI * w + mi * 16 + (lane & 15);
         const int tl = r / JB, jl = r - tl * JB;
         abase[mi] = (tl * FR + jl * d.fmul) * PP;
         e_tl[mi] = tl;
-        RowPos rp;
-        rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
-        e_off0[mi] = (int)dst_row_offset(d.dst[0], rp, d.fmul);
-        e_off1[mi] = d.dst[1].ptr ? (int)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
     }
-    const long bs0 = (long)d.dst[0].T * d.dst[0].F * d.dst[0].C, bs1 = (long)d.dst[1].T * d.dst[1].F * d.dst[1].C;
-    const int ts0 = d.dst[0].F * d.dst[0].C, ts1 = d.dst[1].F * d.dst[1].C;
-    sehip_nchunk nck[TN];
-    float4 bias4[TN];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = ni * 16 + 4 * g;
-        nck[ni] = d.ntab[n >> 2];
-        bias4[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int wrow = (lane & 15) * KP + 8 * g;  // this lane's weight fragment: row (lane & 15) of each 16-row tile, k chunk g
+    const Cs2Side<TN, MI> sa = cs2_side_init<TN, MI>(d, sW, tmin0, tmin1, fadd_u, JB, w, lane);
+    const Cs2Side<TN, MI> sb = cs2_side_init<TN, MI>(PAIR ? d2 : d, sW2, tmin0, tmin1, fadd_u, JB, w, lane);
 
     const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
     RegTile<NPC> pr;
@@ -563,91 +691,16 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
         for (int u = 0; u < NPC; ++u) *reinterpret_cast<uint4*>(&patch[p_lds[u]]) = pr.v[u];
         __syncthreads();
         if (mt + 1 < mt_end) CS_FETCH(mt + 1)   // in flight while this tile is multiplied and stored
-
-        f32x4 acc[TN][MI];
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[a][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (CT >= 32) {
-            const int cs_n = CT >> 5;
-#pragma unroll 2
-            for (int it = 0; it < NIT; ++it) {
-                const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
-                const int po0 = ((d.cv_toff[0][kt] - tmin0) * FR + tap) * PP, po1 = ((d.cv_toff[1][kt] - tmin1) * FR + tap) * PP;
-                for (int cs = 0; cs < cs_n; ++cs) {
-                    const int c = 32 * cs + 8 * g;
-                    const int poff = (c >= C0 ? po1 : po0) + c;
-                    bf16x8 af[MI], wf[TN];
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[ni * 16 * KP + wrow + it * CT + 32 * cs]));
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-                }
-            }
-        } else {
-            const int ksteps = KR >> 5;
-            for (int s = 0; s < ksteps; ++s) {
-                const int k = 32 * s + 8 * g;
-                const int it = k >> lgct, c = k & (CT - 1);
-                const bool second = c >= C0;
-                const int kt = it >= nf ? 1 : 0, tap = it - kt * nf;
-                const int dt = (second ? d.cv_toff[1][kt] - tmin1 : d.cv_toff[0][kt] - tmin0);
-                const int poff = (dt * FR + tap) * PP + c;
-                bf16x8 af[MI], wf[TN];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[ni * 16 * KP + wrow + 32 * s]));
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            if (t0 + e_tl[mi] >= d.TT) continue;
-            const long ro0 = e_off0[mi] + b * bs0 + (long)t0 * ts0;
-            const long ro1 = e_off1[mi] + b * bs1 + (long)t0 * ts1;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const sehip_nchunk nc = nck[ni];
-                if (nc.nvalid <= 0) continue;
-                f32x4 v = acc[ni][mi];
-                v[0] += bias4[ni].x; v[1] += bias4[ni].y; v[2] += bias4[ni].z; v[3] += bias4[ni].w;
-                const long off = (nc.dst ? ro1 : ro0) + nc.coff;
-                void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
-                const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
-                if (is_f32) {
-                    float* q = reinterpret_cast<float*>(dptr) + off;
-                    if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
-                    else
-                        for (int e = 0; e < nc.nvalid; ++e) q[e] = v[e];
-                } else {
-                    bf16_raw* q = reinterpret_cast<bf16_raw*>(dptr) + off;
-                    if (nc.nvalid == 4) *reinterpret_cast<uint2*>(q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                    else
-                        for (int e = 0; e < nc.nvalid; ++e) q[e] = f2bf(v[e]);
-                }
-            }
-        }
+        cs2_multiply_store<TN, MI>(sa, d, patch, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
+        if (PAIR) cs2_multiply_store<TN, MI>(sb, d2, patch, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
         __syncthreads();  // every read of this tile's patch is done before the next one is written
     }
 #undef CS_FETCH
 }
 
-static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
+// d2 == nullptr: one product.  d2 != nullptr: the pair (d, *d2) over one staged patch; returns 0 when the pair does not
+// qualify (the caller then launches the two products separately).
+static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_SMALL") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
@@ -656,16 +709,30 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
     if (d.J > 128 || (128 % d.J)) return 0;
     const int KR = 2 * d.cv_nf * CT;
     if ((KR & 31) || KR > d.K) return 0;
+    int fadd_u = d.cv_fadd, fend = d.cv_fadd + d.cv_nf;
+    size_t wbytes = (size_t)d.Npad * (d.K + 8) * 2;
+    if (d2) {
+        static const bool nopair = getenv("SEHIP_NO_PAIR") != nullptr;
+        const sehip_gemm_desc& e = *d2;
+        if (nopair || e.cv_nf <= 0 || d.Npad > 32 || e.Npad != d.Npad || e.M != d.M || e.TT != d.TT || e.J != d.J || e.fmul != d.fmul) return 0;
+        if (memcmp(e.src, d.src, sizeof(d.src)) != 0) return 0;  // same sources, same frame windows
+        const int KR2 = 2 * e.cv_nf * CT;
+        if ((KR2 & 31) || KR2 > e.K) return 0;
+        fadd_u = min(fadd_u, e.cv_fadd);
+        fend = max(fend, e.cv_fadd + e.cv_nf);
+        wbytes += (size_t)e.Npad * (e.K + 8) * 2;
+    }
     const int JB = d.J;
-    const int FR = (JB - 1) * d.fmul + d.cv_nf;
+    const int FR = (JB - 1) * d.fmul + (fend - fadd_u);
     // rows per tile = 64 MI.  Larger tiles amortise the per-tile instruction stream and the weight-fragment reads (every wave
     // reads all of W per K step) but cost registers and LDS, i.e. resident workgroups; measured per layer (B=32, us, MI 2 / 4):
     // enc1.fwd 35/31, enc1.dg 27/27, enc2.fwd 56/48, enc2.dg0 29/33, dec4.fwd 42/37, dec4.dg 46/63, dec5.fwd 42/53.
     // Rule that reproduces the winners: 4 when the pieces-per-thread class (6 / 12) does not grow, for 64 outputs when K >= 256.
     static const int mi_force = getenv("SEHIP_SMALL_MI") ? atoi(getenv("SEHIP_SMALL_MI")) : 0;
+    const size_t lds_cap = d2 ? 160 * 1024 : 120 * 1024;
     auto pieces = [&](int mi) { return (64 * mi / JB + 1) * FR * (CT >> 3); };
-    auto lds_of = [&](int mi) { return (size_t)d.Npad * (d.K + 8) * 2 + (size_t)(64 * mi / JB + 1) * FR * (CT + 8) * 2 + 16; };
-    auto fits = [&](int mi) { return pieces(mi) <= 12 * 256 && lds_of(mi) <= 120 * 1024; };
+    auto lds_of = [&](int mi) { return wbytes + (size_t)(64 * mi / JB + 1) * FR * (CT + 8) * 2 + 16; };
+    auto fits = [&](int mi) { return pieces(mi) <= 12 * 256 && lds_of(mi) <= lds_cap; };
     int MI = 2;
     if (d.Npad <= 32 && fits(4) && (pieces(2) <= 6 * 256) == (pieces(4) <= 6 * 256)) MI = 4;
     if (d.Npad == 64 && fits(4) && d.K >= 256) MI = 4;
@@ -679,24 +746,27 @@ static int try_conv_small(const sehip_gemm_desc& d, hipStream_t st) {
     if (wgs > MT) wgs = MT;
     const int tiles_per_wg = (MT + wgs - 1) / wgs;
     const int grid = (MT + tiles_per_wg - 1) / tiles_per_wg;
-    const bool few = (TB + 1) * FR * (CT >> 3) <= 6 * 256;
-#define CS2_CASE(BN_, NPC_, MI_)                                                                                    \
-    if (d.Npad == BN_ && MI == MI_ && few == (NPC_ == 6)) {                                                         \
+    const bool few = pieces(MI) <= 6 * 256;
+#define CS2_CASE(BN_, NPC_, MI_, PAIR_)                                                                             \
+    if (d.Npad == BN_ && MI == MI_ && few == (NPC_ == 6) && (d2 != nullptr) == PAIR_) {                              \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small2_kernel<BN_, NPC_, MI_>),           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small2_kernel<BN_, NPC_, MI_, PAIR_>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_ ? 160 * 1024 : 120 * 1024); \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        sehip_note_kernel("conv_small2_kernel<%d, %d, %d>", BN_, NPC_, MI_);                                       \
-        conv_small2_kernel<BN_, NPC_, MI_><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);                    \
+        sehip_note_kernel(PAIR_ ? "conv_small2_kernel<%d, %d, %d, pair>" : "conv_small2_kernel<%d, %d, %d>", BN_, NPC_, MI_); \
+        conv_small2_kernel<BN_, NPC_, MI_, PAIR_><<<grid, 256, lds, st>>>(d, d2 ? *d2 : d, TB, JB, FR, fadd_u, tiles_per_wg); \
         return 1;                                                                                                   \
     }
-#define CS2_BOTH(BN_, MI_) CS2_CASE(BN_, 6, MI_) CS2_CASE(BN_, 12, MI_)
+#define CS2_BOTH(BN_, MI_) CS2_CASE(BN_, 6, MI_, false) CS2_CASE(BN_, 12, MI_, false)
+#define CS2_PAIR(BN_, MI_) CS2_CASE(BN_, 6, MI_, true) CS2_CASE(BN_, 12, MI_, true)
     CS2_BOTH(16, 4) CS2_BOTH(16, 2)
     CS2_BOTH(32, 4) CS2_BOTH(32, 2)
     CS2_BOTH(64, 4) CS2_BOTH(64, 2)
     CS2_BOTH(128, 2)
+    CS2_PAIR(16, 4) CS2_PAIR(16, 2) CS2_PAIR(32, 4) CS2_PAIR(32, 2)
+#undef CS2_PAIR
 #undef CS2_BOTH
 #undef CS2_CASE
     return 0;
@@ -1034,7 +1104,7 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("gemm(conv)");
         return 0;
     }
-    if (try_conv_small(*d, st)) {
+    if (try_conv_small(*d, nullptr, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv-small)");
         return 0;
     }
@@ -1064,6 +1134,20 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     }
     SEHIP_CHECK_LAUNCH("gemm");
     return 0;
+}
+
+// Two products over the SAME sources (the two output-row parities of a transposed convolution, src/model/dccrn.py:387-450):
+// one launch that stages the input once when the small-channel kernel takes the pair, otherwise the two launches.
+extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream) {
+    if (int e = check_desc("gemm_pair", a)) return e;
+    if (int e = check_desc("gemm_pair", b)) return e;
+    SEHIP_REQUIRE(a->W != nullptr && b->W != nullptr, "gemm_pair: missing weights");
+    if (try_conv_small(*a, b, (hipStream_t)stream)) {
+        SEHIP_CHECK_LAUNCH("gemm_pair(conv-small)");
+        return 0;
+    }
+    if (int e = sehip_gemm(a, stream)) return e;
+    return sehip_gemm(b, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1766,9 +1850,12 @@ extern "C" int sehip_init(void) {
     set_lds(&conv_wgrad_kernel<NF_>, 96 * 1024);
     INIT_CONV(2) INIT_CONV(3) INIT_CONV(5)
 #undef INIT_CONV
-#define INIT_CS2(BN_, MI_) set_lds(&conv_small2_kernel<BN_, 6, MI_>, 120 * 1024); set_lds(&conv_small2_kernel<BN_, 12, MI_>, 120 * 1024);
+#define INIT_CS2(BN_, MI_) set_lds(&conv_small2_kernel<BN_, 6, MI_, false>, 120 * 1024); set_lds(&conv_small2_kernel<BN_, 12, MI_, false>, 120 * 1024);
     INIT_CS2(16, 4) INIT_CS2(16, 2) INIT_CS2(32, 4) INIT_CS2(32, 2) INIT_CS2(64, 4) INIT_CS2(64, 2) INIT_CS2(128, 2)
 #undef INIT_CS2
+#define INIT_CS2P(BN_, MI_) set_lds(&conv_small2_kernel<BN_, 6, MI_, true>, 160 * 1024); set_lds(&conv_small2_kernel<BN_, 12, MI_, true>, 160 * 1024);
+    INIT_CS2P(16, 4) INIT_CS2P(16, 2) INIT_CS2P(32, 4) INIT_CS2P(32, 2)
+#undef INIT_CS2P
 #define INIT_SW(BN_, KPW_) set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 6>, 120 * 1024); set_lds(&conv_small_wgrad_kernel<BN_, KPW_, 12>, 120 * 1024);
     INIT_SW(16, 1) INIT_SW(16, 2) INIT_SW(16, 3) INIT_SW(16, 4) INIT_SW(16, 5) INIT_SW(16, 6) INIT_SW(16, 8) INIT_SW(16, 12)
     INIT_SW(32, 1) INIT_SW(32, 2) INIT_SW(32, 3) INIT_SW(32, 4) INIT_SW(32, 5) INIT_SW(32, 6) INIT_SW(32, 8) INIT_SW(32, 12)

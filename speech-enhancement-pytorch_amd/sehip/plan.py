@@ -746,6 +746,12 @@ class DCCRNWorkspace:
         self._chain_dirty = True
         call("sehip_gemm", C.byref(self.desc[name]), stream())
 
+    def gemm_pair(self, a, b):
+        """Two products over the same sources (the two output-row parities of a transposed convolution): one launch that
+        stages the input once where the library can fuse them."""
+        self._chain_dirty = True
+        call("sehip_gemm_pair", C.byref(self.desc[a]), C.byref(self.desc[b]), stream())
+
     def _event(self):
         """Round-robin pool of fence-free events (sehip_stream_depend)."""
         if not self._events:
@@ -831,8 +837,7 @@ class DCCRNWorkspace:
         for tag in "ri":
             self.gemm(f"proj_{tag}")
         for j in range(6):
-            self.gemm(f"dec{j}.fwd0")
-            self.gemm(f"dec{j}.fwd1")
+            self.gemm_pair(f"dec{j}.fwd0", f"dec{j}.fwd1")
             if j < 5:
                 self.bn_forward(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"yd{j}"], b[f"zd{j}"], params, buffers, nbt,
                                 training)
