@@ -537,28 +537,38 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[a][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (CT >= 32) {
-        const int cs_n = CT >> 5;
-#pragma unroll 2
-        for (int it = 0; it < sd.NIT; ++it) {
-            const int kt = it >= sd.nf ? 1 : 0, tap = it - kt * sd.nf;
-            const int po0 = ((kt ? sd.dt01 : sd.dt00) * FR + tap + sd.fshift) * PP, po1 = ((kt ? sd.dt11 : sd.dt10) * FR + tap + sd.fshift) * PP;
-            for (int cs = 0; cs < cs_n; ++cs) {
-                const int c = 32 * cs + 8 * g;
-                const int poff = (c >= C0 ? po1 : po0) + c;
-                bf16x8 af[MI], wf[TN];
+        // software pipeline over the K steps (tap it, 32-channel slice cs): the fragments of step s+1 are requested before
+        // the MFMAs of step s (the loop is too long to unroll and the compiler does not rotate it by itself)
+        const int cs_n = CT >> 5, lgcs = 31 - __clz(cs_n);
+        const int steps = sd.NIT << lgcs;
+        bf16x8 af[MI], wf[TN], afn[MI], wfn[TN];
+#define CS2_LOAD(s_, af_, wf_)                                                                                         \
+        {                                                                                                              \
+            const int it_ = (s_) >> lgcs, cs_ = (s_) & (cs_n - 1);                                                     \
+            const int kt_ = it_ >= sd.nf ? 1 : 0, tap_ = it_ - kt_ * sd.nf;                                            \
+            const int c_ = 32 * cs_ + 8 * g;                                                                           \
+            const int dt_ = c_ >= C0 ? (kt_ ? sd.dt11 : sd.dt10) : (kt_ ? sd.dt01 : sd.dt00);                          \
+            const int poff_ = (dt_ * FR + tap_ + sd.fshift) * PP + c_;                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                          \
+                af_[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff_]));      \
+            _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                                          \
+                wf_[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sd.sW[ni * 16 * sd.KP + wrow + it_ * CT + 32 * cs_])); \
+        }
+        CS2_LOAD(0, af, wf)
+        for (int s = 0; s < steps; ++s) {
+            const int sn = s + 1 < steps ? s + 1 : s;
+            CS2_LOAD(sn, afn, wfn)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + poff]));
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sd.sW[ni * 16 * sd.KP + wrow + it * CT + 32 * cs]));
+            for (int mi = 0; mi < MI; ++mi) af[mi] = afn[mi];
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-            }
+            for (int ni = 0; ni < TN; ++ni) wf[ni] = wfn[ni];
         }
+#undef CS2_LOAD
     } else {
         const int ksteps = sd.KR >> 5;
         const int lgct = 31 - __clz(CT);
