@@ -11,6 +11,7 @@
 //   d = dz * (o > 0 ? 1 : a);  da = sum dz*o*[o<=0];  dB = sum d;  dWm from  P = Q U  (Q = sum d c^T)
 //   dxh = Wm d;  dU from H = Wm Q;  dV by reverse mode through the closed-form inverse square root;
 //   dy = A d + E c - A mean(d),  A = U Wm,  E = (1/N) [[2 dVrr, dVri],[dVri, 2 dVii]].
+#include <stdlib.h>
 #include "common.h"
 
 #define COEF_STRIDE 16  // floats per channel in the coefficient records
@@ -405,6 +406,10 @@ static int apply_blocks(long rows, int Cr) {
 static int stat_blocks(long rows, int Cr) {
     const int rpb = 256 / (Cr >> 3);
     long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
+    // one block per CU: the finalize kernels (on the dependent chain) read half the partials of the 512-block version;
+    // measured 6.24 vs 6.27 ms per step (128 blocks: 6.40)
+    static const int cap = getenv("SEHIP_CBN_BLOCKS") ? atoi(getenv("SEHIP_CBN_BLOCKS")) : 256;
+    if (g > cap) g = cap;
     if (g > CBN_MAX_BLOCKS) g = CBN_MAX_BLOCKS;
     if (g < 1) g = 1;
     return (int)g;
