@@ -133,6 +133,9 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
                                     float* __restrict__ RVri, float* __restrict__ RVii, long* __restrict__ nbt, long rows,
                                     int Cr, float eps, float momentum, int training, float* __restrict__ coef) {
     const int c = blockIdx.x;
+    // requested before the reduction (one memory round trip less on the chain)
+    const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c], br_ = Br[c], bi_ = Bi[c];
+    const float rmr = RMr[c], rmi = RMi[c], rvrr = RVrr[c], rvri = RVri[c], rvii = RVii[c];
     float mr, mi, vrr, vri, vii;
     if (training) {
         const double n = (double)rows;
@@ -145,15 +148,15 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
         vrr = (float)(a2 / n - dmr * dmr);
         vri = (float)(a3 / n - dmr * dmi);
         vii = (float)(a4 / n - dmi * dmi);
-        RMr[c] += momentum * (mr - RMr[c]);
-        RMi[c] += momentum * (mi - RMi[c]);
-        RVrr[c] += momentum * (vrr - RVrr[c]);
-        RVri[c] += momentum * (vri - RVri[c]);
-        RVii[c] += momentum * (vii - RVii[c]);
+        RMr[c] = rmr + momentum * (mr - rmr);
+        RMi[c] = rmi + momentum * (mi - rmi);
+        RVrr[c] = rvrr + momentum * (vrr - rvrr);
+        RVri[c] = rvri + momentum * (vri - rvri);
+        RVii[c] = rvii + momentum * (vii - rvii);
         if (c == 0 && nbt) nbt[0] += 1;
     } else {
         if (threadIdx.x != 0) return;
-        mr = RMr[c]; mi = RMi[c]; vrr = RVrr[c]; vri = RVri[c]; vii = RVii[c];
+        mr = rmr; mi = rmi; vrr = rvrr; vri = rvri; vii = rvii;
     }
     vrr += eps; vii += eps;
     const float tau = vrr + vii;
@@ -162,13 +165,12 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
     const float t = sqrtf(tau + 2.f * s);
     const float rst = 1.f / (s * t);
     const float urr = (s + vii) * rst, uii = (s + vrr) * rst, uri = -vri * rst;
-    const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
     float* o = coef + (size_t)c * COEF_STRIDE;
     o[0] = wrr * urr + wri * uri;
     o[1] = wrr * uri + wri * uii;
     o[2] = wri * urr + wii * uri;
     o[3] = wri * uri + wii * uii;
-    o[4] = mr; o[5] = mi; o[6] = Br[c]; o[7] = Bi[c];
+    o[4] = mr; o[5] = mi; o[6] = br_; o[7] = bi_;
     o[8] = urr; o[9] = uri; o[10] = uii; o[11] = vrr; o[12] = vri; o[13] = vii;
 }
 
@@ -272,18 +274,20 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
                                         float* __restrict__ gBi, float* __restrict__ gslope, float* __restrict__ bcoef) {
     const int c = blockIdx.x;
     const int st = 6 * Cr + 1;
-    double a[6];
-    wave_reduce_partials<6>(part, nblk, st, c, Cr, a);
-    const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
-    if (c == 0) {
+    if (c == Cr) {  // extra block: the PReLU slope gradient (its own block, so that channel 0 is not a straggler)
         double ds[1];
         wave_reduce_partials<1>(part, nblk, st, 6 * Cr, Cr, ds);
         if (threadIdx.x == 0) gslope[0] = (float)ds[0];
+        return;
     }
-    if (threadIdx.x != 0) return;
+    // the per-channel constants are requested before the reduction, not after it (one memory round trip less on the chain)
     const float* k = coef + (size_t)c * COEF_STRIDE;
     const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
     const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
+    double a[6];
+    wave_reduce_partials<6>(part, nblk, st, c, Cr, a);
+    const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
+    if (threadIdx.x != 0) return;
     const float n = (float)rows;
     // P = Q U  (sum d xh^T)
     const float prr = qrr * urr + qri * uri, pri = qrr * uri + qri * uii;
@@ -457,7 +461,7 @@ extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, cons
                                       const float* Wii, long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr,
                                       float* gBi, float* gslope, float* bcoef, void* stream) {
     if (int e = check_cbn("cbn_bwd_finalize", rows, Cr)) return e;
-    cbn_bwd_finalize_kernel<<<Cr, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), coef, Wrr, Wri, Wii, rows, Cr, gWrr,
+    cbn_bwd_finalize_kernel<<<Cr + 1, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), coef, Wrr, Wri, Wii, rows, Cr, gWrr,
                                                                 gWri, gWii, gBr, gBi, gslope, bcoef);
     SEHIP_CHECK_LAUNCH("cbn_bwd_finalize");
     return 0;
