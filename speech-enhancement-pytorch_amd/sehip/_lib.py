@@ -63,6 +63,8 @@ _PROTOS = {
     "sehip_cbn_bwd_apply": [P, P, P, P, P, P, L, I, I, I, I, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
+    "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
+    "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
 _RESTYPE = {"sehip_cbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
 

@@ -27,8 +27,10 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
+// Steps [t0, t1) of the sequence.  A chunk that does not start at 0 resumes from the h / c records the previous chunk wrote
+// (the two stacked layers are pipelined chunk by chunk on two streams, sehip/plan.py).
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ pre0, const float* __restrict__ pre1,
-                                                       const bf16_raw* __restrict__ whh, int B, int T,
+                                                       const bf16_raw* __restrict__ whh, int B, int T, int t0, int t1,
                                                        bf16_raw* __restrict__ hout, bf16_raw* __restrict__ gates,
                                                        float* __restrict__ cout) {
     __shared__ __attribute__((aligned(16))) bf16_raw hbuf[2][16 * HP];
@@ -56,15 +58,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     float4 pn[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pn[g] = *reinterpret_cast<const float4*>(pre + g * H);
+    for (int g = 0; g < 4; ++g) pn[g] = *reinterpret_cast<const float4*>(pre + (size_t)t0 * (2 * G4) + g * H);
     __syncthreads();
+    if (t0 > 0) {  // resume: h(t0-1) of this lane's four units from the output, c(t0-1) from the cell-state record
+        if (bvalid) *reinterpret_cast<uint2*>(&hbuf[0][m * HP + 16 * w + 4 * ug]) =
+            *reinterpret_cast<const uint2*>(hout + (obase + t0 - 1) * H + 16 * w + 4 * ug);
+        const size_t rec = ((size_t)(combo * ntiles + tile) * T + t0 - 1);
+        const float4 cv = *reinterpret_cast<const float4*>(cout + rec * 1024 + w * 256 + lane * 4);
+        c[0] = cv.x; c[1] = cv.y; c[2] = cv.z; c[3] = cv.w;
+        __syncthreads();
+    }
 
     int cur = 0;
-    for (int t = 0; t < T; ++t) {
+    for (int t = t0; t < t1; ++t) {
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = (f32x4){pn[g].x, pn[g].y, pn[g].z, pn[g].w};
-        if (t + 1 < T) {
+        if (t + 1 < t1) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) pn[g] = *reinterpret_cast<const float4*>(pre + (size_t)(t + 1) * (2 * G4) + g * H);
         }
@@ -112,7 +122,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 // combo 0 (r,real): +dh_a   combo 1 (r,imag): +dh_b   combo 2 (i,real): +dh_b   combo 3 (i,imag): -dh_a
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restrict__ dh_a, const bf16_raw* __restrict__ dh_b,
                                                        const bf16_raw* __restrict__ whhT, const bf16_raw* __restrict__ gates,
-                                                       const float* __restrict__ cst, int B, int T,
+                                                       const float* __restrict__ cst, int B, int T, int t0, int t1,
+                                                       float* __restrict__ state,
                                                        bf16_raw* __restrict__ dpre0, bf16_raw* __restrict__ dpre1) {
     __shared__ __attribute__((aligned(16))) bf16_raw dgbuf[2][16 * DGP];
     const int combo = blockIdx.x & 3, tile = blockIdx.x >> 2;
@@ -135,8 +146,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
     for (int s = 0; s < 8; ++s)
         wf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(whhT + ((size_t)lstm * H + 16 * w + m) * G4 + 32 * s + 8 * ug));
 
+    // steps t1-1 ... t0; a chunk that does not end at T resumes from the (dc, recurrent dh) the later chunk left in `state`
     float dc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 dhrec = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* stp = state ? state + ((size_t)blockIdx.x * 256 + threadIdx.x) * 8 : nullptr;
+    if (t1 < T) {
+        const float4 a = *reinterpret_cast<const float4*>(stp), bq = *reinterpret_cast<const float4*>(stp + 4);
+        dc[0] = a.x; dc[1] = a.y; dc[2] = a.z; dc[3] = a.w;
+        dhrec = (f32x4){bq.x, bq.y, bq.z, bq.w};
+    }
     // software pipeline: the (gates, dh) of step t-1 and the cell state of step t-2 are requested while step t runs
     struct StepIn { uint2 gi, gf, gg, go, dh; };
     const int ntiles = gridDim.x >> 2;
@@ -153,15 +171,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
         return v;
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 c_t = *reinterpret_cast<const float4*>(cbase + (rbase + T - 1) * 1024);
-    float4 c_m1 = T > 1 ? *reinterpret_cast<const float4*>(cbase + (rbase + T - 2) * 1024) : zero4;
-    StepIn in = load_step(T - 1);
+    float4 c_t = *reinterpret_cast<const float4*>(cbase + (rbase + t1 - 1) * 1024);
+    float4 c_m1 = t1 > 1 ? *reinterpret_cast<const float4*>(cbase + (rbase + t1 - 2) * 1024) : zero4;
+    StepIn in = load_step(t1 - 1);
     int cur = 0;
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = t1 - 1; t >= t0; --t) {
         StepIn nxt = in;
-        if (t > 0) nxt = load_step(t - 1);
+        if (t > t0) nxt = load_step(t - 1);
         float4 c_m2 = zero4;
-        if (t > 1) c_m2 = *reinterpret_cast<const float4*>(cbase + (rbase + t - 2) * 1024);
+        if (t > 1 && t > t0) c_m2 = *reinterpret_cast<const float4*>(cbase + (rbase + t - 2) * 1024);
         const float gi[4] = {bf2f(in.gi.x & 0xffff), bf2f(in.gi.x >> 16), bf2f(in.gi.y & 0xffff), bf2f(in.gi.y >> 16)};
         const float gf[4] = {bf2f(in.gf.x & 0xffff), bf2f(in.gf.x >> 16), bf2f(in.gf.y & 0xffff), bf2f(in.gf.y >> 16)};
         const float gg[4] = {bf2f(in.gg.x & 0xffff), bf2f(in.gg.x >> 16), bf2f(in.gg.y & 0xffff), bf2f(in.gg.y >> 16)};
@@ -210,25 +228,43 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
         c_t = c_m1;
         c_m1 = c_m2;
     }
+    if (t0 > 0 && stp) {
+        *reinterpret_cast<float4*>(stp) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+        *reinterpret_cast<float4*>(stp + 4) = make_float4(dhrec[0], dhrec[1], dhrec[2], dhrec[3]);
+    }
+}
+
+extern "C" int sehip_lstm_fwd_chunk(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, int t0,
+                                    int t1, void* h, void* gates, float* c, void* stream) {
+    SEHIP_REQUIRE(hidden == H, "lstm_fwd: only hidden size 64 (rnn_units=128) is built, got %d", hidden);
+    SEHIP_REQUIRE(B > 0 && T > 0, "lstm_fwd: empty input");
+    SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_fwd: bad step range [%d, %d) of %d", t0, t1, T);
+    lstm_fwd_kernel<<<4 * cdiv(B, 16), 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1,
+                                                                     (bf16_raw*)h, (bf16_raw*)gates, c);
+    SEHIP_CHECK_LAUNCH("lstm_fwd");
+    return 0;
 }
 
 extern "C" int sehip_lstm_fwd(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, void* h,
                               void* gates, float* c, void* stream) {
-    SEHIP_REQUIRE(hidden == H, "lstm_fwd: only hidden size 64 (rnn_units=128) is built, got %d", hidden);
-    SEHIP_REQUIRE(B > 0 && T > 0, "lstm_fwd: empty input");
-    lstm_fwd_kernel<<<4 * cdiv(B, 16), 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, (bf16_raw*)h,
-                                                                     (bf16_raw*)gates, c);
-    SEHIP_CHECK_LAUNCH("lstm_fwd");
+    return sehip_lstm_fwd_chunk(pre0, pre1, whh, B, T, hidden, 0, T, h, gates, c, stream);
+}
+
+// state: 4 * ceil(B/16) * 256 * 8 floats carried between chunks (needed unless the chunk is the whole sequence)
+extern "C" int sehip_lstm_bwd_chunk(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B,
+                                    int T, int hidden, int t0, int t1, float* state, void* dpre0, void* dpre1, void* stream) {
+    SEHIP_REQUIRE(hidden == H, "lstm_bwd: only hidden size 64 (rnn_units=128) is built, got %d", hidden);
+    SEHIP_REQUIRE(B > 0 && T > 0, "lstm_bwd: empty input");
+    SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_bwd: bad step range [%d, %d) of %d", t0, t1, T);
+    SEHIP_REQUIRE(state != nullptr || (t0 == 0 && t1 == T), "lstm_bwd: a partial step range needs the state buffer");
+    lstm_bwd_kernel<<<4 * cdiv(B, 16), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
+                                                                     (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T, t0,
+                                                                     t1, state, (bf16_raw*)dpre0, (bf16_raw*)dpre1);
+    SEHIP_CHECK_LAUNCH("lstm_bwd");
     return 0;
 }
 
 extern "C" int sehip_lstm_bwd(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B,
                               int T, int hidden, void* dpre0, void* dpre1, void* stream) {
-    SEHIP_REQUIRE(hidden == H, "lstm_bwd: only hidden size 64 (rnn_units=128) is built, got %d", hidden);
-    SEHIP_REQUIRE(B > 0 && T > 0, "lstm_bwd: empty input");
-    lstm_bwd_kernel<<<4 * cdiv(B, 16), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
-                                                                     (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T,
-                                                                     (bf16_raw*)dpre0, (bf16_raw*)dpre1);
-    SEHIP_CHECK_LAUNCH("lstm_bwd");
-    return 0;
+    return sehip_lstm_bwd_chunk(dh_a, dh_b, whhT, gates, c, B, T, hidden, 0, T, nullptr, dpre0, dpre1, stream);
 }

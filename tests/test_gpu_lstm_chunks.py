@@ -1,0 +1,42 @@
+"""GPU: the complex LSTM layers run as a chunk pipeline on two streams (sehip/plan.py).  Chunking must not change a single
+bit: the same kernels resume from the h / c records (forward) and the carried (dc, dh) state (backward)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def run_once(chunk, B, N):
+    from sehip.model import DCCRN
+    old = os.environ.get("SEHIP_LSTM_CHUNK")
+    os.environ["SEHIP_LSTM_CHUNK"] = str(chunk)
+    try:
+        dev = torch.device("cuda:0")
+        torch.manual_seed(3)
+        model = DCCRN(rnn_units=128, kernel_num=[16, 16, 32, 32, 64, 64], length=N).to(dev).train()
+        g = torch.Generator().manual_seed(11)
+        x = (0.1 * torch.randn(B, 1, N, generator=g)).to(dev)
+        out = model(x)
+        out.backward(torch.ones_like(out) * 1e-3)
+        torch.cuda.synchronize()
+        ws = model.workspace(B, N)
+        keep = {k: ws.bufs[k].t.clone() for k in ("P", "h1", "h2", "dz5l", "dpre1_r", "dpre2_i")}
+        return keep, model.flat_grads.clone(), len(ws.lstm_chunks)
+    finally:
+        if old is None:
+            os.environ.pop("SEHIP_LSTM_CHUNK", None)
+        else:
+            os.environ["SEHIP_LSTM_CHUNK"] = old
+
+
+@pytest.mark.parametrize("B,N,chunk", [(3, 6000, 16), (17, 3000, 7), (2, 6000, 40)])
+def test_chunked_equals_whole_sequence(B, N, chunk):
+    whole, gw, n1 = run_once(0, B, N)
+    parts, gp, n2 = run_once(chunk, B, N)
+    assert n1 == 1 and n2 > 1
+    for k in whole:
+        assert torch.equal(whole[k], parts[k]), k
+    # the weight gradients accumulate with fp32 atomics (order varies run to run): equal up to that
+    assert float((gw - gp).abs().max()) <= 1e-3 * float(gw.abs().max())
