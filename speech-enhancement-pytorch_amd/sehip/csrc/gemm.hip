@@ -1357,8 +1357,9 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     const int gx = (d.Npad >> 6) * ((C0 + C1) >> 6);
     // m-splits: a multiple of 8 (one group of splits per XCD) or 1, 2, 4 (8, 4, 2 XCDs share a split).  Every split flushes
     // its dW with atomics, and the weight gradients run beside the dependent chain on a second stream, so fewer, longer-lived
-    // workgroups than "fill the GPU twice" pay: measured per step with 8 / 16 / 32 / 64 splits: 7.24 / 7.15 / 7.19 / 7.3 ms.
-    static const int cw_splits = getenv("SEHIP_CW_SPLITS") ? atoi(getenv("SEHIP_CW_SPLITS")) : 16;
+    // workgroups than "fill the GPU twice" pay.  Measured per step (ms), splits 4 / 8 / 16 / 32 with at least 128 workgroups
+    // per launch: 5.95 / 5.97 / 6.08 / 6.17 (earlier in the round, with a slower chain, 16 was the optimum).
+    static const int cw_splits = getenv("SEHIP_CW_SPLITS") ? atoi(getenv("SEHIP_CW_SPLITS")) : 8;
     int splits = cw_splits >= 8 ? cw_splits / 8 * 8 : (cw_splits >= 4 ? 4 : (cw_splits >= 2 ? 2 : 1));
     static const int cw_minwg = getenv("SEHIP_CW_MINWG") ? atoi(getenv("SEHIP_CW_MINWG")) : 128;
     if (gx * splits < cw_minwg) splits = (cw_minwg / gx + 7) / 8 * 8;  // few (n, channel) tiles (enc3, dec2): 16 splits would leave 32-64 workgroups
