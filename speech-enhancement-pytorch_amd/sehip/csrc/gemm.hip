@@ -156,7 +156,7 @@ __device__ __forceinline__ RegTile<NRW> fetch_w_tile(const bf16_raw* Wb, int K, 
 }
 
 template <int BN, int BM, int WN, int WM>
-__global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
+__device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
     constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
     constexpr int NRA = BM / 32;
     constexpr int NRW = (BN + 31) / 32;
@@ -251,6 +251,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
             store_out4(d, nc, acc[ni][mi], ro0, ro1, n);
         }
     }
+}
+
+template <int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
+    gemm_body<BN, BM, WN, WM>(d);
+}
+
+// two products of the same shape in one launch (blockIdx.y picks the descriptor): the real / imaginary halves of the LSTM
+// input, projection and input-gradient products are 10-20 us kernels that are mostly launch and pipeline fill
+struct GemmPair { sehip_gemm_desc d[2]; };
+template <int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair p) {
+    // indexed in the kernel-argument segment (a select between two by-value descriptors was copied to scratch)
+    gemm_body<BN, BM, WN, WM>(p.d[blockIdx.y]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1155,6 +1169,26 @@ extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* 
     if (try_conv_small(*a, b, (hipStream_t)stream)) {
         SEHIP_CHECK_LAUNCH("gemm_pair(conv-small)");
         return 0;
+    }
+    // same-shape dense products that the generic 64-row kernels take: one launch
+    static const bool nopair = getenv("SEHIP_NO_PAIR") != nullptr;
+    if (!nopair && a->cv_nf <= 0 && b->cv_nf <= 0 && a->M == b->M && a->Npad == b->Npad && a->K == b->K && a->J == b->J &&
+        a->TT == b->TT && a->fmul == b->fmul) {
+        hipStream_t st = (hipStream_t)stream;
+        if (a->Npad == 64 && a->M < 256 * 192) {
+            sehip_note_kernel("gemm_pair_kernel<64, 64, 2, 2>");
+            GemmPair pr; pr.d[0] = *a; pr.d[1] = *b;
+            gemm_pair_kernel<64, 64, 2, 2><<<dim3(cdiv(a->M, 64), 2), 256, 0, st>>>(pr);
+            SEHIP_CHECK_LAUNCH("gemm_pair");
+            return 0;
+        }
+        if (a->Npad % 128 == 0 && (long)cdiv(a->M, 128) * (a->Npad / 128) < 512) {
+            sehip_note_kernel("gemm_pair_kernel<128, 64, 2, 2>");
+            GemmPair pr; pr.d[0] = *a; pr.d[1] = *b;
+            gemm_pair_kernel<128, 64, 2, 2><<<dim3(cdiv(a->M, 64) * (a->Npad / 128), 2), 256, 0, st>>>(pr);
+            SEHIP_CHECK_LAUNCH("gemm_pair");
+            return 0;
+        }
     }
     if (int e = sehip_gemm(a, stream)) return e;
     return sehip_gemm(b, stream);

@@ -860,20 +860,17 @@ class DCCRNWorkspace:
     def _lstm_forward(self, B, T, h):
         self._chain_dirty = True
         main = stream()
-        for tag in "ri":
-            self.gemm(f"ih1_{tag}")
+        self.gemm_pair("ih1_r", "ih1_i")
         if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():  # graph replay serialises the streams
             self._lstm_fwd_call(1, 0, T, main)
-            for tag in "ri":
-                self.gemm(f"ih2_{tag}")
+            self.gemm_pair("ih2_r", "ih2_i")
             self._lstm_fwd_call(2, 0, T, main)
             return
         s2 = self.lstm_stream.cuda_stream
         for (t0, t1) in self.lstm_chunks:
             self._lstm_fwd_call(1, t0, t1, main)
             call("sehip_stream_depend", s2, main, self._event())
-            for tag in "ri":
-                call("sehip_gemm", C.byref(self._chunk_desc(f"ih2_{tag}", t0, t1)), s2)
+            call("sehip_gemm_pair", C.byref(self._chunk_desc("ih2_r", t0, t1)), C.byref(self._chunk_desc("ih2_i", t0, t1)), s2)
             self._lstm_fwd_call(2, t0, t1, s2)
         call("sehip_stream_depend", main, s2, self._event())
 
@@ -894,16 +891,14 @@ class DCCRNWorkspace:
                     self.wgrad(f"ih{layer}_{tag}")
                 for combo in range(4):
                     self.wgrad(f"hh{layer}_{combo}")
-                self._chain_dirty = True
-                for tag in "ri":
-                    self.gemm(f"dx{layer}_{tag}")
+                self.gemm_pair(f"dx{layer}_r", f"dx{layer}_i")
             return
         s2 = self.lstm_stream.cuda_stream
         for (t0, t1) in reversed(self.lstm_chunks):
             self._lstm_bwd_call(2, t0, t1, main)                  # layer 2, later chunks first
             call("sehip_stream_depend", s2, main, self._event())
-            for tag in "ri":                                      # its input gradient = layer 1's output gradient
-                call("sehip_gemm", C.byref(self._chunk_desc(f"dx2_{tag}", t0, t1)), s2)
+            # its input gradient = layer 1's output gradient
+            call("sehip_gemm_pair", C.byref(self._chunk_desc("dx2_r", t0, t1)), C.byref(self._chunk_desc("dx2_i", t0, t1)), s2)
             self._lstm_bwd_call(1, t0, t1, s2)
         call("sehip_stream_depend", main, s2, self._event())
         self._chain_dirty = True
@@ -912,8 +907,7 @@ class DCCRNWorkspace:
                 self.wgrad(f"ih{layer}_{tag}")
             for combo in range(4):
                 self.wgrad(f"hh{layer}_{combo}")
-        for tag in "ri":
-            self.gemm(f"dx1_{tag}")
+        self.gemm_pair("dx1_r", "dx1_i")
 
     # ---- forward / backward --------------------------------------------------------------------
     def pack_weights(self, params):
@@ -932,8 +926,7 @@ class DCCRNWorkspace:
             self.gemm(f"enc{i}.fwd")
             self.bn_forward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, b[f"y{i}"], b[f"z{i}"], params, buffers, nbt, training)
         self._lstm_forward(B, T, h)
-        for tag in "ri":
-            self.gemm(f"proj_{tag}")
+        self.gemm_pair("proj_r", "proj_i")
         for j in range(6):
             self.gemm_pair(f"dec{j}.fwd0", f"dec{j}.fwd1")
             if j < 5:
@@ -960,8 +953,7 @@ class DCCRNWorkspace:
             self.gemm(f"dec{j}.dg")
         for tag in "ri":
             self.wgrad(f"proj_{tag}")
-        for tag in "ri":
-            self.gemm(f"dproj_{tag}")
+        self.gemm_pair("dproj_r", "dproj_i")
         self._lstm_backward(B, T, h)
         for i in range(5, -1, -1):
             dz = b["dz5l"] if i == 5 else b[f"dz{i}"]
