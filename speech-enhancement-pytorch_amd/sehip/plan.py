@@ -673,9 +673,12 @@ class DCCRNWorkspace:
         if len(self.lstm_chunks) > 1 and self.lstm_chunks[-1][1] - self.lstm_chunks[-1][0] < chunk // 4:
             last = self.lstm_chunks.pop()            # no tiny trailing chunk
             self.lstm_chunks[-1] = (self.lstm_chunks[-1][0], last[1])
-        self.lstm_stream = None
+        self.lstm_stream = self.lstm_gemm_stream = None
         if len(self.lstm_chunks) > 1 and not os.environ.get("SEHIP_NO_SIDE_STREAM"):
-            self.lstm_stream = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[1])
+            hi = torch.cuda.Stream.priority_range()[1]
+            self.lstm_stream = torch.cuda.Stream(device=device, priority=hi)
+            # the small products between the layers get their own stream: chunk c's product overlaps layer 2's chunk c-1
+            self.lstm_gemm_stream = torch.cuda.Stream(device=device, priority=hi)
         self.lstm_state = {layer: torch.zeros(4 * ((B + 15) // 16) * 2048, dtype=torch.float32, device=device) for layer in (1, 2)}
         self._bind()
 
@@ -793,7 +796,7 @@ class DCCRNWorkspace:
     def _event(self):
         """Round-robin pool of fence-free events (sehip_stream_depend)."""
         if not self._events:
-            for _ in range(8):
+            for _ in range(32):
                 e = _lib.lib().sehip_event_create()
                 if not e:
                     raise SehipError("sehip_event_create: " + _lib.lib().sehip_last_error().decode())
@@ -866,11 +869,12 @@ class DCCRNWorkspace:
             self.gemm_pair("ih2_r", "ih2_i")
             self._lstm_fwd_call(2, 0, T, main)
             return
-        s2 = self.lstm_stream.cuda_stream
+        s2, s3 = self.lstm_stream.cuda_stream, self.lstm_gemm_stream.cuda_stream
         for (t0, t1) in self.lstm_chunks:
             self._lstm_fwd_call(1, t0, t1, main)
-            call("sehip_stream_depend", s2, main, self._event())
-            call("sehip_gemm_pair", C.byref(self._chunk_desc("ih2_r", t0, t1)), C.byref(self._chunk_desc("ih2_i", t0, t1)), s2)
+            call("sehip_stream_depend", s3, main, self._event())
+            call("sehip_gemm_pair", C.byref(self._chunk_desc("ih2_r", t0, t1)), C.byref(self._chunk_desc("ih2_i", t0, t1)), s3)
+            call("sehip_stream_depend", s2, s3, self._event())
             self._lstm_fwd_call(2, t0, t1, s2)
         call("sehip_stream_depend", main, s2, self._event())
 
@@ -893,12 +897,13 @@ class DCCRNWorkspace:
                     self.wgrad(f"hh{layer}_{combo}")
                 self.gemm_pair(f"dx{layer}_r", f"dx{layer}_i")
             return
-        s2 = self.lstm_stream.cuda_stream
+        s2, s3 = self.lstm_stream.cuda_stream, self.lstm_gemm_stream.cuda_stream
         for (t0, t1) in reversed(self.lstm_chunks):
             self._lstm_bwd_call(2, t0, t1, main)                  # layer 2, later chunks first
-            call("sehip_stream_depend", s2, main, self._event())
+            call("sehip_stream_depend", s3, main, self._event())
             # its input gradient = layer 1's output gradient
-            call("sehip_gemm_pair", C.byref(self._chunk_desc("dx2_r", t0, t1)), C.byref(self._chunk_desc("dx2_i", t0, t1)), s2)
+            call("sehip_gemm_pair", C.byref(self._chunk_desc("dx2_r", t0, t1)), C.byref(self._chunk_desc("dx2_i", t0, t1)), s3)
+            call("sehip_stream_depend", s2, s3, self._event())
             self._lstm_bwd_call(1, t0, t1, s2)
         call("sehip_stream_depend", main, s2, self._event())
         self._chain_dirty = True
