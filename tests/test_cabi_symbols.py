@@ -50,3 +50,14 @@ def test_errors_are_reported_not_thrown():
     assert b"fft_len 512" in lib.sehip_last_error()
     with pytest.raises(_lib.SehipError):
         _lib.call("sehip_lstm_fwd", None, None, None, 1, 1, 32, None, None, None, None)
+    # chunked recurrences: the step range is validated, a partial backward range needs the carried state
+    assert lib.sehip_lstm_fwd_chunk(None, None, None, 2, 10, 64, 5, 5, None, None, None, None) != 0
+    assert b"step range" in lib.sehip_last_error()
+    assert lib.sehip_lstm_bwd_chunk(None, None, None, None, None, 2, 10, 64, 0, 5, None, None, None, None) != 0
+    assert b"state buffer" in lib.sehip_last_error()
+    # stft_custom: only n_fft 512 is built; frame count helper follows torch.stft
+    assert lib.sehip_stft_custom_fwd(None, 1, 1000, 320, 160, 320, 1, None, None) != 0
+    assert b"n_fft 512" in lib.sehip_last_error()
+    assert lib.sehip_stft_custom_frames(32768, 512, 128, 1) == 257
+    assert lib.sehip_stft_custom_frames(2048, 512, 256, 0) == 7
+    assert lib.sehip_stream_depend(None, None, None) != 0
