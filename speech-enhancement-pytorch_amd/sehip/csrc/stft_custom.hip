@@ -83,27 +83,37 @@ __global__ __launch_bounds__(256) void istft_custom_frames_kernel(const float2* 
     // tensor * win_length (src/evaluate.py:131), the 1/n_fft of the inverse transform, and the synthesis window
     const float scale = (float)win_length / (float)FFT_N;
     constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-    for (int tl = w; tl < nt; tl += 4) {
+    // TWO frames per transform: both Hermitian-extended spectra are packed as H1 + i H2; the inverse transform of a
+    // Hermitian spectrum is real, so frame 1 comes out in the real part and frame 2 in the imaginary part.
+    for (int tp = 2 * w; tp < nt; tp += 8) {
+        const int ta = tp, tb = tp + 1 < nt ? tp + 1 : tp;   // an odd tail transforms its last frame twice
         float re[8], im[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int k = lane + 64 * r;
             // Hermitian extension of the one-sided spectrum; a c2r transform ignores Im of DC and Nyquist
-            const float2 z = tile[tl * SC_PITCH + (k <= 256 ? k : FFT_N - k)];
-            re[r] = z.x;
-            im[r] = (k == 0 || k == 256) ? 0.f : (k < 256 ? z.y : -z.y);
+            const int kk = k <= 256 ? k : FFT_N - k;
+            const float2 za = tile[ta * SC_PITCH + kk], zb = tile[tb * SC_PITCH + kk];
+            const float sg = (k == 0 || k == 256) ? 0.f : (k < 256 ? 1.f : -1.f);
+            re[r] = za.x - sg * zb.y;
+            im[r] = sg * za.y + zb.x;
         }
         fft512_wave<1>(re, im, tw, lane);
         const int n0 = 8 * brev6(lane);
-        float u[8];
+        float ua[8], ub[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[brev3[j]] = re[j];
-        float* fo = frames + ((size_t)row * T + t0 + tl) * FFT_N + n0;
-        float o[8];
+        for (int j = 0; j < 8; ++j) { ua[brev3[j]] = re[j]; ub[brev3[j]] = im[j]; }
+        float wq[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = u[q] * scale * sc_window(n0 + q, left, win_length);
-        *reinterpret_cast<float4*>(fo) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(fo + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        for (int q = 0; q < 8; ++q) wq[q] = scale * sc_window(n0 + q, left, win_length);
+        float* fa = frames + ((size_t)row * T + t0 + ta) * FFT_N + n0;
+        *reinterpret_cast<float4*>(fa) = make_float4(ua[0] * wq[0], ua[1] * wq[1], ua[2] * wq[2], ua[3] * wq[3]);
+        *reinterpret_cast<float4*>(fa + 4) = make_float4(ua[4] * wq[4], ua[5] * wq[5], ua[6] * wq[6], ua[7] * wq[7]);
+        if (tb != ta) {
+            float* fb = frames + ((size_t)row * T + t0 + tb) * FFT_N + n0;
+            *reinterpret_cast<float4*>(fb) = make_float4(ub[0] * wq[0], ub[1] * wq[1], ub[2] * wq[2], ub[3] * wq[3]);
+            *reinterpret_cast<float4*>(fb + 4) = make_float4(ub[4] * wq[4], ub[5] * wq[5], ub[6] * wq[6], ub[7] * wq[7]);
+        }
     }
 }
 
