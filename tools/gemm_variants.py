@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of gemm launch variants in ONE process (SEHIP_GEMM_FLAGS is read once per process, so each variant runs in a
-child process on the same device, interleaved)."""
+"""A/B of launch variants of single products on ONE GPU box: the tuning variables are read once per process, so each variant
+runs in a child process on the same device, in the order given.  Usage: SEHIP_NAMES=enc3.fwd,dec0.dg python
+tools/gemm_variants.py base SEHIP_CW_SPLITS=16 lib:tools/_prev.so"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -28,28 +29,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     print("RES " + json.dumps(res))
 else:
     names = os.environ.get("SEHIP_NAMES", "").split(",") if os.environ.get("SEHIP_NAMES") else ["dec1.dg", "dec0.fwd0", "enc5.fwd", "dec0.fwd0.wg", "enc4.fwd.wg", "enc1.fwd", "enc2.fwd", "enc1.dg0", "enc2.dg0", "dec3.fwd0", "dec4.fwd0", "dec5.fwd0", "dec4.dg", "enc0.fwd", "dec5.dg", "enc1.fwd.wg", "enc2.fwd.wg", "dec4.fwd0.wg", "dec3.fwd0.wg", "dec5.fwd0.wg", "enc0.fwd.wg"]
+    # a variant is "base", "lib:<path to another libsehip.so>" or NAME=VALUE (any SEHIP_* tuning variable)
     for flags in sys.argv[1:]:
         env = dict(os.environ)
-        if flags == "nopatch":
-            env["SEHIP_NO_PATCH"] = "1"
-        if flags.startswith("abl"):
-            env["SEHIP_ABL"] = flags[3:]
-        if flags.startswith("cw"):
-            env["SEHIP_CW_WGS"] = flags[2:]
         if flags.startswith("lib:"):
             env["SEHIP_LIB"] = os.path.join(ROOT, flags[4:])
-        if flags.startswith("direct"):
-            env["SEHIP_DIRECT"] = flags[6:]
-        if flags.startswith("minwg"):
-            env["SEHIP_CW_MINWG"] = flags[5:]
-        if flags.startswith("mi"):
-            env["SEHIP_SMALL_MI"] = flags[2:]
-        if flags == "small128":
-            env["SEHIP_SMALL128"] = "1"
-        if flags == "nobm64":
-            env["SEHIP_NO_BM64"] = "1"
-        if flags == "nosmall":
-            env["SEHIP_NO_SMALL"] = "1"
+        elif "=" in flags:
+            k, v = flags.split("=", 1)
+            env[k] = v
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RES ")]
         print(flags, {k: round(v * 1e3) for k, v in json.loads(line[0][4:]).items()} if line else r.stderr[-500:])
