@@ -1,0 +1,49 @@
+"""GPU: the specialised kernels (LDS-patch conv GEMMs, small-channel / 2-channel kernels, paired launches, LSTM chunk pipeline)
+against the table-gathered generic kernels that remain the fallback for shapes they do not take.  The tuning variables are
+read once per process, so each configuration runs in a child process."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(%(root)r, "speech-enhancement-pytorch_amd")); sys.path.insert(0, %(root)r)
+from sehip.model import DCCRN
+dev = torch.device("cuda:0")
+torch.manual_seed(21)
+model = DCCRN(rnn_units=128, kernel_num=[16, 32, 64, 128, 128, 128], length=6000).to(dev).train()
+g = torch.Generator().manual_seed(22)
+x = (0.1 * torch.randn(4, 1, 6000, generator=g)).to(dev)
+out = model(x)
+out.backward(1e-3 * torch.ones_like(out))
+torch.cuda.synchronize()
+torch.save({"out": out.detach().cpu(), "grads": model.flat_grads.cpu()}, sys.argv[1])
+"""
+
+
+def run(env_extra):
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "r.pt")
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return torch.load(path)
+
+
+def test_specialised_kernels_match_generic_fallback():
+    fast = run({})
+    slow = run({"SEHIP_NO_PATCH": "1", "SEHIP_NO_NARROW": "1", "SEHIP_NO_PAIR": "1", "SEHIP_NO_BM64": "1", "SEHIP_LSTM_CHUNK": "0",
+                "SEHIP_NO_SIDE_STREAM": "1"})
+    # same bf16 rounding points, different fp32 summation order: outputs agree far inside the bf16 noise of the chain
+    eo = float((fast["out"] - slow["out"]).norm() / slow["out"].norm())
+    eg = float((fast["grads"] - slow["grads"]).norm() / slow["grads"].norm())
+    assert eo < 2e-2, eo
+    assert eg < 5e-2, eg
