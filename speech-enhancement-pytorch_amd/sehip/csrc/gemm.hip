@@ -406,7 +406,50 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d,
         }
     }
 
-    // epilogue (same scatter as gemm_kernel)
+    // ---- epilogue.  A lane holds 4 consecutive channels of a row, so the direct scatter writes 8-byte pieces (32 bytes per
+    // row and instruction).  When the wave's 64 output channels are one dense run of a bf16 destination, the tile goes
+    // through a wave-private LDS image instead and leaves as 16-byte pieces, 128 contiguous bytes per row.
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN, TP = WCOLS + 8;
+    const int nw0 = n0 + wn * WCOLS;
+    bool dense = WCOLS == 64;
+    sehip_nchunk first = d.ntab[nw0 >> 2];
+    {
+        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + (lane & 15)];
+        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * (lane & 15);
+        dense = dense && __all(ok) && !(first.dst ? d.dst[1].is_f32 : d.dst[0].is_f32) && ((first.coff & 7) == 0) &&
+                (((first.dst ? d.dst[1].C : d.dst[0].C) & 7) == 0);
+    }
+    __syncthreads();  // every wave has finished reading the weight tile and the patch: the LDS is free (unconditional: the
+                      // waves of a workgroup may disagree about `dense`)
+    if (dense) {
+        bf16_raw* tb_ = reinterpret_cast<bf16_raw*>(smem) + wave * (WROWS * TP);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const f32x4 v = acc[ni][mi];
+                *reinterpret_cast<uint2*>(&tb_[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * (lane >> 4)]) =
+                    make_uint2(pack_bf2(v[0] + bv.x, v[1] + bv.y), pack_bf2(v[2] + bv.z, v[3] + bv.w));
+            }
+        }
+        // wave-private image: the LDS queue of a wave is in order, no barrier needed between its writes and reads
+        const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
+        bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
+#pragma unroll
+        for (int it = 0; it < WROWS / 8; ++it) {
+            const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+            const int rr = wm * WROWS + row;
+            const int tl = rr / JB, jl = rr - tl * JB;
+            RowPos r;
+            r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
+            const uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + c8 * 8]);
+            if (r.valid) *reinterpret_cast<uint4*>(dptr + dst_row_offset(dd, r, d.fmul) + c8 * 8) = v;
+        }
+        return;
+    }
+    // direct scatter (same as gemm_kernel)
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int rr = wm * (BM / WM) + mi * 16 + (lane & 15);
