@@ -536,6 +536,10 @@ struct Cs2Side {
     int ts0, ts1;
     sehip_nchunk nck[TN];
     float4 bias4[TN];
+    // dense bf16 destination (all TN*16 channels one contiguous run): the tile leaves through a wave-private LDS image as
+    // 16-byte pieces; o_off[it] = destination offset (b 0, tile frame 0) of the row of piece lane + 64 it, o_tl its tile frame
+    bool dense;
+    int o_off[(MI * TN + 1) / 2], o_tl[(MI * TN + 1) / 2];
 };
 
 template <int TN, int MI>
@@ -567,6 +571,26 @@ __device__ __forceinline__ Cs2Side<TN, MI> cs2_side_init(const sehip_gemm_desc& 
         sd.nck[ni] = d.ntab[n >> 2];
         sd.bias4[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    {
+        constexpr int CH = TN * 4;                      // 4-channel chunks of a row
+        const sehip_nchunk first = d.ntab[0];
+        const sehip_nchunk mine = d.ntab[lane % CH];
+        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * (lane % CH);
+        const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
+        sd.dense = TN >= 2 && TN <= 4 && __all(ok) &&   // 128 outputs: the staging cost more registers than it saved (82 -> 100 us)
+                   !dd.is_f32 && (first.coff & 7) == 0 && (dd.C & 7) == 0;
+        constexpr int PPR = TN * 2;                     // 16-byte pieces per row
+#pragma unroll
+        for (int it = 0; it < (MI * TN + 1) / 2; ++it) {
+            const int row = (lane + 64 * it) / PPR, c8 = (lane + 64 * it) - row * PPR;
+            const int r = 16 * MI * w + row;
+            const int tl = r / JB, jl = r - tl * JB;
+            RowPos rp;
+            rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+            sd.o_off[it] = (int)dst_row_offset(dd, rp, d.fmul) + first.coff + c8 * 8;
+            sd.o_tl[it] = tl;
+        }
+    }
     return sd;
 }
 
@@ -584,8 +608,8 @@ __device__ __forceinline__ void cs2_load_weights(const sehip_gemm_desc& d, bf16_
 // all K steps of one side over the staged patch, then its stores
 template <int TN, int MI>
 __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, const sehip_gemm_desc& d, const bf16_raw* patch,
-                                                   const int (&abase)[MI], const int (&e_tl)[MI], int FR, int PP, int CT, int C0,
-                                                   int b, int t0, int lane) {
+                                                   bf16_raw* obuf /* wave-private [16 MI][16 TN + 8] */, const int (&abase)[MI],
+                                                   const int (&e_tl)[MI], int FR, int PP, int CT, int C0, int b, int t0, int lane) {
     const int g = lane >> 4;
     const int wrow = (lane & 15) * sd.KP + 8 * g;  // this lane's weight fragment: row (lane & 15) of each 16-row tile, k chunk g
     f32x4 acc[TN][MI];
@@ -649,6 +673,29 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
     }
+    if (sd.dense) {
+        constexpr int TP = 16 * TN + 8;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const f32x4 v = acc[ni][mi];
+                *reinterpret_cast<uint2*>(&obuf[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * g]) =
+                    make_uint2(pack_bf2(v[0] + sd.bias4[ni].x, v[1] + sd.bias4[ni].y), pack_bf2(v[2] + sd.bias4[ni].z, v[3] + sd.bias4[ni].w));
+            }
+        const sehip_nchunk first = sd.nck[0];
+        bf16_raw* dptr = reinterpret_cast<bf16_raw*>(first.dst ? d.dst[1].ptr : d.dst[0].ptr);
+        const long tile_off = first.dst ? b * sd.bs1 + (long)t0 * sd.ts1 : b * sd.bs0 + (long)t0 * sd.ts0;
+        constexpr int PPR = TN * 2;
+#pragma unroll
+        for (int it = 0; it < (MI * TN + 1) / 2; ++it) {
+            const int idx = lane + 64 * it;
+            const int row = idx / PPR, c8 = idx - row * PPR;
+            if (idx < 16 * MI * PPR && t0 + sd.o_tl[it] < d.TT)
+                *reinterpret_cast<uint4*>(dptr + tile_off + sd.o_off[it]) = *reinterpret_cast<const uint4*>(&obuf[row * TP + c8 * 8]);
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         if (t0 + e_tl[mi] >= d.TT) continue;
@@ -690,6 +737,8 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
     bf16_raw* sW = reinterpret_cast<bf16_raw*>(smem);
     bf16_raw* sW2 = sW + BN * (d.K + 8);
     bf16_raw* patch = PAIR ? sW2 + BN * (d2.K + 8) : sW2;
+    // output staging image of this wave, behind the patch and its 16-byte dump slot
+    bf16_raw* obuf = patch + (TB + 1) * FR * PP + 8 + (threadIdx.x >> 6) * (16 * MI * (BN + 8));
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     cs2_load_weights<BN>(d, sW, tid);
@@ -758,8 +807,8 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
         for (int u = 0; u < NPC; ++u) *reinterpret_cast<uint4*>(&patch[p_lds[u]]) = pr.v[u];
         __syncthreads();
         if (mt + 1 < mt_end) CS_FETCH(mt + 1)   // in flight while this tile is multiplied and stored
-        cs2_multiply_store<TN, MI>(sa, d, patch, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
-        if (PAIR) cs2_multiply_store<TN, MI>(sb, d2, patch, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
+        cs2_multiply_store<TN, MI>(sa, d, patch, obuf, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
+        if (PAIR) cs2_multiply_store<TN, MI>(sb, d2, patch, obuf, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
         __syncthreads();  // every read of this tile's patch is done before the next one is written
     }
 #undef CS_FETCH
@@ -798,7 +847,9 @@ static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, h
     static const int mi_force = getenv("SEHIP_SMALL_MI") ? atoi(getenv("SEHIP_SMALL_MI")) : 0;
     const size_t lds_cap = d2 ? 160 * 1024 : 120 * 1024;
     auto pieces = [&](int mi) { return (64 * mi / JB + 1) * FR * (CT >> 3); };
-    auto lds_of = [&](int mi) { return wbytes + (size_t)(64 * mi / JB + 1) * FR * (CT + 8) * 2 + 16; };
+    auto lds_of = [&](int mi) {  // weights + patch + dump slot + the four waves' output staging images
+        return wbytes + (size_t)(64 * mi / JB + 1) * FR * (CT + 8) * 2 + 16 + (d.Npad >= 32 && d.Npad <= 64 ? (size_t)4 * 16 * mi * (d.Npad + 8) * 2 : 0);
+    };
     auto fits = [&](int mi) { return pieces(mi) <= 12 * 256 && lds_of(mi) <= lds_cap; };
     int MI = 2;
     if (d.Npad <= 32 && fits(4) && (pieces(2) <= 6 * 256) == (pieces(4) <= 6 * 256)) MI = 4;
