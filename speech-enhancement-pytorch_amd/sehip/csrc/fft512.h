@@ -143,3 +143,23 @@ __device__ __forceinline__ void fft512_wave(float (&re)[8], float (&im)[8], cons
 
 __device__ __forceinline__ int brev6(int l) { return (int)(__brev((unsigned)l) >> 26); }
 
+// Two REAL 512-point transforms for the price of one.  Forward: transform z = x1 + i x2, then
+//   X1[k] = (Z[k] + conj(Z[512-k])) / 2,   X2[k] = (Z[k] - conj(Z[512-k])) / (2i).
+// In the output layout of fft512_wave (lane l, register j <-> k = 8 brev6(l) + brev3(j)) bin 512-k lives in lane l ^ 63,
+// register jp[j] for brev3(j) != 0, and in lane brev6((64 - brev6(l)) & 63), register 0 for j = 0: 16 shuffles instead
+// of a second transform's 96.  Inverse: the inverse transform of a Hermitian spectrum is real, so H1 + i H2 comes back as
+// frame 1 in the real part and frame 2 in the imaginary part with no exchange at all.
+__device__ __forceinline__ void fft_pair_split(const float (&zr)[8], const float (&zi)[8], int lane, float (&ar)[8],
+                                               float (&ai)[8], float (&br)[8], float (&bi)[8]) {
+    constexpr int jp[8] = {0, 1, 3, 2, 7, 6, 5, 4};
+    const int mir = lane ^ 63;
+    const int l0 = brev6((64 - brev6(lane)) & 63);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int src = j == 0 ? l0 : mir;
+        const float pr = __shfl(zr[jp[j]], src, 64), pi = __shfl(zi[jp[j]], src, 64);
+        ar[j] = 0.5f * (zr[j] + pr); ai[j] = 0.5f * (zi[j] - pi);
+        br[j] = 0.5f * (zi[j] + pi); bi[j] = -0.5f * (zr[j] - pr);
+    }
+}
+

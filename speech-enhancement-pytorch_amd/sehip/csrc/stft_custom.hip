@@ -35,24 +35,32 @@ __global__ __launch_bounds__(256) void stft_custom_kernel(const float* __restric
     for (int r = 0; r < 8; ++r) wv[r] = sc_window(lane + 64 * r, left, win_length) * scale;
     const int pad = center ? FFT_N / 2 : 0;
     constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-    for (int tl = w; tl < SC_TF; tl += 4) {
-        const int t = t0 + tl;
-        if (t >= T) break;
+    // two frames per transform (fft_pair_split); a frame beyond T or an odd tail transforms the last valid frame twice
+    const int ntl = min(SC_TF, T - t0);
+    for (int tp = 2 * w; tp < ntl; tp += 8) {
+        const int tla = tp, tlb = tp + 1 < ntl ? tp + 1 : tp;
         float re[8], im[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            int s = t * hop + lane + 64 * r - pad;
-            if (s < 0) s = -s;                              // reflect (no edge repeat), as torch's pad_mode="reflect"
-            if (s >= N) s = 2 * (N - 1) - s;
-            re[r] = x[s] * wv[r];
-            im[r] = 0.f;
+            int sa = (t0 + tla) * hop + lane + 64 * r - pad, sb = (t0 + tlb) * hop + lane + 64 * r - pad;
+            if (sa < 0) sa = -sa;                            // reflect (no edge repeat), as torch's pad_mode="reflect"
+            if (sa >= N) sa = 2 * (N - 1) - sa;
+            if (sb < 0) sb = -sb;
+            if (sb >= N) sb = 2 * (N - 1) - sb;
+            re[r] = x[sa] * wv[r];
+            im[r] = x[sb] * wv[r];
         }
         fft512_wave<-1>(re, im, tw, lane);
+        float ar[8], ai[8], br[8], bi[8];
+        fft_pair_split(re, im, lane, ar, ai, br, bi);
         const int k0 = 8 * brev6(lane);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + brev3[j];
-            if (k <= 256) tile[tl * SC_PITCH + k] = make_float2(re[j], im[j]);
+            if (k <= 256) {
+                tile[tla * SC_PITCH + k] = make_float2(ar[j], ai[j]);
+                if (tlb != tla) tile[tlb * SC_PITCH + k] = make_float2(br[j], bi[j]);
+            }
         }
     }
     __syncthreads();
