@@ -138,7 +138,10 @@ typedef struct {
      * stage each input element once per tile in LDS instead of once per tap.  cv_nf == 0: not described. */
     int32_t cv_nf, cv_fadd;
     int32_t cv_toff[2][2];
-    int32_t cv_pad_[2];
+    /* Optional residual: a bf16 tensor laid out exactly like dst[0]; when set, the channels that go to dst[0] are stored as
+     * product + res (the encoder's input gradient = dgrad of the next layer + the gradient that arrived over the skip
+     * connection, src/model/dccrn.py:186-197 backward: one tensor pass less in each of the two BatchNorm backward kernels) */
+    const void* res;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);

@@ -110,6 +110,22 @@ __device__ __forceinline__ RegTile<NPC> sw_fetch_patch(const bf16_raw* const (&p
 }
 
 
+// residual (descriptor field res): out = product + res, bf16 in, fp32 add
+__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 r) {
+    const unsigned av[4] = {a.x, a.y, a.z, a.w}, rv[4] = {r.x, r.y, r.z, r.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf2(__uint_as_float(av[i] << 16) + __uint_as_float(rv[i] << 16),
+                        __uint_as_float(av[i] & 0xffff0000u) + __uint_as_float(rv[i] & 0xffff0000u));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void add_res4(f32x4& v, const void* res, size_t off) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_raw*>(res) + off);
+    v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+    v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+}
+
 // Scatter of one lane's 4 consecutive output channels (shared by both product kernels).
 __device__ __forceinline__ void store_out4(const sehip_gemm_desc& d, const sehip_nchunk nc, f32x4 v, size_t ro0, size_t ro1,
                                            int n) {
@@ -120,6 +136,7 @@ __device__ __forceinline__ void store_out4(const sehip_gemm_desc& d, const sehip
     const size_t off = (nc.dst ? ro1 : ro0) + nc.coff;
     void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
     const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+    if (d.res && nc.dst == 0 && nc.nvalid == 4) add_res4(v, d.res, off);
     if (is_f32) {
         float* p = reinterpret_cast<float*>(dptr) + off;
         if (nc.nvalid == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -444,8 +461,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d,
             const int tl = rr / JB, jl = rr - tl * JB;
             RowPos r;
             r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
-            const uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + c8 * 8]);
-            if (r.valid) *reinterpret_cast<uint4*>(dptr + dst_row_offset(dd, r, d.fmul) + c8 * 8) = v;
+            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + c8 * 8]);
+            if (r.valid) {
+                const size_t off = dst_row_offset(dd, r, d.fmul) + c8 * 8;
+                if (d.res && first.dst == 0)
+                    v = add_bf16x8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(d.res) + first.coff + off));
+                *reinterpret_cast<uint4*>(dptr + off) = v;
+            }
         }
         return;
     }
@@ -691,8 +713,12 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
         for (int it = 0; it < (MI * TN + 1) / 2; ++it) {
             const int idx = lane + 64 * it;
             const int row = idx / PPR, c8 = idx - row * PPR;
-            if (idx < 16 * MI * PPR && t0 + sd.o_tl[it] < d.TT)
-                *reinterpret_cast<uint4*>(dptr + tile_off + sd.o_off[it]) = *reinterpret_cast<const uint4*>(&obuf[row * TP + c8 * 8]);
+            if (idx < 16 * MI * PPR && t0 + sd.o_tl[it] < d.TT) {
+                uint4 v = *reinterpret_cast<const uint4*>(&obuf[row * TP + c8 * 8]);
+                if (d.res && first.dst == 0)
+                    v = add_bf16x8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(d.res) + tile_off + sd.o_off[it]));
+                *reinterpret_cast<uint4*>(dptr + tile_off + sd.o_off[it]) = v;
+            }
         }
         return;
     }
@@ -710,6 +736,7 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
             const long off = (nc.dst ? ro1 : ro0) + nc.coff;
             void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
             const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+            if (d.res && nc.dst == 0 && nc.nvalid == 4) add_res4(v, d.res, (size_t)off);
             if (is_f32) {
                 float* q = reinterpret_cast<float*>(dptr) + off;
                 if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1191,7 +1218,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const sehip_gemm_desc 
 
 static int try_conv_narrow(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
-    if (disabled || d.cv_nf <= 0 || d.cv_nf > 5 || d.src[0].C != 2 || d.src[1].ptr) return 0;
+    if (disabled || d.cv_nf <= 0 || d.cv_nf > 5 || d.src[0].C != 2 || d.src[1].ptr || d.res) return 0;
     if ((d.Npad != 16 && d.Npad != 32) || d.K < 32 || d.J > 128 || (128 % d.J)) return 0;
     const int fa = (d.cv_fadd >= 0 ? d.cv_fadd / 4 : -((-d.cv_fadd + 3) / 4)) * 4;
     if ((d.cv_fadd - fa) & 1) return 0;  // 8-byte aligned operand reads

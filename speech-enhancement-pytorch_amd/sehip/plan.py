@@ -12,6 +12,7 @@ Channel-last layout [B][T][F][C]; decoder tensors that feed a BatchNorm keep the
 drops after the BatchNorm (src/model/dccrn.py:193-196), i.e. they store T+1 frames and logical frame t lives at t+1.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -42,7 +43,12 @@ class CGemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32),
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
                 ("pad_", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
-                ("cv_pad_", C.c_int32 * 2)]
+                ("res", C.c_void_p)]
+
+
+# The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient
+# (descriptor field `res`), so the BatchNorm backward kernels read one gradient tensor instead of two.
+FUSE_SKIP_GRAD = not os.environ.get("SEHIP_NO_FUSE_SKIP")
 
 
 def npad_of(n):
@@ -265,7 +271,7 @@ def pad_ktab(rows):
 class GemmSpec:
     """Batch-independent description of one product (see sehip_gemm_desc)."""
 
-    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd", conv=None):
+    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd", conv=None, res=None):
         self.name = name
         self.conv = conv  # (nf, fadd, [[toff(s0,kt0), toff(s0,kt1)], [toff(s1,kt0), toff(s1,kt1)]]) or None
         self.ktab, self.K = pad_ktab(rows)
@@ -287,6 +293,7 @@ class GemmSpec:
         self.dsts = dsts   # list of (buffer name, toff, fmul, fadd)
         self.ntab = ntab if ntab is not None else dense_ntab(n, self.Npad)
         self.kind = kind
+        self.res = res     # buffer added to what goes to dsts[0] (same layout), or None
         self.w_off = self.b_off = self.dw_off = self.db_off = None
         self.kt_off = self.nt_off = None
 
@@ -352,7 +359,8 @@ class DCCRNStatic:
                     self.specs[f"enc{i}.dg{p}"] = GemmSpec(f"enc{i}.dg{p}", rows, w.reshape(ci, -1), wn.reshape(ci, -1), ci,
                                                            None, "T", self.F0 >> (i + 1), 1, [(f"dye{i}", "all")],
                                                            [(f"dz{i - 1}", 0, 2, p)], kind="dgrad",
-                                                           conv=(len(ds), ds[0], [[1, 0], [0, 0]]))
+                                                           conv=(len(ds), ds[0], [[1, 0], [0, 0]]),
+                                                           res=f"dskip{i - 1}" if FUSE_SKIP_GRAD else None)
 
         # ---------------- decoder ----------------
         for j in range(6):
@@ -731,6 +739,10 @@ class DCCRNWorkspace:
                 d.bias = tb.bpack.data_ptr() + 4 * s.b_off
             d.M, d.N, d.Npad, d.K = B * tt * s.J, s.N, s.Npad, s.K
             d.TT, d.J, d.fmul = tt, s.J, s.fmul
+            if s.res is not None:
+                rb, db_ = self.bufs[s.res], self.bufs[s.dsts[0][0]]
+                assert (rb.Tst, rb.F, rb.C) == (db_.Tst, db_.F, db_.C) and rb.t.dtype == torch.bfloat16
+                d.res = rb.ptr
             if s.conv is not None:
                 d.cv_nf, d.cv_fadd = s.conv[0], s.conv[1]
                 for q in range(2):
@@ -962,7 +974,8 @@ class DCCRNWorkspace:
         self._lstm_backward(B, T, h)
         for i in range(5, -1, -1):
             dz = b["dz5l"] if i == 5 else b[f"dz{i}"]
-            self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, b[f"dskip{i}"], b[f"y{i}"], b[f"dye{i}"], params, 0)
+            dz2 = b[f"dskip{i}"] if (i == 5 or not FUSE_SKIP_GRAD) else None   # enc{i+1}.dg0/dg1 already added it (res)
+            self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, dz2, b[f"y{i}"], b[f"dye{i}"], params, 0)
             self.wgrad(f"enc{i}.fwd")
             if i > 0:
                 self.gemm(f"enc{i}.dg0")

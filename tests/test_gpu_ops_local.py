@@ -76,7 +76,10 @@ def test_encoder_conv_forward_dgrad_wgrad(run, i):
     dy = to_ref(b[f"dye{i}"])
     gx, gwr, gbr, gwi, gbi = torch.autograd.grad((y * dy).sum(), [x, wr, br, wi, bi])
     if i > 0:
-        assert rel_err(to_ref(b[f"dz{i - 1}"]), gx) < 6e-3
+        # the dgrad product also adds the gradient that arrived over the skip connection (descriptor field `res`)
+        from sehip.plan import FUSE_SKIP_GRAD
+        want = gx + to_ref(b[f"dskip{i - 1}"]) if FUSE_SKIP_GRAD else gx
+        assert rel_err(to_ref(b[f"dz{i - 1}"]), want) < 6e-3
     G = run["grads"]
     pre = f"encoder.{i}.0."
     assert rel_err(G[pre + "real_conv.weight"], gwr) < 5e-3 and rel_err(G[pre + "imag_conv.weight"], gwi) < 5e-3
@@ -126,7 +129,10 @@ def test_complex_batchnorm_prelu_forward_backward(run, name):
     sl = slice(None) if enc else slice(1, None)  # the dropped decoder frame is never written
     assert rel_err(zh[..., sl], z.detach()[..., sl]) < 4e-3
     if enc:
-        dz = to_ref(b["dz5l"] if idx == "5" else b[f"dz{idx}"]) + to_ref(b[f"dskip{idx}"])
+        from sehip.plan import FUSE_SKIP_GRAD
+        dz = to_ref(b["dz5l"] if idx == "5" else b[f"dz{idx}"])
+        if idx == "5" or not FUSE_SKIP_GRAD:      # for encoder 0..4 the skip gradient is already inside dz
+            dz = dz + to_ref(b[f"dskip{idx}"])
         dyh = to_ref(b[f"dye{idx}"])
     else:
         dz = b[f"dzd{idx}"].t.float().cpu().permute(0, 3, 2, 1).clone()
