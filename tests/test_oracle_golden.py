@@ -136,3 +136,37 @@ def test_stft_custom_oracle_matches_reference():
         assert np.abs(y - ref).max() < 1e-6 * np.abs(ref).max()
         rt = S.istft_custom(g[name + ".stft"], length, n_fft, hop, win)
         assert np.abs(rt - g[name + ".roundtrip"]).max() < 1e-6
+
+
+# ---- complex DCUNet: oracle/dcunet_oracle.py vs the reference's activations / gradients
+def test_dcunet_oracle_matches_reference():
+    import os
+    from oracle import dcunet_oracle as D
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dcunet_tiny.npz"))
+    p = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    n_lin = sum(k.startswith("linear.") for k in p)
+    assert int(g["n_state_dict_keys"]) == 2 * (len(p) - n_lin) + n_lin    # every block is registered twice in the reference
+    x, tgt = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
+    # eval mode: running statistics
+    out_eval = D.dcunet_forward(p, x, model_complexity=8, model_depth=10, training=False)
+    assert rel_err(out_eval, torch.from_numpy(g["eval_out"])) < 2e-5
+    # train mode: activations, output, loss, gradients, running-stat updates
+    names = [k for k in p if D.is_trainable(k)]
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    taps, stats = {}, {}
+    est = D.dcunet_forward(work, x, model_complexity=8, model_depth=10, training=True, stats_out=stats, taps=taps)
+    for k in taps:
+        assert rel_err(taps[k].detach(), torch.from_numpy(g["tap." + k])) < 2e-5, k
+    assert rel_err(est.detach(), torch.from_numpy(g["train_out"])) < 2e-5
+    loss = torch.nn.functional.mse_loss(est, tgt)
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    assert len(names) == 84
+    for k, gr in zip(names, grads):
+        ref = torch.from_numpy(g["grad." + k])
+        # (a conv bias in front of a BatchNorm has an analytically zero gradient: ~1e-9 of rounding noise on both sides)
+        assert float((gr - ref).norm()) <= 2e-4 * float(ref.norm()) + 1e-7, k
+    for k, v in stats.items():
+        assert rel_err(v, torch.from_numpy(g["stat." + k])) < 1e-5, k
+    assert len(stats) == 40
