@@ -83,3 +83,13 @@ def allreduce_gradients(flat_grads):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
         flat_grads.mul_(1.0 / dist.get_world_size())
     return flat_grads
+
+
+def allreduce_mean_scalar(value):
+    """Mean of a host scalar over the ranks (the epoch score that drives _is_best / early stopping in Solver.train)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / dist.get_world_size()

@@ -7,6 +7,9 @@ the persistent stft/istft buffers), so checkpoints of the reference load here an
   * forward/backward run the hand-written HIP kernels through the C ABI; there is no PyTorch/CPU fallback:
     calling forward on a CPU tensor raises SehipError.
 """
+import os
+from collections import OrderedDict
+
 import numpy as np
 import torch
 from torch import nn
@@ -36,10 +39,16 @@ class _DCCRNFunction(torch.autograd.Function):
     def forward(ctx, model, wav, anchor):
         ctx.model = model
         ctx.ws = model._run_forward(wav)
+        ctx.generation = ctx.ws.generation
         return ctx.ws.wav.view(wav.shape[0], 1, -1).clone()
 
     @staticmethod
     def backward(ctx, grad_out):
+        # the activations live in the workspace shared by every call of this (batch, samples) shape, not in autograd's
+        # saved tensors: a second forward of the same shape before this backward has overwritten them
+        if ctx.generation != ctx.ws.generation or ctx.ws.closed:
+            raise SehipError("DCCRN.backward: the workspace of this forward was overwritten by a later forward of the same "
+                             "shape (or evicted); run backward before the next forward of that shape")
         ctx.model._run_backward(ctx.ws, grad_out)
         return None, None, None
 
@@ -62,7 +71,9 @@ class DCCRN(nn.Module):
         self._bflat = torch.zeros(max(L.n_buffers, 1))
         self._nbt = torch.zeros(len(L.nbt_names), dtype=torch.int64)
         self._tables = None
-        self._ws = {}
+        self._ws = OrderedDict()      # LRU over (batch, samples): ragged validation clips must not grow memory unboundedly
+        self._ws_cap = max(1, int(os.environ.get("SEHIP_WS_CACHE", "4")))
+        self.storage_epoch = 0        # bumped whenever the flat buffers are re-created (captured hipGraphs go stale)
         self._anchor = None
         self._grads_live = False
 
@@ -160,7 +171,10 @@ class DCCRN(nn.Module):
             nbt[i] = getattr(node, leaf).to(torch.int64)
             node._buffers[leaf] = nbt[i]
         self._flat, self._bflat, self._nbt = flat, bflat, nbt
-        self._gflat, self._tables, self._ws, self._anchor, self._grads_live = None, None, {}, None, False
+        for ws in self._ws.values():
+            ws.close()
+        self._gflat, self._tables, self._ws, self._anchor, self._grads_live = None, None, OrderedDict(), None, False
+        self.storage_epoch += 1
         return self
 
     @property
@@ -190,12 +204,22 @@ class DCCRN(nn.Module):
         if self._tables is None:
             self._tables = plan.DeviceTables(self.static, dev)
         key = (batch, nsample)
-        if key not in self._ws:
-            self._ws[key] = plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev)
-        return self._ws[key]
+        ws = self._ws.get(key)
+        if ws is None:
+            # evict the least recently used shapes first (never one a captured hipGraph points into)
+            while len(self._ws) >= self._ws_cap:
+                victim = next((k for k, w in self._ws.items() if not w.pinned), None)
+                if victim is None:
+                    break
+                self._ws.pop(victim).close()
+            ws = self._ws[key] = plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev)
+        else:
+            self._ws.move_to_end(key)
+        return ws
 
     def _run_forward(self, wav):
         ws = self.workspace(wav.shape[0], wav.shape[-1])
+        ws.generation += 1
         x = wav.reshape(wav.shape[0], wav.shape[-1]).contiguous().float()
         ws.forward(x, self._flat, self._bflat, self._nbt, training=self.training)
         return ws

@@ -124,7 +124,8 @@ class FlatOptimizer(torch.optim.Optimizer):
                 self._v[sl].copy_(st["exp_avg_sq"].reshape(-1))
             elif "momentum_buffer" in st and st["momentum_buffer"] is not None:
                 self._m[sl].copy_(st["momentum_buffer"].reshape(-1))
-            self._step = int(float(st["step"]))
+            if "step" in st:   # torch.optim.SGD keeps only momentum_buffer
+                self._step = int(float(st["step"]))
         self._step_dev.fill_(int(self._step))
         for g, saved in zip(self.param_groups, state_dict["param_groups"]):
             for k in ("lr", "betas", "eps", "momentum", "weight_decay"):

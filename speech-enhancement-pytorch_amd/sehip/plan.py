@@ -603,6 +603,9 @@ class DCCRNWorkspace:
     def __init__(self, st: DCCRNStatic, tables: DeviceTables, B, N, device):
         cfg = st.cfg
         self.st, self.tb, self.B, self.N, self.device = st, tables, B, N, device
+        self.generation = 0     # bumped by every forward (a backward checks that its activations are still the live ones)
+        self.pinned = False     # a captured hipGraph holds raw pointers into this workspace: never evict
+        self.closed = False
         self.T = T = ops.stft_frames(N, cfg.win_len, cfg.win_inc)
         if T < 1:
             raise SehipError(f"input of {N} samples is shorter than one frame")
@@ -689,6 +692,22 @@ class DCCRNWorkspace:
             self.lstm_gemm_stream = torch.cuda.Stream(device=device, priority=hi)
         self.lstm_state = {layer: torch.zeros(4 * ((B + 15) // 16) * 2048, dtype=torch.float32, device=device) for layer in (1, 2)}
         self._bind()
+
+    def close(self):
+        """Destroys the HIP events of this workspace (the tensors go with the Python object)."""
+        if self.closed:
+            return
+        self.closed = True
+        lib = _lib.lib()
+        for e in self._events:
+            lib.sehip_event_destroy(e)
+        self._events = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- descriptors ---------------------------------------------------------------------------
     def _bind(self):

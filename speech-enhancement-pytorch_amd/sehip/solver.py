@@ -155,6 +155,9 @@ class Solver(object):
             torch.save(state_dict, (self.checkpoints_dir / "best_model.tar").as_posix())
 
     def _is_best(self, score, find_max=True):
+        """Same rule as src/solver.py:343-353.  With several ranks `score` is the mean over ranks (train() reduces it
+        first), so every rank takes the same branch, keeps the same best_score / early-stopping counter and leaves the
+        epoch loop together -- a rank-local decision would strand the others in the next gradient all-reduce."""
         if find_max and score >= self.score["best_score"]:
             self.score["best_score"] = score
             return True
@@ -174,6 +177,7 @@ class Solver(object):
                 self._save_checkpoint(epoch)
             if epoch % self.validation_interval == 0:
                 score = self._run_one_epoch(epoch, self.epochs, train=False)
+                score = distrib.allreduce_mean_scalar(score)   # one decision for all ranks (see _is_best)
                 if self._is_best(score, find_max=self.find_max):
                     self._save_checkpoint(epoch, is_best=True)
                     early_stopping = 0
@@ -230,6 +234,8 @@ class Solver(object):
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         g = self._graphs.get(key)
+        if g is not None and g["epoch"] != self.model.storage_epoch:
+            g = None   # the model's flat buffers were re-created (.to() / _apply): the captured pointers are stale
         if g is None:
             g = self._graphs[key] = self._capture_step(mixture, sources)
         g["mix"].copy_(mixture)
@@ -246,7 +252,7 @@ class Solver(object):
             raise SehipError("train_step_graphed needs the fused FlatOptimizer")
         call("sehip_init")
         self.model.train()
-        self.model.workspace(mixture.shape[0], mixture.shape[-1])  # all buffers exist before capture
+        self.model.workspace(mixture.shape[0], mixture.shape[-1]).pinned = True  # all buffers exist before capture and stay
         self.optimizer._ensure_state()
         self.model.flat_grads
         if self.model._anchor is None or self.model._anchor.device != mixture.device:
@@ -267,7 +273,7 @@ class Solver(object):
             metric_out = self.optimizer.grad_metric().clone()
         # capture executed nothing: undo the host-side step increment made while recording
         self.optimizer._step -= 1
-        return dict(fb=fb, upd=upd, mix=mix, src=src, loss=loss_out, metric=metric_out)
+        return dict(fb=fb, upd=upd, mix=mix, src=src, loss=loss_out, metric=metric_out, epoch=self.model.storage_epoch)
 
     def _run_one_epoch(self, epoch, total_epoch, train=False):
         cfg = self.config
@@ -304,8 +310,9 @@ class Solver(object):
             if train:
                 step_fn = self.train_step_graphed if _cfg(cfg.solver, "use_graph", False) else self.train_step
                 loss_t, metric_t = step_fn(mixture, sources)
-                # (loss / metric live in per-step tensors: no copy needed before the deferred read-back)
-                pending.append((step, loss_t, metric_t.clone() if metric_t is not None else None))
+                # the graphed step returns its STATIC output tensors (overwritten by the next replay) and the fused
+                # optimizer's metric scratch is reused too: deferred read-backs need their own copies
+                pending.append((step, loss_t.clone(), metric_t.clone() if metric_t is not None else None))
             else:
                 self.model.eval()
                 with torch.no_grad():

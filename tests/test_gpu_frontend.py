@@ -126,6 +126,33 @@ def test_clip_adam_matches_oracle(dev):
         assert max_abs(p.cpu(), ref_p) < 2e-6
 
 
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_clip_sgd_matches_torch(dev, momentum):
+    """optim.hip mode 1 against torch.optim.SGD (what src/distrib.py:246-250 builds), with and without momentum, with the
+    reference's clip-then-step order (src/solver.py:487-492)."""
+    from sehip._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(13)
+    n = 40007
+    p_ref = torch.nn.Parameter(torch.randn(n, generator=g))
+    opt = torch.optim.SGD([p_ref], lr=0.05, momentum=momentum)
+    p = p_ref.detach().clone().to(dev)
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+    for step in range(1, 5):
+        grads = torch.randn(n, generator=g) * (1.0 if step == 2 else 0.01)
+        p_ref.grad = grads.clone()
+        torch.nn.utils.clip_grad_norm_([p_ref], 5.0)
+        opt.step()
+        gdev = grads.to(dev)
+        call("sehip_grad_sumsq", ptr(gdev), n, ptr(sumsq), stream())
+        call("sehip_opt_step", ptr(p), ptr(gdev), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 0.05, momentum, 0.0, 1e-8, step, None,
+             0.0, 1, stream())
+        assert max_abs(gdev.cpu(), p_ref.grad) < 1e-6          # the clipped gradient is written back like p.grad
+        assert max_abs(p.cpu(), p_ref.detach()) < 2e-6, step
+    if momentum:
+        assert max_abs(m.cpu(), opt.state[p_ref]["momentum_buffer"]) < 2e-6
+
+
 @pytest.mark.parametrize("name", ["l1", "mse"])
 def test_l1_mse_losses(dev, name):
     from sehip import distrib, utils

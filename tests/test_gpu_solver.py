@@ -153,3 +153,55 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
     assert out["final_loss"] == out["final_loss"]  # not NaN
+
+
+def test_deferred_logging_under_graph_replay(tmp_path):
+    """use_graph + log_interval 2: every deferred Train/Loss_step entry is its own step's loss (the graphed step returns
+    static output tensors that the next replay overwrites), i.e. the same sequence an eager, per-step-logged run gives."""
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    batches = []
+    for s in range(4):
+        noisy, clean = make_batch(400 + s, 2, 4000)
+        batches.append((noisy, clean, [None], [None], ["x"], [s]))
+    logged = []
+    for use_graph, interval in ((False, 1), (True, 2)):
+        cfg = solver_config(tmp_path)
+        cfg.solver.use_graph, cfg.solver.log_interval = use_graph, interval
+        cfg.solver.save_checkpoint_interval = 1000
+        torch.manual_seed(cfg.seed)
+        model = distrib.get_model(cfg.model)
+        opt = distrib.get_optimizer(cfg.optim, model)
+        log = ScalarLog()
+        solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), train_dataloader=batches,
+                        validation_dataloader=[batches[0]], device="gpu", writer=log)
+        solver._run_one_epoch(0, 1, train=True)
+        logged.append(([v for (t, v, _s) in log.scalars if t == "Train/Loss_step"], solver.score["loss"]))
+    (eager, mean_e), (graph, mean_g) = logged
+    assert len(eager) == len(graph) == 4
+    assert len(set(round(v, 4) for v in graph)) == 4, graph            # four different batches -> four different losses
+    for a, b in zip(eager, graph):
+        assert abs(a - b) < 0.05, (eager, graph)
+    assert abs(mean_e - mean_g) < 0.05
+
+
+def test_workspace_generation_and_lru():
+    from sehip.model import DCCRN
+    from sehip import SehipError
+    from sehip.loss import loss_sisdr
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    model = DCCRN(**KW).to(dev).train()
+    noisy, clean = make_batch(7, 2, 4000)
+    a = model(noisy.to(dev))
+    b = model(0.5 * noisy.to(dev))        # same shape: overwrites the activations `a` would need
+    with pytest.raises(SehipError):
+        loss_sisdr(a, clean[:, 0].to(dev)).backward()
+    loss_sisdr(b, clean[:, 0].to(dev)).backward()    # the live one is fine
+    assert float(model.flat_grads.norm()) > 0
+    # ragged validation lengths do not grow the cache without bound
+    model.eval()
+    with torch.no_grad():
+        for n in (3000, 3100, 3200, 3300, 3400, 3500):
+            model(torch.zeros(1, 1, n, device=dev))
+    assert len(model._ws) <= model._ws_cap
