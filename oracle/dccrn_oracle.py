@@ -421,6 +421,20 @@ def init_params(cfg: DCCRNConfig, seed=0) -> "OrderedDict[str, torch.Tensor]":
     return p
 
 
+def perturb_params(p, seed=5):
+    """Non-trivial biases / BatchNorm affine terms / PReLU slopes (the constructors' zeros and ones would hide sign and
+    indexing errors).  Deterministic in `seed`: the golden generator and the tests rebuild the same weights from it."""
+    g = torch.Generator().manual_seed(seed)
+    for k in p:
+        if k.endswith(".bias") or k.endswith((".Br", ".Bi")):
+            p[k] = 0.1 * torch.randn(p[k].shape, generator=g)
+        if k.endswith((".Wrr", ".Wii")):
+            p[k] = 1.0 + 0.2 * torch.randn(p[k].shape, generator=g)
+        if k.endswith("2.weight"):
+            p[k] = 0.25 + 0.1 * torch.randn(p[k].shape, generator=g)
+    return p
+
+
 BUFFER_SUFFIXES = ("RMr", "RMi", "RVrr", "RVri", "RVii", "num_batches_tracked")
 
 

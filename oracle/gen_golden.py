@@ -13,6 +13,13 @@ Fixtures
   dccrn_tiny_solver.npz  : the real ``Solver.train()`` (src/solver.py:355-532) for 1 epoch x 2
                            steps on synthetic batches with non-numeric deps stubbed: logged
                            Train/Loss_step, Train/grad_norm_step, final state_dict, Adam state.
+  dccrn_legal_fwd_bwd.npz: a configuration the HIP path accepts (kernel_num [16,16,32,32,64,64], rnn_units 128,
+                           N=4000, B=2) so that one GPU test compares HIP with reference vectors DIRECTLY.  Weights are
+                           rebuilt from a seed (oracle.init_params + perturb_params) and loaded into the reference
+                           model, so only outputs are stored: waveform, loss, eval-mode waveform, running statistics,
+                           every parameter gradient (float16 x per-tensor scale).
+  dccrn_c1_checksum.npz  : the FULL-SIZE C1 model (kernel_num [16,32,64,128,256,256], N=32000, B=2), same recipe:
+                           loss, waveform (float16) + its exact L2 norm, per-tensor gradient norms, small gradients.
   stft_bases_rows.npz    : sampled rows of stft.weight / istft.weight (pins init_kernels).
   sisnr_cases.npz        : si_snr on a few shapes incl. zero target.
 """
@@ -115,6 +122,71 @@ def fwd_bwd_fixture():
                         stft=w["stft.weight"][rows, 0].numpy(),
                         istft=w["istft.weight"][rows, 0].numpy(),
                         window=w["istft.window"][0, :, 0].numpy())
+
+
+def _reference_from_seed(kw, seed, perturb_seed):
+    """Reference DCCRN carrying the weights oracle.init_params(seed) + perturb_params(perturb_seed) produce."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import dccrn_oracle as O
+    from src.model.dccrn import DCCRN
+    p = O.perturb_params(O.init_params(O.DCCRNConfig(**kw), seed=seed), perturb_seed)
+    model = DCCRN(**kw)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and all(k.startswith(("stft.", "istft.")) for k in missing), (missing, unexpected)
+    return model
+
+
+def _pack_grads(model, out, full_below):
+    """float16 x per-tensor scale for every gradient with fewer than `full_below` elements; norms for all."""
+    names, norms = [], []
+    for k, prm in model.named_parameters():
+        g = prm.grad.detach()
+        names.append(k); norms.append(float(g.double().norm()))
+        if g.numel() < full_below:
+            scale = float(g.abs().max()) or 1.0
+            out["grad16/" + k] = (g / scale).numpy().astype(np.float16)
+            out["gscale/" + k] = np.float32(scale)
+    out["grad_norms"] = np.asarray(norms, dtype=np.float64)
+    out["grad_names_json"] = np.frombuffer(json.dumps(names).encode(), dtype=np.uint8)
+
+
+LEGAL = dict(rnn_units=128, kernel_num=[16, 16, 32, 32, 64, 64], length=4000)
+C1 = dict(rnn_units=128, kernel_num=[16, 32, 64, 128, 256, 256], length=32000)
+
+
+def legal_fixture():
+    from src.loss import loss_sisdr
+    model = _reference_from_seed(LEGAL, seed=21, perturb_seed=22)
+    noisy, clean = make_batch(23, 2, 4000)
+    model.train()
+    est = model(noisy)
+    loss = loss_sisdr(est, clean[:, 0])
+    loss.backward()
+    out = {"est": est.detach().numpy(), "loss": np.float32(loss.item())}
+    for k, v in model.state_dict().items():
+        if k.endswith(("RMr", "RMi", "RVrr", "RVri", "RVii", "num_batches_tracked")):
+            out["state_after/" + k] = v.numpy()
+    _pack_grads(model, out, full_below=1 << 30)
+    model.eval()
+    with torch.no_grad():
+        out["est_eval"] = model(noisy).numpy()
+    np.savez_compressed(os.path.join(OUT, "dccrn_legal_fwd_bwd.npz"), **out)
+    print("legal: loss", loss.item())
+
+
+def c1_fixture():
+    from src.loss import loss_sisdr
+    model = _reference_from_seed(C1, seed=10, perturb_seed=11)
+    noisy, clean = make_batch(0, 2, 32000)
+    model.train()
+    est = model(noisy)
+    loss = loss_sisdr(est, clean[:, 0])
+    loss.backward()
+    e = est.detach()
+    out = {"est16": e.numpy().astype(np.float16), "est_l2": np.float64(e.double().norm()), "loss": np.float32(loss.item())}
+    _pack_grads(model, out, full_below=4096)
+    np.savez_compressed(os.path.join(OUT, "dccrn_c1_checksum.npz"), **out)
+    print("c1: loss", loss.item(), "est L2", float(e.double().norm()))
 
 
 def install_stubs():
@@ -242,6 +314,10 @@ def sisnr_fixture():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
-    fwd_bwd_fixture()
-    sisnr_fixture()
-    solver_fixture()
+    if "--new" not in sys.argv:   # the round-1 fixtures (unchanged files: regenerate only on purpose)
+        fwd_bwd_fixture()
+        sisnr_fixture()
+    legal_fixture()
+    c1_fixture()
+    if "--new" not in sys.argv:
+        solver_fixture()

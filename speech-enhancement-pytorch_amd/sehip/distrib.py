@@ -11,10 +11,11 @@ import torch.distributed as dist
 from ._lib import SehipError
 from .loss import loss_sisdr, l1_loss, mse_loss
 from .model.dccrn import DCCRN
+from .model.dnn import DeepNeuralNetwork
 from .optim import FlatOptimizer
 from .utils import obj2dict
 
-MODEL_REGISTRY = {"dccrn": DCCRN}
+MODEL_REGISTRY = {"dccrn": DCCRN, "dnn": DeepNeuralNetwork}
 _REFERENCE_NAMES = ("dnn", "mel-rnn", "unet", "dccrn", "dcunet", "demucs", "wav-unet", "conv-tasnet", "crn", "rnn-stft-mask")
 
 
@@ -28,6 +29,12 @@ def get_model(config):
 
 
 def get_optimizer(config, model):
+    if not hasattr(model, "flat_params"):   # stock-PyTorch model (C0 plumbing config): what src/distrib.py:244-261 builds
+        if config.optim == "sgd":
+            return torch.optim.SGD(params=model.parameters(), lr=config.lr, momentum=config.momentum)
+        if config.optim == "adam":
+            return torch.optim.Adam(params=model.parameters(), lr=config.lr, betas=(config.beta1, config.beta2))
+        raise ValueError(f"Optimizer {config.optim} cannot use...")
     if config.optim == "sgd":
         return FlatOptimizer(model, lr=config.lr, kind="sgd", momentum=config.momentum)
     if config.optim == "adam":
@@ -35,7 +42,12 @@ def get_optimizer(config, model):
     raise ValueError(f"Optimizer {config.optim} cannot use...")
 
 
-def get_loss_function(config):
+def get_loss_function(config, device="gpu"):
+    if str(device) == "cpu":   # the explicit CPU plumbing configuration (sehip/plumbing.py), never a fallback
+        from . import plumbing
+        if config.loss in plumbing.LOSSES:
+            return plumbing.LOSSES[config.loss]
+        raise SehipError(f"loss '{config.loss}' is not part of the CPU plumbing configuration")
     if config.loss == "l1":  # mae
         return l1_loss
     if config.loss == "mse":
@@ -73,6 +85,17 @@ def broadcast_parameters(flat_params, flat_buffers=None, src=0):
         dist.broadcast(flat_params, src)
         if flat_buffers is not None:
             dist.broadcast(flat_buffers, src)
+
+
+def allreduce_module_gradients(model):
+    """Models without a flat gradient buffer (stock-PyTorch plumbing models): one coalesced all-reduce of their .grad tensors."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
+        for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(f)
 
 
 def allreduce_gradients(flat_grads):

@@ -1,2 +1,3 @@
 from .dccrn import DCCRN  # noqa: F401
 from . import types  # noqa: F401
+from .dnn import DeepNeuralNetwork  # noqa: F401

@@ -21,9 +21,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import distrib
+from . import distrib, plumbing
 from ._lib import SehipError
 from .model.types import MONARCH_SPEECH_SEPARTAION_MODELS, MULTI_SPEECH_SEPERATION_MODELS, STFT_MODELS
+from .evaluate import stft_custom
 from .optim import FlatOptimizer
 from .utils import obj2dict
 
@@ -73,13 +74,21 @@ class Solver(object):
             torch.cuda.set_device(self.device)
         else:
             self.device = torch.device(device) if not isinstance(device, torch.device) else device
+            if self.device.type == "cpu" and config.model.name not in plumbing.TORCH_MODELS:
+                raise SehipError(f"Solver(device='cpu'): model '{config.model.name}' runs on the HIP path only; the CPU "
+                                 f"plumbing configuration exists for {plumbing.TORCH_MODELS} (BASELINE config C0)")
         self.is_main = self.rank == 0
 
         self.optimizer = optimizer
         self.loss_function = loss_function
         self.model = model.to(self.device)
+        self.flat_model = hasattr(self.model, "flat_params")
         if self.world_size > 1:
-            distrib.broadcast_parameters(self.model.flat_params, self.model._bflat)
+            if self.flat_model:
+                distrib.broadcast_parameters(self.model.flat_params, self.model._bflat)
+            else:
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    dist.broadcast(t.data, 0)
 
         self.epochs = config.solver.epochs
         self.save_checkpoint_interval = config.solver.save_checkpoint_interval
@@ -202,7 +211,11 @@ class Solver(object):
             mixture = torch.reshape(mixture, shape=(batch * nchannel, 1, nsample))
             sources = torch.reshape(sources, shape=(batch * num_spk * nchannel, 1, nsample))
         if cfg.model.name in STFT_MODELS:
-            raise SehipError(f"STFT-domain model '{cfg.model.name}' has no HIP path yet")
+            # src/solver.py:454-458: mixture and sources go to the STFT domain [B, C, F, T, 2] and the loss is taken there.
+            # HIP kernels on the GPU; torch.stft only in the explicit CPU plumbing configuration (sehip/plumbing.py)
+            stft = plumbing.stft_custom if mixture.device.type == "cpu" else stft_custom
+            mixture = stft(tensor=mixture, config=cfg.model)
+            sources = stft(tensor=sources, config=cfg.model)
         return mixture, sources
 
     def train_step(self, mixture, sources):
@@ -214,7 +227,10 @@ class Solver(object):
         self.optimizer.zero_grad()
         loss.backward()
         if self.world_size > 1:
-            distrib.allreduce_gradients(self.model.flat_grads)
+            if self.flat_model:
+                distrib.allreduce_gradients(self.model.flat_grads)
+            else:
+                distrib.allreduce_module_gradients(self.model)
         fused = isinstance(self.optimizer, FlatOptimizer)
         if self.config.optim.clip_grad:
             if fused:
@@ -222,7 +238,11 @@ class Solver(object):
             else:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.config.optim.clip_grad)
         self.optimizer.step()
-        metric = self.optimizer.grad_metric() if fused else None
+        if fused:
+            metric = self.optimizer.grad_metric()
+        else:   # the reference's sum-based metric (src/solver.py:494-498), kept on the device
+            sums = torch.stack([p.grad.sum() for p in self.model.parameters() if p.grad is not None])
+            metric = torch.stack([sums.square().sum().sqrt(), sums.new_zeros(())])
         return loss.detach(), metric
 
     # ---- hipGraph replay of the step (config.solver.use_graph) ------------------------------------------

@@ -19,7 +19,7 @@ def main(obj_config, return_solver=False, mode="train", device="gpu", train_data
     random.seed(config.seed)
     model = get_model(config.model)
     optimizer = get_optimizer(config.optim, model)
-    loss_function = get_loss_function(config.optim)
+    loss_function = get_loss_function(config.optim, device=device)
     solver = Solver(config=config, model=model, optimizer=optimizer, loss_function=loss_function,
                     train_dataloader=train_dataloader, validation_dataloader=validation_dataloader,
                     test_dataloader=test_dataloader, device=device, writer=writer)

@@ -1,0 +1,177 @@
+"""GPU parity at the HEADLINE configuration (BASELINE.json configs[1]): DCCRN(length=32000, kernel_num=[16,32,64,128,256,256]),
+32000-sample clips -- the shapes bench.py times (conv_gemm_kernel<128,2,2,5> at K=2560/5120 with 256/512-channel sources,
+conv_wgrad_kernel<5> with m-splits, the LSTM at input 512 and T=323 with its 3-chunk two-stream pipeline, the BatchNorm
+kernels at 21 M elements).
+
+  (a) B=4: every operator re-computed by the oracle FROM THE HIP PATH'S OWN INPUTS (the op-local tests of
+      test_gpu_ops_local.py, same tolerances: one bf16 rounding of the output) + the stage-by-stage forward chain.
+  (b) B=32: one full Solver.train_step against the fp32 oracle on identical weights and batch: |d loss|, waveform error,
+      gradient error, weights after the Adam step.
+  (c) HIP against vectors produced by the imported REFERENCE directly (tests/golden/dccrn_legal_fwd_bwd.npz: a HIP-legal
+      small model; dccrn_c1_checksum.npz: the full-size model at B=2)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccrn_oracle as O
+from util import rel_err, max_abs, load_golden, sub, golden_grads, make_batch
+import test_gpu_ops_local as L
+from test_gpu_ops_local import (test_encoder_conv_forward_dgrad_wgrad, test_decoder_deconv_forward_dgrad_wgrad,  # noqa: F401
+                                test_complex_batchnorm_prelu_forward_backward, test_complex_lstm_forward_backward)
+
+pytestmark = pytest.mark.gpu
+C1 = dict(kernel_num=[16, 32, 64, 128, 256, 256], rnn_units=128, length=32000)
+LEGAL = dict(rnn_units=128, kernel_num=[16, 16, 32, 32, 64, 64], length=4000)
+
+
+@pytest.fixture(scope="module")
+def run():
+    """(a): the fixture the imported op-local tests resolve -- full-size model, B=4, 32000 samples (T = 323 frames)."""
+    r = L.build_run(C1, 4, 32000, seed=14)
+    assert r["T"] == 323 and len(r["ws"].lstm_chunks) == 3          # the 3-chunk LSTM pipeline is what ran
+    return r
+
+
+def test_forward_chain_stages_full_size(run):
+    """Stage-by-stage forward of the full-size model against the bf16-storage simulation of the oracle."""
+    ws, p, cfg = run["ws"], run["p"], run["cfg"]
+    noisy = run["noisy"]      # the fixture's own input: the forward below re-creates exactly the activations it left
+    q = {k: v.clone() for k, v in p.items()}
+    cap = {}
+    est = O.dccrn_forward(q, noisy, cfg, training=True, capture=cap, sim=O.Bf16Sim)
+    model = run["model"]
+    out = model(noisy.cuda()).detach().cpu()
+    b = ws.bufs
+    cl = lambda x: x.permute(0, 3, 2, 1)
+    errs = {}
+    for i in range(6):
+        errs[f"enc{i}"] = rel_err(b[f"z{i}"].t.float().cpu(), cl(cap[f"enc{i}"]))
+    for j in range(5):
+        errs[f"dec{j}"] = rel_err(b[f"zd{j}"].t.float().cpu()[:, 1:], cl(cap[f"dec{j}"]))
+    errs["mask"] = rel_err(b["mask"].t.cpu(), cl(cap["dec5"]))
+    errs["wav"] = rel_err(out, est)
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < 1.5e-2 for v in errs.values()), errs
+
+
+def _flat_to_named(model, flat):
+    Lh = model.static.layout
+    out = {}
+    for name in Lh.param_names:
+        off, shape = Lh.param_off[name]
+        out[name] = flat[off:off + int(np.prod(shape))].reshape(shape)
+    return out
+
+
+def test_b32_train_step_vs_fp32_oracle(tmp_path):
+    """(b) the exact step bench.py times: B=32, 2-s clips, SI-SNR, clip 5, Adam 3e-4 -- against the fp32 oracle."""
+    import importlib.util, os
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    cfg = bench.bench_config(32000)
+    cfg.solver.root = str(tmp_path)
+    torch.manual_seed(cfg.seed)
+    model = distrib.get_model(cfg.model)
+    opt = distrib.get_optimizer(cfg.optim, model)
+    solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+    p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if not k.startswith(("stft.", "istft."))}
+    noisy, clean = bench.make_batch(32, 32000, 0, "cpu")
+    mix, src = solver._prepare_batch(noisy, clean)
+    model.train()
+    with torch.no_grad():
+        est0 = model(mix).cpu()                                    # also advances the running statistics once ...
+    model.load_state_dict({**model.state_dict(), **{k: v for k, v in p.items()}})   # ... undo
+    loss_t, metric_t = solver.train_step(mix, src)
+    torch.cuda.synchronize()
+    g_hip = _flat_to_named(model, model.flat_grads.cpu())          # clipped gradients, like p.grad after the reference's step
+    w_hip = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    cfg_o = O.DCCRNConfig(**C1)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref_est = O.dccrn_forward(p, noisy, cfg_o, training=True)
+    adam = O.AdamState({k: v for k, v in p.items() if O.is_trainable(k)}, lr=3e-4)
+    loss_ref, metric_ref, g_ref = O.train_step(p, noisy, clean[:, 0], cfg_o, adam, clip_grad=5.0)
+
+    wav_rel = rel_err(est0, ref_est)
+    wav_abs = max_abs(est0, ref_est)
+    dloss = abs(float(loss_t) - loss_ref)
+    num = sum(float(((g_hip[k].double() - g.double()) ** 2).sum()) for k, g in g_ref.items())
+    den = sum(float((g.double() ** 2).sum()) for g in g_ref.values())
+    grad_rel = (num / den) ** 0.5
+    lr = 3e-4
+    names = [k for k in p if O.is_trainable(k)]
+    wdiff = torch.cat([(w_hip[k] - p[k]).reshape(-1) for k in names]).abs()
+    print(f"B=32 full size: loss hip {float(loss_t):.4f} oracle {loss_ref:.4f} | waveform rel {wav_rel:.3e} max-abs {wav_abs:.3e} | "
+          f"global grad rel {grad_rel:.3e} | grad_norm metric hip {float(metric_t[0]):.3f} oracle {metric_ref:.3f} | "
+          f"weights after Adam: max |dw| {float(wdiff.max()):.2e} mean |dw|/lr {float(wdiff.mean()) / lr:.3f}")
+    assert dloss < 0.1                      # dB; bf16 activation storage vs fp32
+    assert wav_rel < 3e-2
+    assert grad_rel < 0.2
+    # the first Adam step moves every weight by ~lr * sign(g): agreement = the same sign almost everywhere
+    assert float(wdiff.max()) <= 2.05 * lr and float(wdiff.mean()) < 0.25 * lr
+    for k in p:
+        if k.endswith(("RVrr", "RVii")):
+            assert rel_err(w_hip[k], p[k]) < 2e-2, k
+
+
+def _hip_model_from_seed(kw, seed, pseed):
+    from sehip.model import DCCRN
+    p = O.perturb_params(O.init_params(O.DCCRNConfig(**kw), seed=seed), pseed)
+    model = DCCRN(**kw)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and all(k.startswith(("stft.", "istft.")) for k in missing)
+    return model.cuda().train()
+
+
+def _fwd_bwd(model, noisy, clean):
+    from sehip.loss import loss_sisdr
+    est = model(noisy.cuda())
+    loss = loss_sisdr(est, clean[:, 0].cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return est.detach().cpu(), float(loss.detach()), {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters()}
+
+
+def test_hip_vs_reference_vectors_legal_config():
+    """(c) no oracle in between: the HIP path against what the imported reference produced for the same weights / inputs."""
+    g = load_golden("dccrn_legal_fwd_bwd.npz")
+    model = _hip_model_from_seed(LEGAL, 21, 22)
+    noisy, clean = make_batch(23, 2, 4000)
+    est, loss, grads = _fwd_bwd(model, noisy, clean)
+    assert rel_err(est, g["est"]) < 3e-2 and abs(loss - float(g["loss"])) < 0.1
+    full, norms = golden_grads(g)
+    num = sum(float(((grads[k].double() - full[k].double()) ** 2).sum()) for k in full)
+    den = sum(n * n for n in norms.values())
+    print(f"HIP vs reference vectors: waveform rel {rel_err(est, g['est']):.3e} dloss {abs(loss - float(g['loss'])):.4f} "
+          f"global grad rel {(num / den) ** 0.5:.3e}")
+    assert (num / den) ** 0.5 < 0.25        # whole-chain bf16 bound (see test_gpu_dccrn_plan.py); op-local tests pin the kernels
+    sd = model.state_dict()
+    for k, v in sub(g, "state_after").items():
+        if k.endswith(("RVrr", "RVii")):
+            assert rel_err(sd[k].cpu().float(), v.float()) < 2e-2, k
+    model.eval()
+    with torch.no_grad():
+        assert rel_err(model(noisy.cuda()).cpu(), g["est_eval"]) < 3e-2
+
+
+def test_hip_vs_reference_full_size_checksum():
+    """(c) the full-size model at B=2 against the reference's stored loss / waveform / gradient norms."""
+    g = load_golden("dccrn_c1_checksum.npz")
+    model = _hip_model_from_seed(C1, 10, 11)
+    noisy, clean = make_batch(0, 2, 32000)
+    est, loss, grads = _fwd_bwd(model, noisy, clean)
+    ref = torch.from_numpy(g["est16"].astype(np.float32))
+    print(f"full-size checksum: loss hip {loss:.4f} reference {float(g['loss']):.4f} | waveform rel {rel_err(est, ref):.3e} | "
+          f"L2 hip {float(est.double().norm()):.4f} reference {float(g['est_l2']):.4f}")
+    assert abs(loss - float(g["loss"])) < 0.1
+    assert rel_err(est, ref) < 3e-2
+    assert abs(float(est.double().norm()) - float(g["est_l2"])) < 1e-2 * float(g["est_l2"])
+    full, norms = golden_grads(g)
+    gn_ref = sum(n * n for n in norms.values()) ** 0.5
+    gn_hip = sum(float((v.double() ** 2).sum()) for v in grads.values()) ** 0.5
+    assert abs(gn_hip - gn_ref) < 0.1 * gn_ref, (gn_hip, gn_ref)
+    big = [k for k in norms if norms[k] > 0.02 * gn_ref]
+    for k in big:                            # per-tensor gradient norms of everything that matters
+        assert abs(float(grads[k].double().norm()) - norms[k]) < 0.2 * norms[k], (k, float(grads[k].norm()), norms[k])

@@ -27,21 +27,22 @@ def bf(x):
     return x.to(torch.bfloat16).float()
 
 
-@pytest.fixture(scope="module")
-def run():
+def build_run(kw, B, N, seed=4):
+    """One forward/backward of DCCRN(**kw) on B clips of N samples through libsehip; returns the workspace (every stored
+    activation / activation gradient), the weights and the parameter gradients.  tests/test_gpu_c1_fullsize.py reuses
+    this and the tests below at the headline configuration."""
     from sehip.model import DCCRN
     from sehip import ops
     dev = torch.device("cuda:0")
-    torch.manual_seed(4)
-    model = DCCRN(**SMALL).to(dev).train()
-    g = torch.Generator().manual_seed(5)
+    torch.manual_seed(seed)
+    model = DCCRN(**kw).to(dev).train()
+    g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():  # non-trivial biases / affine terms
         for name, p in model.named_parameters():
             if name.endswith(".bias") or name.endswith((".Br", ".Bi")):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g))
             if name.endswith("2.weight"):
                 p.copy_(0.25 + 0.1 * torch.randn(p.shape, generator=g))
-    B, N = 3, 4000
     clean = 0.1 * torch.randn(B, 1, N, generator=g)
     noisy = clean + 0.05 * torch.randn(B, 1, N, generator=g)
     p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if not k.startswith(("stft.", "istft."))}
@@ -56,7 +57,12 @@ def run():
     for name in L.param_names:
         off, shape = L.param_off[name]
         grads[name] = gflat[off:off + int(np.prod(shape))].reshape(shape)
-    return dict(ws=ws, p=p, grads=grads, B=B, T=ws.T, cfg=O.DCCRNConfig(**SMALL), kn=[2] + SMALL["kernel_num"])
+    return dict(ws=ws, p=p, grads=grads, B=B, T=ws.T, cfg=O.DCCRNConfig(**kw), kn=[2] + list(kw["kernel_num"]), model=model, noisy=noisy, clean=clean)
+
+
+@pytest.fixture(scope="module")
+def run():
+    return build_run(SMALL, 3, 4000)
 
 
 def conv_params(p, pre):

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import dccrn_oracle as O
-from util import load_golden, sub, json_entry, rel_err, max_abs
+from util import load_golden, sub, json_entry, rel_err, max_abs, golden_grads, make_batch
 
 TINY = dict(rnn_units=16, kernel_num=[4, 4, 8, 8, 16, 16], length=4000)
 
@@ -107,6 +107,56 @@ def test_two_solver_steps():
     keys = json_entry(g, "ckpt_keys_json")
     assert keys["top"] == ["best_score", "epoch", "model", "optimizer"]
     assert len(keys["model"]) == 204
+
+
+LEGAL = dict(rnn_units=128, kernel_num=[16, 16, 32, 32, 64, 64], length=4000)
+C1 = dict(rnn_units=128, kernel_num=[16, 32, 64, 128, 256, 256], length=32000)
+
+
+def _oracle_fwd_bwd(kw, seed, pseed, bseed, b, n):
+    cfg = O.DCCRNConfig(**kw)
+    p = O.perturb_params(O.init_params(cfg, seed=seed), pseed)
+    noisy, clean = make_batch(bseed, b, n)
+    names = [k for k in p if O.is_trainable(k)]
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    stats = {}
+    est = O.dccrn_forward(work, noisy, cfg, training=True, stats_out=stats)
+    loss = O.loss_sisdr(est, clean[:, 0])
+    grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names])))
+    return cfg, p, noisy, est.detach(), float(loss.detach()), grads, stats
+
+
+def test_hip_legal_config_against_reference():
+    """A configuration the HIP path accepts (the tiny golden model is below its channel minimum): the oracle against the
+    reference's outputs for weights rebuilt from a seed.  tests/test_gpu_c1_fullsize.py compares HIP with the same file."""
+    g = load_golden("dccrn_legal_fwd_bwd.npz")
+    cfg, p, noisy, est, loss, grads, stats = _oracle_fwd_bwd(LEGAL, 21, 22, 23, 2, 4000)
+    assert rel_err(est, g["est"]) < 5e-5 and abs(loss - float(g["loss"])) < 2e-4
+    full, norms = golden_grads(g)
+    assert set(full) == set(grads)
+    for k, gr in grads.items():
+        # fp16 storage: 5e-4 of the tensor's largest element per entry; conv biases in front of a BatchNorm have an
+        # analytically zero gradient (round-off noise on both sides): absolute floor
+        tol = 5e-3 * norms[k] + 6e-4 * float(full[k].abs().max()) * gr.numel() ** 0.5 + 2e-6 * gr.numel() ** 0.5
+        assert float((gr - full[k]).norm()) < tol, (k, float((gr - full[k]).norm()), norms[k])
+    for k, v in sub(g, "state_after").items():
+        assert rel_err(stats[k].float(), v.float()) < 1e-5, k
+    q = dict(p); q.update({k: v for k, v in stats.items()})
+    assert rel_err(O.dccrn_forward(q, noisy, cfg, training=False), g["est_eval"]) < 5e-5
+
+
+def test_full_size_c1_checksum():
+    """The headline model (kernel_num 16-32-64-128-256-256, 32000 samples) at B=2: oracle vs the reference's loss, waveform
+    and gradient norms (one full-size C1 checksum)."""
+    g = load_golden("dccrn_c1_checksum.npz")
+    cfg, p, noisy, est, loss, grads, stats = _oracle_fwd_bwd(C1, 10, 11, 0, 2, 32000)
+    assert abs(loss - float(g["loss"])) < 5e-4
+    assert abs(float(est.double().norm()) - float(g["est_l2"])) < 1e-4 * float(g["est_l2"])
+    assert rel_err(est, g["est16"].astype(np.float32)) < 1e-3          # float16 storage
+    full, norms = golden_grads(g)
+    for k, gr in grads.items():
+        assert abs(float(gr.double().norm()) - norms[k]) < 3e-3 * norms[k] + 2e-5, (k, float(gr.norm()), norms[k])
 
 
 def test_param_init_shapes_match_reference_schema():

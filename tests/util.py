@@ -31,3 +31,20 @@ def rel_err(a, b):
 
 def max_abs(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+def golden_grads(g):
+    """Gradients stored by oracle/gen_golden.py:_pack_grads -> ({name: fp32 tensor} for the fully stored ones, {name: norm})."""
+    names = json_entry(g, "grad_names_json")
+    norms = dict(zip(names, [float(v) for v in g["grad_norms"]]))
+    full = {k[len("grad16/"):]: torch.from_numpy(g[k].astype(np.float32)) * float(g["gscale/" + k[len("grad16/"):]])
+            for k in g if k.startswith("grad16/")}
+    return full, norms
+
+
+def make_batch(seed, b, n):
+    """The synthetic (noisy [B,1,N], clean [B,1,1,N]) pair used by every DCCRN fixture (SURVEY section 8d recipe)."""
+    gen = torch.Generator().manual_seed(seed)
+    clean = 0.1 * torch.randn(b, 1, 1, n, generator=gen)
+    noisy = clean[:, 0] + 0.05 * torch.randn(b, 1, n, generator=gen)
+    return noisy, clean
