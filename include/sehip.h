@@ -87,7 +87,7 @@ int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, 
  *        nn.LSTM input GEMMs + Linear projections of NavieComplexLSTM  src/model/dccrn.py:264-302
  *      out[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]);  row m <-> (b, t, j): m = (b*TT + t)*J + j.
  *      A is never materialised: element (m, 8*c .. 8*c+7) is gathered through ktab[c] from up to 2 channels-last
- *      source tensors:   src[s][ ((b*T_s + t + toff) * F_s + j*fmul + fadd) * C_s + coff .. +7 ]
+ *      source tensors:   src[s][ ((b*T_s + t*tmul + toff) * F_s + j*fmul + fadd) * C_s + coff .. +7 ]
  *      (zero outside [tlo,thi) x [0,F_s)).  C_s == 2 sources use "narrow" chunks: 4 consecutive rows x 2 channels.
  *      Output columns are scattered 4 at a time through ntab into up to 2 destination tensors. */
 typedef struct {
@@ -109,9 +109,11 @@ typedef struct {
 typedef struct {
     void* ptr;
     int32_t T, F, C;      /* destination geometry [B][T][F][C] */
-    int32_t toff;         /* row (b,t,j) -> ((b*T + t + toff)*F + j*fmul + fadd)*C */
+    int32_t toff;         /* row (b,t,j) -> ((b*T + t*tmul + toff)*F + j*fmul + fadd)*C */
     int32_t fmul, fadd;
     int32_t is_f32;       /* 0: bf16, 1: fp32 */
+    int32_t tmul;         /* frame stride of the row space in this destination (0 is read as 1): 2 for the output-frame
+                             parities of a stride-2 transposed convolution (src/model/dcunet.py:341-371) */
 } sehip_dst;
 
 typedef struct {
@@ -132,7 +134,8 @@ typedef struct {
     float* dbias;             /* wgrad only: fp32 [Npad] column sums of dOut, or NULL */
     int32_t M, N, Npad, K;    /* K multiple of 64, Npad multiple of 16 */
     int32_t TT, J, fmul;
-    int32_t pad_;
+    int32_t tmul;             /* frame stride of the row space in the sources (0 is read as 1): row (b,t,j) reads source frame
+                                 t*tmul + toff -- 2 for the time-strided convolutions of DCUnet (src/model/dcunet.py:165-212) */
     /* Optional: the product is a regular convolution over (frame, row) -- K ordered (kt, tap, source, channel),
      * kt in {0,1}, taps at rows j*fmul + cv_fadd + 0..cv_nf-1, frame offsets cv_toff[source][kt].  Lets the library
      * stage each input element once per tile in LDS instead of once per tap.  cv_nf == 0: not described. */
@@ -179,6 +182,36 @@ int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wr
                            float* bcoef /*[Cr][16]*/, void* stream);
 int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
                         const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream);
+
+/* ---- DCUnet's ComplexBatchNorm2d + LeakyReLU: src/model/dcunet.py:374-386 (two independent real nn.BatchNorm2d, bn_re on the real
+ *      part and bn_im on the imaginary part; biased batch variance for the normalisation, UNBIASED one into running_var) fused
+ *      with nn.LeakyReLU() (slope 0.01) of Encoder / Decoder (:8-50).  Activations are [rows][2*Cs] bf16: Cs channels stored
+ *      per half, the first Cr of them real (31 / 62 complex channels are stored as 32 / 64); padding channels come out as
+ *      exact zeros.  w/b/rm/rv are the [Cr] parameter / buffer tensors of bn_re and bn_im, nbt their num_batches_tracked.
+ *      coef / bcoef: [2*Cs][4] fp32 scratch; part: sehip_rbn_scratch_floats() floats. */
+long sehip_rbn_scratch_floats(long rows, int Cs);
+int sehip_rbn_stats(const void* y, long rows, int Cs, int Cr, float* part, void* stream);
+int sehip_rbn_finalize(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im, float* rm_re,
+                       float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows, int Cs, int Cr, float eps,
+                       float momentum, int training, float* coef, void* stream);
+int sehip_rbn_apply(const void* y, const float* coef, long rows, int Cs, int Cr, void* z, void* stream);
+int sehip_rbn_bwd_reduce(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part, void* stream);
+int sehip_rbn_bwd_finalize(const float* part, const float* coef, long rows, int Cs, int Cr, float* gw_re, float* gb_re, float* gw_im,
+                           float* gb_im, float* bcoef, void* stream);
+int sehip_rbn_bwd_apply(const void* dz, const void* y, const float* coef, const float* bcoef, long rows, int Cs, int Cr, void* dy,
+                        void* stream);
+
+/* ---- DCUnet.forward around the convolution stack: src/model/dcunet.py:102-162.
+ *      pack_input: x.transpose(2, 3) (:106) of the STFT-domain input [R][F][T][2] fp32 -> channels-last bf16 [R][T][F][2].
+ *      mask_fwd:   linear = 1x1 ComplexConv2d (:93-95, :323-338) on the last decoder's output z [R][T][F][2*Cs] bf16, tanh (:131),
+ *                  transpose back (:132), mask E/C/R (:136-159) on `spec` -> out [R][F][T][2] fp32; mask_ws [R][T][F][2] fp32
+ *                  keeps tanh(linear) for the backward pass.  w_re / w_im: [Cr] (conv_re / conv_im weights), b_re / b_im: [1].
+ *      mask_bwd:   d out -> dz [R][T][F][2*Cs] bf16 and gacc += {d w_re [Cs], d w_im [Cs], d b_re, d b_im} (caller zeroes). */
+int sehip_dcunet_pack_input(const float* spec, int R, int F, int T, void* out_bf16, void* stream);
+int sehip_dcunet_mask_fwd(const void* z_bf16, const float* w_re, const float* w_im, const float* b_re, const float* b_im,
+                          const float* spec, int R, int F, int T, int Cs, int Cr, int mode, float* mask_ws, float* out, void* stream);
+int sehip_dcunet_mask_bwd(const float* dout, const float* spec, const float* mask_ws, const void* z_bf16, const float* w_re,
+                          const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, void* dz_bf16, float* gacc, void* stream);
 
 /* ---- recurrent part of NavieComplexLSTM: src/model/dccrn.py:264-302 (four nn.LSTM passes of one complex layer in one
  *      persistent launch; hidden size 64).  pre*: [B][T][2 lstm * 256] gates from the input GEMMs (fp32);

@@ -61,12 +61,22 @@ _PROTOS = {
     "sehip_cbn_bwd_reduce": [P, P, P, P, P, L, I, I, I, I, P, P],
     "sehip_cbn_bwd_finalize": [P, P, P, P, P, L, I, P, P, P, P, P, P, P, P],
     "sehip_cbn_bwd_apply": [P, P, P, P, P, P, L, I, I, I, I, P, P],
+    "sehip_rbn_scratch_floats": [L, I],
+    "sehip_rbn_stats": [P, L, I, I, P, P],
+    "sehip_rbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, F, I, P, P],
+    "sehip_rbn_apply": [P, P, L, I, I, P, P],
+    "sehip_rbn_bwd_reduce": [P, P, P, L, I, I, P, P],
+    "sehip_rbn_bwd_finalize": [P, P, L, I, I, P, P, P, P, P, P],
+    "sehip_rbn_bwd_apply": [P, P, P, P, L, I, I, P, P],
+    "sehip_dcunet_pack_input": [P, I, I, I, P, P],
+    "sehip_dcunet_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
+    "sehip_dcunet_mask_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_cbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
+_RESTYPE = {"sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
 
 
 def lib():

@@ -1,0 +1,247 @@
+// Front and back end of the complex DCUnet (src/model/dcunet.py:102-162) around its convolution stack:
+//   dcunet_pack_input : the STFT-domain input [R][F][T][2] fp32 (what stft_custom returns, time innermost) ->
+//                       channels-last bf16 [R][T][F][2] = x.transpose(2, 3) of :106, the first encoder's source
+//   dcunet_mask_fwd   : linear = 1x1 ComplexConv2d(C -> 1) (:93-95, :323-338) + tanh (:131) + transpose back (:132)
+//                       + the mask of :136-159 applied to the input spectrum -> enhanced spectrum [R][F][T][2] fp32
+//   dcunet_mask_bwd   : d enhanced -> d(last decoder output) [R][T][F][2 Cs] bf16 + gradients of the 1x1 conv
+// All three are HBM streams: the last decoder's output is 62 complex channels at the FULL 257 x 257 resolution
+// (1.08 GB in bf16 at batch 64); the 1x1 convolution reads it exactly once (a row is 256 contiguous bytes, 16 lanes
+// x 16 bytes), the backward pass reads it once more for the weight gradient while it writes its gradient.
+// Tiles of 32 frames x 32 bins go through LDS so that both the [T][F] side (activations) and the [F][T] side
+// (spectra) are accessed in >= 128-byte runs.
+#include "common.h"
+#include "mask.h"
+
+#define DT 32   // tile edge (frames and bins)
+#define DP 33   // LDS pitch of a tile row (float2 elements)
+
+__global__ __launch_bounds__(256) void dcunet_pack_input_kernel(const float2* __restrict__ spec, int F, int T,
+                                                                unsigned* __restrict__ out) {
+    __shared__ float2 tile[DT][DP];
+    const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float2* s = spec + (size_t)r * F * T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = f0 + ty + 8 * k, t = t0 + tx;
+        if (f < F && t < T) tile[ty + 8 * k][tx] = s[(size_t)f * T + t];
+    }
+    __syncthreads();
+    unsigned* o = out + (size_t)r * T * F;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + ty + 8 * k, f = f0 + tx;
+        if (f < F && t < T) {
+            const float2 v = tile[tx][ty + 8 * k];
+            o[(size_t)t * F + f] = pack_bf2(v.x, v.y);
+        }
+    }
+}
+
+// per-lane coefficients of the 1x1 complex conv for this lane's 8-channel piece q of a row (nq = C/8 pieces; the first
+// nq/2 are real-part channels, the rest imaginary-part channels):
+//   lin_re = sum wre zr - wim zi ; lin_im = sum wre zi + wim zr    ->  piece of zr: (wa, wb) = (wre, wim); of zi: (-wim, wre)
+struct LinCoef { float wa[8], wb[8]; };
+__device__ __forceinline__ LinCoef lin_coef(const float* __restrict__ w_re, const float* __restrict__ w_im, int q, int nq, int Cs,
+                                            int Cr) {
+    LinCoef c;
+    const bool imag = q >= (nq >> 1);
+    const int c0 = (imag ? q - (nq >> 1) : q) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool ok = c0 + j < Cr;
+        const float wr = ok ? w_re[c0 + j] : 0.f, wi = ok ? w_im[c0 + j] : 0.f;
+        c.wa[j] = imag ? -wi : wr;
+        c.wb[j] = imag ? wr : wi;
+    }
+    return c;
+}
+
+__device__ __forceinline__ void unpack8f(uint4 u, float (&v)[8]) {
+    v[0] = bf2f((bf16_raw)(u.x & 0xffff)); v[1] = bf2f((bf16_raw)(u.x >> 16));
+    v[2] = bf2f((bf16_raw)(u.y & 0xffff)); v[3] = bf2f((bf16_raw)(u.y >> 16));
+    v[4] = bf2f((bf16_raw)(u.z & 0xffff)); v[5] = bf2f((bf16_raw)(u.z >> 16));
+    v[6] = bf2f((bf16_raw)(u.w & 0xffff)); v[7] = bf2f((bf16_raw)(u.w >> 16));
+}
+
+__global__ __launch_bounds__(256) void dcunet_mask_fwd_kernel(const bf16_raw* __restrict__ z, const float* __restrict__ w_re,
+                                                              const float* __restrict__ w_im, const float* __restrict__ b_re,
+                                                              const float* __restrict__ b_im, const float2* __restrict__ spec,
+                                                              int F, int T, int Cs, int Cr, int mode, float2* __restrict__ mask_ws,
+                                                              float2* __restrict__ out) {
+    __shared__ float2 tile[DT][DP];   // tanh(linear) per position, [frame][bin]
+    const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
+    const int C = 2 * Cs, nq = C >> 3, ppi = 64 / nq;   // positions per wave instruction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % nq, pl = lane / nq;
+    const LinCoef lc = lin_coef(w_re, w_im, q, nq, Cs, Cr);
+    const float bre = b_re[0] - b_im[0], bim = b_re[0] + b_im[0];   // each of the four real convs carries its own bias
+    const bf16_raw* zb = z + (size_t)r * T * F * C;
+    const int fw = min(DT, F - f0);            // valid bins of this tile
+    const int npos = min(DT, T - t0) * fw;
+    for (int p0 = wave * ppi; p0 < npos; p0 += 4 * ppi) {
+        const int p = p0 + pl;
+        float sre = 0.f, sim = 0.f;
+        int tl = 0, fl = 0;
+        if (p < npos) {
+            tl = p / fw; fl = p - tl * fw;
+            float v[8];
+            unpack8f(*reinterpret_cast<const uint4*>(zb + ((size_t)(t0 + tl) * F + f0 + fl) * C + q * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sre += lc.wa[j] * v[j]; sim += lc.wb[j] * v[j]; }
+        }
+        for (int o = 1; o < nq; o <<= 1) { sre += __shfl_xor(sre, o, 64); sim += __shfl_xor(sim, o, 64); }
+        if (p < npos && q == 0) tile[tl][fl] = make_float2(tanhf(sre + bre), tanhf(sim + bim));
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float2* mw = mask_ws + (size_t)r * T * F;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // the mask, [frame][bin] order, kept for the backward pass
+        const int t = t0 + ty + 8 * k, f = f0 + tx;
+        if (t < T && f < F) mw[(size_t)t * F + f] = tile[ty + 8 * k][tx];
+    }
+    const float2* s = spec + (size_t)r * F * T;
+    float2* ob = out + (size_t)r * F * T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // masking, [bin][frame] order
+        const int f = f0 + ty + 8 * k, t = t0 + tx;
+        if (t < T && f < F) {
+            const float2 x = s[(size_t)f * T + t], m = tile[tx][ty + 8 * k];
+            float er, ei;
+            apply_mask(mode, x.x, x.y, m.x, m.y, er, ei);
+            ob[(size_t)f * T + t] = make_float2(er, ei);
+        }
+    }
+}
+
+// gacc: fp32 [2*Cs + 2]: d w_re [Cs], d w_im [Cs], d b_re, d b_im (caller zeroes; accumulated with atomics)
+__global__ __launch_bounds__(256) void dcunet_mask_bwd_kernel(const float2* __restrict__ dout, const float2* __restrict__ spec,
+                                                              const float2* __restrict__ mask_ws, const bf16_raw* __restrict__ z,
+                                                              const float* __restrict__ w_re, const float* __restrict__ w_im, int F,
+                                                              int T, int Cs, int Cr, int mode, bf16_raw* __restrict__ dz,
+                                                              float* __restrict__ gacc) {
+    __shared__ float2 tile[DT][DP];      // in: the mask; out: d linear, [frame][bin]
+    __shared__ float red[4][16][16];     // per wave: [piece q][8 a-sums | 8 b-sums]
+    const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float2* mw = mask_ws + (size_t)r * T * F;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + ty + 8 * k, f = f0 + tx;
+        if (t < T && f < F) tile[ty + 8 * k][tx] = mw[(size_t)t * F + f];
+    }
+    __syncthreads();
+    const float2* s = spec + (size_t)r * F * T;
+    const float2* go = dout + (size_t)r * F * T;
+    float2 gl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = f0 + ty + 8 * k, t = t0 + tx;
+        gl[k] = make_float2(0.f, 0.f);
+        if (t < T && f < F) {
+            const float2 x = s[(size_t)f * T + t], g = go[(size_t)f * T + t], m = tile[tx][ty + 8 * k];
+            float gmr, gmi;
+            mask_grad(mode, x.x, x.y, m.x, m.y, g.x, g.y, gmr, gmi);
+            gl[k] = make_float2(gmr * (1.f - m.x * m.x), gmi * (1.f - m.y * m.y));   // through the tanh
+        }
+    }
+    float sbr = 0.f, sbi = 0.f;   // bias gradients: d b_re = sum (g_re + g_im), d b_im = sum (-g_re + g_im)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sbr += gl[k].x + gl[k].y; sbi += gl[k].y - gl[k].x; }
+    __syncthreads();              // every thread has read its mask values: the tile is rewritten with d linear
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[tx][ty + 8 * k] = gl[k];
+    __syncthreads();
+
+    const int C = 2 * Cs, nq = C >> 3, ppi = 64 / nq;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % nq, pl = lane / nq;
+    const LinCoef lc = lin_coef(w_re, w_im, q, nq, Cs, Cr);
+    const bf16_raw* zb = z + (size_t)r * T * F * C;
+    bf16_raw* dzb = dz + (size_t)r * T * F * C;
+    const int fw = min(DT, F - f0);
+    const int npos = min(DT, T - t0) * fw;
+    float aa[8], ab[8];           // sum g_re z[c], sum g_im z[c] over this lane's positions
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { aa[j] = 0.f; ab[j] = 0.f; }
+    for (int p0 = wave * ppi; p0 < npos; p0 += 4 * ppi) {
+        const int p = p0 + pl;
+        if (p >= npos) continue;
+        const int tl = p / fw, fl = p - tl * fw;
+        const float2 g = tile[tl][fl];
+        const size_t off = ((size_t)(t0 + tl) * F + f0 + fl) * C + q * 8;
+        float v[8], o[8];
+        unpack8f(*reinterpret_cast<const uint4*>(zb + off), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = g.x * lc.wa[j] + g.y * lc.wb[j];
+            aa[j] += g.x * v[j]; ab[j] += g.y * v[j];
+        }
+        *reinterpret_cast<uint4*>(dzb + off) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+    }
+    // fold the lanes that own the same piece, then the four waves, then one atomic per weight and workgroup
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        for (int o = nq; o < 64; o <<= 1) { aa[j] += __shfl_xor(aa[j], o, 64); ab[j] += __shfl_xor(ab[j], o, 64); }
+    }
+    if (lane < nq) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[wave][lane][j] = aa[j]; red[wave][lane][8 + j] = ab[j]; }
+    }
+    sbr = wave_sum(sbr); sbi = wave_sum(sbi);
+    __shared__ float redb[4][2];
+    if (lane == 0) { redb[wave][0] = sbr; redb[wave][1] = sbi; }
+    __syncthreads();
+    if (threadIdx.x < nq * 8) {
+        const int qq = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const float a = red[0][qq][j] + red[1][qq][j] + red[2][qq][j] + red[3][qq][j];          // sum g_re z
+        const float b = red[0][qq][8 + j] + red[1][qq][8 + j] + red[2][qq][8 + j] + red[3][qq][8 + j];  // sum g_im z
+        const bool imag = qq >= (nq >> 1);
+        const int c = (imag ? qq - (nq >> 1) : qq) * 8 + j;
+        if (c < Cr) {
+            // real-part piece: d wre += g_re zr, d wim += g_im zr ; imaginary-part piece: d wre += g_im zi, d wim -= g_re zi
+            atomicAdd(&gacc[c], imag ? b : a);
+            atomicAdd(&gacc[Cs + c], imag ? -a : b);
+        }
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&gacc[2 * Cs], redb[0][0] + redb[1][0] + redb[2][0] + redb[3][0]);
+        atomicAdd(&gacc[2 * Cs + 1], redb[0][1] + redb[1][1] + redb[2][1] + redb[3][1]);
+    }
+}
+
+static int check_dcu(const char* who, int R, int F, int T, int Cs, int Cr, int mode) {
+    SEHIP_REQUIRE(R > 0 && F > 0 && T > 0, "%s: empty input", who);
+    SEHIP_REQUIRE(Cs >= 8 && Cs <= 64 && (Cs & (Cs - 1)) == 0 && Cr >= 1 && Cr <= Cs, "%s: bad channel counts Cs=%d Cr=%d", who, Cs, Cr);
+    SEHIP_REQUIRE(mode >= 0 && mode <= 2, "%s: masking mode must be 0(E) 1(C) 2(R)", who);
+    return 0;
+}
+
+extern "C" int sehip_dcunet_pack_input(const float* spec, int R, int F, int T, void* out_bf16, void* stream) {
+    SEHIP_REQUIRE(R > 0 && F > 0 && T > 0, "dcunet_pack_input: empty input");
+    dcunet_pack_input_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, (hipStream_t)stream>>>((const float2*)spec, F, T, (unsigned*)out_bf16);
+    SEHIP_CHECK_LAUNCH("dcunet_pack_input");
+    return 0;
+}
+
+extern "C" int sehip_dcunet_mask_fwd(const void* z_bf16, const float* w_re, const float* w_im, const float* b_re, const float* b_im,
+                                     const float* spec, int R, int F, int T, int Cs, int Cr, int mode, float* mask_ws, float* out,
+                                     void* stream) {
+    if (int e = check_dcu("dcunet_mask_fwd", R, F, T, Cs, Cr, mode)) return e;
+    dcunet_mask_fwd_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_raw*)z_bf16, w_re, w_im, b_re, b_im, (const float2*)spec, F, T, Cs, Cr, mode, (float2*)mask_ws, (float2*)out);
+    SEHIP_CHECK_LAUNCH("dcunet_mask_fwd");
+    return 0;
+}
+
+extern "C" int sehip_dcunet_mask_bwd(const float* dout, const float* spec, const float* mask_ws, const void* z_bf16, const float* w_re,
+                                     const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, void* dz_bf16, float* gacc,
+                                     void* stream) {
+    if (int e = check_dcu("dcunet_mask_bwd", R, F, T, Cs, Cr, mode)) return e;
+    dcunet_mask_bwd_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, (hipStream_t)stream>>>(
+        (const float2*)dout, (const float2*)spec, (const float2*)mask_ws, (const bf16_raw*)z_bf16, w_re, w_im, F, T, Cs, Cr, mode,
+        (bf16_raw*)dz_bf16, gacc);
+    SEHIP_CHECK_LAUNCH("dcunet_mask_bwd");
+    return 0;
+}

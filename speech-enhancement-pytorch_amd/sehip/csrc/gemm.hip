@@ -21,9 +21,9 @@
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-struct RowPos { int b, t, jf; bool valid; };
+struct RowPos { int b, t, jf; bool valid; int ts; };  // ts = source frame of the row (t * tmul); t = frame of the row space
 
-__device__ __forceinline__ RowPos row_pos(int m, int M, int TT, int J, int fmul) {
+__device__ __forceinline__ RowPos row_pos(int m, int M, int TT, int J, int fmul, int tmul = 1) {
     RowPos r;
     r.valid = m < M;
     const int mm = r.valid ? m : 0;
@@ -31,12 +31,14 @@ __device__ __forceinline__ RowPos row_pos(int m, int M, int TT, int J, int fmul)
     r.jf = (mm - bt * J) * fmul;
     r.b = bt / TT;
     r.t = bt - r.b * TT;
+    r.ts = r.t * tmul;
     return r;
 }
+__device__ __forceinline__ int src_tmul(const sehip_gemm_desc& d) { return d.tmul > 1 ? d.tmul : 1; }
 
-// element offset of (b, t, jf) in source s, before the per-chunk delta
+// element offset of (b, t*tmul, jf) in source s, before the per-chunk delta
 __device__ __forceinline__ long row_base(const sehip_src& s, const RowPos r) {
-    return (((long)r.b * s.T + r.t) * s.F + r.jf) * s.C;
+    return (((long)r.b * s.T + r.ts) * s.F + r.jf) * s.C;
 }
 
 // One 16-byte chunk (8 consecutive k) of the implicit A matrix.  The chunk table carries the precomputed element
@@ -47,7 +49,7 @@ __device__ __forceinline__ uint4 gather_chunk(const sehip_src& s0, const sehip_s
     if (!r.valid || e.src < 0) return z;
     const bool second = e.src != 0;
     const int toff = e.toff >> 16, fadd = (int)(short)(e.toff & 0xffff);
-    const int ts = r.t + toff;
+    const int ts = r.ts + toff;
     const int f = r.jf + fadd;
     const int tlo = second ? s1.tlo : s0.tlo, thi = second ? s1.thi : s0.thi, F = second ? s1.F : s0.F;
     if (ts < tlo || ts >= thi) return z;
@@ -71,7 +73,7 @@ __device__ __forceinline__ uint4 gather_chunk(const sehip_src& s0, const sehip_s
 __device__ __forceinline__ size_t dst_row_offset(const sehip_dst& d, const RowPos r, int fmul_row) {
     // r.jf = j*fmul_row ; destination uses its own multiplier
     const int j = r.jf / fmul_row;
-    return (((size_t)r.b * d.T + r.t + d.toff) * d.F + (size_t)j * d.fmul + d.fadd) * d.C;
+    return (((size_t)r.b * d.T + r.t * (d.tmul > 1 ? d.tmul : 1) + d.toff) * d.F + (size_t)j * d.fmul + d.fadd) * d.C;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -197,7 +199,7 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
     long rb0[NRA], rb1[NRA];
 #pragma unroll
     for (int i = 0; i < NRA; ++i) {
-        rp[i] = row_pos(m0 + r0 + 32 * i, d.M, d.TT, d.J, d.fmul);
+        rp[i] = row_pos(m0 + r0 + 32 * i, d.M, d.TT, d.J, d.fmul, src_tmul(d));
         rb0[i] = row_base(d.src[0], rp[i]);
         rb1[i] = row_base(d.src[1], rp[i]);
     }
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = mb + r0 + 32 * i;
-            RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul);
+            RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul, src_tmul(d));
             xa[i] = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
         }
 #pragma unroll

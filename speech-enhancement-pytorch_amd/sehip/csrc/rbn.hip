@@ -1,0 +1,349 @@
+// DCUnet's ComplexBatchNorm2d = two INDEPENDENT real BatchNorm2d (bn_re on the real part, bn_im on the imaginary part:
+// src/model/dcunet.py:374-386, no whitening) fused with the LeakyReLU(0.01) that follows it in Encoder / Decoder
+// (src/model/dcunet.py:8-50), forward and backward, on channels-last bf16 activations [rows][C].
+//   C = 2*Cs: real half | imaginary half, Cs channels STORED per half of which the first Cr are real channels of the
+//   model (31 / 62 complex channels are stored as 32 / 64: every row is then a whole number of 16-byte pieces and the
+//   MFMA K chunks stay aligned).  The padding channels are written as exact zeros by the forward pass and get zero
+//   gradients.
+//   forward : stats (1 read) -> per-channel finalize -> apply + LeakyReLU (1 read, 1 write)
+//   backward: reduce (2 reads) -> per-channel finalize -> apply (2 reads, 1 write)
+// all HBM-bound with 16-byte accesses; one thread owns one 8-channel piece of a row for all its rows.
+//
+//   o = w (y - mean) rstd + b;  z = o > 0 ? o : 0.01 o
+//   g = dz * (o > 0 ? 1 : 0.01);  db = sum g;  dw = sum g xh  (xh = (y - mean) rstd);
+//   dy = w rstd (g - mean(g) - xh mean(g xh))
+#include <stdlib.h>
+#include "common.h"
+
+#define RBN_SLOPE 0.01f
+#define RBN_MAX_BLOCKS 512
+
+struct RChunk8 { float v[8]; };
+__device__ __forceinline__ RChunk8 r_unpack8(uint4 u) {
+    RChunk8 c;
+    c.v[0] = bf2f((bf16_raw)(u.x & 0xffff)); c.v[1] = bf2f((bf16_raw)(u.x >> 16));
+    c.v[2] = bf2f((bf16_raw)(u.y & 0xffff)); c.v[3] = bf2f((bf16_raw)(u.y >> 16));
+    c.v[4] = bf2f((bf16_raw)(u.z & 0xffff)); c.v[5] = bf2f((bf16_raw)(u.z >> 16));
+    c.v[6] = bf2f((bf16_raw)(u.w & 0xffff)); c.v[7] = bf2f((bf16_raw)(u.w >> 16));
+    return c;
+}
+__device__ __forceinline__ uint4 r_pack8(const float* v) {
+    return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// per-block partial sums: part[blockIdx.x][a*C + channel], a < NS
+template <int NS>
+__device__ __forceinline__ void rbn_block_partials(float (&s)[NS][8], int nq, int C, float* __restrict__ part,
+                                                   float* lds /* [4][NS*8][nq] */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* out = part + (size_t)blockIdx.x * NS * C;
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = s[a][j];
+            for (int o = 32; o >= nq; o >>= 1) v += __shfl_xor(v, o, 64);   // lanes that share a piece column (nq divides 64)
+            if (lane < nq) lds[(w * NS * 8 + a * 8 + j) * nq + lane] = v;
+        }
+    __syncthreads();
+    for (int i = tid; i < NS * 8 * nq; i += 256) {
+        const float t = lds[i] + lds[NS * 8 * nq + i] + lds[2 * NS * 8 * nq + i] + lds[3 * NS * 8 * nq + i];
+        const int aj = i / nq, q = i - aj * nq;
+        out[(size_t)(aj >> 3) * C + q * 8 + (aj & 7)] = t;
+    }
+}
+
+// sums over the blocks' partials by one wave (all loads issued before the first add, see cbn.hip)
+template <int NS>
+__device__ __forceinline__ void rbn_wave_reduce(const float* __restrict__ part, int nblk, int C, int c, double (&out)[NS]) {
+    float v[RBN_MAX_BLOCKS / 64][NS];
+#pragma unroll
+    for (int t = 0; t < RBN_MAX_BLOCKS / 64; ++t) {
+        const int b = (threadIdx.x & 63) + 64 * t;
+        const float* p = part + (size_t)(b < nblk ? b : 0) * NS * C + c;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[t][k] = p[(size_t)k * C];
+    }
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int t = 0; t < RBN_MAX_BLOCKS / 64; ++t) {
+        const bool live = (int)(threadIdx.x & 63) + 64 * t < nblk;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += live ? (double)v[t][k] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) out[k] = wave_sum_d(acc[k]);
+}
+
+__global__ __launch_bounds__(256) void rbn_stats_kernel(const bf16_raw* __restrict__ y, long rows, int C, float* __restrict__ part) {
+    __shared__ float lds[4 * 2 * 8 * 16];
+    const int nq = C >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    float s[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[0][j] = 0.f; s[1][j] = 0.f; }
+    const long stride = (long)gridDim.x * rpb;
+    for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 4 * stride) {
+        uint4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {    // four independent 16-byte loads in flight per thread
+            const long r = r0 + k * stride;
+            u[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < rows) u[k] = *reinterpret_cast<const uint4*>(y + r * C + q * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const RChunk8 a = r_unpack8(u[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[0][j] += a.v[j]; s[1][j] += a.v[j] * a.v[j]; }
+        }
+    }
+    rbn_block_partials<2>(s, nq, C, part, lds);
+}
+
+// coef record per stored channel: scale (w rstd), shift (b - mean scale), mean, rstd
+// one wave per stored channel c: half = c / Cs (0 bn_re, 1 bn_im), index = c % Cs (>= Cr: padding -> all zero)
+__global__ void rbn_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ w_re, const float* __restrict__ b_re,
+                                    const float* __restrict__ w_im, const float* __restrict__ b_im, float* __restrict__ rm_re,
+                                    float* __restrict__ rv_re, float* __restrict__ rm_im, float* __restrict__ rv_im,
+                                    long* __restrict__ nbt_re, long* __restrict__ nbt_im, long rows, int Cs, int Cr, float eps,
+                                    float momentum, int training, float4* __restrict__ coef) {
+    const int c = blockIdx.x, C = 2 * Cs;
+    const int half = c / Cs, i = c - half * Cs;
+    if (i >= Cr) {
+        if (threadIdx.x == 0) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float w = (half ? w_im : w_re)[i], b = (half ? b_im : b_re)[i];
+    float* rm = half ? rm_im : rm_re;
+    float* rv = half ? rv_im : rv_re;
+    const float rmo = rm[i], rvo = rv[i];
+    float mean, var;
+    if (training) {
+        double a[2];
+        rbn_wave_reduce<2>(part, nblk, C, c, a);
+        if (threadIdx.x != 0) return;
+        const double n = (double)rows;
+        const double m = a[0] / n;
+        double v = a[1] / n - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m; var = (float)v;
+        rm[i] = rmo + momentum * (mean - rmo);
+        rv[i] = rvo + momentum * ((float)(v * n / (n - 1.0)) - rvo);   // nn.BatchNorm2d: running_var takes the UNBIASED variance
+        if (i == 0) { long* nb = half ? nbt_im : nbt_re; if (nb) nb[0] += 1; }
+    } else {
+        if (threadIdx.x != 0) return;
+        mean = rmo; var = rvo;
+    }
+    const float rstd = 1.f / sqrtf(var + eps);
+    coef[c] = make_float4(w * rstd, b - mean * w * rstd, mean, rstd);
+}
+
+__global__ __launch_bounds__(256) void rbn_apply_kernel(const bf16_raw* __restrict__ y, const float4* __restrict__ coef, long rows,
+                                                        int C, bf16_raw* __restrict__ z) {
+    const int nq = C >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float4 k = coef[q * 8 + j]; sc[j] = k.x; sh[j] = k.y; }
+    const long stride = (long)gridDim.x * rpb;
+    for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 4 * stride) {
+        uint4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long r = r0 + k * stride;
+            u[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < rows) u[k] = *reinterpret_cast<const uint4*>(y + r * C + q * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long r = r0 + k * stride;
+            if (r >= rows) continue;
+            const RChunk8 a = r_unpack8(u[k]);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = sc[j] * a.v[j] + sh[j];
+                o[j] = v > 0.f ? v : RBN_SLOPE * v;
+            }
+            *reinterpret_cast<uint4*>(z + r * C + q * 8) = r_pack8(o);
+        }
+    }
+}
+
+// backward pass 1: per-channel sum g, sum g xh
+__global__ __launch_bounds__(256) void rbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
+                                                             const float4* __restrict__ coef, long rows, int C,
+                                                             float* __restrict__ part) {
+    __shared__ float lds[4 * 2 * 8 * 16];
+    const int nq = C >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    float4 k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = coef[q * 8 + j];
+    float s[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[0][j] = 0.f; s[1][j] = 0.f; }
+    const long stride = (long)gridDim.x * rpb;
+    for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 2 * stride) {
+        uint4 uy[2], ug[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long r = r0 + t * stride;
+            uy[t] = make_uint4(0u, 0u, 0u, 0u); ug[t] = uy[t];
+            if (r < rows) {
+                uy[t] = *reinterpret_cast<const uint4*>(y + r * C + q * 8);
+                ug[t] = *reinterpret_cast<const uint4*>(dz + r * C + q * 8);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const RChunk8 a = r_unpack8(uy[t]), g = r_unpack8(ug[t]);   // rows beyond the end: g == 0 contributes nothing
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float o = k[j].x * a.v[j] + k[j].y;
+                const float gg = o > 0.f ? g.v[j] : RBN_SLOPE * g.v[j];
+                s[0][j] += gg;
+                s[1][j] += gg * (a.v[j] - k[j].z) * k[j].w;
+            }
+        }
+    }
+    rbn_block_partials<2>(s, nq, C, part, lds);
+}
+
+// bcoef record per stored channel: a = w rstd, k1 = mean(g), k2 = mean(g xh)
+__global__ void rbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, const float4* __restrict__ coef, long rows, int Cs,
+                                        int Cr, float* __restrict__ gw_re, float* __restrict__ gb_re, float* __restrict__ gw_im,
+                                        float* __restrict__ gb_im, float4* __restrict__ bcoef) {
+    const int c = blockIdx.x, C = 2 * Cs;
+    const int half = c / Cs, i = c - half * Cs;
+    if (i >= Cr) {
+        if (threadIdx.x == 0) bcoef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 k = coef[c];
+    double a[2];
+    rbn_wave_reduce<2>(part, nblk, C, c, a);
+    if (threadIdx.x != 0) return;
+    (half ? gb_im : gb_re)[i] = (float)a[0];
+    (half ? gw_im : gw_re)[i] = (float)a[1];
+    const double n = (double)rows;
+    bcoef[c] = make_float4(k.x, (float)(a[0] / n), (float)(a[1] / n), 0.f);
+}
+
+__global__ __launch_bounds__(256) void rbn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
+                                                            const float4* __restrict__ coef, const float4* __restrict__ bcoef,
+                                                            long rows, int C, bf16_raw* __restrict__ dy) {
+    const int nq = C >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    float4 k[8], kb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k[j] = coef[q * 8 + j]; kb[j] = bcoef[q * 8 + j]; }
+    const long stride = (long)gridDim.x * rpb;
+    for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 2 * stride) {
+        uint4 uy[2], ug[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long r = r0 + t * stride;
+            uy[t] = make_uint4(0u, 0u, 0u, 0u); ug[t] = uy[t];
+            if (r < rows) {
+                uy[t] = *reinterpret_cast<const uint4*>(y + r * C + q * 8);
+                ug[t] = *reinterpret_cast<const uint4*>(dz + r * C + q * 8);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long r = r0 + t * stride;
+            if (r >= rows) continue;
+            const RChunk8 a = r_unpack8(uy[t]), g = r_unpack8(ug[t]);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = k[j].x * a.v[j] + k[j].y;
+                const float gg = v > 0.f ? g.v[j] : RBN_SLOPE * g.v[j];
+                const float xh = (a.v[j] - k[j].z) * k[j].w;
+                o[j] = kb[j].x * (gg - kb[j].y - xh * kb[j].z);
+            }
+            *reinterpret_cast<uint4*>(dy + r * C + q * 8) = r_pack8(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_rbn(const char* who, long rows, int Cs, int Cr) {
+    SEHIP_REQUIRE(rows > 1, "%s: BatchNorm needs more than one value per channel (rows=%ld)", who, rows);
+    SEHIP_REQUIRE(Cs >= 8 && Cs <= 64 && (Cs & (Cs - 1)) == 0, "%s: stored channels per half Cs=%d must be 8, 16, 32 or 64", who, Cs);
+    SEHIP_REQUIRE(Cr >= 1 && Cr <= Cs, "%s: Cr=%d must be in [1, Cs=%d]", who, Cr, Cs);
+    return 0;
+}
+static int rbn_stat_blocks(long rows, int C) {
+    const int rpb = 256 / (C >> 3);
+    long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
+    if (g > RBN_MAX_BLOCKS) g = RBN_MAX_BLOCKS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+static int rbn_apply_blocks(long rows, int C) {
+    const int rpb = 256 / (C >> 3);
+    long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" long sehip_rbn_scratch_floats(long rows, int Cs) { return (long)rbn_stat_blocks(rows, 2 * Cs) * 2L * 2 * Cs; }
+
+extern "C" int sehip_rbn_stats(const void* y, long rows, int Cs, int Cr, float* part, void* stream) {
+    if (int e = check_rbn("rbn_stats", rows, Cs, Cr)) return e;
+    rbn_stats_kernel<<<rbn_stat_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, rows, 2 * Cs, part);
+    SEHIP_CHECK_LAUNCH("rbn_stats");
+    return 0;
+}
+
+extern "C" int sehip_rbn_finalize(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im,
+                                  float* rm_re, float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows,
+                                  int Cs, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
+    if (int e = check_rbn("rbn_finalize", rows, Cs, Cr)) return e;
+    rbn_finalize_kernel<<<2 * Cs, 64, 0, (hipStream_t)stream>>>(part, rbn_stat_blocks(rows, 2 * Cs), w_re, b_re, w_im, b_im, rm_re, rv_re,
+                                                             rm_im, rv_im, nbt_re, nbt_im, rows, Cs, Cr, eps, momentum, training,
+                                                             (float4*)coef);
+    SEHIP_CHECK_LAUNCH("rbn_finalize");
+    return 0;
+}
+
+extern "C" int sehip_rbn_apply(const void* y, const float* coef, long rows, int Cs, int Cr, void* z, void* stream) {
+    if (int e = check_rbn("rbn_apply", rows, Cs, Cr)) return e;
+    rbn_apply_kernel<<<rbn_apply_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, (const float4*)coef, rows,
+                                                                                   2 * Cs, (bf16_raw*)z);
+    SEHIP_CHECK_LAUNCH("rbn_apply");
+    return 0;
+}
+
+extern "C" int sehip_rbn_bwd_reduce(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part,
+                                    void* stream) {
+    if (int e = check_rbn("rbn_bwd_reduce", rows, Cs, Cr)) return e;
+    rbn_bwd_reduce_kernel<<<rbn_stat_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y,
+                                                                                       (const float4*)coef, rows, 2 * Cs, part);
+    SEHIP_CHECK_LAUNCH("rbn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int sehip_rbn_bwd_finalize(const float* part, const float* coef, long rows, int Cs, int Cr, float* gw_re, float* gb_re,
+                                      float* gw_im, float* gb_im, float* bcoef, void* stream) {
+    if (int e = check_rbn("rbn_bwd_finalize", rows, Cs, Cr)) return e;
+    rbn_bwd_finalize_kernel<<<2 * Cs, 64, 0, (hipStream_t)stream>>>(part, rbn_stat_blocks(rows, 2 * Cs), (const float4*)coef, rows, Cs, Cr,
+                                                                 gw_re, gb_re, gw_im, gb_im, (float4*)bcoef);
+    SEHIP_CHECK_LAUNCH("rbn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sehip_rbn_bwd_apply(const void* dz, const void* y, const float* coef, const float* bcoef, long rows, int Cs, int Cr,
+                                   void* dy, void* stream) {
+    if (int e = check_rbn("rbn_bwd_apply", rows, Cs, Cr)) return e;
+    rbn_bwd_apply_kernel<<<rbn_apply_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_raw*)dz, (const bf16_raw*)y, (const float4*)coef, (const float4*)bcoef, rows, 2 * Cs, (bf16_raw*)dy);
+    SEHIP_CHECK_LAUNCH("rbn_bwd_apply");
+    return 0;
+}

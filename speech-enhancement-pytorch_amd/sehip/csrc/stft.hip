@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include "fft512.h"
+#include "mask.h"
 
 // ------------------------------------------------------------------------------------------------
 // STFT forward: wav [B][N] fp32 -> spec [B][T][257] float2 (re, im) and the encoder input
@@ -61,26 +62,6 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__
 //   spec [B][T][257] float2, mask [B][T][256][2] fp32 (bins 1..256) -> frames [B][T][win] fp32
 // 'E' without trigonometry: cos(phase)=re/|z|, cos(mask_phase)=m_r/|m| (atan2(0,0)=0 conventions kept).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void apply_mask(int mode, float re, float im, float mr, float mi, float& er, float& ei) {
-    if (mode == 0) {  // E
-        const float z2 = re * re + im * im;
-        const float mags = sqrtf(z2 + 1e-8f);
-        const float zabs = sqrtf(z2);
-        const float cp = zabs > 0.f ? re / zabs : 1.f, sp = zabs > 0.f ? im / zabs : 0.f;
-        const float rho = sqrtf(mr * mr + mi * mi);
-        const float cm = rho > 0.f ? mr / rho : 1.f, sm = rho > 0.f ? mi / rho : 0.f;
-        const float a = tanhf(rho) * mags;
-        er = a * (cp * cm - sp * sm);
-        ei = a * (sp * cm + cp * sm);
-    } else if (mode == 1) {  // C
-        er = re * mr - im * mi;
-        ei = re * mi + im * mr;
-    } else {  // R
-        er = re * mr;
-        ei = im * mi;
-    }
-}
-
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float2* __restrict__ spec, const float2* __restrict__ mask,
                                                            const float* __restrict__ window, int nframes, int win, int mode,
                                                            float* __restrict__ frames) {
@@ -201,28 +182,7 @@ __global__ __launch_bounds__(256) void istft_bwd_kernel(const float* __restrict_
         const float2 z = sp[k];
         const float2 m = mk[k - 1];
         float gmr, gmi;
-        if (mode == 0) {
-            const float z2 = z.x * z.x + z.y * z.y;
-            const float mags = sqrtf(z2 + 1e-8f);
-            const float zabs = sqrtf(z2);
-            const float cp = zabs > 0.f ? z.x / zabs : 1.f, sp_ = zabs > 0.f ? z.y / zabs : 0.f;
-            const float rho = sqrtf(m.x * m.x + m.y * m.y);
-            if (rho > 0.f) {
-                const float cm = m.x / rho, sm = m.y / rho;
-                const float ce = cp * cm - sp_ * sm, se = sp_ * cm + cp * sm;  // cos/sin(phase + mask phase)
-                const float th = tanhf(rho);
-                const float g_rho = (dr * ce + di * se) * mags * (1.f - th * th);
-                const float g_mu = th * mags * (-dr * se + di * ce);
-                gmr = g_rho * cm - g_mu * sm / rho;
-                gmi = g_rho * sm + g_mu * cm / rho;
-            } else { gmr = 0.f; gmi = 0.f; }
-        } else if (mode == 1) {
-            gmr = dr * z.x + di * z.y;
-            gmi = -dr * z.y + di * z.x;
-        } else {
-            gmr = dr * z.x;
-            gmi = di * z.y;
-        }
+        mask_grad(mode, z.x, z.y, m.x, m.y, dr, di, gmr, gmi);
         dm[k - 1] = pack_bf2(gmr, gmi);
     }
 }

@@ -11,11 +11,12 @@ import torch.distributed as dist
 from ._lib import SehipError
 from .loss import loss_sisdr, l1_loss, mse_loss
 from .model.dccrn import DCCRN
+from .model.dcunet import DCUnet
 from .model.dnn import DeepNeuralNetwork
 from .optim import FlatOptimizer
 from .utils import obj2dict
 
-MODEL_REGISTRY = {"dccrn": DCCRN, "dnn": DeepNeuralNetwork}
+MODEL_REGISTRY = {"dccrn": DCCRN, "dcunet": DCUnet, "dnn": DeepNeuralNetwork}
 _REFERENCE_NAMES = ("dnn", "mel-rnn", "unet", "dccrn", "dcunet", "demucs", "wav-unet", "conv-tasnet", "crn", "rnn-stft-mask")
 
 

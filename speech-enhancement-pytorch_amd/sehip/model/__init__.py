@@ -1,3 +1,4 @@
 from .dccrn import DCCRN  # noqa: F401
 from . import types  # noqa: F401
 from .dnn import DeepNeuralNetwork  # noqa: F401
+from .dcunet import DCUnet  # noqa: F401

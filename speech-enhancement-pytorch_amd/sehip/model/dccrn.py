@@ -8,14 +8,13 @@ the persistent stft/istft buffers), so checkpoints of the reference load here an
     calling forward on a CPU tensor raises SehipError.
 """
 import os
-from collections import OrderedDict
-
 import numpy as np
 import torch
 from torch import nn
 
 from .. import plan, ops
 from .._lib import SehipError
+from .flat import FlatModule, _Node
 
 _STATIC_CACHE = {}
 
@@ -25,13 +24,6 @@ def _static_for(cfg):
     if key not in _STATIC_CACHE:
         _STATIC_CACHE[key] = plan.DCCRNStatic(cfg)
     return _STATIC_CACHE[key]
-
-
-class _Node(nn.Module):
-    """Plain container; the tree of these reproduces the reference's module/parameter names."""
-
-    def __getitem__(self, idx):  # encoder[i][0] style access like the reference's nn.Sequential
-        return getattr(self, str(idx))
 
 
 class _DCCRNFunction(torch.autograd.Function):
@@ -53,7 +45,7 @@ class _DCCRNFunction(torch.autograd.Function):
         return None, None, None
 
 
-class DCCRN(nn.Module):
+class DCCRN(FlatModule):
     def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512, length=16384, win_type="hann",
                  masking_mode="E", use_clstm=True, use_cbn=True, kernel_size=5, kernel_num=[16, 32, 64, 128, 256, 256],
                  *args, **kwargs):
@@ -65,17 +57,8 @@ class DCCRN(nn.Module):
         self.win_len, self.win_inc, self.fft_len, self.rnn_units = win_len, win_inc, fft_len, rnn_units
         self.masking_mode, self.kernel_num = masking_mode, cfg.kernel_num
         self.static = _static_for(cfg)
-        L = self.static.layout
-        self._flat = torch.zeros(L.n_params)
-        self._gflat = None
-        self._bflat = torch.zeros(max(L.n_buffers, 1))
-        self._nbt = torch.zeros(len(L.nbt_names), dtype=torch.int64)
         self._tables = None
-        self._ws = OrderedDict()      # LRU over (batch, samples): ragged validation clips must not grow memory unboundedly
         self._ws_cap = max(1, int(os.environ.get("SEHIP_WS_CACHE", "4")))
-        self.storage_epoch = 0        # bumped whenever the flat buffers are re-created (captured hipGraphs go stale)
-        self._anchor = None
-        self._grads_live = False
 
         # persistent STFT buffers (checkpoint compatibility; the FFT kernels do not read them)
         an, sy, win = _stft_bases(win_len, fft_len)
@@ -85,39 +68,9 @@ class DCCRN(nn.Module):
         self.istft.register_buffer("weight", torch.from_numpy(sy[:, None, :]))
         self.istft.register_buffer("window", torch.from_numpy(win[None, :, None]))
         self.istft.register_buffer("enframe", torch.eye(win_len)[:, None, :])
-        self.encoder, self.decoder, self.enhance = nn.ModuleList(), nn.ModuleList(), _Node()
-        self._params, self._buffers_named, self._nbt_named = [], [], []
-        for name, shape, kind in L.specs:
-            parts = name.split(".")
-            node = self._descend(parts[:-1])
-            if kind == "param":
-                off, _ = L.param_off[name]
-                p = nn.Parameter(self._flat[off:off + int(np.prod(shape))].view(shape))
-                node.register_parameter(parts[-1], p)
-                self._params.append((name, p))
-            elif kind == "buffer":
-                off, _ = L.buffer_off[name]
-                node.register_buffer(parts[-1], self._bflat[off:off + int(np.prod(shape))].view(shape))
-                self._buffers_named.append((name, node, parts[-1]))
-            else:
-                node.register_buffer(parts[-1], self._nbt[L.nbt_idx[name]])
-                self._nbt_named.append((name, node, parts[-1]))
+        self._build_flat(list_roots=("encoder", "decoder"))   # registration order encoder, decoder, enhance = the reference's
+                                                               # parameters() order (optimizer state indices interchange)
         self.reset_parameters()
-        self._register_state_dict_hook(_clone_state_hook)
-
-    # ---- construction helpers ----------------------------------------------------------------------
-    def _descend(self, parts):
-        node = self
-        for q, key in enumerate(parts):
-            if isinstance(node, nn.ModuleList):
-                while len(node) <= int(key):
-                    node.append(_Node())
-                node = node[int(key)]
-            else:
-                if not hasattr(node, key):
-                    node.add_module(key, _Node())
-                node = getattr(node, key)
-        return node
 
     def reset_parameters(self):
         """Same distributions as the reference constructors: conv N(0,0.05)/bias 0 (src/model/dccrn.py:352-355,
@@ -147,75 +100,13 @@ class DCCRN(nn.Module):
                 getattr(node, leaf).fill_(1.0 if leaf in ("RVrr", "RVii") else 0.0)
             self._nbt.zero_()
 
-    # ---- flat storage follows the module across devices ---------------------------------------------
-    def _apply(self, fn, *a, **k):
-        super()._apply(fn, *a, **k)
-        L = self.static.layout
-        dev = self._params[0][1].device
-        flat = torch.zeros(L.n_params, device=dev)
-        for name, p in self._params:
-            off, shape = L.param_off[name]
-            v = flat[off:off + p.numel()].view(shape)
-            v.copy_(p.data)
-            p.data = v
-            p.grad = None
-        bflat = torch.zeros(max(L.n_buffers, 1), device=dev)
-        for name, node, leaf in self._buffers_named:
-            off, shape = L.buffer_off[name]
-            v = bflat[off:off + int(np.prod(shape))].view(shape)
-            v.copy_(getattr(node, leaf))
-            node._buffers[leaf] = v
-        nbt = torch.zeros(len(L.nbt_names), dtype=torch.int64, device=dev)
-        for name, node, leaf in self._nbt_named:
-            i = L.nbt_idx[name]
-            nbt[i] = getattr(node, leaf).to(torch.int64)
-            node._buffers[leaf] = nbt[i]
-        self._flat, self._bflat, self._nbt = flat, bflat, nbt
-        for ws in self._ws.values():
-            ws.close()
-        self._gflat, self._tables, self._ws, self._anchor, self._grads_live = None, None, OrderedDict(), None, False
-        self.storage_epoch += 1
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def flat_grads(self):
-        if self._gflat is None or self._gflat.device != self._flat.device:
-            self._gflat = torch.zeros_like(self._flat)
-        return self._gflat
-
-    def bind_grads(self):
-        """Make every p.grad a view into flat_grads (what the fused optimizer and the all-reduce operate on)."""
-        L = self.static.layout
-        g = self.flat_grads
-        for name, p in self._params:
-            off, shape = L.param_off[name]
-            p.grad = g[off:off + p.numel()].view(shape)
-
     # ---- HIP path -------------------------------------------------------------------------------------
     def workspace(self, batch, nsample):
-        dev = self._flat.device
-        if dev.type != "cuda":
-            raise SehipError(f"DCCRN parameters are on {dev}: the HIP path needs a gfx950 GPU (no CPU fallback); "
-                             "call model.to('cuda') first")
+        dev = self._require_gpu("DCCRN")
         if self._tables is None:
             self._tables = plan.DeviceTables(self.static, dev)
-        key = (batch, nsample)
-        ws = self._ws.get(key)
-        if ws is None:
-            # evict the least recently used shapes first (never one a captured hipGraph points into)
-            while len(self._ws) >= self._ws_cap:
-                victim = next((k for k, w in self._ws.items() if not w.pinned), None)
-                if victim is None:
-                    break
-                self._ws.pop(victim).close()
-            ws = self._ws[key] = plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev)
-        else:
-            self._ws.move_to_end(key)
-        return ws
+        return self._lru_get((batch, nsample), self._ws_cap,
+                             lambda: plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev))
 
     def _run_forward(self, wav):
         ws = self.workspace(wav.shape[0], wav.shape[-1])
@@ -228,15 +119,7 @@ class DCCRN(nn.Module):
         if not self.training:
             raise SehipError("DCCRN.backward in eval mode (running-statistics BatchNorm) is not built")
         g = grad_out.reshape(ws.B, ws.length).contiguous().float()
-        accumulate = self._grads_live and self._params[0][1].grad is not None
-        if accumulate:
-            tmp = torch.empty_like(self.flat_grads)
-            ws.backward(g, self._flat, tmp)
-            self.flat_grads.add_(tmp)
-        else:
-            ws.backward(g, self._flat, self.flat_grads)
-        self.bind_grads()
-        self._grads_live = True
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst))
 
     def forward(self, inputs, lens=None):
         if inputs.dim() == 2:
@@ -256,13 +139,6 @@ class DCCRN(nn.Module):
         for name, p in self.named_parameters():
             (biases if "bias" in name else weights).append(p)
         return [{"params": weights, "weight_decay": weight_decay}, {"params": biases, "weight_decay": 0.0}]
-
-
-def _clone_state_hook(module, state_dict, prefix, local_metadata):
-    # parameters are views of one flat buffer; give every checkpoint entry its own storage like the reference's
-    for k in list(state_dict.keys()):
-        state_dict[k] = state_dict[k].detach().clone()
-    return state_dict
 
 
 def _stft_bases(win_len, fft_len):

@@ -35,14 +35,14 @@ class CSrc(C.Structure):
 
 class CDst(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("T", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("toff", C.c_int32),
-                ("fmul", C.c_int32), ("fadd", C.c_int32), ("is_f32", C.c_int32)]
+                ("fmul", C.c_int32), ("fadd", C.c_int32), ("is_f32", C.c_int32), ("tmul", C.c_int32)]
 
 
 class CGemmDesc(C.Structure):
     _fields_ = [("src", CSrc * 4), ("dst", CDst * 2), ("ktab", C.c_void_p), ("ntab", C.c_void_p), ("W", C.c_void_p),
                 ("bias", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32),
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
-                ("pad_", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
+                ("tmul", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
                 ("res", C.c_void_p)]
 
 
@@ -263,6 +263,25 @@ def pad_ktab(rows):
     kp = round_up(k, 64)
     rows = rows + [(-1, 0, 0, 0)] * ((kp - k) // 8)
     return np.asarray(rows, dtype=np.int32).reshape(-1, 4), kp
+
+
+def bind_chunk_table(src_tab, out_tab, kt_off, nchunks, geometry):
+    """Binds the chunk rows [kt_off, kt_off + nchunks) of a (src, frame offset, row offset, channel offset) table to the
+    geometry [(F, C)] of the product's sources: [src, (toff << 16) | (fadd & 0xffff), element delta, rows of a narrow chunk]
+    (sehip_kchunk in include/sehip.h)."""
+    rows = src_tab[kt_off:kt_off + nchunks]
+    out = out_tab[kt_off:kt_off + nchunks]
+    for q, (F, Cc) in enumerate(geometry):
+        m = rows[:, 0] == q
+        if not m.any():
+            continue
+        toff, fadd, coff = rows[m, 1].astype(np.int64), rows[m, 2].astype(np.int64), rows[m, 3].astype(np.int64)
+        narrow = Cc == 2
+        delta = (toff * F + fadd) * Cc + (0 if narrow else coff)
+        assert np.abs(delta).max() < 2 ** 31 and np.abs(toff).max() < 2 ** 15 and np.abs(fadd).max() < 2 ** 15
+        out[m, 1] = (((toff << 16) | (fadd & 0xffff)) & 0xffffffff).astype(np.uint32).view(np.int32)
+        out[m, 2] = delta.astype(np.int32)
+        out[m, 3] = coff.astype(np.int32) if narrow else 0
 
 
 # --------------------------------------------------------------------------------------------------
@@ -717,19 +736,7 @@ class DCCRNWorkspace:
         # chunk table bound to this workspace's source geometry: [src, (toff<<16)|(fadd&0xffff), element delta, npieces]
         kt = st.ktab.copy()
         for name, s in st.specs.items():
-            rows = st.ktab[s.kt_off:s.kt_off + s.K // 8]
-            out = kt[s.kt_off:s.kt_off + s.K // 8]
-            for q, (bname, mode) in enumerate(s.srcs):
-                b = self.bufs[bname]
-                m = rows[:, 0] == q
-                toff, fadd, coff = rows[m, 1].astype(np.int64), rows[m, 2].astype(np.int64), rows[m, 3].astype(np.int64)
-                narrow = b.C == 2
-                delta = (toff * b.F + fadd) * b.C + (0 if narrow else coff)
-                assert np.abs(delta).max() < 2 ** 31 and np.abs(toff).max() < 2 ** 15 and np.abs(fadd).max() < 2 ** 15
-                out[m, 1] = ((toff << 16) | (fadd & 0xffff)).astype(np.int64).astype(np.uint32).view(np.int32) if False else \
-                    (((toff << 16) | (fadd & 0xffff)) & 0xffffffff).astype(np.uint32).view(np.int32)
-                out[m, 2] = delta.astype(np.int32)
-                out[m, 3] = coff.astype(np.int32) if narrow else 0
+            bind_chunk_table(st.ktab, kt, s.kt_off, s.K // 8, [(self.bufs[b].F, self.bufs[b].C) for b, _ in s.srcs])
         self.ktab_dev = torch.from_numpy(kt).to(self.device)
         for name, s in st.specs.items():
             d = CGemmDesc()

@@ -1,0 +1,308 @@
+"""GPU parity of the complex DCUnet HIP path (BASELINE config C2):
+  * the kernels of csrc/rbn.hip and csrc/dcunet.hip op-locally against the oracle's functions on shared inputs,
+  * every convolution / transposed convolution / its input and weight gradients "teacher-forced" from the HIP path's own stored
+    activations (one bf16 rounding of the output),
+  * the whole train-mode forward + mse loss + backward and the eval forward against VECTORS OF THE IMPORTED REFERENCE
+    (tests/golden/dcunet_tiny.npz: the tiny model's 5 / 10 complex channels are stored as 8 / 16 here),
+  * the headline shape [64, 1, 257, 257, 2] of config C2 (model_complexity 45 -> 31 / 62 complex channels): one Solver step,
+    and B=2 of the same model against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dcunet_oracle as D
+from util import load_golden, rel_err, max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def to_ref(buf, cr):
+    """channels-last [B, T, F, 2*Cs] bf16 device buffer -> oracle layout [B, cr, T, F, 2] fp32 (padding channels dropped)."""
+    x = buf.t.float().cpu()
+    cs = x.shape[-1] // 2
+    return torch.stack([x[..., :cr], x[..., cs:cs + cr]], dim=-1).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def padding_is_zero(buf, cr):
+    x = buf.t.float()
+    cs = x.shape[-1] // 2
+    return float(x[..., cr:cs].abs().max()) == 0.0 and float(x[..., cs + cr:].abs().max()) == 0.0 if cr < cs else True
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    """The reference's tiny model (weights from the golden file), one forward/backward through libsehip."""
+    from sehip.model import DCUnet
+    from sehip.loss import mse_loss
+    g = load_golden("dcunet_tiny.npz")
+    model = DCUnet(data_type=True, model_complexity=8, model_depth=10)
+    ref_sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    model.load_state_dict(ref_sd, strict=False)
+    model = model.cuda().train()
+    x, tgt = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
+    est = model(x.cuda())
+    loss = mse_loss(est, tgt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    ws = model.workspace(2, 257, 33)
+    grads = {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters()}
+    return dict(g=g, model=model, ws=ws, est=est.detach().cpu(), loss=float(loss.detach()), grads=grads, p=ref_sd, x=x, tgt=tgt,
+                sz=D.dcunet_sizes(8, 10, 1))
+
+
+def test_whole_chain_vs_reference_vectors(tiny):
+    g = tiny["g"]
+    assert rel_err(tiny["est"], g["train_out"]) < 3e-2
+    assert abs(tiny["loss"] - float(g["loss"])) < 2e-3 * float(g["loss"])
+    num = den = 0.0
+    for k, got in tiny["grads"].items():
+        ref = torch.from_numpy(g["grad." + k])
+        num += float(((got.double() - ref.double()) ** 2).sum()); den += float((ref.double() ** 2).sum())
+    print(f"DCUnet tiny vs reference vectors: output rel {rel_err(tiny['est'], g['train_out']):.3e}, loss {tiny['loss']:.6f} vs "
+          f"{float(g['loss']):.6f}, global grad rel {(num / den) ** 0.5:.3e}")
+    assert (num / den) ** 0.5 < 0.1
+    sd = tiny["model"].state_dict()
+    for k in g:
+        if k.startswith("stat."):
+            tol = 2e-2 if k.endswith("running_var") else 1e-2
+            assert rel_err(sd[k[5:]].cpu().float(), torch.from_numpy(g[k]).float()) < tol, k
+    assert int(sd["encoder0.bn.bn_re.num_batches_tracked"]) == 1 and int(sd["encoders.0.bn.bn_im.num_batches_tracked"]) == 1
+
+
+def test_eval_forward_vs_reference_vectors():
+    from sehip.model import DCUnet
+    g = load_golden("dcunet_tiny.npz")
+    model = DCUnet(data_type=True, model_complexity=8, model_depth=10)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=False)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        out = model(torch.from_numpy(g["x"]).cuda())
+    assert rel_err(out.cpu(), g["eval_out"]) < 3e-2
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_encoder_conv_op_local(tiny, i):
+    ws, p, sz, st = tiny["ws"], tiny["p"], tiny["sz"], tiny["model"].static
+    b = ws.bufs
+    cin, cout = sz["enc_ch"][i], sz["enc_ch"][i + 1]
+    x = (to_ref(b["x0"], 1) if i == 0 else to_ref(b[f"ze{i - 1}"], cin)).requires_grad_(True)
+    q = {k: (bf(v) if k.endswith("weight") else v).clone().requires_grad_(True) for k, v in p.items() if k.startswith(f"encoder{i}.conv.")}
+    y = D.complex_conv2d(x, q, f"encoder{i}.conv.", sz["enc_s"][i], sz["enc_p"][i])
+    assert rel_err(to_ref(b[f"ye{i}"], cout), y.detach()) < 4e-3
+    assert padding_is_zero(b[f"ye{i}"], cout) and padding_is_zero(b[f"ze{i}"], cout)
+    dy = to_ref(b[f"dye{i}"], cout)
+    names = sorted(q)
+    outs = torch.autograd.grad((y * dy).sum(), [x] + [q[k] for k in names])
+    if i > 0:
+        want = outs[0] + (to_ref(b[f"dskip{i - 1}"], cin) if i - 1 < 4 else 0)   # the dgrad adds the skip-connection gradient (res)
+        assert rel_err(to_ref(b[f"dze{i - 1}"], cin), want) < 6e-3
+    for k, gref in zip(names, outs[1:]):
+        got = tiny["grads"][k]
+        if k.endswith("weight"):
+            assert rel_err(got, gref) < 5e-3, k
+        else:
+            assert float((got - gref).norm()) < 5e-3 * float(outs[1 + names.index(k.replace("bias", "weight"))].norm()) + 1e-6, k
+
+
+@pytest.mark.parametrize("j", range(5))
+def test_decoder_deconv_op_local(tiny, j):
+    ws, p, sz, st = tiny["ws"], tiny["p"], tiny["sz"], tiny["model"].static
+    b, n = ws.bufs, 5
+    c1, c2, cout = sz["dec_ch"][j], sz["enc_ch"][n - j], sz["dec_ch"][j + 1]
+    skip = to_ref(b[f"ze{n - 1 - j}"], c2).requires_grad_(True)
+    if j == 0:
+        leaves, cat = [skip], skip
+    else:
+        a = to_ref(b[f"zd{j - 1}"], c1).requires_grad_(True)
+        leaves, cat = [a, skip], torch.cat([a, skip], dim=1)
+    q = {k: (bf(v) if k.endswith("weight") else v).clone().requires_grad_(True) for k, v in p.items() if k.startswith(f"decoder{j}.transconv.")}
+    y = D.complex_conv_transpose2d(cat, q, f"decoder{j}.transconv.", sz["dec_s"][j], sz["dec_p"][j])
+    assert rel_err(to_ref(b[f"yd{j}"], cout), y.detach()) < 4e-3
+    dy = to_ref(b[f"dyd{j}"], cout)
+    names = sorted(q)
+    outs = torch.autograd.grad((y * dy).sum(), leaves + [q[k] for k in names])
+    if j == 0:
+        assert rel_err(to_ref(b["dze4"], c2), outs[0]) < 6e-3
+    else:
+        assert rel_err(to_ref(b[f"dzd{j - 1}"], c1), outs[0]) < 6e-3
+        assert rel_err(to_ref(b[f"dskip{n - 1 - j}"], c2), outs[1]) < 6e-3
+    for k, gref in zip(names, outs[len(leaves):]):
+        if k.endswith("weight"):
+            assert rel_err(tiny["grads"][k], gref) < 5e-3, k
+
+
+@pytest.mark.parametrize("tag", [f"e{i}" for i in range(5)] + [f"d{j}" for j in range(5)])
+def test_batchnorm_leakyrelu_op_local(tiny, tag):
+    ws, p, sz = tiny["ws"], tiny["p"], tiny["sz"]
+    b = ws.bufs
+    enc, idx = tag[0] == "e", int(tag[1])
+    cr = sz["enc_ch"][idx + 1] if enc else sz["dec_ch"][idx + 1]
+    pre = f"encoder{idx}.bn." if enc else f"decoder{idx}.bn."
+    y = to_ref(b[("ye" if enc else "yd") + str(idx)], cr).requires_grad_(True)
+    q = {k: v.clone() for k, v in p.items() if k.startswith(pre)}
+    leaves = {k: q[k].requires_grad_(True) for k in q if k.endswith((".weight", ".bias"))}
+    z = F.leaky_relu(D.complex_batchnorm2d(y, q, pre, True), 0.01)
+    assert rel_err(to_ref(b[("ze" if enc else "zd") + str(idx)], cr), z.detach()) < 4e-3
+    dz = to_ref(b[("dze" if enc else "dzd") + str(idx)], cr)
+    names = sorted(leaves)
+    outs = torch.autograd.grad((z * dz).sum(), [y] + [leaves[k] for k in names])
+    assert rel_err(to_ref(b[("dye" if enc else "dyd") + str(idx)], cr), outs[0]) < 8e-3
+    for k, gref in zip(names, outs[1:]):
+        assert rel_err(tiny["grads"][k], gref) < 5e-3, k
+
+
+def test_linear_tanh_mask_op_local(tiny):
+    """csrc/dcunet.hip: 1x1 complex conv + tanh + polar mask + the two transposes, forward and backward."""
+    ws, p, sz = tiny["ws"], tiny["p"], tiny["sz"]
+    b = ws.bufs
+    cr = sz["dec_ch"][-1]
+    zq = to_ref(b["zd4"], cr).requires_grad_(True)
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("linear.")}
+    x = tiny["x"]
+    mask = torch.tanh(D.complex_conv2d(zq, q, "linear.", 1, 0)).transpose(2, 3)
+    assert rel_err(ws.mask_ws.cpu(), mask.detach().transpose(2, 3)[:, 0]) < 1e-5
+    real, imag = x[..., 0], x[..., 1]
+    mr, mi = mask[..., 0], mask[..., 1]
+    x_mag, x_phase = torch.sqrt(real ** 2 + imag ** 2 + 1e-8), torch.atan2(imag, real)
+    mm = (mr ** 2 + mi ** 2) ** 0.5
+    ph = x_phase + torch.atan2(mi / (mm + 1e-8), mr / (mm + 1e-8))
+    est = torch.stack([torch.tanh(mm) * x_mag * torch.cos(ph), torch.tanh(mm) * x_mag * torch.sin(ph)], dim=-1)
+    assert rel_err(tiny["est"], est.detach()) < 1e-5
+    dout = 2.0 * (tiny["est"] - tiny["tgt"]) / tiny["tgt"].numel()            # d mse / d est
+    names = sorted(q)
+    outs = torch.autograd.grad((est * dout).sum(), [zq] + [q[k] for k in names])
+    assert rel_err(to_ref(b["dzd4"], cr), outs[0]) < 6e-3                     # bf16 output
+    for k, gref in zip(names, outs[1:]):
+        assert rel_err(tiny["grads"][k], gref) < 1e-4, k
+
+
+def test_masking_modes_and_rejections():
+    from sehip.model import DCUnet
+    from sehip import SehipError
+    g = load_golden("dcunet_tiny.npz")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    x = torch.from_numpy(g["x"])
+    for mode in ("C", "R"):
+        model = DCUnet(data_type=True, model_complexity=8, model_depth=10, masking_mode=mode)
+        model.load_state_dict(sd, strict=False)
+        model = model.cuda().eval()
+        with torch.no_grad():
+            out = model(x.cuda()).cpu()
+        ref = D.dcunet_forward(sd, x, model_complexity=8, model_depth=10, masking_mode=mode, training=False)
+        assert rel_err(out, ref) < 3e-2, mode
+    model = DCUnet(data_type=True, model_complexity=8, model_depth=10).cuda()
+    with pytest.raises(SehipError):
+        model(torch.zeros(1, 1, 257, 40, 2, device="cuda"))      # frames != 1 mod 32: the skip connections do not line up
+    with pytest.raises(SehipError):
+        DCUnet(data_type=False)
+
+
+def c2_config(tmp, complexity=45):
+    from sehip.utils import dict2obj
+    return dict2obj({
+        "seed": 10, "root": None, "ha": None,
+        "model": {"name": "dcunet", "audio_channels": 1, "num_spk": 1, "n_fft": 512, "hop_length": 128, "win_length": 512,
+                  "center": True, "model_complexity": complexity, "model_depth": 10, "data_type": True, "padding_mode": "zeros"},
+        "optim": {"optim": "adam", "lr": 3e-4, "beta1": 0.9, "beta2": 0.999, "loss": "mse", "clip_grad": 5, "pit": False, "load": False},
+        "dset": {"name": "synthetic"},
+        "solver": {"epochs": 1, "save_checkpoint_interval": 1000, "all_steps": True, "total_steps": 0, "patience": 0,
+                   "root": str(tmp), "resume": None, "preloaded_model": None,
+                   "validation": {"interval": 1000, "metric": "loss", "total_steps": 0}, "test": {"interval": 1000}},
+    })
+
+
+def oracle_train_steps(p, specs, targets, complexity, lr=3e-4, clip=5.0):
+    """The reference's step (mse in the STFT domain, clip_grad_norm_, torch.optim.Adam) on the oracle's functional model."""
+    names = [k for k in p if D.is_trainable(k)]
+    leaves = {k: torch.nn.Parameter(p[k].clone()) for k in names}
+    opt = torch.optim.Adam([leaves[k] for k in names], lr=lr, betas=(0.9, 0.999))
+    losses = []
+    work = dict(p); work.update(leaves)
+    for x, tgt in zip(specs, targets):
+        stats = {}
+        est = D.dcunet_forward(work, x, model_complexity=complexity, model_depth=10, training=True, stats_out=stats)
+        loss = F.mse_loss(est, tgt)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([leaves[k] for k in names], clip)
+        opt.step()
+        work.update(stats)
+        losses.append(float(loss.detach()))
+    return losses, {k: v.detach() for k, v in work.items()}
+
+
+def test_solver_two_steps_stft_branch_vs_oracle(tmp_path):
+    """Solver.train() with model 'dcunet': stft_custom on mixture and sources (src/solver.py:454-458), mse in the STFT domain,
+    clip + Adam -- two steps on the full-width model (complexity 45) at B=2, 8192 samples (65 frames), against the oracle."""
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    from oracle import stft_oracle as S
+    cfg = c2_config(tmp_path)
+    torch.manual_seed(cfg.seed)
+    model = distrib.get_model(cfg.model)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith(("encoders.", "decoders."))}
+    opt = distrib.get_optimizer(cfg.optim, model)
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for s in range(2):
+        clean = 0.1 * torch.randn(2, 1, 1, 8192, generator=g)
+        noisy = clean[:, 0] + 0.05 * torch.randn(2, 1, 8192, generator=g)
+        batches.append((noisy, clean, [None], [None], ["x"], [s]))
+    log = ScalarLog()
+    solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), train_dataloader=batches,
+                    validation_dataloader=[batches[0]], device="gpu", writer=log)
+    solver._run_one_epoch(0, 1, train=True)
+    losses = [v for (t, v, _s) in log.scalars if t == "Train/Loss_step"]
+    specs = [torch.from_numpy(S.stft_custom(b[0].numpy(), 512, 128, 512)) for b in batches]
+    tgts = [torch.from_numpy(S.stft_custom(b[1][:, 0].numpy(), 512, 128, 512)) for b in batches]
+    assert specs[0].shape == (2, 1, 257, 65, 2)
+    ref_losses, work = oracle_train_steps(p, specs, tgts, 45)
+    print("DCUnet Solver steps: hip", losses, "oracle", ref_losses)
+    for a, b_ in zip(losses, ref_losses):
+        assert abs(a - b_) < 2e-2 * abs(b_), (losses, ref_losses)
+    sd = {k: v.cpu() for k, v in solver.model.state_dict().items()}
+    wd = torch.cat([(sd[k] - work[k]).reshape(-1) for k in work if D.is_trainable(k)]).abs()
+    assert float(wd.max()) < 2 * 2.1 * 3e-4 and float(wd.mean()) < 0.35 * 2 * 3e-4, (float(wd.max()), float(wd.mean()))
+
+
+def test_c2_headline_shape_one_step(tmp_path):
+    """BASELINE config C2: batch 64 of [1, 257, 257, 2] spectra (32768 samples, n_fft 512, hop 128), DCUnet-10 complexity 45.
+    One full Solver step at that size (finite loss, non-zero gradients for every tensor, padding channels exactly zero), and
+    the first 2 clips of the same batch through the oracle: the enhanced spectra agree."""
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    cfg = c2_config(tmp_path)
+    torch.manual_seed(cfg.seed)
+    model = distrib.get_model(cfg.model)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith(("encoders.", "decoders."))}
+    opt = distrib.get_optimizer(cfg.optim, model)
+    solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+    g = torch.Generator().manual_seed(0)
+    clean = 0.1 * torch.randn(64, 1, 1, 32768, generator=g)
+    noisy = clean[:, 0] + 0.05 * torch.randn(64, 1, 32768, generator=g)
+    mix, src = solver._prepare_batch(noisy, clean)
+    assert tuple(mix.shape) == (64, 1, 257, 257, 2) and tuple(src.shape) == (64, 1, 257, 257, 2)
+    model.eval()
+    with torch.no_grad():
+        est_eval = model(mix[:2]).cpu()
+    ref_eval = D.dcunet_forward(p, mix[:2].cpu(), model_complexity=45, model_depth=10, training=False)
+    assert rel_err(est_eval, ref_eval) < 3e-2
+    loss, metric = solver.train_step(mix, src)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and float(metric[0]) > 0
+    for k, v in model.named_parameters():
+        assert float(v.grad.abs().max()) > 0 and bool(torch.isfinite(v.grad).all()), k
+    ws = model.workspace(64, 257, 257)
+    assert padding_is_zero(ws.bufs["zd4"], 62) and padding_is_zero(ws.bufs["ze0"], 31)
+    # batch statistics of the B=64 training forward, checked through a property: BatchNorm output before the LeakyReLU has
+    # zero mean / unit variance per channel -> reproduce from the stored pre-activation
+    y = ws.bufs["ye1"].t.float()
+    m = y.mean(dim=(0, 1, 2))[:62]
+    sdv = y.var(dim=(0, 1, 2), unbiased=True)[:62]
+    rv = model.state_dict()["encoder1.bn.bn_re.running_var"]
+    assert rel_err(rv.cpu(), (0.9 + 0.1 * sdv).cpu()) < 1e-2 and float(m.abs().max()) < 10
