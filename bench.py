@@ -50,6 +50,18 @@ def bench_config(length):
     })
 
 
+def dcunet_config(complexity=45):
+    """BASELINE config C2: DCUnet-10 (the reference has no depth 16: SURVEY section 0.1), complex, n_fft 512 / hop 128, mse in
+    the STFT domain (src/solver.py:454-480), Adam 3e-4, clip 5."""
+    from sehip.utils import dict2obj
+    cfg = bench_config(0)
+    d = dict2obj({"name": "dcunet", "audio_channels": 1, "num_spk": 1, "n_fft": 512, "hop_length": 128, "win_length": 512,
+                  "center": True, "model_complexity": complexity, "model_depth": 10, "data_type": True, "padding_mode": "zeros"})
+    cfg.model = d
+    cfg.optim.loss = "mse"
+    return cfg
+
+
 def gemm_roofline(ws, reps=5):
     """Times every product launch of the step separately, groups them by the kernel instantiation libsehip picked, and
     returns the per-class table: launches per step, average launch duration and algorithmic TFLOP/s.
@@ -64,7 +76,7 @@ def gemm_roofline(ws, reps=5):
         if not name.endswith(".wg") and not d.W:
             continue  # recurrent-weight gradients exist only as wgrad launches
         fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
-        flops = 2.0 * d.M * d.N * _real_k(ws, name)
+        flops = 2.0 * d.M * _weight_entries(ws, name)   # algorithmic: padding channels / padded K columns do not count
         call(fn, C.byref(d), stream())
         kname = lib().sehip_last_kernel().decode()
         torch.cuda.synchronize()
@@ -87,9 +99,10 @@ def gemm_roofline(ws, reps=5):
     return rows
 
 
-def _real_k(ws, name):
-    s = ws.st.specs[name[:-3] if name.endswith(".wg") else name]
-    return int((s.widx[0] >= 0).sum()) if s.N > 0 else s.K
+def _weight_entries(ws, name):
+    specs = ws.pl.specs if hasattr(ws, "pl") else ws.st.specs
+    s = specs[name[:-3] if name.endswith(".wg") else name]
+    return int((s.widx >= 0).sum())
 
 
 PARITY_STEPS = 4           # 1 warm-up + 3 timed oracle steps; the HIP side runs the same 4
@@ -189,7 +202,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dccrn, 64 for dcunet)")
+    ap.add_argument("--workload", choices=("dccrn", "dcunet"), default="dccrn",
+                    help="dccrn = BASELINE configs[1], the headline metric; dcunet = configs[2] (DCUnet-10, STFT-domain mse, B=64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as two captured hipGraphs instead of launching "
@@ -200,6 +215,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core of the affinity mask)")
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("STATE", "OUT"))
     args = ap.parse_args()
+    dcu = args.workload == "dcunet"
+    if not args.batch:
+        args.batch = 64 if dcu else BATCH
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], args.batch,
                             args.cpu_threads or len(os.sched_getaffinity(0)))
@@ -209,8 +227,11 @@ def main():
     from sehip.solver import Solver, ScalarLog
     rank, world, local = distrib.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    n = int(SR * CLIP_S)
-    cfg = bench_config(n)
+    n = 32768 if dcu else int(SR * CLIP_S)        # C2: 257 frames (= 1 mod 32, the depth-10 constraint) at hop 128
+    clip_s = n / SR
+    cfg = dcunet_config() if dcu else bench_config(n)
+    if dcu:
+        args.no_cpu_baseline = True               # the CPU baseline / parity block belong to the headline workload (tests pin C2)
     torch.manual_seed(cfg.seed)
     model = distrib.get_model(cfg.model)
     opt = distrib.get_optimizer(cfg.optim, model)
@@ -218,6 +239,11 @@ def main():
     dev = solver.device
     noisy, clean = make_batch(args.batch, n, rank, dev)
     mixture, sources = solver._prepare_batch(noisy, clean)
+    if dcu:
+        # the reference transforms mixture and sources inside every step (src/solver.py:454-458): timed with the step
+        base_step = (lambda fn: (lambda mix_, src_: fn(*solver._prepare_batch(noisy, clean))))
+    else:
+        base_step = lambda fn: fn
 
     def sync():
         if world > 1:
@@ -237,7 +263,7 @@ def main():
             hip_par = hip_parity_run(solver, model, mixture, sources)
     note(f"model built, batch staged on {dev}; warm-up {args.warmup} steps")
     args.eager = not args.graph
-    step_fn = solver.train_step if args.eager else solver.train_step_graphed
+    step_fn = base_step(solver.train_step if args.eager else solver.train_step_graphed)
     # the dependent chain of the step runs on a high-priority stream; the weight gradients (side stream, default
     # priority) then only take the CUs the chain leaves idle
     lo, hi = torch.cuda.Stream.priority_range()
@@ -269,20 +295,22 @@ def main():
         dt = float(t)
     ms = dt / args.steps * 1e3
     note(f"{ms:.2f} ms/step")
-    value = world * args.batch * CLIP_S * args.steps / dt
+    value = world * args.batch * clip_s * args.steps / dt
 
     out = {
-        "metric": "audio-sec/sec training, DCCRN 16kHz 2s bs32", "value": value, "unit": "audio-s/s", "n_gpus": world,
+        "metric": "audio-sec/sec training, DCUnet-10 16kHz 2.048s bs64" if dcu else "audio-sec/sec training, DCCRN 16kHz 2s bs32", "value": value, "unit": "audio-s/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
-                               "clips, SI-SNR, Adam 3e-4, clip 5", "per_gpu_batch": args.batch,
+        "config": {"workload": ("DCUnet-10 (complex, model_complexity 45 -> 31/62 channels, mask E) train step on [64,1,257,257,2] "
+                                "spectra: stft_custom of mixture and sources, mse in the STFT domain, Adam 3e-4, clip 5" if dcu else
+                                "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
+                                "clips, SI-SNR, Adam 3e-4, clip 5"), "per_gpu_batch": args.batch,
                    "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
                    "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step" if args.h2d else "resident in HBM"},
         "final_loss": float(loss),
     }
     if rank == 0 and not args.no_roofline:
-        ws = model.workspace(args.batch, n)
+        ws = model.workspace(args.batch, 257, 257) if dcu else model.workspace(args.batch, n)
         note("per-kernel roofline pass")
         rows = gemm_roofline(ws)
         top = rows[0]
@@ -300,7 +328,8 @@ def main():
                            "gflop_per_launch": top["gflop"] / top["launches"],
                            "all_product_kernels": {"ms_per_step": total_ms, "tflops": total_gf / total_ms,
                                                    "frac": total_gf / total_ms / PEAK_BF16_TFLOPS}}
-        out["step_tflops"] = 45.96e9 * args.batch / (ms * 1e-3) / 1e12
+        # algorithmic FLOPs per clip-step (SURVEY section 8d / BASELINE.md): DCCRN 45.96 GF, DCUnet-10 111.9 GF (fwd + bwd)
+        out["step_tflops"] = (111.9e9 if dcu else 45.96e9) * args.batch / (ms * 1e-3) / 1e12
         out["kernel_classes"] = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                   "tflops": round(r["tflops"], 1)} for r in rows[:10]]
     if do_cpu:

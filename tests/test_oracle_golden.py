@@ -220,3 +220,25 @@ def test_dcunet_oracle_matches_reference():
     for k, v in stats.items():
         assert rel_err(v, torch.from_numpy(g["stat." + k])) < 1e-5, k
     assert len(stats) == 40
+
+
+# ---- ConvTasNet: oracle/convtasnet_oracle.py vs the reference's activations / gradients
+def test_convtasnet_oracle_matches_reference():
+    from oracle import convtasnet_oracle as CT
+    g = load_golden("convtasnet_tiny.npz")
+    kw = dict(C=2, N=16, L=8, B=16, H=32, P=3, X=3, R=2, audio_channels=1)
+    p = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    taps = {}
+    est = CT.convtasnet_forward(leaves, torch.from_numpy(g["mix"]), taps=taps, **kw)
+    for k, v in taps.items():
+        assert rel_err(v.detach(), g["tap." + k]) < 2e-5, k
+    assert est.shape == (2, 2, 1, 404) and rel_err(est.detach(), g["est"]) < 2e-5
+    loss = O.loss_sisdr(est, torch.from_numpy(g["target"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    names = sorted(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    assert len(names) == len([k for k in g if k.startswith("grad.")])
+    for k, gr in zip(names, grads):
+        ref = torch.from_numpy(g["grad." + k])
+        assert float((gr - ref).norm()) <= 5e-4 * float(ref.norm()) + 1e-6, k
