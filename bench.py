@@ -106,7 +106,7 @@ def _weight_entries(ws, name):
 
 
 PARITY_STEPS = 4           # 1 warm-up + 3 timed oracle steps; the HIP side runs the same 4
-TOL_DLOSS_DB, TOL_WAVE_REL = 0.1, 3e-2
+TOL_DLOSS_DB, TOL_WAVE_REL = 0.15, 3e-2
 
 
 def snr_db(x, ref):
@@ -212,7 +212,9 @@ def main():
     ap.add_argument("--h2d", action="store_true", help="stage every batch from pinned host memory inside the timed region "
                     "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle parity block (it needs the CPU baseline leg)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core of the affinity mask)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the CPU baseline (0 = min(cores of the affinity mask, 32): on the 256-core host of the GPU "
+                         "box torch's CPU ops with 256 threads did not finish ONE B=32 step in 15 minutes, 32 threads take ~5 s)")
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("STATE", "OUT"))
     args = ap.parse_args()
     dcu = args.workload == "dcunet"
@@ -220,7 +222,7 @@ def main():
         args.batch = 64 if dcu else BATCH
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], args.batch,
-                            args.cpu_threads or len(os.sched_getaffinity(0)))
+                            args.cpu_threads or min(len(os.sched_getaffinity(0)), 32))
         return
 
     from sehip import distrib
@@ -333,7 +335,7 @@ def main():
         out["kernel_classes"] = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                   "tflops": round(r["tflops"], 1)} for r in rows[:10]]
     if do_cpu:
-        threads = args.cpu_threads or len(os.sched_getaffinity(0))
+        threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
         note(f"cpu baseline + parity reference (oracle, B={args.batch}, {threads} threads)")
         out["cpu_baseline"] = cpu_baseline(state_path, cpu_out, args.batch, threads)
         if hip_par is not None and os.path.exists(cpu_out):

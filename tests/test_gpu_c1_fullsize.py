@@ -106,11 +106,13 @@ def test_b32_train_step_vs_fp32_oracle(tmp_path):
     print(f"B=32 full size: loss hip {float(loss_t):.4f} oracle {loss_ref:.4f} | waveform rel {wav_rel:.3e} max-abs {wav_abs:.3e} | "
           f"global grad rel {grad_rel:.3e} | grad_norm metric hip {float(metric_t[0]):.3f} oracle {metric_ref:.3f} | "
           f"weights after Adam: max |dw| {float(wdiff.max()):.2e} mean |dw|/lr {float(wdiff.mean()) / lr:.3f}")
-    assert dloss < 0.1                      # dB; bf16 activation storage vs fp32
-    assert wav_rel < 3e-2
-    assert grad_rel < 0.2
+    # measured on MI355X (round 2): |d loss| 0.084 dB at a loss of 12.7 dB, waveform rel 7.2e-3, global gradient rel 1.0e-3,
+    # mean |dw| 0.046 lr -- the bounds leave ~2x for the run-to-run spread of the atomically accumulated weight gradients
+    assert dloss < 0.15                     # dB; bf16 activation storage vs fp32
+    assert wav_rel < 1.5e-2
+    assert grad_rel < 2e-2
     # the first Adam step moves every weight by ~lr * sign(g): agreement = the same sign almost everywhere
-    assert float(wdiff.max()) <= 2.05 * lr and float(wdiff.mean()) < 0.25 * lr
+    assert float(wdiff.max()) <= 2.05 * lr and float(wdiff.mean()) < 0.12 * lr
     for k in p:
         if k.endswith(("RVrr", "RVii")):
             assert rel_err(w_hip[k], p[k]) < 2e-2, k
@@ -146,7 +148,7 @@ def test_hip_vs_reference_vectors_legal_config():
     den = sum(n * n for n in norms.values())
     print(f"HIP vs reference vectors: waveform rel {rel_err(est, g['est']):.3e} dloss {abs(loss - float(g['loss'])):.4f} "
           f"global grad rel {(num / den) ** 0.5:.3e}")
-    assert (num / den) ** 0.5 < 0.25        # whole-chain bf16 bound (see test_gpu_dccrn_plan.py); op-local tests pin the kernels
+    assert (num / den) ** 0.5 < 5e-2        # measured 6.1e-3 (whole chain, bf16 storage); the op-local tests pin every kernel
     sd = model.state_dict()
     for k, v in sub(g, "state_after").items():
         if k.endswith(("RVrr", "RVii")):
