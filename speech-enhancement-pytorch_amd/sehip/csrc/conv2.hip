@@ -1,0 +1,446 @@
+// conv_gemm_v2_kernel: the LDS-patch implicit-GEMM of gemm.hip (conv_gemm_kernel) rebuilt around what bounded it.
+//
+// Round-1 kernel (128 x 128 tile, 4 waves, 2 workgroups per CU): per 64-deep K step every thread wrote 64 bytes of the weight
+// tile from registers into LDS (ds_write_b128: ~79 B/clk per CU, as costly as the 16 fragment reads of the step), with TWO
+// workgroup barriers around it, and tiles never crossed an utterance (T = 323 frames against 32-frame blocks: 8 % of the
+// workgroups' rows were padding).  27 % of the dense bf16 MFMA peak.
+//
+// Here (one 512-thread workgroup per CU, 8 waves as 4 (m) x 2 (n), tile 256 rows x 128 output channels):
+//   * the weight tile [128 n][64 k] goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, two instructions per wave and K step:
+//     no VGPR round trip, no ds_write), through a ring of THREE 16 KB slots with a counted s_waitcnt vmcnt: tile s+2 is issued
+//     while tile s is multiplied, one tile stays in flight across the barrier.  The 16-byte XOR swizzle of the tile (conflict
+//     free b128 fragment reads) sits on the per-lane SOURCE address, the LDS image is lane-linear (what the DMA writes);
+//   * ONE raw s_barrier per K step (it publishes tile s and retires the reads of tile s-1 whose slot tile s+2 overwrites);
+//   * the weight tile is shared by 256 rows instead of 128: half the DMA bytes and half the barriers per FLOP;
+//   * rows are tiled over a VIRTUAL flat frame index: every utterance owns TT + 2 frames, the last two are padding, so a tile
+//     runs across utterance boundaries while "frame -1" / "frame TT" of an utterance still read zeros (the causal time padding
+//     of ComplexConv2d, src/model/dccrn.py:359-360, and the frame the reference drops after the transposed convolution,
+//     :193-196): 0.6 % padding rows instead of 8-16 %;
+//   * the input patch ((TB + 1) frames x FR rows x 64 channels, pitch 144 B) is still staged through registers (its image is
+//     padded, an LDS-DMA image cannot be), prefetched one channel chunk ahead; per-piece addresses and validity are computed
+//     once per workgroup.
+// Same operand / fragment / epilogue conventions as conv_gemm_kernel (weights are the MFMA A operand, a lane ends up with 4
+// consecutive output channels of a row; dense 64-channel runs leave through a wave-private LDS image as 16-byte pieces).
+#include <stdlib.h>
+#include "common.h"
+#include "../../../include/sehip.h"
+
+#define C2_MAXP 7          // 16-byte patch pieces per thread and 32-channel chunk
+#define C2_WSLOT 16384     // bytes per weight-tile slot: 128 rows x 128 B
+typedef __attribute__((address_space(3))) void c2_lds_void;
+typedef __attribute__((address_space(1))) const void c2_gvoid;
+typedef unsigned c2_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) c2_u32x4* c2_gvec_ptr;
+
+// 16 zero bytes: pieces outside a source (padding frames / rows) and the unused piece slots of a thread read this instead of
+// skipping the load, so that EVERY thread issues exactly C2_MAXP loads per prefetch: the counted s_waitcnt vmcnt below relies on it
+__device__ uint4 c2_zero16 = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ uint4 c2_add_bf16x8(uint4 a, uint4 r) {
+    const unsigned av[4] = {a.x, a.y, a.z, a.w}, rv[4] = {r.x, r.y, r.z, r.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf2(__uint_as_float(av[i] << 16) + __uint_as_float(rv[i] << 16),
+                        __uint_as_float(av[i] & 0xffff0000u) + __uint_as_float(rv[i] & 0xffff0000u));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__device__ __forceinline__ size_t c2_dst_off(const sehip_dst& d, int b, int t, int j) {
+    return (((size_t)b * d.T + t * (d.tmul > 1 ? d.tmul : 1) + d.toff) * d.F + (size_t)j * d.fmul + d.fadd) * d.C;
+}
+
+// WMW = waves along m (64 rows each): 2 -> 128-row tile, 256 threads, two workgroups per CU; 4 -> 256-row tile, 512 threads
+template <int NF, int WMW>
+__global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int B, int PP /* patch row pitch, elements */,
+                                                                 int FS /* patch rows per frame (>= FR) */) {
+    constexpr int BM = 64 * WMW, BN = 128, NTHR = 128 * WMW;
+    constexpr int TN = 4, TM = 4;          // 16 x 16 MFMA tiles per wave: 64 output channels x 64 rows
+    constexpr int NIT = 2 * NF, H = NF;    // K steps per 32-channel chunk: taps (2j, 2j + 1), j < H
+    constexpr int DW = 1024 / NTHR;        // weight-tile DMA instructions per thread and K step
+    static_assert(BM == 128 || BM == 256, "tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* sW = reinterpret_cast<uint4*>(smem);                                // 3 slots of [128][8] uint4, lane-linear
+    bf16_raw* patch = reinterpret_cast<bf16_raw*>(smem + 3 * C2_WSLOT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WMW, wn = wave / WMW;
+    const int ntn = d.Npad / BN;
+    const int TV = d.TT + 2;                                                   // virtual frames per utterance (2 padding frames)
+    // XCD-contiguous order, n-tile fastest (see gemm_kernel)
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = logical % ntn, mt = logical / ntn;
+    const int g0 = mt * TB, n0 = nt * BN;                                      // first virtual frame / output channel of the tile
+    const int f0 = d.cv_fadd;                                                  // patch row 0 <-> source row j*fmul + cv_fadd at j = 0
+
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int Ctot = C0 + C1;
+    const int nch = Ctot >> 5;                                                 // 32-channel chunks
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const int NP = (TB + 1) * FR * 4;
+
+    // ---- patch staging.  Piece u of this thread = 16 bytes at (patch frame p, row r, channel piece c4), packed once into
+    // pk[u] = p | (r*4 + c4) << 8 (-1: no such piece).  What depends on the frame -- which utterance / source frame a patch frame
+    // is, or that it is padding -- is the same for every piece of that frame: a table in LDS, filled once per workgroup
+    // (ftab[s][p] = b*T_s + x, -1 if invalid), instead of two integer divisions per piece and channel chunk.
+    const bf16_raw* s0p = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
+    const bf16_raw* s1p = reinterpret_cast<const bf16_raw*>(d.src[1].ptr);
+    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&c2_zero16);
+    int* ftab = reinterpret_cast<int*>(smem + 3 * C2_WSLOT + (size_t)(TB + 1) * FS * PP * 2);   // [2][TB + 1], behind the patch
+    const int dump = (TB + 1) * FS * PP + 4 * (TB + 1);                  // 16 bytes behind the table for the unused piece slots
+    if (tid < 2 * (TB + 1)) {
+        const int s = tid / (TB + 1), p = tid - s * (TB + 1);
+        const sehip_src& S = s ? d.src[1] : d.src[0];
+        const int sv = g0 + p + (s ? tmin1 : tmin0);
+        int v = -1;
+        if (sv >= 0 && (s == 0 || C1)) {
+            const int b = sv / TV, x = sv - b * TV;
+            if (b < B && x >= S.tlo && x < S.thi) v = b * S.T + x;
+        }
+        ftab[tid] = v;
+    }
+    int pk[C2_MAXP];
+    {
+        const int fr4 = FR * 4;
+#pragma unroll
+        for (int u = 0; u < C2_MAXP; ++u) {
+            const int idx = tid + NTHR * u;
+            const int p = idx / fr4, rem = idx - p * fr4;
+            pk[u] = idx < NP ? (p | (rem << 8)) : -1;
+        }
+    }
+    __syncthreads();
+    uint4 pr[C2_MAXP];
+    auto fetch_patch = [&](int ch) {
+        const int second = ch * 32 >= C0 ? 1 : 0;
+        const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+        const bf16_raw* base = (second ? s1p : s0p) + (ch * 32 - (second ? C0 : 0));
+        const int* ft = ftab + second * (TB + 1);
+        int fb[C2_MAXP];
+#pragma unroll
+        for (int u = 0; u < C2_MAXP; ++u) fb[u] = ft[pk[u] < 0 ? 0 : (pk[u] & 0xff)];   // all table reads in flight together
+#pragma unroll
+        for (int u = 0; u < C2_MAXP; ++u) {
+            const int rem = (pk[u] < 0 ? 0 : pk[u]) >> 8;
+            const int f = f0 + (rem >> 2);
+            const int ok = (int)(pk[u] >= 0) & (int)(fb[u] >= 0) & (int)((unsigned)f < (unsigned)sF);   // no short-circuit branches
+            const bf16_raw* q = base + ((fb[u] * sF + f) * sC + (rem & 3) * 8);
+            q = ok ? q : zero_page;
+            const c2_u32x4 x4 = *(c2_gvec_ptr)(q);       // explicit global-address-space load (a select of generic pointers is a flat load)
+            pr[u] = make_uint4(x4[0], x4[1], x4[2], x4[3]);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int u = 0; u < C2_MAXP; ++u) {
+            const int p = pk[u] & 0xff, rem = pk[u] >> 8;
+            const int at = pk[u] >= 0 ? (p * FS + (rem >> 2)) * PP + (rem & 3) * 8 : dump;   // branch-free: unused slots hit a dump
+            *reinterpret_cast<uint4*>(&patch[at]) = pr[u];
+        }
+    };
+
+    // ---- weight-tile DMA: piece q = tid + NTHR*i -> row r = q >> 3; LDS chunk c' = q & 7 holds tile chunk c = c' ^ (r & 7);
+    //      tile chunk c = tap (2j + (c >> 2)), channels 8*(c & 3) .. +7 of the 32-channel chunk
+    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
+    const bf16_raw* wsrc[DW];
+#pragma unroll
+    for (int i = 0; i < DW; ++i) {
+        const int q = tid + NTHR * i;
+        const int r = q >> 3, c = (q & 7) ^ (r & 7);
+        wsrc[i] = Wb + (size_t)(n0 + r) * d.K + (c >> 2) * Ctot + (c & 3) * 8;
+    }
+    auto issue_w = [&](int s) {                  // K step s = ch * H + j reads W columns (2j + {0, 1}) * Ctot + ch*32 ..
+        const int ch = s / H, j = s - ch * H;
+        const int kcol = 2 * j * Ctot + ch * 32;
+        unsigned char* slot = smem + (s % 3) * C2_WSLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < DW; ++i)
+            __builtin_amdgcn_global_load_lds((c2_gvoid*)(wsrc[i] + kcol), (c2_lds_void*)(slot + i * (NTHR * 16)), 16, 0, 0);
+    };
+
+    // per-lane patch offsets of its TM activation rows (element units, k-chunk of the lane included)
+    int abase[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * 64 + mi * 16 + (lane & 15);
+        const int tl = r / JB, jl = r - tl * JB;
+        abase[mi] = (tl * FS + jl * d.fmul) * PP + 8 * (lane >> 4);
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int S = nch * H;
+    // prologue: patch of chunk 0 through registers, weight tiles 0 and 1 in flight
+    fetch_patch(0);
+    issue_w(0);
+    if (S > 1) issue_w(1);
+    store_patch();
+    if (nch > 1) fetch_patch(1);           // next chunk's patch rides behind the first K steps
+
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool second = ch * 32 >= C0;
+        const int dt0 = (second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0);
+        const int dt1 = (second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0);
+        if (ch > 0) {
+            // every wave has finished reading the previous chunk's patch once it has passed this barrier
+            __builtin_amdgcn_s_barrier();
+            store_patch();                                    // (the compiler waits for the prefetched registers here)
+            if (ch + 1 < nch) fetch_patch(ch + 1);
+        }
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int s = ch * H + j;
+            // weight tile s has landed for this wave's own pieces; the barrier makes everybody's pieces (and the patch stores)
+            // visible and retires the reads of tile s-1.  Outstanding behind tile s: tile s+1 (DW DMAs) and, in the first two
+            // steps after a chunk boundary, the patch prefetch of the next chunk (C2_MAXP loads) issued behind it.
+            if (s + 1 >= S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (j <= 1 && ch + 1 < nch) {
+                if (DW == 4) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            } else {
+                if (DW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < S) issue_w(s + 2);
+            const uint4* sWs = sW + (s % 3) * (C2_WSLOT / 16);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                constexpr int dummy = 0; (void)dummy;
+                const int it = 2 * j + ks;
+                const int kt = it / NF, tap = it - kt * NF;
+                const int toff_e = ((kt ? dt1 : dt0) * FS + tap) * PP;
+                const int c = ks * 4 + (lane >> 4);
+                bf16x8 wf[TN], af[TM];
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int r = wn * 64 + ni * 16 + (lane & 15);
+                    wf[ni] = __builtin_bit_cast(bf16x8, sWs[r * 8 + (c ^ (r & 7))]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + toff_e]));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (as conv_gemm_kernel): dense 64-channel runs of a bf16 destination leave through a wave-private LDS image
+    constexpr int WROWS = 64, WCOLS = 64, TP = WCOLS + 8;
+    const int nw0 = n0 + wn * WCOLS;
+    sehip_nchunk first = d.ntab[nw0 >> 2];
+    bool dense;
+    {
+        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + (lane & 15)];
+        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * (lane & 15);
+        dense = __all(ok) && !(first.dst ? d.dst[1].is_f32 : d.dst[0].is_f32) && ((first.coff & 7) == 0) &&
+                (((first.dst ? d.dst[1].C : d.dst[0].C) & 7) == 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // every wave has finished reading the weight tiles and the patch: the LDS is free
+    if (dense) {
+        bf16_raw* tb_ = reinterpret_cast<bf16_raw*>(smem) + wave * (WROWS * TP);   // 9 KB per wave: inside the (now idle) weight ring + patch
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const f32x4 v = acc[ni][mi];
+                *reinterpret_cast<uint2*>(&tb_[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * (lane >> 4)]) =
+                    make_uint2(pack_bf2(v[0] + bv.x, v[1] + bv.y), pack_bf2(v[2] + bv.z, v[3] + bv.w));
+            }
+        }
+        const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
+        bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
+#pragma unroll
+        for (int itr = 0; itr < WROWS / 8; ++itr) {
+            const int row = itr * 8 + (lane >> 3), c8 = lane & 7;
+            const int rr = wm * WROWS + row;
+            const int tl = rr / JB, jl = rr - tl * JB;
+            const int gv = g0 + tl;
+            const int b = gv / TV, t = gv - b * TV;
+            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + c8 * 8]);
+            if (b < B && t < d.TT) {
+                const size_t off = c2_dst_off(dd, b, t, jl) + c8 * 8;
+                if (d.res && first.dst == 0)
+                    v = c2_add_bf16x8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(d.res) + first.coff + off));
+                *reinterpret_cast<uint4*>(dptr + off) = v;
+            }
+        }
+        return;
+    }
+    // direct scatter, 4 consecutive channels per lane (fp32 destinations, narrow or split column groups)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int rr = wm * 64 + mi * 16 + (lane & 15);
+        const int tl = rr / JB, jl = rr - tl * JB;
+        const int gv = g0 + tl;
+        const int b = gv / TV, t = gv - b * TV;
+        if (b >= B || t >= d.TT) continue;
+        const size_t ro0 = c2_dst_off(d.dst[0], b, t, jl);
+        const size_t ro1 = d.dst[1].ptr ? c2_dst_off(d.dst[1], b, t, jl) : 0;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = nw0 + ni * 16 + 4 * (lane >> 4);
+            const sehip_nchunk nc = d.ntab[n >> 2];
+            if (nc.nvalid <= 0) continue;
+            f32x4 v = acc[ni][mi];
+            if (d.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(d.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            const size_t off = (nc.dst ? ro1 : ro0) + nc.coff;
+            void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
+            const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+            if (d.res && nc.dst == 0 && nc.nvalid == 4) {
+                const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_raw*>(d.res) + off);
+                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+            }
+            if (is_f32) {
+                float* q = reinterpret_cast<float*>(dptr) + off;
+                if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nc.nvalid; ++e) q[e] = v[e];
+            } else {
+                bf16_raw* q = reinterpret_cast<bf16_raw*>(dptr) + off;
+                if (nc.nvalid == 4) *reinterpret_cast<uint2*>(q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else
+                    for (int e = 0; e < nc.nvalid; ++e) q[e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+template <int NF, int WMW>
+static void c2_launch(const sehip_gemm_desc& d, int TB, int JB, int FR, int B, int PP, int FS, int grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, WMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    sehip_note_kernel("conv_gemm_v2_kernel<%d, %d>", NF, WMW);
+    conv_gemm_v2_kernel<NF, WMW><<<grid, 128 * WMW, lds, st>>>(d, TB, JB, FR, B, PP, FS);
+}
+
+// LDS cycles of one A-fragment ds_read_b128 wave instruction (4 = conflict free) for a patch with row pitch `pitch` bytes and
+// `fs` rows per frame, averaged over the taps / frame offsets / wave rows of the kernel: 16-byte reads are served in four
+// 16-lane groups, bank = (address / 4) % 64 (MI355X_MICROARCH.md, LDS).  The rows a group touches (8 rows at one 8-channel piece
+// and 8 others at the next) depend on rows per frame, row stride and taps, so no single pitch is conflict free for every
+// layer: the dispatcher takes a census over a few (pitch, frame stride) candidates once per geometry and keeps the best.
+static double c2_read_cycles(int JB, int fmul, int NF, int pitch, int fs) {
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    long tot = 0, n = 0;
+    for (int row0 = 0; row0 < 128; row0 += 16)
+        for (int tap = 0; tap < NF; ++tap)
+            for (int dt = 0; dt < 2; ++dt) {
+                for (int g = 0; g < 4; ++g) {
+                    int cnt[64] = {0}, worst = 0;
+                    for (int q = 0; q < 16; ++q) {
+                        const int l = groups[g][q];
+                        const int r = row0 + (l & 15), tl = r / JB, jl = r - tl * JB;
+                        const int addr = ((tl + dt) * fs + jl * fmul + tap) * pitch + 16 * (l >> 4);
+                        for (int k = 0; k < 4; ++k) {
+                            int& c = cnt[((addr >> 2) + k) & 63];
+                            if (++c > worst) worst = c;
+                        }
+                    }
+                    tot += worst;
+                }
+                ++n;
+            }
+    return (double)tot / n;
+}
+
+static_assert(C2_MAXP == 7, "the counted waits (vmcnt(DW + C2_MAXP)) are written for 7 prefetch loads per thread");
+
+// returns 1 if the kernel was launched, 0 if the descriptor does not qualify (the caller falls back to conv_gemm_kernel)
+int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_CONV_V2") != nullptr || getenv("SEHIP_NO_PATCH") != nullptr;
+    static const int bm_force = getenv("SEHIP_CONV_V2_BM") ? atoi(getenv("SEHIP_CONV_V2_BM")) : 0;
+    static const bool no_census = getenv("SEHIP_CONV_V2_NO_CENSUS") != nullptr;
+    if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    if ((C0 & 63) || (C1 & 63) || (d.Npad & 127) || d.J > 64 || (128 % d.J)) return 0;
+    if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
+    if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return 0;
+    for (int s = 0; s < 2; ++s) {
+        if (!d.src[s].ptr) continue;
+        // frame offsets reach at most one frame outside [0, TT): what the two padding frames per utterance absorb
+        for (int kt = 0; kt < 2; ++kt)
+            if (d.cv_toff[s][kt] < -1 || d.cv_toff[s][kt] > 1) return 0;
+        if (d.src[s].thi > d.TT + 1) return 0;
+        if ((long)d.M / d.J / d.TT * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 31)) return 0;   // 32-bit piece offsets
+    }
+    const int B = d.M / (d.TT * d.J);
+    const long vframes = (long)B * (d.TT + 2);
+    int BM = bm_force == 256 ? 256 : 128;
+    const int JB = d.J;
+    const int FR = (JB - 1) * d.fmul + d.cv_nf;
+    for (;;) {
+        const int TB = BM / JB;
+        const int nthr = BM * 2;
+        // bank-conflict census: row pitch 80 / 96 / 112 bytes x up to 3 padding rows per frame
+        // (measured per tap count, B=32 full-size layers, us per launch, round-1 kernel / this kernel at 80 B / with the census:
+        //  5 taps 116 / 145 / 110, 3 taps 109 / 96 / 111, 2 taps 88 / 83 / 80 -- the census is a model of the fragment reads only,
+        //  so the 3-tap layers keep the plain 80-byte pitch)
+        int PP = 40, FS = FR;
+        if (!no_census && d.cv_nf != 3) {
+            double best = 1e9;
+            for (int pitch = 80; pitch <= 112; pitch += 16)
+                for (int fs = FR; fs <= FR + 3; ++fs) {
+                    const size_t bytes = (size_t)(TB + 1) * fs * pitch + 3 * C2_WSLOT + 2 * (TB + 1) * sizeof(int) + 16;
+                    if (bytes > (size_t)(BM == 128 ? 80 : 160) * 1024) continue;
+                    const double c = c2_read_cycles(JB, d.fmul, d.cv_nf, pitch, fs) + 1e-3 * (pitch - 80) + 1e-4 * (fs - FR);
+                    if (c < best) { best = c; PP = pitch / 2; FS = fs; }
+                }
+        }
+        const size_t patch_bytes = (size_t)(TB + 1) * FS * PP * 2;
+        size_t lds = 3 * C2_WSLOT + patch_bytes + 2 * (TB + 1) * sizeof(int) + 16;
+        const size_t epi = (size_t)(nthr / 64) * 64 * 72 * 2;         // the waves' output staging images reuse the same LDS
+        if (lds < epi) lds = epi;
+        const bool fits = (TB + 1) * FR * 4 <= C2_MAXP * nthr && TB + 1 <= 255 && lds <= (BM == 128 ? 80 : 160) * 1024;
+        if (!fits) {
+            if (BM == 256) return 0;
+            BM = 256;                                                 // one workgroup per CU with all its LDS
+            continue;
+        }
+        const int mtiles = (int)((vframes + TB - 1) / TB);
+        const int grid = mtiles * (d.Npad / 128);
+#define C2_CASE(NF_)                                                                          \
+        case NF_:                                                                             \
+            if (BM == 128) c2_launch<NF_, 2>(d, TB, JB, FR, B, PP, FS, grid, lds, st);        \
+            else c2_launch<NF_, 4>(d, TB, JB, FR, B, PP, FS, grid, lds, st);                  \
+            return 1;
+        switch (d.cv_nf) {
+            C2_CASE(2) C2_CASE(3) C2_CASE(5)
+            default: return 0;
+        }
+#undef C2_CASE
+    }
+}
+
+template <int NF>
+static void c2_init_nf() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+void sehip_conv2_init(void) {
+    c2_init_nf<2>(); c2_init_nf<3>(); c2_init_nf<5>();
+}
