@@ -68,11 +68,14 @@ int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, int mode, d
 int sehip_pointwise_loss_bwd(const float* x, const float* y, long n, int mode, const float* upstream, float* dx, void* stream);
 
 /* ---- optimizer path on one flat fp32 buffer: src/solver.py:487-498 (clip_grad_norm_, optimizer.step, grad_norm
- *      metric) and src/distrib.py:244-261 (Adam / SGD).  mode 0 = Adam, 1 = SGD(momentum=beta1). */
+ *      metric) and src/distrib.py:244-261 (Adam / SGD).  mode 0 = Adam, 1 = SGD(momentum=beta1).
+ *      grad_scale multiplies every gradient first (1/world after the data-parallel all-reduce(sum): the mean over the global
+ *      batch that nn.DataParallel's reduce produces, src/solver.py:144-145; 1 for a single replica); the clipped norm is the
+ *      norm of the scaled gradient and the scaled, clipped gradient is written back (the reference's p.grad after the step). */
 int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream);
 int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
                    float lr, float beta1, float beta2, float eps, int step, const int* step_dev /*device counter or NULL*/,
-                   float weight_decay, int mode, void* stream);
+                   float weight_decay, int mode, float grad_scale, void* stream);
 int sehip_counter_add(int* counter, int value, void* stream);
 /* sets the dynamic-LDS attributes of every kernel up front (call once before capturing a hipGraph) */
 int sehip_init(void);

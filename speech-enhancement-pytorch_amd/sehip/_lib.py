@@ -40,7 +40,7 @@ _PROTOS = {
     "sehip_pointwise_loss_fwd": [P, P, L, I, P, P, P],
     "sehip_pointwise_loss_bwd": [P, P, L, I, P, P, P],
     "sehip_grad_sumsq": [P, L, P, P],
-    "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, P],
+    "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P],
     "sehip_counter_add": [P, I, P],
     "sehip_init": [],
     "sehip_grad_metric": [P, P, I, L, P, P, P, P],

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, fl
                                                        float* __restrict__ v, long n, const double* __restrict__ sumsq,
                                                        float max_norm, float lr, float b1, float b2, float eps, float bc1,
                                                        float sqrt_bc2, float wd, int mode, int first_step,
-                                                       const int* __restrict__ step_dev) {
+                                                       const int* __restrict__ step_dev, float gscale) {
     if (step_dev) {  // step counter lives on the device (graph replay): bias corrections computed here
         const int step = step_dev[0];
         first_step = step == 1;
@@ -40,10 +40,12 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, fl
             sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, (double)step));
         }
     }
-    float coef = 1.f;
+    // gscale: 1/world of the data-parallel mean (the all-reduce SUMS the replicas' gradients); the norm that is clipped is the
+    // norm of the scaled gradient, as the reference clips the reduced gradient (src/solver.py:487-490)
+    float coef = gscale;
     if (max_norm > 0.f) {
-        const float total = (float)sqrt(sumsq[0]);
-        coef = fminf(1.f, max_norm / (total + 1e-6f));
+        const float total = (float)sqrt(sumsq[0]) * gscale;
+        coef = gscale * fminf(1.f, max_norm / (total + 1e-6f));
     }
     const float step_size = lr / bc1;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
@@ -116,10 +118,11 @@ extern "C" int sehip_counter_add(int* counter, int value, void* stream) {
 
 extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
                               float max_norm, float lr, float beta1, float beta2, float eps, int step, const int* step_dev,
-                              float weight_decay, int mode, void* stream) {
+                              float weight_decay, int mode, float grad_scale, void* stream) {
     SEHIP_REQUIRE(n >= 0 && (step >= 1 || step_dev != nullptr), "opt_step: bad n/step (n=%ld step=%d)", n, step);
     if (step < 1) step = 1;
     SEHIP_REQUIRE(mode == 0 || mode == 1, "opt_step: mode must be 0 (adam) or 1 (sgd)");
+    SEHIP_REQUIRE(grad_scale > 0.f, "opt_step: grad_scale must be positive (1 for a single replica, 1/world after the all-reduce)");
     SEHIP_REQUIRE(max_norm <= 0.f || sumsq != nullptr, "opt_step: clipping needs the sumsq buffer");
     if (n == 0) return 0;
     const double bc1 = mode == 0 ? 1.0 - pow((double)beta1, step) : 1.0;
@@ -127,7 +130,8 @@ extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, l
     int grid = cdiv(n, 256 * 4);
     if (grid > 2048) grid = 2048;
     opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
-                                                           (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev);
+                                                           (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev,
+                                                           grad_scale);
     SEHIP_CHECK_LAUNCH("opt_step");
     return 0;
 }

@@ -99,14 +99,28 @@ def allreduce_module_gradients(model):
             g.copy_(f)
 
 
-def allreduce_gradients(flat_grads):
-    """ONE all-reduce(sum) of the flat fp32 gradient buffer, then x 1/world: the mean over the global batch
+def allreduce_gradients(flat_grads, scale=True):
+    """ONE all-reduce(sum) of the flat fp32 gradient buffer [then x 1/world]: the mean over the global batch
     (equal shards), i.e. what DataParallel's gather + loss mean + backward reduce produces on GPU 0.
-    Clipping happens after this (src/solver.py:487-490 clips the reduced gradients)."""
+    Clipping happens after this (src/solver.py:487-490 clips the reduced gradients).  scale=False leaves the SUM: the fused
+    optimizer applies 1/world itself (FlatOptimizer.grad_scale, no extra pass over the buffer)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
-        flat_grads.mul_(1.0 / dist.get_world_size())
+        if scale:
+            flat_grads.mul_(1.0 / dist.get_world_size())
     return flat_grads
+
+
+def allreduce_range_async(flat_grads, lo, hi, stream=None):
+    """all-reduce(sum) of flat_grads[lo:hi], enqueued behind `stream` (a torch.cuda.Stream, or None for the current one);
+    returns the work handle (.wait() makes the CURRENT stream wait for it).  Used by the Solver to start the exchange of
+    the decoder / LSTM gradients while the encoder's backward pass still runs (the reference has no overlap: DataParallel
+    reduces during its single backward, src/solver.py:144-145, 485)."""
+    view = flat_grads[lo:hi]
+    if stream is not None and flat_grads.is_cuda:
+        with torch.cuda.stream(stream):
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
+    return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
 
 
 def allreduce_mean_scalar(value):

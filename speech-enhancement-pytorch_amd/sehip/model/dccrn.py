@@ -59,6 +59,7 @@ class DCCRN(FlatModule):
         self.static = _static_for(cfg)
         self._tables = None
         self._ws_cap = max(1, int(os.environ.get("SEHIP_WS_CACHE", "4")))
+        self.grad_range_hook = None   # data-parallel: called with (lo, hi, stream) when flat_grads[lo:hi] is final (see plan.backward)
 
         # persistent STFT buffers (checkpoint compatibility; the FFT kernels do not read them)
         an, sy, win = _stft_bases(win_len, fft_len)
@@ -119,7 +120,8 @@ class DCCRN(FlatModule):
         if not self.training:
             raise SehipError("DCCRN.backward in eval mode (running-statistics BatchNorm) is not built")
         g = grad_out.reshape(ws.B, ws.length).contiguous().float()
-        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst))
+        hook = self.grad_range_hook if not (self._grads_live and self._params[0][1].grad is not None) else None   # not when accumulating
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, range_ready=hook))
 
     def forward(self, inputs, lens=None):
         if inputs.dim() == 2:

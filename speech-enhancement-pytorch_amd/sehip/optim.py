@@ -24,6 +24,7 @@ class FlatOptimizer(torch.optim.Optimizer):
         self._step_dev = None
         self._scratch = None
         self.max_norm = 0.0  # set by clip_grad_norm_() for the next step only
+        self.grad_scale = 1.0  # 1/world when the flat gradients hold the all-reduced SUM of the replicas (Solver sets it)
 
     # ---- flat state -------------------------------------------------------------------------------
     def _ensure_state(self):
@@ -78,7 +79,8 @@ class FlatOptimizer(torch.optim.Optimizer):
         else:
             b1, b2, mode = g["momentum"], 0.0, 1
         call("sehip_opt_step", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq"]),
-             self.max_norm, g["lr"], b1, b2, g["eps"], self._step, ptr(self._step_dev), g["weight_decay"], mode, stream())
+             self.max_norm, g["lr"], b1, b2, g["eps"], self._step, ptr(self._step_dev), g["weight_decay"], mode, float(self.grad_scale),
+             stream())
         self.max_norm = 0.0
 
     def grad_metric(self):

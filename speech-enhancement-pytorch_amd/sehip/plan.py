@@ -691,6 +691,7 @@ class DCCRNWorkspace:
         import os
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True
+        self.comm = None     # third stream: early un-pack + all-reduce of the decoder / LSTM gradients (data-parallel runs only)
         # The two stacked complex LSTM layers are pipelined over chunks of time steps: layer 2 (and the input product that
         # feeds it) runs chunk c on a second high-priority stream while layer 1 runs chunk c+1 (backward: the other way
         # round).  Each recurrence keeps 8 workgroups busy for ~0.9 us per step, so two of them side by side cost nothing.
@@ -979,8 +980,13 @@ class DCCRNWorkspace:
              cfg.win_inc, cfg.fft_len, self.length, self.mode, ptr(self.frames), ptr(self.wav), stream())
         return self.wav
 
-    def backward(self, dwav, params, grads):
-        """dwav [B,length] fp32 -> flat parameter gradients (overwritten)."""
+    def backward(self, dwav, params, grads, range_ready=None):
+        """dwav [B,length] fp32 -> flat parameter gradients (overwritten).
+
+        range_ready(lo, hi, stream) -- data-parallel hook: called as soon as grads[lo:hi] is final ON `stream` (a torch stream),
+        first for the decoder + LSTM parameters (the tail of the flat buffer in state_dict order), whose weight gradients are
+        complete once the LSTM backward has been enqueued, so their all-reduce overlaps the encoder's backward pass; then for
+        the encoder range at the end."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, T, h = self.B, self.T, cfg.hid
         self.gpack.zero_()
@@ -998,6 +1004,19 @@ class DCCRNWorkspace:
             self.wgrad(f"proj_{tag}")
         self.gemm_pair("dproj_r", "dproj_i")
         self._lstm_backward(B, T, h)
+        n_params = st.layout.n_params
+        lo = st.layout.param_off["decoder.0.0.real_conv.weight"][0] if range_ready is not None else 0
+        if range_ready is not None:
+            # decoder / LSTM gradients: un-packed and handed over on a third stream that waits for the chain (BatchNorm / PReLU
+            # gradients) and for the weight-gradient stream as they stand now -- the chain itself does not wait
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=self.device)
+            cs = self.comm.cuda_stream
+            call("sehip_stream_depend", cs, stream(), self._event())
+            if self.side is not None:
+                call("sehip_stream_depend", cs, self.side.cuda_stream, self._event())
+            call("sehip_unpack_grad", ptr(self.gpack), tb.utab.data_ptr() + 16 * lo, n_params - lo, grads.data_ptr() + 4 * lo, cs)
+            range_ready(lo, n_params, self.comm)
         for i in range(5, -1, -1):
             dz = b["dz5l"] if i == 5 else b[f"dz{i}"]
             dz2 = b[f"dskip{i}"] if (i == 5 or not FUSE_SKIP_GRAD) else None   # enc{i+1}.dg0/dg1 already added it (res)
@@ -1008,5 +1027,8 @@ class DCCRNWorkspace:
                 self.gemm(f"enc{i}.dg1")
         if self.side is not None:
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
+        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), lo if range_ready is not None else n_params, ptr(grads), stream())
+        if range_ready is not None:
+            range_ready(0, lo, torch.cuda.current_stream())
+            call("sehip_stream_depend", stream(), self.comm.cuda_stream, self._event())
         return grads

@@ -225,13 +225,30 @@ class Solver(object):
         # (the reference computes a PIT loss here and then overwrites it, src/solver.py:469-480)
         loss = self.loss_function(enhanced, sources)
         self.optimizer.zero_grad()
-        loss.backward()
-        if self.world_size > 1:
-            if self.flat_model:
-                distrib.allreduce_gradients(self.model.flat_grads)
-            else:
-                distrib.allreduce_module_gradients(self.model)
         fused = isinstance(self.optimizer, FlatOptimizer)
+        if self.world_size > 1 and self.flat_model and fused:
+            # one SUM all-reduce of the flat buffer, in two ranges where the model hands them over early (the decoder / LSTM
+            # range starts its exchange under the encoder's backward pass); 1/world is folded into the optimizer launch
+            self.optimizer.grad_scale = 1.0 / self.world_size
+            works = []
+            if hasattr(self.model, "grad_range_hook"):
+                self.model.grad_range_hook = lambda lo, hi, st: works.append(
+                    distrib.allreduce_range_async(self.model.flat_grads, lo, hi, st))
+            loss.backward()
+            if hasattr(self.model, "grad_range_hook"):
+                self.model.grad_range_hook = None
+            if works:
+                for w in works:
+                    w.wait()
+            else:
+                distrib.allreduce_gradients(self.model.flat_grads, scale=False)
+        else:
+            loss.backward()
+            if self.world_size > 1:
+                if self.flat_model:
+                    distrib.allreduce_gradients(self.model.flat_grads)
+                else:
+                    distrib.allreduce_module_gradients(self.model)
         if self.config.optim.clip_grad:
             if fused:
                 self.optimizer.clip_grad_norm_(self.config.optim.clip_grad)
@@ -262,7 +279,7 @@ class Solver(object):
         g["src"].copy_(sources)
         g["fb"].replay()
         if self.world_size > 1:
-            distrib.allreduce_gradients(self.model.flat_grads)
+            distrib.allreduce_gradients(self.model.flat_grads, scale=False)   # 1/world is baked into the captured optimizer launch
         g["upd"].replay()
         return g["loss"], g["metric"]
 
@@ -272,6 +289,7 @@ class Solver(object):
             raise SehipError("train_step_graphed needs the fused FlatOptimizer")
         call("sehip_init")
         self.model.train()
+        self.optimizer.grad_scale = 1.0 / self.world_size
         self.model.workspace(mixture.shape[0], mixture.shape[-1]).pinned = True  # all buffers exist before capture and stay
         self.optimizer._ensure_state()
         self.model.flat_grads

@@ -118,12 +118,32 @@ def test_clip_adam_matches_oracle(dev):
         gdev = grads.to(dev)
         call("sehip_grad_sumsq", ptr(gdev), n, ptr(sumsq), stream())
         call("sehip_opt_step", ptr(p), ptr(gdev), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 3e-4, 0.9, 0.999, 1e-8, step, None,
-             0.0, 0, stream())
+             0.0, 0, 1.0, stream())
         call("sehip_grad_metric", ptr(gdev), ptr(offs_d), len(sizes), max(sizes), ptr(sumsq), ptr(tsum), ptr(metric), stream())
         assert abs(float(metric[1]) - float(total)) < 1e-4 * float(total)
         assert abs(float(metric[0]) - want_metric) < 1e-3 * max(1.0, want_metric)
         ref_p = torch.cat([params[str(i)] for i in range(len(sizes))])
         assert max_abs(p.cpu(), ref_p) < 2e-6
+
+
+def test_opt_step_grad_scale_is_the_data_parallel_mean(dev):
+    """grad_scale = 1/world on the SUMMED gradients == the step on the mean gradient (clipping included)."""
+    from sehip._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(17)
+    n, world = 30011, 4
+    p0 = torch.randn(n, generator=g)
+    gsum = torch.randn(n, generator=g) * 0.3           # norm of the mean ~ 13: clipping at 5 is active
+    res = []
+    for grads, scale in ((gsum.clone(), 1.0 / world), (gsum / world, 1.0)):
+        p = p0.clone().to(dev); gd = grads.to(dev)
+        m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+        sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        call("sehip_grad_sumsq", ptr(gd), n, ptr(sumsq), stream())
+        call("sehip_opt_step", ptr(p), ptr(gd), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 3e-4, 0.9, 0.999, 1e-8, 1, None, 0.0, 0, scale,
+             stream())
+        res.append((p.cpu(), gd.cpu()))
+    assert max_abs(res[0][0], res[1][0]) < 1e-6 and max_abs(res[0][1], res[1][1]) < 1e-6
+    assert abs(float(res[0][1].norm()) - 5.0) < 1e-3  # the written-back gradient is the clipped mean
 
 
 @pytest.mark.parametrize("momentum", [0.0, 0.9])
@@ -146,7 +166,7 @@ def test_clip_sgd_matches_torch(dev, momentum):
         gdev = grads.to(dev)
         call("sehip_grad_sumsq", ptr(gdev), n, ptr(sumsq), stream())
         call("sehip_opt_step", ptr(p), ptr(gdev), ptr(m), ptr(v), n, ptr(sumsq), 5.0, 0.05, momentum, 0.0, 1e-8, step, None,
-             0.0, 1, stream())
+             0.0, 1, 1.0, stream())
         assert max_abs(gdev.cpu(), p_ref.grad) < 1e-6          # the clipped gradient is written back like p.grad
         assert max_abs(p.cpu(), p_ref.detach()) < 2e-6, step
     if momentum:

@@ -205,3 +205,44 @@ def test_workspace_generation_and_lru():
         for n in (3000, 3100, 3200, 3300, 3400, 3500):
             model(torch.zeros(1, 1, n, device=dev))
     assert len(model._ws) <= model._ws_cap
+
+
+def test_two_ranks_equal_one_rank_with_per_replica_batchnorm(tmp_path):
+    """Data parallel = DataParallel's semantics (src/solver.py:144-145): two ranks with 2 clips each give the parameters of ONE
+    process that runs the two halves separately (per-replica BatchNorm statistics), averages the gradients, clips and steps.
+    Exercises the overlapped two-range all-reduce (decoder / LSTM range first) and the 1/world folded into the optimizer.
+    Two processes share cuda:0 over gloo (RCCL refuses two ranks on one device)."""
+    import os, socket, subprocess, sys
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp.pt")
+    env = dict(os.environ, SEHIP_DIST_BACKEND="gloo", SEHIP_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dp_worker.py"), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    # the same thing in one process
+    cfg = solver_config(tmp_path)
+    torch.manual_seed(cfg.seed)
+    model = distrib.get_model(cfg.model)
+    opt = distrib.get_optimizer(cfg.optim, model)
+    solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+    noisy, clean = make_batch(900, 4, 4000)
+    model.train()
+    opt.zero_grad()
+    bsave, nsave = model._bflat.clone(), model._nbt.clone()
+    for r_ in range(2):
+        mix, src = solver._prepare_batch(noisy[2 * r_:2 * r_ + 2], clean[2 * r_:2 * r_ + 2])
+        solver.loss_function(model(mix), src).backward()          # second call accumulates into flat_grads
+        if r_ == 0:
+            model._bflat.copy_(bsave); model._nbt.copy_(nsave)    # rank 1 starts from the same running statistics
+    opt.grad_scale = 0.5
+    opt.clip_grad_norm_(cfg.optim.clip_grad)
+    opt.step()
+    torch.cuda.synchronize()
+    ref_g, ref_p = model.flat_grads.cpu(), model.flat_params.cpu()
+    assert rel_err(got["grads"], ref_g) < 2e-3                     # fp32 atomics of the weight gradients: run-to-run noise only
+    assert max_abs(got["params"], ref_p) < 2.1 * 3e-4 and float((got["params"] - ref_p).abs().mean()) < 0.05 * 3e-4
