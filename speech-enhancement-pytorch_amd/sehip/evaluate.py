@@ -4,11 +4,14 @@ Same names, arguments and shapes as the reference functions the Solver calls twi
 (src/solver.py:457-458): ``config`` is any object with ``n_fft, hop_length, win_length, center``; 3-D ``[B, C, N]`` and
 4-D ``[B, S, C, N]`` inputs give ``[B, C, F, T, 2]`` / ``[B, S, C, F, T, 2]``.  The arithmetic is the HIP kernels of
 csrc/stft_custom.hip through the C ABI; there is no CPU or torch.stft fallback (a CPU tensor raises SehipError).
-``evaluate()`` itself (chunked inference) is out of scope.
+``evaluate()`` (the chunked inference of src/evaluate.py:10-98) runs ON THE DEVICE here: segmentation is a strided view,
+the stitch one gather, the STFT-domain branch the HIP kernels above -- the reference builds segments and output with Python
+loops on the CPU and moves each half batch to the GPU.
 """
 import torch
 
 from ._lib import SehipError, call, lib, ptr, stream
+from .model.types import MONARCH_SPEECH_SEPARTAION_MODELS, MULTI_SPEECH_SEPERATION_MODELS, STFT_MODELS
 
 
 def _cfg(config):
@@ -51,3 +54,69 @@ def istft_custom(tensor: torch.Tensor, length, config):
     wav = torch.empty(z.shape[0], int(length), dtype=torch.float32, device=tensor.device)
     call("sehip_istft_custom_fwd", ptr(z), z.shape[0], t, n_fft, hop, win, center, int(length), ptr(frames), ptr(wav), stream())
     return wav.view(*lead, int(length))
+
+
+def _prepare_input_wav_zero_filled(wav, num_feature, stride):
+    """[..., N] -> [num_segment, ..., num_feature]: windows of num_feature samples every `stride`, the tail zero-padded to a whole
+    number of strides (src/evaluate.py:164-183) -- a strided view instead of a copy loop."""
+    assert wav.shape[-1] >= num_feature, "the length of data is too short comparing the number of features..."
+    extra = (wav.shape[-1] - num_feature) % stride
+    if extra:
+        wav = torch.nn.functional.pad(wav, (0, stride - extra))
+    seg = wav.unfold(-1, num_feature, stride)                    # [..., num_segment, num_feature]
+    return seg.movedim(-2, 0)
+
+
+def evaluate(mixture, model, device, config, max_segments_per_call=None):
+    """Same contract as the reference's evaluate() (src/evaluate.py:10-98): mixture [B, C, N] -> enhanced [B, C, N] (or
+    [B, S, C, N] for the multi-speaker models), with config.dset.norm in {"z-score", "linear-scale", None},
+    config.model.{name, segment, win_length, ...} and config.dset.sample_rate.  Everything stays on `device`; the segments go
+    through the model in chunks of `max_segments_per_call` (default: two halves, like the reference)."""
+    with torch.no_grad():
+        x = mixture.to(device)
+        norm = getattr(config.dset, "norm", None)
+        if norm == "z-score":
+            mean, std = torch.mean(x, dim=-1, keepdim=True), torch.std(x, dim=-1, keepdim=True)
+            x = (x - mean) / (std + 1e-9)
+        elif norm == "linear-scale":
+            # (the reference subtracts torch.max's (values, indices) tuple here and raises; the evident intent is implemented)
+            hi, lo = torch.amax(x, dim=-1, keepdim=True), torch.amin(x, dim=-1, keepdim=True)
+            x = (x - lo) / (hi - lo + 1e-9)
+        stride = int(config.model.win_length)
+        num_feature = int(config.dset.sample_rate * config.model.segment)
+        seg = _prepare_input_wav_zero_filled(x, num_feature, stride)          # [S, B, C, F] (view)
+        num_segment, nbatch, nchannel, nsample = seg.shape
+        batch = seg.reshape(num_segment * nbatch, nchannel, nsample).contiguous()
+        name = config.model.name
+        if name in STFT_MODELS:
+            batch = stft_custom(batch, config.model)
+        if model is not None:
+            model.eval()
+            step = max_segments_per_call or max(1, batch.shape[0] // 2)
+            first = batch.shape[0] // 2 if not max_segments_per_call else step
+            cuts = [0, first] + list(range(first + step, batch.shape[0], step)) + [batch.shape[0]] if first else [0, batch.shape[0]]
+            output = torch.cat([model(batch[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a], dim=0)
+        else:
+            output = batch
+        if name in MONARCH_SPEECH_SEPARTAION_MODELS:
+            output = torch.unsqueeze(output, dim=1)
+        if name in STFT_MODELS:
+            output = istft_custom(output.contiguous(), nsample, config.model)
+        if model is not None and name in MULTI_SPEECH_SEPERATION_MODELS:
+            nsrc = len(config.model.sources)
+            output = output.reshape(num_segment, nbatch, nsrc, nchannel, nsample)
+        else:
+            output = output.reshape(num_segment, nbatch, nchannel, nsample)
+        # stitch: the first segment whole, then the last `stride` samples of every further segment
+        tail = output[1:, ..., nsample - stride:]                             # [S-1, ..., stride]
+        tail = tail.movedim(0, -2).reshape(*output.shape[1:-1], (num_segment - 1) * stride)
+        enhanced = torch.cat([output[0], tail], dim=-1)[..., :mixture.shape[-1]]
+        if model is not None and name in MULTI_SPEECH_SEPERATION_MODELS:
+            mean_, std_ = (mean.unsqueeze(1), std.unsqueeze(1)) if norm == "z-score" else (None, None)
+        else:
+            mean_, std_ = (mean, std) if norm == "z-score" else (None, None)
+        if norm == "z-score":
+            enhanced = enhanced * (std_ + 1e-9) + mean_
+        elif norm == "linear-scale":
+            enhanced = enhanced * (hi - lo + 1e-9) + lo
+    return enhanced

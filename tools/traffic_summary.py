@@ -18,16 +18,20 @@ for kind in ("fetch", "write"):
         name = r["Kernel_Name"]
         m = re.match(r"(?:void )?([\w:]+(?:<[^(]*>)?)", name)
         acc[kind][m.group(1) if m else name].append(float(r["Counter_Value"]))
-res, tot_f, tot_w = {}, 0.0, 0.0
+res, tot_f, tot_w, lib_f, lib_w = {}, 0.0, 0.0, 0.0, 0.0
 for k in sorted(set(acc["fetch"]) | set(acc["write"])):
     f, w = acc["fetch"].get(k, []), acc["write"].get(k, [])
     fk = sum(f) / len(f) if f else 0.0
     wk = sum(w) / len(w) if w else 0.0
     tot_f += sum(f); tot_w += sum(w)
+    if not k.startswith(("at::", "__amd")):      # the library's own kernels (torch fill / copy kernels of the allocations excluded)
+        lib_f += sum(f); lib_w += sum(w)
     res[k] = {"launches_per_step": round(max(len(f), len(w)) / steps, 2), "fetch_size_kib": fk, "write_size_kib": wk,
               "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
 out = {"_whole_step": {"steps_profiled": steps, "fetch_size_kib_per_step": tot_f / steps, "write_size_kib_per_step": tot_w / steps,
                        "hbm_bytes_per_step": (2.0 * tot_f + tot_w) * 1024.0 / steps,
+                       "library_kernels_hbm_bytes_per_step": (2.0 * lib_f + lib_w) * 1024.0 / steps,
+                       "algorithmic_bytes_per_step": 80.7e6 * 32,
                        "note": "all dispatches of the profiled run / steps (model construction and the first-step allocations "
                                "included: an upper bound); FETCH_SIZE doubled (gfx950 wide-read correction)"}}
 out.update(res)
