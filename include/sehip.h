@@ -216,6 +216,37 @@ int sehip_dcunet_mask_fwd(const void* z_bf16, const float* w_re, const float* w_
 int sehip_dcunet_mask_bwd(const float* dout, const float* spec, const float* mask_ws, const void* z_bf16, const float* w_re,
                           const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, void* dz_bf16, float* gacc, void* stream);
 
+/* ---- ConvTasNet, everything that is not a 1x1 convolution (those are sehip_gemm products): src/model/conv_tasnet.py:34-487 with
+ *      the shipped options (skip=False, gLN, non-causal, relu mask).  Activations are channels-last bf16 [M][K][C] (M utterances,
+ *      K = (T - L)/(L/2) + 1 frames); statistics records are double [M][2]; every accumulator named "caller zeroes" is added to
+ *      with atomics.
+ *      encoder_fwd : Conv1d(ac -> N, L, stride L/2, no bias) + ReLU (:157-176) and the cLN that follows (:439-462):
+ *                    w [M][K][N] fp32 (mixture_w, kept for the decoder) and cln [M][K][N] bf16
+ *      encoder_bwd : gacc += {dU [N][ac*L], dgamma [N], dbeta [N]} from dcln (bf16) and dw_dec (fp32, the decoder's share)
+ *      gln_stats   : stats[m] += (sum, sum of squares) of PReLU(h[m]; slope)                                   (:465-487)
+ *      dwconv_fwd  : h2 = depthwise dilated Conv1d(groups = C, P = 3, 'same') of gLN(PReLU(h1)) (:366-379); stats2 += PReLU(h2)
+ *      gln_apply   : u = gLN(PReLU(h))
+ *      gln_bwd     : gradient of y = gLN(PReLU(h)) [dw = 1: behind the depthwise conv, g = d h2]: dh, sums [M][2],
+ *                    gch += {dgamma [C], dbeta [C] [, dWd [C][P]]}, dslope += d PReLU slope
+ *      decoder_fwd : out [M][Cs][ac][T] += overlap_and_add(Linear(N -> ac*L)(w * relu(mlin)))      (:179-204, :11-31)
+ *      decoder_bwd : dmlin [M][K][Cs*N] bf16, dw_dec [M][K][N] fp32, gacc += dV [ac*L][N] */
+int sehip_ctn_encoder_fwd(const float* wav, const float* U, const float* gamma, const float* beta, int M, int ac, int T, int N, int L,
+                          float* w, void* cln_bf16, void* stream);
+int sehip_ctn_encoder_bwd(const float* wav, const float* w, const void* dcln_bf16, const float* dw_dec, const float* gamma, int M, int ac,
+                          int T, int N, int L, float* gacc, void* stream);
+int sehip_ctn_gln_stats(const void* h, const float* slope, int M, int K, int C, double* stats, void* stream);
+int sehip_ctn_dwconv_fwd(const void* h1, const float* slope1, const double* stats1, const float* gamma, const float* beta, const float* Wd,
+                         int P, int dilation, const float* slope2, int M, int K, int C, void* h2, double* stats2, void* stream);
+int sehip_ctn_gln_apply(const void* h, const float* slope, const double* stats, const float* gamma, const float* beta, int M, int K, int C,
+                        void* u, void* stream);
+int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
+                      const float* Wd, int P, int dilation, int dw, int M, int K, int C, double* sums, float* gch, void* dh, float* dslope,
+                      void* stream);
+int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac, int Cs, int T,
+                          float* out, void* stream);
+int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac,
+                          int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, void* stream);
+
 /* ---- recurrent part of NavieComplexLSTM: src/model/dccrn.py:264-302 (four nn.LSTM passes of one complex layer in one
  *      persistent launch; hidden size 64).  pre*: [B][T][2 lstm * 256] gates from the input GEMMs (fp32);
  *      h/gates/c: [4 combos][B][T][64|256|64]; combo = part*2 + lstm. */

@@ -71,6 +71,14 @@ _PROTOS = {
     "sehip_dcunet_pack_input": [P, I, I, I, P, P],
     "sehip_dcunet_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     "sehip_dcunet_mask_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
+    "sehip_ctn_encoder_fwd": [P, P, P, P, I, I, I, I, I, P, P, P],
+    "sehip_ctn_encoder_bwd": [P, P, P, P, P, I, I, I, I, I, P, P],
+    "sehip_ctn_gln_stats": [P, P, I, I, I, P, P],
+    "sehip_ctn_dwconv_fwd": [P, P, P, P, P, P, I, I, P, I, I, I, P, P, P],
+    "sehip_ctn_gln_apply": [P, P, P, P, P, I, I, I, P, P],
+    "sehip_ctn_gln_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P],
+    "sehip_ctn_decoder_fwd": [P, P, P, I, I, I, I, I, I, I, P, P],
+    "sehip_ctn_decoder_bwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],

@@ -1,0 +1,624 @@
+// ConvTasNet (src/model/conv_tasnet.py:34-487, shipped options: skip=False, gLN, non-causal, relu mask) -- everything that is not
+// a 1x1 convolution (those are dense products on the implicit-GEMM engine of gemm.hip).  The network is memory-bound
+// (3.2 GFLOP per 4-s clip against ~25 activation tensors of 0.4-0.8 MB per clip and block), so every kernel here is an HBM
+// stream over channels-last bf16 activations [M][K][C] (row = one frame k of utterance m; a thread owns 8 channels = 16 bytes):
+//
+//   ctn_encoder_fwd        Conv1d(ac -> N, L, stride L/2, no bias) + ReLU (:157-176) fused with the channel-wise LayerNorm that
+//                          follows it (:439-462): mixture_w (fp32, kept for the decoder) and cLN(mixture_w) (bf16) in one pass
+//   ctn_gln_stats          per-utterance sum / sum of squares of PReLU(h) for the global LayerNorm (:465-487)
+//   ctn_dwconv_fwd         n = gLN(PReLU(h1)) on the fly, depthwise dilated conv (groups = channels, 'same' zero padding, :366-379),
+//                          stores h2 and accumulates the statistics of PReLU(h2) for the second gLN
+//   ctn_gln_apply          u = gLN(PReLU(h2)) (the input of the pointwise 1x1 conv)
+//   ctn_decoder_fwd        source_w = mixture_w * relu(mask logits) (:140, :196), basis_signals Linear(N -> ac*L) (:198) and
+//                          overlap_and_add (:11-31) -> separated waveforms [M][C][ac][T]
+//   ctn_*_bwd              the gradients of all of the above (two passes per LayerNorm: per-utterance sums, then apply)
+//
+//   gLN:  y = gamma (v - mu) / sqrt(var + 1e-8) + beta,  mu / var over (channels, frames) of ONE utterance;  v = PReLU(h; a)
+//         dv = (gamma dy - mean(gamma dy) - xh mean(gamma dy xh)) / sigma;  dh = dv (h > 0 ? 1 : a);  da = sum dv h [h <= 0]
+#include "common.h"
+
+#define CTN_EPS 1e-8f
+
+struct C8 { float v[8]; };
+__device__ __forceinline__ C8 ld8(const bf16_raw* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    C8 c;
+    c.v[0] = bf2f((bf16_raw)(u.x & 0xffff)); c.v[1] = bf2f((bf16_raw)(u.x >> 16));
+    c.v[2] = bf2f((bf16_raw)(u.y & 0xffff)); c.v[3] = bf2f((bf16_raw)(u.y >> 16));
+    c.v[4] = bf2f((bf16_raw)(u.z & 0xffff)); c.v[5] = bf2f((bf16_raw)(u.z >> 16));
+    c.v[6] = bf2f((bf16_raw)(u.w & 0xffff)); c.v[7] = bf2f((bf16_raw)(u.w >> 16));
+    return c;
+}
+__device__ __forceinline__ void st8(bf16_raw* p, const float* v) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+__device__ __forceinline__ C8 zero8() { C8 c; for (int j = 0; j < 8; ++j) c.v[j] = 0.f; return c; }
+__device__ __forceinline__ float prelu(float h, float a) { return h > 0.f ? h : a * h; }
+
+// mean and 1/sigma of an utterance from its (sum, sumsq) record
+__device__ __forceinline__ void gln_moments(const double* __restrict__ st, int m, long n, float& mu, float& rs) {
+    const double s = st[2 * m], q = st[2 * m + 1];
+    const double mean = s / (double)n;
+    double var = q / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mu = (float)mean;
+    rs = 1.f / sqrtf((float)var + CTN_EPS);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// encoder + cLN.  One wave per frame; lane owns channels lane, lane + 64, ... (N <= 256); U^T in LDS.
+// ------------------------------------------------------------------------------------------------------------------
+#define ENC_MAXC 4
+__global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __restrict__ wav, const float* __restrict__ U /*[N][ac*L]*/,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int M,
+                                                              int ac, int T, int K, int N, int L, float* __restrict__ w,
+                                                              bf16_raw* __restrict__ cln) {
+    extern __shared__ float sU[];                    // [ac*L][N]
+    const int AL = ac * L;
+    for (int i = threadIdx.x; i < N * AL; i += 256) { const int n = i / AL, l = i - n * AL; sU[l * N + n] = U[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    for (long fr = (long)blockIdx.x * 4 + wave; fr < frames; fr += (long)gridDim.x * 4) {
+        const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
+        float acc[ENC_MAXC];
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) acc[i] = 0.f;
+        for (int a = 0; a < ac; ++a) {
+            const float* x = wav + ((long)m * ac + a) * T + (long)k * step;
+            for (int l = 0; l < L; ++l) {
+                const float xv = x[l];
+#pragma unroll
+                for (int i = 0; i < ENC_MAXC; ++i) {
+                    const int n = lane + 64 * i;
+                    if (n < N) acc[i] += xv * sU[(a * L + l) * N + n];
+                }
+            }
+        }
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) {
+            acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
+            if (lane + 64 * i < N) { s += acc[i]; q += acc[i] * acc[i]; }
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        const float mean = s / N;
+        float var = q / N - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rs = 1.f / sqrtf(var + CTN_EPS);
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) {
+            const int n = lane + 64 * i;
+            if (n < N) {
+                w[fr * N + n] = acc[i];
+                cln[fr * N + n] = f2bf(gamma[n] * (acc[i] - mean) * rs + beta[n]);
+            }
+        }
+    }
+}
+
+// backward of cLN + ReLU + encoder conv:  dw = dw_dec + cLN'(dcln);  dpre = dw [w > 0];  dU[n][l] += dpre x[l]
+// gacc: dU [N][ac*L] | dgamma [N] | dbeta [N]   (fp32, atomics; caller zeroes)
+__global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                              const bf16_raw* __restrict__ dcln, const float* __restrict__ dw_dec,
+                                                              const float* __restrict__ gamma, int M, int ac, int T, int K, int N, int L,
+                                                              int frames_per_wave, float* __restrict__ gacc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int step = L / 2, AL = ac * L;
+    const long frames = (long)M * K;
+    const long f0 = ((long)blockIdx.x * 4 + wave) * frames_per_wave;
+    float dg[ENC_MAXC], db[ENC_MAXC];
+#pragma unroll
+    for (int i = 0; i < ENC_MAXC; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    // dU accumulators: this lane's channels x taps, kept in LDS rows private to the wave (ENC_MAXC * AL floats per lane is too
+    // many registers for L = 40): [wave][l][n]
+    extern __shared__ float sdU[];
+    float* mine = sdU + (size_t)wave * AL * N;
+    for (int i = lane; i < AL * N; i += 64) mine[i] = 0.f;
+    float gam[ENC_MAXC];
+#pragma unroll
+    for (int i = 0; i < ENC_MAXC; ++i) gam[i] = lane + 64 * i < N ? gamma[lane + 64 * i] : 0.f;
+    for (long fr = f0; fr < f0 + frames_per_wave && fr < frames; ++fr) {
+        const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
+        float wv[ENC_MAXC], dy[ENC_MAXC];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) {
+            const int n = lane + 64 * i;
+            wv[i] = n < N ? w[fr * N + n] : 0.f;
+            dy[i] = n < N ? bf2f(dcln[fr * N + n]) : 0.f;
+            s += wv[i]; q += wv[i] * wv[i];
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        const float mean = s / N;
+        float var = q / N - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rs = 1.f / sqrtf(var + CTN_EPS);
+        float s1 = 0.f, s2 = 0.f, xh[ENC_MAXC];
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) {
+            xh[i] = (wv[i] - mean) * rs;
+            if (lane + 64 * i < N) { s1 += gam[i] * dy[i]; s2 += gam[i] * dy[i] * xh[i]; dg[i] += dy[i] * xh[i]; db[i] += dy[i]; }
+        }
+        s1 = wave_sum(s1) / N; s2 = wave_sum(s2) / N;
+        float dpre[ENC_MAXC];
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) {
+            const int n = lane + 64 * i;
+            float dwv = n < N ? (gam[i] * dy[i] - s1 - xh[i] * s2) * rs + dw_dec[fr * N + n] : 0.f;
+            dpre[i] = wv[i] > 0.f ? dwv : 0.f;
+        }
+        for (int a = 0; a < ac; ++a) {
+            const float* x = wav + ((long)m * ac + a) * T + (long)k * step;
+            for (int l = 0; l < L; ++l) {
+                const float xv = x[l];
+#pragma unroll
+                for (int i = 0; i < ENC_MAXC; ++i) {
+                    const int n = lane + 64 * i;
+                    if (n < N) mine[(a * L + l) * N + n] += dpre[i] * xv;
+                }
+            }
+        }
+    }
+    for (int i = lane; i < AL * N; i += 64) {
+        const int l = i / N, n = i - l * N;
+        const float v = mine[i];
+        if (v != 0.f) atomicAdd(&gacc[n * AL + l], v);
+    }
+#pragma unroll
+    for (int i = 0; i < ENC_MAXC; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) { atomicAdd(&gacc[N * AL + n], dg[i]); atomicAdd(&gacc[N * AL + N + n], db[i]); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// global LayerNorm pieces.  Rows of utterance m: [m*K, (m+1)*K).  grid = (blocks per utterance, M).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_add2_double(float s, float q, double* dst) {
+    __shared__ float red[2][4];
+    s = wave_sum(s); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&dst[0], (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&dst[1], (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ctn_gln_stats_kernel(const bf16_raw* __restrict__ h, const float* __restrict__ slope, int K, int C,
+                                                            double* __restrict__ stats) {
+    const int m = blockIdx.y, nq = C >> 3;
+    const float a = slope[0];
+    const long pieces = (long)K * nq;
+    const bf16_raw* base = h + (long)m * K * C;
+    float s = 0.f, q = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
+        const C8 x = ld8(base + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = prelu(x.v[j], a); s += v; q += v * v; }
+    }
+    block_add2_double(s, q, stats + 2 * m);
+}
+
+// h2[t][c] = sum_j Wd[c][j] n1[t + (j - P/2) d][c],  n1 = gLN1(PReLU(h1)) (zero outside [0, K)); stats2 += PReLU(h2; a2)
+template <int P>
+__global__ __launch_bounds__(256) void ctn_dwconv_fwd_kernel(const bf16_raw* __restrict__ h1, const float* __restrict__ slope1,
+                                                             const double* __restrict__ stats1, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ Wd /*[C][P]*/,
+                                                             int dil, const float* __restrict__ slope2, int K, int C,
+                                                             bf16_raw* __restrict__ h2, double* __restrict__ stats2) {
+    const int m = blockIdx.y, nq = C >> 3;
+    const float a1 = slope1[0], a2 = slope2[0];
+    float mu, rs;
+    gln_moments(stats1, m, (long)K * C, mu, rs);
+    const long pieces = (long)K * nq;
+    const bf16_raw* base = h1 + (long)m * K * C;
+    bf16_raw* out = h2 + (long)m * K * C;
+    float s = 0.f, q = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / nq), c0 = (int)(i - (long)t * nq) * 8;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int tt = t + (p - P / 2) * dil;
+            if (tt < 0 || tt >= K) continue;
+            const C8 x = ld8(base + ((long)tt * nq) * 8 + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n1 = gamma[c0 + j] * (prelu(x.v[j], a1) - mu) * rs + beta[c0 + j];
+                o[j] += Wd[(c0 + j) * P + p] * n1;
+            }
+        }
+        st8(out + i * 8, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = prelu(bf2f(f2bf(o[j])), a2); s += v; q += v * v; }   // statistics of what is stored
+    }
+    block_add2_double(s, q, stats2 + 2 * m);
+}
+
+__global__ __launch_bounds__(256) void ctn_gln_apply_kernel(const bf16_raw* __restrict__ h, const float* __restrict__ slope,
+                                                            const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int K, int C, bf16_raw* __restrict__ u) {
+    const int m = blockIdx.y, nq = C >> 3;
+    const float a = slope[0];
+    float mu, rs;
+    gln_moments(stats, m, (long)K * C, mu, rs);
+    const long pieces = (long)K * nq;
+    const bf16_raw* base = h + (long)m * K * C;
+    bf16_raw* out = u + (long)m * K * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % nq) * 8;
+        const C8 x = ld8(base + i * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = gamma[c0 + j] * (prelu(x.v[j], a) - mu) * rs + beta[c0 + j];
+        st8(out + i * 8, o);
+    }
+}
+
+// Backward of y = gLN(PReLU(h)).  The incoming gradient dy is either read directly (DW = false: du, the gradient of the
+// pointwise conv's input) or is the transposed depthwise conv of dh2 (DW = true: dy[t][c] = sum_p Wd[c][p] dh2[t - (p - P/2) d][c]).
+// pass 1 (reduce): per utterance S1 = sum gamma dy, S2 = sum gamma dy xh (double atomics into sums[2m..]); per channel
+//                  dgamma += dy xh, dbeta += dy [, dWd[c][p] += dh2[t][c] n[t + (p - P/2) d][c]]  (fp32 atomics into gch)
+// pass 2 (apply) : dh = ((gamma dy - S1/n - xh S2/n) / sigma) (h > 0 ? 1 : a);  dslope += sum dv h [h <= 0]
+template <int P, bool DW>
+__device__ __forceinline__ C8 gln_dy(const bf16_raw* __restrict__ g, const float* __restrict__ Wd, int t, int c0, int nq, int K, int dil) {
+    if (!DW) return ld8(g + ((long)t * nq) * 8 + c0);
+    C8 o = zero8();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int tt = t - (p - P / 2) * dil;
+        if (tt < 0 || tt >= K) continue;
+        const C8 x = ld8(g + ((long)tt * nq) * 8 + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] += Wd[(c0 + j) * P + p] * x.v[j];
+    }
+    return o;
+}
+
+// gch layout: dgamma [C] | dbeta [C] | dWd [C][P] (DW only)
+template <int P, bool DW>
+__global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw* __restrict__ g, const bf16_raw* __restrict__ h,
+                                                                 const float* __restrict__ slope, const double* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ Wd, int dil, int K, int C,
+                                                                 double* __restrict__ sums, float* __restrict__ gch) {
+    extern __shared__ float lds[];       // per-channel partials of the block: [(2 + (DW ? P : 0))][C]
+    const int m = blockIdx.y, nq = C >> 3;
+    const int NV = 2 + (DW ? P : 0);
+    for (int i = threadIdx.x; i < NV * C; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    const float a = slope[0];
+    float mu, rs;
+    gln_moments(stats, m, (long)K * C, mu, rs);
+    const bf16_raw* gb = g + (long)m * K * C;
+    const bf16_raw* hb = h + (long)m * K * C;
+    // a thread keeps ONE channel piece (the block's stride is a multiple of nq): per-channel sums stay in registers
+    const int stride = (256 / nq) * nq;           // active threads per block
+    float s1 = 0.f, s2 = 0.f;
+    float dg[8], db[8], dw[DW ? P : 1][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; for (int p = 0; p < (DW ? P : 1); ++p) dw[p][j] = 0.f; }
+    const int c0 = (threadIdx.x % nq) * 8;
+    if ((int)threadIdx.x < stride) {
+        const long pieces = (long)K * nq;
+        for (long i = (long)blockIdx.x * stride + threadIdx.x; i < pieces; i += (long)gridDim.x * stride) {
+            const int t = (int)(i / nq);
+            const C8 dy = gln_dy<P, DW>(gb, Wd, t, c0, nq, K, dil);
+            const C8 x = ld8(hb + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (prelu(x.v[j], a) - mu) * rs;
+                const float gd = gamma[c0 + j] * dy.v[j];
+                s1 += gd; s2 += gd * xh;
+                dg[j] += dy.v[j] * xh; db[j] += dy.v[j];
+            }
+            if (DW) {
+                const C8 d2 = ld8(gb + i * 8);       // dh2[t]
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int tt = t + (p - P / 2) * dil;
+                    if (tt < 0 || tt >= K) continue;
+                    const C8 xn = ld8(hb + ((long)tt * nq) * 8 + c0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        dw[p][j] += d2.v[j] * (gamma[c0 + j] * (prelu(xn.v[j], a) - mu) * rs + beta[c0 + j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&lds[c0 + j], dg[j]);
+            atomicAdd(&lds[C + c0 + j], db[j]);
+            if (DW)
+                for (int p = 0; p < P; ++p) atomicAdd(&lds[(2 + p) * C + c0 + j], dw[p][j]);
+        }
+    }
+    block_add2_double(s1, s2, sums + 2 * m);      // (contains a __syncthreads: the LDS partials are complete after it)
+    for (int i = threadIdx.x; i < NV * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        const float v = lds[i];
+        if (which < 2) atomicAdd(&gch[which * C + c], v);
+        else atomicAdd(&gch[2 * C + c * P + (which - 2)], v);
+    }
+}
+
+template <int P, bool DW>
+__global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* __restrict__ g, const bf16_raw* __restrict__ h,
+                                                                const float* __restrict__ slope, const double* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ Wd, int dil,
+                                                                const double* __restrict__ sums, int K, int C, bf16_raw* __restrict__ dh,
+                                                                float* __restrict__ dslope) {
+    const int m = blockIdx.y, nq = C >> 3;
+    const float a = slope[0];
+    float mu, rs;
+    gln_moments(stats, m, (long)K * C, mu, rs);
+    const double n = (double)K * C;
+    const float k1 = (float)(sums[2 * m] / n), k2 = (float)(sums[2 * m + 1] / n);
+    const bf16_raw* gb = g + (long)m * K * C;
+    const bf16_raw* hb = h + (long)m * K * C;
+    bf16_raw* out = dh + (long)m * K * C;
+    const long pieces = (long)K * nq;
+    float da = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / nq), c0 = (int)(i - (long)t * nq) * 8;
+        const C8 dy = gln_dy<P, DW>(gb, Wd, t, c0, nq, K, dil);
+        const C8 x = ld8(hb + i * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (prelu(x.v[j], a) - mu) * rs;
+            const float dv = (gamma[c0 + j] * dy.v[j] - k1 - xh * k2) * rs;
+            if (x.v[j] > 0.f) o[j] = dv;
+            else { o[j] = a * dv; da += dv * x.v[j]; }
+        }
+        st8(out + i * 8, o);
+    }
+    __shared__ float red[4];
+    da = wave_sum(da);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = da;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dslope, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// decoder: one wave per frame (m, k), both / all speakers in the wave.  V^T in LDS ([n][AL], pitch AL + 1).
+//   sw[c][n] = w[n] relu(mlin[c*N + n]);  frame[c][l] = sum_n sw[c][n] V[l][n];  out[m][c][a][k*step + l'] += frame (2 adds per
+//   sample: fp32 addition of two terms commutes, so the atomics are deterministic; caller zeroes `out`)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ctn_decoder_fwd_kernel(const float* __restrict__ w, const bf16_raw* __restrict__ mlin,
+                                                              const float* __restrict__ V /*[ac*L][N]*/, int M, int K, int N, int L, int ac,
+                                                              int Cs, int T, float* __restrict__ out /*[M][Cs][ac][T]*/) {
+    extern __shared__ float smem[];
+    const int AL = ac * L;
+    float* sV = smem;                                  // [AL][N + 1]
+    float* ssw = smem + (size_t)AL * (N + 1);          // per wave [N]
+    for (int i = threadIdx.x; i < AL * N; i += 256) { const int l = i / N, n = i - l * N; sV[l * (N + 1) + n] = V[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mysw = ssw + wave * N;
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    for (long fr = (long)blockIdx.x * 4 + wave; fr < frames; fr += (long)gridDim.x * 4) {
+        const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
+        for (int c = 0; c < Cs; ++c) {
+            for (int n = lane; n < N; n += 64) {
+                const float ml = bf2f(mlin[fr * ((long)Cs * N) + c * N + n]);
+                mysw[n] = w[fr * N + n] * (ml > 0.f ? ml : 0.f);
+            }
+            // the LDS queue of a wave is in order: no s_barrier needed inside the wave, only a compiler-level barrier so that
+            // the reads below are not scheduled above the other lanes' stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int al = lane; al < AL; al += 64) {
+                float acc = 0.f;
+                for (int n = 0; n < N; ++n) acc += mysw[n] * sV[al * (N + 1) + n];
+                const int a = al / L, l = al - a * L;
+                const long t = (long)k * step + l;
+                if (t < T) atomicAdd(&out[(((long)m * Cs + c) * ac + a) * T + t], acc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// gacc: dV [AL][N] (fp32 atomics, caller zeroes).  dmlin [M][K][Cs*N] bf16, dw_dec [M][K][N] fp32 (overwritten)
+__global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                              const bf16_raw* __restrict__ mlin, const float* __restrict__ V, int M, int K,
+                                                              int N, int L, int ac, int Cs, int T, int frames_per_wave,
+                                                              bf16_raw* __restrict__ dmlin, float* __restrict__ dw_dec,
+                                                              float* __restrict__ gacc) {
+    extern __shared__ float smem[];
+    const int AL = ac * L;
+    float* sV = smem;                                  // [AL][N]  (read with n on the lane: conflict free)
+    float* sdV = smem + (size_t)AL * N;                // per wave [AL][N] partial dV
+    float* sdf = sdV + (size_t)4 * AL * N;             // per wave [AL] dframe
+    for (int i = threadIdx.x; i < AL * N; i += 256) sV[i] = V[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mydV = sdV + (size_t)wave * AL * N;
+    float* mydf = sdf + wave * AL;
+    for (int i = lane; i < AL * N; i += 64) mydV[i] = 0.f;
+    __syncthreads();
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    const long f0 = ((long)blockIdx.x * 4 + wave) * frames_per_wave;
+    for (long fr = f0; fr < f0 + frames_per_wave && fr < frames; ++fr) {
+        const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
+        float dwacc[ENC_MAXC];
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) dwacc[i] = 0.f;
+        for (int c = 0; c < Cs; ++c) {
+            for (int al = lane; al < AL; al += 64) {
+                const int a = al / L, l = al - a * L;
+                const long t = (long)k * step + l;
+                mydf[al] = t < T ? dout[(((long)m * Cs + c) * ac + a) * T + t] : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int i = 0; i < ENC_MAXC; ++i) {
+                const int n = lane + 64 * i;
+                if (n >= N) continue;
+                const float wv = w[fr * N + n];
+                const float ml = bf2f(mlin[fr * ((long)Cs * N) + c * N + n]);
+                const float mk = ml > 0.f ? ml : 0.f;
+                const float sw = wv * mk;
+                float dsw = 0.f;
+                for (int al = 0; al < AL; ++al) {
+                    const float df = mydf[al];
+                    dsw += df * sV[al * N + n];
+                    mydV[al * N + n] += df * sw;
+                }
+                dmlin[fr * ((long)Cs * N) + c * N + n] = f2bf(ml > 0.f ? dsw * wv : 0.f);
+                dwacc[i] += dsw * mk;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int i = 0; i < ENC_MAXC; ++i) {
+            const int n = lane + 64 * i;
+            if (n < N) dw_dec[fr * N + n] = dwacc[i];
+        }
+    }
+    for (int i = lane; i < AL * N; i += 64) {
+        const float v = mydV[i];
+        if (v != 0.f) atomicAdd(&gacc[i], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+static int ctn_check(const char* who, int M, int K, int C) {
+    SEHIP_REQUIRE(M > 0 && K > 0, "%s: empty input", who);
+    SEHIP_REQUIRE(C >= 8 && C <= 512 && (C & 7) == 0, "%s: channels C=%d must be a multiple of 8 in [8, 512]", who, C);
+    return 0;
+}
+static dim3 ctn_grid(int M, int K, int C) {
+    long pieces = (long)K * (C >> 3);
+    long g = (pieces + 256 * 4 - 1) / (256 * 4);
+    if (g < 1) g = 1;
+    if (g > 64) g = 64;
+    return dim3((unsigned)g, (unsigned)M);
+}
+
+extern "C" int sehip_ctn_encoder_fwd(const float* wav, const float* U, const float* gamma, const float* beta, int M, int ac, int T, int N,
+                                     int L, float* w, void* cln_bf16, void* stream) {
+    SEHIP_REQUIRE(M > 0 && ac > 0 && T >= L && L >= 2 && (L & 1) == 0, "ctn_encoder_fwd: bad sizes (M=%d ac=%d T=%d L=%d)", M, ac, T, L);
+    SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC && (N & 7) == 0, "ctn_encoder_fwd: N=%d must be a multiple of 8 up to %d", N, 64 * ENC_MAXC);
+    const int K = (T - L) / (L / 2) + 1;
+    const size_t lds = (size_t)N * ac * L * sizeof(float);
+    SEHIP_REQUIRE(lds <= 64 * 1024, "ctn_encoder_fwd: basis of %zu bytes does not fit the LDS budget", lds);
+    long g = ((long)M * K + 3) / 4;
+    if (g > 2048) g = 2048;
+    ctn_encoder_fwd_kernel<<<(int)g, 256, lds, (hipStream_t)stream>>>(wav, U, gamma, beta, M, ac, T, K, N, L, w, (bf16_raw*)cln_bf16);
+    SEHIP_CHECK_LAUNCH("ctn_encoder_fwd");
+    return 0;
+}
+
+extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const void* dcln_bf16, const float* dw_dec, const float* gamma, int M,
+                                     int ac, int T, int N, int L, float* gacc, void* stream) {
+    SEHIP_REQUIRE(M > 0 && ac > 0 && T >= L && (L & 1) == 0, "ctn_encoder_bwd: bad sizes");
+    SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC && (N & 7) == 0, "ctn_encoder_bwd: bad N=%d", N);
+    const int K = (T - L) / (L / 2) + 1;
+    const size_t lds = (size_t)4 * N * ac * L * sizeof(float);
+    SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_encoder_bwd: %zu bytes of LDS needed", lds);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const long frames = (long)M * K;
+    int fpw = (int)((frames + 4 * 512 - 1) / (4 * 512));        // ~512 workgroups
+    if (fpw < 1) fpw = 1;
+    const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
+    ctn_encoder_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, gacc);
+    SEHIP_CHECK_LAUNCH("ctn_encoder_bwd");
+    return 0;
+}
+
+extern "C" int sehip_ctn_gln_stats(const void* h, const float* slope, int M, int K, int C, double* stats /*[M][2], caller zeroes*/, void* stream) {
+    if (int e = ctn_check("ctn_gln_stats", M, K, C)) return e;
+    ctn_gln_stats_kernel<<<ctn_grid(M, K, C), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h, slope, K, C, stats);
+    SEHIP_CHECK_LAUNCH("ctn_gln_stats");
+    return 0;
+}
+
+extern "C" int sehip_ctn_dwconv_fwd(const void* h1, const float* slope1, const double* stats1, const float* gamma, const float* beta,
+                                    const float* Wd, int P, int dilation, const float* slope2, int M, int K, int C, void* h2, double* stats2,
+                                    void* stream) {
+    if (int e = ctn_check("ctn_dwconv_fwd", M, K, C)) return e;
+    SEHIP_REQUIRE(P == 3, "ctn_dwconv_fwd: only kernel size P=3 is built (got %d)", P);
+    ctn_dwconv_fwd_kernel<3><<<ctn_grid(M, K, C), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h1, slope1, stats1, gamma, beta, Wd, dilation,
+                                                                                slope2, K, C, (bf16_raw*)h2, stats2);
+    SEHIP_CHECK_LAUNCH("ctn_dwconv_fwd");
+    return 0;
+}
+
+extern "C" int sehip_ctn_gln_apply(const void* h, const float* slope, const double* stats, const float* gamma, const float* beta, int M, int K,
+                                   int C, void* u, void* stream) {
+    if (int e = ctn_check("ctn_gln_apply", M, K, C)) return e;
+    ctn_gln_apply_kernel<<<ctn_grid(M, K, C), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h, slope, stats, gamma, beta, K, C, (bf16_raw*)u);
+    SEHIP_CHECK_LAUNCH("ctn_gln_apply");
+    return 0;
+}
+
+// dw != 0: g = dh2 and the incoming gradient is its transposed depthwise convolution (Wd, dilation); gch additionally
+// receives dWd.  sums [M][2] and gch / dslope are accumulated with atomics: the caller zeroes them.
+extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
+                                 const float* Wd, int P, int dilation, int dw, int M, int K, int C, double* sums, float* gch, void* dh,
+                                 float* dslope, void* stream) {
+    if (int e = ctn_check("ctn_gln_bwd", M, K, C)) return e;
+    SEHIP_REQUIRE(!dw || P == 3, "ctn_gln_bwd: only kernel size P=3 is built (got %d)", P);
+    SEHIP_REQUIRE((C >> 3) <= 256, "ctn_gln_bwd: too many channels");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = ctn_grid(M, K, C);
+    const size_t lds = (size_t)(2 + (dw ? 3 : 0)) * C * sizeof(float);
+    if (dw) {
+        ctn_gln_bwd_reduce_kernel<3, true><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, gch);
+        ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
+    } else {
+        ctn_gln_bwd_reduce_kernel<3, false><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, gch);
+        ctn_gln_bwd_apply_kernel<3, false><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
+    }
+    SEHIP_CHECK_LAUNCH("ctn_gln_bwd");
+    return 0;
+}
+
+extern "C" int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac, int Cs, int T,
+                                     float* out /*zeroed by the caller*/, void* stream) {
+    SEHIP_REQUIRE(M > 0 && K > 0 && Cs > 0 && ac > 0, "ctn_decoder_fwd: empty input");
+    SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC, "ctn_decoder_fwd: bad N=%d", N);
+    const size_t lds = ((size_t)ac * L * (N + 1) + 4 * N) * sizeof(float);
+    SEHIP_REQUIRE(lds <= 64 * 1024, "ctn_decoder_fwd: %zu bytes of LDS needed", lds);
+    long g = ((long)M * K + 3) / 4;
+    if (g > 2048) g = 2048;
+    ctn_decoder_fwd_kernel<<<(int)g, 256, lds, (hipStream_t)stream>>>(w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, out);
+    SEHIP_CHECK_LAUNCH("ctn_decoder_fwd");
+    return 0;
+}
+
+extern "C" int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac,
+                                     int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, void* stream) {
+    SEHIP_REQUIRE(M > 0 && K > 0 && Cs > 0 && ac > 0, "ctn_decoder_bwd: empty input");
+    SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC, "ctn_decoder_bwd: bad N=%d", N);
+    const size_t lds = ((size_t)5 * ac * L * N + 4 * ac * L) * sizeof(float);
+    SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_decoder_bwd: %zu bytes of LDS needed", lds);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const long frames = (long)M * K;
+    int fpw = (int)((frames + 4 * 512 - 1) / (4 * 512));
+    if (fpw < 1) fpw = 1;
+    const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
+    ctn_decoder_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
+                                                                   (bf16_raw*)dmlin_bf16, dw_dec, gacc);
+    SEHIP_CHECK_LAUNCH("ctn_decoder_bwd");
+    return 0;
+}

@@ -11,12 +11,13 @@ import torch.distributed as dist
 from ._lib import SehipError
 from .loss import loss_sisdr, l1_loss, mse_loss
 from .model.dccrn import DCCRN
+from .model.conv_tasnet import ConvTasNet
 from .model.dcunet import DCUnet
 from .model.dnn import DeepNeuralNetwork
 from .optim import FlatOptimizer
 from .utils import obj2dict
 
-MODEL_REGISTRY = {"dccrn": DCCRN, "dcunet": DCUnet, "dnn": DeepNeuralNetwork}
+MODEL_REGISTRY = {"dccrn": DCCRN, "dcunet": DCUnet, "dnn": DeepNeuralNetwork, "conv-tasnet": ConvTasNet}
 _REFERENCE_NAMES = ("dnn", "mel-rnn", "unet", "dccrn", "dcunet", "demucs", "wav-unet", "conv-tasnet", "crn", "rnn-stft-mask")
 
 
