@@ -62,6 +62,15 @@ def dcunet_config(complexity=45):
     return cfg
 
 
+def convtasnet_config():
+    """BASELINE config C4: ConvTasNet (N128 L40 B128 H256 P3 X7 R2, gLN), 2-speaker separation, SI-SNR, 8 kHz 4-s clips, batch 32."""
+    from sehip.utils import dict2obj
+    cfg = bench_config(0)
+    cfg.model = dict2obj({"name": "conv-tasnet", "audio_channels": 1, "num_spk": 2, "sources": ["None", "None"], "skip": False,
+                          "sample_rate": 8000, "segment": 4})
+    return cfg
+
+
 def gemm_roofline(ws, reps=5):
     """Times every product launch of the step separately, groups them by the kernel instantiation libsehip picked, and
     returns the per-class table: launches per step, average launch duration and algorithmic TFLOP/s.
@@ -203,8 +212,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dccrn, 64 for dcunet)")
-    ap.add_argument("--workload", choices=("dccrn", "dcunet"), default="dccrn",
-                    help="dccrn = BASELINE configs[1], the headline metric; dcunet = configs[2] (DCUnet-10, STFT-domain mse, B=64)")
+    ap.add_argument("--workload", choices=("dccrn", "dcunet", "convtasnet"), default="dccrn",
+                    help="dccrn = BASELINE configs[1], the headline metric; dcunet = configs[2] (DCUnet-10, STFT-domain mse, B=64); "
+                         "convtasnet = configs[4] (2-speaker separation, 8 kHz 4-s clips, B=32 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as two captured hipGraphs instead of launching "
@@ -218,6 +228,7 @@ def main():
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("STATE", "OUT"))
     args = ap.parse_args()
     dcu = args.workload == "dcunet"
+    ctn = args.workload == "convtasnet"
     if not args.batch:
         args.batch = 64 if dcu else BATCH
     if args.cpu_baseline_worker:
@@ -232,7 +243,9 @@ def main():
     n = 32768 if dcu else int(SR * CLIP_S)        # C2: 257 frames (= 1 mod 32, the depth-10 constraint) at hop 128
     clip_s = n / SR
     cfg = dcunet_config() if dcu else bench_config(n)
-    if dcu:
+    if ctn:
+        n, clip_s, cfg = 32000, 4.0, convtasnet_config()       # 4 s at 8 kHz
+    if dcu or ctn:
         args.no_cpu_baseline = True               # the CPU baseline / parity block belong to the headline workload (tests pin C2)
     torch.manual_seed(cfg.seed)
     model = distrib.get_model(cfg.model)
@@ -240,6 +253,8 @@ def main():
     solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
     dev = solver.device
     noisy, clean = make_batch(args.batch, n, rank, dev)
+    if ctn:   # two sources per clip, the mixture is their sum (sources [B, S, 1, N] stay 4-D for this model, src/solver.py:443-452)
+        clean = torch.cat([clean, noisy.unsqueeze(1) - clean], dim=1)
     mixture, sources = solver._prepare_batch(noisy, clean)
     if dcu:
         # the reference transforms mixture and sources inside every step (src/solver.py:454-458): timed with the step
@@ -300,11 +315,14 @@ def main():
     value = world * args.batch * clip_s * args.steps / dt
 
     out = {
-        "metric": "audio-sec/sec training, DCUnet-10 16kHz 2.048s bs64" if dcu else "audio-sec/sec training, DCCRN 16kHz 2s bs32", "value": value, "unit": "audio-s/s", "n_gpus": world,
+        "metric": ("audio-sec/sec training, DCUnet-10 16kHz 2.048s bs64" if dcu else "audio-sec/sec training, ConvTasNet 8kHz 4s bs32"
+                   if ctn else "audio-sec/sec training, DCCRN 16kHz 2s bs32"), "value": value, "unit": "audio-s/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("DCUnet-10 (complex, model_complexity 45 -> 31/62 channels, mask E) train step on [64,1,257,257,2] "
                                 "spectra: stft_custom of mixture and sources, mse in the STFT domain, Adam 3e-4, clip 5" if dcu else
+                                "ConvTasNet (N128 L40 B128 H256 P3 X7 R2, gLN, relu mask) 2-speaker separation train step, 8 kHz 4-s clips, "
+                                "SI-SNR, Adam 3e-4, clip 5" if ctn else
                                 "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
                                 "clips, SI-SNR, Adam 3e-4, clip 5"), "per_gpu_batch": args.batch,
                    "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
@@ -313,6 +331,8 @@ def main():
     }
     if rank == 0 and not args.no_roofline:
         ws = model.workspace(args.batch, 257, 257) if dcu else model.workspace(args.batch, n)
+        if ctn:
+            ws.st.specs = ws.st.specs   # (TasNetWorkspace keeps its products in ws.st.specs like the DCCRN workspace)
         note("per-kernel roofline pass")
         rows = gemm_roofline(ws)
         top = rows[0]
@@ -331,7 +351,7 @@ def main():
                            "all_product_kernels": {"ms_per_step": total_ms, "tflops": total_gf / total_ms,
                                                    "frac": total_gf / total_ms / PEAK_BF16_TFLOPS}}
         # algorithmic FLOPs per clip-step (SURVEY section 8d / BASELINE.md): DCCRN 45.96 GF, DCUnet-10 111.9 GF (fwd + bwd)
-        out["step_tflops"] = (111.9e9 if dcu else 45.96e9) * args.batch / (ms * 1e-3) / 1e12
+        out["step_tflops"] = (111.9e9 if dcu else 3 * 3.2e9 if ctn else 45.96e9) * args.batch / (ms * 1e-3) / 1e12
         out["kernel_classes"] = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                   "tflops": round(r["tflops"], 1)} for r in rows[:10]]
     if do_cpu:

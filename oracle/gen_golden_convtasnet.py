@@ -31,7 +31,12 @@ with torch.no_grad():   # non-trivial norm affine terms and PReLU slopes
         if prm.numel() == 1:
             prm.copy_(0.25 + 0.1 * torch.randn(prm.shape, generator=g))
 mix = 0.3 * torch.randn(2, 1, 404, generator=g)
-tgt = 0.3 * torch.randn(2, 2, 1, 404, generator=g)
+# targets = the untrained network's own output + 30 % noise: SI-SNR around +10 dB.  (With targets that are uncorrelated with
+# the output of a randomly initialised network, <est, target> is a cancellation-dominated number -- SI-SNR near -35 dB -- and
+# the loss and every gradient are ill-conditioned: a 1 % change of est moves the loss by ~1 dB.  Useless for a parity check.)
+with torch.no_grad():
+    e0 = model(mix)
+tgt = e0 + 0.3 * e0.std() * torch.randn(e0.shape, generator=g)
 out = {"sd." + k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
 taps = {}
 net = model.separator.network
