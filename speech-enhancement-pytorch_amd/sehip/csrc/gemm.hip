@@ -925,46 +925,55 @@ static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, h
 
 
 // ------------------------------------------------------------------------------------------------
-// wgrad: tile BNW (n) x 64 (k), m consumed 64 rows per step
+// wgrad: tile BNW (n) x 64*KQ (k), m consumed 64 rows per step.  KQ = 1: the LSTM / projection products (K <= 512).  KQ = 4:
+// products with a long K (the DCUnet convolutions, K up to 4480 = 35 taps x 128 channels): every 64-row slab of dOut that a
+// workgroup stages is multiplied with 256 k-columns instead of 64, i.e. dOut is re-read K/256 instead of K/64 times (it was
+// 2/3 of that kernel's traffic).
 // ------------------------------------------------------------------------------------------------
-template <int BNW, int WNN, int WNK>
+template <int BNW, int WNN, int WNK, int KQ>
 __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int m_per_block) {
     constexpr int TN = BNW / WNN / 16, TK = 64 / WNK / 16;
     constexpr int PG = BNW + 8;  // pitch in bf16 elements (16 B pad)
-    constexpr int PX = 64 + 8;
+    constexpr int PX = 64 * KQ + 8;
     constexpr int GCH = BNW / 8;         // 16-byte chunks per dOut row
     constexpr int GPT = (64 * GCH + 255) / 256;  // dOut chunks per thread
+    constexpr int NCH = 8 * KQ;          // 16-byte chunks per A row of the tile
+    constexpr int RPP = 256 / NCH;       // rows per staging pass
+    constexpr int NXA = 64 / RPP;        // A chunks per thread
     __shared__ __attribute__((aligned(16))) bf16_raw sG[64 * PG];
     __shared__ __attribute__((aligned(16))) bf16_raw sX[64 * PX];
     __shared__ sehip_dst sdst[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WNK, wk = wave % WNK;
-    const int n0 = blockIdx.x * BNW, k0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * BNW, k0 = blockIdx.y * (64 * KQ);
     const int m_begin = blockIdx.z * m_per_block;
     const int m_end = min(d.M, m_begin + m_per_block);
     if (tid < 2) sdst[tid] = d.dst[tid];
     __syncthreads();
 
-    const int kc = tid & 7, r0 = tid >> 3;
-    const sehip_kchunk e = d.ktab[(k0 >> 3) + kc];
+    const int kc = tid % NCH, r0 = tid / NCH;
+    sehip_kchunk e = d.ktab[min((k0 >> 3) + kc, (d.K >> 3) - 1)];
+    if (k0 + 8 * kc >= d.K) e.src = -1;  // the last k tile of a K that is not a multiple of 64*KQ: zero chunks
 
-    f32x4 acc[TN][TK];
+    f32x4 acc[KQ][TN][TK];
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+    for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-        for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TK; ++b) acc[kq][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // bias gradient = column sums of dOut: one extra MFMA against an all-ones operand in the waves that own k-subtile 0
     const bool do_bias = d.dbias != nullptr && blockIdx.y == 0 && wk == 0;
     f32x4 accb[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) accb[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 xa[2], ga[GPT];
+    uint4 xa[NXA], ga[GPT];
     auto fetch = [&](int mb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = mb + r0 + 32 * i;
+        for (int i = 0; i < NXA; ++i) {
+            const int m = mb + r0 + RPP * i;
             RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul, src_tmul(d));
             xa[i] = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
         }
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
     fetch(m_begin);
     for (int mb = m_begin; mb < m_end; mb += 64) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(&sX[(r0 + 32 * i) * PX + kc * 8]) = xa[i];
+        for (int i = 0; i < NXA; ++i) *reinterpret_cast<uint4*>(&sX[(r0 + RPP * i) * PX + kc * 8]) = xa[i];
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int id = tid + 256 * i;
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
         for (int sub = 0; sub < 2; ++sub) {
             const int g = lane >> 4, i16 = lane & 15;
             const int mrow = sub * 32 + 8 * g + (i16 >> 2);
-            bf16x8 gf[TN], xf[TK];
+            bf16x8 gf[TN];
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 const int col = wn * (BNW / WNN) + ni * 16 + 4 * (i16 & 3);
@@ -1028,17 +1037,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
                 gf[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
-            for (int ki = 0; ki < TK; ++ki) {
-                const int col = wk * (64 / WNK) + ki * 16 + 4 * (i16 & 3);
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sX[mrow * PX + col]);
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sX[(mrow + 4) * PX + col]);
-                xf[ki] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int kq = 0; kq < KQ; ++kq) {
+                bf16x8 xf[TK];
+#pragma unroll
+                for (int ki = 0; ki < TK; ++ki) {
+                    const int col = kq * 64 + wk * (64 / WNK) + ki * 16 + 4 * (i16 & 3);
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sX[mrow * PX + col]);
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sX[(mrow + 4) * PX + col]);
+                    xf[ki] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int ki = 0; ki < TK; ++ki)
+                        acc[kq][ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], xf[ki], acc[kq][ni][ki], 0, 0, 0);
             }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int ki = 0; ki < TK; ++ki)
-                    acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], xf[ki], acc[ni][ki], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], BF16_ONES, accb[ni], 0, 0, 0);
@@ -1049,14 +1062,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
 
     // D rows = n (4*(lane>>4)+q), cols = k (lane&15)
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
+    for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-        for (int ki = 0; ki < TK; ++ki) {
-            const int n = n0 + wn * (BNW / WNN) + ni * 16 + 4 * (lane >> 4);
-            const int k = k0 + wk * (64 / WNK) + ki * 16 + (lane & 15);
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(&d.dW[(size_t)(n + q) * d.K + k], acc[ni][ki][q]);
-        }
+            for (int ki = 0; ki < TK; ++ki) {
+                const int n = n0 + wn * (BNW / WNN) + ni * 16 + 4 * (lane >> 4);
+                const int k = k0 + kq * 64 + wk * (64 / WNK) + ki * 16 + (lane & 15);
+                if (k < d.K) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) atomicAdd(&d.dW[(size_t)(n + q) * d.K + k], acc[kq][ni][ki][q]);
+                }
+            }
     if (do_bias && (lane & 15) == 0) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
@@ -1988,11 +2005,13 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("wgrad(conv-small)");
         return 0;
     }
-    const int ktiles = d->K / 64;
     int ntiles, bnw;
     if (d->Npad == 16) bnw = 16; else if (d->Npad == 32) bnw = 32; else if (d->Npad == 64) bnw = 64; else bnw = 128;
     SEHIP_REQUIRE(d->Npad % bnw == 0, "wgrad: Npad=%d must be 16, 32, 64 or a multiple of 128", d->Npad);
     ntiles = d->Npad / bnw;
+    static const bool nowide = getenv("SEHIP_NO_WIDE_WGRAD") != nullptr;
+    const int kq = (!nowide && d->K >= 1024) ? 4 : 1;       // long K: 256 k-columns per staged dOut slab
+    const int ktiles = cdiv(d->K, 64 * kq);
     // split m so that the grid has ~2048 workgroups, at least 256 rows each
     static const int gw_wgs = getenv("SEHIP_GW_WGS") ? atoi(getenv("SEHIP_GW_WGS")) : 2048;
     long want = gw_wgs / ((long)ntiles * ktiles);
@@ -2001,11 +2020,18 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     if (mpb < 256) mpb = 256;
     const int splits = cdiv(d->M, mpb);
     dim3 grid(ntiles, ktiles, splits);
-    sehip_note_kernel("wgrad_kernel<%d, %d, %d>", bnw, bnw >= 64 ? 2 : 1, bnw >= 64 ? 2 : 4);
-    if (bnw == 16) wgrad_kernel<16, 1, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
-    else if (bnw == 32) wgrad_kernel<32, 1, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
-    else if (bnw == 64) wgrad_kernel<64, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
-    else wgrad_kernel<128, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
+    sehip_note_kernel("wgrad_kernel<%d, %d, %d, %d>", bnw, bnw >= 64 ? 2 : 1, bnw >= 64 ? 2 : 4, kq);
+    if (kq == 4) {
+        if (bnw == 16) wgrad_kernel<16, 1, 4, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else if (bnw == 32) wgrad_kernel<32, 1, 4, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else if (bnw == 64) wgrad_kernel<64, 2, 2, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else wgrad_kernel<128, 2, 2, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
+    } else {
+        if (bnw == 16) wgrad_kernel<16, 1, 4, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else if (bnw == 32) wgrad_kernel<32, 1, 4, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else if (bnw == 64) wgrad_kernel<64, 2, 2, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else wgrad_kernel<128, 2, 2, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
+    }
     SEHIP_CHECK_LAUNCH("wgrad");
     return 0;
 }

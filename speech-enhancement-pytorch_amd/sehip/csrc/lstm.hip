@@ -69,14 +69,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         __syncthreads();
     }
 
+    // The pre-gates of step t + 2 are requested while step t runs (two rotating register sets, the loop is unrolled by two so
+    // that they stay in registers): one step (~0.5 us of dependent work) does not cover an HBM round trip under load, and the
+    // eight workgroups of this kernel have nothing else to hide it with.
+    float4 pm[4];
+    if (t0 + 1 < t1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pm[g] = *reinterpret_cast<const float4*>(pre + (size_t)(t0 + 1) * (2 * G4) + g * H);
+    }
     int cur = 0;
-    for (int t = t0; t < t1; ++t) {
+    auto step = [&](int t, float4 (&pq)[4]) {
         f32x4 acc[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){pn[g].x, pn[g].y, pn[g].z, pn[g].w};
-        if (t + 1 < t1) {
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){pq[g].x, pq[g].y, pq[g].z, pq[g].w};
+        if (t + 2 < t1) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pn[g] = *reinterpret_cast<const float4*>(pre + (size_t)(t + 1) * (2 * G4) + g * H);
+            for (int g = 0; g < 4; ++g) pq[g] = *reinterpret_cast<const float4*>(pre + (size_t)(t + 2) * (2 * G4) + g * H);
         }
         bf16x8 hf[2];
 #pragma unroll
@@ -114,6 +122,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         }
         lds_barrier();
         cur ^= 1;
+    };
+    for (int t = t0; t < t1; t += 2) {
+        step(t, pn);
+        if (t + 1 < t1) step(t + 1, pm);
     }
 }
 
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
         dc[0] = a.x; dc[1] = a.y; dc[2] = a.z; dc[3] = a.w;
         dhrec = (f32x4){bq.x, bq.y, bq.z, bq.w};
     }
-    // software pipeline: the (gates, dh) of step t-1 and the cell state of step t-2 are requested while step t runs
+    // software pipeline: the (gates, dh) and the cell state of step t-2 are requested while step t runs
     struct StepIn { uint2 gi, gf, gg, go, dh; };
     const int ntiles = gridDim.x >> 2;
     const size_t rbase = (size_t)(combo * ntiles + tile) * T;  // tile-major records written by lstm_fwd_kernel
@@ -174,10 +186,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
     float4 c_t = *reinterpret_cast<const float4*>(cbase + (rbase + t1 - 1) * 1024);
     float4 c_m1 = t1 > 1 ? *reinterpret_cast<const float4*>(cbase + (rbase + t1 - 2) * 1024) : zero4;
     StepIn in = load_step(t1 - 1);
+    StepIn nx1 = in;                       // two steps ahead (one step of dependent work does not cover an HBM round trip)
+    if (t1 - 2 >= t0) nx1 = load_step(t1 - 2);
     int cur = 0;
     for (int t = t1 - 1; t >= t0; --t) {
-        StepIn nxt = in;
-        if (t > t0) nxt = load_step(t - 1);
+        StepIn nx2 = nx1;
+        if (t - 2 >= t0) nx2 = load_step(t - 2);
         float4 c_m2 = zero4;
         if (t > 1 && t > t0) c_m2 = *reinterpret_cast<const float4*>(cbase + (rbase + t - 2) * 1024);
         const float gi[4] = {bf2f(in.gi.x & 0xffff), bf2f(in.gi.x >> 16), bf2f(in.gi.y & 0xffff), bf2f(in.gi.y >> 16)};
@@ -224,7 +238,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
             dhrec = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], gfrag, dhrec, 0, 0, 0);
         }
         cur ^= 1;
-        in = nxt;
+        in = nx1;
+        nx1 = nx2;
         c_t = c_m1;
         c_m1 = c_m2;
     }
