@@ -2009,8 +2009,11 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     if (d->Npad == 16) bnw = 16; else if (d->Npad == 32) bnw = 32; else if (d->Npad == 64) bnw = 64; else bnw = 128;
     SEHIP_REQUIRE(d->Npad % bnw == 0, "wgrad: Npad=%d must be 16, 32, 64 or a multiple of 128", d->Npad);
     ntiles = d->Npad / bnw;
-    static const bool nowide = getenv("SEHIP_NO_WIDE_WGRAD") != nullptr;
-    const int kq = (!nowide && d->K >= 1024) ? 4 : 1;       // long K: 256 k-columns per staged dOut slab
+    // 256 k-columns per staged dOut slab (KQ = 4) quarter the dOut re-reads of long-K products, but measured SLOWER on the DCUnet
+    // weight gradients (B=64: 1124 vs 914 us per launch): what bounds them is the per-tap gather of the input, not dOut, and
+    // the wide tile has a quarter of the workgroups.  Opt-in for experiments only.
+    static const bool wide = getenv("SEHIP_WIDE_WGRAD") != nullptr;
+    const int kq = (wide && d->K >= 1024) ? 4 : 1;
     const int ktiles = cdiv(d->K, 64 * kq);
     // split m so that the grid has ~2048 workgroups, at least 256 rows each
     static const int gw_wgs = getenv("SEHIP_GW_WGS") ? atoi(getenv("SEHIP_GW_WGS")) : 2048;
