@@ -50,20 +50,27 @@ __device__ __forceinline__ size_t c2_dst_off(const sehip_dst& d, int b, int t, i
     return (((size_t)b * d.T + t * (d.tmul > 1 ? d.tmul : 1) + d.toff) * d.F + (size_t)j * d.fmul + d.fadd) * d.C;
 }
 
-// WMW = waves along m (64 rows each): 2 -> 128-row tile, 256 threads, two workgroups per CU; 4 -> 256-row tile, 512 threads
-template <int NF, int WMW>
-__global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int B, int PP /* patch row pitch, elements */,
+// WMW = waves along m (64 rows each): 2 -> 128-row tile, 256 threads, two workgroups per CU; 4 -> 256-row tile, 512 threads.
+// PP = patch row pitch in elements (40 / 48 / 56: 32 channels + padding), a template parameter so that the tap offset of every
+// fragment read is an instruction immediate.
+//
+// Instruction diet (PMC, round 2: 3.3 non-MFMA vector instructions per MFMA in the first version, with an MFMA occupying the
+// SIMD's vector issue for half of its 16 cycles that is an issue-bound loop): every LDS fragment address is ONE register per
+// (row group, frame offset) / (k half) + an immediate; the weight DMA takes a wave-uniform base (SGPR) + a constant per-lane
+// offset; the patch pieces keep their LDS address and row offset in registers and only look the frame up per channel chunk.
+template <int NF, int WMW, int PP>
+__global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int B,
                                                                  int FS /* patch rows per frame (>= FR) */) {
     constexpr int BM = 64 * WMW, BN = 128, NTHR = 128 * WMW;
     constexpr int TN = 4, TM = 4;          // 16 x 16 MFMA tiles per wave: 64 output channels x 64 rows
-    constexpr int NIT = 2 * NF, H = NF;    // K steps per 32-channel chunk: taps (2j, 2j + 1), j < H
+    constexpr int H = NF;                  // K steps per 32-channel chunk: taps (2j, 2j + 1), j < H
     constexpr int DW = 1024 / NTHR;        // weight-tile DMA instructions per thread and K step
     static_assert(BM == 128 || BM == 256, "tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* sW = reinterpret_cast<uint4*>(smem);                                // 3 slots of [128][8] uint4, lane-linear
     bf16_raw* patch = reinterpret_cast<bf16_raw*>(smem + 3 * C2_WSLOT);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                 // wave-uniform: LDS-DMA destinations stay scalar math
     const int wm = wave % WMW, wn = wave / WMW;
     const int ntn = d.Npad / BN;
     const int TV = d.TT + 2;                                                   // virtual frames per utterance (2 padding frames)
@@ -82,15 +89,16 @@ __global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gem
     const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
     const int NP = (TB + 1) * FR * 4;
 
-    // ---- patch staging.  Piece u of this thread = 16 bytes at (patch frame p, row r, channel piece c4), packed once into
-    // pk[u] = p | (r*4 + c4) << 8 (-1: no such piece).  What depends on the frame -- which utterance / source frame a patch frame
-    // is, or that it is padding -- is the same for every piece of that frame: a table in LDS, filled once per workgroup
-    // (ftab[s][p] = b*T_s + x, -1 if invalid), instead of two integer divisions per piece and channel chunk.
+    // ---- patch staging.  Piece u of this thread = 16 bytes at (patch frame p, row r, channel piece c4).  Kept per piece: its
+    // LDS element address, its patch frame and its offset inside a source frame ((f0 + r) * C_s + 8 c4, per source; -1 when the
+    // row lies outside the source).  What depends on the frame -- which utterance / source frame a patch frame is, or that it is
+    // padding -- is the same for every piece of that frame: a table in LDS, filled once per workgroup (ftab[s][p] = element
+    // offset of frame b*T_s + x, -1 if invalid).
     const bf16_raw* s0p = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
     const bf16_raw* s1p = reinterpret_cast<const bf16_raw*>(d.src[1].ptr);
     const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&c2_zero16);
     int* ftab = reinterpret_cast<int*>(smem + 3 * C2_WSLOT + (size_t)(TB + 1) * FS * PP * 2);   // [2][TB + 1], behind the patch
-    const int dump = (TB + 1) * FS * PP + 4 * (TB + 1);                  // 16 bytes behind the table for the unused piece slots
+    const int dump = (TB + 1) * FS * PP + 4 * (TB + 1);                        // 16 bytes behind the table for the unused piece slots
     if (tid < 2 * (TB + 1)) {
         const int s = tid / (TB + 1), p = tid - s * (TB + 1);
         const sehip_src& S = s ? d.src[1] : d.src[0];
@@ -98,70 +106,75 @@ __global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gem
         int v = -1;
         if (sv >= 0 && (s == 0 || C1)) {
             const int b = sv / TV, x = sv - b * TV;
-            if (b < B && x >= S.tlo && x < S.thi) v = b * S.T + x;
+            if (b < B && x >= S.tlo && x < S.thi) v = (b * S.T + x) * S.F * S.C;
         }
         ftab[tid] = v;
     }
-    int pk[C2_MAXP];
+    int p_at[C2_MAXP], p_fr[C2_MAXP], p_r0[C2_MAXP], p_r1[C2_MAXP];
     {
         const int fr4 = FR * 4;
 #pragma unroll
         for (int u = 0; u < C2_MAXP; ++u) {
             const int idx = tid + NTHR * u;
             const int p = idx / fr4, rem = idx - p * fr4;
-            pk[u] = idx < NP ? (p | (rem << 8)) : -1;
+            const int r = rem >> 2, c4 = rem & 3, f = f0 + r;
+            const bool have = idx < NP;
+            p_at[u] = have ? (p * FS + r) * PP + c4 * 8 : dump;
+            p_fr[u] = have ? p : 0;
+            p_r0[u] = (have && (unsigned)f < (unsigned)d.src[0].F) ? f * C0 + c4 * 8 : -1;
+            p_r1[u] = (have && C1 && (unsigned)f < (unsigned)d.src[1].F) ? f * C1 + c4 * 8 : -1;
         }
     }
     __syncthreads();
     uint4 pr[C2_MAXP];
     auto fetch_patch = [&](int ch) {
         const int second = ch * 32 >= C0 ? 1 : 0;
-        const int sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
         const bf16_raw* base = (second ? s1p : s0p) + (ch * 32 - (second ? C0 : 0));
         const int* ft = ftab + second * (TB + 1);
         int fb[C2_MAXP];
 #pragma unroll
-        for (int u = 0; u < C2_MAXP; ++u) fb[u] = ft[pk[u] < 0 ? 0 : (pk[u] & 0xff)];   // all table reads in flight together
+        for (int u = 0; u < C2_MAXP; ++u) fb[u] = ft[p_fr[u]];                 // all table reads in flight together
 #pragma unroll
         for (int u = 0; u < C2_MAXP; ++u) {
-            const int rem = (pk[u] < 0 ? 0 : pk[u]) >> 8;
-            const int f = f0 + (rem >> 2);
-            const int ok = (int)(pk[u] >= 0) & (int)(fb[u] >= 0) & (int)((unsigned)f < (unsigned)sF);   // no short-circuit branches
-            const bf16_raw* q = base + ((fb[u] * sF + f) * sC + (rem & 3) * 8);
-            q = ok ? q : zero_page;
+            const int ro = second ? p_r1[u] : p_r0[u];
+            const bf16_raw* q = ((fb[u] | ro) >= 0) ? base + (fb[u] + ro) : zero_page;   // either negative: padding -> zeros
             const c2_u32x4 x4 = *(c2_gvec_ptr)(q);       // explicit global-address-space load (a select of generic pointers is a flat load)
             pr[u] = make_uint4(x4[0], x4[1], x4[2], x4[3]);
         }
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int u = 0; u < C2_MAXP; ++u) {
-            const int p = pk[u] & 0xff, rem = pk[u] >> 8;
-            const int at = pk[u] >= 0 ? (p * FS + (rem >> 2)) * PP + (rem & 3) * 8 : dump;   // branch-free: unused slots hit a dump
-            *reinterpret_cast<uint4*>(&patch[at]) = pr[u];
-        }
+        for (int u = 0; u < C2_MAXP; ++u) *reinterpret_cast<uint4*>(&patch[p_at[u]]) = pr[u];   // unused slots hit the dump
     };
 
     // ---- weight-tile DMA: piece q = tid + NTHR*i -> row r = q >> 3; LDS chunk c' = q & 7 holds tile chunk c = c' ^ (r & 7);
-    //      tile chunk c = tap (2j + (c >> 2)), channels 8*(c & 3) .. +7 of the 32-channel chunk
-    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
-    const bf16_raw* wsrc[DW];
+    //      tile chunk c = tap (2j + (c >> 2)), channels 8*(c & 3) .. +7 of the 32-channel chunk.  Address = wave-uniform pointer
+    //      (W + step offset, SGPR) + this lane's constant element offset.
+    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;
+    unsigned woff[DW];
 #pragma unroll
     for (int i = 0; i < DW; ++i) {
         const int q = tid + NTHR * i;
         const int r = q >> 3, c = (q & 7) ^ (r & 7);
-        wsrc[i] = Wb + (size_t)(n0 + r) * d.K + (c >> 2) * Ctot + (c & 3) * 8;
+        woff[i] = (unsigned)(r * d.K + (c >> 2) * Ctot + (c & 3) * 8);
     }
-    auto issue_w = [&](int s) {                  // K step s = ch * H + j reads W columns (2j + {0, 1}) * Ctot + ch*32 ..
-        const int ch = s / H, j = s - ch * H;
-        const int kcol = 2 * j * Ctot + ch * 32;
-        unsigned char* slot = smem + (s % 3) * C2_WSLOT + wave * 1024;
+    auto issue_w = [&](int ch, int j, int slot) {        // K step (ch, j) reads W columns (2j + {0, 1}) * Ctot + ch*32 ..
+        const bf16_raw* wb = Wb + (2 * j * Ctot + ch * 32);
+        unsigned char* dst = smem + slot * C2_WSLOT + wave * 1024;
 #pragma unroll
         for (int i = 0; i < DW; ++i)
-            __builtin_amdgcn_global_load_lds((c2_gvoid*)(wsrc[i] + kcol), (c2_lds_void*)(slot + i * (NTHR * 16)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((c2_gvoid*)(wb + woff[i]), (c2_lds_void*)(dst + i * (NTHR * 16)), 16, 0, 0);
     };
 
-    // per-lane patch offsets of its TM activation rows (element units, k-chunk of the lane included)
+    // ---- fragment addresses.  Weights: byte offset of this lane's row / k piece inside a slot for the two k halves of a step;
+    // the 16-row tiles of a wave are immediates (ni * 16 rows * 128 B).  Activations: element offset of the lane's row in the
+    // patch for each of its TM row groups; frame offset of the tap pair and the tap itself are added per chunk / as immediates.
+    int wrd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int r = wn * 64 + (lane & 15);
+        wrd[ks] = (r * 8 + ((ks * 4 + (lane >> 4)) ^ (r & 7))) * 16;
+    }
     int abase[TM];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -179,15 +192,19 @@ __global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gem
     const int S = nch * H;
     // prologue: patch of chunk 0 through registers, weight tiles 0 and 1 in flight
     fetch_patch(0);
-    issue_w(0);
-    if (S > 1) issue_w(1);
+    issue_w(0, 0, 0);
+    if (S > 1) issue_w(H > 1 ? 0 : 1, H > 1 ? 1 : 0, 1);
     store_patch();
     if (nch > 1) fetch_patch(1);           // next chunk's patch rides behind the first K steps
 
+    int slot = 0;                          // slot of tile s; tile s + 2 goes to (slot + 2) % 3
     for (int ch = 0; ch < nch; ++ch) {
         const bool second = ch * 32 >= C0;
         const int dt0 = (second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0);
         const int dt1 = (second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0);
+        int afr[2][TM];                    // row-group address + frame offset of kt = 0 / 1
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) { afr[0][mi] = abase[mi] + dt0 * FS * PP; afr[1][mi] = abase[mi] + dt1 * FS * PP; }
         if (ch > 0) {
             // every wave has finished reading the previous chunk's patch once it has passed this barrier
             __builtin_amdgcn_s_barrier();
@@ -209,30 +226,30 @@ __global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gem
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < S) issue_w(s + 2);
-            const uint4* sWs = sW + (s % 3) * (C2_WSLOT / 16);
+            if (s + 2 < S) {                                   // tile s + 2 = (ch, j + 2) or the next chunk's (j + 2 - H)
+                const int slot2 = slot == 0 ? 2 : slot - 1;    // (slot + 2) % 3
+                if (j + 2 < H) issue_w(ch, j + 2, slot2); else issue_w(ch + 1, j + 2 - H, slot2);
+            }
+            const unsigned char* wslot = smem + slot * C2_WSLOT;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 constexpr int dummy = 0; (void)dummy;
                 const int it = 2 * j + ks;
                 const int kt = it / NF, tap = it - kt * NF;
-                const int toff_e = ((kt ? dt1 : dt0) * FS + tap) * PP;
-                const int c = ks * 4 + (lane >> 4);
                 bf16x8 wf[TN], af[TM];
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    const int r = wn * 64 + ni * 16 + (lane & 15);
-                    wf[ni] = __builtin_bit_cast(bf16x8, sWs[r * 8 + (c ^ (r & 7))]);
-                }
+                for (int ni = 0; ni < TN; ++ni)
+                    wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wslot + wrd[ks] + ni * (16 * 128)));
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
-                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[abase[mi] + toff_e]));
+                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[afr[kt][mi] + tap * PP]));
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
+            slot = slot == 2 ? 0 : slot + 1;
         }
     }
 
@@ -324,16 +341,22 @@ __global__ __launch_bounds__(128 * WMW) void conv_gemm_v2_kernel(const sehip_gem
     }
 }
 
-template <int NF, int WMW>
-static void c2_launch(const sehip_gemm_desc& d, int TB, int JB, int FR, int B, int PP, int FS, int grid, size_t lds, hipStream_t st) {
+template <int NF, int WMW, int PP>
+static void c2_launch_pp(const sehip_gemm_desc& d, int TB, int JB, int FR, int B, int FS, int grid, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, WMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, WMW, PP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    conv_gemm_v2_kernel<NF, WMW, PP><<<grid, 128 * WMW, lds, st>>>(d, TB, JB, FR, B, FS);
+}
+template <int NF, int WMW>
+static void c2_launch(const sehip_gemm_desc& d, int TB, int JB, int FR, int B, int PP, int FS, int grid, size_t lds, hipStream_t st) {
     sehip_note_kernel("conv_gemm_v2_kernel<%d, %d>", NF, WMW);
-    conv_gemm_v2_kernel<NF, WMW><<<grid, 128 * WMW, lds, st>>>(d, TB, JB, FR, B, PP, FS);
+    if (PP == 40) c2_launch_pp<NF, WMW, 40>(d, TB, JB, FR, B, FS, grid, lds, st);
+    else if (PP == 48) c2_launch_pp<NF, WMW, 48>(d, TB, JB, FR, B, FS, grid, lds, st);
+    else c2_launch_pp<NF, WMW, 56>(d, TB, JB, FR, B, FS, grid, lds, st);
 }
 
 // LDS cycles of one A-fragment ds_read_b128 wave instruction (4 = conflict free) for a patch with row pitch `pitch` bytes and
@@ -374,7 +397,7 @@ static_assert(C2_MAXP == 7, "the counted waits (vmcnt(DW + C2_MAXP)) are written
 int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_CONV_V2") != nullptr || getenv("SEHIP_NO_PATCH") != nullptr;
     static const int bm_force = getenv("SEHIP_CONV_V2_BM") ? atoi(getenv("SEHIP_CONV_V2_BM")) : 0;
-    static const bool no_census = getenv("SEHIP_CONV_V2_NO_CENSUS") != nullptr;
+    static const bool census = getenv("SEHIP_CONV_V2_CENSUS") != nullptr;
     if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     if ((C0 & 63) || (C1 & 63) || (d.Npad & 127) || d.J > 64 || (128 % d.J)) return 0;
@@ -397,11 +420,11 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
         const int TB = BM / JB;
         const int nthr = BM * 2;
         // bank-conflict census: row pitch 80 / 96 / 112 bytes x up to 3 padding rows per frame
-        // (measured per tap count, B=32 full-size layers, us per launch, round-1 kernel / this kernel at 80 B / with the census:
-        //  5 taps 116 / 145 / 110, 3 taps 109 / 96 / 111, 2 taps 88 / 83 / 80 -- the census is a model of the fragment reads only,
-        //  so the 3-tap layers keep the plain 80-byte pitch)
+        // (opt-in: with the register budget pinned to two waves per SIMD the plain 80-byte pitch measures the same or better --
+        //  5 taps 104 vs 108 us, 3 taps 96 vs 111, 2 taps 83 vs 81; an earlier "145 -> 110 us" of the census was an occupancy
+        //  artefact: without __launch_bounds__(.., 2) that build spilled into AGPRs and ran ONE wave per SIMD)
         int PP = 40, FS = FR;
-        if (!no_census && d.cv_nf != 3) {
+        if (census) {
             double best = 1e9;
             for (int pitch = 80; pitch <= 112; pitch += 16)
                 for (int fs = FR; fs <= FR + 3; ++fs) {
@@ -436,10 +459,14 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
     }
 }
 
+template <int NF, int WMW, int PP>
+static void c2_init_one() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, WMW, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 template <int NF>
 static void c2_init_nf() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v2_kernel<NF, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    c2_init_one<NF, 2, 40>(); c2_init_one<NF, 2, 48>(); c2_init_one<NF, 2, 56>();
+    c2_init_one<NF, 4, 40>(); c2_init_one<NF, 4, 48>(); c2_init_one<NF, 4, 56>();
 }
 void sehip_conv2_init(void) {
     c2_init_nf<2>(); c2_init_nf<3>(); c2_init_nf<5>();
