@@ -19,42 +19,58 @@
 // fwd coef record: 0 Zrr 1 Zri 2 Zir 3 Zii 4 Mr 5 Mi 6 Br 7 Bi 8 Urr 9 Uri 10 Uii 11 vrr(+eps) 12 vri 13 vii(+eps)
 // bwd coef record: 0 Arr 1 Ari 2 Air 3 Aii 4 Err 5 Eri 6 Eii 7 kr 8 ki
 
-struct Chunk8 { float v[8]; };
-__device__ __forceinline__ Chunk8 unpack8(uint4 u) {
-    Chunk8 c;
+// A thread's slice of a row: CH complex channels = one 2*CH-byte load from the real half and one from the imaginary half.
+// CH = 8 (16-byte loads) keeps 8 channels' coefficient records in registers, CH = 4 (8-byte loads) half of them: the
+// backward passes hold 17 floats per channel, and at 8 channels that is one wave per SIMD -- too few loads in flight.
+template <int CH> struct Raw;
+template <> struct Raw<8> { typedef uint4 type; };
+template <> struct Raw<4> { typedef uint2 type; };
+template <int CH> struct Chunk { float v[CH]; };
+__device__ __forceinline__ Chunk<8> unpack(uint4 u) {
+    Chunk<8> c;
     c.v[0] = bf2f((bf16_raw)(u.x & 0xffff)); c.v[1] = bf2f((bf16_raw)(u.x >> 16));
     c.v[2] = bf2f((bf16_raw)(u.y & 0xffff)); c.v[3] = bf2f((bf16_raw)(u.y >> 16));
     c.v[4] = bf2f((bf16_raw)(u.z & 0xffff)); c.v[5] = bf2f((bf16_raw)(u.z >> 16));
     c.v[6] = bf2f((bf16_raw)(u.w & 0xffff)); c.v[7] = bf2f((bf16_raw)(u.w >> 16));
     return c;
 }
-__device__ __forceinline__ uint4 pack8(const float* v) {
-    return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+__device__ __forceinline__ Chunk<4> unpack(uint2 u) {
+    Chunk<4> c;
+    c.v[0] = bf2f((bf16_raw)(u.x & 0xffff)); c.v[1] = bf2f((bf16_raw)(u.x >> 16));
+    c.v[2] = bf2f((bf16_raw)(u.y & 0xffff)); c.v[3] = bf2f((bf16_raw)(u.y >> 16));
+    return c;
+}
+__device__ __forceinline__ void pack_store(bf16_raw* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+__device__ __forceinline__ void pack_store(bf16_raw* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
 }
 
 // Reduce NS per-thread sums (for 8 channels each) over the threads of the block that share a chunk column q and
 // store the block's partial sums at part[blockIdx.x][a*Cr + channel] (no atomics: a later per-channel wave adds the
 // partials of all blocks in double precision).
-template <int NS>
-__device__ __forceinline__ void block_partials(float (&s)[NS][8], int nq, int Cr, float* __restrict__ part, int stride,
-                                               float* lds /* [4][NS*8][nq] floats */) {
+template <int NS, int CH>
+__device__ __forceinline__ void block_partials(float (&s)[NS][CH], int nq, int Cr, float* __restrict__ part, int stride,
+                                               float* lds /* [4][NS*CH][nq] floats */) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* out = part + (size_t)blockIdx.x * stride;
     // fold the lanes of a wave that share a chunk column (nq divides 64), park the wave partials in LDS, ONE barrier,
-    // then NS*8*nq threads add the four waves
+    // then NS*CH*nq threads add the four waves
 #pragma unroll
     for (int a = 0; a < NS; ++a)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CH; ++j) {
             float v = s[a][j];
             for (int o = 32; o >= nq; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane < nq) lds[(w * NS * 8 + a * 8 + j) * nq + lane] = v;
+            if (lane < nq) lds[(w * NS * CH + a * CH + j) * nq + lane] = v;
         }
     __syncthreads();
-    for (int i = tid; i < NS * 8 * nq; i += 256) {
-        const float t = lds[i] + lds[NS * 8 * nq + i] + lds[2 * NS * 8 * nq + i] + lds[3 * NS * 8 * nq + i];
+    const int n = NS * CH * nq;
+    for (int i = tid; i < n; i += 256) {
+        const float t = lds[i] + lds[n + i] + lds[2 * n + i] + lds[3 * n + i];
         const int aj = i / nq, q = i - aj * nq;
-        out[(size_t)(aj >> 3) * Cr + q * 8 + (aj & 7)] = t;
+        out[(size_t)(aj / CH) * Cr + q * CH + (aj % CH)] = t;
     }
 }
 
@@ -87,43 +103,44 @@ __device__ __forceinline__ void wave_reduce_partials(const float* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
+template <int CH>
 __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restrict__ y, long rows, int Cr,
                                                         float* __restrict__ part /* [nblk][5*Cr] */) {
+    typedef typename Raw<CH>::type raw_t;
     __shared__ float lds[4 * 5 * 8 * 32];
-    const int nq = Cr >> 3;
+    const int nq = Cr / CH;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
-    float s[5][8];
+    float s[5][CH];
 #pragma unroll
     for (int a = 0; a < 5; ++a)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[a][j] = 0.f;
+        for (int j = 0; j < CH; ++j) s[a][j] = 0.f;
     const int C = 2 * Cr;
-    if (rl < rpb) {
-        // four rows per trip: 8 independent 16-byte loads in flight per thread (one workgroup per CU must cover HBM latency)
-        const long stride = (long)gridDim.x * rpb;
-        for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 4 * stride) {
-            uint4 ua[4], ub[4];
+    auto add_row = [&](const raw_t& ua, const raw_t& ub) {
+        const Chunk<CH> a = unpack(ua), b = unpack(ub);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long r = r0 + u * stride;
-                ua[u] = make_uint4(0u, 0u, 0u, 0u); ub[u] = ua[u];
-                if (r < rows) {
-                    ua[u] = *reinterpret_cast<const uint4*>(y + r * C + q * 8);
-                    ub[u] = *reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const Chunk8 a = unpack8(ua[u]), b = unpack8(ub[u]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    s[0][j] += a.v[j]; s[1][j] += b.v[j];
-                    s[2][j] += a.v[j] * a.v[j]; s[3][j] += a.v[j] * b.v[j]; s[4][j] += b.v[j] * b.v[j];
-                }
-            }
+        for (int j = 0; j < CH; ++j) {
+            s[0][j] += a.v[j]; s[1][j] += b.v[j];
+            s[2][j] += a.v[j] * a.v[j]; s[3][j] += a.v[j] * b.v[j]; s[4][j] += b.v[j] * b.v[j];
         }
+    };
+    // four rows per trip, no predicate inside the trip: 8 independent loads in flight per thread
+    const long stride = (long)gridDim.x * rpb;
+    const bf16_raw* p = y + q * CH;
+    long r = (long)blockIdx.x * rpb + rl;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+        raw_t ua[4], ub[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ua[u] = *reinterpret_cast<const raw_t*>(p + (r + u * stride) * C);
+            ub[u] = *reinterpret_cast<const raw_t*>(p + (r + u * stride) * C + Cr);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add_row(ua[u], ub[u]);
     }
-    block_partials<5>(s, nq, Cr, part, 5 * Cr, lds);
+    for (; r < rows; r += stride)
+        add_row(*reinterpret_cast<const raw_t*>(p + r * C), *reinterpret_cast<const raw_t*>(p + r * C + Cr));
+    block_partials<5, CH>(s, nq, Cr, part, 5 * Cr, lds);
 }
 
 // one wave per complex channel
@@ -174,91 +191,148 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
     o[8] = urr; o[9] = uri; o[10] = uii; o[11] = vrr; o[12] = vri; o[13] = vii;
 }
 
-__global__ __launch_bounds__(256) void cbn_apply_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ coef,
-                                                        const float* __restrict__ slope, long rows, int Cr,
-                                                        bf16_raw* __restrict__ z) {
-    // a thread owns ONE chunk of 8 complex channels for all its rows: the 64 coefficient floats stay in registers
-    // (re-loading them per row made the kernel TA-issue bound: 16 coefficient loads per 2 data loads)
-    const int nq = Cr >> 3;
+// The per-channel coefficient records reach the threads through LDS: every thread needs the records of its CH complex
+// channels, and fetching them straight from memory (16-40 scattered 16-byte loads per thread, 32 cache lines per wave
+// instruction on the wide layers) cost more address traffic than the rows the thread then streams.  One coalesced pass
+// puts field f of channel q*CH+j at slot [f][j*nq + q]: the lanes of a wave read consecutive slots (no bank conflict).
+template <int CH>
+__device__ __forceinline__ void stage_coef(const float* __restrict__ rec, int Cr, int nfield, float4* __restrict__ slot) {
+    const int nq = Cr / CH;
+    for (int i = threadIdx.x; i < Cr * nfield; i += 256) {
+        const int c = i / nfield, f = i - c * nfield;
+        slot[f * Cr + (c % CH) * nq + (c / CH)] = reinterpret_cast<const float4*>(rec)[c * (COEF_STRIDE / 4) + f];
+    }
+}
+
+template <int U, int CH>
+__global__ __launch_bounds__(256, 2) void cbn_apply_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                           const float* __restrict__ slope, long rows, int Cr,
+                                                           bf16_raw* __restrict__ z) {
+    typedef typename Raw<CH>::type raw_t;
+    __shared__ float4 cl[2 * 256];
+    // a thread owns ONE chunk of CH complex channels for all its rows: their coefficient floats stay in registers
+    const int nq = Cr / CH;
     const int C = 2 * Cr;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     const float a = slope[0];
-    float4 zc[8], mb[8];
+    stage_coef<CH>(coef, Cr, 2, cl);
+    __syncthreads();
+    float4 zc[CH], mb[CH];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
-        zc[j] = *reinterpret_cast<const float4*>(k);
-        mb[j] = *reinterpret_cast<const float4*>(k + 4);
-    }
-    for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
-        const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
-        const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
-        float orr[8], oii[8];
+    for (int j = 0; j < CH; ++j) { zc[j] = cl[j * nq + q]; mb[j] = cl[Cr + j * nq + q]; }
+    auto row = [&](const raw_t& ur, const raw_t& ui, long r) {
+        const Chunk<CH> xr = unpack(ur), xi = unpack(ui);
+        float orr[CH], oii[CH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
             const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
             const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
             orr[j] = vr > 0.f ? vr : a * vr;
             oii[j] = vi > 0.f ? vi : a * vi;
         }
-        *reinterpret_cast<uint4*>(z + r * C + q * 8) = pack8(orr);
-        *reinterpret_cast<uint4*>(z + r * C + Cr + q * 8) = pack8(oii);
+        pack_store(z + r * C + q * CH, orr);
+        pack_store(z + r * C + Cr + q * CH, oii);
+    };
+    const long stride = (long)gridDim.x * rpb;
+    const bf16_raw* p = y + q * CH;
+    long r = (long)blockIdx.x * rpb + rl;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+        raw_t ur[U], ui[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ur[u] = *reinterpret_cast<const raw_t*>(p + (r + u * stride) * C);
+            ui[u] = *reinterpret_cast<const raw_t*>(p + (r + u * stride) * C + Cr);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(ur[u], ui[u], r + u * stride);
     }
+    if (U > 1)
+        for (; r < rows; r += stride)
+            row(*reinterpret_cast<const raw_t*>(p + r * C), *reinterpret_cast<const raw_t*>(p + r * C + Cr), r);
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward pass 1: per-channel sums  0 sum d_r  1 sum d_i  2 Qrr  3 Qri  4 Qir  5 Qii ; slope grad -> acc[6*Cr]
 // rows whose stored frame index (row / F) % Tst is < tfirst carry dz == 0 (dropped decoder frame).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
-                                                             const bf16_raw* __restrict__ y, const float* __restrict__ coef,
-                                                             const float* __restrict__ slope, long rows, int Cr, int F,
-                                                             int Tst, int tfirst, float* __restrict__ part) {
+template <int CH, bool HAS2> struct RowIn { typename Raw<CH>::type yr, yi, gr, gi, hr, hi; };
+
+template <int CH, bool HAS2>
+__device__ __forceinline__ RowIn<CH, HAS2> load_row(const bf16_raw* __restrict__ y, const bf16_raw* __restrict__ dz,
+                                                    const bf16_raw* __restrict__ dz2, long o, int Cr) {
+    typedef typename Raw<CH>::type raw_t;
+    RowIn<CH, HAS2> v;
+    v.yr = *reinterpret_cast<const raw_t*>(y + o);
+    v.yi = *reinterpret_cast<const raw_t*>(y + o + Cr);
+    v.gr = *reinterpret_cast<const raw_t*>(dz + o);
+    v.gi = *reinterpret_cast<const raw_t*>(dz + o + Cr);
+    if (HAS2) {
+        v.hr = *reinterpret_cast<const raw_t*>(dz2 + o);
+        v.hi = *reinterpret_cast<const raw_t*>(dz2 + o + Cr);
+    }
+    return v;
+}
+
+template <int U, int CH, bool HAS2>
+__global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
+                                                                const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                                const float* __restrict__ slope, long rows, int Cr, int F,
+                                                                int Tst, int tfirst, float* __restrict__ part) {
     __shared__ float lds[4 * 6 * 8 * 32];
-    const int nq = Cr >> 3;
+    const int nq = Cr / CH;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     const int C = 2 * Cr;
     const float a = slope[0];
-    float s[6][8];
+    float s[6][CH];
 #pragma unroll
     for (int u = 0; u < 6; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[u][j] = 0.f;
+        for (int j = 0; j < CH; ++j) s[u][j] = 0.f;
     float da = 0.f;
-    float4 zc[8], mb[8];
+    float4 zc[CH], mb[CH];
+    {
+        float4* cl = reinterpret_cast<float4*>(lds);   // 2 * Cr float4 <= 8 KB of the 24 KB partial-sum area
+        stage_coef<CH>(coef, Cr, 2, cl);
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
-        zc[j] = *reinterpret_cast<const float4*>(k);
-        mb[j] = *reinterpret_cast<const float4*>(k + 4);
+        for (int j = 0; j < CH; ++j) { zc[j] = cl[j * nq + q]; mb[j] = cl[Cr + j * nq + q]; }
+        __syncthreads();
     }
-    if (rl < rpb)
-        for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
-            if (tfirst > 0 && (int)((r / F) % Tst) < tfirst) continue;
-            const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
-            const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
-            Chunk8 gr = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + q * 8));
-            Chunk8 gi = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + Cr + q * 8));
-            if (dz2) {
-                const Chunk8 hr = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + q * 8));
-                const Chunk8 hi = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + Cr + q * 8));
+    // rows of a dropped decoder frame are loaded like the others (the buffer is there) and then skipped
+    auto row = [&](const RowIn<CH, HAS2>& v, long r) {
+        if (tfirst > 0 && (int)(((unsigned)r / (unsigned)F) % (unsigned)Tst) < tfirst) return;
+        const Chunk<CH> xr = unpack(v.yr), xi = unpack(v.yi);
+        Chunk<CH> gr = unpack(v.gr), gi = unpack(v.gi);
+        if (HAS2) {
+            const Chunk<CH> hr = unpack(v.hr), hi = unpack(v.hi);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
-                const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
-                const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
-                float dr = gr.v[j], di = gi.v[j];
-                if (!(vr > 0.f)) { da += dr * vr; dr *= a; }
-                if (!(vi > 0.f)) { da += di * vi; di *= a; }
-                s[0][j] += dr; s[1][j] += di;
-                s[2][j] += dr * cr; s[3][j] += dr * ci; s[4][j] += di * cr; s[5][j] += di * ci;
-            }
+            for (int j = 0; j < CH; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
         }
-    block_partials<6>(s, nq, Cr, part, 6 * Cr + 1, lds);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
+            const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
+            const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
+            float dr = gr.v[j], di = gi.v[j];
+            if (!(vr > 0.f)) { da += dr * vr; dr *= a; }
+            if (!(vi > 0.f)) { da += di * vi; di *= a; }
+            s[0][j] += dr; s[1][j] += di;
+            s[2][j] += dr * cr; s[3][j] += dr * ci; s[4][j] += di * cr; s[5][j] += di * ci;
+        }
+    };
+    const long stride = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + rl;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+        RowIn<CH, HAS2> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load_row<CH, HAS2>(y, dz, dz2, (r + u * stride) * C + q * CH, Cr);
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(v[u], r + u * stride);
+    }
+    if (U > 1)
+        for (; r < rows; r += stride) row(load_row<CH, HAS2>(y, dz, dz2, r * C + q * CH, Cr), r);
+    block_partials<6, CH>(s, nq, Cr, part, 6 * Cr + 1, lds);
     da = wave_sum(da);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = da;
@@ -328,61 +402,66 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
     o[8] = -(air * sdr + aii * sdi) / n;
 }
 
-__global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
-                                                            const bf16_raw* __restrict__ y, const float* __restrict__ coef,
-                                                            const float* __restrict__ bcoef, const float* __restrict__ slope,
-                                                            long rows, int Cr, int F, int Tst, int tfirst,
-                                                            bf16_raw* __restrict__ dy) {
-    const int nq = Cr >> 3;
+template <int U, int CH, bool HAS2>
+__global__ __launch_bounds__(256, 2) void cbn_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
+                                                               const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                               const float* __restrict__ bcoef, const float* __restrict__ slope,
+                                                               long rows, int Cr, int F, int Tst, int tfirst,
+                                                               bf16_raw* __restrict__ dy) {
+    __shared__ float4 cl[5 * 256];
+    const int nq = Cr / CH;
     const int C = 2 * Cr;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     const float a = slope[0];
-    // per-channel coefficients of this thread's 8 complex channels, in registers for the whole pass
-    float4 zc[8], mb[8], A[8], E[8];
-    float ki[8];
+    // per-channel coefficients of this thread's CH complex channels, in registers for the whole pass
+    stage_coef<CH>(coef, Cr, 2, cl);
+    stage_coef<CH>(bcoef, Cr, 3, cl + 2 * Cr);
+    __syncthreads();
+    float4 zc[CH], mb[CH], A[CH], E[CH];
+    float ki[CH];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float* k = coef + (size_t)(q * 8 + j) * COEF_STRIDE;
-        const float* kb = bcoef + (size_t)(q * 8 + j) * COEF_STRIDE;
-        zc[j] = *reinterpret_cast<const float4*>(k);
-        mb[j] = *reinterpret_cast<const float4*>(k + 4);
-        A[j] = *reinterpret_cast<const float4*>(kb);
-        E[j] = *reinterpret_cast<const float4*>(kb + 4);  // Err Eri Eii kr
-        ki[j] = kb[8];
+    for (int j = 0; j < CH; ++j) {
+        zc[j] = cl[j * nq + q];
+        mb[j] = cl[Cr + j * nq + q];
+        A[j] = cl[2 * Cr + j * nq + q];
+        E[j] = cl[3 * Cr + j * nq + q];  // Err Eri Eii kr
+        ki[j] = cl[4 * Cr + j * nq + q].x;
     }
-    for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
-        const bool dropped = tfirst > 0 && (int)((r / F) % Tst) < tfirst;
-        const Chunk8 xr = unpack8(*reinterpret_cast<const uint4*>(y + r * C + q * 8));
-        const Chunk8 xi = unpack8(*reinterpret_cast<const uint4*>(y + r * C + Cr + q * 8));
-        Chunk8 gr, gi;
-        if (dropped) {
+    auto row = [&](const RowIn<CH, HAS2>& v, long r) {
+        const bool dropped = tfirst > 0 && (int)(((unsigned)r / (unsigned)F) % (unsigned)Tst) < tfirst;
+        const Chunk<CH> xr = unpack(v.yr), xi = unpack(v.yi);
+        Chunk<CH> gr = unpack(v.gr), gi = unpack(v.gi);
+        if (HAS2) {
+            const Chunk<CH> hr = unpack(v.hr), hi = unpack(v.hi);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { gr.v[j] = 0.f; gi.v[j] = 0.f; }
-        } else {
-            gr = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + q * 8));
-            gi = unpack8(*reinterpret_cast<const uint4*>(dz + r * C + Cr + q * 8));
-            if (dz2) {
-                const Chunk8 hr = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + q * 8));
-                const Chunk8 hi = unpack8(*reinterpret_cast<const uint4*>(dz2 + r * C + Cr + q * 8));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
-            }
+            for (int j = 0; j < CH; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
         }
-        float orr[8], oii[8];
+        float orr[CH], oii[CH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
             const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
             const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
-            float dr = gr.v[j], di = gi.v[j];
+            float dr = dropped ? 0.f : gr.v[j], di = dropped ? 0.f : gi.v[j];
             if (!(vr > 0.f)) dr *= a;
             if (!(vi > 0.f)) di *= a;
             orr[j] = A[j].x * dr + A[j].y * di + E[j].x * cr + E[j].y * ci + E[j].w;
             oii[j] = A[j].z * dr + A[j].w * di + E[j].y * cr + E[j].z * ci + ki[j];
         }
-        *reinterpret_cast<uint4*>(dy + r * C + q * 8) = pack8(orr);
-        *reinterpret_cast<uint4*>(dy + r * C + Cr + q * 8) = pack8(oii);
+        pack_store(dy + r * C + q * CH, orr);
+        pack_store(dy + r * C + Cr + q * CH, oii);
+    };
+    const long stride = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + rl;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+        RowIn<CH, HAS2> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load_row<CH, HAS2>(y, dz, dz2, (r + u * stride) * C + q * CH, Cr);
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(v[u], r + u * stride);
     }
+    if (U > 1)
+        for (; r < rows; r += stride) row(load_row<CH, HAS2>(y, dz, dz2, r * C + q * CH, Cr), r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,20 +478,41 @@ static int grid_for(long work_items) {
     return (int)g;
 }
 
+static int env_int(const char* key, int dflt) {
+    const char* v = getenv(key);
+    return v ? atoi(v) : dflt;
+}
+
+// streaming passes: rows-per-thread target -> grid (the coefficient preamble is paid per workgroup)
+// experiment knobs (defaults = the measured best, tools/bench_cbn.py): channels per thread, rows per trip, rows per thread of
+// the streaming passes.  Sum over the six C1 layer shapes (us), 8 channels x 1 row (the first version) -> 4 channels x 2 rows:
+// stats 110 -> 77, apply 108 -> 108, bwd_reduce 203 -> 123, bwd_apply 174 -> 160 (4.4 TB/s read+write).
+static int cbn_ch(int Cr) {
+    static const int ch = env_int("SEHIP_CBN_CH", 4);
+    return (ch == 8 && Cr >= 8) ? 8 : 4;
+}
+static int unroll_rows() {
+    static const int u = env_int("SEHIP_CBN_U", 2);
+    return u == 1 || u == 4 ? u : 2;
+}
+// streaming passes: rows-per-thread target -> grid (the coefficient preamble is paid per workgroup)
 static int apply_blocks(long rows, int Cr) {
-    const int rpb = 256 / (Cr >> 3);
-    long g = (rows + (long)rpb * 4 - 1) / ((long)rpb * 4);
-    if (g > 2048) g = 2048;
+    static const int rpt = env_int("SEHIP_CBN_APPLY_ROWS", 8);
+    static const int cap = env_int("SEHIP_CBN_APPLY_BLOCKS", 2048);
+    const int rpb = 256 / (Cr / cbn_ch(Cr));
+    long g = (rows + (long)rpb * rpt - 1) / ((long)rpb * rpt);
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
 
 static int stat_blocks(long rows, int Cr) {
-    const int rpb = 256 / (Cr >> 3);
+    const int rpb = 256 / (Cr / cbn_ch(Cr));
     long g = (rows + (long)rpb * 8 - 1) / ((long)rpb * 8);
-    // one block per CU: the finalize kernels (on the dependent chain) read half the partials of the 512-block version;
-    // measured 6.24 vs 6.27 ms per step (128 blocks: 6.40)
-    static const int cap = getenv("SEHIP_CBN_BLOCKS") ? atoi(getenv("SEHIP_CBN_BLOCKS")) : 256;
+    // two workgroups per CU: with 4 channels per thread the reductions run 3-5 waves per SIMD, and the second workgroup's
+    // loads cover the first one's arithmetic (tools/bench_cbn.py, sum over the six C1 shapes: bwd_reduce 158 us at 256
+    // blocks, 139 at 384, 123 at 512); the finalize kernels read twice the partials for it (+1 us each)
+    static const int cap = env_int("SEHIP_CBN_BLOCKS", 512);
     if (g > cap) g = cap;
     if (g > CBN_MAX_BLOCKS) g = CBN_MAX_BLOCKS;
     if (g < 1) g = 1;
@@ -424,7 +524,10 @@ extern "C" long sehip_cbn_scratch_floats(long rows, int Cr) { return (long)stat_
 
 extern "C" int sehip_cbn_stats(const void* y, long rows, int Cr, float* part, void* stream) {
     if (int e = check_cbn("cbn_stats", rows, Cr)) return e;
-    cbn_stats_kernel<<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, rows, Cr, part);
+    if (cbn_ch(Cr) == 8)
+        cbn_stats_kernel<8><<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, rows, Cr, part);
+    else
+        cbn_stats_kernel<4><<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, rows, Cr, part);
     SEHIP_CHECK_LAUNCH("cbn_stats");
     return 0;
 }
@@ -442,8 +545,16 @@ extern "C" int sehip_cbn_finalize(const float* part, const float* Wrr, const flo
 
 extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream) {
     if (int e = check_cbn("cbn_apply", rows, Cr)) return e;
-    cbn_apply_kernel<<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, coef, slope, rows, Cr,
-                                                                              (bf16_raw*)z);
+#define CBN_APPLY(U, CH) cbn_apply_kernel<U, CH><<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, coef, slope, rows, Cr, (bf16_raw*)z)
+    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+        case 1 * 16 + 8: CBN_APPLY(1, 8); break;
+        case 2 * 16 + 8: CBN_APPLY(2, 8); break;
+        case 4 * 16 + 8: CBN_APPLY(4, 8); break;
+        case 1 * 16 + 4: CBN_APPLY(1, 4); break;
+        case 4 * 16 + 4: CBN_APPLY(4, 4); break;
+        default: CBN_APPLY(2, 4); break;
+    }
+#undef CBN_APPLY
     SEHIP_CHECK_LAUNCH("cbn_apply");
     return 0;
 }
@@ -451,8 +562,20 @@ extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* sl
 extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
                                     long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream) {
     if (int e = check_cbn("cbn_bwd_reduce", rows, Cr)) return e;
-    cbn_bwd_reduce_kernel<<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(
-        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part);
+    SEHIP_REQUIRE(rows < (1L << 31), "cbn_bwd_reduce: %ld rows exceed the 32-bit frame arithmetic", rows);
+#define CBN_RED(U, CH, H2) cbn_bwd_reduce_kernel<U, CH, H2><<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>( \
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part)
+#define CBN_RED2(U, CH) do { if (dz2) CBN_RED(U, CH, true); else CBN_RED(U, CH, false); } while (0)
+    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+        case 1 * 16 + 8: CBN_RED2(1, 8); break;
+        case 2 * 16 + 8: CBN_RED2(2, 8); break;
+        case 4 * 16 + 8: CBN_RED2(4, 8); break;
+        case 1 * 16 + 4: CBN_RED2(1, 4); break;
+        case 4 * 16 + 4: CBN_RED2(4, 4); break;
+        default: CBN_RED2(2, 4); break;
+    }
+#undef CBN_RED2
+#undef CBN_RED
     SEHIP_CHECK_LAUNCH("cbn_bwd_reduce");
     return 0;
 }
@@ -470,9 +593,20 @@ extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, cons
 extern "C" int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
                                    const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream) {
     if (int e = check_cbn("cbn_bwd_apply", rows, Cr)) return e;
-    cbn_bwd_apply_kernel<<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(
-        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, bcoef, slope, rows, Cr, F, Tst, tfirst,
-        (bf16_raw*)dy);
+    SEHIP_REQUIRE(rows < (1L << 31), "cbn_bwd_apply: %ld rows exceed the 32-bit frame arithmetic", rows);
+#define CBN_BAPP(U, CH, H2) cbn_bwd_apply_kernel<U, CH, H2><<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>( \
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, bcoef, slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy)
+#define CBN_BAPP2(U, CH) do { if (dz2) CBN_BAPP(U, CH, true); else CBN_BAPP(U, CH, false); } while (0)
+    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+        case 1 * 16 + 8: CBN_BAPP2(1, 8); break;
+        case 2 * 16 + 8: CBN_BAPP2(2, 8); break;
+        case 4 * 16 + 8: CBN_BAPP2(4, 8); break;
+        case 1 * 16 + 4: CBN_BAPP2(1, 4); break;
+        case 4 * 16 + 4: CBN_BAPP2(4, 4); break;
+        default: CBN_BAPP2(2, 4); break;
+    }
+#undef CBN_BAPP2
+#undef CBN_BAPP
     SEHIP_CHECK_LAUNCH("cbn_bwd_apply");
     return 0;
 }
