@@ -112,17 +112,22 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_
     }
     int p_at[C2_MAXP], p_fr[C2_MAXP], p_r0[C2_MAXP], p_r1[C2_MAXP];
     {
-        const int fr4 = FR * 4;
+        // idx = tid + NTHR*u -> (frame p, row r, channel piece c4): ONE division (u = 0), then steps of NTHR with a carry
+        // (a generic 32-bit division is ~17 vector instructions; seven of them were a fifth of the workgroup's prologue)
+        const unsigned fr4 = (unsigned)FR * 4u;
+        const unsigned dp = (unsigned)NTHR / fr4, dr = (unsigned)NTHR - dp * fr4;
+        unsigned p = (unsigned)tid / fr4, rem = (unsigned)tid - p * fr4;
 #pragma unroll
         for (int u = 0; u < C2_MAXP; ++u) {
             const int idx = tid + NTHR * u;
-            const int p = idx / fr4, rem = idx - p * fr4;
-            const int r = rem >> 2, c4 = rem & 3, f = f0 + r;
+            const int r = (int)(rem >> 2), c4 = (int)(rem & 3), f = f0 + r;
             const bool have = idx < NP;
-            p_at[u] = have ? (p * FS + r) * PP + c4 * 8 : dump;
-            p_fr[u] = have ? p : 0;
+            p_at[u] = have ? ((int)p * FS + r) * PP + c4 * 8 : dump;
+            p_fr[u] = have ? (int)p : 0;
             p_r0[u] = (have && (unsigned)f < (unsigned)d.src[0].F) ? f * C0 + c4 * 8 : -1;
             p_r1[u] = (have && C1 && (unsigned)f < (unsigned)d.src[1].F) ? f * C1 + c4 * 8 : -1;
+            rem += dr; p += dp;
+            if (rem >= fr4) { rem -= fr4; ++p; }
         }
     }
     __syncthreads();
@@ -176,10 +181,11 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_
         wrd[ks] = (r * 8 + ((ks * 4 + (lane >> 4)) ^ (r & 7))) * 16;
     }
     int abase[TM];
+    const int lgJ = 31 - __clz(JB);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int r = wm * 64 + mi * 16 + (lane & 15);
-        const int tl = r / JB, jl = r - tl * JB;
+        const int tl = r >> lgJ, jl = r & (JB - 1);                            // JB is a power of two (it divides 128)
         abase[mi] = (tl * FS + jl * d.fmul) * PP + 8 * (lane >> 4);
     }
 
@@ -281,18 +287,23 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_
         }
         const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
         bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
+        const bf16_raw* rptr = (d.res && first.dst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + first.coff : nullptr;
+        // destination offsets in 32 bits (the dispatcher checked the sizes) from per-workgroup constants; the tile's first
+        // virtual frame is split into (utterance, frame) once, the rows step from there with a wrap
+        const int b0 = g0 / TV, t0 = g0 - b0 * TV;
+        const int tsz = dd.F * dd.C * (dd.tmul > 1 ? dd.tmul : 1), bsz = dd.T * dd.F * dd.C, jsz = dd.fmul * dd.C;
+        const int base0 = (dd.toff * dd.F + dd.fadd) * dd.C + (lane & 7) * 8;
 #pragma unroll
         for (int itr = 0; itr < WROWS / 8; ++itr) {
-            const int row = itr * 8 + (lane >> 3), c8 = lane & 7;
+            const int row = itr * 8 + (lane >> 3);
             const int rr = wm * WROWS + row;
-            const int tl = rr / JB, jl = rr - tl * JB;
-            const int gv = g0 + tl;
-            const int b = gv / TV, t = gv - b * TV;
-            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + c8 * 8]);
+            const int tl = rr >> lgJ, jl = rr & (JB - 1);
+            int b = b0, t = t0 + tl;
+            for (; t >= TV; t -= TV) ++b;                     // at most once unless the utterances are shorter than a tile
+            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + (lane & 7) * 8]);
             if (b < B && t < d.TT) {
-                const size_t off = c2_dst_off(dd, b, t, jl) + c8 * 8;
-                if (d.res && first.dst == 0)
-                    v = c2_add_bf16x8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(d.res) + first.coff + off));
+                const int off = b * bsz + t * tsz + jl * jsz + base0;
+                if (rptr) v = c2_add_bf16x8(v, *reinterpret_cast<const uint4*>(rptr + off));
                 *reinterpret_cast<uint4*>(dptr + off) = v;
             }
         }
@@ -412,6 +423,8 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
         if ((long)d.M / d.J / d.TT * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 31)) return 0;   // 32-bit piece offsets
     }
     const int B = d.M / (d.TT * d.J);
+    for (int s = 0; s < 2; ++s)                          // 32-bit destination offsets in the epilogue
+        if (d.dst[s].ptr && (long)B * d.dst[s].T * d.dst[s].F * d.dst[s].C >= (1L << 31)) return 0;
     const long vframes = (long)B * (d.TT + 2);
     int BM = bm_force == 256 ? 256 : 128;
     const int JB = d.J;
