@@ -158,6 +158,13 @@ int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
 int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream);
 /* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */
 int sehip_wgrad(const sehip_gemm_desc* desc, void* stream);
+/* n (<= 16) plain weight-gradient products (no convolution description, Npad a multiple of 128: the LSTM input / recurrent
+ * products of src/model/dccrn.py:264-302) in ONE launch.  prepare copies the descriptors and their block table into dev_buf
+ * (sehip_wgrad_group_bytes(n) bytes of device memory; synchronous, once per binding) and returns the grid size; the launch
+ * itself only reads dev_buf.  Same arithmetic and the same fp32 atomics into dW as n sehip_wgrad calls. */
+long sehip_wgrad_group_bytes(int n);
+int sehip_wgrad_group_prepare(const sehip_gemm_desc* descs, int n, void* dev_buf, int* total_blocks);
+int sehip_wgrad_group(const void* dev_buf, int n, int total_blocks, void* stream);
 
 /* ---- table-driven packing between the reference's parameter tensors (one flat fp32 buffer in state_dict order,
  *      src/model/dccrn.py:62-137) and the GEMM-side layouts; entries are (index << 1) | negate, -1 = absent.

@@ -51,6 +51,9 @@ _PROTOS = {
     "sehip_gemm": [P, P],
     "sehip_gemm_pair": [P, P, P],
     "sehip_wgrad": [P, P],
+    "sehip_wgrad_group_bytes": [I],
+    "sehip_wgrad_group_prepare": [P, I, P, P],
+    "sehip_wgrad_group": [P, I, I, P],
     "sehip_gemm_desc_size": [],
     "sehip_pack_bf16": [P, P, L, P, P],
     "sehip_pack_f32": [P, P, L, P, P],
@@ -84,7 +87,7 @@ _PROTOS = {
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
+_RESTYPE = {"sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
 
 
 def lib():

@@ -931,7 +931,7 @@ static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, h
 // 2/3 of that kernel's traffic).
 // ------------------------------------------------------------------------------------------------
 template <int BNW, int WNN, int WNK, int KQ>
-__global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int m_per_block) {
+__device__ __forceinline__ void wgrad_body(const sehip_gemm_desc& d, const int bx, const int by, const int bz, const int m_per_block) {
     constexpr int TN = BNW / WNN / 16, TK = 64 / WNK / 16;
     constexpr int PG = BNW + 8;  // pitch in bf16 elements (16 B pad)
     constexpr int PX = 64 * KQ + 8;
@@ -946,8 +946,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WNK, wk = wave % WNK;
-    const int n0 = blockIdx.x * BNW, k0 = blockIdx.y * (64 * KQ);
-    const int m_begin = blockIdx.z * m_per_block;
+    const int n0 = bx * BNW, k0 = by * (64 * KQ);
+    const int m_begin = bz * m_per_block;
     const int m_end = min(d.M, m_begin + m_per_block);
     if (tid < 2) sdst[tid] = d.dst[tid];
     __syncthreads();
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
 #pragma unroll
             for (int b = 0; b < TK; ++b) acc[kq][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // bias gradient = column sums of dOut: one extra MFMA against an all-ones operand in the waves that own k-subtile 0
-    const bool do_bias = d.dbias != nullptr && blockIdx.y == 0 && wk == 0;
+    const bool do_bias = d.dbias != nullptr && by == 0 && wk == 0;
     f32x4 accb[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) accb[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1081,6 +1081,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int
             for (int q = 0; q < 4; ++q)
                 atomicAdd(&d.dbias[n0 + wn * (BNW / WNN) + ni * 16 + 4 * (lane >> 4) + q], accb[ni][q]);
     }
+}
+
+template <int BNW, int WNN, int WNK, int KQ>
+__global__ __launch_bounds__(256) void wgrad_kernel(const sehip_gemm_desc d, int m_per_block) {
+    wgrad_body<BNW, WNN, WNK, KQ>(d, blockIdx.x, blockIdx.y, blockIdx.z, m_per_block);
+}
+
+// Several weight-gradient products in ONE launch (sehip_wgrad_group): the LSTM input / recurrent products are 82-1300
+// workgroups of 256 rows each and take ~30 us apiece back to back on the side stream, almost all of it launch ramp and
+// the dependent slab chain; side by side they take about as long as the largest one.  The descriptors live in device
+// memory (copied once, sehip_wgrad_group_prepare); gtab[g] = {first block, n tiles, k tiles, rows per block}.
+struct WgradGroupEntry { int first, ntiles, ktiles, mpb; };
+#define SEHIP_WGRAD_GROUP_MAX 16
+template <int BNW, int WNN, int WNK>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const sehip_gemm_desc* __restrict__ descs,
+                                                          const WgradGroupEntry* __restrict__ gtab, int ngroups) {
+    int g = 0;
+    for (int i = 1; i < ngroups; ++i)
+        if ((int)blockIdx.x >= gtab[i].first) g = i;
+    const WgradGroupEntry e = gtab[g];
+    const int local = blockIdx.x - e.first;
+    const int bx = local % e.ntiles, rest = local / e.ntiles;
+    const int by = rest % e.ktiles, bz = rest / e.ktiles;
+    wgrad_body<BNW, WNN, WNK, 1>(descs[g], bx, by, bz, e.mpb);   // g is workgroup-uniform: the fields arrive by scalar loads
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2036,6 +2060,51 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
         else wgrad_kernel<128, 2, 2, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
     }
     SEHIP_CHECK_LAUNCH("wgrad");
+    return 0;
+}
+
+// ---- grouped weight gradients -----------------------------------------------------------------------------
+// Device image: [SEHIP_WGRAD_GROUP_MAX] WgradGroupEntry, then the descriptors.
+static size_t wgrad_group_desc_off() { return SEHIP_WGRAD_GROUP_MAX * sizeof(WgradGroupEntry); }
+extern "C" long sehip_wgrad_group_bytes(int n) { return (long)(wgrad_group_desc_off() + (size_t)n * sizeof(sehip_gemm_desc)); }
+
+// Copies the n descriptors and their block table into dev_buf (synchronous: call at bind time, not per step).
+// Only products that sehip_wgrad would give to wgrad_kernel<128, 2, 2, 1> can be grouped (Npad a multiple of 128, no
+// convolution description): anything else is an error, the caller then launches them one by one.
+extern "C" int sehip_wgrad_group_prepare(const sehip_gemm_desc* descs, int n, void* dev_buf, int* total_blocks) {
+    SEHIP_REQUIRE(descs && dev_buf && total_blocks, "wgrad_group_prepare: null argument");
+    SEHIP_REQUIRE(n >= 1 && n <= SEHIP_WGRAD_GROUP_MAX, "wgrad_group_prepare: %d products (1..%d)", n, SEHIP_WGRAD_GROUP_MAX);
+    WgradGroupEntry tab[SEHIP_WGRAD_GROUP_MAX] = {};
+    int first = 0;
+    for (int g = 0; g < n; ++g) {
+        const sehip_gemm_desc* d = descs + g;
+        if (int e = check_desc("wgrad_group", d)) return e;
+        SEHIP_REQUIRE(d->dW != nullptr, "wgrad_group: product %d has no dW", g);
+        SEHIP_REQUIRE(d->cv_nf <= 0 && (d->Npad & 127) == 0, "wgrad_group: product %d is not a plain 128-column-tile product", g);
+        const int ntiles = d->Npad / 128, ktiles = cdiv(d->K, 64);
+        long want = 2048 / ((long)ntiles * ktiles);
+        if (want < 1) want = 1;
+        long mpb = ((d->M + want - 1) / want + 63) / 64 * 64;
+        if (mpb < 256) mpb = 256;
+        const int splits = cdiv(d->M, mpb);
+        tab[g] = {first, ntiles, ktiles, (int)mpb};
+        first += ntiles * ktiles * splits;
+    }
+    *total_blocks = first;
+    hipError_t e = hipMemcpy(dev_buf, tab, sizeof(tab), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy((char*)dev_buf + wgrad_group_desc_off(), descs, (size_t)n * sizeof(sehip_gemm_desc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return sehip_set_error(-2, "wgrad_group_prepare: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int sehip_wgrad_group(const void* dev_buf, int n, int total_blocks, void* stream) {
+    SEHIP_REQUIRE(dev_buf && n >= 1 && n <= SEHIP_WGRAD_GROUP_MAX && total_blocks > 0, "wgrad_group: bad arguments");
+    sehip_note_kernel("wgrad_group_kernel<128, 2, 2>");
+    wgrad_group_kernel<128, 2, 2><<<total_blocks, 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const sehip_gemm_desc*>((const char*)dev_buf + wgrad_group_desc_off()),
+        reinterpret_cast<const WgradGroupEntry*>(dev_buf), n);
+    SEHIP_CHECK_LAUNCH("wgrad_group");
     return 0;
 }
 

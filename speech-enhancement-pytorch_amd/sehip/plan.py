@@ -734,6 +734,7 @@ class DCCRNWorkspace:
         st, tb, B, T = self.st, self.tb, self.B, self.T
         self.desc = {}
         self._chunk_cache = {}
+        self._wg_groups = {}
         # chunk table bound to this workspace's source geometry: [src, (toff<<16)|(fadd&0xffff), element delta, npieces]
         kt = st.ktab.copy()
         for name, s in st.specs.items():
@@ -859,6 +860,33 @@ class DCCRNWorkspace:
             self._chain_dirty = False
         call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), self.side.cuda_stream)
 
+    def wgrad_group(self, names):
+        """The weight gradients of several plain products as ONE launch on the side stream (sehip_wgrad_group): the LSTM
+        products are small grids that took ~30 us each back to back."""
+        import os
+        if os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+            for nm in names:
+                self.wgrad(nm)
+            return
+        key = tuple(names)
+        g = self._wg_groups.get(key)
+        if g is None:
+            n = len(names)
+            arr = (CGemmDesc * n)(*[CGemmDesc.from_buffer_copy(self.desc[nm + ".wg"]) for nm in names])
+            buf = torch.empty(int(_lib.lib().sehip_wgrad_group_bytes(n)), dtype=torch.uint8, device=self.bufs["enc_in"].t.device)
+            total = C.c_int(0)
+            call("sehip_wgrad_group_prepare", C.cast(arr, C.c_void_p), n, ptr(buf), C.cast(C.pointer(total), C.c_void_p))
+            g = self._wg_groups[key] = (buf, n, total.value)
+        buf, n, total = g
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            call("sehip_wgrad_group", ptr(buf), n, total, main.cuda_stream)
+            return
+        if self._chain_dirty:
+            call("sehip_stream_depend", self.side.cuda_stream, main.cuda_stream, self._event())
+            self._chain_dirty = False
+        call("sehip_wgrad_group", ptr(buf), n, total, self.side.cuda_stream)
+
     # ---- BatchNorm helpers ---------------------------------------------------------------------
     def _bn_ptrs(self, pre, params, buffers, nbt):
         L = self.st.layout
@@ -930,10 +958,7 @@ class DCCRNWorkspace:
         if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():
             for layer in (2, 1):
                 self._lstm_bwd_call(layer, 0, T, main)
-                for tag in "ri":
-                    self.wgrad(f"ih{layer}_{tag}")
-                for combo in range(4):
-                    self.wgrad(f"hh{layer}_{combo}")
+                self.wgrad_group([f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)])
                 self.gemm_pair(f"dx{layer}_r", f"dx{layer}_i")
             return
         s2, s3 = self.lstm_stream.cuda_stream, self.lstm_gemm_stream.cuda_stream
@@ -946,11 +971,7 @@ class DCCRNWorkspace:
             self._lstm_bwd_call(1, t0, t1, s2)
         call("sehip_stream_depend", main, s2, self._event())
         self._chain_dirty = True
-        for layer in (2, 1):
-            for tag in "ri":
-                self.wgrad(f"ih{layer}_{tag}")
-            for combo in range(4):
-                self.wgrad(f"hh{layer}_{combo}")
+        self.wgrad_group([nm for layer in (2, 1) for nm in [f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)]])
         self.gemm_pair("dx1_r", "dx1_i")
 
     # ---- forward / backward --------------------------------------------------------------------
