@@ -201,6 +201,21 @@ def parity_block(hip, cpu_path, batch):
             "pass": bool(max(dl) < TOL_DLOSS_DB and w0["rel"] < TOL_WAVE_REL and wk["rel"] < 2 * TOL_WAVE_REL)}
 
 
+def build_for_profile(batch=BATCH):
+    """Model, solver and one staged batch of the headline workload (tools/host_profile.py)."""
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    n = int(SR * CLIP_S)
+    cfg = bench_config(n)
+    torch.manual_seed(cfg.seed)
+    model = distrib.get_model(cfg.model)
+    opt = distrib.get_optimizer(cfg.optim, model)
+    solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+    noisy, clean = make_batch(batch, n, 0, solver.device)
+    mixture, sources = solver._prepare_batch(noisy, clean)
+    return solver, model, mixture, sources
+
+
 def note(msg):
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -304,8 +319,10 @@ def main():
     for _ in range(args.steps):
         stage()
         loss, metric = step_fn(mixture, sources)
+    t_enq = time.time() - t0            # host time to enqueue the steps; close to dt = the launches, not the GPU, set the pace
     sync()
     dt = time.time() - t0
+    note(f"host enqueue {t_enq / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f}")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

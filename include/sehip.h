@@ -239,20 +239,26 @@ int sehip_dcunet_mask_bwd(const float* dout, const float* spec, const float* mas
  *      decoder_bwd : dmlin [M][K][Cs*N] bf16, dw_dec [M][K][N] fp32, gacc += dV [ac*L][N] */
 int sehip_ctn_encoder_fwd(const float* wav, const float* U, const float* gamma, const float* beta, int M, int ac, int T, int N, int L,
                           float* w, void* cln_bf16, void* stream);
+/* scratch (encoder and decoder backward): sehip_ctn_codec_bwd_scratch_floats(M, K, N, L, ac) floats -- one row of partial
+ * weight-gradient sums per workgroup, added into gacc by a column-sum launch */
+long sehip_ctn_codec_bwd_scratch_floats(int M, int K, int N, int L, int ac);
 int sehip_ctn_encoder_bwd(const float* wav, const float* w, const void* dcln_bf16, const float* dw_dec, const float* gamma, int M, int ac,
-                          int T, int N, int L, float* gacc, void* stream);
+                          int T, int N, int L, float* gacc, float* scratch, void* stream);
 int sehip_ctn_gln_stats(const void* h, const float* slope, int M, int K, int C, double* stats, void* stream);
 int sehip_ctn_dwconv_fwd(const void* h1, const float* slope1, const double* stats1, const float* gamma, const float* beta, const float* Wd,
                          int P, int dilation, const float* slope2, int M, int K, int C, void* h2, double* stats2, void* stream);
 int sehip_ctn_gln_apply(const void* h, const float* slope, const double* stats, const float* gamma, const float* beta, int M, int K, int C,
                         void* u, void* stream);
+/* scratch: sehip_ctn_gln_bwd_scratch_floats(M, K, C) floats (one row of per-channel partial sums per workgroup; a column-sum
+ * launch adds them into gch instead of 1 600 workgroups x 1 280 fp32 atomics on the same addresses) */
+long sehip_ctn_gln_bwd_scratch_floats(int M, int K, int C);
 int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
                       const float* Wd, int P, int dilation, int dw, int M, int K, int C, double* sums, float* gch, void* dh, float* dslope,
-                      void* stream);
+                      float* scratch, void* stream);
 int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac, int Cs, int T,
                           float* out, void* stream);
 int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac,
-                          int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, void* stream);
+                          int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, float* scratch, void* stream);
 
 /* ---- recurrent part of NavieComplexLSTM: src/model/dccrn.py:264-302 (four nn.LSTM passes of one complex layer in one
  *      persistent launch; hidden size 64).  pre*: [B][T][2 lstm * 256] gates from the input GEMMs (fp32);

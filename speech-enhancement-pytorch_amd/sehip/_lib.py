@@ -75,19 +75,21 @@ _PROTOS = {
     "sehip_dcunet_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     "sehip_dcunet_mask_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     "sehip_ctn_encoder_fwd": [P, P, P, P, I, I, I, I, I, P, P, P],
-    "sehip_ctn_encoder_bwd": [P, P, P, P, P, I, I, I, I, I, P, P],
+    "sehip_ctn_encoder_bwd": [P, P, P, P, P, I, I, I, I, I, P, P, P],
+    "sehip_ctn_codec_bwd_scratch_floats": [I, I, I, I, I],
     "sehip_ctn_gln_stats": [P, P, I, I, I, P, P],
     "sehip_ctn_dwconv_fwd": [P, P, P, P, P, P, I, I, P, I, I, I, P, P, P],
     "sehip_ctn_gln_apply": [P, P, P, P, P, I, I, I, P, P],
-    "sehip_ctn_gln_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P],
+    "sehip_ctn_gln_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P],
+    "sehip_ctn_gln_bwd_scratch_floats": [I, I, I],
     "sehip_ctn_decoder_fwd": [P, P, P, I, I, I, I, I, I, I, P, P],
-    "sehip_ctn_decoder_bwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
+    "sehip_ctn_decoder_bwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
+_RESTYPE = {"sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
 
 
 def lib():
@@ -132,8 +134,31 @@ def ptr(t):
     return t.data_ptr()
 
 
+_stream_handle = None
+
+
 def stream():
+    """hipStream_t of torch's current stream (cached inside a stream_scope)."""
+    if _stream_handle is not None:
+        return _stream_handle
     return torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope:
+    """Looks torch's current stream up ONCE for all library calls made inside the scope: the lookup costs ~8 us of host time
+    and a training step makes ~110 of them (a quarter of the step's launch time).  Code inside must not switch torch's
+    current stream and then expect stream() to follow (the side streams of sehip/plan.py are passed as explicit handles)."""
+
+    def __enter__(self):
+        global _stream_handle
+        self._prev = _stream_handle
+        _stream_handle = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _stream_handle
+        _stream_handle = self._prev
+        return False
 
 
 def require_gpu(t, what):

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                                               const bf16_raw* __restrict__ dcln, const float* __restrict__ dw_dec,
                                                               const float* __restrict__ gamma, int M, int ac, int T, int K, int N, int L,
-                                                              int frames_per_wave, float* __restrict__ gacc) {
+                                                              int frames_per_wave, float* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int step = L / 2, AL = ac * L;
     const long frames = (long)M * K;
@@ -161,16 +161,23 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
             }
         }
     }
-    for (int i = lane; i < AL * N; i += 64) {
-        const int l = i / N, n = i - l * N;
-        const float v = mine[i];
-        if (v != 0.f) atomicAdd(&gacc[n * AL + l], v);
-    }
+    // One row of partial sums per workgroup in gacc layout (dU [N][AL] | dgamma [N] | dbeta [N]); ctn_colsum_kernel adds the
+    // rows.  (Flushing every wave with atomics was 2 048 waves x 5 120 addresses: 1.2 ms of a 1.24-ms kernel.)
+    float* sgb = sdU + (size_t)4 * AL * N;             // [2][N] behind the four waves' dU images
+    for (int i = threadIdx.x; i < 2 * N; i += 256) sgb[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < ENC_MAXC; ++i) {
         const int n = lane + 64 * i;
-        if (n < N) { atomicAdd(&gacc[N * AL + n], dg[i]); atomicAdd(&gacc[N * AL + N + n], db[i]); }
+        if (n < N) { atomicAdd(&sgb[n], dg[i]); atomicAdd(&sgb[N + n], db[i]); }
     }
+    __syncthreads();
+    float* row = part + (size_t)blockIdx.x * (AL * N + 2 * N);
+    for (int i = threadIdx.x; i < AL * N; i += 256) {
+        const int l = i / N, n = i - l * N;
+        row[n * AL + l] = sdU[i] + sdU[AL * N + i] + sdU[2 * AL * N + i] + sdU[3 * AL * N + i];
+    }
+    for (int i = threadIdx.x; i < 2 * N; i += 256) row[AL * N + i] = sgb[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -202,6 +209,25 @@ __global__ __launch_bounds__(256) void ctn_gln_stats_kernel(const bf16_raw* __re
     block_add2_double(s, q, stats + 2 * m);
 }
 
+// Thread layout of the frame-streaming kernels below: a thread owns ONE piece of 8 channels (q = tid % nq) for all its
+// frames, so gamma / beta / the depthwise taps of those channels are loaded once and stay in registers (fetched per piece
+// they were 40 four-byte loads beside 3-8 sixteen-byte ones, and the kernels ran at the address unit's pace: 90-260 us for
+// 26-MB tensors); rows t = bx*rpb + tid/nq, stepping by gridDim.x*rpb (rpb = 256/nq rows per block pass).
+struct PieceMap { int q, c0, rsub, rpb; bool active; };
+__device__ __forceinline__ PieceMap piece_map(int nq) {
+    PieceMap p;
+    p.rpb = 256 / nq;
+    p.q = threadIdx.x % nq;
+    p.rsub = threadIdx.x / nq;
+    p.c0 = p.q * 8;
+    p.active = p.rsub < p.rpb;
+    return p;
+}
+__device__ __forceinline__ void ld8f(const float* __restrict__ p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 // h2[t][c] = sum_j Wd[c][j] n1[t + (j - P/2) d][c],  n1 = gLN1(PReLU(h1)) (zero outside [0, K)); stats2 += PReLU(h2; a2)
 template <int P>
 __global__ __launch_bounds__(256) void ctn_dwconv_fwd_kernel(const bf16_raw* __restrict__ h1, const float* __restrict__ slope1,
@@ -210,32 +236,45 @@ __global__ __launch_bounds__(256) void ctn_dwconv_fwd_kernel(const bf16_raw* __r
                                                              int dil, const float* __restrict__ slope2, int K, int C,
                                                              bf16_raw* __restrict__ h2, double* __restrict__ stats2) {
     const int m = blockIdx.y, nq = C >> 3;
+    const PieceMap pm = piece_map(nq);
     const float a1 = slope1[0], a2 = slope2[0];
     float mu, rs;
     gln_moments(stats1, m, (long)K * C, mu, rs);
-    const long pieces = (long)K * nq;
-    const bf16_raw* base = h1 + (long)m * K * C;
-    bf16_raw* out = h2 + (long)m * K * C;
+    const bf16_raw* base = h1 + (long)m * K * C + pm.c0;
+    bf16_raw* out = h2 + (long)m * K * C + pm.c0;
     float s = 0.f, q = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
-        const int t = (int)(i / nq), c0 = (int)(i - (long)t * nq) * 8;
-        float o[8];
+    if (pm.active) {
+        // n1 = gs * prelu(x) + bs  with  gs = gamma rs,  bs = beta - gamma mu rs
+        float gs[8], bs[8], wd[P][8];
+        ld8f(gamma + pm.c0, gs); ld8f(beta + pm.c0, bs);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        for (int j = 0; j < 8; ++j) {
+            gs[j] *= rs; bs[j] -= gs[j] * mu;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int tt = t + (p - P / 2) * dil;
-            if (tt < 0 || tt >= K) continue;
-            const C8 x = ld8(base + ((long)tt * nq) * 8 + c0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float n1 = gamma[c0 + j] * (prelu(x.v[j], a1) - mu) * rs + beta[c0 + j];
-                o[j] += Wd[(c0 + j) * P + p] * n1;
-            }
+            for (int p = 0; p < P; ++p) wd[p][j] = Wd[(pm.c0 + j) * P + p];
         }
-        st8(out + i * 8, o);
+        for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
+            C8 x[P];
+            bool ok[P];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float v = prelu(bf2f(f2bf(o[j])), a2); s += v; q += v * v; }   // statistics of what is stored
+            for (int p = 0; p < P; ++p) {
+                const int tt = t + (p - P / 2) * dil;
+                ok[p] = tt >= 0 && tt < K;
+                x[p] = ld8(base + (long)(ok[p] ? tt : t) * C);          // all loads in flight together (the centre row stands in)
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (ok[p]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += wd[p][j] * (gs[j] * prelu(x[p].v[j], a1) + bs[j]);
+                }
+            st8(out + (long)t * C, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float v = prelu(bf2f(f2bf(o[j])), a2); s += v; q += v * v; }   // statistics of what is stored
+        }
     }
     block_add2_double(s, q, stats2 + 2 * m);
 }
@@ -244,107 +283,124 @@ __global__ __launch_bounds__(256) void ctn_gln_apply_kernel(const bf16_raw* __re
                                                             const double* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int K, int C, bf16_raw* __restrict__ u) {
     const int m = blockIdx.y, nq = C >> 3;
+    const PieceMap pm = piece_map(nq);
+    if (!pm.active) return;
     const float a = slope[0];
     float mu, rs;
     gln_moments(stats, m, (long)K * C, mu, rs);
-    const long pieces = (long)K * nq;
-    const bf16_raw* base = h + (long)m * K * C;
-    bf16_raw* out = u + (long)m * K * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % nq) * 8;
-        const C8 x = ld8(base + i * 8);
+    const bf16_raw* base = h + (long)m * K * C + pm.c0;
+    bf16_raw* out = u + (long)m * K * C + pm.c0;
+    float gs[8], bs[8];
+    ld8f(gamma + pm.c0, gs); ld8f(beta + pm.c0, bs);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] *= rs; bs[j] -= gs[j] * mu; }
+    for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
+        const C8 x = ld8(base + (long)t * C);
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = gamma[c0 + j] * (prelu(x.v[j], a) - mu) * rs + beta[c0 + j];
-        st8(out + i * 8, o);
+        for (int j = 0; j < 8; ++j) o[j] = gs[j] * prelu(x.v[j], a) + bs[j];
+        st8(out + (long)t * C, o);
     }
 }
 
 // Backward of y = gLN(PReLU(h)).  The incoming gradient dy is either read directly (DW = false: du, the gradient of the
 // pointwise conv's input) or is the transposed depthwise conv of dh2 (DW = true: dy[t][c] = sum_p Wd[c][p] dh2[t - (p - P/2) d][c]).
 // pass 1 (reduce): per utterance S1 = sum gamma dy, S2 = sum gamma dy xh (double atomics into sums[2m..]); per channel
-//                  dgamma += dy xh, dbeta += dy [, dWd[c][p] += dh2[t][c] n[t + (p - P/2) d][c]]  (fp32 atomics into gch)
+//                  dgamma += dy xh, dbeta += dy [, dWd[c][p] += dh2[t][c] n[t + (p - P/2) d][c]]: every block writes ONE row of
+//                  per-channel partials (gch layout) to `part`, ctn_colsum_kernel adds the rows into gch.  (A first version
+//                  flushed each block with fp32 atomics: 1 600 blocks x 1 280 addresses, 261 us for a 26-MB tensor.)
 // pass 2 (apply) : dh = ((gamma dy - S1/n - xh S2/n) / sigma) (h > 0 ? 1 : a);  dslope += sum dv h [h <= 0]
-template <int P, bool DW>
-__device__ __forceinline__ C8 gln_dy(const bf16_raw* __restrict__ g, const float* __restrict__ Wd, int t, int c0, int nq, int K, int dil) {
-    if (!DW) return ld8(g + ((long)t * nq) * 8 + c0);
-    C8 o = zero8();
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int tt = t - (p - P / 2) * dil;
-        if (tt < 0 || tt >= K) continue;
-        const C8 x = ld8(g + ((long)tt * nq) * 8 + c0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.v[j] += Wd[(c0 + j) * P + p] * x.v[j];
-    }
-    return o;
-}
-
 // gch layout: dgamma [C] | dbeta [C] | dWd [C][P] (DW only)
 template <int P, bool DW>
 __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw* __restrict__ g, const bf16_raw* __restrict__ h,
                                                                  const float* __restrict__ slope, const double* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ Wd, int dil, int K, int C,
-                                                                 double* __restrict__ sums, float* __restrict__ gch) {
-    extern __shared__ float lds[];       // per-channel partials of the block: [(2 + (DW ? P : 0))][C]
+                                                                 double* __restrict__ sums, float* __restrict__ part) {
+    extern __shared__ float lds[];       // per-channel partials of the block in gch layout: [(2 + (DW ? P : 0)) * C]
     const int m = blockIdx.y, nq = C >> 3;
-    const int NV = 2 + (DW ? P : 0);
+    const PieceMap pm = piece_map(nq);
+    constexpr int NV = 2 + (DW ? P : 0);
     for (int i = threadIdx.x; i < NV * C; i += 256) lds[i] = 0.f;
     __syncthreads();
     const float a = slope[0];
     float mu, rs;
     gln_moments(stats, m, (long)K * C, mu, rs);
-    const bf16_raw* gb = g + (long)m * K * C;
-    const bf16_raw* hb = h + (long)m * K * C;
-    // a thread keeps ONE channel piece (the block's stride is a multiple of nq): per-channel sums stay in registers
-    const int stride = (256 / nq) * nq;           // active threads per block
+    const bf16_raw* gb = g + (long)m * K * C + pm.c0;
+    const bf16_raw* hb = h + (long)m * K * C + pm.c0;
     float s1 = 0.f, s2 = 0.f;
-    float dg[8], db[8], dw[DW ? P : 1][8];
+    if (pm.active) {
+        float gm[8], bt[8], wd[DW ? P : 1][8];
+        float dg[8], db[8], dw[DW ? P : 1][8];
+        ld8f(gamma + pm.c0, gm); ld8f(beta + pm.c0, bt);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; for (int p = 0; p < (DW ? P : 1); ++p) dw[p][j] = 0.f; }
-    const int c0 = (threadIdx.x % nq) * 8;
-    if ((int)threadIdx.x < stride) {
-        const long pieces = (long)K * nq;
-        for (long i = (long)blockIdx.x * stride + threadIdx.x; i < pieces; i += (long)gridDim.x * stride) {
-            const int t = (int)(i / nq);
-            const C8 dy = gln_dy<P, DW>(gb, Wd, t, c0, nq, K, dil);
-            const C8 x = ld8(hb + i * 8);
+        for (int j = 0; j < 8; ++j) {
+            dg[j] = 0.f; db[j] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (prelu(x.v[j], a) - mu) * rs;
-                const float gd = gamma[c0 + j] * dy.v[j];
-                s1 += gd; s2 += gd * xh;
-                dg[j] += dy.v[j] * xh; db[j] += dy.v[j];
-            }
-            if (DW) {
-                const C8 d2 = ld8(gb + i * 8);       // dh2[t]
+            for (int p = 0; p < (DW ? P : 1); ++p) { dw[p][j] = 0.f; wd[p][j] = DW ? Wd[(pm.c0 + j) * P + p] : 0.f; }
+        }
+        for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
+            const C8 x = ld8(hb + (long)t * C);
+            C8 dy;
+            if (!DW) {
+                dy = ld8(gb + (long)t * C);
+            } else {
+                // rows t - d, t, t + d of dh2 (dy and the centre tap's dWd) and of h (the three taps' dWd): 7 loads in flight
+                C8 gq[P], xq[P];
+                bool ok[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int tt = t + (p - P / 2) * dil;
-                    if (tt < 0 || tt >= K) continue;
-                    const C8 xn = ld8(hb + ((long)tt * nq) * 8 + c0);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        dw[p][j] += d2.v[j] * (gamma[c0 + j] * (prelu(xn.v[j], a) - mu) * rs + beta[c0 + j]);
+                    ok[p] = tt >= 0 && tt < K;
+                    gq[p] = ld8(gb + (long)(ok[p] ? tt : t) * C);
+                    xq[p] = p == P / 2 ? x : ld8(hb + (long)(ok[p] ? tt : t) * C);
                 }
+                dy = zero8();
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    // dy[t] += Wd[p'] dh2[t - (p' - P/2) d]: the row t + (p - P/2) d is tap p' = P - 1 - p
+                    if (ok[p]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dy.v[j] += wd[P - 1 - p][j] * gq[p].v[j];
+                    }
+                    // dWd[p] += dh2[t] n[t + (p - P/2) d]
+                    if (ok[p]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            dw[p][j] += gq[P / 2].v[j] * (gm[j] * ((prelu(xq[p].v[j], a) - mu) * rs) + bt[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (prelu(x.v[j], a) - mu) * rs;
+                const float gd = gm[j] * dy.v[j];
+                s1 += gd; s2 += gd * xh;
+                dg[j] += dy.v[j] * xh; db[j] += dy.v[j];
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            atomicAdd(&lds[c0 + j], dg[j]);
-            atomicAdd(&lds[C + c0 + j], db[j]);
-            if (DW)
-                for (int p = 0; p < P; ++p) atomicAdd(&lds[(2 + p) * C + c0 + j], dw[p][j]);
+            atomicAdd(&lds[pm.c0 + j], dg[j]);
+            atomicAdd(&lds[C + pm.c0 + j], db[j]);
+            if (DW) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) atomicAdd(&lds[2 * C + (pm.c0 + j) * P + p], dw[p][j]);
+            }
         }
     }
     block_add2_double(s1, s2, sums + 2 * m);      // (contains a __syncthreads: the LDS partials are complete after it)
-    for (int i = threadIdx.x; i < NV * C; i += 256) {
-        const int which = i / C, c = i - which * C;
-        const float v = lds[i];
-        if (which < 2) atomicAdd(&gch[which * C + c], v);
-        else atomicAdd(&gch[2 * C + c * P + (which - 2)], v);
-    }
+    float* row = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NV * C);
+    for (int i = threadIdx.x; i < NV * C; i += 256) row[i] = lds[i];
+}
+
+// out[c] += sum over rows of part[row][c]   (grid = (ceil(ncols / 256), row splits); out zeroed by the caller)
+__global__ __launch_bounds__(256) void ctn_colsum_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int r = blockIdx.y; r < nrows; r += gridDim.y) s += part[(size_t)r * ncols + c];
+    atomicAdd(&out[c], s);
 }
 
 template <int P, bool DW>
@@ -354,29 +410,55 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
                                                                 const double* __restrict__ sums, int K, int C, bf16_raw* __restrict__ dh,
                                                                 float* __restrict__ dslope) {
     const int m = blockIdx.y, nq = C >> 3;
+    const PieceMap pm = piece_map(nq);
     const float a = slope[0];
     float mu, rs;
     gln_moments(stats, m, (long)K * C, mu, rs);
     const double n = (double)K * C;
     const float k1 = (float)(sums[2 * m] / n), k2 = (float)(sums[2 * m + 1] / n);
-    const bf16_raw* gb = g + (long)m * K * C;
-    const bf16_raw* hb = h + (long)m * K * C;
-    bf16_raw* out = dh + (long)m * K * C;
-    const long pieces = (long)K * nq;
+    const bf16_raw* gb = g + (long)m * K * C + pm.c0;
+    const bf16_raw* hb = h + (long)m * K * C + pm.c0;
+    bf16_raw* out = dh + (long)m * K * C + pm.c0;
     float da = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
-        const int t = (int)(i / nq), c0 = (int)(i - (long)t * nq) * 8;
-        const C8 dy = gln_dy<P, DW>(gb, Wd, t, c0, nq, K, dil);
-        const C8 x = ld8(hb + i * 8);
-        float o[8];
+    if (pm.active) {
+        float gm[8], wd[DW ? P : 1][8];
+        ld8f(gamma + pm.c0, gm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (prelu(x.v[j], a) - mu) * rs;
-            const float dv = (gamma[c0 + j] * dy.v[j] - k1 - xh * k2) * rs;
-            if (x.v[j] > 0.f) o[j] = dv;
-            else { o[j] = a * dv; da += dv * x.v[j]; }
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int p = 0; p < (DW ? P : 1); ++p) wd[p][j] = DW ? Wd[(pm.c0 + j) * P + p] : 0.f;
+        for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
+            const C8 x = ld8(hb + (long)t * C);
+            C8 dy;
+            if (!DW) {
+                dy = ld8(gb + (long)t * C);
+            } else {
+                C8 gq[P];
+                bool ok[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int tt = t - (p - P / 2) * dil;
+                    ok[p] = tt >= 0 && tt < K;
+                    gq[p] = ld8(gb + (long)(ok[p] ? tt : t) * C);
+                }
+                dy = zero8();
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    if (ok[p]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dy.v[j] += wd[p][j] * gq[p].v[j];
+                    }
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (prelu(x.v[j], a) - mu) * rs;
+                const float dv = (gm[j] * dy.v[j] - k1 - xh * k2) * rs;
+                if (x.v[j] > 0.f) o[j] = dv;
+                else { o[j] = a * dv; da += dv * x.v[j]; }
+            }
+            st8(out + (long)t * C, o);
         }
-        st8(out + i * 8, o);
     }
     __shared__ float red[4];
     da = wave_sum(da);
@@ -434,7 +516,7 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __res
                                                               const bf16_raw* __restrict__ mlin, const float* __restrict__ V, int M, int K,
                                                               int N, int L, int ac, int Cs, int T, int frames_per_wave,
                                                               bf16_raw* __restrict__ dmlin, float* __restrict__ dw_dec,
-                                                              float* __restrict__ gacc) {
+                                                              float* __restrict__ part) {
     extern __shared__ float smem[];
     const int AL = ac * L;
     float* sV = smem;                                  // [AL][N]  (read with n on the lane: conflict free)
@@ -490,10 +572,9 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __res
             if (n < N) dw_dec[fr * N + n] = dwacc[i];
         }
     }
-    for (int i = lane; i < AL * N; i += 64) {
-        const float v = mydV[i];
-        if (v != 0.f) atomicAdd(&gacc[i], v);
-    }
+    __syncthreads();                                  // one row of partial dV per workgroup, added up by ctn_colsum_kernel
+    float* row = part + (size_t)blockIdx.x * (AL * N);
+    for (int i = threadIdx.x; i < AL * N; i += 256) row[i] = sdV[i] + sdV[AL * N + i] + sdV[2 * AL * N + i] + sdV[3 * AL * N + i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -526,20 +607,35 @@ extern "C" int sehip_ctn_encoder_fwd(const float* wav, const float* U, const flo
     return 0;
 }
 
+static int ctn_frames_per_wave(long frames) {
+    int fpw = (int)((frames + 4 * 512 - 1) / (4 * 512));        // ~512 workgroups
+    return fpw < 1 ? 1 : fpw;
+}
+// floats of scratch the encoder / decoder backward passes need (one row of partial weight-gradient sums per workgroup)
+extern "C" long sehip_ctn_codec_bwd_scratch_floats(int M, int K, int N, int L, int ac) {
+    const long frames = (long)M * K;
+    const int fpw = ctn_frames_per_wave(frames);
+    const long grid = (frames + 4L * fpw - 1) / (4L * fpw);
+    return grid * ((long)ac * L * N + 2L * N);
+}
+
 extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const void* dcln_bf16, const float* dw_dec, const float* gamma, int M,
-                                     int ac, int T, int N, int L, float* gacc, void* stream) {
+                                     int ac, int T, int N, int L, float* gacc, float* scratch, void* stream) {
     SEHIP_REQUIRE(M > 0 && ac > 0 && T >= L && (L & 1) == 0, "ctn_encoder_bwd: bad sizes");
     SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC && (N & 7) == 0, "ctn_encoder_bwd: bad N=%d", N);
+    SEHIP_REQUIRE(scratch != nullptr, "ctn_encoder_bwd: missing scratch buffer");
     const int K = (T - L) / (L / 2) + 1;
-    const size_t lds = (size_t)4 * N * ac * L * sizeof(float);
+    const size_t lds = ((size_t)4 * N * ac * L + 2 * N) * sizeof(float);
     SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_encoder_bwd: %zu bytes of LDS needed", lds);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const long frames = (long)M * K;
-    int fpw = (int)((frames + 4 * 512 - 1) / (4 * 512));        // ~512 workgroups
-    if (fpw < 1) fpw = 1;
+    const int fpw = ctn_frames_per_wave(frames);
     const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
-    ctn_encoder_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, gacc);
+    hipStream_t st = (hipStream_t)stream;
+    ctn_encoder_bwd_kernel<<<grid, 256, lds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch);
+    const int ncols = ac * L * N + 2 * N;
+    ctn_colsum_kernel<<<dim3((ncols + 255) / 256, grid >= 32 ? 8 : 1), 256, 0, st>>>(scratch, grid, ncols, gacc);
     SEHIP_CHECK_LAUNCH("ctn_encoder_bwd");
     return 0;
 }
@@ -571,21 +667,32 @@ extern "C" int sehip_ctn_gln_apply(const void* h, const float* slope, const doub
 }
 
 // dw != 0: g = dh2 and the incoming gradient is its transposed depthwise convolution (Wd, dilation); gch additionally
-// receives dWd.  sums [M][2] and gch / dslope are accumulated with atomics: the caller zeroes them.
+// receives dWd.  sums [M][2] and gch / dslope are accumulated with atomics: the caller zeroes them.  scratch: at least
+// sehip_ctn_gln_bwd_scratch_floats(M, K, C) floats (the blocks' per-channel partial rows).
+extern "C" long sehip_ctn_gln_bwd_scratch_floats(int M, int K, int C) {
+    const dim3 grid = ctn_grid(M, K, C);
+    return (long)grid.x * grid.y * 5L * C;
+}
+
 extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
                                  const float* Wd, int P, int dilation, int dw, int M, int K, int C, double* sums, float* gch, void* dh,
-                                 float* dslope, void* stream) {
+                                 float* dslope, float* scratch, void* stream) {
     if (int e = ctn_check("ctn_gln_bwd", M, K, C)) return e;
     SEHIP_REQUIRE(!dw || P == 3, "ctn_gln_bwd: only kernel size P=3 is built (got %d)", P);
     SEHIP_REQUIRE((C >> 3) <= 256, "ctn_gln_bwd: too many channels");
+    SEHIP_REQUIRE(scratch != nullptr, "ctn_gln_bwd: missing scratch buffer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = ctn_grid(M, K, C);
-    const size_t lds = (size_t)(2 + (dw ? 3 : 0)) * C * sizeof(float);
+    const int ncols = (2 + (dw ? 3 : 0)) * C, nrows = (int)(grid.x * grid.y);
+    const size_t lds = (size_t)ncols * sizeof(float);
+    const dim3 cgrid((ncols + 255) / 256, nrows >= 32 ? 16 : 1);
     if (dw) {
-        ctn_gln_bwd_reduce_kernel<3, true><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, gch);
+        ctn_gln_bwd_reduce_kernel<3, true><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
+        ctn_colsum_kernel<<<cgrid, 256, 0, st>>>(scratch, nrows, ncols, gch);
         ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
     } else {
-        ctn_gln_bwd_reduce_kernel<3, false><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, gch);
+        ctn_gln_bwd_reduce_kernel<3, false><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
+        ctn_colsum_kernel<<<cgrid, 256, 0, st>>>(scratch, nrows, ncols, gch);
         ctn_gln_bwd_apply_kernel<3, false><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
     }
     SEHIP_CHECK_LAUNCH("ctn_gln_bwd");
@@ -606,19 +713,22 @@ extern "C" int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, cons
 }
 
 extern "C" int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac,
-                                     int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, void* stream) {
+                                     int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, float* scratch, void* stream) {
     SEHIP_REQUIRE(M > 0 && K > 0 && Cs > 0 && ac > 0, "ctn_decoder_bwd: empty input");
     SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC, "ctn_decoder_bwd: bad N=%d", N);
+    SEHIP_REQUIRE(scratch != nullptr, "ctn_decoder_bwd: missing scratch buffer");
     const size_t lds = ((size_t)5 * ac * L * N + 4 * ac * L) * sizeof(float);
     SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_decoder_bwd: %zu bytes of LDS needed", lds);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const long frames = (long)M * K;
-    int fpw = (int)((frames + 4 * 512 - 1) / (4 * 512));
-    if (fpw < 1) fpw = 1;
+    const int fpw = ctn_frames_per_wave(frames);
     const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
-    ctn_decoder_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
-                                                                   (bf16_raw*)dmlin_bf16, dw_dec, gacc);
+    hipStream_t st = (hipStream_t)stream;
+    ctn_decoder_bwd_kernel<<<grid, 256, lds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
+                                                   (bf16_raw*)dmlin_bf16, dw_dec, scratch);
+    const int ncols = ac * L * N;
+    ctn_colsum_kernel<<<dim3((ncols + 255) / 256, grid >= 32 ? 8 : 1), 256, 0, st>>>(scratch, grid, ncols, gacc);
     SEHIP_CHECK_LAUNCH("ctn_decoder_bwd");
     return 0;
 }

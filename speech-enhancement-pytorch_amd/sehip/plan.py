@@ -787,6 +787,9 @@ class DCCRNWorkspace:
                     w.dst[0].ptr = gb.ptr
                     w.dst[0].is_f32 = 0
                 self.desc[name + ".wg"] = w
+        if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+            for layers in ((1,), (2,), (2, 1)):
+                self._wgrad_group_handle(self._lstm_wgrad_names(layers))
 
     def _chunk_desc(self, name, t0, t1):
         """Copy of a dense (J == 1) descriptor restricted to the frames [t0, t1): TT and M shrink, every source /
@@ -860,14 +863,12 @@ class DCCRNWorkspace:
             self._chain_dirty = False
         call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), self.side.cuda_stream)
 
-    def wgrad_group(self, names):
-        """The weight gradients of several plain products as ONE launch on the side stream (sehip_wgrad_group): the LSTM
-        products are small grids that took ~30 us each back to back."""
-        import os
-        if os.environ.get("SEHIP_NO_WGRAD_GROUP"):
-            for nm in names:
-                self.wgrad(nm)
-            return
+    def _lstm_wgrad_names(self, layers):
+        return [nm for layer in layers for nm in [f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)]]
+
+    def _wgrad_group_handle(self, names):
+        """Device image (descriptors + block table) of a grouped weight-gradient launch; built at bind time, because
+        sehip_wgrad_group_prepare copies synchronously and must not run inside a stream capture."""
         key = tuple(names)
         g = self._wg_groups.get(key)
         if g is None:
@@ -877,7 +878,16 @@ class DCCRNWorkspace:
             total = C.c_int(0)
             call("sehip_wgrad_group_prepare", C.cast(arr, C.c_void_p), n, ptr(buf), C.cast(C.pointer(total), C.c_void_p))
             g = self._wg_groups[key] = (buf, n, total.value)
-        buf, n, total = g
+        return g
+
+    def wgrad_group(self, names):
+        """The weight gradients of several plain products as ONE launch on the side stream (sehip_wgrad_group): the LSTM
+        products are small grids that took ~30 us each back to back."""
+        if os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+            for nm in names:
+                self.wgrad(nm)
+            return
+        buf, n, total = self._wgrad_group_handle(names)
         main = torch.cuda.current_stream()
         if self.side is None:
             call("sehip_wgrad_group", ptr(buf), n, total, main.cuda_stream)
@@ -958,7 +968,7 @@ class DCCRNWorkspace:
         if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():
             for layer in (2, 1):
                 self._lstm_bwd_call(layer, 0, T, main)
-                self.wgrad_group([f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)])
+                self.wgrad_group(self._lstm_wgrad_names((layer,)))
                 self.gemm_pair(f"dx{layer}_r", f"dx{layer}_i")
             return
         s2, s3 = self.lstm_stream.cuda_stream, self.lstm_gemm_stream.cuda_stream
@@ -971,7 +981,7 @@ class DCCRNWorkspace:
             self._lstm_bwd_call(1, t0, t1, s2)
         call("sehip_stream_depend", main, s2, self._event())
         self._chain_dirty = True
-        self.wgrad_group([nm for layer in (2, 1) for nm in [f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)]])
+        self.wgrad_group(self._lstm_wgrad_names((2, 1)))
         self.gemm_pair("dx1_r", "dx1_i")
 
     # ---- forward / backward --------------------------------------------------------------------

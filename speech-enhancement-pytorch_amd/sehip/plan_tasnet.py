@@ -192,6 +192,9 @@ class TasNetWorkspace:
         self.stats = torch.zeros(nb, 2, M, 2, dtype=torch.float64, device=device)      # forward: (sum, sumsq) per block / gLN / utterance
         self.bsums = torch.zeros(nb, 2, M, 2, dtype=torch.float64, device=device)      # backward: (S1, S2)
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
+        self.gln_scratch = torch.empty(int(_lib.lib().sehip_ctn_gln_bwd_scratch_floats(M, K, H)), dtype=torch.float32, device=device)
+        self.codec_scratch = torch.empty(int(_lib.lib().sehip_ctn_codec_bwd_scratch_floats(M, K, N, cfg.L, cfg.audio_channels)),
+                                         dtype=torch.float32, device=device)
         self.wav = None
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True
@@ -308,7 +311,7 @@ class TasNetWorkspace:
         self.bsums.zero_()
         self._chain_dirty = True
         call("sehip_ctn_decoder_bwd", ptr(dout), ptr(self.w), b["mlin"].ptr, pp("decoder.basis_signals.weight"), M, K, N, cfg.L,
-             cfg.audio_channels, cfg.C, self.T, b["dmlin"].ptr, ptr(self.dw_dec), gp(st.dec_g_off), stream())
+             cfg.audio_channels, cfg.C, self.T, b["dmlin"].ptr, ptr(self.dw_dec), gp(st.dec_g_off), ptr(self.codec_scratch), stream())
         self.wgrad("mask.fwd")
         self.gemm("mask.dg")
         for i in range(nb - 1, -1, -1):
@@ -319,17 +322,17 @@ class TasNetWorkspace:
             self.gemm(f"b{i}.pw.dg")
             call("sehip_ctn_gln_bwd", b["du"].ptr, b[f"h2_{i}"].ptr, pp(q + "3.net.1.weight"), self.stats[i, 1].data_ptr(),
                  pp(q + "3.net.2.gamma"), pp(q + "3.net.2.beta"), pp(q + "3.net.0.weight"), cfg.P, 2 ** x, 0, M, K, H,
-                 self.bsums[i, 1].data_ptr(), gp(o["gch2"]), b["dh2"].ptr, gp(o["a2"]), stream())
+                 self.bsums[i, 1].data_ptr(), gp(o["gch2"]), b["dh2"].ptr, gp(o["a2"]), ptr(self.gln_scratch), stream())
             call("sehip_ctn_gln_bwd", b["dh2"].ptr, b[f"h1_{i}"].ptr, pp(q + "1.weight"), self.stats[i, 0].data_ptr(),
                  pp(q + "2.gamma"), pp(q + "2.beta"), pp(q + "3.net.0.weight"), cfg.P, 2 ** x, 1, M, K, H,
-                 self.bsums[i, 0].data_ptr(), gp(o["gch1"]), b[f"dh1_{i}"].ptr, gp(o["a1"]), stream())
+                 self.bsums[i, 0].data_ptr(), gp(o["gch1"]), b[f"dh1_{i}"].ptr, gp(o["a1"]), ptr(self.gln_scratch), stream())
             self._chain_dirty = True
             self.wgrad(f"b{i}.in.fwd")
             self.gemm(f"b{i}.in.dg")
         self.wgrad("bott.fwd")
         self.gemm("bott.dg")
         call("sehip_ctn_encoder_bwd", ptr(self.wav), ptr(self.w), b["dcln"].ptr, ptr(self.dw_dec), pp(net + "0.gamma"), M,
-             cfg.audio_channels, self.T, N, cfg.L, gp(st.enc_g_off), stream())
+             cfg.audio_channels, self.T, N, cfg.L, gp(st.enc_g_off), ptr(self.codec_scratch), stream())
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
         call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())

@@ -220,7 +220,15 @@ class Solver(object):
 
     def train_step(self, mixture, sources):
         """One optimisation step on device tensors; returns (loss, grad_metric[2]) as DEVICE tensors (no sync)."""
-        self.model.train()
+        if mixture.is_cuda:
+            from ._lib import stream_scope
+            with stream_scope():
+                return self._train_step(mixture, sources)
+        return self._train_step(mixture, sources)
+
+    def _train_step(self, mixture, sources):
+        if not self.model.training:
+            self.model.train()
         enhanced = self.model(mixture)
         # (the reference computes a PIT loss here and then overwrites it, src/solver.py:469-480)
         loss = self.loss_function(enhanced, sources)
