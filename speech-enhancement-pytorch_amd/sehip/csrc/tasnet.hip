@@ -180,6 +180,85 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
     for (int i = threadIdx.x; i < 2 * N; i += 256) row[AL * N + i] = sgb[i];
 }
 
+// The same pass with the dU accumulators in REGISTERS (frame length AL = ac*L known at compile time, AL <= 64): lane n keeps
+// dU[n][0..AL) of its NC channels; the frame's AL input samples sit one per lane and reach the FMAs through v_readlane.
+// The LDS version above pays 2 LDS operations per multiply-add (0.48 ms at C4); this one none.
+template <int AL, int NC>
+__global__ __launch_bounds__(256) void ctn_encoder_bwd_reg_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                                  const bf16_raw* __restrict__ dcln, const float* __restrict__ dw_dec,
+                                                                  const float* __restrict__ gamma, int M, int ac, int T, int K, int N, int L,
+                                                                  int frames_per_wave, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    const long f0 = ((long)blockIdx.x * 4 + wave) * frames_per_wave;
+    float dg[NC], db[NC], gam[NC], acc[NC][AL];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        dg[i] = 0.f; db[i] = 0.f;
+        gam[i] = lane + 64 * i < N ? gamma[lane + 64 * i] : 0.f;
+#pragma unroll
+        for (int l = 0; l < AL; ++l) acc[i][l] = 0.f;
+    }
+    const int xa = lane / L, xl = lane - xa * L;          // this lane's sample of the frame: channel xa, tap xl (lane < AL)
+    for (long fr = f0; fr < f0 + frames_per_wave && fr < frames; ++fr) {
+        const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
+        const float xv = lane < AL ? wav[((long)m * ac + xa) * T + (long)k * step + xl] : 0.f;
+        float wv[NC], dy[NC];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int n = lane + 64 * i;
+            wv[i] = n < N ? w[fr * N + n] : 0.f;
+            dy[i] = n < N ? bf2f(dcln[fr * N + n]) : 0.f;
+            s += wv[i]; q += wv[i] * wv[i];
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        const float mean = s / N;
+        float var = q / N - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rs = 1.f / sqrtf(var + CTN_EPS);
+        float s1 = 0.f, s2 = 0.f, xh[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            xh[i] = (wv[i] - mean) * rs;
+            if (lane + 64 * i < N) { s1 += gam[i] * dy[i]; s2 += gam[i] * dy[i] * xh[i]; dg[i] += dy[i] * xh[i]; db[i] += dy[i]; }
+        }
+        s1 = wave_sum(s1) / N; s2 = wave_sum(s2) / N;
+        float dpre[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int n = lane + 64 * i;
+            const float dwv = n < N ? (gam[i] * dy[i] - s1 - xh[i] * s2) * rs + dw_dec[fr * N + n] : 0.f;
+            dpre[i] = wv[i] > 0.f ? dwv : 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < AL; ++l) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), l));
+#pragma unroll
+            for (int i = 0; i < NC; ++i) acc[i][l] += dpre[i] * x;
+        }
+    }
+    // the four waves' sums meet in LDS; one row per workgroup in gacc layout (dU [N][AL] | dgamma [N] | dbeta [N])
+    extern __shared__ float srow[];                       // [N*AL + 2N]
+    const int ncols = N * AL + 2 * N;
+    for (int i = threadIdx.x; i < ncols; i += 256) srow[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) {
+#pragma unroll
+            for (int l = 0; l < AL; ++l) atomicAdd(&srow[n * AL + l], acc[i][l]);
+            atomicAdd(&srow[N * AL + n], dg[i]);
+            atomicAdd(&srow[N * AL + N + n], db[i]);
+        }
+    }
+    __syncthreads();
+    float* row = part + (size_t)blockIdx.x * ncols;
+    for (int i = threadIdx.x; i < ncols; i += 256) row[i] = srow[i];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // global LayerNorm pieces.  Rows of utterance m: [m*K, (m+1)*K).  grid = (blocks per utterance, M).
 // ------------------------------------------------------------------------------------------------------------------
@@ -577,6 +656,85 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __res
     for (int i = threadIdx.x; i < AL * N; i += 256) row[i] = sdV[i] + sdV[AL * N + i] + sdV[2 * AL * N + i] + sdV[3 * AL * N + i];
 }
 
+// Register version of the pass above (AL = ac*L <= 64 at compile time): lane n keeps dV[0..AL)[n] of its NC channels, the
+// frame's AL output-gradient samples sit one per lane and are broadcast with v_readlane; only V itself is read from LDS.
+template <int AL, int NC>
+__global__ __launch_bounds__(256) void ctn_decoder_bwd_reg_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                                  const bf16_raw* __restrict__ mlin, const float* __restrict__ V, int M,
+                                                                  int K, int N, int L, int ac, int Cs, int T, int frames_per_wave,
+                                                                  bf16_raw* __restrict__ dmlin, float* __restrict__ dw_dec,
+                                                                  float* __restrict__ part) {
+    extern __shared__ float smem[];
+    float* sV = smem;                                  // [AL][N]; reused as the workgroup's dV row at the end
+    for (int i = threadIdx.x; i < AL * N; i += 256) sV[i] = V[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    const long f0 = ((long)blockIdx.x * 4 + wave) * frames_per_wave;
+    float acc[NC][AL];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int al = 0; al < AL; ++al) acc[i][al] = 0.f;
+    const int xa = lane / L, xl = lane - xa * L;
+    for (long fr = f0; fr < f0 + frames_per_wave && fr < frames; ++fr) {
+        const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
+        float dwacc[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) dwacc[i] = 0.f;
+        for (int c = 0; c < Cs; ++c) {
+            const long t = (long)k * step + xl;
+            const float dfv = (lane < AL && t < T) ? dout[(((long)m * Cs + c) * ac + xa) * T + t] : 0.f;
+            float wv[NC], ml[NC], mk[NC], sw[NC], dsw[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int n = lane + 64 * i;
+                wv[i] = n < N ? w[fr * N + n] : 0.f;
+                ml[i] = n < N ? bf2f(mlin[fr * ((long)Cs * N) + c * N + n]) : 0.f;
+                mk[i] = ml[i] > 0.f ? ml[i] : 0.f;
+                sw[i] = wv[i] * mk[i];
+                dsw[i] = 0.f;
+            }
+#pragma unroll
+            for (int al = 0; al < AL; ++al) {
+                const float df = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dfv), al));
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int n = lane + 64 * i;
+                    dsw[i] += df * sV[al * N + (n < N ? n : 0)];
+                    acc[i][al] += df * sw[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int n = lane + 64 * i;
+                if (n < N) dmlin[fr * ((long)Cs * N) + c * N + n] = f2bf(ml[i] > 0.f ? dsw[i] * wv[i] : 0.f);
+                dwacc[i] += dsw[i] * mk[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int n = lane + 64 * i;
+            if (n < N) dw_dec[fr * N + n] = dwacc[i];
+        }
+    }
+    __syncthreads();                                   // everybody is done with V
+    for (int i = threadIdx.x; i < AL * N; i += 256) sV[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) {
+#pragma unroll
+            for (int al = 0; al < AL; ++al) atomicAdd(&sV[al * N + n], acc[i][al]);
+        }
+    }
+    __syncthreads();
+    float* row = part + (size_t)blockIdx.x * (AL * N);
+    for (int i = threadIdx.x; i < AL * N; i += 256) row[i] = sV[i];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
@@ -584,6 +742,23 @@ static int ctn_check(const char* who, int M, int K, int C) {
     SEHIP_REQUIRE(M > 0 && K > 0, "%s: empty input", who);
     SEHIP_REQUIRE(C >= 8 && C <= 512 && (C & 7) == 0, "%s: channels C=%d must be a multiple of 8 in [8, 512]", who, C);
     return 0;
+}
+// the backward reductions pay a per-workgroup prologue / epilogue (40 channel constants, the LDS image, a partial row):
+// ~512 workgroups in all, each thread then walks 10+ rows
+static dim3 ctn_reduce_grid(int M, int K, int C) {
+    const int rpb = 256 / (C >> 3) > 0 ? 256 / (C >> 3) : 1;
+    long g = (512 + M - 1) / M;
+    const long cap = ((long)K + rpb - 1) / rpb;
+    if (g > cap) g = cap;
+    if (g > 64) g = 64;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g, (unsigned)M);
+}
+static dim3 ctn_colsum_grid(int nrows, int ncols) {
+    int rs = nrows / 8;                      // >= 8 rows per thread, up to 64 row groups
+    if (rs > 64) rs = 64;
+    if (rs < 1) rs = 1;
+    return dim3((unsigned)((ncols + 255) / 256), (unsigned)rs);
 }
 static dim3 ctn_grid(int M, int K, int C) {
     long pieces = (long)K * (C >> 3);
@@ -633,9 +808,17 @@ extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const voi
     const int fpw = ctn_frames_per_wave(frames);
     const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
     hipStream_t st = (hipStream_t)stream;
-    ctn_encoder_bwd_kernel<<<grid, 256, lds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch);
     const int ncols = ac * L * N + 2 * N;
-    ctn_colsum_kernel<<<dim3((ncols + 255) / 256, grid >= 32 ? 8 : 1), 256, 0, st>>>(scratch, grid, ncols, gacc);
+    const int AL = ac * L, NC = (N + 63) / 64;
+    const size_t rlds = (size_t)ncols * sizeof(float);
+#define ENC_REG(AL_, NC_) ctn_encoder_bwd_reg_kernel<AL_, NC_><<<grid, 256, rlds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch)
+    if (AL == 40 && NC == 2 && rlds <= 64 * 1024) ENC_REG(40, 2);
+    else if (AL == 40 && NC == 1) ENC_REG(40, 1);
+    else if (AL == 16 && NC <= 2 && rlds <= 64 * 1024) ENC_REG(16, 2);
+    else if (AL == 20 && NC <= 2 && rlds <= 64 * 1024) ENC_REG(20, 2);
+    else ctn_encoder_bwd_kernel<<<grid, 256, lds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch);
+#undef ENC_REG
+    ctn_colsum_kernel<<<ctn_colsum_grid(grid, ncols), 256, 0, st>>>(scratch, grid, ncols, gacc);
     SEHIP_CHECK_LAUNCH("ctn_encoder_bwd");
     return 0;
 }
@@ -670,7 +853,7 @@ extern "C" int sehip_ctn_gln_apply(const void* h, const float* slope, const doub
 // receives dWd.  sums [M][2] and gch / dslope are accumulated with atomics: the caller zeroes them.  scratch: at least
 // sehip_ctn_gln_bwd_scratch_floats(M, K, C) floats (the blocks' per-channel partial rows).
 extern "C" long sehip_ctn_gln_bwd_scratch_floats(int M, int K, int C) {
-    const dim3 grid = ctn_grid(M, K, C);
+    const dim3 grid = ctn_reduce_grid(M, K, C);
     return (long)grid.x * grid.y * 5L * C;
 }
 
@@ -682,16 +865,16 @@ extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slop
     SEHIP_REQUIRE((C >> 3) <= 256, "ctn_gln_bwd: too many channels");
     SEHIP_REQUIRE(scratch != nullptr, "ctn_gln_bwd: missing scratch buffer");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid = ctn_grid(M, K, C);
-    const int ncols = (2 + (dw ? 3 : 0)) * C, nrows = (int)(grid.x * grid.y);
+    const dim3 grid = ctn_grid(M, K, C), rgrid = ctn_reduce_grid(M, K, C);
+    const int ncols = (2 + (dw ? 3 : 0)) * C, nrows = (int)(rgrid.x * rgrid.y);
     const size_t lds = (size_t)ncols * sizeof(float);
-    const dim3 cgrid((ncols + 255) / 256, nrows >= 32 ? 16 : 1);
+    const dim3 cgrid = ctn_colsum_grid(nrows, ncols);
     if (dw) {
-        ctn_gln_bwd_reduce_kernel<3, true><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
+        ctn_gln_bwd_reduce_kernel<3, true><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
         ctn_colsum_kernel<<<cgrid, 256, 0, st>>>(scratch, nrows, ncols, gch);
         ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
     } else {
-        ctn_gln_bwd_reduce_kernel<3, false><<<grid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
+        ctn_gln_bwd_reduce_kernel<3, false><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
         ctn_colsum_kernel<<<cgrid, 256, 0, st>>>(scratch, nrows, ncols, gch);
         ctn_gln_bwd_apply_kernel<3, false><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
     }
@@ -725,10 +908,18 @@ extern "C" int sehip_ctn_decoder_bwd(const float* dout, const float* w, const vo
     const int fpw = ctn_frames_per_wave(frames);
     const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
     hipStream_t st = (hipStream_t)stream;
-    ctn_decoder_bwd_kernel<<<grid, 256, lds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
-                                                   (bf16_raw*)dmlin_bf16, dw_dec, scratch);
     const int ncols = ac * L * N;
-    ctn_colsum_kernel<<<dim3((ncols + 255) / 256, grid >= 32 ? 8 : 1), 256, 0, st>>>(scratch, grid, ncols, gacc);
+    const int AL = ac * L, NC = (N + 63) / 64;
+    const size_t rlds = (size_t)ncols * sizeof(float);
+#define DEC_REG(AL_, NC_) ctn_decoder_bwd_reg_kernel<AL_, NC_><<<grid, 256, rlds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw, (bf16_raw*)dmlin_bf16, dw_dec, scratch)
+    if (AL == 40 && NC == 2 && rlds <= 64 * 1024) DEC_REG(40, 2);
+    else if (AL == 40 && NC == 1) DEC_REG(40, 1);
+    else if (AL == 16 && NC <= 2 && rlds <= 64 * 1024) DEC_REG(16, 2);
+    else if (AL == 20 && NC <= 2 && rlds <= 64 * 1024) DEC_REG(20, 2);
+    else ctn_decoder_bwd_kernel<<<grid, 256, lds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
+                                                        (bf16_raw*)dmlin_bf16, dw_dec, scratch);
+#undef DEC_REG
+    ctn_colsum_kernel<<<ctn_colsum_grid(grid, ncols), 256, 0, st>>>(scratch, grid, ncols, gacc);
     SEHIP_CHECK_LAUNCH("ctn_decoder_bwd");
     return 0;
 }
