@@ -148,6 +148,15 @@ typedef struct {
      * product + res (the encoder's input gradient = dgrad of the next layer + the gradient that arrived over the skip
      * connection, src/model/dccrn.py:186-197 backward: one tensor pass less in each of the two BatchNorm backward kernels) */
     const void* res;
+    /* Optional (forward products whose output feeds ComplexBatchNorm, src/model/dccrn.py:549-611): the kernel also accumulates
+     * the layer's batch statistics from the bf16 values it stores, so that no separate pass reads the tensor back.
+     * stats: fp32 [8 replicas][5][stats_cr] (sum re, sum im, sum re^2, sum re*im, sum im^2 per complex channel; atomics, the
+     * caller zeroes it; the replica is the workgroup's XCD).  Requires Npad a multiple of 128 with every 128-column tile
+     * holding [64 real | 64 imaginary] columns of the SAME 64 complex channels (tile t <-> channels 64 t ..), a bf16 dense
+     * destination, and is honoured by the LDS-DMA convolution kernel only: sehip_gemm fails loudly when it cannot honour it. */
+    float* stats;
+    int32_t stats_cr;
+    int32_t pad2_;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);
@@ -182,6 +191,10 @@ int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n,
 long sehip_cbn_scratch_floats(long rows, int Cr);
 int sehip_cbn_stats(const void* y, long rows, int Cr, float* part, void* stream);
 int sehip_cbn_finalize(const float* part, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
+                       const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
+                       long rows, int Cr, float eps, float momentum, int training, float* coef /*[Cr][16]*/, void* stream);
+/* the same from `nblk` rows [nblk][5][Cr] of sums accumulated elsewhere (the `stats` field of sehip_gemm_desc: nblk = 8) */
+int sehip_cbn_finalize_n(const float* part, int nblk, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
                        const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
                        long rows, int Cr, float eps, float momentum, int training, float* coef /*[Cr][16]*/, void* stream);
 int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream);

@@ -60,6 +60,7 @@ _PROTOS = {
     "sehip_unpack_grad": [P, P, L, P, P],
     "sehip_cbn_stats": [P, L, I, P, P],
     "sehip_cbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],
+    "sehip_cbn_finalize_n": [P, I, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],
     "sehip_cbn_apply": [P, P, P, L, I, P, P],
     "sehip_cbn_bwd_reduce": [P, P, P, P, P, L, I, I, I, I, P, P],
     "sehip_cbn_bwd_finalize": [P, P, P, P, P, L, I, P, P, P, P, P, P, P, P],

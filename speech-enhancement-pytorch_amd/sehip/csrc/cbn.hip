@@ -533,14 +533,30 @@ extern "C" int sehip_cbn_stats(const void* y, long rows, int Cr, float* part, vo
 }
 
 // params: Wrr,Wri,Wii,Br,Bi [Cr] fp32; buffers RMr,RMi,RVrr,RVri,RVii [Cr] fp32 (updated in training), nbt int64[1]
+static int cbn_finalize_launch(const float* part, int nblk, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
+                               const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt, long rows,
+                               int Cr, float eps, float momentum, int training, float* coef, void* stream) {
+    if (int e = check_cbn("cbn_finalize", rows, Cr)) return e;
+    SEHIP_REQUIRE(nblk >= 1 && nblk <= CBN_MAX_BLOCKS, "cbn_finalize: %d partial rows (1..%d)", nblk, CBN_MAX_BLOCKS);
+    cbn_finalize_kernel<<<Cr, 64, 0, (hipStream_t)stream>>>(part, nblk, Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr, RVri, RVii, nbt, rows,
+                                                            Cr, eps, momentum, training, coef);
+    SEHIP_CHECK_LAUNCH("cbn_finalize");
+    return 0;
+}
+
 extern "C" int sehip_cbn_finalize(const float* part, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
                                   const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
                                   long rows, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
-    if (int e = check_cbn("cbn_finalize", rows, Cr)) return e;
-    cbn_finalize_kernel<<<Cr, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr,
-                                                            RVri, RVii, nbt, rows, Cr, eps, momentum, training, coef);
-    SEHIP_CHECK_LAUNCH("cbn_finalize");
-    return 0;
+    return cbn_finalize_launch(part, stat_blocks(rows, Cr), Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr, RVri, RVii, nbt, rows, Cr, eps,
+                               momentum, training, coef, stream);
+}
+
+// the same from nblk rows of sums [nblk][5][Cr] that somebody else accumulated (the convolution kernel's `stats` field: 8 replicas)
+extern "C" int sehip_cbn_finalize_n(const float* part, int nblk, const float* Wrr, const float* Wri, const float* Wii, const float* Br,
+                                    const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
+                                    long rows, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
+    return cbn_finalize_launch(part, nblk, Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr, RVri, RVii, nbt, rows, Cr, eps, momentum, training,
+                               coef, stream);
 }
 
 extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream) {

@@ -272,6 +272,20 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // every wave has finished reading the weight tiles and the patch: the LDS is free
+    // statistics need every wave of the workgroup on the dense path (they meet at a barrier below): decided workgroup-wide
+    // (flags in the dynamic LDS behind the waves' images: __syncthreads_and would add static LDS on top of the 160 KB request)
+    bool with_stats = false;
+    if (d.stats) {
+        int* flag = reinterpret_cast<int*>(smem + (size_t)(NTHR / 64) * (64 * 72 * 2));
+        if (lane == 0) flag[wave] = dense ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        with_stats = true;
+#pragma unroll
+        for (int i = 0; i < NTHR / 64; ++i) with_stats = with_stats && flag[i] != 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // everybody has read the flags before the images are written
+    }
     if (dense) {
         bf16_raw* tb_ = reinterpret_cast<bf16_raw*>(smem) + wave * (WROWS * TP);   // 9 KB per wave: inside the (now idle) weight ring + patch
 #pragma unroll
@@ -286,6 +300,58 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_
             }
         }
         const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
+        if (with_stats) {
+            // Batch statistics of the ComplexBatchNorm that follows (descriptor field `stats`), from the bf16 values just parked
+            // in the waves' LDS images: wave (wm, 0) holds the real halves and wave (wm, 1) the imaginary halves of the tile's
+            // 64 complex channels for the same 64 rows.  Wave (wm, wn) takes channels 32 wn .. 32 wn + 31: lane = channel pair
+            // (lane & 15) x row group (lane >> 4, 16 rows each); padding rows (virtual frames) are masked out.
+            bool rv;
+            {
+                const int rr = wm * WROWS + lane;
+                const int tl = rr >> lgJ;
+                int b = g0 / TV, t = g0 - b * TV + tl;
+                for (; t >= TV; t -= TV) ++b;
+                rv = b < B && t < d.TT;
+            }
+            const unsigned long long rmask = __ballot(rv);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // both images of this row block are complete
+            const bf16_raw* imr = reinterpret_cast<const bf16_raw*>(smem) + (wm + WMW * 0) * (WROWS * TP);
+            const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + WMW * 1) * (WROWS * TP);
+            const int cp = 32 * wn + 2 * (lane & 15), rg = lane >> 4;
+            float sr[2] = {0.f, 0.f}, si[2] = {0.f, 0.f}, srr[2] = {0.f, 0.f}, sri[2] = {0.f, 0.f}, sii[2] = {0.f, 0.f};
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int r = 16 * rg + it;
+                const unsigned ur = *reinterpret_cast<const unsigned*>(&imr[r * TP + cp]);
+                const unsigned ui = *reinterpret_cast<const unsigned*>(&imi[r * TP + cp]);
+                const float ok = (rmask >> r) & 1ull ? 1.f : 0.f;
+                const float yr[2] = {__uint_as_float(ur << 16) * ok, __uint_as_float(ur & 0xffff0000u) * ok};
+                const float yi[2] = {__uint_as_float(ui << 16) * ok, __uint_as_float(ui & 0xffff0000u) * ok};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    sr[e] += yr[e]; si[e] += yi[e];
+                    srr[e] += yr[e] * yr[e]; sri[e] += yr[e] * yi[e]; sii[e] += yi[e] * yi[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    sr[e] += __shfl_xor(sr[e], o, 64); si[e] += __shfl_xor(si[e], o, 64);
+                    srr[e] += __shfl_xor(srr[e], o, 64); sri[e] += __shfl_xor(sri[e], o, 64); sii[e] += __shfl_xor(sii[e], o, 64);
+                }
+            }
+            if (lane < 16) {
+                const int Cr = d.stats_cr;
+                float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + cp;   // tile n0 <-> complex channels n0/2 ..
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    atomicAdd(sp + e, sr[e]); atomicAdd(sp + Cr + e, si[e]);
+                    atomicAdd(sp + 2 * Cr + e, srr[e]); atomicAdd(sp + 3 * Cr + e, sri[e]); atomicAdd(sp + 4 * Cr + e, sii[e]);
+                }
+            }
+        }
         bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
         const bf16_raw* rptr = (d.res && first.dst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + first.coff : nullptr;
         // destination offsets in 32 bits (the dispatcher checked the sizes) from per-workgroup constants; the tile's first
@@ -410,6 +476,7 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
     static const int bm_force = getenv("SEHIP_CONV_V2_BM") ? atoi(getenv("SEHIP_CONV_V2_BM")) : 0;
     static const bool census = getenv("SEHIP_CONV_V2_CENSUS") != nullptr;
     if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
+    if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return 0;   // see sehip.h
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     if ((C0 & 63) || (C1 & 63) || (d.Npad & 127) || d.J > 64 || (128 % d.J)) return 0;
     if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
@@ -449,7 +516,7 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
         }
         const size_t patch_bytes = (size_t)(TB + 1) * FS * PP * 2;
         size_t lds = 3 * C2_WSLOT + patch_bytes + 2 * (TB + 1) * sizeof(int) + 16;
-        const size_t epi = (size_t)(nthr / 64) * 64 * 72 * 2;         // the waves' output staging images reuse the same LDS
+        const size_t epi = (size_t)(nthr / 64) * 64 * 72 * 2 + 64;    // the waves' output staging images reuse the same LDS (+ flags)
         if (lds < epi) lds = epi;
         const bool fits = (TB + 1) * FR * 4 <= C2_MAXP * nthr && TB + 1 <= 255 && lds <= (BM == 128 ? 80 : 160) * 1024;
         if (!fits) {

@@ -1292,6 +1292,14 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("gemm", d)) return e;
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
+    if (d->stats) {   // only the LDS-DMA convolution kernel accumulates the BatchNorm statistics (sehip.h): no silent omission
+        if (sehip_try_conv_gemm_v2(*d, st)) {
+            SEHIP_CHECK_LAUNCH("gemm(conv+stats)");
+            return 0;
+        }
+        return sehip_set_error(-1, "gemm: this product cannot accumulate BatchNorm statistics (field stats): it does not qualify "
+                                   "for conv_gemm_v2 (Npad=%d, stats_cr=%d, cv_nf=%d)", d->Npad, d->stats_cr, d->cv_nf);
+    }
     if (try_conv_gemm(*d, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv)");
         return 0;
@@ -2036,8 +2044,8 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     // 256 k-columns per staged dOut slab (KQ = 4) quarter the dOut re-reads of long-K products, but measured SLOWER on the DCUnet
     // weight gradients (B=64: 1124 vs 914 us per launch): what bounds them is the per-tap gather of the input, not dOut, and
     // the wide tile has a quarter of the workgroups.  Opt-in for experiments only.
-    static const bool wide = getenv("SEHIP_WIDE_WGRAD") != nullptr;
-    const int kq = (wide && d->K >= 1024) ? 4 : 1;
+    static const int wide = getenv("SEHIP_WIDE_WGRAD") ? atoi(getenv("SEHIP_WIDE_WGRAD")) : 0;   // 2 or 4: k-columns per slab / 64
+    const int kq = (wide >= 4 && d->K >= 1024) ? 4 : ((wide >= 2 && d->K >= 1024) ? 2 : 1);
     const int ktiles = cdiv(d->K, 64 * kq);
     // split m so that the grid has ~2048 workgroups, at least 256 rows each
     static const int gw_wgs = getenv("SEHIP_GW_WGS") ? atoi(getenv("SEHIP_GW_WGS")) : 2048;
@@ -2048,7 +2056,11 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     const int splits = cdiv(d->M, mpb);
     dim3 grid(ntiles, ktiles, splits);
     sehip_note_kernel("wgrad_kernel<%d, %d, %d, %d>", bnw, bnw >= 64 ? 2 : 1, bnw >= 64 ? 2 : 4, kq);
-    if (kq == 4) {
+    if (kq == 2) {
+        if (bnw == 64) wgrad_kernel<64, 2, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else if (bnw == 128) wgrad_kernel<128, 2, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
+        else return sehip_set_error(-1, "wgrad: the 128-column slab variant is built for 64 / 128 output columns only");
+    } else if (kq == 4) {
         if (bnw == 16) wgrad_kernel<16, 1, 4, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
         else if (bnw == 32) wgrad_kernel<32, 1, 4, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);
         else if (bnw == 64) wgrad_kernel<64, 2, 2, 4><<<grid, 256, 0, st>>>(*d, (int)mpb);

@@ -43,7 +43,7 @@ class CGemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32),
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
                 ("tmul", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
-                ("res", C.c_void_p)]
+                ("res", C.c_void_p), ("stats", C.c_void_p), ("stats_cr", C.c_int32), ("pad2_", C.c_int32)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient
@@ -315,10 +315,40 @@ class GemmSpec:
         self.res = res     # buffer added to what goes to dsts[0] (same layout), or None
         self.w_off = self.b_off = self.dw_off = self.db_off = None
         self.kt_off = self.nt_off = None
+        self.stats_of = None   # BatchNorm prefix whose batch statistics this forward product accumulates (sehip_gemm_desc.stats)
+
+    def tile_complex_columns(self):
+        """Re-orders the output columns [re 0..Cr) | im 0..Cr) so that every 128-column tile holds [64 re | 64 im] of the SAME 64
+        complex channels (what the fused BatchNorm statistics of conv_gemm_v2 need); rows of W / bias and the column table move
+        together, so the weight-gradient product and the un-packing of its dW follow automatically."""
+        n = self.N
+        assert n == self.Npad and n % 128 == 0 and self.ntab.shape[0] == n // 4
+        cr = n // 2
+        perm = np.concatenate([np.concatenate([np.arange(64 * t, 64 * t + 64), cr + np.arange(64 * t, 64 * t + 64)])
+                               for t in range(cr // 64)])
+        self.widx, self.wneg = self.widx[perm], self.wneg[perm]
+        if self.bias_pairs is not None:
+            self.bias_pairs = self.bias_pairs[perm]
+        self.ntab = self.ntab.reshape(n // 4, 4)[perm[::4] // 4].copy()
 
 
 class DCCRNStatic:
+    def _maybe_fuse_stats(self, pre, names, co, cins, J):
+        """Forward products that conv_gemm_v2 takes (64-multiple source channels, 128-multiple outputs, J | 128, J <= 64) also
+        accumulate the batch statistics of the ComplexBatchNorm behind them: no cbn_stats pass for these layers."""
+        if os.environ.get("SEHIP_NO_FUSE_STATS"):
+            return
+        if co % 128 or any(c % 64 for c in cins) or J > 64 or 128 % J:
+            return
+        for nm in names:
+            sp = self.specs[nm]
+            if co > 128:
+                sp.tile_complex_columns()
+            sp.stats_of = pre
+        self.fused_stats.add(pre)
+
     def __init__(self, cfg: DCCRNConfig):
+        self.fused_stats = set()
         self.cfg = cfg
         self.layout = L = ParamLayout(cfg)
         kn = cfg.kernel_num
@@ -360,6 +390,7 @@ class DCCRNStatic:
                                                   self.F0 >> (i + 1), 2, [(src, "all")], [(f"y{i}", 0, 1, 0)],
                                                   conv=(5, -2, [[-1, 0], [0, 0]]))  # ci == 2: read by the narrow wgrad only
             self.bn.append((pre, co // 2))
+            self._maybe_fuse_stats(pre, [f"enc{i}.fwd"], co, [ci], self.F0 >> (i + 1))
             if i >= 1:
                 # dgrad by output-row parity: dX[b,t,2j+p,ci] = sum dY[b,t+1-kt,j+d,co] * full[co,ci,kf,kt], kf = p+2-2d
                 for p in (0, 1):
@@ -426,6 +457,7 @@ class DCCRNStatic:
                                                                                [bt, bt - 1]]))
             if not last:
                 self.bn.append((pre, co // 2))
+                self._maybe_fuse_stats(pre, [f"dec{j}.fwd0", f"dec{j}.fwd1"], co, [c1, c2], f_in)
             # dgrad: dIn[b,t,fi,(s,c)] = sum dOut'[b,t+kt,2fi-2+kf,co] * full[cin,co,kf,kt]
             gsrc = "dmask" if last else f"dyd{j}"
             if co >= 8:
@@ -686,6 +718,14 @@ class DCCRNWorkspace:
             need = max(need, int(lib.sehip_cbn_scratch_floats(src.t.numel() // (2 * cr), cr)))
         self.bn_acc = torch.zeros(need, dtype=torch.float32, device=device)
         self.bn_coef = {pre: torch.zeros(cr, 16, dtype=torch.float32, device=device) for pre, cr in st.bn}
+        # [8 replicas][5][Cr] sums per fused layer (sehip_gemm_desc.stats), one allocation so that one memset clears them all
+        offs, tot = {}, 0
+        for pre, cr in st.bn:
+            if pre in st.fused_stats:
+                offs[pre] = tot
+                tot += 8 * 5 * cr
+        self.bn_stats_all = torch.zeros(max(tot, 1), dtype=torch.float32, device=device)
+        self.bn_stats = {pre: self.bn_stats_all[o:o + 8 * 5 * cr] for (pre, cr) in st.bn if pre in offs for o in [offs[pre]]}
         self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
         import os
@@ -767,6 +807,9 @@ class DCCRNWorkspace:
                 d.bias = tb.bpack.data_ptr() + 4 * s.b_off
             d.M, d.N, d.Npad, d.K = B * tt * s.J, s.N, s.Npad, s.K
             d.TT, d.J, d.fmul = tt, s.J, s.fmul
+            if s.stats_of is not None:
+                d.stats = self.bn_stats[s.stats_of].data_ptr()
+                d.stats_cr = s.N // 2
             if s.res is not None:
                 rb, db_ = self.bufs[s.res], self.bufs[s.dsts[0][0]]
                 assert (rb.Tst, rb.F, rb.C) == (db_.Tst, db_.F, db_.C) and rb.t.dtype == torch.bfloat16
@@ -908,6 +951,12 @@ class DCCRNWorkspace:
         rows = y.t.numel() // (2 * cr)
         pp, bp, nb = self._bn_ptrs(pre, params, buffers, nbt)
         coef = self.bn_coef[pre]
+        if pre in self.st.fused_stats:     # the producing convolution accumulated the sums (8 replicas)
+            call("sehip_cbn_finalize_n", ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
+                 bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
+                 1 if training else 0, ptr(coef), stream())
+            call("sehip_cbn_apply", y.ptr, ptr(coef), pp("2.weight"), rows, cr, z.ptr, stream())
+            return
         if training:
             call("sehip_cbn_stats", y.ptr, rows, cr, ptr(self.bn_acc), stream())
         call("sehip_cbn_finalize", ptr(self.bn_acc), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
@@ -995,6 +1044,8 @@ class DCCRNWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, T, h = self.B, self.T, cfg.hid
         self.pack_weights(params)
+        if self.st.fused_stats:
+            self.bn_stats_all.zero_()
         call("sehip_stft_fwd", ptr(wav_in), ptr(tb.window), B, self.N, cfg.win_len, cfg.win_inc, cfg.fft_len,
              ptr(self.spec), b["enc_in"].ptr, stream())
         for i in range(6):
