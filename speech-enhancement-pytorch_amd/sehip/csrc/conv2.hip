@@ -430,7 +430,7 @@ static void c2_launch_pp(const sehip_gemm_desc& d, int TB, int JB, int FR, int B
 }
 template <int NF, int WMW>
 static void c2_launch(const sehip_gemm_desc& d, int TB, int JB, int FR, int B, int PP, int FS, int grid, size_t lds, hipStream_t st) {
-    sehip_note_kernel("conv_gemm_v2_kernel<%d, %d>", NF, WMW);
+    sehip_note_kernel("conv_gemm_v2_kernel<%d, %d, %d>", NF, WMW, PP == 40 || PP == 48 ? PP : 56);   // as rocprofv3 prints the symbol
     if (PP == 40) c2_launch_pp<NF, WMW, 40>(d, TB, JB, FR, B, FS, grid, lds, st);
     else if (PP == 48) c2_launch_pp<NF, WMW, 48>(d, TB, JB, FR, B, FS, grid, lds, st);
     else c2_launch_pp<NF, WMW, 56>(d, TB, JB, FR, B, FS, grid, lds, st);
