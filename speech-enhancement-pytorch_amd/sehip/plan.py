@@ -336,8 +336,8 @@ class DCCRNStatic:
     def _maybe_fuse_stats(self, pre, names, co, cins, J):
         """Forward products that conv_gemm_v2 takes (64-multiple source channels, 128-multiple outputs, J | 128, J <= 64) also
         accumulate the batch statistics of the ComplexBatchNorm behind them: no cbn_stats pass for these layers."""
-        if os.environ.get("SEHIP_NO_FUSE_STATS"):
-            return
+        if any(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_PATCH", "SEHIP_NO_CONV_V2")):
+            return      # (the experiment switches that take conv_gemm_v2 away also take its statistics away)
         if co % 128 or any(c % 64 for c in cins) or J > 64 or 128 % J:
             return
         for nm in names:
