@@ -969,43 +969,97 @@ __device__ __forceinline__ void wgrad_body(const sehip_gemm_desc& d, const int b
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) accb[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- staging addresses.  Everything that does not depend on the slab is fixed per thread: its k chunk (source, tap
+    // offsets, bounds) and, for dOut, its 8-column group (destination, column offset).  The rows it stages advance by 64 per
+    // slab, so (utterance, frame, row) are stepped with carries instead of two integer divisions per row and slab -- the
+    // first version spent ~630 vector instructions per slab on this against 16-24 MFMAs (the DCUnet weight gradients ran at
+    // 95 TFLOP/s on address arithmetic).
+    struct RowState { int b, t, j; };
+    auto decompose = [&](int m) {
+        RowState r;
+        const int mm = m < d.M ? m : 0;
+        const int bt = mm / d.J;
+        r.j = mm - bt * d.J;
+        r.b = bt / d.TT;
+        r.t = bt - r.b * d.TT;
+        return r;
+    };
+    const int adv_t = 64 / d.J, adv_j = 64 - adv_t * d.J;
+    auto advance = [&](RowState& r) {
+        r.j += adv_j; r.t += adv_t;
+        if (r.j >= d.J) { r.j -= d.J; ++r.t; }
+        for (; r.t >= d.TT; r.t -= d.TT) ++r.b;
+    };
+    // A operand: this thread's chunk of the rows r0 + RPP*i
+    const bool a_second = e.src > 0;
+    const sehip_src& AS = a_second ? d.src[1] : d.src[0];
+    const bool a_narrow = e.src >= 0 && AS.C == 2;
+    const int a_toff = e.toff >> 16, a_fadd = (int)(short)(e.toff & 0xffff);
+    const int a_tlo = AS.tlo, a_thi = AS.thi, a_F = AS.F, a_C = AS.C, a_T = AS.T, a_tm = src_tmul(d);
+    const bf16_raw* a_base = reinterpret_cast<const bf16_raw*>(AS.ptr) + e.fadd;      // e.fadd = element delta of the chunk
+    RowState ra[NXA];
+#pragma unroll
+    for (int i = 0; i < NXA; ++i) ra[i] = decompose(m_begin + r0 + RPP * i);
+    // dOut: piece id = tid + 256 i is row id / GCH, column group id % GCH; 256 is a multiple of GCH, so the column group (hence
+    // destination, column offset, density) is the same for all of a thread's pieces and only the row differs
+    static_assert(256 % GCH == 0, "column group of a thread must not depend on the piece");
+    const int g_gc = tid % GCH, g_r0 = tid / GCH;
+    const bool g_have = tid < 64 * GCH;
+    const sehip_nchunk g_c0 = d.ntab[(n0 + g_gc * 8) >> 2], g_c1 = d.ntab[((n0 + g_gc * 8) >> 2) + 1];
+    const bool g_dense = g_c0.nvalid == 4 && g_c1.nvalid == 4 && g_c1.dst == g_c0.dst && g_c1.coff == g_c0.coff + 4;
+    const sehip_dst& GD = sdst[g_c0.dst > 0 ? 1 : 0];
+    const bf16_raw* g_base = reinterpret_cast<const bf16_raw*>(GD.ptr) + g_c0.coff;
+    const int g_T = GD.T, g_F = GD.F, g_C = GD.C, g_tm = GD.tmul > 1 ? GD.tmul : 1, g_toff = GD.toff, g_fmul = GD.fmul, g_fadd = GD.fadd;
+    RowState rg[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) rg[i] = decompose(m_begin + g_r0 + (256 / GCH) * i);
+    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&sehip_zero16);
+
     uint4 xa[NXA], ga[GPT];
     auto fetch = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < NXA; ++i) {
-            const int m = mb + r0 + RPP * i;
-            RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul, src_tmul(d));
-            xa[i] = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
+            const RowState r = ra[i];
+            const bool valid = mb + r0 + RPP * i < m_end;
+            if (a_narrow) {    // 2-channel source: the generic gather (4 rows x (re, im) per chunk)
+                RowPos rp;
+                rp.valid = valid; rp.b = r.b; rp.t = r.t; rp.jf = r.j * d.fmul; rp.ts = r.t * a_tm;
+                xa[i] = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
+            } else {
+                const int ts = r.t * a_tm + a_toff, f = r.j * d.fmul + a_fadd;
+                const bool ok = valid && e.src >= 0 && ts >= a_tlo && ts < a_thi && (unsigned)f < (unsigned)a_F;
+                const long off = ((long)(r.b * a_T + r.t * a_tm) * a_F + r.j * d.fmul) * a_C;
+                const bf16_raw* q = ok ? a_base + off : zero_page;        // unconditional load (zeros for padding): no branch per piece
+                xa[i] = *reinterpret_cast<const uint4*>(q);
+            }
+            advance(ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
-            const int id = tid + 256 * i;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (id < 64 * GCH) {
-                const int r = id / GCH, gc = id - r * GCH;
-                const int m = mb + r;
-                RowPos rp = row_pos(m, m_end, d.TT, d.J, d.fmul);
-                if (rp.valid) {
-                    const int n = n0 + gc * 8;
-                    const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
-                    if (c0.nvalid == 4 && c1.nvalid == 4 && c1.dst == c0.dst && c1.coff == c0.coff + 4) {
-                        const sehip_dst& ds = sdst[c0.dst];
-                        const bf16_raw* p = reinterpret_cast<const bf16_raw*>(ds.ptr) + dst_row_offset(ds, rp, d.fmul) + c0.coff;
-                        v = *reinterpret_cast<const uint4*>(p);
-                    } else {
-                        bf16_raw tmp[8];
+            const int row = g_r0 + (256 / GCH) * i;
+            if (g_have && row < 64) {
+                const RowState r = rg[i];
+                const bool valid = mb + row < m_end;
+                if (g_dense) {
+                    const long off = ((long)(r.b * g_T + r.t * g_tm + g_toff) * g_F + r.j * g_fmul + g_fadd) * g_C;
+                    const bf16_raw* q = valid ? g_base + off : zero_page;
+                    v = *reinterpret_cast<const uint4*>(q);
+                } else if (valid) {
+                    bf16_raw tmp[8];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const sehip_nchunk c = h ? c1 : c0;
-                            const sehip_dst& ds = sdst[c.dst > 0 ? 1 : 0];
-                            const bf16_raw* p = reinterpret_cast<const bf16_raw*>(ds.ptr) + dst_row_offset(ds, rp, d.fmul) + c.coff;
+                    for (int h = 0; h < 2; ++h) {
+                        const sehip_nchunk c = h ? g_c1 : g_c0;
+                        const sehip_dst& ds = sdst[c.dst > 0 ? 1 : 0];
+                        const long o2 = ((long)(r.b * ds.T + r.t * (ds.tmul > 1 ? ds.tmul : 1) + ds.toff) * ds.F + r.j * ds.fmul + ds.fadd) * ds.C;
+                        const bf16_raw* p = reinterpret_cast<const bf16_raw*>(ds.ptr) + o2 + c.coff;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) tmp[h * 4 + q] = (q < c.nvalid) ? p[q] : (bf16_raw)0;
-                        }
-                        v = make_uint4(tmp[0] | ((unsigned)tmp[1] << 16), tmp[2] | ((unsigned)tmp[3] << 16),
-                                       tmp[4] | ((unsigned)tmp[5] << 16), tmp[6] | ((unsigned)tmp[7] << 16));
+                        for (int q = 0; q < 4; ++q) tmp[h * 4 + q] = (q < c.nvalid) ? p[q] : (bf16_raw)0;
                     }
+                    v = make_uint4(tmp[0] | ((unsigned)tmp[1] << 16), tmp[2] | ((unsigned)tmp[3] << 16),
+                                   tmp[4] | ((unsigned)tmp[5] << 16), tmp[6] | ((unsigned)tmp[7] << 16));
                 }
+                advance(rg[i]);
             }
             ga[i] = v;
         }

@@ -11,3 +11,14 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A bound on every test (pytest-timeout, when the plugin is there): a wedged GPU kernel or an oversubscribed CPU oracle
+    then fails ONE test after 10 minutes instead of holding the whole run."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    import pytest
+    for it in items:
+        if it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(600))
