@@ -21,14 +21,15 @@
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-struct RowPos { int b, t, jf; bool valid; int ts; };  // ts = source frame of the row (t * tmul); t = frame of the row space
+struct RowPos { int b, t, jf; bool valid; int ts; int j; };  // ts = source frame of the row (t * tmul); t = frame of the row space; jf = j * fmul
 
 __device__ __forceinline__ RowPos row_pos(int m, int M, int TT, int J, int fmul, int tmul = 1) {
     RowPos r;
     r.valid = m < M;
     const int mm = r.valid ? m : 0;
     const int bt = mm / J;
-    r.jf = (mm - bt * J) * fmul;
+    r.j = mm - bt * J;
+    r.jf = r.j * fmul;
     r.b = bt / TT;
     r.t = bt - r.b * TT;
     r.ts = r.t * tmul;
@@ -71,8 +72,9 @@ __device__ __forceinline__ uint4 gather_chunk(const sehip_src& s0, const sehip_s
 }
 
 __device__ __forceinline__ size_t dst_row_offset(const sehip_dst& d, const RowPos r, int fmul_row) {
-    // r.jf = j*fmul_row ; destination uses its own multiplier
-    const int j = r.jf / fmul_row;
+    // the destination uses its own row multiplier (fmul_row is the row space's: r.jf = r.j * fmul_row)
+    (void)fmul_row;
+    const int j = r.j;
     return (((size_t)r.b * d.T + r.t * (d.tmul > 1 ? d.tmul : 1) + d.toff) * d.F + (size_t)j * d.fmul + d.fadd) * d.C;
 }
 
@@ -213,8 +215,47 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    RegTile<NRA> ra = fetch_a_tile<NRA>(d, 0, kc, rp, rb0, rb1);
-    RegTile<NRW> rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, kc * 8);
+    // A-tile gather.  The chunk-table entry of K step kt+2 is requested while step kt runs (it used to be loaded and then used
+    // for the gather addresses inside the same step: two dependent memory round trips per 64 k-columns), out-of-range pieces
+    // read a zero page instead of branching, and the weight rows are a pointer that moves 64 columns per step.
+    const bool narrow = d.src[0].C == 2 || (d.src[1].ptr && d.src[1].C == 2);
+    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&sehip_zero16);
+    const bf16_raw* sp0 = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
+    const bf16_raw* sp1 = reinterpret_cast<const bf16_raw*>(d.src[1].ptr);
+    auto gather = [&](const sehip_kchunk e) {
+        RegTile<NRA> t;
+        if (narrow) {
+#pragma unroll
+            for (int i = 0; i < NRA; ++i) t.v[i] = gather_chunk(d.src[0], d.src[1], e, rp[i], rb0[i], rb1[i]);
+            return t;
+        }
+        const bool second = e.src > 0;
+        const int toff = e.toff >> 16, fadd = (int)(short)(e.toff & 0xffff);
+        const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+        const unsigned F = (unsigned)(second ? d.src[1].F : d.src[0].F);
+        const bf16_raw* base = (second ? sp1 : sp0) + e.fadd;        // e.fadd = element delta of the chunk
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int ts = rp[i].ts + toff;
+            const bool ok = rp[i].valid && e.src >= 0 && ts >= tlo && ts < thi && (unsigned)(rp[i].jf + fadd) < F;
+            const bf16_raw* q = ok ? base + (second ? rb1[i] : rb0[i]) : zero_page;
+            t.v[i] = *reinterpret_cast<const uint4*>(q);
+        }
+        return t;
+    };
+    const bf16_raw* wrow[NRW];
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) wrow[i] = Wb + (size_t)(n0 + min(r0 + 32 * i, BN - 1)) * d.K + kc * 8;
+    auto fetch_w = [&](int kt) {
+        RegTile<NRW> t;
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) t.v[i] = *reinterpret_cast<const uint4*>(wrow[i] + kt * 64);   // rows >= BN: a duplicate, never stored
+        return t;
+    };
+
+    sehip_kchunk e1 = d.ktab[min(8 + kc, (d.K >> 3) - 1)];          // entry of K step 1
+    RegTile<NRA> ra = gather(d.ktab[kc]);
+    RegTile<NRW> rw = fetch_w(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
@@ -228,8 +269,9 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
         }
         __syncthreads();
         if (kt + 1 < nk) {  // next K tile in flight behind this tile's MFMAs
-            ra = fetch_a_tile<NRA>(d, kt + 1, kc, rp, rb0, rb1);
-            rw = fetch_w_tile<NRW, BN>(Wb, d.K, n0, r0, (kt + 1) * 64 + kc * 8);
+            ra = gather(e1);
+            rw = fetch_w(kt + 1);
+            e1 = d.ktab[min((kt + 2) * 8 + kc, (d.K >> 3) - 1)];
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -462,7 +504,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d,
             const int rr = wm * WROWS + row;
             const int tl = rr / JB, jl = rr - tl * JB;
             RowPos r;
-            r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
+            r.b = b; r.t = t0 + tl; r.j = j0 + jl; r.jf = r.j * d.fmul; r.valid = r.t < d.TT;
             uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + c8 * 8]);
             if (r.valid) {
                 const size_t off = dst_row_offset(dd, r, d.fmul) + c8 * 8;
@@ -479,7 +521,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const sehip_gemm_desc d,
         const int rr = wm * (BM / WM) + mi * 16 + (lane & 15);
         const int tl = rr / JB, jl = rr - tl * JB;
         RowPos r;
-        r.b = b; r.t = t0 + tl; r.jf = (j0 + jl) * d.fmul; r.valid = r.t < d.TT;
+        r.b = b; r.t = t0 + tl; r.j = j0 + jl; r.jf = r.j * d.fmul; r.valid = r.t < d.TT;
         if (!r.valid) continue;
         const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
         const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
@@ -587,7 +629,7 @@ __device__ __forceinline__ Cs2Side<TN, MI> cs2_side_init(const sehip_gemm_desc& 
         const int r = 16 * MI * w + mi * 16 + (lane & 15);
         const int tl = r / JB, jl = r - tl * JB;
         RowPos rp;
-        rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+        rp.b = 0; rp.t = tl; rp.j = jl; rp.jf = jl * d.fmul; rp.valid = true;
         sd.e_off0[mi] = (int)dst_row_offset(d.dst[0], rp, d.fmul);
         sd.e_off1[mi] = d.dst[1].ptr ? (int)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
     }
@@ -614,7 +656,7 @@ __device__ __forceinline__ Cs2Side<TN, MI> cs2_side_init(const sehip_gemm_desc& 
             const int r = 16 * MI * w + row;
             const int tl = r / JB, jl = r - tl * JB;
             RowPos rp;
-            rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+            rp.b = 0; rp.t = tl; rp.j = jl; rp.jf = jl * d.fmul; rp.valid = true;
             sd.o_off[it] = (int)dst_row_offset(dd, rp, d.fmul) + first.coff + c8 * 8;
             sd.o_tl[it] = tl;
         }
@@ -1023,7 +1065,7 @@ __device__ __forceinline__ void wgrad_body(const sehip_gemm_desc& d, const int b
             const bool valid = mb + r0 + RPP * i < m_end;
             if (a_narrow) {    // 2-channel source: the generic gather (4 rows x (re, im) per chunk)
                 RowPos rp;
-                rp.valid = valid; rp.b = r.b; rp.t = r.t; rp.jf = r.j * d.fmul; rp.ts = r.t * a_tm;
+                rp.valid = valid; rp.b = r.b; rp.t = r.t; rp.j = r.j; rp.jf = r.j * d.fmul; rp.ts = r.t * a_tm;
                 xa[i] = gather_chunk(d.src[0], d.src[1], e, rp, row_base(d.src[0], rp), row_base(d.src[1], rp));
             } else {
                 const int ts = r.t * a_tm + a_toff, f = r.j * d.fmul + a_fadd;
@@ -1232,7 +1274,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const sehip_gemm_desc 
         abase[mi] = (tl + d.cv_toff[0][kt] - tmin) * FRA + jl * d.fmul + 4 * hf + (d.cv_fadd - fa);
         e_tl[mi] = tl;
         RowPos rp;
-        rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+        rp.b = 0; rp.t = tl; rp.j = jl; rp.jf = jl * d.fmul; rp.valid = true;
         e_off0[mi] = (int)dst_row_offset(d.dst[0], rp, d.fmul);
         e_off1[mi] = d.dst[1].ptr ? (int)dst_row_offset(d.dst[1], rp, d.fmul) : 0;
     }
@@ -1523,7 +1565,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
         if (c0.nvalid == 4 && c1.nvalid == 4 && c1.dst == c0.dst && c1.coff == c0.coff + 4) {
             const sehip_dst& dd = c0.dst ? d.dst[1] : d.dst[0];
             RowPos rp;
-            rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+            rp.b = 0; rp.t = tl; rp.j = jl; rp.jf = jl * d.fmul; rp.valid = true;
             g_ptr[u] = reinterpret_cast<const bf16_raw*>(dd.ptr) + dst_row_offset(dd, rp, d.fmul) + c0.coff;
             g_tstride[u] = dd.F * dd.C;
             g_bstride[u] = (long)dd.T * dd.F * dd.C;
@@ -1787,7 +1829,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
             const int r = idx / GCH, gc = idx - r * GCH;
             const int tl = r / JB, jl = r - tl * JB;
             RowPos rp;
-            rp.b = 0; rp.t = tl; rp.jf = jl * d.fmul; rp.valid = true;
+            rp.b = 0; rp.t = tl; rp.j = jl; rp.jf = jl * d.fmul; rp.valid = true;
             const sehip_nchunk c0 = d.ntab[(gc * 8) >> 2], c1 = d.ntab[((gc * 8) >> 2) + 1];
             g_ptr[u] = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr) + dst_row_offset(d.dst[0], rp, d.fmul) + c0.coff;
             g_tl[u] = tl; g_lds[u] = r * GP + gc * 8;
