@@ -181,8 +181,12 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
     constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
     constexpr int NRA = BM / 32;
     constexpr int NRW = (BN + 31) / 32;
-    __shared__ uint4 sW[BN * 8];
-    __shared__ uint4 sA[BM * 8];
+    // one LDS block: the two operand tiles during the K loop, the waves' bf16 output images afterwards (dense epilogue)
+    constexpr int WR = BM / WM, WC = BN / WN, TP = WC + 8;
+    constexpr int OPER_U4 = (BN + BM) * 8, IMG_U4 = (4 * WR * TP * 2 + 15) / 16;
+    __shared__ uint4 sbuf[OPER_U4 > IMG_U4 ? OPER_U4 : IMG_U4];
+    uint4* sW = sbuf;
+    uint4* sA = sbuf + BN * 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
@@ -197,13 +201,25 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
     const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
 
     const int kc = tid & 7, r0 = tid >> 3;
+    // rows r0 + 32 i of the tile: ONE decomposition into (utterance, frame, row), the others by stepping 32 rows with carries
+    // (a generic division is ~17 vector instructions; products with a short K spend their time in this prologue / the epilogue)
     RowPos rp[NRA];
     long rb0[NRA], rb1[NRA];
+    {
+        const int tm = src_tmul(d);
+        RowPos cur = row_pos(m0 + r0, d.M, d.TT, d.J, d.fmul, tm);
+        const int st = 32 / d.J, sj = 32 - st * d.J;
 #pragma unroll
-    for (int i = 0; i < NRA; ++i) {
-        rp[i] = row_pos(m0 + r0 + 32 * i, d.M, d.TT, d.J, d.fmul, src_tmul(d));
-        rb0[i] = row_base(d.src[0], rp[i]);
-        rb1[i] = row_base(d.src[1], rp[i]);
+        for (int i = 0; i < NRA; ++i) {
+            rp[i] = cur;
+            rp[i].valid = m0 + r0 + 32 * i < d.M;
+            rb0[i] = row_base(d.src[0], rp[i]);
+            rb1[i] = row_base(d.src[1], rp[i]);
+            cur.j += sj; cur.t += st;
+            if (cur.j >= d.J) { cur.j -= d.J; ++cur.t; }
+            for (; cur.t >= d.TT; cur.t -= d.TT) ++cur.b;
+            cur.jf = cur.j * d.fmul; cur.ts = cur.t * tm;
+        }
     }
 
     const int nk = d.K >> 6;
@@ -296,7 +312,68 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
         __syncthreads();
     }
 
-    // epilogue: lane holds n = nb + 4*(lane>>4) + {0..3}, m = mb + (lane&15)
+    // epilogue: lane holds n = nb + 4*(lane>>4) + {0..3}, m = mb + (lane&15).
+    // Dense case (the wave's WC columns are one contiguous run of a bf16 destination): the tile leaves through a wave-private
+    // LDS image as 16-byte pieces, a row's WC columns in consecutive lanes, rows stepped with carries -- instead of 8-byte
+    // pieces scattered over 16 rows per store instruction and two divisions per row.
+    {
+        const int nw0 = n0 + wn * WC;
+        const sehip_nchunk first = d.ntab[nw0 >> 2];
+        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + (lane % (WC / 4))];
+        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * (lane % (WC / 4));
+        const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
+        const bool dense = WC >= 8 && __all(ok) && !dd.is_f32 && (first.coff & 7) == 0 && (dd.C & 7) == 0;
+        if (dense) {
+            if (d.res && first.dst == 0) {
+                // residual: added to the fp32 accumulators BEFORE the one rounding to bf16 (the residual stream of ConvTasNet
+                // passes 14 of these in a row); rows mi*16 + (lane & 15) of the wave, stepped 16 at a time
+                RowPos cur = row_pos(m0 + wm * WR + (lane & 15), d.M, d.TT, d.J, d.fmul);
+                const int st = 16 / d.J, sj = 16 - st * d.J;
+                const bf16_raw* rp0 = reinterpret_cast<const bf16_raw*>(d.res) + first.coff + 4 * (lane >> 4);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    if (m0 + wm * WR + mi * 16 + (lane & 15) < d.M) {
+                        const size_t off = dst_row_offset(dd, cur, d.fmul);
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni) add_res4(acc[ni][mi], rp0, off + ni * 16);
+                    }
+                    cur.j += sj; cur.t += st;
+                    if (cur.j >= d.J) { cur.j -= d.J; ++cur.t; }
+                    for (; cur.t >= d.TT; cur.t -= d.TT) ++cur.b;
+                }
+            }
+            bf16_raw* img = reinterpret_cast<bf16_raw*>(sbuf) + wave * (WR * TP);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4));
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const f32x4 v = acc[ni][mi];
+                    *reinterpret_cast<uint2*>(&img[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * (lane >> 4)]) =
+                        make_uint2(pack_bf2(v[0] + bv.x, v[1] + bv.y), pack_bf2(v[2] + bv.z, v[3] + bv.w));
+                }
+            }
+            constexpr int PPR = WC / 8, RPI = 64 / PPR;      // 16-byte pieces per row, rows per pass of the wave
+            const int c8 = lane % PPR, rl = lane / PPR;
+            bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff + c8 * 8;
+            const int mrow0 = m0 + wm * WR + rl;
+            RowPos cur = row_pos(mrow0, d.M, d.TT, d.J, d.fmul);
+            const int st = RPI / d.J, sj = RPI - st * d.J;
+#pragma unroll
+            for (int it = 0; it < (WR + RPI - 1) / RPI; ++it) {
+                const int row = rl + RPI * it;
+                if (row < WR && mrow0 + RPI * it < d.M) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&img[row * TP + c8 * 8]);
+                    *reinterpret_cast<uint4*>(dptr + dst_row_offset(dd, cur, d.fmul)) = v;
+                }
+                cur.j += sj; cur.t += st;
+                if (cur.j >= d.J) { cur.j -= d.J; ++cur.t; }
+                for (; cur.t >= d.TT; cur.t -= d.TT) ++cur.b;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + wm * (BM / WM) + mi * 16 + (lane & 15);
