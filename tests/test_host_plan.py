@@ -211,3 +211,36 @@ def test_module_schema_and_optimizer_state_on_cpu():
         m2(torch.zeros(1, 1, 1200))  # CPU tensor: the HIP path has no fallback
     with pytest.raises(SehipError):
         distrib.get_model(utils.dict2obj({"name": "dcunet"}))
+
+
+def test_fused_statistics_column_tiles():
+    """The forward products that also accumulate the ComplexBatchNorm sums (sehip_gemm_desc.stats): every 128-column tile
+    must hold [64 re | 64 im] of the same 64 complex channels, and the re-ordered product is still the reference's conv."""
+    from sehip import plan
+    kw = dict(kernel_num=[16, 32, 64, 128, 256, 256], rnn_units=128, length=1200)
+    st = plan.DCCRNStatic(plan.DCCRNConfig(**kw))
+    assert st.fused_stats == {"encoder.3.", "encoder.4.", "encoder.5.", "decoder.0.", "decoder.1."}
+    for name, co in (("enc3.fwd", 128), ("enc4.fwd", 256), ("enc5.fwd", 256), ("dec0.fwd0", 256), ("dec0.fwd1", 256), ("dec1.fwd1", 128)):
+        sp = st.specs[name]
+        assert sp.stats_of is not None and sp.N == co
+        cr = co // 2
+        chan = np.concatenate([sp.ntab[q, 1] + np.arange(4) for q in range(co // 4)])   # destination channel of every column
+        for t in range(co // 128):
+            tile = chan[128 * t:128 * t + 128]
+            assert (tile[:64] == 64 * t + np.arange(64)).all() and (tile[64:] == cr + 64 * t + np.arange(64)).all(), (name, t)
+    # numerics of a permuted product (enc4: 128 -> 256 channels) through the table interpreter
+    p = O.init_params(O.DCCRNConfig(**kw), seed=3)
+    flat = np.zeros(st.layout.n_params, dtype=np.float64)
+    for nm in st.layout.param_names:
+        off, _ = st.layout.param_off[nm]
+        flat[off:off + p[nm].numel()] = p[nm].reshape(-1).double().numpy()
+    g = torch.Generator().manual_seed(4)
+    B, T, i = 1, 3, 4
+    ci, co, fi = 128, 256, 256 >> i
+    x = torch.randn(B, ci, fi, T, generator=g)
+    pre = f"encoder.{i}."
+    ref = O.complex_conv2d(x, p[pre + "0.real_conv.weight"], p[pre + "0.real_conv.bias"], p[pre + "0.imag_conv.weight"],
+                           p[pre + "0.imag_conv.bias"])
+    res = run_spec(st, flat, st.specs["enc4.fwd"], {"z3": cl(x)}, T, B)
+    got = scatter(res, "y4", (B, T, fi // 2, co))
+    assert np.abs(got - cl(ref)).max() < 1e-4
