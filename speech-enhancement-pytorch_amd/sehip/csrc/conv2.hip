@@ -237,24 +237,30 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_gemm_v2_kernel(const sehip_
                 if (j + 2 < H) issue_w(ch, j + 2, slot2); else issue_w(ch + 1, j + 2 - H, slot2);
             }
             const unsigned char* wslot = smem + slot * C2_WSLOT;
+            // All 16 fragment reads of the step are issued first, then the 32 MFMAs (scheduling groups: left alone the compiler
+            // interleaved pairs of reads with short MFMA runs and a full `s_waitcnt lgkmcnt(0)` each time -- six exposed LDS
+            // latencies per K step).  The LDS returns in order, so the waits in front of the MFMAs are counted ones.
+            bf16x8 wf[2][TN], af[2][TM];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                constexpr int dummy = 0; (void)dummy;
                 const int it = 2 * j + ks;
                 const int kt = it / NF, tap = it - kt * NF;
-                bf16x8 wf[TN], af[TM];
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wslot + wrd[ks] + ni * (16 * 128)));
+                    wf[ks][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wslot + wrd[ks] + ni * (16 * 128)));
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
-                    af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[afr[kt][mi] + tap * PP]));
+                    af[ks][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&patch[afr[kt][mi] + tap * PP]));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-            }
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[ks][mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TN + TM), 0);   // DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN * TM, 0);     // MFMAs
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
