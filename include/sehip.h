@@ -60,6 +60,9 @@ int sehip_istft_custom_fwd(const float* spec, int rows, int n_frames, int n_fft,
 
 /* ---- SI-SNR loss: src/loss.py:14-29 (si_snr, loss_sisdr).  rowstat is [rows][4] fp32 scratch kept for bwd. */
 int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* rowstat, float* loss, void* stream);
+/* SI-SDR validation metric of src/metric.py:92-123 (SI_SDR) on device rows [rows][n]: out[0] = 10 log10(mean ratio + eps);
+ * ratios[rows] is scratch */
+int sehip_sisdr_metric(const float* reference, const float* estimation, int rows, int n, float* ratios, float* out, void* stream);
 int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, const float* upstream /*scalar or NULL*/,
                     int rows, int n, float* dest, void* stream);
 

@@ -36,6 +36,7 @@ _PROTOS = {
     "sehip_stft_custom_fwd": [P, I, I, I, I, I, I, P, P],
     "sehip_istft_custom_fwd": [P, I, I, I, I, I, I, I, P, P, P],
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
+    "sehip_sisdr_metric": [P, P, I, I, P, P, P],
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
     "sehip_pointwise_loss_fwd": [P, P, L, I, P, P, P],
     "sehip_pointwise_loss_bwd": [P, P, L, I, P, P, P],

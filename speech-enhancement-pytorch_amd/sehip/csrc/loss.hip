@@ -87,6 +87,48 @@ __global__ __launch_bounds__(256) void sisnr_bwd_kernel(const float* __restrict_
         dest[base + i] = a * est[base + i] + b * ref[base + i];
 }
 
+// SI-SDR validation metric (src/metric.py:92-123, SI_SDR): per row alpha = <e,r> / (<r,r> + eps), ratio = |alpha r|^2 /
+// (|e - alpha r|^2 + eps); result 10 log10(mean_rows(ratio) + eps) with eps = float32 machine epsilon (np.finfo of the
+// reference's float32 arrays).  Same two-pass row kernel as the loss; ratios[rows] is scratch.
+#define SDR_EPS 1.1920929e-07f
+__global__ __launch_bounds__(256) void sisdr_metric_kernel(const float* __restrict__ ref, const float* __restrict__ est, int n,
+                                                           float* __restrict__ ratios) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const float* s = ref + (size_t)r * n;
+    const float* x = est + (size_t)r * n;
+    float xs = 0.f, ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { xs += x[i] * s[i]; ss += s[i] * s[i]; }
+    xs = block_sum<4>(xs, red);
+    ss = block_sum<4>(ss, red);
+    const float alpha = xs / (ss + SDR_EPS);
+    float et = 0.f, en = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float t = alpha * s[i], e = x[i] - t;
+        et += t * t; en += e * e;
+    }
+    et = block_sum<4>(et, red);
+    en = block_sum<4>(en, red);
+    if (threadIdx.x == 0) ratios[r] = et / (en + SDR_EPS);
+}
+
+__global__ void sisdr_metric_finalize_kernel(const float* __restrict__ ratios, int rows, float* __restrict__ out) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 64) acc += ratios[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[0] = 10.f * log10f(acc / rows + SDR_EPS);
+}
+
+extern "C" int sehip_sisdr_metric(const float* reference, const float* estimation, int rows, int n, float* ratios, float* out,
+                                  void* stream) {
+    SEHIP_REQUIRE(rows > 0 && n > 0, "sisdr_metric: empty input (rows=%d n=%d)", rows, n);
+    hipStream_t st = (hipStream_t)stream;
+    sisdr_metric_kernel<<<rows, 256, 0, st>>>(reference, estimation, n, ratios);
+    sisdr_metric_finalize_kernel<<<1, 64, 0, st>>>(ratios, rows, out);
+    SEHIP_CHECK_LAUNCH("sisdr_metric");
+    return 0;
+}
+
 extern "C" int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* rowstat, float* loss,
                                void* stream) {
     SEHIP_REQUIRE(rows > 0 && n > 0, "sisnr_fwd: empty input (rows=%d n=%d)", rows, n);

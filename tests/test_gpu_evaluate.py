@@ -61,3 +61,29 @@ def test_evaluate_with_the_hip_dccrn():
     want = torch.cat([segs[0]] + [s[..., -512:] for s in segs[1:]], -1)[..., :x.shape[-1]]
     want = want * (x.std(-1, keepdim=True).cuda() + 1e-9) + x.mean(-1, keepdim=True).cuda()
     assert rel_err(y.cpu(), want.cpu()) < 1e-5
+
+
+def test_si_sdr_metric_on_device():
+    """sehip.metric.SI_SDR against the formula of src/metric.py:92-123 restated in numpy float32 (the reference module itself
+    cannot be imported here: it needs pesq / pystoi / museval at import time, so this metric's parity is restatement-only)."""
+    import numpy as np
+    from sehip.metric import SI_SDR
+
+    def ref_si_sdr(reference, estimation):
+        eps = np.finfo(np.float32).eps
+        energy = np.sum(reference ** 2, axis=-1, keepdims=True)
+        scale = np.sum(estimation * reference, axis=-1, keepdims=True) / (energy + eps)
+        proj = scale * reference
+        noise = estimation - proj
+        ratio = np.mean(np.sum(proj ** 2, axis=-1) / (np.sum(noise ** 2, axis=-1) + eps))
+        return 10 * np.log10(ratio + eps)
+
+    g = torch.Generator().manual_seed(5)
+    for shape in ((3, 1, 16000), (2, 2, 1, 4001), (1, 8)):
+        clean = torch.randn(shape, generator=g)
+        est = clean + 0.3 * torch.randn(shape, generator=g)
+        got = float(SI_SDR(clean.cuda(), est.cuda()))
+        want = float(ref_si_sdr(clean.numpy(), est.numpy()))
+        assert abs(got - want) < 2e-3, (shape, got, want)
+    z = torch.zeros(2, 100)
+    assert abs(float(SI_SDR(z.cuda(), z.cuda())) - float(ref_si_sdr(z.numpy(), z.numpy()))) < 1e-3   # silent rows: log10(eps)
