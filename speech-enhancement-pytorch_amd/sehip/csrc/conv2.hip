@@ -484,7 +484,7 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st) {
     if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
     if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return 0;   // see sehip.h
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
-    if ((C0 & 63) || (C1 & 63) || (d.Npad & 127) || d.J > 64 || (128 % d.J)) return 0;
+    if ((C0 & 31) || (C1 & 31) || (d.Npad & 127) || d.J > 64 || (128 % d.J)) return 0;   // (32-channel patch chunks, 128-column tiles)
     if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
     if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return 0;
     for (int s = 0; s < 2; ++s) {
