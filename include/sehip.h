@@ -159,6 +159,10 @@ typedef struct {
      * destination, and is honoured by the LDS-DMA convolution kernel only: sehip_gemm fails loudly when it cannot honour it. */
     float* stats;
     int32_t stats_cr;
+    /* Optional second convolution description (weight gradients only; the parity classes of DCUnet's transposed convolutions,
+     * src/model/dcunet.py:341-371): stride 1 in both directions, K ordered (time tap, row tap, source, channel), time taps at
+     * source frames t + cv2_t0 + 0..cv2_nkt-1 (both sources), row taps at rows j + cv2_fadd + 0..cv2_nf-1.  cv2_nkt == 0: absent. */
+    int32_t cv2_nkt, cv2_nf, cv2_fadd, cv2_t0;
     int32_t pad2_;
 } sehip_gemm_desc;
 

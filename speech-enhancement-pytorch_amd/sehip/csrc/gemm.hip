@@ -1770,6 +1770,234 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
 #undef CW_CASE
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad2_kernel: the same idea for the second convolution description (cv2_*: NKT consecutive time taps x NF consecutive
+// row taps, stride 1 -- the output-parity classes of DCUnet's transposed convolutions, 6-12 taps over 128-192 input
+// channels at up to 129 x 129 positions per clip).  The table-gathered wgrad_kernel re-reads dOut once per 64 k-columns
+// (36 times for 12 taps x 192 channels) and gathers every input element once per tap from L2: 14.7 GB of L2 traffic for
+// one class of the last decoder.  Here a workgroup owns 64 output channels x ONE 64-channel input chunk x ALL taps and walks
+// over tiles of TB whole frames (TB*J <= 32 NKS rows, padded to a multiple of 32; J = 129 takes NKS = 5): the dOut tile and
+// the input patch ((TB + NKT - 1) frames x (J + NF - 1) rows) are staged in LDS once per tile and every tap reuses them.
+// Waves as in conv_wgrad_kernel: wave w accumulates dW[32 n][taps][16 channels] in registers (2 x NIT MFMA tiles).
+// ------------------------------------------------------------------------------------------------
+#define CW2_NPS 9   // patch pieces per thread (16 bytes each, 512 threads)
+template <int NKT, int NF, int NKS>
+__global__ __launch_bounds__(512) void conv_wgrad2_kernel(const sehip_gemm_desc d, int TB, int FR, int tiles_per_wg, int nsplit) {
+    constexpr int NIT = NKT * NF;
+    constexpr int TR = 32 * NKS;         // rows of a tile incl. the padding rows behind TB*J
+    constexpr int GP = 80, PPW = 80;     // pitches (bf16 elements): 160 B, 8 consecutive rows on 8 disjoint 32-byte bank slots
+    constexpr int GPT = (TR * 8 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_raw* sG = reinterpret_cast<bf16_raw*>(smem);  // [TR][GP]
+    bf16_raw* patch = sG + TR * GP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = wv & 3, nh = wv >> 2;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int Ctot = C0 + C1;
+    const int ntn = d.Npad >> 6;
+    const int gx = ntn * (Ctot >> 6);
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    int xi, split;
+    if (nsplit >= 8) { xi = rr % gx; split = (rr / gx) * 8 + xcd; }
+    else { split = xcd % nsplit; xi = (xcd / nsplit) * (gx * nsplit >> 3) + rr; }
+    const int nt = xi % ntn, cc = xi / ntn;
+    const int n0 = nt * 64;
+    const int J = d.J, rows_valid = TB * J;
+    const int tblocks = (d.TT + TB - 1) / TB;
+    const int B = d.M / (d.TT * J);
+    const int MT = B * tblocks;
+    const int mt_begin = split * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+
+    const bool second = cc * 64 >= C0;
+    const int sT = second ? d.src[1].T : d.src[0].T, sF = second ? d.src[1].F : d.src[0].F, sC = second ? C1 : C0;
+    const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
+    const bf16_raw* sbase = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) + (cc * 64 - (second ? C0 : 0));
+    const int tfirst = d.cv2_t0, f0 = d.cv2_fadd;
+    const int NPF = TB + NKT - 1;
+    const int NP = NPF * FR * 8;
+
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = 4 * (i16 & 3);
+    int pbase[NKS][2], gbase[NKS][2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ks * 32 + 16 * h + 4 * g + q;          // (see conv_wgrad_kernel: 8 consecutive rows per 32-lane half)
+            const int mc = m < rows_valid ? m : 0;               // padding rows carry dOut == 0: any valid patch row will do
+            const int tl = mc / J, jl = mc - tl * J;
+            pbase[ks][h] = (tl * FR + jl) * PPW + 16 * w + p4;
+            gbase[ks][h] = m * GP + p4 + 32 * nh;
+        }
+
+    f32x4 acc[2][NIT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = d.dbias != nullptr && cc == 0 && w == 0;
+    f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+
+    int p_goff[CW2_NPS], p_lds[CW2_NPS];  // element offset from the tile's first patch frame (or INT_MIN), LDS slot | frame << 16 (or -1)
+#pragma unroll
+    for (int i = 0; i < CW2_NPS; ++i) {
+        const int idx = tid + 512 * i;
+        p_goff[i] = INT_MIN; p_lds[i] = -1;
+        if (idx < NP) {
+            const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
+            const int f = f0 + (rem >> 3);
+            p_lds[i] = ((pp * FR + (rem >> 3)) * PPW + (rem & 7) * 8) | (pp << 16);
+            if (f >= 0 && f < sF) p_goff[i] = (pp * sF + f) * sC + (rem & 7) * 8;
+        }
+    }
+    const bf16_raw* g_ptr[GPT];
+    int g_tl[GPT];
+    long g_bstride = 0;
+    int g_tstride = 0;
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        const int idx = tid + 512 * u;
+        const int r = idx >> 3, gc = idx & 7;
+        g_ptr[u] = nullptr; g_tl[u] = 0;
+        if (r < rows_valid) {
+            const int tl = r / J, jl = r - tl * J;
+            g_tl[u] = tl;
+            const int n = n0 + gc * 8;
+            const sehip_nchunk c0 = d.ntab[n >> 2], c1 = d.ntab[(n >> 2) + 1];
+            if (c0.nvalid == 4 && c1.nvalid == 4 && c1.dst == c0.dst && c1.coff == c0.coff + 4) {
+                const sehip_dst& dd = c0.dst ? d.dst[1] : d.dst[0];
+                RowPos rp;
+                rp.b = 0; rp.t = tl; rp.j = jl; rp.jf = jl * d.fmul; rp.valid = true;
+                g_ptr[u] = reinterpret_cast<const bf16_raw*>(dd.ptr) + dst_row_offset(dd, rp, d.fmul) + c0.coff;
+                g_tstride = dd.F * dd.C * (dd.tmul > 1 ? dd.tmul : 1);
+                g_bstride = (long)dd.T * dd.F * dd.C;
+            }
+        }
+    }
+
+    uint4 pr[CW2_NPS], gr[GPT];
+#define CW2_FETCH(mt_)                                                                                             \
+    {                                                                                                              \
+        const int b_ = (mt_) / tblocks, t0_ = ((mt_) - b_ * tblocks) * TB;                                         \
+        const bf16_raw* tb_ = sbase + ((long)b_ * sT + t0_ + tfirst) * sF * sC;                                    \
+        _Pragma("unroll") for (int i = 0; i < CW2_NPS; ++i) {                                                      \
+            pr[i] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            const int ts_ = t0_ + tfirst + (p_lds[i] >> 16);                                                       \
+            if (p_goff[i] != INT_MIN && ts_ >= tlo && ts_ < thi) pr[i] = *reinterpret_cast<const uint4*>(tb_ + p_goff[i]); \
+        }                                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < GPT; ++u) {                                                          \
+            gr[u] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            if (g_ptr[u] && t0_ + g_tl[u] < d.TT)                                                                  \
+                gr[u] = *reinterpret_cast<const uint4*>(g_ptr[u] + b_ * g_bstride + (long)t0_ * g_tstride);        \
+        }                                                                                                          \
+    }
+
+    if (mt_begin < mt_end) CW2_FETCH(mt_begin)
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+#pragma unroll
+        for (int i = 0; i < CW2_NPS; ++i)
+            if (p_lds[i] >= 0) *reinterpret_cast<uint4*>(&patch[p_lds[i] & 0xffff]) = pr[i];
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) {
+            const int idx = tid + 512 * u;
+            if (idx < TR * 8) *reinterpret_cast<uint4*>(&sG[(idx >> 3) * GP + (idx & 7) * 8]) = gr[u];
+        }
+        __syncthreads();
+        if (mt + 1 < mt_end) CW2_FETCH(mt + 1)   // in flight while this tile is consumed
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 gf[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][0] + ni * 16]);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[gbase[ks][1] + ni * 16]);
+                gf[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], BF16_ONES, accb[ni], 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int toff_e = ((it / NF) * FR + (it % NF)) * PPW;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][0] + toff_e]);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&patch[pbase[ks][1] + toff_e]);
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[ni][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ni], xf, acc[ni][it], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef CW2_FETCH
+
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = n0 + 32 * nh + ni * 16 + 4 * (lane >> 4);
+            const int k = it * Ctot + cc * 64 + 16 * w + (lane & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][it][u]);
+        }
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&d.dbias[n0 + 32 * nh + ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
+    }
+}
+
+static int try_conv_wgrad2(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_WGRAD2") != nullptr;
+    if (disabled || d.cv2_nkt <= 0) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.fmul != 1 || d.tmul > 1) return 0;
+    if (d.K != d.cv2_nkt * d.cv2_nf * (C0 + C1)) return 0;
+    if (d.src[1].ptr && (d.src[1].T != d.src[0].T || d.src[1].F != d.src[0].F)) return 0;      // one grid for both sources
+    const int J = d.J;
+    int TB;
+    if (J >= 128) TB = 1;
+    else if (128 % J == 0) TB = 128 / J;
+    else return 0;
+    const int rows = TB * J;
+    if (rows > 160) return 0;
+    const int NKS = (rows + 31) / 32;
+    const int FR = J + d.cv2_nf - 1;
+    const int NPF = TB + d.cv2_nkt - 1;
+    if (NPF * FR * 8 > CW2_NPS * 512 || NPF * FR * 80 > 65535) return 0;
+    for (int s = 0; s < 2; ++s)
+        if (d.src[s].ptr && (long)d.src[s].T * d.src[s].F * d.src[s].C * (NPF + 1) >= (1L << 31)) return 0;   // 32-bit piece offsets
+    const size_t lds = (size_t)NKS * 32 * 80 * 2 + (size_t)NPF * FR * 80 * 2;
+    if (lds > 160 * 1024) return 0;
+    const int B = d.M / (d.TT * d.J);
+    const int MT = B * ((d.TT + TB - 1) / TB);
+    const int gx = (d.Npad >> 6) * ((C0 + C1) >> 6);
+    // one resident workgroup per CU (512 threads, >100 KB of LDS): about one round of workgroups, splits a multiple of 8
+    int splits = (256 / gx) / 8 * 8;
+    if (splits < 8) splits = 8;
+    const int tiles_per_wg = (MT + splits - 1) / splits;
+    const int grid = gx * splits;
+#define CW2_CASE(NKT_, NF_, NKS_)                                                                                  \
+    if (d.cv2_nkt == NKT_ && d.cv2_nf == NF_ && NKS == NKS_) {                                                     \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<NKT_, NF_, NKS_>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        sehip_note_kernel("conv_wgrad2_kernel<%d, %d, %d>", NKT_, NF_, NKS_);                                      \
+        conv_wgrad2_kernel<NKT_, NF_, NKS_><<<grid, 512, lds, st>>>(d, TB, FR, tiles_per_wg, splits);              \
+        return 1;                                                                                                  \
+    }
+    CW2_CASE(4, 3, 5) CW2_CASE(3, 3, 5) CW2_CASE(4, 3, 4) CW2_CASE(3, 3, 4)
+    CW2_CASE(4, 2, 4) CW2_CASE(3, 2, 4) CW2_CASE(4, 2, 5) CW2_CASE(3, 2, 5)
+    CW2_CASE(2, 2, 4) CW2_CASE(2, 3, 4)
+#undef CW2_CASE
+    return 0;
+}
+
 // dOut pieces: mode 1 = eight dense channels, 2 = the two channels of a narrow layer as one dword, 3 = element by element
 template <int GPT>
 __device__ __forceinline__ RegTile<GPT> sw_fetch_dout(const sehip_gemm_desc& d, const bf16_raw* const (&g_ptr)[GPT], const int (&g_mode)[GPT],
@@ -2204,6 +2432,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     }
     if (try_conv_wgrad(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv)");
+        return 0;
+    }
+    if (try_conv_wgrad2(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(conv2)");
         return 0;
     }
     if (try_conv_small_wgrad(*d, st)) {

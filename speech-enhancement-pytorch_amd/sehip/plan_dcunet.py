@@ -285,6 +285,10 @@ class DCUNetPlan:
             group = []
             for pt, ttaps in tcls:
                 for pf, ftaps in fcls:
+                    # taps in ascending source offset: K is then ordered (time tap, row tap, source, channel) with consecutive
+                    # offsets, the regular stride-1 convolution the patch-based weight gradient (cv2_* of sehip_gemm_desc) takes
+                    ttaps = sorted(ttaps, key=lambda x: x[1])
+                    ftaps = sorted(ftaps, key=lambda x: x[1])
                     rows, cols_i, cols_n = [], [], []
                     for a, ta in ttaps:
                         for b, fb in ftaps:
@@ -300,6 +304,9 @@ class DCUNetPlan:
                                   eff_bias(pre + "tconv_re", pre + "tconv_im", cout_s, cout_r), TT, J, 1,
                                   [(s[0], "all") for s in srcs], [(f"yd{j}", pt, s_f, pf)])
                     sp.tmul, sp.dst_tmul = 1, [s_t]
+                    toffs, foffs = [x[1] for x in ttaps], [x[1] for x in ftaps]
+                    if toffs == list(range(toffs[0], toffs[0] + len(toffs))) and foffs == list(range(foffs[0], foffs[0] + len(foffs))):
+                        sp.conv2 = (len(toffs), len(foffs), foffs[0], toffs[0])      # (nkt, nf, fadd, t0)
                     self.specs[name] = sp
                     group.append(name)
             self.bias_group[f"dec{j}"] = group
@@ -515,6 +522,8 @@ class DCUNetWorkspace:
                 w.dbias = self.gpack.data_ptr() + 4 * s.db_off if s.db_off is not None else None
                 out_name = s.dsts[0][0]
                 w.dst[0].ptr = self.bufs["d" + out_name].ptr
+                if getattr(s, "conv2", None) is not None:
+                    w.cv2_nkt, w.cv2_nf, w.cv2_fadd, w.cv2_t0 = s.conv2
                 self.desc[name + ".wg"] = w
 
     # ---- launches ------------------------------------------------------------------------------------
