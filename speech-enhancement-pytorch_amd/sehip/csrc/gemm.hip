@@ -2278,7 +2278,7 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
                                                                       int frames_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int J = d.J, fmul = d.fmul;
+    const int J = d.J;
     const int gbytes = J * 16 * 2, xbytes = 2 * FRA * 2 * 2;
     unsigned char* wbase = smem + (size_t)w * (gbytes + xbytes);
     bf16_raw* sG = reinterpret_cast<bf16_raw*>(wbase);             // [J][16]
