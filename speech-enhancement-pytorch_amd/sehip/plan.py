@@ -738,7 +738,10 @@ class DCCRNWorkspace:
         # round).  Each recurrence keeps 8 workgroups busy for ~0.9 us per step, so two of them side by side cost nothing.
         # Measured at T = 321 (ms per step): whole sequence 6.19-6.25, chunks of 64: 6.12-6.17, of 108 (three chunks): 6.09.
         # Every chunk costs a kernel prologue, an event and two small products on the second stream, so few chunks win.
-        chunk = int(os.environ.get("SEHIP_LSTM_CHUNK", "-1"))
+        # Round 2: with 4-row batch tiles and an 8-step input prefetch a layer takes 131 / 183 us instead of 290, and the
+        # pipeline no longer pays for its extra launches, events and chunked products (T = 323, ms per step: whole sequence
+        # 4.61, three chunks 4.63, four 4.65, six 4.70): the default is the whole sequence, SEHIP_LSTM_CHUNK=<steps> re-enables it.
+        chunk = int(os.environ.get("SEHIP_LSTM_CHUNK", "0"))
         if chunk < 0:
             chunk = (T + 2) // 3 if T >= 96 else 0
         self.lstm_chunks = [(t, min(T, t + chunk)) for t in range(0, T, chunk)] if chunk > 0 else [(0, T)]
