@@ -108,6 +108,65 @@ def gemm_roofline(ws, reps=5):
     return rows
 
 
+def cbn_roofline(ws, model, reps=3):
+    """HBM roofline entry of the ComplexBatchNorm class (DCCRN): every streaming pass of every layer timed as ONE launch between
+    HIP events after the same 320 MB cache flush as the products.  Algorithmic bytes per pass = tensor bytes x (stats 1,
+    apply 2, backward reduce 2, backward apply 3); the per-channel finalize launches move kilobytes and are left out of the
+    byte count but not of the time."""
+    from sehip._lib import call, ptr, stream
+    flush = torch.empty(80 * 1024 * 1024, dtype=torch.float32, device=ws.device)
+    params = model._flat
+    L = ws.st.layout
+    cfg = ws.st.cfg
+    b = ws.bufs
+    layers = [(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, b[f"y{i}"], b[f"z{i}"], b[f"dye{i}"], b[f"dye{i}"], 0) for i in range(6)]
+    layers += [(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"yd{j}"], b[f"zd{j}"], b[f"dzd{j}"], b[f"dyd{j}"], 1) for j in range(5)]
+    # bracket overhead of two events around one launch (these passes take 10-35 us, the bracket costs several): an
+    # empty-sized fill timed the same way, minus the ~2 us such a kernel runs, is subtracted from every measurement
+    one = torch.zeros(64, device=ws.device)
+    empt = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        one.fill_(1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        empt.append(e0.elapsed_time(e1))
+    bracket_ms = max(0.0, sorted(empt)[len(empt) // 2] - 0.002)
+    tot_ms, tot_bytes, n = 0.0, 0.0, 0
+    for pre, cr, y, z, dz, dy, tfirst in layers:
+        rows = y.t.numel() // (2 * cr)
+        tbytes = y.t.numel() * 2
+        pp = lambda k: params.data_ptr() + 4 * L.param_off[pre + k][0]
+        coef = ws.bn_coef[pre]
+        passes = [
+            (lambda: call("sehip_cbn_stats", y.ptr, rows, cr, ptr(ws.bn_acc), stream()), 1),
+            (lambda: call("sehip_cbn_apply", y.ptr, ptr(coef), pp("2.weight"), rows, cr, z.ptr, stream()), 2),
+            (lambda: call("sehip_cbn_bwd_reduce", dz.ptr, None, y.ptr, ptr(coef), pp("2.weight"), rows, cr, y.F, y.Tst, tfirst,
+                          ptr(ws.bn_acc), stream()), 2),
+            (lambda: call("sehip_cbn_bwd_apply", dz.ptr, None, y.ptr, ptr(coef), ptr(ws.bn_bcoef), pp("2.weight"), rows, cr, y.F,
+                          y.Tst, tfirst, dy.ptr, stream()), 3),
+        ]
+        for fn, mult in passes:
+            if mult == 1 and pre in ws.st.fused_stats:
+                continue          # this layer's sums come out of the convolution's epilogue: no stats pass in the step
+            times = []
+            for _ in range(reps):
+                flush.fill_(1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1))
+            tot_ms += max(sorted(times)[len(times) // 2] - bracket_ms, 1e-3)
+            tot_bytes += mult * tbytes
+            n += 1
+    return {"bound": "hbm", "kernel": "cbn_stats / cbn_apply / cbn_bwd_reduce / cbn_bwd_apply (all layers)", "achieved": tot_bytes / tot_ms / 1e6,
+            "peak": 8000.0, "unit": "GB/s", "frac": tot_bytes / tot_ms / 1e6 / 8000.0, "traffic": None, "launches_per_step": n,
+            "ms_per_step": tot_ms, "algorithmic_bytes_per_step": tot_bytes, "event_bracket_us_subtracted": bracket_ms * 1e3}
+
+
 def _weight_entries(ws, name):
     specs = ws.pl.specs if hasattr(ws, "pl") else ws.st.specs
     s = specs[name[:-3] if name.endswith(".wg") else name]
@@ -367,6 +426,13 @@ def main():
                            "gflop_per_launch": top["gflop"] / top["launches"],
                            "all_product_kernels": {"ms_per_step": total_ms, "tflops": total_gf / total_ms,
                                                    "frac": total_gf / total_ms / PEAK_BF16_TFLOPS}}
+        if not dcu and not ctn:
+            out["roofline_hbm"] = cbn_roofline(ws, model)   # second entry: the largest HBM-bound class of the step
+            if os.path.exists(tpath):   # PMC bytes of the same passes over the real step (finalize launches excluded)
+                tj = json.load(open(tpath))
+                tb = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for k, v in tj.items()
+                         if k.startswith("cbn_") and "finalize" not in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v)
+                out["roofline_hbm"]["traffic"] = tb or None
         # algorithmic FLOPs per clip-step (SURVEY section 8d / BASELINE.md): DCCRN 45.96 GF, DCUnet-10 111.9 GF (fwd + bwd)
         out["step_tflops"] = (111.9e9 if dcu else 3 * 3.2e9 if ctn else 45.96e9) * args.batch / (ms * 1e-3) / 1e12
         out["kernel_classes"] = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["avg_us"], 1),
