@@ -1,5 +1,6 @@
 """CPU: pins oracle/dccrn_oracle.py against vectors produced by the imported reference
 (oracle/gen_golden.py).  Tolerances are fp32 round-off of two different op orders."""
+import math
 import numpy as np
 import pytest
 import torch
@@ -242,3 +243,57 @@ def test_convtasnet_oracle_matches_reference():
     for k, gr in zip(names, grads):
         ref = torch.from_numpy(g["grad." + k])
         assert float((gr - ref).norm()) <= 5e-4 * float(ref.norm()) + 1e-6, k
+
+
+DEMUCS_CASES = {
+    "a": dict(sources=["s0", "s1"], audio_channels=2, channels=4, depth=5, norm_starts=3, dconv_lstm=3, dconv_attn=3, resample=False),
+    "b": dict(sources=["s0"], audio_channels=1, channels=8, depth=3, dconv_lstm=1, dconv_attn=2, norm_starts=1, resample=False),
+}
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_demucs_oracle_matches_reference(tag):
+    """Demucs with resample=False against vectors of the imported reference: every encoder / decoder output, the
+    separated sources, the SI-SNR loss, every parameter gradient; case b runs the BLSTM on overlapping chunks (T > 200)."""
+    from oracle import demucs_oracle as DM
+    g = {k[2:]: v for k, v in load_golden("demucs_tiny.npz").items() if k.startswith(tag + ".")}
+    cfg = DM.DemucsConfig(**DEMUCS_CASES[tag])
+    p = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    shapes = DM.param_shapes(cfg)
+    assert [n for n, _ in shapes] == list(g["names"]), "parameters() order"
+    assert all(tuple(p[n].shape) == s for n, s in shapes)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    taps = {}
+    mix = torch.from_numpy(g["mix"])
+    est = DM.demucs_forward(leaves, mix, cfg, taps=taps)
+    assert len(taps) == 2 * cfg.depth
+    for k, v in taps.items():
+        assert rel_err(v.detach(), g["tap." + k]) < 2e-5, k
+    assert tuple(est.shape) == tuple(g["est"].shape) and rel_err(est.detach(), g["est"]) < 2e-5
+    loss = O.loss_sisdr(est, torch.from_numpy(g["target"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    names = sorted(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    assert len(names) == len([k for k in g if k.startswith("grad.")])
+    for k, gr in zip(names, grads):
+        ref = torch.from_numpy(g["grad." + k])
+        assert float((gr - ref).norm()) <= 1e-3 * float(ref.norm()) + 1e-6, k
+
+
+def test_demucs_resampler_properties():
+    """julius.resample_frac restated (parity UNPINNED: the package is absent, oracle/demucs_oracle.py): lengths, unit DC gain, a
+    band-limited sine survives x2 -> /2, and the x2 output interleaves the input samples with interpolated ones."""
+    from oracle import demucs_oracle as DM
+    x = torch.ones(1, 1, 300)
+    up = DM.resample_frac(x, 1, 2)
+    assert up.shape[-1] == 600 and float((up - 1).abs().max()) < 1e-5
+    assert DM.resample_frac(torch.ones(1, 1, 601), 2, 1).shape[-1] == 300
+    t = torch.arange(2000, dtype=torch.float32)
+    s = torch.sin(2 * math.pi * 0.05 * t)[None, None]
+    up = DM.resample_frac(s, 1, 2)
+    ref = torch.sin(2 * math.pi * 0.025 * torch.arange(4000, dtype=torch.float32))
+    assert float((up[0, 0, 100:-100] - ref[100:-100]).abs().max()) < 2e-3
+    back = DM.resample_frac(up, 2, 1)
+    assert back.shape == s.shape and float((back - s)[..., 100:-100].abs().max()) < 2e-3
+    k, width, _, _ = DM.resample_kernels(1, 2)
+    assert width == 26 and tuple(k.shape) == (2, 53) and float((k.sum(1) - 1).abs().max()) < 1e-6
