@@ -86,6 +86,18 @@ _PROTOS = {
     "sehip_ctn_gln_bwd_scratch_floats": [I, I, I],
     "sehip_ctn_decoder_fwd": [P, P, P, I, I, I, I, I, I, I, P, P],
     "sehip_ctn_decoder_bwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P],
+    "sehip_dmx_prep": [P, I, I, I, I, I, I, I, I, P, I, I, P, P, P],
+    "sehip_dmx_post": [P, P, I, I, I, L, I, I, I, P, I, I, P, P],
+    "sehip_dmx_post_bwd": [P, P, I, I, I, L, I, I, I, P, I, I, P, P],
+    "sehip_dmx_gn_stats": [P, I, I, I, I, P, P],
+    "sehip_dmx_act_fwd": [P, P, P, P, I, F, I, P, P, P, I, I, I, P, P],
+    "sehip_dmx_act_bwd": [P, P, P, P, P, I, F, I, P, I, I, I, P, P, P, P],
+    "sehip_dmx_add": [P, P, L, P, P],
+    "sehip_dmx_f32_to_bf16": [P, L, P, P],
+    "sehip_dmx_lstm_fwd": [P, P, I, I, I, P, P, P],
+    "sehip_dmx_lstm_bwd": [P, P, P, P, I, I, I, P, P, P],
+    "sehip_dmx_attn_fwd": [P, I, I, I, I, I, I, P, P],
+    "sehip_dmx_attn_bwd": [P, P, I, I, I, I, I, I, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],

@@ -1,0 +1,829 @@
+// Demucs (src/model/demucs.py:272-501), everything that is not a convolution / linear product (those are sehip_gemm products of the
+// implicit-GEMM engine over channels-last bf16 activations [B][T][C]):
+//   prep / post   normalise + pad + julius-style x2 up-sampling, and /2 down-sampling + de-normalise + center_trim (:453-470, :485-490)
+//   gn / act      GroupNorm (:176, :382) fused with GELU or GLU, LayerScale (:52-71) and the residual / skip additions (:204-207, :483)
+//   lstm          one time step of a bidirectional nn.LSTM layer (:83) per launch, both directions in the launch
+//   attn          LocalState (:210-269, nfreqs = 0): scores, distance penalty, softmax over the key axis, weighted content
+// Thread layout of the streaming kernels: a thread owns ONE piece of 8 output channels for all its frames (the launch's thread
+// count is a multiple of the number of pieces, so piece = global thread id % pieces), hence per-channel affine terms and the
+// per-channel gradient sums stay in registers.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct D8 { float v[8]; };
+__device__ __forceinline__ D8 ld8(const bf16_raw* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    D8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st8(bf16_raw* p, const float (&v)[8]) {
+    uint4 u;
+    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ void ld8f(const float* __restrict__ p, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[j];
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+// exact GELU (nn.GELU default, approximate='none') and its derivative
+__device__ __forceinline__ float gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// piece walk: piece index i = t * nq + q; this thread's q is fixed, t = t0, t0 + tstep, ...
+struct Walk { int q, t0, tstep; };
+__device__ __forceinline__ Walk walk(int nq) {
+    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    Walk w;
+    w.q = (int)(gi % nq);
+    w.t0 = (int)(gi / nq);
+    w.tstep = (int)(((long)gridDim.x * 256) / nq);
+    return w;
+}
+
+__device__ __forceinline__ void moments(const double* __restrict__ stats, int b, int G, int g, double n, float eps, float& mu, float& rs) {
+    const double s = stats[(b * G + g) * 2], q = stats[(b * G + g) * 2 + 1];
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0) var = 0;
+    mu = (float)m;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// prep / post
+// ---------------------------------------------------------------------------------------------------------------------------
+// ms[b] = (mean, std) of the mono mix over time (unbiased std, src/model/demucs.py:457-461); normalize == 0: (0, 1)
+__global__ __launch_bounds__(256) void dmx_moments_kernel(const float* __restrict__ mix, int ac, int T, int normalize, float* __restrict__ ms) {
+    const int b = blockIdx.x;
+    __shared__ double red[2][4];
+    double s = 0, q = 0;
+    if (normalize) {
+        for (int t = threadIdx.x; t < T; t += 256) {
+            float m = 0.f;
+            for (int a = 0; a < ac; ++a) m += mix[((long)b * ac + a) * T + t];
+            m /= (float)ac;
+            s += m; q += (double)m * m;
+        }
+    }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!normalize) { ms[2 * b] = 0.f; ms[2 * b + 1] = 1.f; return; }
+        s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mean = s / T;
+        double var = (q - s * mean) / (T > 1 ? T - 1 : 1);
+        if (var < 0) var = 0;
+        ms[2 * b] = (float)mean;
+        ms[2 * b + 1] = (float)sqrt(var);
+    }
+}
+
+// x[b][u][c] (bf16, acp channels, channels >= ac are zero).  up == 0: u indexes the padded signal; up == 1: u = 2 n + i and
+// x = sum_j kup[i][j] xin(clamp(n + j - width)), xin = the normalised, zero-padded signal of Tv samples (replicate at the ends)
+__global__ __launch_bounds__(256) void dmx_prep_kernel(const float* __restrict__ mix, const float* __restrict__ ms, const float* __restrict__ kup,
+                                                       int ac, int acp, int T, int padl, int Tv, int up, int width, int KL,
+                                                       bf16_raw* __restrict__ x) {
+    const int b = blockIdx.y;
+    const long T0 = up ? 2L * Tv : Tv;
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= T0) return;
+    const float mean = ms[2 * b], inv = 1.f / (1e-5f + ms[2 * b + 1]);
+    for (int c = 0; c < acp; ++c) {
+        float v = 0.f;
+        if (c < ac) {
+            const float* src = mix + ((long)b * ac + c) * T;
+            if (!up) {
+                const long p = u - padl;
+                v = (p >= 0 && p < T) ? (src[p] - mean) * inv : 0.f;
+            } else {
+                const long n = u >> 1;
+                const float* k = kup + (u & 1) * KL;
+                for (int j = 0; j < KL; ++j) {
+                    long p = n + j - width;
+                    p = p < 0 ? 0 : (p >= Tv ? Tv - 1 : p);
+                    p -= padl;
+                    if (p >= 0 && p < T) v += k[j] * (src[p] - mean) * inv;
+                }
+            }
+        }
+        x[((long)b * T0 + u) * acp + c] = f2bf(v);
+    }
+}
+
+// out[b][c][n] = z(n + padl) * std + mean, z = y (down == 0) or y down-sampled by 2: z[m] = sum_j kdn[j] y(clamp(2 m + j - width))
+__global__ __launch_bounds__(256) void dmx_post_kernel(const float* __restrict__ y /*[B][Tf][cop]*/, const float* __restrict__ ms,
+                                                       const float* __restrict__ kdn, int co, int cop, long Tf, int padl, int T, int down,
+                                                       int width, int KL, float* __restrict__ out /*[B][co][T]*/) {
+    const int b = blockIdx.y;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= T) return;
+    const float mean = ms[2 * b], sd = ms[2 * b + 1];
+    const float* yb = y + (long)b * Tf * cop;
+    const long m = n + padl;
+    for (int c = 0; c < co; ++c) {
+        float v = 0.f;
+        if (!down) {
+            v = yb[m * cop + c];
+        } else {
+            for (int j = 0; j < KL; ++j) {
+                long p = 2 * m + j - width;
+                p = p < 0 ? 0 : (p >= Tf ? Tf - 1 : p);
+                v += kdn[j] * yb[p * cop + c];
+            }
+        }
+        out[((long)b * co + c) * T + n] = v * sd + mean;
+    }
+}
+
+// dy[b][u][c] (bf16, cop channels) = std * sum over the output samples the position fed
+__global__ __launch_bounds__(256) void dmx_post_bwd_kernel(const float* __restrict__ dout /*[B][co][T]*/, const float* __restrict__ ms,
+                                                           const float* __restrict__ kdn, int co, int cop, long Tf, int padl, int T, int down,
+                                                           int width, int KL, bf16_raw* __restrict__ dy) {
+    const int b = blockIdx.y;
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= Tf) return;
+    const float sd = ms[2 * b + 1];
+    for (int c = 0; c < cop; ++c) {
+        float v = 0.f;
+        if (c < co) {
+            const float* d = dout + ((long)b * co + c) * T;
+            if (!down) {
+                const long n = u - padl;
+                if (n >= 0 && n < T) v = d[n];
+            } else {
+                // padded positions p with clamp(p) == u
+                long plo = u, phi = u;
+                if (u == 0) plo = -width;
+                if (u == Tf - 1) phi = Tf + width + 1;
+                for (long p = plo; p <= phi; ++p) {
+                    // j = p + width - 2 m in [0, KL)  <=>  m in [(p + width - KL + 1) / 2 (ceil), (p + width) / 2 (floor)]
+                    long mlo = p + width - KL + 1;
+                    mlo = mlo <= 0 ? 0 : (mlo + 1) / 2;
+                    long mhi = (p + width) / 2;
+                    if (mlo < padl) mlo = padl;
+                    if (mhi > padl + T - 1) mhi = padl + T - 1;
+                    for (long m = mlo; m <= mhi; ++m) v += kdn[p + width - 2 * m] * d[m - padl];
+                }
+            }
+        }
+        dy[((long)b * Tf + u) * cop + c] = f2bf(v * sd);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// GroupNorm + activation family.  mode 0: z = gelu(n(y)) over C channels; mode 1: z = n(y)[:C/2] * sigmoid(n(y)[C/2:]) (GLU).
+// Optional LayerScale + residual: z <- resid + scale[c] * z; optional addend: z <- z + add.  n = GroupNorm(G) or identity.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dmx_gn_stats_kernel(const bf16_raw* __restrict__ y, int T, int C, int G, double* __restrict__ stats) {
+    const int b = blockIdx.y, nq = C >> 3;
+    const Walk w = walk(nq);
+    const int g = (w.q * 8) / (C / G);
+    __shared__ float acc[16];
+    if (threadIdx.x < 16) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    const bf16_raw* base = y + (long)b * T * C + w.q * 8;
+    float s = 0.f, q = 0.f;
+    for (int t = w.t0; t < T; t += w.tstep) {
+        const D8 x = ld8(base + (long)t * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += x.v[j]; q += x.v[j] * x.v[j]; }
+    }
+    atomicAdd(&acc[2 * g], s);
+    atomicAdd(&acc[2 * g + 1], q);
+    __syncthreads();
+    if (threadIdx.x < 2 * G) atomicAdd(&stats[(long)b * G * 2 + threadIdx.x], (double)acc[threadIdx.x]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dmx_act_fwd_kernel(const bf16_raw* __restrict__ y, const double* __restrict__ stats,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int G, float eps,
+                                                          const float* __restrict__ scale, const bf16_raw* __restrict__ resid,
+                                                          const bf16_raw* __restrict__ add, int T, int C, bf16_raw* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int Co = MODE ? C >> 1 : C, nq = Co >> 3;
+    const Walk w = walk(nq);
+    const int c0 = w.q * 8, c1 = (C >> 1) + c0;
+    const bool norm = stats != nullptr;
+    float ga[8], ba[8], gg[8], bg[8], sc[8];
+    float mua = 0.f, rsa = 1.f, mug = 0.f, rsg = 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = gg[j] = 1.f; ba[j] = bg[j] = 0.f; sc[j] = 1.f; }
+    if (norm) {
+        const double n = (double)T * (C / G);
+        ld8f(gamma + c0, ga); ld8f(beta + c0, ba);
+        moments(stats, b, G, c0 / (C / G), n, eps, mua, rsa);
+        if (MODE) { ld8f(gamma + c1, gg); ld8f(beta + c1, bg); moments(stats, b, G, c1 / (C / G), n, eps, mug, rsg); }
+    }
+    if (scale) ld8f(scale + c0, sc);
+    const bf16_raw* yb = y + (long)b * T * C;
+    for (int t = w.t0; t < T; t += w.tstep) {
+        const D8 a = ld8(yb + (long)t * C + c0);
+        float v[8];
+        if (MODE) {
+            const D8 g = ld8(yb + (long)t * C + c1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ((a.v[j] - mua) * rsa * ga[j] + ba[j]) * sigm((g.v[j] - mug) * rsg * gg[j] + bg[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu((a.v[j] - mua) * rsa * ga[j] + ba[j]);
+        }
+        const long o = ((long)b * T + t) * Co + c0;
+        if (scale) {
+            const D8 r = ld8(resid + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r.v[j] + sc[j] * v[j];
+        }
+        if (add) {
+            const D8 r = ld8(add + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r.v[j];
+        }
+        st8(out + o, v);
+    }
+}
+
+// pass 1 of the backward (GroupNorm present): sums[b][g] += (sum dyh, sum dyh xh), gch += {dgamma [C] | dbeta [C] | dscale [Co]}
+template <int MODE>
+__global__ __launch_bounds__(256) void dmx_act_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
+                                                                 const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int G, float eps,
+                                                                 const float* __restrict__ scale, int T, int C, double* __restrict__ sums,
+                                                                 float* __restrict__ gch) {
+    extern __shared__ float lds[];   // [2 C + Co] per-channel partials of the block, then [16] group partials
+    const int b = blockIdx.y;
+    const int Co = MODE ? C >> 1 : C, nq = Co >> 3;
+    const int NV = 2 * C + Co;
+    for (int i = threadIdx.x; i < NV + 16; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    const Walk w = walk(nq);
+    const int c0 = w.q * 8, c1 = (C >> 1) + c0;
+    const int grp_a = c0 / (C / G), grp_g = c1 / (C / G);
+    float ga[8], ba[8], gg[8], bg[8], sc[8];
+    float mua, rsa, mug = 0.f, rsg = 1.f;
+    const double n = (double)T * (C / G);
+    ld8f(gamma + c0, ga); ld8f(beta + c0, ba);
+    moments(stats, b, G, grp_a, n, eps, mua, rsa);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gg[j] = 1.f; bg[j] = 0.f; sc[j] = 1.f; }
+    if (MODE) { ld8f(gamma + c1, gg); ld8f(beta + c1, bg); moments(stats, b, G, grp_g, n, eps, mug, rsg); }
+    if (scale) ld8f(scale + c0, sc);
+    float dga[8], dba[8], dgg[8], dbg[8], dsc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dga[j] = dba[j] = dgg[j] = dbg[j] = dsc[j] = 0.f;
+    float s1a = 0.f, s2a = 0.f, s1g = 0.f, s2g = 0.f;
+    const bf16_raw* yb = y + (long)b * T * C;
+    for (int t = w.t0; t < T; t += w.tstep) {
+        const D8 a = ld8(yb + (long)t * C + c0);
+        const D8 d = ld8(dz + ((long)b * T + t) * Co + c0);
+        if (MODE) {
+            const D8 g = ld8(yb + (long)t * C + c1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xa = (a.v[j] - mua) * rsa, xg = (g.v[j] - mug) * rsg;
+                const float na = xa * ga[j] + ba[j], sg = sigm(xg * gg[j] + bg[j]);
+                dsc[j] += d.v[j] * na * sg;
+                const float dv = d.v[j] * sc[j];
+                const float dna = dv * sg, dng = dv * na * sg * (1.f - sg);
+                dga[j] += dna * xa; dba[j] += dna; dgg[j] += dng * xg; dbg[j] += dng;
+                const float ha = dna * ga[j], hg = dng * gg[j];
+                s1a += ha; s2a += ha * xa; s1g += hg; s2g += hg * xg;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xa = (a.v[j] - mua) * rsa;
+                const float na = xa * ga[j] + ba[j];
+                dsc[j] += d.v[j] * gelu(na);
+                const float dna = d.v[j] * sc[j] * gelu_grad(na);
+                dga[j] += dna * xa; dba[j] += dna;
+                const float ha = dna * ga[j];
+                s1a += ha; s2a += ha * xa;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        atomicAdd(&lds[c0 + j], dga[j]);
+        atomicAdd(&lds[C + c0 + j], dba[j]);
+        if (MODE) { atomicAdd(&lds[c1 + j], dgg[j]); atomicAdd(&lds[C + c1 + j], dbg[j]); }
+        if (scale) atomicAdd(&lds[2 * C + c0 + j], dsc[j]);
+    }
+    atomicAdd(&lds[NV + 2 * grp_a], s1a);
+    atomicAdd(&lds[NV + 2 * grp_a + 1], s2a);
+    if (MODE) { atomicAdd(&lds[NV + 2 * grp_g], s1g); atomicAdd(&lds[NV + 2 * grp_g + 1], s2g); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256)
+        if (lds[i] != 0.f) atomicAdd(&gch[i], lds[i]);
+    if (threadIdx.x < 2 * G) atomicAdd(&sums[(long)b * G * 2 + threadIdx.x], (double)lds[NV + threadIdx.x]);
+}
+
+// pass 2: dy[b][t][C]
+template <int MODE>
+__global__ __launch_bounds__(256) void dmx_act_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
+                                                                const double* __restrict__ stats, const double* __restrict__ sums,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int G, float eps,
+                                                                const float* __restrict__ scale, int T, int C, bf16_raw* __restrict__ dy) {
+    const int b = blockIdx.y;
+    const int Co = MODE ? C >> 1 : C, nq = Co >> 3;
+    const Walk w = walk(nq);
+    const int c0 = w.q * 8, c1 = (C >> 1) + c0;
+    const bool norm = stats != nullptr;
+    float ga[8], ba[8], gg[8], bg[8], sc[8];
+    float mua = 0.f, rsa = 1.f, mug = 0.f, rsg = 1.f, k1a = 0.f, k2a = 0.f, k1g = 0.f, k2g = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = gg[j] = 1.f; ba[j] = bg[j] = 0.f; sc[j] = 1.f; }
+    if (norm) {
+        const double n = (double)T * (C / G);
+        const int grp_a = c0 / (C / G), grp_g = c1 / (C / G);
+        ld8f(gamma + c0, ga); ld8f(beta + c0, ba);
+        moments(stats, b, G, grp_a, n, eps, mua, rsa);
+        k1a = (float)(sums[((long)b * G + grp_a) * 2] / n); k2a = (float)(sums[((long)b * G + grp_a) * 2 + 1] / n);
+        if (MODE) {
+            ld8f(gamma + c1, gg); ld8f(beta + c1, bg);
+            moments(stats, b, G, grp_g, n, eps, mug, rsg);
+            k1g = (float)(sums[((long)b * G + grp_g) * 2] / n); k2g = (float)(sums[((long)b * G + grp_g) * 2 + 1] / n);
+        }
+    }
+    if (scale) ld8f(scale + c0, sc);
+    const bf16_raw* yb = y + (long)b * T * C;
+    bf16_raw* ob = dy + (long)b * T * C;
+    for (int t = w.t0; t < T; t += w.tstep) {
+        const D8 a = ld8(yb + (long)t * C + c0);
+        const D8 d = ld8(dz + ((long)b * T + t) * Co + c0);
+        float oa[8], og[8];
+        if (MODE) {
+            const D8 g = ld8(yb + (long)t * C + c1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xa = (a.v[j] - mua) * rsa, xg = (g.v[j] - mug) * rsg;
+                const float na = xa * ga[j] + ba[j], sg = sigm(xg * gg[j] + bg[j]);
+                const float dv = d.v[j] * sc[j];
+                const float dna = dv * sg, dng = dv * na * sg * (1.f - sg);
+                oa[j] = norm ? (dna * ga[j] - k1a - xa * k2a) * rsa : dna;
+                og[j] = norm ? (dng * gg[j] - k1g - xg * k2g) * rsg : dng;
+            }
+            st8(ob + (long)t * C + c0, oa);
+            st8(ob + (long)t * C + c1, og);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xa = (a.v[j] - mua) * rsa;
+                const float dna = d.v[j] * sc[j] * gelu_grad(xa * ga[j] + ba[j]);
+                oa[j] = norm ? (dna * ga[j] - k1a - xa * k2a) * rsa : dna;
+            }
+            st8(ob + (long)t * C + c0, oa);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dmx_add_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, long n8,
+                                                      bf16_raw* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const D8 x = ld8(a + i * 8), y = ld8(b + i * 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = x.v[j] + y.v[j];
+        st8(out + i * 8, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void dmx_f32_to_bf16_kernel(const float* __restrict__ a, long n, bf16_raw* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = f2bf(a[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// bidirectional LSTM layer, one time step per launch.  grid (H/16, 2 directions, ceil(Bn/16)); 4 waves.
+//   pre   fp32 [Bn][T][2][4][H]: x W_ih^T + b_ih + b_hh on entry, the ACTIVATED gates (i, f, g, o) on exit (kept for backward)
+//   whh   bf16 [2][4H][H];  hs bf16 [Bn][T][2H] (output = next step's operand);  cs fp32 [Bn][T][2H]
+// Forward: wave w computes gate w of 16 units for 16 batch rows with 16x16x32 MFMAs (A = h(t-1), B = W_hh rows), the gates meet
+// in LDS, thread (row, unit) does the cell update.  Direction 1 walks the sequence backwards.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dmx_lstm_step_fwd_kernel(float* __restrict__ pre, const bf16_raw* __restrict__ whh,
+                                                                bf16_raw* __restrict__ hs, float* __restrict__ cs, int Bn, int T, int H, int s) {
+    __shared__ float gl[4][16][17];
+    const int dir = blockIdx.y, u0 = blockIdx.x * 16, bt = blockIdx.z * 16;
+    const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, ug = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+        const int brow = bt + m;
+        const bf16_raw* hp = hs + ((long)(brow < Bn ? brow : Bn - 1) * T + tp) * 2 * H + dir * H + 8 * ug;
+        const bf16_raw* wp = whh + ((long)(dir * 4 + w) * H + u0 + m) * H + 8 * ug;
+        for (int k0 = 0; k0 < H; k0 += 32) {
+            uint4 av = *reinterpret_cast<const uint4*>(hp + k0);
+            if (brow >= Bn) av = make_uint4(0, 0, 0, 0);
+            const uint4 bv = *reinterpret_cast<const uint4*>(wp + k0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gl[w][4 * ug + r][m] = acc[r];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, u = threadIdx.x & 15, b = bt + row;
+    if (b >= Bn) return;
+    float* pg = pre + (((long)b * T + t) * 2 + dir) * 4 * H + u0 + u;
+    const float gi = sigm(pg[0] + gl[0][row][u]);
+    const float gf = sigm(pg[H] + gl[1][row][u]);
+    const float gg = tanhf(pg[2 * H] + gl[2][row][u]);
+    const float go = sigm(pg[3 * H] + gl[3][row][u]);
+    const long o = ((long)b * T + t) * 2 * H + dir * H + u0 + u;
+    const float cp = s > 0 ? cs[((long)b * T + tp) * 2 * H + dir * H + u0 + u] : 0.f;
+    const float c = gf * cp + gi * gg;
+    cs[o] = c;
+    hs[o] = f2bf(go * tanhf(c));
+    pg[0] = gi; pg[H] = gf; pg[2 * H] = gg; pg[3 * H] = go;
+}
+
+// Backward step: dh = dhs[t] + dG(next) W_hh (wave w reduces the K quarter of gate w), then the cell backward.
+//   whhT bf16 [2][H][4H];  dhs bf16 [Bn][T][2H] gradient of the layer output;  dG bf16 [Bn][T][2][4H] pre-activation gate gradients
+//   dc fp32 [2][Bn][H] running cell-state gradient
+__global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __restrict__ gates, const bf16_raw* __restrict__ whhT,
+                                                                const float* __restrict__ cs, const bf16_raw* __restrict__ dhs,
+                                                                bf16_raw* __restrict__ dG, float* __restrict__ dc, int Bn, int T, int H, int s) {
+    __shared__ float pl[4][16][17];
+    const int dir = blockIdx.y, u0 = blockIdx.x * 16, bt = blockIdx.z * 16;
+    const int t = dir ? s : T - 1 - s;          // reverse of the forward order
+    const int tn = dir ? t - 1 : t + 1;         // the step after t in forward order (processed by the previous launch)
+    const int tp = dir ? t + 1 : t - 1;         // the step before t in forward order
+    const bool has_prev = dir ? (t < T - 1) : (t > 0);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, ug = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+        const int brow = bt + m;
+        const bf16_raw* ap = dG + (((long)(brow < Bn ? brow : Bn - 1) * T + tn) * 2 + dir) * 4 * H + w * H + 8 * ug;
+        const bf16_raw* wp = whhT + ((long)dir * H + u0 + m) * 4 * H + w * H + 8 * ug;
+        for (int k0 = 0; k0 < H; k0 += 32) {
+            uint4 av = *reinterpret_cast<const uint4*>(ap + k0);
+            if (brow >= Bn) av = make_uint4(0, 0, 0, 0);
+            const uint4 bv = *reinterpret_cast<const uint4*>(wp + k0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pl[w][4 * ug + r][m] = acc[r];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, u = threadIdx.x & 15, b = bt + row;
+    if (b >= Bn) return;
+    const long o = ((long)b * T + t) * 2 * H + dir * H + u0 + u;
+    const float dh = bf2f(dhs[o]) + pl[0][row][u] + pl[1][row][u] + pl[2][row][u] + pl[3][row][u];
+    const float* pg = gates + (((long)b * T + t) * 2 + dir) * 4 * H + u0 + u;
+    const float gi = pg[0], gf = pg[H], gg = pg[2 * H], go = pg[3 * H];
+    const float c = cs[o];
+    const float cp = has_prev ? cs[((long)b * T + tp) * 2 * H + dir * H + u0 + u] : 0.f;
+    float* dcp = dc + ((long)dir * Bn + b) * H + u0 + u;
+    const float tc = tanhf(c);
+    const float dcc = dh * go * (1.f - tc * tc) + (s > 0 ? *dcp : 0.f);
+    *dcp = dcc * gf;
+    bf16_raw* dg = dG + (((long)b * T + t) * 2 + dir) * 4 * H + u0 + u;
+    dg[0] = f2bf(dcc * gg * gi * (1.f - gi));
+    dg[H] = f2bf(dcc * cp * gf * (1.f - gf));
+    dg[2 * H] = f2bf(dcc * gi * (1.f - gg * gg));
+    dg[3 * H] = f2bf(dh * tc * go * (1.f - go));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LocalState attention.  qkv bf16 [B][T][NQ]: query [0, hid) | key [hid, 2 hid) | content [2 hid, 3 hid) | decay [3 hid, 3 hid + heads nd).
+// One workgroup = one (batch, head, tile of QT queries) and ALL keys; scores live in LDS as sc[t][QT].
+// ---------------------------------------------------------------------------------------------------------------------------
+#define QT 32
+
+__device__ __forceinline__ float dot_chunks(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, int c) {
+    float s = 0.f;
+    for (int j = 0; j < c; j += 8) {
+        const D8 x = ld8(a + j), y = ld8(b + j);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += x.v[i] * y.v[i];
+    }
+    return s;
+}
+
+// scores -> softmax weights in sc (columns of queries beyond T hold zeros); dsum[sl] = sum_f (f+1) sigmoid(raw_f)/2 / sqrt(nd)
+__device__ __forceinline__ void attn_weights(const bf16_raw* __restrict__ qb, int T, int c, int NQ, int hid, int h, int nd, int s0,
+                                             float* __restrict__ sc, float* __restrict__ dsum, float* __restrict__ red) {
+    const int tid = threadIdx.x;
+    if (tid < QT) {
+        const int s = s0 + tid;
+        float v = 0.f;
+        if (s < T)
+            for (int f = 0; f < nd; ++f) v += (float)(f + 1) * 0.5f * sigm(bf2f(qb[(long)s * NQ + 3 * hid + h * nd + f]));
+        dsum[tid] = v * rsqrtf((float)nd);
+    }
+    __syncthreads();
+    const float isq = rsqrtf((float)c);
+    for (int p = tid; p < T * QT; p += 256) {
+        const int t = p / QT, sl = p % QT, s = s0 + sl;
+        float v = 0.f;
+        if (s < T) {
+            v = dot_chunks(qb + (long)t * NQ + hid + h * c, qb + (long)s * NQ + h * c, c) * isq - fabsf((float)(t - s)) * dsum[sl];
+            if (t == s) v = -100.f;
+        }
+        sc[p] = v;
+    }
+    __syncthreads();
+    // softmax over t per column: 8 threads per column
+    const int sl = tid % QT, sub = tid / QT;
+    float mx = -3.0e38f;
+    for (int t = sub; t < T; t += 8) mx = fmaxf(mx, sc[t * QT + sl]);
+    red[sub * QT + sl] = mx;
+    __syncthreads();
+    mx = red[sl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, red[i * QT + sl]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = sub; t < T; t += 8) { const float e = __expf(sc[t * QT + sl] - mx); sc[t * QT + sl] = e; sum += e; }
+    red[sub * QT + sl] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += red[i * QT + sl];
+    const float inv = (s0 + sl < T) ? 1.f / sum : 0.f;
+    for (int t = sub; t < T; t += 8) sc[t * QT + sl] *= inv;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __restrict__ qkv, int T, int hid, int heads, int nd, int NQ,
+                                                           bf16_raw* __restrict__ out) {
+    extern __shared__ float smem[];
+    float* sc = smem;                 // [T][QT]
+    float* dsum = sc + (size_t)T * QT;   // [QT]
+    float* red = dsum + QT;           // [8][QT]
+    const int b = blockIdx.z, h = blockIdx.y, s0 = blockIdx.x * QT, c = hid / heads;
+    const bf16_raw* qb = qkv + (long)b * T * NQ;
+    attn_weights(qb, T, c, NQ, hid, h, nd, s0, sc, dsum, red);
+    const int nch = c >> 3;
+    for (int it = threadIdx.x; it < QT * nch; it += 256) {
+        const int sl = it % QT, j = it / QT, s = s0 + sl;
+        if (s >= T) continue;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const float wv = sc[t * QT + sl];
+            const D8 x = ld8(qb + (long)t * NQ + 2 * hid + h * c + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += wv * x.v[i];
+        }
+        st8(out + ((long)b * T + s) * hid + h * c + 8 * j, acc);
+    }
+}
+
+// dqkv fp32 [B][T][NQ] += gradients of query / key / content / decay (caller zeroes; keys and content collect over query tiles)
+__global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dres, int T, int hid,
+                                                           int heads, int nd, int NQ, float* __restrict__ dqkv) {
+    extern __shared__ float smem[];
+    float* sc = smem;                     // [T][QT] softmax weights
+    float* dw = sc + (size_t)T * QT;      // [T][QT] d weights -> d scores
+    float* dsum = dw + (size_t)T * QT;    // [QT]
+    float* red = dsum + QT;               // [8][QT]
+    const int b = blockIdx.z, h = blockIdx.y, s0 = blockIdx.x * QT, c = hid / heads;
+    const int tid = threadIdx.x;
+    const bf16_raw* qb = qkv + (long)b * T * NQ;
+    const bf16_raw* db = dres + (long)b * T * hid + h * c;
+    float* gq = dqkv + (long)b * T * NQ;
+    attn_weights(qb, T, c, NQ, hid, h, nd, s0, sc, dsum, red);
+    for (int p = tid; p < T * QT; p += 256) {
+        const int t = p / QT, sl = p % QT, s = s0 + sl;
+        dw[p] = s < T ? dot_chunks(db + (long)s * hid, qb + (long)t * NQ + 2 * hid + h * c, c) : 0.f;
+    }
+    __syncthreads();
+    const int sl = tid % QT, sub = tid / QT;
+    float part = 0.f;
+    for (int t = sub; t < T; t += 8) part += sc[t * QT + sl] * dw[t * QT + sl];
+    red[sub * QT + sl] = part;
+    __syncthreads();
+    float dotw = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dotw += red[i * QT + sl];
+    for (int t = sub; t < T; t += 8) {
+        const float v = sc[t * QT + sl] * (dw[t * QT + sl] - dotw);
+        dw[t * QT + sl] = (t == s0 + sl) ? 0.f : v;      // masked_fill: no gradient through the diagonal
+    }
+    __syncthreads();
+    const float isq = rsqrtf((float)c);
+    const int nch = c >> 3;
+    // keys and content: item (t, chunk j)
+    for (int it = tid; it < T * nch; it += 256) {
+        const int t = it / nch, j = it % nch;
+        float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ac[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < QT && s0 + q < T; ++q) {
+            const float wv = sc[t * QT + q], dv = dw[t * QT + q] * isq;
+            const D8 qv = ld8(qb + (long)(s0 + q) * NQ + h * c + 8 * j);
+            const D8 rv = ld8(db + (long)(s0 + q) * hid + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ak[i] += dv * qv.v[i]; ac[i] += wv * rv.v[i]; }
+        }
+        float* gk = gq + (long)t * NQ + hid + h * c + 8 * j;
+        float* gc = gq + (long)t * NQ + 2 * hid + h * c + 8 * j;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { atomicAdd(&gk[i], ak[i]); atomicAdd(&gc[i], ac[i]); }
+    }
+    // queries: item (sl, chunk j), owned by this workgroup alone
+    for (int it = tid; it < QT * nch; it += 256) {
+        const int q = it % QT, j = it / QT, s = s0 + q;
+        if (s >= T) continue;
+        float aq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const float dv = dw[t * QT + q] * isq;
+            const D8 kv = ld8(qb + (long)t * NQ + hid + h * c + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) aq[i] += dv * kv.v[i];
+        }
+        float* g = gq + (long)s * NQ + h * c + 8 * j;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = aq[i];
+    }
+    // decay: d raw_f[s] = -(f+1)/sqrt(nd) * (sum_t dscore[t][s] |t - s|) * sigmoid'(raw_f) / 2
+    if (tid < QT && s0 + tid < T) {
+        const int s = s0 + tid;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += dw[t * QT + tid] * fabsf((float)(t - s));
+        a *= -rsqrtf((float)nd);
+        for (int f = 0; f < nd; ++f) {
+            const float sg = sigm(bf2f(qb[(long)s * NQ + 3 * hid + h * nd + f]));
+            gq[(long)s * NQ + 3 * hid + h * nd + f] = a * (float)(f + 1) * 0.5f * sg * (1.f - sg);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+static int dmx_check(const char* who, int B, int T, int C, int mode, int G) {
+    SEHIP_REQUIRE(B > 0 && T > 0, "%s: empty input", who);
+    SEHIP_REQUIRE(C >= 8 && (C & 7) == 0, "%s: C=%d must be a multiple of 8", who, C);
+    SEHIP_REQUIRE(!mode || (C & 15) == 0, "%s: GLU needs C=%d to be a multiple of 16", who, C);
+    SEHIP_REQUIRE(G >= 1 && G <= 8 && C % G == 0 && ((C / G) & 7) == 0, "%s: %d groups over C=%d: groups must hold a multiple of 8 channels", who, G, C);
+    return 0;
+}
+static int gcd_(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+// grid.x such that grid.x * 256 is a multiple of nq pieces, about 8 pieces per thread, at most ~2048 workgroups in all
+static dim3 dmx_grid(int B, int T, int nq) {
+    const int unit = nq / gcd_(nq, 256);
+    long want = ((long)T * nq + 256 * 8 - 1) / (256 * 8);
+    const long cap = 2048 / B > 1 ? 2048 / B : 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    const long gx = (want + unit - 1) / unit * unit;
+    return dim3((unsigned)gx, (unsigned)B);
+}
+
+extern "C" int sehip_dmx_prep(const float* mix, int B, int ac, int acp, int T, int padl, int Tv, int normalize, int up, const float* kup,
+                              int width, int KL, float* ms, void* x_bf16, void* stream) {
+    SEHIP_REQUIRE(B > 0 && ac > 0 && acp >= ac && T > 0 && Tv >= T + padl, "dmx_prep: bad sizes (B=%d ac=%d acp=%d T=%d padl=%d Tv=%d)", B, ac, acp, T, padl, Tv);
+    SEHIP_REQUIRE(!up || (kup && KL > 0), "dmx_prep: up-sampling needs its kernels");
+    dmx_moments_kernel<<<B, 256, 0, (hipStream_t)stream>>>(mix, ac, T, normalize, ms);
+    const long T0 = up ? 2L * Tv : Tv;
+    dmx_prep_kernel<<<dim3((unsigned)((T0 + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(mix, ms, kup, ac, acp, T, padl, Tv, up, width, KL,
+                                                                                           (bf16_raw*)x_bf16);
+    SEHIP_CHECK_LAUNCH("dmx_prep");
+    return 0;
+}
+
+extern "C" int sehip_dmx_post(const float* y, const float* ms, int B, int co, int cop, long Tf, int padl, int T, int down, const float* kdn,
+                              int width, int KL, float* out, void* stream) {
+    SEHIP_REQUIRE(B > 0 && co > 0 && cop >= co && T > 0 && Tf > 0, "dmx_post: bad sizes");
+    SEHIP_REQUIRE((down ? Tf / 2 : Tf) >= padl + T, "dmx_post: the network output (%ld) is shorter than pad + clip (%d + %d)", Tf, padl, T);
+    dmx_post_kernel<<<dim3((unsigned)((T + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(y, ms, kdn, co, cop, Tf, padl, T, down, width, KL, out);
+    SEHIP_CHECK_LAUNCH("dmx_post");
+    return 0;
+}
+
+extern "C" int sehip_dmx_post_bwd(const float* dout, const float* ms, int B, int co, int cop, long Tf, int padl, int T, int down,
+                                  const float* kdn, int width, int KL, void* dy_bf16, void* stream) {
+    SEHIP_REQUIRE(B > 0 && co > 0 && cop >= co && T > 0 && Tf > 0, "dmx_post_bwd: bad sizes");
+    dmx_post_bwd_kernel<<<dim3((unsigned)((Tf + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(dout, ms, kdn, co, cop, Tf, padl, T, down, width, KL,
+                                                                                              (bf16_raw*)dy_bf16);
+    SEHIP_CHECK_LAUNCH("dmx_post_bwd");
+    return 0;
+}
+
+extern "C" int sehip_dmx_gn_stats(const void* y, int B, int T, int C, int G, double* stats, void* stream) {
+    if (int e = dmx_check("dmx_gn_stats", B, T, C, 0, G)) return e;
+    dmx_gn_stats_kernel<<<dmx_grid(B, T, C >> 3), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, T, C, G, stats);
+    SEHIP_CHECK_LAUNCH("dmx_gn_stats");
+    return 0;
+}
+
+extern "C" int sehip_dmx_act_fwd(const void* y, const double* stats, const float* gamma, const float* beta, int G, float eps, int mode,
+                                 const float* scale, const void* resid, const void* add, int B, int T, int C, void* out, void* stream) {
+    if (int e = dmx_check("dmx_act_fwd", B, T, C, mode, stats ? G : 1)) return e;
+    SEHIP_REQUIRE(!stats || (gamma && beta), "dmx_act_fwd: GroupNorm needs its affine terms");
+    SEHIP_REQUIRE(!scale || resid, "dmx_act_fwd: LayerScale comes with the residual input");
+    const int nq = (mode ? C >> 1 : C) >> 3;
+    const dim3 g = dmx_grid(B, T, nq);
+    if (mode)
+        dmx_act_fwd_kernel<1><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, stats, gamma, beta, G, eps, scale, (const bf16_raw*)resid,
+                                                                   (const bf16_raw*)add, T, C, (bf16_raw*)out);
+    else
+        dmx_act_fwd_kernel<0><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, stats, gamma, beta, G, eps, scale, (const bf16_raw*)resid,
+                                                                   (const bf16_raw*)add, T, C, (bf16_raw*)out);
+    SEHIP_CHECK_LAUNCH("dmx_act_fwd");
+    return 0;
+}
+
+extern "C" int sehip_dmx_act_bwd(const void* dz, const void* y, const double* stats, const float* gamma, const float* beta, int G, float eps,
+                                 int mode, const float* scale, int B, int T, int C, double* sums, float* gch, void* dy, void* stream) {
+    if (int e = dmx_check("dmx_act_bwd", B, T, C, mode, stats ? G : 1)) return e;
+    SEHIP_REQUIRE(!scale || stats, "dmx_act_bwd: LayerScale is only built behind a GroupNorm");
+    const int nq = (mode ? C >> 1 : C) >> 3;
+    const dim3 g = dmx_grid(B, T, nq);
+    if (stats) {
+        SEHIP_REQUIRE(gamma && beta && sums && gch, "dmx_act_bwd: GroupNorm needs gamma, beta, sums and the gradient accumulator");
+        const size_t lds = ((size_t)2 * C + (mode ? C >> 1 : C) + 16) * sizeof(float);
+        SEHIP_REQUIRE(lds <= 64 * 1024, "dmx_act_bwd: C=%d does not fit the LDS partials", C);
+        if (mode)
+            dmx_act_bwd_reduce_kernel<1><<<g, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, gamma, beta, G, eps, scale, T,
+                                                                                C, sums, gch);
+        else
+            dmx_act_bwd_reduce_kernel<0><<<g, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, gamma, beta, G, eps, scale, T,
+                                                                                C, sums, gch);
+        SEHIP_CHECK_LAUNCH("dmx_act_bwd_reduce");
+    }
+    if (mode)
+        dmx_act_bwd_apply_kernel<1><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, sums, gamma, beta, G, eps, scale, T, C,
+                                                                         (bf16_raw*)dy);
+    else
+        dmx_act_bwd_apply_kernel<0><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, sums, gamma, beta, G, eps, scale, T, C,
+                                                                         (bf16_raw*)dy);
+    SEHIP_CHECK_LAUNCH("dmx_act_bwd_apply");
+    return 0;
+}
+
+extern "C" int sehip_dmx_add(const void* a, const void* b, long n, void* out, void* stream) {
+    SEHIP_REQUIRE(n > 0 && (n & 7) == 0, "dmx_add: n=%ld must be a positive multiple of 8", n);
+    long g = (n / 8 + 255) / 256;
+    if (g > 4096) g = 4096;
+    dmx_add_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)a, (const bf16_raw*)b, n / 8, (bf16_raw*)out);
+    SEHIP_CHECK_LAUNCH("dmx_add");
+    return 0;
+}
+
+extern "C" int sehip_dmx_f32_to_bf16(const float* a, long n, void* out, void* stream) {
+    SEHIP_REQUIRE(n > 0, "dmx_f32_to_bf16: empty");
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    dmx_f32_to_bf16_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(a, n, (bf16_raw*)out);
+    SEHIP_CHECK_LAUNCH("dmx_f32_to_bf16");
+    return 0;
+}
+
+// the whole layer: T step launches
+extern "C" int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, int H, void* hs, float* cs, void* stream) {
+    SEHIP_REQUIRE(Bn > 0 && T > 0 && H >= 32 && (H & 31) == 0, "dmx_lstm_fwd: hidden size H=%d must be a multiple of 32 (Bn=%d T=%d)", H, Bn, T);
+    const dim3 g(H / 16, 2, (Bn + 15) / 16);
+    for (int s = 0; s < T; ++s)
+        dmx_lstm_step_fwd_kernel<<<g, 256, 0, (hipStream_t)stream>>>(pre, (const bf16_raw*)whh, (bf16_raw*)hs, cs, Bn, T, H, s);
+    SEHIP_CHECK_LAUNCH("dmx_lstm_fwd");
+    return 0;
+}
+
+extern "C" int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const float* cs, const void* dhs, int Bn, int T, int H, void* dG, float* dc,
+                                  void* stream) {
+    SEHIP_REQUIRE(Bn > 0 && T > 0 && H >= 32 && (H & 31) == 0, "dmx_lstm_bwd: hidden size H=%d must be a multiple of 32", H);
+    const dim3 g(H / 16, 2, (Bn + 15) / 16);
+    for (int s = 0; s < T; ++s)
+        dmx_lstm_step_bwd_kernel<<<g, 256, 0, (hipStream_t)stream>>>(gates, (const bf16_raw*)whhT, cs, (const bf16_raw*)dhs, (bf16_raw*)dG, dc, Bn, T, H, s);
+    SEHIP_CHECK_LAUNCH("dmx_lstm_bwd");
+    return 0;
+}
+
+static int attn_check(const char* who, int B, int T, int hid, int heads, int nd, int NQ, size_t lds) {
+    SEHIP_REQUIRE(B > 0 && T > 0 && heads > 0 && hid % heads == 0 && ((hid / heads) & 7) == 0,
+                  "%s: %d channels over %d heads: a head must hold a multiple of 8 channels", who, hid, heads);
+    SEHIP_REQUIRE(nd >= 0 && nd <= 8 && NQ >= 3 * hid + heads * nd && (NQ & 7) == 0, "%s: bad row length NQ=%d", who, NQ);
+    SEHIP_REQUIRE(lds <= 150 * 1024, "%s: T=%d frames do not fit the LDS score tile", who, T);
+    return 0;
+}
+
+extern "C" int sehip_dmx_attn_fwd(const void* qkv, int B, int T, int hid, int heads, int nd, int NQ, void* out, void* stream) {
+    const size_t lds = ((size_t)T * QT + QT + 8 * QT) * sizeof(float);
+    if (int e = attn_check("dmx_attn_fwd", B, T, hid, heads, nd, NQ, lds)) return e;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    dmx_attn_fwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, lds, (hipStream_t)stream>>>((const bf16_raw*)qkv, T, hid, heads, nd, NQ, (bf16_raw*)out);
+    SEHIP_CHECK_LAUNCH("dmx_attn_fwd");
+    return 0;
+}
+
+extern "C" int sehip_dmx_attn_bwd(const void* qkv, const void* dres, int B, int T, int hid, int heads, int nd, int NQ, float* dqkv, void* stream) {
+    const size_t lds = ((size_t)2 * T * QT + QT + 8 * QT) * sizeof(float);
+    if (int e = attn_check("dmx_attn_bwd", B, T, hid, heads, nd, NQ, lds)) return e;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    dmx_attn_bwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, lds, (hipStream_t)stream>>>((const bf16_raw*)qkv, (const bf16_raw*)dres, T, hid, heads, nd, NQ,
+                                                                                           dqkv);
+    SEHIP_CHECK_LAUNCH("dmx_attn_bwd");
+    return 0;
+}

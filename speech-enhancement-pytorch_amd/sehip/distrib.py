@@ -14,10 +14,11 @@ from .model.dccrn import DCCRN
 from .model.conv_tasnet import ConvTasNet
 from .model.dcunet import DCUnet
 from .model.dnn import DeepNeuralNetwork
+from .model.demucs import Demucs
 from .optim import FlatOptimizer
 from .utils import obj2dict
 
-MODEL_REGISTRY = {"dccrn": DCCRN, "dcunet": DCUnet, "dnn": DeepNeuralNetwork, "conv-tasnet": ConvTasNet}
+MODEL_REGISTRY = {"dccrn": DCCRN, "dcunet": DCUnet, "dnn": DeepNeuralNetwork, "conv-tasnet": ConvTasNet, "demucs": Demucs}
 _REFERENCE_NAMES = ("dnn", "mel-rnn", "unet", "dccrn", "dcunet", "demucs", "wav-unet", "conv-tasnet", "crn", "rnn-stft-mask")
 
 

@@ -1,0 +1,134 @@
+"""Drop-in Demucs on libsehip (reference: src/model/demucs.py:272-501; BASELINE config C3).
+
+Same constructor arguments, same ``forward(mix[B, ac, T]) -> [B, S, ac, T]`` (S = len(sources)), same state_dict keys
+(``encoder.{i}.0.weight``, ``encoder.{i}.3.layers.{d}.3.lstm.weight_ih_l0_reverse``, ``decoder.{j}.3.weight`` ...), including the
+key migration of load_state_dict (:492-501), so the reference's checkpoints load here and vice versa.  Parameters are views
+into one flat fp32 buffer; forward / backward run the HIP kernels through the C ABI; a CPU tensor raises SehipError.
+Built: the structure of the constructor defaults (sehip/plan_demucs.py lists the options and limits).
+"""
+import math
+import os
+
+import torch
+
+from .. import plan_demucs as P
+from .._lib import SehipError
+from .flat import FlatModule
+
+_STATIC_CACHE = {}
+
+
+class _DemucsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, mix, anchor):
+        ctx.model = model
+        ctx.ws = model._run_forward(mix)
+        ctx.generation = ctx.ws.generation
+        return ctx.ws.out.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.generation != ctx.ws.generation or ctx.ws.closed:
+            raise SehipError("Demucs.backward: the workspace of this forward was overwritten by a later forward of the same shape "
+                             "(or evicted); run backward before the next forward of that shape")
+        ctx.model._run_backward(ctx.ws, grad_out)
+        return None, None, None
+
+
+class Demucs(FlatModule):
+    def __init__(self, sources, audio_channels=2, channels=64, growth=2., depth=6, rewrite=True, lstm_layers=0, kernel_size=8, stride=4,
+                 context=1, gelu=True, glu=True, norm_starts=4, norm_groups=4, dconv_mode=1, dconv_depth=2, dconv_comp=4, dconv_attn=4,
+                 dconv_lstm=4, dconv_init=1e-4, normalize=True, resample=True, rescale=0.1, samplerate=44100, segment=4 * 10, *args, **kwargs):
+        super().__init__()
+        self.cfg = cfg = P.DemucsConfig(sources, audio_channels=audio_channels, channels=channels, growth=growth, depth=depth, rewrite=rewrite,
+                                        lstm_layers=lstm_layers, kernel_size=kernel_size, stride=stride, context=context, gelu=gelu, glu=glu,
+                                        norm_starts=norm_starts, norm_groups=norm_groups, dconv_mode=dconv_mode, dconv_depth=dconv_depth,
+                                        dconv_comp=dconv_comp, dconv_attn=dconv_attn, dconv_lstm=dconv_lstm, dconv_init=dconv_init,
+                                        normalize=normalize, resample=resample, rescale=rescale)
+        if cfg.key() not in _STATIC_CACHE:
+            _STATIC_CACHE[cfg.key()] = P.DemucsStatic(cfg)
+        self.static = _STATIC_CACHE[cfg.key()]
+        self.audio_channels, self.sources, self.kernel_size, self.context, self.stride, self.depth = audio_channels, sources, kernel_size, context, stride, depth
+        self.resample, self.channels, self.normalize, self.samplerate, self.segment = resample, channels, normalize, samplerate, segment
+        self._tables = None
+        self._ws_cap = max(1, int(os.environ.get("SEHIP_WS_CACHE", "2")))
+        self._build_flat(list_roots=("encoder", "decoder"))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """PyTorch's default initialisers of the reference's layers (Conv1d / ConvTranspose1d / Linear: U(+-1/sqrt(fan_in)) for
+        weight and bias; nn.LSTM: U(+-1/sqrt(hidden)); GroupNorm 1 / 0), LayerScale = dconv_init (src/model/demucs.py:64-65),
+        LocalState's decay query: weight * 0.01, bias -2 (:230-232), then rescale_module (:123-136, :427-428): every convolution's
+        weight and bias divided by sqrt(std(weight) / rescale)."""
+        cfg = self.cfg
+        with torch.no_grad():
+            named = dict(self._params)
+            for name, p in self._params:
+                leaf = name.rsplit(".", 1)[-1]
+                if ".lstm." in name:
+                    hid = p.shape[0] // 4
+                    p.uniform_(-1 / math.sqrt(hid), 1 / math.sqrt(hid))
+                elif leaf == "scale":
+                    p.fill_(cfg.dconv_init)
+                elif p.dim() >= 2:
+                    transposed = p.dim() == 3 and name.startswith("decoder.") and name.endswith(".3.weight")
+                    fan_in = (p.shape[1] if not transposed else p.shape[1]) * (p.shape[2] if p.dim() == 3 else 1)
+                    bound = 1 / math.sqrt(fan_in)
+                    p.uniform_(-bound, bound)
+                    b = named.get(name[:-len("weight")] + "bias")
+                    if b is not None:
+                        b.uniform_(-bound, bound)
+                elif leaf == "weight":          # GroupNorm (every 1-D tensor named weight)
+                    p.fill_(1.0)
+                elif leaf == "bias" and (name[:-len("bias")] + "weight") in named and named[name[:-len("bias")] + "weight"].dim() == 1:
+                    p.zero_()
+            for name, p in self._params:
+                if name.endswith("query_decay.weight"):
+                    p.mul_(0.01)
+                    named[name[:-len("weight")] + "bias"].fill_(-2.0)
+            if cfg.rescale:
+                for name, p in self._params:
+                    if p.dim() == 3 and name.endswith("weight"):      # nn.Conv1d / nn.ConvTranspose1d
+                        scale = (p.std() / cfg.rescale) ** 0.5
+                        p.div_(scale)
+                        named[name[:-len("weight")] + "bias"].div_(scale)
+
+    def valid_length(self, length):
+        return self.cfg.valid_length(length)
+
+    def load_state_dict(self, state, strict=True, **kw):
+        state = dict(state)
+        for idx in range(self.depth):    # the reference's own key migration (src/model/demucs.py:492-501)
+            for a in ("encoder", "decoder"):
+                for b in ("bias", "weight"):
+                    new, old = f"{a}.{idx}.3.{b}", f"{a}.{idx}.2.{b}"
+                    if old in state and new not in state:
+                        state[new] = state.pop(old)
+        return super().load_state_dict(state, strict=strict, **kw)
+
+    def workspace(self, batch, nsample):
+        dev = self._require_gpu("Demucs")
+        if self._tables is None:
+            self._tables = P.DemucsDeviceTables(self.static, dev)
+        return self._lru_get((batch, nsample), self._ws_cap, lambda: P.DemucsWorkspace(self.static, self._tables, batch, nsample, dev))
+
+    def _run_forward(self, mix):
+        ws = self.workspace(mix.shape[0], mix.shape[-1])
+        ws.generation += 1
+        ws.forward(mix.contiguous().float(), self._flat)
+        return ws
+
+    def _run_backward(self, ws, grad_out):
+        g = grad_out.contiguous().float()
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst))
+
+    def forward(self, mix):
+        if mix.dim() != 3 or mix.shape[1] != self.audio_channels:
+            raise SehipError(f"Demucs.forward: [B, {self.audio_channels}, T] expected, got {tuple(mix.shape)}")
+        if not mix.is_cuda:
+            raise SehipError("Demucs.forward got a CPU tensor: the HIP path needs a gfx950 GPU (no CPU fallback)")
+        if torch.is_grad_enabled():
+            if self._anchor is None or self._anchor.device != mix.device:
+                self._anchor = torch.zeros(1, device=mix.device, requires_grad=True)
+            return _DemucsFunction.apply(self, mix, self._anchor)
+        return self._run_forward(mix).out.clone()
