@@ -71,6 +71,14 @@ def convtasnet_config():
     return cfg
 
 
+def demucs_config():
+    """BASELINE config C3: Demucs denoiser (channels 64, depth 6, the constructor defaults), 48 kHz stereo 2-s clips, one source, batch 16."""
+    from sehip.utils import dict2obj
+    cfg = bench_config(0)
+    cfg.model = dict2obj({"name": "demucs", "audio_channels": 2, "num_spk": 1, "sources": ["clean"], "samplerate": 48000, "segment": 2})
+    return cfg
+
+
 def gemm_roofline(ws, reps=5):
     """Times every product launch of the step separately, groups them by the kernel instantiation libsehip picked, and
     returns the per-class table: launches per step, average launch duration and algorithmic TFLOP/s.
@@ -286,9 +294,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: 32 for dccrn, 64 for dcunet)")
-    ap.add_argument("--workload", choices=("dccrn", "dcunet", "convtasnet"), default="dccrn",
+    ap.add_argument("--workload", choices=("dccrn", "dcunet", "convtasnet", "demucs"), default="dccrn",
                     help="dccrn = BASELINE configs[1], the headline metric; dcunet = configs[2] (DCUnet-10, STFT-domain mse, B=64); "
-                         "convtasnet = configs[4] (2-speaker separation, 8 kHz 4-s clips, B=32 per GPU)")
+                         "convtasnet = configs[4] (2-speaker separation, 8 kHz 4-s clips, B=32 per GPU); demucs = configs[3] (48 kHz stereo "
+                         "2-s clips, B=16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as two captured hipGraphs instead of launching "
@@ -303,8 +312,9 @@ def main():
     args = ap.parse_args()
     dcu = args.workload == "dcunet"
     ctn = args.workload == "convtasnet"
+    dmx = args.workload == "demucs"
     if not args.batch:
-        args.batch = 64 if dcu else BATCH
+        args.batch = 64 if dcu else 16 if dmx else BATCH
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], args.batch,
                             args.cpu_threads or min(len(os.sched_getaffinity(0)), 32))
@@ -319,7 +329,9 @@ def main():
     cfg = dcunet_config() if dcu else bench_config(n)
     if ctn:
         n, clip_s, cfg = 32000, 4.0, convtasnet_config()       # 4 s at 8 kHz
-    if dcu or ctn:
+    if dmx:
+        n, clip_s, cfg = 96000, 2.0, demucs_config()           # 2 s at 48 kHz
+    if dcu or ctn or dmx:
         args.no_cpu_baseline = True               # the CPU baseline / parity block belong to the headline workload (tests pin C2)
     torch.manual_seed(cfg.seed)
     model = distrib.get_model(cfg.model)
@@ -327,6 +339,10 @@ def main():
     solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
     dev = solver.device
     noisy, clean = make_batch(args.batch, n, rank, dev)
+    if dmx:   # stereo: the second channel is an attenuated, differently-noised copy; one source [B, 1, 2, N]
+        n2, c2 = make_batch(args.batch, n, rank + 1000, dev)
+        noisy = torch.cat([noisy, 0.8 * clean[:, 0] + (n2 - c2[:, 0])], dim=1)
+        clean = torch.cat([clean, 0.8 * clean], dim=2)
     if ctn:   # two sources per clip, the mixture is their sum (sources [B, S, 1, N] stay 4-D for this model, src/solver.py:443-452)
         clean = torch.cat([clean, noisy.unsqueeze(1) - clean], dim=1)
     mixture, sources = solver._prepare_batch(noisy, clean)
@@ -392,20 +408,22 @@ def main():
 
     out = {
         "metric": ("audio-sec/sec training, DCUnet-10 16kHz 2.048s bs64" if dcu else "audio-sec/sec training, ConvTasNet 8kHz 4s bs32"
-                   if ctn else "audio-sec/sec training, DCCRN 16kHz 2s bs32"), "value": value, "unit": "audio-s/s", "n_gpus": world,
+                   if ctn else "audio-sec/sec training, Demucs 48kHz stereo 2s bs16" if dmx else "audio-sec/sec training, DCCRN 16kHz 2s bs32"), "value": value, "unit": "audio-s/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("DCUnet-10 (complex, model_complexity 45 -> 31/62 channels, mask E) train step on [64,1,257,257,2] "
                                 "spectra: stft_custom of mixture and sources, mse in the STFT domain, Adam 3e-4, clip 5" if dcu else
                                 "ConvTasNet (N128 L40 B128 H256 P3 X7 R2, gLN, relu mask) 2-speaker separation train step, 8 kHz 4-s clips, "
                                 "SI-SNR, Adam 3e-4, clip 5" if ctn else
+                                "Demucs (channels 64, depth 6, DConv with BLSTM + LocalState from layer 4, x2 resampling; 133.7 M parameters) "
+                                "denoising train step, 48 kHz stereo 2-s clips, SI-SNR, Adam 3e-4, clip 5" if dmx else
                                 "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
                                 "clips, SI-SNR, Adam 3e-4, clip 5"), "per_gpu_batch": args.batch,
                    "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
                    "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step" if args.h2d else "resident in HBM"},
         "final_loss": float(loss),
     }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not dmx:
         ws = model.workspace(args.batch, 257, 257) if dcu else model.workspace(args.batch, n)
         if ctn:
             ws.st.specs = ws.st.specs   # (TasNetWorkspace keeps its products in ws.st.specs like the DCCRN workspace)

@@ -393,12 +393,18 @@ class DemucsStatic:
         tab = np.full((L.n_params, 4), -1, dtype=np.int32)
         fill = np.zeros(L.n_params, dtype=np.int8)
 
-        def put(pidx, gidx):
+        def put(pidx, gidx, unique=False):
             pidx = np.asarray(pidx, dtype=np.int64).reshape(-1)
             gidx = np.asarray(gidx, dtype=np.int64).reshape(-1)
             if pidx.size == 0:
                 return
             assert gidx.max() < 2 ** 30
+            if unique:                                      # a weight element occurs once in its forward product
+                slot = fill[pidx]
+                assert slot.max() < 4
+                tab[pidx, slot] = (gidx << 1).astype(np.int32)
+                fill[pidx] += 1
+                return
             order = np.argsort(pidx, kind="stable")        # a parameter may occur several times in one call (the four output
             ps, gs = pidx[order], gidx[order]               # phases of a transposed convolution share its bias)
             first = np.flatnonzero(np.r_[True, ps[1:] != ps[:-1]])
@@ -414,7 +420,7 @@ class DemucsStatic:
                 continue
             w = self.wtab[p.w_off:p.w_off + p.Npad * p.K]
             m = np.flatnonzero(w >= 0)
-            put(w[m] >> 1, p.dw_off + m)
+            put(w[m] >> 1, p.dw_off + m, unique=True)
             if p.db_off is not None:
                 for col in range(p.bias.shape[1]):
                     b = p.bias[:, col]

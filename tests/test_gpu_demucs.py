@@ -1,0 +1,361 @@
+"""GPU parity of the Demucs HIP path (BASELINE config C3) against the CPU oracle (oracle/demucs_oracle.py,
+pinned to vectors of the imported reference by tests/test_oracle_golden.py::test_demucs_oracle_matches_reference): the streaming
+kernels, the LSTM layer and the LocalState attention op-locally through the C ABI, whole chains (every encoder / decoder output,
+the separated sources, every parameter gradient) on 4-layer models with and without the resampler / stereo / several sources, the
+full-width default network (channels 64, depth 6, 133.7 M parameters), and Solver steps at the C3 shape [16, 2, 96000]."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import demucs_oracle as DM
+from oracle import dccrn_oracle as O
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+SMALL = dict(sources=["a", "b"], audio_channels=2, channels=32, depth=4, norm_starts=2, dconv_lstm=2, dconv_attn=2)
+
+
+def _lib():
+    from sehip import _lib
+    return _lib
+
+
+def cl(x):
+    """oracle [B, C, T] -> channels-last [B, T, C]"""
+    return x.detach().transpose(1, 2).contiguous()
+
+
+def randomise_small_terms(model, g):
+    """non-trivial GroupNorm affine terms and layer scales (1e-4 at init would hide the DConv branches)"""
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith(".scale"):
+                prm.copy_(0.3 + 0.1 * torch.randn(prm.shape, generator=g))
+            elif prm.dim() == 1 and "lstm" not in name and name.endswith("weight"):
+                prm.copy_(1 + 0.2 * torch.randn(prm.shape, generator=g))
+
+
+def run_chain(kw, B, T, seed):
+    from sehip.model import Demucs
+    torch.manual_seed(seed)
+    model = Demucs(**kw)
+    g = torch.Generator().manual_seed(seed + 1)
+    randomise_small_terms(model, g)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    mix = 0.3 * torch.randn(B, kw["audio_channels"], T, generator=g) + 0.05
+    cfg = DM.DemucsConfig(**kw)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    taps = {}
+    ref = DM.demucs_forward(leaves, mix, cfg, taps=taps)
+    est = model(mix.cuda())
+    ws = model.workspace(B, T)
+    D = cfg.depth
+    fwd = {}
+    for i in range(D):
+        fwd[f"enc{i}"] = rel_err(ws.bufs[f"e{i}.out"].t.float().cpu()[:, :, 0], cl(taps[f"enc{i}"]))
+    for j in range(D - 1):
+        i = D - 1 - j        # the oracle's dec{j} is decoder j's output; the HIP path stores it with the skip connection added
+        fwd[f"dec{j}"] = rel_err(ws.bufs[f"d{i - 1}.in"].t.float().cpu()[:, :, 0], cl(taps[f"dec{j}"]) + cl(taps[f"enc{i - 1}"]))
+    fwd["est"] = rel_err(est.detach().cpu(), ref.detach())
+    G = torch.randn(ref.shape, generator=g) / ref.numel() ** 0.5
+    names = sorted(leaves)
+    grads = torch.autograd.grad((ref * G).sum(), [leaves[k] for k in names])
+    est.backward(G.cuda())
+    got = {k: v.grad.detach().cpu() for k, v in model.named_parameters()}
+    num = den = 0.0
+    rows = []
+    for k, gr in zip(names, grads):
+        e, n = float((got[k].double() - gr.double()).norm()), float(gr.double().norm())
+        num += e * e; den += n * n
+        rows.append((e, n, k))
+    return dict(model=model, ws=ws, fwd=fwd, glob=(num / den) ** 0.5, gnorm=den ** 0.5, rows=rows, shape=tuple(est.shape), p=p, mix=mix, ref=ref.detach())
+
+
+def check_chain(r, what, fwd_tol=2e-2, est_tol=1e-2, glob_tol=5e-2, big_tol=0.12):
+    print(f"Demucs {what}: forward {', '.join(f'{k} {v:.2e}' for k, v in r['fwd'].items())}; global grad rel {r['glob']:.3e} (|g| = {r['gnorm']:.3f})")
+    for k, v in r["fwd"].items():
+        assert v < (est_tol if k == "est" else fwd_tol), (k, v)
+    assert r["glob"] < glob_tol
+    for e, n, k in r["rows"]:
+        if n > 0.03 * r["gnorm"]:          # (the key bias of LocalState has an exactly-zero gradient: softmax over the keys)
+            assert e < big_tol * n, (k, e, n)
+
+
+def test_chain_stereo_two_sources_resampled():
+    """4 layers (32..256 channels), GroupNorm(4) / BLSTM / LocalState from layer 2, x2 resampling, [2, 2, 6000]: T = 3028, 756, 188, 46."""
+    r = run_chain(dict(SMALL), 2, 6000, 3)
+    assert r["shape"] == (2, 2, 2, 6000)
+    check_chain(r, "stereo, 2 sources, resampled")
+
+
+def test_chain_mono_one_source_plain():
+    """mono, one source (the padded input / output channels), no resampler, no normalisation, batch 3, an odd clip length."""
+    kw = dict(SMALL, sources=["a"], audio_channels=1, resample=False, normalize=False)
+    r = run_chain(kw, 3, 5001, 5)
+    assert r["shape"] == (3, 1, 1, 5001)
+    check_chain(r, "mono, 1 source, no resampler")
+
+
+def test_chain_attention_without_lstm_and_deeper_dconv():
+    """LocalState from layer 1 but BLSTM only from layer 3, three DConv branches per layer (dilations 1, 2, 4), GroupNorm(2)."""
+    kw = dict(SMALL, channels=64, dconv_attn=1, dconv_lstm=3, dconv_depth=3, norm_groups=2, norm_starts=1, resample=False)
+    r = run_chain(kw, 2, 4000, 7)
+    check_chain(r, "attention from layer 1, LSTM from layer 3, DConv depth 3", est_tol=2e-2)    # (no normalisation: est is the raw last layer)
+
+
+def test_full_width_default_network():
+    """The C3 network (channels 64, depth 6, every default; 133.7 M parameters) on [1, 2, 24000] against the oracle: forward taps,
+    output, and every parameter gradient under a fixed upstream gradient."""
+    r = run_chain(dict(sources=["clean"], audio_channels=2), 1, 24000, 11)
+    assert sum(v.numel() for v in r["p"].values()) == 133749986
+    check_chain(r, "full width (64 channels, depth 6)", fwd_tol=3e-2, est_tol=1.5e-2, glob_tol=6e-2, big_tol=0.15)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# op-local
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+@pytest.mark.parametrize("mode,G,scaled,C", [(0, 0, False, 64), (0, 4, False, 64), (1, 0, False, 64), (1, 1, True, 48), (1, 4, False, 128), (0, 1, False, 8),
+                                             (1, 1, True, 4096)])
+def test_groupnorm_activation_family(mode, G, scaled, C):
+    """GroupNorm(G) (or none) + GELU / GLU (+ LayerScale + residual, + addend), forward and backward, against torch on the same
+    bf16-rounded input."""
+    L = _lib()
+    g = torch.Generator().manual_seed(C + 10 * mode + G)
+    B, T = 3, 157 if C < 4096 else 23
+    Co = C // 2 if mode else C
+    y = (torch.randn(B, T, C, generator=g) * 1.5 + 0.3).to(BF)
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    scale = 0.3 + 0.2 * torch.randn(Co, generator=g) if scaled else None
+    resid = torch.randn(B, T, Co, generator=g).to(BF) if scaled else None
+    add = torch.randn(B, T, Co, generator=g).to(BF)
+    dz = torch.randn(B, T, Co, generator=g).to(BF)
+    yf = y.float().transpose(1, 2).requires_grad_(True)                       # [B, C, T]
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    sc = scale.clone().requires_grad_(True) if scaled else None
+    n = F.group_norm(yf, G, gm, bt, eps=1e-5) if G else yf
+    v = F.glu(n, dim=1) if mode else F.gelu(n)
+    if scaled:
+        v = resid.float().transpose(1, 2) + sc[:, None] * v
+    v = v + add.float().transpose(1, 2)
+    leaves = [yf] + ([gm, bt] if G else []) + ([sc] if scaled else [])
+    refs = torch.autograd.grad((v * dz.float().transpose(1, 2)).sum(), leaves)
+    dev = "cuda"
+    yd, dzd = y.to(dev), dz.to(dev)
+    stats = torch.zeros(B, 8, 2, dtype=torch.float64, device=dev)
+    sums = torch.zeros(B, 8, 2, dtype=torch.float64, device=dev)
+    out = torch.zeros(B, T, Co, dtype=BF, device=dev)
+    dy = torch.zeros(B, T, C, dtype=BF, device=dev)
+    gch = torch.zeros(2 * C + Co, device=dev)
+    gmd, btd = gamma.to(dev), beta.to(dev)
+    scd, rd, ad = (scale.to(dev) if scaled else None), (resid.to(dev) if scaled else None), add.to(dev)
+    st = None
+    if G:
+        L.call("sehip_dmx_gn_stats", yd.data_ptr(), B, T, C, G, stats.data_ptr(), None)
+    L.call("sehip_dmx_act_fwd", yd.data_ptr(), _ptr(stats) if G else None, _ptr(gmd) if G else None, _ptr(btd) if G else None, max(G, 1), 1e-5, mode,
+           _ptr(scd), _ptr(rd), _ptr(ad), B, T, C, out.data_ptr(), None)
+    L.call("sehip_dmx_act_bwd", dzd.data_ptr(), yd.data_ptr(), _ptr(stats) if G else None, _ptr(gmd) if G else None, _ptr(btd) if G else None, max(G, 1),
+           1e-5, mode, _ptr(scd), B, T, C, _ptr(sums) if G else None, _ptr(gch) if G else None, dy.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), v.detach().transpose(1, 2)) < 4e-3
+    assert rel_err(dy.float().cpu(), refs[0].transpose(1, 2)) < 6e-3
+    if G:
+        assert rel_err(gch[:C].cpu(), refs[1]) < 5e-3 and rel_err(gch[C:2 * C].cpu(), refs[2]) < 5e-3
+    if scaled:
+        assert rel_err(gch[2 * C:].cpu(), refs[-1]) < 5e-3
+
+
+@pytest.mark.parametrize("Bn,T,H", [(2, 37, 32), (16, 50, 64), (19, 12, 256)])
+def test_bidirectional_lstm_layer(Bn, T, H):
+    """One bidirectional layer, forward and backward, through the step kernels against the oracle's recurrence (given the same
+    pre-gates and bf16 weights): h, and the pre-activation gate gradients of both directions."""
+    L = _lib()
+    g = torch.Generator().manual_seed(H + T)
+    whh = (torch.randn(2, 4 * H, H, generator=g) / H ** 0.5).to(BF)
+    pre = torch.randn(Bn, T, 2, 4 * H, generator=g)
+    dh = torch.randn(Bn, T, 2 * H, generator=g).to(BF)
+    pre_l = pre.clone().requires_grad_(True)
+    outs = []
+    for d in range(2):
+        h = torch.zeros(Bn, H); c = torch.zeros(Bn, H)
+        seq = [None] * T
+        for t in (range(T - 1, -1, -1) if d else range(T)):
+            hb = h.to(BF).float()                                                   # the HIP path feeds h back in bf16
+            i, f, gg, o = (pre_l[:, t, d] + hb @ whh[d].float().t()).chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            seq[t] = h
+        outs.append(torch.stack(seq, 1))
+    hs_ref = torch.cat(outs, dim=2)                                                # [Bn, T, 2H]
+    dpre_ref, = torch.autograd.grad((hs_ref * dh.float()).sum(), [pre_l])
+    dev = "cuda"
+    pre_d = pre.to(dev).contiguous()
+    hs = torch.zeros(Bn, T, 2 * H, dtype=BF, device=dev)
+    cs = torch.zeros(Bn, T, 2 * H, device=dev)
+    dG = torch.zeros(Bn, T, 2, 4 * H, dtype=BF, device=dev)
+    dc = torch.zeros(2 * Bn * H, device=dev)
+    whh_d, whhT_d = whh.to(dev).contiguous(), whh.transpose(1, 2).contiguous().to(dev)
+    L.call("sehip_dmx_lstm_fwd", pre_d.data_ptr(), whh_d.data_ptr(), Bn, T, H, hs.data_ptr(), cs.data_ptr(), None)
+    L.call("sehip_dmx_lstm_bwd", pre_d.data_ptr(), whhT_d.data_ptr(), cs.data_ptr(), dh.to(dev).data_ptr(), Bn, T, H, dG.data_ptr(), dc.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rel_err(hs.float().cpu(), hs_ref.detach()) < 4e-3
+    assert rel_err(dG.float().cpu(), dpre_ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,T,hid", [(2, 50, 32), (1, 187, 256), (3, 33, 64)])
+def test_local_state_attention(B, T, hid):
+    """The attention between LocalState's 1x1 convolutions against the oracle's local_state (identity convolutions feed it the same
+    query / key / content / decay rows): output and the gradient of every row."""
+    L = _lib()
+    heads, nd = 4, 4
+    g = torch.Generator().manual_seed(T + hid)
+    nq = 3 * hid + heads * nd
+    qkv = torch.randn(B, T, nq, generator=g).to(BF)
+    dres = torch.randn(B, T, hid, generator=g).to(BF)
+    x = qkv.float().requires_grad_(True)
+    xc = x.transpose(1, 2)                                                         # [B, nq, T]
+    q, k, content, raw = xc[:, :hid], xc[:, hid:2 * hid], xc[:, 2 * hid:3 * hid], xc[:, 3 * hid:]
+    idx = torch.arange(T, dtype=torch.float32)
+    delta = idx[:, None] - idx[None, :]
+    qh, kh = q.reshape(B, heads, -1, T), k.reshape(B, heads, -1, T)
+    dots = torch.einsum("bhct,bhcs->bhts", kh, qh) / kh.shape[2] ** 0.5
+    dq = torch.sigmoid(raw.reshape(B, heads, -1, T)) / 2
+    kern = -torch.arange(1, nd + 1, dtype=torch.float32).view(-1, 1, 1) * delta.abs() / nd ** 0.5
+    dots = dots + torch.einsum("fts,bhfs->bhts", kern, dq)
+    dots = dots.masked_fill(torch.eye(T, dtype=torch.bool), -100.0)
+    w = torch.softmax(dots, dim=2)
+    res = torch.einsum("bhts,bhct->bhcs", w, content.reshape(B, heads, -1, T)).reshape(B, -1, T)
+    dref, = torch.autograd.grad((res * dres.float().transpose(1, 2)).sum(), [x])
+    dev = "cuda"
+    qd = qkv.to(dev)
+    out = torch.zeros(B, T, hid, dtype=BF, device=dev)
+    dqkv = torch.zeros(B, T, nq, device=dev)
+    L.call("sehip_dmx_attn_fwd", qd.data_ptr(), B, T, hid, heads, nd, nq, out.data_ptr(), None)
+    L.call("sehip_dmx_attn_bwd", qd.data_ptr(), dres.to(dev).data_ptr(), B, T, hid, heads, nd, nq, dqkv.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu(), res.detach().transpose(1, 2)) < 4e-3
+    got = dqkv.cpu()
+    for name, a, b in (("query", 0, hid), ("key", hid, 2 * hid), ("content", 2 * hid, 3 * hid), ("decay", 3 * hid, nq)):
+        assert rel_err(got[..., a:b], dref[..., a:b]) < 5e-3, name
+
+
+@pytest.mark.parametrize("ac,S,resample,normalize,T", [(2, 2, True, True, 5000), (1, 1, True, False, 3001), (2, 1, False, True, 4000)])
+def test_prep_and_post(ac, S, resample, normalize, T):
+    """normalise + pad + x2 up-sampling, and /2 down-sampling + de-normalise + center_trim with its gradient, against the oracle's
+    restated julius resampler."""
+    from sehip import plan_demucs as P
+    L = _lib()
+    cfg = P.DemucsConfig(sources=["s"] * S, audio_channels=ac, channels=32, depth=4, resample=resample, normalize=normalize)
+    g = torch.Generator().manual_seed(T)
+    B = 2
+    mix = 0.3 * torch.randn(B, ac, T, generator=g) + 0.1
+    Tv = cfg.valid_length(T)
+    padl = (Tv - T) // 2
+    Tin = 2 * Tv if resample else Tv
+    x = mix
+    mean, std = 0.0, 1.0
+    if normalize:
+        mono = mix.mean(1, keepdim=True)
+        mean, std = mono.mean(-1, keepdim=True), mono.std(-1, keepdim=True)
+        x = (x - mean) / (1e-5 + std)
+    x = F.pad(x, (padl, Tv - T - padl))
+    if resample:
+        x = DM.resample_frac(x, 1, 2)
+    dev = "cuda"
+    ms = torch.zeros(B, 2, device=dev)
+    xb = torch.zeros(B, Tin, cfg.acp, dtype=BF, device=dev)
+    kup = kdn = None
+    wup = wdn = klu = kld = 0
+    if resample:
+        ku, wup = P.resample_kernels(1, 2)
+        kd, wdn = P.resample_kernels(2, 1)
+        kup, kdn = torch.from_numpy(ku.reshape(-1)).to(dev), torch.from_numpy(kd.reshape(-1)).to(dev)
+        klu, kld = ku.shape[1], kd.shape[1]
+    L.call("sehip_dmx_prep", mix.to(dev).data_ptr(), B, ac, cfg.acp, T, padl, Tv, int(normalize), int(resample), _ptr(kup), wup, klu, ms.data_ptr(),
+           xb.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rel_err(xb.float().cpu()[..., :ac], x.transpose(1, 2)) < 4e-3
+    assert float(xb.float()[..., ac:].abs().max()) == 0 if cfg.acp > ac else True
+    # post: a random network output y [B, Tin, cop] -> out [B, S*ac, T]
+    co, cop = cfg.co, cfg.cop
+    y = torch.randn(B, Tin, cop, generator=g)
+    yl = y[..., :co].transpose(1, 2).clone().requires_grad_(True)              # [B, co, Tin]
+    z = DM.resample_frac(yl, 2, 1) if resample else yl
+    z = z * std + mean
+    z = DM.center_trim(z, T)
+    dout = torch.randn(B, co, T, generator=g)
+    dy_ref, = torch.autograd.grad((z * dout).sum(), [yl])
+    out = torch.zeros(B, co, T, device=dev)
+    dy = torch.zeros(B, Tin, cop, dtype=BF, device=dev)
+    L.call("sehip_dmx_post", y.to(dev).data_ptr(), ms.data_ptr(), B, co, cop, Tin, padl, T, int(resample), _ptr(kdn), wdn, kld, out.data_ptr(), None)
+    L.call("sehip_dmx_post_bwd", dout.to(dev).data_ptr(), ms.data_ptr(), B, co, cop, Tin, padl, T, int(resample), _ptr(kdn), wdn, kld, dy.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), z.detach()) < 1e-5
+    assert rel_err(dy.float().cpu()[..., :co], dy_ref.transpose(1, 2)) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# API surface
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_registry_state_dict_and_limits():
+    from sehip import distrib
+    from sehip._lib import SehipError
+    from sehip.utils import dict2obj
+    model = distrib.get_model(dict2obj(dict(SMALL, name="demucs")))
+    cfg = DM.DemucsConfig(**SMALL)
+    assert [k for k, _ in model.named_parameters()] == [n for n, _ in DM.param_shapes(cfg)]
+    sd = {k: v + 1 for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)                                   # (the reference's key migration, src/model/demucs.py:492-501, finds nothing to move)
+    assert all(torch.equal(v, sd[k]) for k, v in model.state_dict().items())
+    assert model.valid_length(6000) == cfg.valid_length(6000)
+    with pytest.raises(SehipError):
+        model(torch.zeros(1, 2, 6000))                         # CPU tensor
+    model = model.cuda()
+    with pytest.raises(SehipError):
+        model(torch.zeros(1, 2, 60000, device="cuda"))          # 470 frames at the first BLSTM: chunking is not built
+    with pytest.raises(SehipError):
+        distrib.get_model(dict2obj(dict(SMALL, name="demucs", dconv_mode=3)))
+
+
+def c3_config(tmp):
+    from sehip.utils import dict2obj
+    return dict2obj({
+        "seed": 10, "root": None, "ha": None,
+        "model": {"name": "demucs", "audio_channels": 2, "num_spk": 1, "sources": ["clean"], "samplerate": 48000, "segment": 2},
+        "optim": {"optim": "adam", "lr": 3e-4, "beta1": 0.9, "beta2": 0.999, "loss": "si-sdr", "clip_grad": 5, "pit": False, "load": False},
+        "dset": {"name": "synthetic"},
+        "solver": {"epochs": 1, "save_checkpoint_interval": 1000, "all_steps": True, "total_steps": 0, "patience": 0,
+                   "root": str(tmp), "resume": None, "preloaded_model": None,
+                   "validation": {"interval": 1000, "metric": "loss", "total_steps": 0}, "test": {"interval": 1000}},
+    })
+
+
+def test_c3_shape_solver_steps(tmp_path):
+    """BASELINE config C3: 48 kHz stereo 2-s clips (96000 samples), batch 16, the default network: three Solver steps through the
+    registry; the loss is finite and goes down, and the network output of the first 2 clips equals the oracle's."""
+    from sehip.train import main
+    from sehip.solver import ScalarLog
+    g = torch.Generator().manual_seed(0)
+    clean = 0.1 * torch.randn(16, 1, 2, 96000, generator=g)
+    mix = clean[:, 0] + 0.05 * torch.randn(16, 2, 96000, generator=g)
+    batches = [(mix, clean, [None], [None], ["x"], [0])] * 3
+    log = ScalarLog()
+    solver = main(c3_config(tmp_path), return_solver=True, device="gpu", train_dataloader=batches, validation_dataloader=[batches[0]], writer=log)
+    p = {k: v.detach().cpu().clone() for k, v in solver.model.state_dict().items()}
+    solver._run_one_epoch(0, 1, train=True)
+    losses = [v for (t, v, _s) in log.scalars if t == "Train/Loss_step"]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[2] < losses[0]
+    solver.model.load_state_dict(p)
+    with torch.no_grad():
+        est = solver.model(mix[:2].cuda())
+        ref = DM.demucs_forward(p, mix[:2], DM.DemucsConfig(sources=["clean"], audio_channels=2))
+    assert tuple(est.shape) == (2, 1, 2, 96000) and rel_err(est.cpu(), ref) < 2e-2
+    print("C3 losses", losses, "oracle loss on 2 clips", float(O.loss_sisdr(ref, clean[:2])))
