@@ -51,6 +51,7 @@ class Demucs(FlatModule):
         self.audio_channels, self.sources, self.kernel_size, self.context, self.stride, self.depth = audio_channels, sources, kernel_size, context, stride, depth
         self.resample, self.channels, self.normalize, self.samplerate, self.segment = resample, channels, normalize, samplerate, segment
         self._tables = None
+        self.grad_range_hook = None   # data-parallel: called with (lo, hi, stream) when flat_grads[lo:hi] is final (plan_demucs.backward)
         self._ws_cap = max(1, int(os.environ.get("SEHIP_WS_CACHE", "2")))
         self._build_flat(list_roots=("encoder", "decoder"))
         self.reset_parameters()
@@ -120,7 +121,8 @@ class Demucs(FlatModule):
 
     def _run_backward(self, ws, grad_out):
         g = grad_out.contiguous().float()
-        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst))
+        hook = self.grad_range_hook if not (self._grads_live and self._params[0][1].grad is not None) else None   # not when accumulating
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, range_ready=hook))
 
     def forward(self, mix):
         if mix.dim() != 3 or mix.shape[1] != self.audio_channels:

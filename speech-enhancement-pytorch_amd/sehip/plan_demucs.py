@@ -485,6 +485,7 @@ class DemucsWorkspace:
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
         self.dc = torch.zeros(2 * B * max([ls["H"] for ls in st.lstms] + [1]), dtype=torch.float32, device=device)
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        self.comm = None     # third stream: early un-pack + all-reduce of finished gradient ranges (data-parallel runs only)
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self._bind()
 
@@ -665,10 +666,29 @@ class DemucsWorkspace:
              st.wdn if up else 0, st.kdn.shape[1] if up else 0, ptr(self.out), stream())
         return self.out
 
-    def backward(self, dout, params, grads):
-        """dout [B, S, ac, T] fp32 -> flat parameter gradients (overwritten)."""
+    def _hand_over(self, lo, hi, grads, range_ready):
+        """Data-parallel hook: grads[lo:hi] is final once the chain and the weight-gradient stream have drained as they stand
+        now; it is un-packed on a third stream, which waits for both, and handed to range_ready(lo, hi, stream) -- the
+        exchange of the decoder's 63 M and the deepest encoder layers' gradients then runs under the rest of the backward pass."""
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(device=self.device)
+        cs = self.comm.cuda_stream
+        call("sehip_stream_depend", cs, stream(), self._event())
+        if self.side is not None:
+            call("sehip_stream_depend", cs, self.side.cuda_stream, self._event())
+        call("sehip_unpack_grad", ptr(self.gpack), self.tb.utab.data_ptr() + 16 * lo, hi - lo, grads.data_ptr() + 4 * lo, cs)
+        range_ready(lo, hi, self.comm)
+
+    def backward(self, dout, params, grads, range_ready=None):
+        """dout [B, S, ac, T] fp32 -> flat parameter gradients (overwritten).
+        range_ready(lo, hi, stream): called as soon as grads[lo:hi] is final ON `stream` (a torch stream); the ranges tile
+        [0, n_params): the decoder's parameters after the decoder's backward pass, then the encoder layers that hold at least
+        5 % of the parameters one by one, the remainder at the end."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, D = self.B, cfg.depth
+        n_params = st.layout.n_params
+        enc_off = [st.layout.param_off[f"encoder.{i}.0.weight"][0] for i in range(D)] + [st.layout.param_off["decoder.0.0.weight"][0]]
+        done_from = n_params
         up = 1 if cfg.resample else 0
         self.gpack.zero_()
         self.sums.zero_()
@@ -687,6 +707,9 @@ class DemucsWorkspace:
             self.gemm(k + "rw.dg")
         top = f"d{D - 1}.din"
         call("sehip_dmx_add", b[top].ptr, b[top].ptr, b[top].t.numel(), b[f"e{D - 1}.dout"].ptr, stream())
+        if range_ready is not None:
+            self._hand_over(enc_off[D], n_params, grads, range_ready)
+            done_from = enc_off[D]
         for i in range(D - 1, -1, -1):
             e = f"e{i}."
             self._norm_bwd(e + "n3", params, e + "dout", e + "dyr")
@@ -727,7 +750,13 @@ class DemucsWorkspace:
             self.wgrad(e + "conv")
             if i > 0:
                 self.gemm(e + "conv.dg")
+            if range_ready is not None and i > 0 and enc_off[i + 1] - enc_off[i] >= 0.05 * n_params and done_from == enc_off[i + 1]:
+                self._hand_over(enc_off[i], done_from, grads, range_ready)
+                done_from = enc_off[i]
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
+        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), done_from, ptr(grads), stream())
+        if range_ready is not None:
+            range_ready(0, done_from, torch.cuda.current_stream())
+            call("sehip_stream_depend", stream(), self.comm.cuda_stream, self._event())
         return grads
