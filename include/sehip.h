@@ -329,6 +329,10 @@ int sehip_dmx_act_bwd(const void* dz, const void* y, const double* stats, const 
                       const float* scale, int B, int T, int C, double* sums, float* gch, void* dy, void* stream);
 int sehip_dmx_add(const void* a, const void* b, long n, void* out, void* stream);
 int sehip_dmx_f32_to_bf16(const float* a, long n, void* out, void* stream);
+/* BLSTM's overlapping chunks (:91-117; unfold :17-32): nf = ceil(T / S) chunks of W = 2 S frames at hop S per item (nf == 1: W == T).
+ * mode 0: out [B nf][W][C] = chunks of a [B][T][C] (zero beyond T); 1: out [B][T][C] = the middle part of each chunk of a [B nf][W][C] + b [B][T][C];
+ * 2: adjoint of 1 (a [B][T][C] -> out [B nf][W][C]); 3: adjoint of 0 plus b (a [B nf][W][C], b [B][T][C] -> out [B][T][C]).  bf16. */
+int sehip_dmx_frames(int mode, const void* a, const void* b, int B, int T, int C, int nf, int W, int S, void* out, void* stream);
 int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, int H, void* hs, float* cs, void* stream);
 int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const float* cs, const void* dhs, int Bn, int T, int H, void* dG, float* dc,
                        void* stream);

@@ -400,6 +400,56 @@ __global__ __launch_bounds__(256) void dmx_add_kernel(const bf16_raw* __restrict
     }
 }
 
+// BLSTM's overlapping chunks (src/model/demucs.py:91-117): W frames at hop S, nf = ceil(T / S) chunks per item (nf == 1: W == T, the
+// whole sequence).  mode 0 gather : out[b nf + k][j] = a[b][S k + j] (0 beyond T)                                  (unfold :17-32)
+//                   mode 1 pick   : out[b][t] = a[b nf + k(t)][t - S k(t)] + b[b][t], k(t) = the chunk whose middle part holds t (:104-117)
+//                   mode 2 select : out[b nf + k][j] = (k == k(t)) ? a[b][t] : 0, t = S k + j                       (adjoint of pick)
+//                   mode 3 sum    : out[b][t] = b[b][t] + sum_k a[b nf + k][t - S k]                               (adjoint of gather)
+__device__ __forceinline__ int chunk_of(int t, int nf, int W, int S) {
+    if (nf == 1 || t < W - S / 2) return 0;
+    const int k = (t - S / 2) / S;
+    return k < nf ? k : nf - 1;
+}
+__global__ __launch_bounds__(256) void dmx_frames_kernel(int mode, const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b2, int B, int T, int C,
+                                                         int nf, int W, int S, bf16_raw* __restrict__ out) {
+    const int nq = C >> 3;
+    const bool framed_out = mode == 0 || mode == 2;
+    const long total = (framed_out ? (long)B * nf * W : (long)B * T) * nq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % nq);
+        const long r = i / nq;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (framed_out) {
+            const int j = (int)(r % W), k = (int)((r / W) % nf), b = (int)(r / ((long)W * nf));
+            const int t = S * k + j;
+            if (t < T && (mode == 0 || chunk_of(t, nf, W, S) == k)) {
+                const D8 x = ld8(a + ((long)b * T + t) * C + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x.v[e];
+            }
+        } else {
+            const int t = (int)(r % T), b = (int)(r / T);
+            const D8 x = ld8(b2 + r * C + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = x.v[e];
+            if (mode == 1) {
+                const int k = chunk_of(t, nf, W, S);
+                const D8 y = ld8(a + (((long)b * nf + k) * W + (t - S * k)) * C + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += y.v[e];
+            } else {
+                for (int k = t / S; k >= 0 && k >= t / S - 1; --k) {
+                    if (k >= nf || t - S * k >= W) continue;
+                    const D8 y = ld8(a + (((long)b * nf + k) * W + (t - S * k)) * C + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += y.v[e];
+                }
+            }
+        }
+        st8(out + r * C + 8 * q, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void dmx_f32_to_bf16_kernel(const float* __restrict__ a, long n, bf16_raw* __restrict__ out) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = f2bf(a[i]);
 }
@@ -767,6 +817,20 @@ extern "C" int sehip_dmx_add(const void* a, const void* b, long n, void* out, vo
     if (g > 4096) g = 4096;
     dmx_add_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)a, (const bf16_raw*)b, n / 8, (bf16_raw*)out);
     SEHIP_CHECK_LAUNCH("dmx_add");
+    return 0;
+}
+
+extern "C" int sehip_dmx_frames(int mode, const void* a, const void* b, int B, int T, int C, int nf, int W, int S, void* out, void* stream) {
+    SEHIP_REQUIRE(mode >= 0 && mode <= 3 && B > 0 && T > 0 && C >= 8 && (C & 7) == 0 && nf >= 1 && W >= 1 && S >= 1,
+                  "dmx_frames: bad arguments (mode=%d B=%d T=%d C=%d nf=%d W=%d S=%d)", mode, B, T, C, nf, W, S);
+    SEHIP_REQUIRE(nf == 1 ? W == T : (W == 2 * S && (S & 1) == 0 && (long)S * (nf - 1) < T && T <= (long)S * nf),
+                  "dmx_frames: %d chunks of %d frames at hop %d do not tile %d frames", nf, W, S, T);
+    SEHIP_REQUIRE(mode == 0 || mode == 2 || b, "dmx_frames: modes 1 and 3 add a second tensor");
+    const long total = ((mode == 0 || mode == 2) ? (long)B * nf * W : (long)B * T) * (C >> 3);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    dmx_frames_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(mode, (const bf16_raw*)a, (const bf16_raw*)b, B, T, C, nf, W, S, (bf16_raw*)out);
+    SEHIP_CHECK_LAUNCH("dmx_frames");
     return 0;
 }
 

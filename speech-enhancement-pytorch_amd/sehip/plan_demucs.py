@@ -12,7 +12,8 @@ Activations are channels-last bf16 ``[B][T][C]``.  Every convolution / linear la
     convolutions of LocalState that read x (query | key | content | decay: one product) and its projection: dense.
 Residual / skip additions ride in product epilogues (descriptor field `res`) or in the activation kernels.  Everything else is
 csrc/demucs.hip.  Built: the constructor defaults' structure (rewrite, GLU, GELU, context=1, kernel 8 / stride 4, DConv in the
-encoder, no central LSTM); BLSTM chunking (sequences longer than max_steps = 200 frames at an LSTM layer) is NOT built.
+encoder, no central LSTM).  The BLSTM's overlapping chunks (sequences longer than max_steps = 200 frames, :91-117) are a gather
+before and a pick after the LSTM products (sehip_dmx_frames): the LSTM then runs on B * ceil(T / 100) sequences of 200 frames.
 """
 import ctypes as C
 import math
@@ -179,8 +180,9 @@ class Prod:
     """One product of the engine (batch- and length-independent part).  src / dst: (buffer name, quad view?); tt: (level, extra)
     = number of row frames T[level] + extra; rows: [(frame offset, channel offset)] one per 8-channel chunk of K."""
 
-    def __init__(self, name, rows, widx, src, dst, tt, bias=None, res=None, kind="fwd", dout=None, ntab_base=0, wg_only=False):
+    def __init__(self, name, rows, widx, src, dst, tt, bias=None, res=None, kind="fwd", dout=None, ntab_base=0, wg_only=False, framed=False):
         self.name, self.src, self.dst, self.tt, self.res, self.kind, self.dout, self.wg_only = name, src, dst, tt, res, kind, dout, wg_only
+        self.framed = framed     # rows are the BLSTM's chunks: B * nf items of W frames instead of B items of T[level] frames
         self.ktab, self.K = pad_ktab([(0, fo, 0, co) for fo, co in rows])
         n, k0 = widx.shape
         self.N, self.Npad = n, npad_of(n)
@@ -211,7 +213,7 @@ class DemucsStatic:
         if L.n_params >= 2 ** 30:
             raise SehipError("sehip Demucs: more than 2^30 parameters do not fit the 32-bit packing tables")
         self.prods = {}
-        self.buffers = {}        # name -> (level, channels, dtype)   level -1 = the network input length
+        self.buffers = {}        # name -> (level, channels, dtype, framed)   level -1 = the network input length
         self.norms = []          # (key, y buffer, C, G or 0, mode, gamma name, beta name, scale name)
         self.lstms, self.attns = [], []
         self.gch = {}            # norm key -> offset of {dgamma | dbeta | dscale} in the packed gradients
@@ -220,8 +222,8 @@ class DemucsStatic:
         chans = cfg.layer_channels()
         D = cfg.depth
 
-        def buf(name, level, c, dtype=BF16):
-            self.buffers[name] = (level, c, dtype)
+        def buf(name, level, c, dtype=BF16, framed=False):
+            self.buffers[name] = (level, c, dtype, framed)
 
         def prod(*a, **k):
             p = Prod(*a, **k)
@@ -229,13 +231,15 @@ class DemucsStatic:
             self.prods[p.name] = p
             return p
 
-        def dense(name, wname, bname, src, dst, level, res=None, dg_src=None, dg_dst=None, dg_res=None, dout=None):
+        def dense(name, wname, bname, src, dst, level, res=None, dg_src=None, dg_dst=None, dg_res=None, dout=None, framed=False):
             """1x1 convolution / linear layer: forward and (optionally) input-gradient products"""
             w = ia(wname)
             w = w.reshape(w.shape[0], w.shape[1])
-            prod(name, _chunks(0, 0, w.shape[1]), w, (src, False), (dst, False), (level, 0), bias=ia(bname) if bname else None, res=res, dout=dout)
+            prod(name, _chunks(0, 0, w.shape[1]), w, (src, False), (dst, False), (level, 0), bias=ia(bname) if bname else None, res=res, dout=dout,
+                 framed=framed)
             if dg_src is not None:
-                prod(name + ".dg", _chunks(0, 0, w.shape[0]), w.T.copy(), (dg_src, False), (dg_dst, False), (level, 0), res=dg_res, kind="dgrad")
+                prod(name + ".dg", _chunks(0, 0, w.shape[0]), w.T.copy(), (dg_src, False), (dg_dst, False), (level, 0), res=dg_res, kind="dgrad",
+                     framed=framed)
 
         def conv3(name, wname, bname, src, dst, level, dil, dg_src, dg_dst, dg_res=None, dout=None):
             w = ia(wname)                                       # [N][Cin][3]
@@ -291,23 +295,26 @@ class DemucsStatic:
                     b = f"{p}{lay['lstm']}."
                     for nm, c_, dt in (("pre0", 8 * hid, torch.float32), ("pre1", 8 * hid, torch.float32), ("hs0", 2 * hid, BF16), ("hs1", 2 * hid, BF16),
                                        ("cs0", 2 * hid, torch.float32), ("cs1", 2 * hid, torch.float32), ("dG0", 8 * hid, BF16), ("dG1", 8 * hid, BF16),
-                                       ("dhs0", 2 * hid, BF16), ("dhs1", 2 * hid, BF16), ("h2", hid, BF16), ("dh2", hid, BF16)):
-                        buf(k + nm, i, c_, dt)
+                                       ("dhs0", 2 * hid, BF16), ("dhs1", 2 * hid, BF16), ("fr", hid, BF16), ("dfr", hid, BF16), ("h2f", hid, BF16),
+                                       ("dh2f", hid, BF16)):
+                        buf(k + nm, i, c_, dt, framed=True)
+                    buf(k + "h2", i, hid); buf(k + "dh2", i, hid)
                     for l in range(2):
                         wih = np.concatenate([ia(f"{b}lstm.weight_ih_l{l}"), ia(f"{b}lstm.weight_ih_l{l}_reverse")])          # [8H][in]
                         bias = np.stack([np.concatenate([ia(f"{b}lstm.bias_ih_l{l}"), ia(f"{b}lstm.bias_ih_l{l}_reverse")]),
                                          np.concatenate([ia(f"{b}lstm.bias_hh_l{l}"), ia(f"{b}lstm.bias_hh_l{l}_reverse")])], axis=1)
-                        src_l = k + "h1" if l == 0 else k + "hs0"
-                        prod(f"{k}ih{l}", _chunks(0, 0, wih.shape[1]), wih, (src_l, False), (f"{k}pre{l}", False), (i, 0), bias=bias, dout=f"{k}dG{l}")
-                        dst_l = k + "dh1" if l == 0 else k + "dhs0"
-                        prod(f"{k}ih{l}.dg", _chunks(0, 0, 8 * hid), wih.T.copy(), (f"{k}dG{l}", False), (dst_l, False), (i, 0),
-                             res=k + "dh2" if l == 0 else None, kind="dgrad")
+                        src_l = k + "fr" if l == 0 else k + "hs0"
+                        prod(f"{k}ih{l}", _chunks(0, 0, wih.shape[1]), wih, (src_l, False), (f"{k}pre{l}", False), (i, 0), bias=bias, dout=f"{k}dG{l}",
+                             framed=True)
+                        dst_l = k + "dfr" if l == 0 else k + "dhs0"
+                        prod(f"{k}ih{l}.dg", _chunks(0, 0, 8 * hid), wih.T.copy(), (f"{k}dG{l}", False), (dst_l, False), (i, 0), kind="dgrad", framed=True)
                         for dr, sfx in enumerate(("", "_reverse")):
                             # dW_hh = sum_t dG[t]^T h[t -+ 1]: weight-gradient product only
                             prod(f"{k}hh{l}.{dr}", _chunks(1 if dr else -1, dr * hid, hid), ia(f"{b}lstm.weight_hh_l{l}{sfx}"), (f"{k}hs{l}", False),
-                                 (f"{k}dG{l}", False), (i, 0), dout=f"{k}dG{l}", ntab_base=dr * 4 * hid, wg_only=True)
-                    dense(k + "lin", b + "linear.weight", b + "linear.bias", k + "hs1", k + "h2", i, res=k + "h1", dg_src=k + "dh2", dg_dst=k + "dhs1",
-                          dout=k + "dh2")
+                                 (f"{k}dG{l}", False), (i, 0), dout=f"{k}dG{l}", ntab_base=dr * 4 * hid, wg_only=True, framed=True)
+                    # (the skip connection h2 = Linear(...) + h1 is added where the chunks are put back together)
+                    dense(k + "lin", b + "linear.weight", b + "linear.bias", k + "hs1", k + "h2f", i, dg_src=k + "dh2f", dg_dst=k + "dhs1",
+                          dout=k + "dh2f", framed=True)
                     self.lstms.append(dict(key=k, level=i, H=hid, pre=b))
                     last, dlast = k + "h2", k + "dh2"
                 if "attn" in lay:
@@ -467,15 +474,20 @@ class DemucsWorkspace:
             n = (n - 8) // 4 + 1
             lens.append(n)
         self.lens = lens                     # T_i = frames of encoder i's output; level -1 = Tin
-        for ls in st.lstms:
-            if lens[ls["level"]] > MAX_STEPS:
-                raise SehipError(f"Demucs: {lens[ls['level']]} frames at the BLSTM of layer {ls['level']}: the overlapping chunks of "
-                                 f"max_steps={MAX_STEPS} (src/model/demucs.py:91-117) are not built; use clips of at most "
-                                 f"{self._max_clip()} samples")
+        # BLSTM chunks per level: (nf chunks per item, W frames each, hop S); a sequence of at most max_steps frames is one chunk
+        self.chunks = [(math.ceil(n / (MAX_STEPS // 2)), MAX_STEPS, MAX_STEPS // 2) if n > MAX_STEPS else (1, n, n) for n in lens]
+        for a in st.attns:
+            if lens[a["level"]] > 580:
+                raise SehipError(f"Demucs: {lens[a['level']]} frames at the LocalState attention of layer {a['level']}: the score tile of all keys "
+                                 f"does not fit the LDS (at most 580 frames)")
         self.bufs = {}
-        for name, (level, c, dt) in st.buffers.items():
+        for name, (level, c, dt, framed) in st.buffers.items():
             frames = self.Tin if level < 0 else lens[level]
-            self.bufs[name] = Buf(torch.zeros(B, frames, 1, c, dtype=dt, device=device), frames, 1, c)
+            items = B
+            if framed:
+                nf, frames, _ = self.chunks[level]
+                items = B * nf
+            self.bufs[name] = Buf(torch.zeros(items, frames, 1, c, dtype=dt, device=device), frames, 1, c)
         self.ms = torch.zeros(B, 2, dtype=torch.float32, device=device)
         self.out = torch.zeros(B, cfg.S, cfg.audio_channels, T, dtype=torch.float32, device=device)
         nn_ = len(st.norms)
@@ -483,19 +495,11 @@ class DemucsWorkspace:
         self.stats = torch.zeros(nn_, B, 8, 2, dtype=torch.float64, device=device)
         self.sums = torch.zeros(nn_, B, 8, 2, dtype=torch.float64, device=device)
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
-        self.dc = torch.zeros(2 * B * max([ls["H"] for ls in st.lstms] + [1]), dtype=torch.float32, device=device)
+        self.dc = torch.zeros(2 * B * max([ls["H"] * self.chunks[ls["level"]][0] for ls in st.lstms] + [1]), dtype=torch.float32, device=device)
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self.comm = None     # third stream: early un-pack + all-reduce of finished gradient ranges (data-parallel runs only)
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self._bind()
-
-    def _max_clip(self):
-        cfg = self.st.cfg
-        lvl = min(ls["level"] for ls in self.st.lstms)
-        n = MAX_STEPS
-        for _ in range(lvl + 1):
-            n = (n - 1) * 4 + 8
-        return n // 2 if cfg.resample else n
 
     def close(self):
         if self.closed:
@@ -537,13 +541,17 @@ class DemucsWorkspace:
             d.dst[0].toff, d.dst[0].fmul, d.dst[0].fadd, d.dst[0].tmul = 0, 1, 0, 1
             d.dst[0].is_f32 = 1 if ob.t.dtype == torch.float32 else 0
             tt = (self.Tin if p.tt[0] < 0 else self.lens[p.tt[0]]) + p.tt[1]
+            items = B
+            if p.framed:
+                nf, tt, _ = self.chunks[p.tt[0]]
+                items = B * nf
             assert tt <= oT, (name, tt, oT)
             d.ktab = self.ktab_dev.data_ptr() + 16 * p.kt_off
             d.ntab = tb.ntab.data_ptr() + 16 * p.nt_off
             d.W = tb.wpack.data_ptr() + 2 * p.w_off
             if p.b_off is not None:
                 d.bias = tb.bpack.data_ptr() + 4 * p.b_off
-            d.M, d.N, d.Npad, d.K = B * tt, p.N, p.Npad, p.K
+            d.M, d.N, d.Npad, d.K = items * tt, p.N, p.Npad, p.K
             d.TT, d.J, d.fmul, d.tmul = tt, 1, 1, 1
             if p.res is not None:
                 rb = self.bufs[p.res]
@@ -636,11 +644,15 @@ class DemucsWorkspace:
                 last = k + "h1"
                 if (k + "ih0") in st.prods:
                     H, T = b[k + "h1"].C, b[k + "h1"].Tst
+                    nf, W, S = self.chunks[i]
+                    call("sehip_dmx_frames", 0, b[k + "h1"].ptr, None, B, T, H, nf, W, S, b[k + "fr"].ptr, stream())
                     for l in range(2):
                         self.gemm(f"{k}ih{l}")
                         woff = st.whh[(k, l)][0]
-                        call("sehip_dmx_lstm_fwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, B, T, H, b[f"{k}hs{l}"].ptr, b[f"{k}cs{l}"].ptr, stream())
+                        call("sehip_dmx_lstm_fwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, B * nf, W, H, b[f"{k}hs{l}"].ptr,
+                             b[f"{k}cs{l}"].ptr, stream())
                     self.gemm(k + "lin")
+                    call("sehip_dmx_frames", 1, b[k + "h2f"].ptr, b[k + "h1"].ptr, B, T, H, nf, W, S, b[k + "h2"].ptr, stream())
                     last = k + "h2"
                 if (k + "qkv") in st.prods:
                     hid, T = b[k + "r"].C, b[k + "r"].Tst
@@ -732,17 +744,22 @@ class DemucsWorkspace:
                     self.gemm(k + "qkv.dg")
                 if (k + "ih0") in st.prods:
                     H, T = b[k + "h1"].C, b[k + "h1"].Tst
+                    nf, W, S = self.chunks[i]
+                    call("sehip_dmx_frames", 2, b[k + "dh2"].ptr, None, B, T, H, nf, W, S, b[k + "dh2f"].ptr, stream())
+                    self._chain_dirty = True
                     self.wgrad(k + "lin")
                     self.gemm(k + "lin.dg")
                     for l in (1, 0):
                         woff = st.whh[(k, l)][1]
-                        call("sehip_dmx_lstm_bwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, b[f"{k}cs{l}"].ptr, b[f"{k}dhs{l}"].ptr, B, T, H,
+                        call("sehip_dmx_lstm_bwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, b[f"{k}cs{l}"].ptr, b[f"{k}dhs{l}"].ptr, B * nf, W, H,
                              b[f"{k}dG{l}"].ptr, ptr(self.dc), stream())
                         self._chain_dirty = True
                         self.wgrad(f"{k}ih{l}")
                         self.wgrad(f"{k}hh{l}.0")
                         self.wgrad(f"{k}hh{l}.1")
                         self.gemm(f"{k}ih{l}.dg")
+                    call("sehip_dmx_frames", 3, b[k + "dfr"].ptr, b[k + "dh2"].ptr, B, T, H, nf, W, S, b[k + "dh1"].ptr, stream())
+                    self._chain_dirty = True
                 self._norm_bwd(k + "n1", params, k + "dh1", k + "dy1")
                 self.wgrad(k + "c1")
                 self.gemm(k + "c1.dg")

@@ -108,6 +108,64 @@ def test_chain_attention_without_lstm_and_deeper_dconv():
     check_chain(r, "attention from layer 1, LSTM from layer 3, DConv depth 3", est_tol=2e-2)    # (no normalisation: est is the raw last layer)
 
 
+def test_chain_with_chunked_blstm():
+    """[2, 2, 16000]: 500 frames at the first BLSTM layer (> max_steps = 200): the LSTM runs on 2 x 5 overlapping chunks of 200 frames
+    (src/model/demucs.py:91-117), 124 frames (one chunk) at the second."""
+    r = run_chain(dict(SMALL), 2, 16000, 13)
+    assert r["ws"].chunks[2] == (5, 200, 100) and r["ws"].chunks[3][0] == 1 and r["ws"].bufs["e2.d0.pre0"].t.shape[0] == 10
+    check_chain(r, "chunked BLSTM (500 frames)")
+
+
+@pytest.mark.parametrize("T,C", [(201, 32), (500, 8), (437, 64), (150, 16)])
+def test_chunk_gather_pick_and_adjoints(T, C):
+    """sehip_dmx_frames against the oracle's unfold / middle-part concatenation (src/model/demucs.py:17-32, :104-117) and their adjoints."""
+    import math
+    L = _lib()
+    g = torch.Generator().manual_seed(T)
+    B = 2
+    nf, W, S = (math.ceil(T / 100), 200, 100) if T > 200 else (1, T, T)
+    x = torch.randn(B, T, C, generator=g).to(BF)
+    skip = torch.randn(B, T, C, generator=g).to(BF)
+    xl = x.float().transpose(1, 2).requires_grad_(True)                                      # [B, C, T]
+    if nf > 1:
+        fr = DM.unfold(xl, W, S)                                                               # [B, C, nf, W]
+        fr_ref = fr.permute(0, 2, 3, 1).reshape(B * nf, W, C)
+    else:
+        fr_ref = xl.transpose(1, 2)
+    dev = "cuda"
+    xd, skd = x.to(dev), skip.to(dev)           # (named: a temporary's storage would be re-used by the next allocation)
+    frames = torch.zeros(B * nf, W, C, dtype=BF, device=dev)
+    L.call("sehip_dmx_frames", 0, xd.data_ptr(), None, B, T, C, nf, W, S, frames.data_ptr(), None)
+    assert torch.equal(frames.float().cpu(), fr_ref.detach())
+    y = torch.randn(B * nf, W, C, generator=g).to(BF)
+    yl = y.float().requires_grad_(True)
+    if nf > 1:
+        f4 = yl.reshape(B, nf, W, C).permute(0, 1, 3, 2)                                       # [B, nf, C, W]
+        lim = S // 2
+        parts = [f4[:, k, :, :-lim] if k == 0 else f4[:, k, :, lim:] if k == nf - 1 else f4[:, k, :, lim:-lim] for k in range(nf)]
+        picked = torch.cat(parts, -1)[..., :T].transpose(1, 2)
+    else:
+        picked = yl
+    want = picked + skip.float()
+    out = torch.zeros(B, T, C, dtype=BF, device=dev)
+    yd = y.to(dev)
+    L.call("sehip_dmx_frames", 1, yd.data_ptr(), skd.data_ptr(), B, T, C, nf, W, S, out.data_ptr(), None)
+    assert rel_err(out.float().cpu(), want.detach()) < 4e-3
+    d = torch.randn(B, T, C, generator=g).to(BF)
+    dy_ref, = torch.autograd.grad((picked * d.float()).sum(), [yl])
+    sel = torch.zeros(B * nf, W, C, dtype=BF, device=dev)
+    dd = d.to(dev)
+    L.call("sehip_dmx_frames", 2, dd.data_ptr(), None, B, T, C, nf, W, S, sel.data_ptr(), None)
+    assert torch.equal(sel.float().cpu(), dy_ref)
+    dfr = torch.randn(B * nf, W, C, generator=g).to(BF)
+    dx_ref, = torch.autograd.grad((fr_ref * dfr.float()).sum(), [xl])
+    got = torch.zeros(B, T, C, dtype=BF, device=dev)
+    dfd = dfr.to(dev)
+    L.call("sehip_dmx_frames", 3, dfd.data_ptr(), skd.data_ptr(), B, T, C, nf, W, S, got.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rel_err(got.float().cpu(), dx_ref.transpose(1, 2) + skip.float()) < 4e-3
+
+
 def test_full_width_default_network():
     """The C3 network (channels 64, depth 6, every default; 133.7 M parameters) on [1, 2, 24000] against the oracle: forward taps,
     output, and every parameter gradient under a fixed upstream gradient."""
@@ -204,7 +262,8 @@ def test_bidirectional_lstm_layer(Bn, T, H):
     dc = torch.zeros(2 * Bn * H, device=dev)
     whh_d, whhT_d = whh.to(dev).contiguous(), whh.transpose(1, 2).contiguous().to(dev)
     L.call("sehip_dmx_lstm_fwd", pre_d.data_ptr(), whh_d.data_ptr(), Bn, T, H, hs.data_ptr(), cs.data_ptr(), None)
-    L.call("sehip_dmx_lstm_bwd", pre_d.data_ptr(), whhT_d.data_ptr(), cs.data_ptr(), dh.to(dev).data_ptr(), Bn, T, H, dG.data_ptr(), dc.data_ptr(), None)
+    dh_d = dh.to(dev)
+    L.call("sehip_dmx_lstm_bwd", pre_d.data_ptr(), whhT_d.data_ptr(), cs.data_ptr(), dh_d.data_ptr(), Bn, T, H, dG.data_ptr(), dc.data_ptr(), None)
     torch.cuda.synchronize()
     assert rel_err(hs.float().cpu(), hs_ref.detach()) < 4e-3
     assert rel_err(dG.float().cpu(), dpre_ref) < 1.5e-2
@@ -239,7 +298,8 @@ def test_local_state_attention(B, T, hid):
     out = torch.zeros(B, T, hid, dtype=BF, device=dev)
     dqkv = torch.zeros(B, T, nq, device=dev)
     L.call("sehip_dmx_attn_fwd", qd.data_ptr(), B, T, hid, heads, nd, nq, out.data_ptr(), None)
-    L.call("sehip_dmx_attn_bwd", qd.data_ptr(), dres.to(dev).data_ptr(), B, T, hid, heads, nd, nq, dqkv.data_ptr(), None)
+    dres_d = dres.to(dev)
+    L.call("sehip_dmx_attn_bwd", qd.data_ptr(), dres_d.data_ptr(), B, T, hid, heads, nd, nq, dqkv.data_ptr(), None)
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu(), res.detach().transpose(1, 2)) < 4e-3
     got = dqkv.cpu()
@@ -279,7 +339,8 @@ def test_prep_and_post(ac, S, resample, normalize, T):
         kd, wdn = P.resample_kernels(2, 1)
         kup, kdn = torch.from_numpy(ku.reshape(-1)).to(dev), torch.from_numpy(kd.reshape(-1)).to(dev)
         klu, kld = ku.shape[1], kd.shape[1]
-    L.call("sehip_dmx_prep", mix.to(dev).data_ptr(), B, ac, cfg.acp, T, padl, Tv, int(normalize), int(resample), _ptr(kup), wup, klu, ms.data_ptr(),
+    mix_d = mix.to(dev)
+    L.call("sehip_dmx_prep", mix_d.data_ptr(), B, ac, cfg.acp, T, padl, Tv, int(normalize), int(resample), _ptr(kup), wup, klu, ms.data_ptr(),
            xb.data_ptr(), None)
     torch.cuda.synchronize()
     assert rel_err(xb.float().cpu()[..., :ac], x.transpose(1, 2)) < 4e-3
@@ -295,8 +356,9 @@ def test_prep_and_post(ac, S, resample, normalize, T):
     dy_ref, = torch.autograd.grad((z * dout).sum(), [yl])
     out = torch.zeros(B, co, T, device=dev)
     dy = torch.zeros(B, Tin, cop, dtype=BF, device=dev)
-    L.call("sehip_dmx_post", y.to(dev).data_ptr(), ms.data_ptr(), B, co, cop, Tin, padl, T, int(resample), _ptr(kdn), wdn, kld, out.data_ptr(), None)
-    L.call("sehip_dmx_post_bwd", dout.to(dev).data_ptr(), ms.data_ptr(), B, co, cop, Tin, padl, T, int(resample), _ptr(kdn), wdn, kld, dy.data_ptr(), None)
+    y_d, dout_d = y.to(dev), dout.to(dev)
+    L.call("sehip_dmx_post", y_d.data_ptr(), ms.data_ptr(), B, co, cop, Tin, padl, T, int(resample), _ptr(kdn), wdn, kld, out.data_ptr(), None)
+    L.call("sehip_dmx_post_bwd", dout_d.data_ptr(), ms.data_ptr(), B, co, cop, Tin, padl, T, int(resample), _ptr(kdn), wdn, kld, dy.data_ptr(), None)
     torch.cuda.synchronize()
     assert rel_err(out.cpu(), z.detach()) < 1e-5
     assert rel_err(dy.float().cpu()[..., :co], dy_ref.transpose(1, 2)) < 4e-3
@@ -320,7 +382,7 @@ def test_registry_state_dict_and_limits():
         model(torch.zeros(1, 2, 6000))                         # CPU tensor
     model = model.cuda()
     with pytest.raises(SehipError):
-        model(torch.zeros(1, 2, 60000, device="cuda"))          # 470 frames at the first BLSTM: chunking is not built
+        model(torch.zeros(1, 2, 80000, device="cuda"))          # 2500 frames at the first LocalState: its score tile does not fit the LDS
     with pytest.raises(SehipError):
         distrib.get_model(dict2obj(dict(SMALL, name="demucs", dconv_mode=3)))
 
