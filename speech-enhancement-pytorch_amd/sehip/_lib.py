@@ -95,8 +95,9 @@ _PROTOS = {
     "sehip_dmx_add": [P, P, L, P, P],
     "sehip_dmx_f32_to_bf16": [P, L, P, P],
     "sehip_dmx_frames": [I, P, P, I, I, I, I, I, I, P, P],
-    "sehip_dmx_lstm_fwd": [P, P, I, I, I, P, P, P],
-    "sehip_dmx_lstm_bwd": [P, P, P, P, I, I, I, P, P, P],
+    "sehip_dmx_lstm_sync_bytes": [],
+    "sehip_dmx_lstm_fwd": [P, P, I, I, I, P, P, P, P],
+    "sehip_dmx_lstm_bwd": [P, P, P, P, I, I, I, P, P, P, P],
     "sehip_dmx_attn_fwd": [P, I, I, I, I, I, I, P, P],
     "sehip_dmx_attn_bwd": [P, P, I, I, I, I, I, I, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],

@@ -9,6 +9,7 @@
 // per-channel gradient sums stay in registers.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -545,6 +546,204 @@ __global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same layer as ONE persistent launch: the workgroups of a (direction, batch tile) group -- H/16 of them, each owning 16 hidden
+// units with its W_hh slice resident in registers -- hand h(t) (forward) / the gate gradients (backward) to each other through
+// global memory once per time step.  Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the table of
+// sc1 hand-offs): every handed-off byte is stored with an 8-byte agent-scope relaxed atomic store (sc1: write-through), every
+// storing wave drains vmcnt, a workgroup barrier, ONE lane adds to the group's arrival counter (agent-scope atomic); the consumer's
+// lane 0 polls that counter with sc1 loads (bounded spin: a time-out sets sync[TMO] and lets the kernel run to its end with
+// garbage instead of hanging), a workgroup barrier, then EVERY load of handed-off bytes is an 8-byte sc1 load to registers.
+// No fence, no L2 write-back.  Results never depend on placement; for speed the members of a group are given equal
+// workgroup-id % 8 (one XCD under round-robin dispatch).  The host wrapper zeroes the sync block before every launch and falls
+// back to the per-step launches when the active workgroups could not all be resident (> 256) or H/32 is not 1, 2, 4, 8 or 16.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define DMX_SYNC_WORDS 64          // sync block: [0, 60) arrival counters of the groups, [60] time-out word
+#define DMX_TMO 60
+#define DMX_SPIN_LIMIT (1u << 20)  // polls of >= 0.3 us each: a fraction of a second, once (the time-out is sticky)
+
+struct SeqMap { int dir, bz, member; bool active; };
+__device__ __forceinline__ SeqMap seq_map(int nb, int btiles) {
+    const int id = blockIdx.x, lab = id & 7, slot = id >> 3;
+    const int group = lab + 8 * (slot / nb);
+    SeqMap m;
+    m.member = slot % nb;
+    m.active = group < 2 * btiles;
+    m.dir = group & 1;
+    m.bz = group >> 1;
+    return m;
+}
+// lane 0 of wave 0 waits until the group's counter has reached `target`, then the workgroup barrier
+__device__ __forceinline__ void group_wait(gu32* cnt, unsigned target, gu32* tmo, bool& dead) {
+    if (threadIdx.x == 0 && !dead) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, RLX_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > DMX_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(tmo, RLX_AGENT) != 0)) {
+                __hip_atomic_store(tmo, 1u, RLX_AGENT);
+                dead = true;      // give up for the rest of the sequence: garbage out, but the launch ends
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+// N 16-byte sc1 loads (buffer_load_dwordx4 ... sc1: L1 bypassed, tracked by the compiler's vmcnt bookkeeping) of the elements
+// base[off + stride * k ..+7]; rsrc describes the whole tensor (wave-uniform), offsets are per lane.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int N>
+__device__ __forceinline__ void ld16_sc1_n(__amdgpu_buffer_rsrc_t rsrc, long off_elems, int stride_elems, uint4 (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((off_elems + (long)stride_elems * k) * 2), 0, 16);
+        v[k] = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void dmx_lstm_seq_fwd_kernel(float* __restrict__ pre, const bf16_raw* __restrict__ whh, bf16_raw* hs,
+                                                               float* __restrict__ cs, int Bn, int T, int btiles, unsigned* sync) {
+    constexpr int H = 32 * KS;
+    __shared__ float gl[4][16][17];
+    __shared__ __attribute__((aligned(16))) bf16_raw hrow[16][16];
+    __shared__ uint4 afr[KS >= 4 ? KS : 1][64];
+    const SeqMap sm = seq_map(H / 16, btiles);
+    if (!sm.active) return;
+    const int dir = sm.dir, u0 = sm.member * 16, bt = sm.bz * 16, nb = H / 16;
+    gu32* cnt = (gu32*)sync + (sm.bz * 2 + dir);
+    gu32* tmo = (gu32*)sync + DMX_TMO;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, ug = lane >> 4;
+    bf16x8 wf[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+        wf[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(whh + ((long)(dir * 4 + w) * H + u0 + m) * H + 32 * k + 8 * ug));
+    const int row = threadIdx.x >> 4, u = threadIdx.x & 15, b = bt + row;
+    const bool bok = b < Bn;
+    const int brow = bt + m < Bn ? bt + m : Bn - 1;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(hs, 0, (int)((long)Bn * T * 2 * H * 2), 0x00020000);
+    float c = 0.f;
+    bool dead = false;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+        float* pg = pre + (((long)(bok ? b : Bn - 1) * T + t) * 2 + dir) * 4 * H + u0 + u;
+        const float p0 = pg[0], p1 = pg[H], p2 = pg[2 * H], p3 = pg[3 * H];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            group_wait(cnt, (unsigned)(nb * s), tmo, dead);
+            const long hp = ((long)brow * T + tp) * 2 * H + dir * H + 8 * ug;
+            uint4 av[KS];
+            if constexpr (KS >= 4) {
+                // the four gate waves need the same h fragments: each fetches a quarter, they meet in LDS
+                uint4 part[KS / 4];
+                ld16_sc1_n<KS / 4>(rsrc, hp + 32 * (KS / 4) * w, 32, part);
+#pragma unroll
+                for (int k = 0; k < KS / 4; ++k) afr[(KS / 4) * w + k][lane] = part[k];
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < KS; ++k) av[k] = afr[k][lane];
+            } else {
+                ld16_sc1_n<KS>(rsrc, hp, 32, av);
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                if (bt + m >= Bn) av[k] = make_uint4(0, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[k]), wf[k], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gl[w][4 * ug + r][m] = acc[r];
+        __syncthreads();
+        const float gi = sigm(p0 + gl[0][row][u]), gf = sigm(p1 + gl[1][row][u]), gg = tanhf(p2 + gl[2][row][u]), go = sigm(p3 + gl[3][row][u]);
+        c = gf * c + gi * gg;
+        const bf16_raw hb = f2bf(go * tanhf(c));
+        hrow[row][u] = hb;
+        if (bok) {
+            cs[((long)b * T + t) * 2 * H + dir * H + u0 + u] = c;
+            pg[0] = gi; pg[H] = gf; pg[2 * H] = gg; pg[3 * H] = go;
+        }
+        __syncthreads();
+        if (w == 0) {       // publish the 16 x 16 tile: one 8-byte write-through store per lane, drain, signal
+            const int r = lane >> 2, part = lane & 3;
+            if (bt + r < Bn)
+                __hip_atomic_store((gu64*)(hs + ((long)(bt + r) * T + t) * 2 * H + dir * H + u0 + 4 * part),
+                                   *reinterpret_cast<const unsigned long long*>(&hrow[r][4 * part]), RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, RLX_AGENT);
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __restrict__ gates, const bf16_raw* __restrict__ whhT,
+                                                               const float* __restrict__ cs, const bf16_raw* __restrict__ dhs, bf16_raw* dG,
+                                                               int Bn, int T, int btiles, unsigned* sync) {
+    constexpr int H = 32 * KS;
+    __shared__ float pl[4][16][17];
+    __shared__ __attribute__((aligned(16))) bf16_raw dgt[4][16][16];
+    const SeqMap sm = seq_map(H / 16, btiles);
+    if (!sm.active) return;
+    const int dir = sm.dir, u0 = sm.member * 16, bt = sm.bz * 16, nb = H / 16;
+    gu32* cnt = (gu32*)sync + (sm.bz * 2 + dir);
+    gu32* tmo = (gu32*)sync + DMX_TMO;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, ug = lane >> 4;
+    bf16x8 wf[KS];      // W_hh^T rows u0 + m, K quarter of gate w
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+        wf[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(whhT + ((long)dir * H + u0 + m) * 4 * H + w * H + 32 * k + 8 * ug));
+    const int row = threadIdx.x >> 4, u = threadIdx.x & 15, b = bt + row;
+    const bool bok = b < Bn;
+    const int bc = bok ? b : Bn - 1;
+    const int brow = bt + m < Bn ? bt + m : Bn - 1;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dG, 0, (int)((long)Bn * T * 8 * H * 2), 0x00020000);
+    float dcs = 0.f;
+    bool dead = false;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s, tn = dir ? t - 1 : t + 1, tp = dir ? t + 1 : t - 1;
+        const bool has_prev = dir ? (t < T - 1) : (t > 0);
+        const long o = ((long)bc * T + t) * 2 * H + dir * H + u0 + u;
+        const float* pg = gates + (((long)bc * T + t) * 2 + dir) * 4 * H + u0 + u;
+        const float gi = pg[0], gf = pg[H], gg = pg[2 * H], go = pg[3 * H];
+        const float c = cs[o], cp = has_prev ? cs[((long)bc * T + tp) * 2 * H + dir * H + u0 + u] : 0.f;
+        const float dh_up = bf2f(dhs[o]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            group_wait(cnt, (unsigned)(nb * s), tmo, dead);
+            const long ap = (((long)brow * T + tn) * 2 + dir) * 4 * H + w * H + 8 * ug;
+            uint4 av[KS];
+            ld16_sc1_n<KS>(rsrc, ap, 32, av);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                if (bt + m >= Bn) av[k] = make_uint4(0, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[k]), wf[k], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[w][4 * ug + r][m] = acc[r];
+        __syncthreads();
+        const float dh = dh_up + pl[0][row][u] + pl[1][row][u] + pl[2][row][u] + pl[3][row][u];
+        const float tc = tanhf(c);
+        const float dcc = dh * go * (1.f - tc * tc) + dcs;
+        dcs = dcc * gf;
+        dgt[0][row][u] = f2bf(dcc * gg * gi * (1.f - gi));
+        dgt[1][row][u] = f2bf(dcc * cp * gf * (1.f - gf));
+        dgt[2][row][u] = f2bf(dcc * gi * (1.f - gg * gg));
+        dgt[3][row][u] = f2bf(dh * tc * go * (1.f - go));
+        __syncthreads();
+        {   // wave w publishes the tile of gate w: one 8-byte write-through store per lane; every wave drains; barrier; one lane signals
+            const int r = lane >> 2, part = lane & 3;
+            if (bt + r < Bn)
+                __hip_atomic_store((gu64*)(dG + (((long)(bt + r) * T + t) * 2 + dir) * 4 * H + w * H + u0 + 4 * part),
+                                   *reinterpret_cast<const unsigned long long*>(&dgt[w][r][4 * part]), RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, RLX_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // LocalState attention.  qkv bf16 [B][T][NQ]: query [0, hid) | key [hid, 2 hid) | content [2 hid, 3 hid) | decay [3 hid, 3 hid + heads nd).
 // One workgroup = one (batch, head, tile of QT queries) and ALL keys; scores live in LDS as sc[t][QT].
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -843,22 +1042,70 @@ extern "C" int sehip_dmx_f32_to_bf16(const float* a, long n, void* out, void* st
     return 0;
 }
 
-// the whole layer: T step launches
-extern "C" int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, int H, void* hs, float* cs, void* stream) {
+// the whole layer: ONE persistent launch where its workgroups can all be resident, otherwise (or with sync == NULL) T step launches
+template <int KS>
+static void lstm_seq_fwd_launch(dim3 g, hipStream_t st, float* pre, const void* whh, void* hs, float* cs, int Bn, int T, int btiles, unsigned* sync) {
+    dmx_lstm_seq_fwd_kernel<KS><<<g, 256, 0, st>>>(pre, (const bf16_raw*)whh, (bf16_raw*)hs, cs, Bn, T, btiles, sync);
+}
+template <int KS>
+static void lstm_seq_bwd_launch(dim3 g, hipStream_t st, const float* gates, const void* whhT, const float* cs, const void* dhs, void* dG, int Bn, int T,
+                                int btiles, unsigned* sync) {
+    dmx_lstm_seq_bwd_kernel<KS><<<g, 256, 0, st>>>(gates, (const bf16_raw*)whhT, cs, (const bf16_raw*)dhs, (bf16_raw*)dG, Bn, T, btiles, sync);
+}
+static bool lstm_seq_ok(int Bn, int T, int H, const unsigned* sync) {
+    static const bool off = getenv("SEHIP_DMX_LSTM_STEPS") != nullptr;
+    const int ks = H / 32, btiles = (Bn + 15) / 16;
+    return sync && !off && (ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16) && 2 * btiles * (H / 16) <= 256 && 2 * btiles <= DMX_TMO &&
+           (long)Bn * T * 8 * H * 2 < (1L << 31);      // 32-bit byte offsets into the handed-off tensors
+}
+extern "C" int sehip_dmx_lstm_sync_bytes(void) { return DMX_SYNC_WORDS * 4; }
+
+extern "C" int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, int H, void* hs, float* cs, unsigned* sync, void* stream) {
     SEHIP_REQUIRE(Bn > 0 && T > 0 && H >= 32 && (H & 31) == 0, "dmx_lstm_fwd: hidden size H=%d must be a multiple of 32 (Bn=%d T=%d)", H, Bn, T);
-    const dim3 g(H / 16, 2, (Bn + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    const int btiles = (Bn + 15) / 16;
+    if (lstm_seq_ok(Bn, T, H, sync)) {
+        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_SYNC_WORDS * 4, st) == hipSuccess, "dmx_lstm_fwd: clearing the sync block failed");
+        const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
+        switch (H / 32) {
+            case 1: lstm_seq_fwd_launch<1>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
+            case 2: lstm_seq_fwd_launch<2>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
+            case 4: lstm_seq_fwd_launch<4>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
+            case 8: lstm_seq_fwd_launch<8>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
+            default: lstm_seq_fwd_launch<16>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
+        }
+        SEHIP_CHECK_LAUNCH("dmx_lstm_seq_fwd");
+        return 0;
+    }
+    const dim3 g(H / 16, 2, btiles);
     for (int s = 0; s < T; ++s)
-        dmx_lstm_step_fwd_kernel<<<g, 256, 0, (hipStream_t)stream>>>(pre, (const bf16_raw*)whh, (bf16_raw*)hs, cs, Bn, T, H, s);
+        dmx_lstm_step_fwd_kernel<<<g, 256, 0, st>>>(pre, (const bf16_raw*)whh, (bf16_raw*)hs, cs, Bn, T, H, s);
     SEHIP_CHECK_LAUNCH("dmx_lstm_fwd");
     return 0;
 }
 
 extern "C" int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const float* cs, const void* dhs, int Bn, int T, int H, void* dG, float* dc,
-                                  void* stream) {
+                                  unsigned* sync, void* stream) {
     SEHIP_REQUIRE(Bn > 0 && T > 0 && H >= 32 && (H & 31) == 0, "dmx_lstm_bwd: hidden size H=%d must be a multiple of 32", H);
-    const dim3 g(H / 16, 2, (Bn + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    const int btiles = (Bn + 15) / 16;
+    if (lstm_seq_ok(Bn, T, H, sync)) {
+        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_SYNC_WORDS * 4, st) == hipSuccess, "dmx_lstm_bwd: clearing the sync block failed");
+        const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
+        switch (H / 32) {
+            case 1: lstm_seq_bwd_launch<1>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;
+            case 2: lstm_seq_bwd_launch<2>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;
+            case 4: lstm_seq_bwd_launch<4>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;
+            case 8: lstm_seq_bwd_launch<8>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;
+            default: lstm_seq_bwd_launch<16>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;
+        }
+        SEHIP_CHECK_LAUNCH("dmx_lstm_seq_bwd");
+        return 0;
+    }
+    SEHIP_REQUIRE(dc, "dmx_lstm_bwd: the per-step path needs the cell-gradient scratch");
+    const dim3 g(H / 16, 2, btiles);
     for (int s = 0; s < T; ++s)
-        dmx_lstm_step_bwd_kernel<<<g, 256, 0, (hipStream_t)stream>>>(gates, (const bf16_raw*)whhT, cs, (const bf16_raw*)dhs, (bf16_raw*)dG, dc, Bn, T, H, s);
+        dmx_lstm_step_bwd_kernel<<<g, 256, 0, st>>>(gates, (const bf16_raw*)whhT, cs, (const bf16_raw*)dhs, (bf16_raw*)dG, dc, Bn, T, H, s);
     SEHIP_CHECK_LAUNCH("dmx_lstm_bwd");
     return 0;
 }

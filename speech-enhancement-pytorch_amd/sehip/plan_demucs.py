@@ -496,6 +496,7 @@ class DemucsWorkspace:
         self.sums = torch.zeros(nn_, B, 8, 2, dtype=torch.float64, device=device)
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
         self.dc = torch.zeros(2 * B * max([ls["H"] * self.chunks[ls["level"]][0] for ls in st.lstms] + [1]), dtype=torch.float32, device=device)
+        self.lstm_sync = torch.zeros(int(_lib.lib().sehip_dmx_lstm_sync_bytes()) // 4, dtype=torch.int32, device=device)   # arrival counters + time-out word
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self.comm = None     # third stream: early un-pack + all-reduce of finished gradient ranges (data-parallel runs only)
         self._events, self._event_i, self._chain_dirty = [], 0, True
@@ -650,7 +651,7 @@ class DemucsWorkspace:
                         self.gemm(f"{k}ih{l}")
                         woff = st.whh[(k, l)][0]
                         call("sehip_dmx_lstm_fwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, B * nf, W, H, b[f"{k}hs{l}"].ptr,
-                             b[f"{k}cs{l}"].ptr, stream())
+                             b[f"{k}cs{l}"].ptr, ptr(self.lstm_sync), stream())
                     self.gemm(k + "lin")
                     call("sehip_dmx_frames", 1, b[k + "h2f"].ptr, b[k + "h1"].ptr, B, T, H, nf, W, S, b[k + "h2"].ptr, stream())
                     last = k + "h2"
@@ -752,7 +753,7 @@ class DemucsWorkspace:
                     for l in (1, 0):
                         woff = st.whh[(k, l)][1]
                         call("sehip_dmx_lstm_bwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, b[f"{k}cs{l}"].ptr, b[f"{k}dhs{l}"].ptr, B * nf, W, H,
-                             b[f"{k}dG{l}"].ptr, ptr(self.dc), stream())
+                             b[f"{k}dG{l}"].ptr, ptr(self.dc), ptr(self.lstm_sync), stream())
                         self._chain_dirty = True
                         self.wgrad(f"{k}ih{l}")
                         self.wgrad(f"{k}hh{l}.0")

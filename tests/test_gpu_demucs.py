@@ -231,10 +231,13 @@ def test_groupnorm_activation_family(mode, G, scaled, C):
         assert rel_err(gch[2 * C:].cpu(), refs[-1]) < 5e-3
 
 
-@pytest.mark.parametrize("Bn,T,H", [(2, 37, 32), (16, 50, 64), (19, 12, 256)])
-def test_bidirectional_lstm_layer(Bn, T, H):
-    """One bidirectional layer, forward and backward, through the step kernels against the oracle's recurrence (given the same
-    pre-gates and bf16 weights): h, and the pre-activation gate gradients of both directions."""
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("Bn,T,H", [(2, 37, 32), (16, 50, 64), (19, 12, 256), (16, 187, 512), (40, 200, 128), (5, 9, 96)])
+def test_bidirectional_lstm_layer(Bn, T, H, persistent):
+    """One bidirectional layer, forward and backward, against the oracle's recurrence (given the same pre-gates and bf16 weights): h,
+    and the pre-activation gate gradients of both directions -- as ONE persistent launch whose workgroups hand h(t) / the gate
+    gradients over once per step (its time-out word must stay clear; H = 96 has no persistent instantiation and falls back), and as
+    one launch per time step."""
     L = _lib()
     g = torch.Generator().manual_seed(H + T)
     whh = (torch.randn(2, 4 * H, H, generator=g) / H ** 0.5).to(BF)
@@ -261,10 +264,14 @@ def test_bidirectional_lstm_layer(Bn, T, H):
     dG = torch.zeros(Bn, T, 2, 4 * H, dtype=BF, device=dev)
     dc = torch.zeros(2 * Bn * H, device=dev)
     whh_d, whhT_d = whh.to(dev).contiguous(), whh.transpose(1, 2).contiguous().to(dev)
-    L.call("sehip_dmx_lstm_fwd", pre_d.data_ptr(), whh_d.data_ptr(), Bn, T, H, hs.data_ptr(), cs.data_ptr(), None)
-    dh_d = dh.to(dev)
-    L.call("sehip_dmx_lstm_bwd", pre_d.data_ptr(), whhT_d.data_ptr(), cs.data_ptr(), dh_d.data_ptr(), Bn, T, H, dG.data_ptr(), dc.data_ptr(), None)
+    sync = torch.zeros(L.lib().sehip_dmx_lstm_sync_bytes() // 4, dtype=torch.int32, device=dev) if persistent else None
+    L.call("sehip_dmx_lstm_fwd", pre_d.data_ptr(), whh_d.data_ptr(), Bn, T, H, hs.data_ptr(), cs.data_ptr(), _ptr(sync), None)
     torch.cuda.synchronize()
+    assert sync is None or int(sync[60]) == 0, "a hand-off spin timed out"
+    dh_d = dh.to(dev)
+    L.call("sehip_dmx_lstm_bwd", pre_d.data_ptr(), whhT_d.data_ptr(), cs.data_ptr(), dh_d.data_ptr(), Bn, T, H, dG.data_ptr(), dc.data_ptr(), _ptr(sync), None)
+    torch.cuda.synchronize()
+    assert sync is None or int(sync[60]) == 0, "a hand-off spin timed out"
     assert rel_err(hs.float().cpu(), hs_ref.detach()) < 4e-3
     assert rel_err(dG.float().cpu(), dpre_ref) < 1.5e-2
 
