@@ -34,6 +34,9 @@ int sehip_check_device(int device);
 void* sehip_event_create(void);
 int sehip_event_destroy(void* event);
 int sehip_stream_depend(void* to_stream, void* from_stream, void* event);
+/* the same in two halves: `stream`'s work so far is recorded now, another stream waits for it later */
+int sehip_event_record(void* event, void* stream);
+int sehip_stream_wait_event(void* stream, void* event);
 
 /* ---- STFT / iSTFT front-end: src/model/dccrn.py:649-747 (init_kernels, ConvSTFT, ConviSTFT) fused with the
  *      glue of DCCRN.forward src/model/dccrn.py:145-154 and :198-229 (mask E/C/R, clamp).  fft_len must be 512. */
@@ -317,7 +320,7 @@ int sehip_lstm_bwd_chunk(const void* dh_a_bf16, const void* dh_b_bf16, const voi
  *      attn_fwd  : LocalState (:210-269, nfreqs = 0) between its 1x1 convolutions: qkv bf16 [B][T][NQ] = query | key | content | decay
  *                  (heads*nd) columns -> out bf16 [B][T][hid];  attn_bwd: dqkv fp32 [B][T][NQ] += (caller zeroes) from dres bf16 [B][T][hid] */
 int sehip_dmx_prep(const float* mix, int B, int ac, int acp, int T, int padl, int Tv, int normalize, int up, const float* kup, int width,
-                   int KL, float* ms, void* x_bf16, void* stream);
+                   int KL, double* acc /*[B][2] scratch*/, float* ms, void* x_bf16, void* stream);
 int sehip_dmx_post(const float* y, const float* ms, int B, int co, int cop, long Tf, int padl, int T, int down, const float* kdn, int width,
                    int KL, float* out, void* stream);
 int sehip_dmx_post_bwd(const float* dout, const float* ms, int B, int co, int cop, long Tf, int padl, int T, int down, const float* kdn,

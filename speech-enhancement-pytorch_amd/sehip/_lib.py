@@ -31,6 +31,8 @@ _PROTOS = {
     "sehip_event_create": [],
     "sehip_event_destroy": [P],
     "sehip_stream_depend": [P, P, P],
+    "sehip_event_record": [P, P],
+    "sehip_stream_wait_event": [P, P],
     "sehip_stft_frames": [I, I, I],
     "sehip_stft_custom_frames": [I, I, I, I],
     "sehip_stft_custom_fwd": [P, I, I, I, I, I, I, P, P],
@@ -86,7 +88,7 @@ _PROTOS = {
     "sehip_ctn_gln_bwd_scratch_floats": [I, I, I],
     "sehip_ctn_decoder_fwd": [P, P, P, I, I, I, I, I, I, I, P, P],
     "sehip_ctn_decoder_bwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P],
-    "sehip_dmx_prep": [P, I, I, I, I, I, I, I, I, P, I, I, P, P, P],
+    "sehip_dmx_prep": [P, I, I, I, I, I, I, I, I, P, I, I, P, P, P, P],
     "sehip_dmx_post": [P, P, I, I, I, L, I, I, I, P, I, I, P, P],
     "sehip_dmx_post_bwd": [P, P, I, I, I, L, I, I, I, P, I, I, P, P],
     "sehip_dmx_gn_stats": [P, I, I, I, I, P, P],

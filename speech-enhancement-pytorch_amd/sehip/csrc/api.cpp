@@ -64,3 +64,18 @@ extern "C" int sehip_stream_depend(void* to_stream, void* from_stream, void* eve
     if (st != hipSuccess) return sehip_set_error(-2, "stream_depend: wait: %s", hipGetErrorString(st));
     return 0;
 }
+
+// the two halves of sehip_stream_depend, for a dependency that is recorded now and waited for later
+extern "C" int sehip_event_record(void* event, void* stream) {
+    if (!event) return sehip_set_error(-1, "event_record: null event");
+    hipError_t st = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    if (st != hipSuccess) return sehip_set_error(-2, "event_record: %s", hipGetErrorString(st));
+    return 0;
+}
+
+extern "C" int sehip_stream_wait_event(void* stream, void* event) {
+    if (!event) return sehip_set_error(-1, "stream_wait_event: null event");
+    hipError_t st = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+    if (st != hipSuccess) return sehip_set_error(-2, "stream_wait_event: %s", hipGetErrorString(st));
+    return 0;
+}

@@ -64,32 +64,36 @@ __device__ __forceinline__ void moments(const double* __restrict__ stats, int b,
 // ---------------------------------------------------------------------------------------------------------------------------
 // prep / post
 // ---------------------------------------------------------------------------------------------------------------------------
-// ms[b] = (mean, std) of the mono mix over time (unbiased std, src/model/demucs.py:457-461); normalize == 0: (0, 1)
-__global__ __launch_bounds__(256) void dmx_moments_kernel(const float* __restrict__ mix, int ac, int T, int normalize, float* __restrict__ ms) {
-    const int b = blockIdx.x;
+// acc[b] += (sum, sum of squares) of the mono mix over this workgroup's share of the clip (double atomics; the caller zeroes acc)
+__global__ __launch_bounds__(256) void dmx_moments_kernel(const float* __restrict__ mix, int ac, int T, double* __restrict__ acc) {
+    const int b = blockIdx.y;
     __shared__ double red[2][4];
     double s = 0, q = 0;
-    if (normalize) {
-        for (int t = threadIdx.x; t < T; t += 256) {
-            float m = 0.f;
-            for (int a = 0; a < ac; ++a) m += mix[((long)b * ac + a) * T + t];
-            m /= (float)ac;
-            s += m; q += (double)m * m;
-        }
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < T; t += (long)gridDim.x * 256) {
+        float m = 0.f;
+        for (int a = 0; a < ac; ++a) m += mix[((long)b * ac + a) * T + t];
+        m /= (float)ac;
+        s += m; q += (double)m * m;
     }
     s = wave_sum_d(s); q = wave_sum_d(q);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (!normalize) { ms[2 * b] = 0.f; ms[2 * b + 1] = 1.f; return; }
-        s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const double mean = s / T;
-        double var = (q - s * mean) / (T > 1 ? T - 1 : 1);
-        if (var < 0) var = 0;
-        ms[2 * b] = (float)mean;
-        ms[2 * b + 1] = (float)sqrt(var);
+        atomicAdd(&acc[2 * b], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&acc[2 * b + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
+}
+// ms[b] = (mean, unbiased std) of the mono mix (src/model/demucs.py:457-461); normalize == 0: (0, 1)
+__global__ void dmx_moments_finish_kernel(const double* __restrict__ acc, int B, int T, int normalize, float* __restrict__ ms) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (!normalize) { ms[2 * b] = 0.f; ms[2 * b + 1] = 1.f; return; }
+    const double s = acc[2 * b], q = acc[2 * b + 1];
+    const double mean = s / T;
+    double var = (q - s * mean) / (T > 1 ? T - 1 : 1);
+    if (var < 0) var = 0;
+    ms[2 * b] = (float)mean;
+    ms[2 * b + 1] = (float)sqrt(var);
 }
 
 // x[b][u][c] (bf16, acp channels, channels >= ac are zero).  up == 0: u indexes the padded signal; up == 1: u = 2 n + i and
@@ -929,10 +933,17 @@ static dim3 dmx_grid(int B, int T, int nq) {
 }
 
 extern "C" int sehip_dmx_prep(const float* mix, int B, int ac, int acp, int T, int padl, int Tv, int normalize, int up, const float* kup,
-                              int width, int KL, float* ms, void* x_bf16, void* stream) {
+                              int width, int KL, double* acc, float* ms, void* x_bf16, void* stream) {
     SEHIP_REQUIRE(B > 0 && ac > 0 && acp >= ac && T > 0 && Tv >= T + padl, "dmx_prep: bad sizes (B=%d ac=%d acp=%d T=%d padl=%d Tv=%d)", B, ac, acp, T, padl, Tv);
     SEHIP_REQUIRE(!up || (kup && KL > 0), "dmx_prep: up-sampling needs its kernels");
-    dmx_moments_kernel<<<B, 256, 0, (hipStream_t)stream>>>(mix, ac, T, normalize, ms);
+    if (normalize) {
+        SEHIP_REQUIRE(acc, "dmx_prep: normalize needs the accumulator scratch (2 doubles per item)");
+        SEHIP_REQUIRE(hipMemsetAsync(acc, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream) == hipSuccess, "dmx_prep: clearing the accumulators failed");
+        int gx = (T + 256 * 16 - 1) / (256 * 16);
+        if (gx > 64) gx = 64;
+        dmx_moments_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(mix, ac, T, acc);
+    }
+    dmx_moments_finish_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(acc, B, T, normalize, ms);
     const long T0 = up ? 2L * Tv : Tv;
     dmx_prep_kernel<<<dim3((unsigned)((T0 + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(mix, ms, kup, ac, acp, T, padl, Tv, up, width, KL,
                                                                                            (bf16_raw*)x_bf16);

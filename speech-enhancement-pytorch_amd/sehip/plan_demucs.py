@@ -365,22 +365,47 @@ class DemucsStatic:
         wa, ba, kta, nta = Arena(64), Arena(4), Arena(1), Arena(1)
         ga = self._ga
         self.whh = {}
+        # packed operands in three runs: what the forward pass reads (packed on the chain's stream at the start of the step) | what only
+        # the backward pass reads (packed on the second stream, under the forward pass) | the recurrent weights as weight-gradient
+        # placeholders (never read on the device: their table only feeds the un-packing map)
+        enc = lambda a: (a.astype(np.int64) << 1).astype(np.int32).reshape(-1)
+        hh = {}
+        for ls in self.lstms:
+            b = ls["pre"]
+            for l in range(2):
+                hh[(ls["key"], l)] = np.stack([ia(f"{b}lstm.weight_hh_l{l}"), ia(f"{b}lstm.weight_hh_l{l}_reverse")])    # [2][4H][H]
         for p in self.prods.values():
             p.kt_off = kta.add(p.ktab)
             p.nt_off = nta.add(p.ntab)
-            p.w_off = wa.add(p.wtab)
             if p.bias is not None:
                 p.b_off = ba.add(p.bias)
             if p.kind == "fwd":
                 p.dw_off = ga.reserve(p.Npad * p.K)
                 if p.bias is not None:
                     p.db_off = ga.reserve(p.Npad)
-        for ls in self.lstms:
-            b, H = ls["pre"], ls["H"]
-            for l in range(2):
-                w = np.stack([ia(f"{b}lstm.weight_hh_l{l}"), ia(f"{b}lstm.weight_hh_l{l}_reverse")])                # [2][4H][H]
-                enc = lambda a: (a.astype(np.int64) << 1).astype(np.int32).reshape(-1)
-                self.whh[(ls["key"], l)] = (wa.add(enc(w)), wa.add(enc(w.transpose(0, 2, 1))))
+        self.late_level = max(0, D - 2)          # the two deepest levels hold 94 % of the weights and are reached last
+        for p in self.prods.values():
+            if p.kind == "fwd" and not p.wg_only and p.tt[0] < self.late_level:
+                p.w_off = wa.add(p.wtab)
+        self.n_wpack_head = wa.size
+        for p in self.prods.values():
+            if p.kind == "fwd" and not p.wg_only and p.tt[0] >= self.late_level:
+                p.w_off = wa.add(p.wtab)
+        fwd_hh = {k: wa.add(enc(w)) for k, w in hh.items()}
+        self.n_wpack_fwd = wa.size
+        for p in self.prods.values():
+            if p.kind != "fwd" and p.tt[0] < self.late_level:
+                p.w_off = wa.add(p.wtab)
+        self.n_wpack_bwd_head = wa.size
+        for p in self.prods.values():
+            if p.kind != "fwd" and p.tt[0] >= self.late_level:
+                p.w_off = wa.add(p.wtab)
+        for k, w in hh.items():
+            self.whh[k] = (fwd_hh[k], wa.add(enc(w.transpose(0, 2, 1))))
+        self.n_wpack_dev = wa.size
+        for p in self.prods.values():
+            if p.wg_only:
+                p.w_off = wa.add(p.wtab)
         self.n_wpack, self.n_bpack, self.n_gpack = wa.size, max(ba.size, 4), ga.size
         self.wtab = wa.build(np.int32)
         self.btab = ba.build(np.int32, 2) if ba.size else np.full((4, 2), -1, dtype=np.int32)
@@ -489,6 +514,7 @@ class DemucsWorkspace:
                 items = B * nf
             self.bufs[name] = Buf(torch.zeros(items, frames, 1, c, dtype=dt, device=device), frames, 1, c)
         self.ms = torch.zeros(B, 2, dtype=torch.float32, device=device)
+        self.ms_acc = torch.zeros(B, 2, dtype=torch.float64, device=device)
         self.out = torch.zeros(B, cfg.S, cfg.audio_channels, T, dtype=torch.float32, device=device)
         nn_ = len(st.norms)
         self.norm_idx = {k: j for j, k in enumerate(st.norms)}
@@ -500,6 +526,7 @@ class DemucsWorkspace:
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self.comm = None     # third stream: early un-pack + all-reduce of finished gradient ranges (data-parallel runs only)
         self._events, self._event_i, self._chain_dirty = [], 0, True
+        self._held_events = []
         self._bind()
 
     def close(self):
@@ -507,9 +534,9 @@ class DemucsWorkspace:
             return
         self.closed = True
         lib = _lib.lib()
-        for e in self._events:
+        for e in self._events + self._held_events:
             lib.sehip_event_destroy(e)
-        self._events = []
+        self._events, self._held_events = [], []
 
     def __del__(self):
         try:
@@ -576,6 +603,15 @@ class DemucsWorkspace:
         self._chain_dirty = True
         call("sehip_gemm", C.byref(self.desc[name]), stream())
 
+    def _own_event(self, j):
+        """Events that stay recorded across many launches (the round-robin pool of _event() would re-use them)."""
+        while len(self._held_events) <= j:
+            e = _lib.lib().sehip_event_create()
+            if not e:
+                raise SehipError("sehip_event_create: " + _lib.lib().sehip_last_error().decode())
+            self._held_events.append(e)
+        return self._held_events[j]
+
     def _event(self):
         if not self._events:
             for _ in range(16):
@@ -627,14 +663,30 @@ class DemucsWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
         self.stats.zero_()
-        call("sehip_pack_bf16", ptr(params), ptr(tb.wtab), st.n_wpack, ptr(tb.wpack), stream())
+        # weight packing (134 M parameters in both operand orientations: 2.5 ms of table-driven gathers).  Only the shallow levels'
+        # forward operands are packed on the chain's stream; the two deepest levels' (94 % of the weights, reached after most of
+        # the encoder) go to the second stream under the shallow encoder levels, and the operands only the backward pass reads
+        # (the transposed copies) under the shallow decoder levels -- never beside the deep levels' own products, which are
+        # latency-bound and ran 3x slower next to a packing kernel.
+        two = self.side is not None and not torch.cuda.is_current_stream_capturing()
+        head = st.n_wpack_head if two else st.n_wpack_dev
+        call("sehip_pack_bf16", ptr(params), ptr(tb.wtab), head, ptr(tb.wpack), stream())
         call("sehip_pack_f32", ptr(params), ptr(tb.btab), st.n_bpack, ptr(tb.bpack), stream())
+        self._late_pack_event = self._bwd_pack_events = None
+        if two:
+            sd = self.side.cuda_stream
+            call("sehip_stream_depend", sd, stream(), self._event())
+            call("sehip_pack_bf16", ptr(params), tb.wtab.data_ptr() + 4 * head, st.n_wpack_fwd - head, tb.wpack.data_ptr() + 2 * head, sd)
+            self._late_pack_event = self._own_event(0)
+            call("sehip_event_record", self._late_pack_event, sd)
         up = 1 if cfg.resample else 0
         call("sehip_dmx_prep", ptr(mix), B, cfg.audio_channels, cfg.acp, self.T, self.padl, self.Tv, 1 if cfg.normalize else 0, up,
-             ptr(tb.kup) if up else None, st.wup if up else 0, st.kup.shape[1] if up else 0, ptr(self.ms), b["x"].ptr, stream())
+             ptr(tb.kup) if up else None, st.wup if up else 0, st.kup.shape[1] if up else 0, ptr(self.ms_acc), ptr(self.ms), b["x"].ptr, stream())
         D = cfg.depth
         for i in range(D):
             e = f"e{i}."
+            if i == st.late_level and self._late_pack_event is not None:
+                call("sehip_stream_wait_event", stream(), self._late_pack_event)
             self.gemm(e + "conv")
             self._norm_fwd(e + "n0", params, e + "a")
             xin = e + "a"
@@ -669,11 +721,15 @@ class DemucsWorkspace:
         call("sehip_dmx_add", b[top].ptr, b[top].ptr, b[top].t.numel(), b[f"d{D - 1}.in"].ptr, stream())
         for i in range(D - 1, -1, -1):
             k = f"d{i}."
+            if two and i == st.late_level - 1 or (two and st.late_level == 0 and i == 0 and self._bwd_pack_events is None):
+                self._pack_backward_operands(params)
             self.gemm(k + "rw")
             self._norm_fwd(k + "n0", params, k + "g")
             self.gemm(k + "ct")
             if i > 0:
                 self._norm_fwd(k + "n1", params, f"d{i - 1}.in", add=f"e{i - 1}.out")
+        if two and self._bwd_pack_events is None:
+            self._pack_backward_operands(params)
         yt = b["d0.yt"]
         call("sehip_dmx_post", yt.ptr, ptr(self.ms), B, cfg.co, cfg.cop, yt.Tst, self.padl, self.T, up, ptr(tb.kdn) if up else None,
              st.wdn if up else 0, st.kdn.shape[1] if up else 0, ptr(self.out), stream())
@@ -692,6 +748,19 @@ class DemucsWorkspace:
         call("sehip_unpack_grad", ptr(self.gpack), self.tb.utab.data_ptr() + 16 * lo, hi - lo, grads.data_ptr() + 4 * lo, cs)
         range_ready(lo, hi, self.comm)
 
+    def _pack_backward_operands(self, params):
+        """Second stream: the shallow levels' backward operands, then the deep levels' (an event after each)."""
+        st, tb, sd = self.st, self.tb, self.side.cuda_stream
+        a, m, z = st.n_wpack_fwd, st.n_wpack_bwd_head, st.n_wpack_dev
+        ev = []
+        for j, (lo, hi) in enumerate(((a, m), (m, z))):
+            if hi > lo:
+                call("sehip_pack_bf16", ptr(params), tb.wtab.data_ptr() + 4 * lo, hi - lo, tb.wpack.data_ptr() + 2 * lo, sd)
+            e = self._own_event(1 + j)
+            call("sehip_event_record", e, sd)
+            ev.append(e)
+        self._bwd_pack_events = ev
+
     def backward(self, dout, params, grads, range_ready=None):
         """dout [B, S, ac, T] fp32 -> flat parameter gradients (overwritten).
         range_ready(lo, hi, stream): called as soon as grads[lo:hi] is final ON `stream` (a torch stream); the ranges tile
@@ -706,11 +775,17 @@ class DemucsWorkspace:
         self.gpack.zero_()
         self.sums.zero_()
         self._chain_dirty = True
+        bwd_ev = getattr(self, "_bwd_pack_events", None)     # the backward operands were packed on the second stream
+        self._bwd_pack_events = None
+        if bwd_ev:
+            call("sehip_stream_wait_event", stream(), bwd_ev[0])
         yt = b["d0.dyt"]
         call("sehip_dmx_post_bwd", ptr(dout), ptr(self.ms), B, cfg.co, cfg.cop, yt.Tst, self.padl, self.T, up, ptr(tb.kdn) if up else None,
              st.wdn if up else 0, st.kdn.shape[1] if up else 0, yt.ptr, stream())
         for i in range(D):
             k = f"d{i}."
+            if bwd_ev and i == st.late_level:
+                call("sehip_stream_wait_event", stream(), bwd_ev[1])
             if i > 0:
                 self._norm_bwd(k + "n1", params, f"d{i - 1}.din", k + "dyt")
             self.wgrad(k + "ct")

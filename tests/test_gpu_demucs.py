@@ -347,7 +347,8 @@ def test_prep_and_post(ac, S, resample, normalize, T):
         kup, kdn = torch.from_numpy(ku.reshape(-1)).to(dev), torch.from_numpy(kd.reshape(-1)).to(dev)
         klu, kld = ku.shape[1], kd.shape[1]
     mix_d = mix.to(dev)
-    L.call("sehip_dmx_prep", mix_d.data_ptr(), B, ac, cfg.acp, T, padl, Tv, int(normalize), int(resample), _ptr(kup), wup, klu, ms.data_ptr(),
+    acc = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    L.call("sehip_dmx_prep", mix_d.data_ptr(), B, ac, cfg.acp, T, padl, Tv, int(normalize), int(resample), _ptr(kup), wup, klu, acc.data_ptr(), ms.data_ptr(),
            xb.data_ptr(), None)
     torch.cuda.synchronize()
     assert rel_err(xb.float().cpu()[..., :ac], x.transpose(1, 2)) < 4e-3

@@ -5,8 +5,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-# a step starts at every stft_fwd_kernel
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("stft_fwd_kernel")]
+# a step starts at every stft_fwd_kernel (or the kernel named in SEHIP_TRACE_START, e.g. dmx_prep_kernel for Demucs)
+import os
+first = os.environ.get("SEHIP_TRACE_START", "stft_fwd_kernel")
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(first)]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 3
 a, b = starts[which], starts[which + 1]
 step = rows[a:b]
@@ -31,3 +33,9 @@ for r in rs:
 print("main queue", mainq, "sum of gaps us", round(sum(g for g, _ in gaps if g > 0), 1))
 big = sorted(gaps, reverse=True)[:25]
 for g, n in big: print(f"  gap {g:7.1f} us before {n}")
+per = collections.defaultdict(lambda: [0, 0.0])
+for r in rs:
+    k = r["Kernel_Name"].split("(")[0][:48]
+    per[k][0] += 1; per[k][1] += (r["e"] - r["s"]) / 1e3
+print("main queue, time by kernel (us):")
+for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:22]: print(f"  {t:9.1f}  x{n:4d}  {k}")
