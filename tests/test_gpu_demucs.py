@@ -470,3 +470,21 @@ def test_gradient_ranges_for_the_data_parallel_exchange():
     err = rel_err(model.flat_grads.cpu(), want.cpu())
     print(f"Demucs gradient ranges {[(lo, hi) for lo, hi, _ in ranges]}: difference to the run without hook {err:.2e}, run-to-run {noise:.2e}")
     assert err < max(3 * noise, 2e-3)
+
+
+def test_bench_two_ranks_on_one_gpu_demucs():
+    """The data-parallel path with the full C3 network (535 MB of gradients): two processes sharing cuda:0 over gloo (RCCL refuses
+    two ranks on one device), gradient ranges handed to the all-reduce as the backward pass finishes them, 1/world folded into
+    the optimizer launch."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SEHIP_DIST_BACKEND="gloo", SEHIP_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--workload", "demucs", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+    assert out["final_loss"] == out["final_loss"]  # not NaN
