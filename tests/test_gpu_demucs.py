@@ -488,3 +488,29 @@ def test_bench_two_ranks_on_one_gpu_demucs():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["final_loss"] == out["final_loss"]  # not NaN
+
+
+def test_evaluate_with_the_hip_demucs():
+    """The chunked inference path (src/evaluate.py:10-98 -> sehip.evaluate.evaluate) with the HIP Demucs, a multi-source WAV model:
+    evaluate() == the model applied to each segment + the stitch rule; the eval-mode forward equals the oracle."""
+    import types
+    from sehip.evaluate import evaluate
+    from sehip.model import Demucs
+    torch.manual_seed(4)
+    kw = dict(SMALL, sources=["a"])
+    model = Demucs(**kw).cuda().eval()
+    x = 0.1 * torch.randn(2, 2, 6000 + 2 * 512 + 9, generator=torch.Generator().manual_seed(1))
+    m = types.SimpleNamespace(name="demucs", win_length=512, n_fft=512, hop_length=128, center=True, segment=0.375, sources=["a"])
+    c = types.SimpleNamespace(model=m, dset=types.SimpleNamespace(norm="z-score", sample_rate=16000))
+    y = evaluate(x, model, torch.device("cuda:0"), c)
+    assert tuple(y.shape) == (2, 1, 2, x.shape[-1])
+    mean, std = x.mean(-1, keepdim=True), x.std(-1, keepdim=True)
+    xn = ((x - mean) / (std + 1e-9)).cuda()
+    xp = torch.nn.functional.pad(xn, (0, 512 - 9))
+    with torch.no_grad():
+        segs = [model(xp[..., k * 512:k * 512 + 6000]) for k in range(4)]
+        ref0 = DM.demucs_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, xp[..., :6000].cpu(), DM.DemucsConfig(**kw))
+    assert rel_err(segs[0].cpu(), ref0) < 1e-2
+    want = torch.cat([segs[0]] + [s[..., -512:] for s in segs[1:]], -1)[..., :x.shape[-1]]
+    want = want * (std.unsqueeze(1).cuda() + 1e-9) + mean.unsqueeze(1).cuda()
+    assert rel_err(y.cpu(), want.cpu()) < 2e-3     # (run-to-run: the GroupNorm sums are atomics, bf16 roundings flip)
