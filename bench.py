@@ -404,6 +404,8 @@ def main():
         dt = float(t)
     ms = dt / args.steps * 1e3
     note(f"{ms:.2f} ms/step")
+    if dmx:
+        model.workspace(args.batch, n).check_lstm_handoffs()    # the timed steps are valid only if no hand-off spin gave up
     value = world * args.batch * clip_s * args.steps / dt
 
     out = {

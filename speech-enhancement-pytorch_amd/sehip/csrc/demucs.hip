@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __r
 // sc1 hand-offs): every handed-off byte is stored with an 8-byte agent-scope relaxed atomic store (sc1: write-through), every
 // storing wave drains vmcnt, a workgroup barrier, ONE lane adds to the group's arrival counter (agent-scope atomic); the consumer's
 // lane 0 polls that counter with sc1 loads (bounded spin: a time-out sets sync[TMO] and lets the kernel run to its end with
-// garbage instead of hanging), a workgroup barrier, then EVERY load of handed-off bytes is an 8-byte sc1 load to registers.
+// garbage instead of hanging; the word is sticky: the call clears the counters only, the owner of the block reads it when it
+// likes), a workgroup barrier, then EVERY load of handed-off bytes is an sc1 load to registers.
 // No fence, no L2 write-back.  Results never depend on placement; for speed the members of a group are given equal
 // workgroup-id % 8 (one XCD under round-robin dispatch).  The host wrapper zeroes the sync block before every launch and falls
 // back to the per-step launches when the active workgroups could not all be resident (> 256) or H/32 is not 1, 2, 4, 8 or 16.
@@ -1076,7 +1077,7 @@ extern "C" int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, in
     hipStream_t st = (hipStream_t)stream;
     const int btiles = (Bn + 15) / 16;
     if (lstm_seq_ok(Bn, T, H, sync)) {
-        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_SYNC_WORDS * 4, st) == hipSuccess, "dmx_lstm_fwd: clearing the sync block failed");
+        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_TMO * 4, st) == hipSuccess, "dmx_lstm_fwd: clearing the sync block failed");
         const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
         switch (H / 32) {
             case 1: lstm_seq_fwd_launch<1>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
@@ -1101,7 +1102,7 @@ extern "C" int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const fl
     hipStream_t st = (hipStream_t)stream;
     const int btiles = (Bn + 15) / 16;
     if (lstm_seq_ok(Bn, T, H, sync)) {
-        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_SYNC_WORDS * 4, st) == hipSuccess, "dmx_lstm_bwd: clearing the sync block failed");
+        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_TMO * 4, st) == hipSuccess, "dmx_lstm_bwd: clearing the sync block failed");
         const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
         switch (H / 32) {
             case 1: lstm_seq_bwd_launch<1>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;

@@ -658,10 +658,18 @@ class DemucsWorkspace:
              self.bufs[dy].ptr, stream())
         self._chain_dirty = True
 
+    def check_lstm_handoffs(self):
+        """Raises if a hand-off spin of the persistent LSTM kernels ever timed out (sticky word; reading it waits for the stream)."""
+        if int(self.lstm_sync[60]) != 0:
+            raise SehipError("Demucs: a hand-off spin of the persistent LSTM kernels timed out (results since then are invalid); "
+                             "set SEHIP_DMX_LSTM_STEPS=1 to use one launch per time step")
+
     def forward(self, mix, params):
         """mix [B, ac, T] fp32 on device -> self.out [B, S, ac, T]."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
+        if st.lstms and self.generation % 64 == 2 and not torch.cuda.is_current_stream_capturing():
+            self.check_lstm_handoffs()       # (every 64th call: the read waits for the previous step)
         self.stats.zero_()
         # weight packing (134 M parameters in both operand orientations: 2.5 ms of table-driven gathers).  Only the shallow levels'
         # forward operands are packed on the chain's stream; the two deepest levels' (94 % of the weights, reached after most of

@@ -62,6 +62,7 @@ def run_chain(kw, B, T, seed):
         i = D - 1 - j        # the oracle's dec{j} is decoder j's output; the HIP path stores it with the skip connection added
         fwd[f"dec{j}"] = rel_err(ws.bufs[f"d{i - 1}.in"].t.float().cpu()[:, :, 0], cl(taps[f"dec{j}"]) + cl(taps[f"enc{i - 1}"]))
     fwd["est"] = rel_err(est.detach().cpu(), ref.detach())
+    ws.check_lstm_handoffs()
     G = torch.randn(ref.shape, generator=g) / ref.numel() ** 0.5
     names = sorted(leaves)
     grads = torch.autograd.grad((ref * G).sum(), [leaves[k] for k in names])
@@ -73,6 +74,7 @@ def run_chain(kw, B, T, seed):
         e, n = float((got[k].double() - gr.double()).norm()), float(gr.double().norm())
         num += e * e; den += n * n
         rows.append((e, n, k))
+    ws.check_lstm_handoffs()
     return dict(model=model, ws=ws, fwd=fwd, glob=(num / den) ** 0.5, gnorm=den ** 0.5, rows=rows, shape=tuple(est.shape), p=p, mix=mix, ref=ref.detach())
 
 
