@@ -88,6 +88,12 @@ int sehip_init(void);
 int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, int ntensors, long max_tensor_numel,
                       const double* sumsq,
                       float* tensor_sums /*[ntensors]*/, float* metric /*[2]: sum-metric, L2 norm*/, void* stream);
+/* One launch in front of the optimizer kernels: *counter += value (NULL: skipped), *sumsq = 0, tensor_sums[0 .. ntensors) = 0; the
+ * `_acc` variants of grad_sumsq / grad_metric then skip their own clearing (runtime memsets: 20-25 us bubbles each on the chain). */
+int sehip_opt_begin(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, void* stream);
+int sehip_grad_sumsq_acc(const float* grads, long n, double* sumsq_out, void* stream);
+int sehip_grad_metric_acc(const float* grads, const long* offsets, int ntensors, long max_tensor_numel, const double* sumsq,
+                          float* tensor_sums, float* metric, void* stream);
 
 /* ---- implicit-GEMM engine (bf16 MFMA, fp32 accumulate) used for
  *        ComplexConv2d            src/model/dccrn.py:316-384      (fwd, dgrad, wgrad)

@@ -47,6 +47,9 @@ _PROTOS = {
     "sehip_counter_add": [P, I, P],
     "sehip_init": [],
     "sehip_grad_metric": [P, P, I, L, P, P, P, P],
+    "sehip_opt_begin": [P, I, P, P, I, P],
+    "sehip_grad_sumsq_acc": [P, L, P, P],
+    "sehip_grad_metric_acc": [P, P, I, L, P, P, P, P],
     "sehip_cbn_scratch_floats": [L, I],
     "sehip_stft_fwd": [P, P, I, I, I, I, I, P, P, P],
     "sehip_istft_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P],

@@ -93,11 +93,13 @@ __global__ void grad_metric_kernel(const float* __restrict__ sums, int ntensors,
     }
 }
 
-extern "C" int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream) {
+static int grad_sumsq_impl(const float* grads, long n, double* sumsq_out, bool clear, void* stream) {
     SEHIP_REQUIRE(n >= 0, "grad_sumsq: negative size");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sumsq_out, 0, sizeof(double), st);
-    SEHIP_REQUIRE(e == hipSuccess, "grad_sumsq: memset failed: %s", hipGetErrorString(e));
+    if (clear) {
+        hipError_t e = hipMemsetAsync(sumsq_out, 0, sizeof(double), st);
+        SEHIP_REQUIRE(e == hipSuccess, "grad_sumsq: memset failed: %s", hipGetErrorString(e));
+    }
     if (n == 0) return 0;
     SEHIP_REQUIRE((((uintptr_t)grads) & 15) == 0, "grad_sumsq: gradient buffer must be 16-byte aligned");
     int grid = cdiv(n, 256 * 16);
@@ -107,7 +109,32 @@ extern "C" int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, v
     return 0;
 }
 
+extern "C" int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream) {
+    return grad_sumsq_impl(grads, n, sumsq_out, true, stream);
+}
+// the same without clearing the accumulator (sehip_opt_begin has done it)
+extern "C" int sehip_grad_sumsq_acc(const float* grads, long n, double* sumsq_out, void* stream) {
+    return grad_sumsq_impl(grads, n, sumsq_out, false, stream);
+}
+
 __global__ void counter_add_kernel(int* p, int v) { p[0] += v; }
+
+// One launch in front of the optimizer kernels: step counter += value, sumsq = 0, tensor_sums[0 .. ntensors) = 0.  (Each of the
+// three was a launch of its own -- two of them runtime memsets, each a 20-25 us bubble on the step's dependent chain.)
+__global__ void opt_begin_kernel(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors) {
+    if (threadIdx.x == 0) {
+        if (counter) counter[0] += value;
+        if (sumsq) sumsq[0] = 0.0;
+    }
+    if (tensor_sums)
+        for (int i = threadIdx.x; i < ntensors; i += blockDim.x) tensor_sums[i] = 0.f;
+}
+extern "C" int sehip_opt_begin(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, void* stream) {
+    SEHIP_REQUIRE(ntensors >= 0, "opt_begin: negative tensor count");
+    opt_begin_kernel<<<1, 256, 0, (hipStream_t)stream>>>(counter, value, sumsq, tensor_sums, ntensors);
+    SEHIP_CHECK_LAUNCH("opt_begin");
+    return 0;
+}
 
 extern "C" int sehip_counter_add(int* counter, int value, void* stream) {
     SEHIP_REQUIRE(counter != nullptr, "counter_add: null counter");
@@ -136,14 +163,26 @@ extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, l
     return 0;
 }
 
-extern "C" int sehip_grad_metric(const float* grads, const long* offsets, int ntensors, long max_tensor, const double* sumsq,
-                                 float* tensor_sums, float* metric, void* stream) {
+static int grad_metric_impl(const float* grads, const long* offsets, int ntensors, long max_tensor, const double* sumsq,
+                            float* tensor_sums, float* metric, bool clear, void* stream) {
     SEHIP_REQUIRE(ntensors > 0 && max_tensor > 0, "grad_metric: no tensors");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(tensor_sums, 0, sizeof(float) * ntensors, st);
-    SEHIP_REQUIRE(e == hipSuccess, "grad_metric: memset failed: %s", hipGetErrorString(e));
+    if (clear) {
+        hipError_t e = hipMemsetAsync(tensor_sums, 0, sizeof(float) * ntensors, st);
+        SEHIP_REQUIRE(e == hipSuccess, "grad_metric: memset failed: %s", hipGetErrorString(e));
+    }
     tensor_sums_kernel<<<dim3(ntensors, cdiv(max_tensor, TS_CHUNK)), 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
     grad_metric_kernel<<<1, 64, 0, st>>>(tensor_sums, ntensors, sumsq, metric);
     SEHIP_CHECK_LAUNCH("grad_metric");
     return 0;
+}
+
+extern "C" int sehip_grad_metric(const float* grads, const long* offsets, int ntensors, long max_tensor, const double* sumsq,
+                                 float* tensor_sums, float* metric, void* stream) {
+    return grad_metric_impl(grads, offsets, ntensors, max_tensor, sumsq, tensor_sums, metric, true, stream);
+}
+// the same without clearing tensor_sums (sehip_opt_begin has done it)
+extern "C" int sehip_grad_metric_acc(const float* grads, const long* offsets, int ntensors, long max_tensor, const double* sumsq,
+                                     float* tensor_sums, float* metric, void* stream) {
+    return grad_metric_impl(grads, offsets, ntensors, max_tensor, sumsq, tensor_sums, metric, false, stream);
 }

@@ -69,10 +69,12 @@ class FlatOptimizer(torch.optim.Optimizer):
         params, grads = model.flat_params, model.flat_grads
         g = self.param_groups[0]
         self._step += 1  # host mirror; the kernel reads the device counter (valid under hipGraph replay)
-        call("sehip_counter_add", ptr(self._step_dev), 1, stream())
         s = self._scratch
+        # one launch: step counter, and the accumulators of the clipping norm and of the grad_norm metric cleared
+        call("sehip_opt_begin", ptr(self._step_dev), 1, ptr(s["sumsq"]), ptr(s["tsums"]), s["tsums"].numel(), stream())
+        self._tsums_clear = True
         if self.max_norm > 0:
-            call("sehip_grad_sumsq", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
+            call("sehip_grad_sumsq_acc", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
         if self.kind == "adam":
             b1, b2 = g["betas"]
             mode = 0
@@ -89,7 +91,9 @@ class FlatOptimizer(torch.optim.Optimizer):
         s = self._scratch
         grads = self.model.flat_grads
         offs = self.model.static.layout.tensor_offsets
-        call("sehip_grad_metric", ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), int((offs[1:] - offs[:-1]).max()),
+        fn = "sehip_grad_metric_acc" if getattr(self, "_tsums_clear", False) else "sehip_grad_metric"     # step() has just cleared tsums
+        self._tsums_clear = False
+        call(fn, ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), int((offs[1:] - offs[:-1]).max()),
              ptr(s["sumsq"]), ptr(s["tsums"]), ptr(s["metric"]), stream())
         return s["metric"]
 
