@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------------------------------
 #define QT 32
 
-__device__ __forceinline__ float dot_chunks(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, int c) {
+__device__ __forceinline__ float dot_chunks(const bf16_raw* a, const bf16_raw* b, int c) {
     float s = 0.f;
     for (int j = 0; j < c; j += 8) {
         const D8 x = ld8(a + j), y = ld8(b + j);
@@ -764,15 +764,33 @@ __device__ __forceinline__ float dot_chunks(const bf16_raw* __restrict__ a, cons
     return s;
 }
 
+// Rows of one head as the kernels read them: row r at p + r * stride.  Either straight from the tensors or, where the LDS has
+// room beside the score tiles (`stage`), from a copy made once per workgroup (pitch c + 8 elements: a wave's 32 query rows then
+// start in different banks): every key / content row is read by all 32 queries and every query row by all T keys, and from
+// memory that was 340 000 sixteen-byte loads per workgroup (430 us per launch at T = 187).
+struct Rows { const bf16_raw* p; int stride; };
+__device__ __forceinline__ Rows stage_rows(const bf16_raw* __restrict__ src, int src_stride, int nrows, int nvalid, int c, bf16_raw* lds, bool stage) {
+    if (!stage) return Rows{src, src_stride};
+    const int nch = c >> 3, pitch = c + 8;
+    for (int i = threadIdx.x; i < nrows * nch; i += 256) {
+        const int r = i / nch, j = i % nch;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < nvalid) v = *reinterpret_cast<const uint4*>(src + (long)r * src_stride + 8 * j);
+        *reinterpret_cast<uint4*>(lds + r * pitch + 8 * j) = v;
+    }
+    return Rows{lds, pitch};
+}
+
 // scores -> softmax weights in sc (columns of queries beyond T hold zeros); dsum[sl] = sum_f (f+1) sigmoid(raw_f)/2 / sqrt(nd)
-__device__ __forceinline__ void attn_weights(const bf16_raw* __restrict__ qb, int T, int c, int NQ, int hid, int h, int nd, int s0,
+// K: key rows 0..T; Q: the tile's query rows 0..QT; raw: decay logits of query s0 at raw + 0, row stride NQ
+__device__ __forceinline__ void attn_weights(Rows K, Rows Q, const bf16_raw* __restrict__ raw, int NQ, int T, int c, int nd, int s0,
                                              float* __restrict__ sc, float* __restrict__ dsum, float* __restrict__ red) {
     const int tid = threadIdx.x;
     if (tid < QT) {
         const int s = s0 + tid;
         float v = 0.f;
         if (s < T)
-            for (int f = 0; f < nd; ++f) v += (float)(f + 1) * 0.5f * sigm(bf2f(qb[(long)s * NQ + 3 * hid + h * nd + f]));
+            for (int f = 0; f < nd; ++f) v += (float)(f + 1) * 0.5f * sigm(bf2f(raw[(long)tid * NQ + f]));
         dsum[tid] = v * rsqrtf((float)nd);
     }
     __syncthreads();
@@ -781,7 +799,7 @@ __device__ __forceinline__ void attn_weights(const bf16_raw* __restrict__ qb, in
         const int t = p / QT, sl = p % QT, s = s0 + sl;
         float v = 0.f;
         if (s < T) {
-            v = dot_chunks(qb + (long)t * NQ + hid + h * c, qb + (long)s * NQ + h * c, c) * isq - fabsf((float)(t - s)) * dsum[sl];
+            v = dot_chunks(K.p + (long)t * K.stride, Q.p + (long)sl * Q.stride, c) * isq - fabsf((float)(t - s)) * dsum[sl];
             if (t == s) v = -100.f;
         }
         sc[p] = v;
@@ -809,15 +827,21 @@ __device__ __forceinline__ void attn_weights(const bf16_raw* __restrict__ qb, in
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __restrict__ qkv, int T, int hid, int heads, int nd, int NQ,
+__global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __restrict__ qkv, int T, int hid, int heads, int nd, int NQ, int stage,
                                                            bf16_raw* __restrict__ out) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                 // [T][QT]
     float* dsum = sc + (size_t)T * QT;   // [QT]
     float* red = dsum + QT;           // [8][QT]
     const int b = blockIdx.z, h = blockIdx.y, s0 = blockIdx.x * QT, c = hid / heads;
+    bf16_raw* tiles = reinterpret_cast<bf16_raw*>(red + 8 * QT);      // staged rows: keys [T] | content [T] | queries [QT], pitch c + 8
     const bf16_raw* qb = qkv + (long)b * T * NQ;
-    attn_weights(qb, T, c, NQ, hid, h, nd, s0, sc, dsum, red);
+    const int nq = T - s0 < QT ? T - s0 : QT;
+    const Rows K = stage_rows(qb + hid + h * c, NQ, T, T, c, tiles, stage);
+    const Rows Cn = stage_rows(qb + 2 * hid + h * c, NQ, T, T, c, tiles + (size_t)T * (c + 8), stage);
+    const Rows Q = stage_rows(qb + (long)s0 * NQ + h * c, NQ, QT, nq, c, tiles + (size_t)2 * T * (c + 8), stage);
+    if (stage) __syncthreads();
+    attn_weights(K, Q, qb + (long)s0 * NQ + 3 * hid + h * nd, NQ, T, c, nd, s0, sc, dsum, red);
     const int nch = c >> 3;
     for (int it = threadIdx.x; it < QT * nch; it += 256) {
         const int sl = it % QT, j = it / QT, s = s0 + sl;
@@ -825,7 +849,7 @@ __global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __res
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < T; ++t) {
             const float wv = sc[t * QT + sl];
-            const D8 x = ld8(qb + (long)t * NQ + 2 * hid + h * c + 8 * j);
+            const D8 x = ld8(Cn.p + (long)t * Cn.stride + 8 * j);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += wv * x.v[i];
         }
@@ -835,21 +859,29 @@ __global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __res
 
 // dqkv fp32 [B][T][NQ] += gradients of query / key / content / decay (caller zeroes; keys and content collect over query tiles)
 __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dres, int T, int hid,
-                                                           int heads, int nd, int NQ, float* __restrict__ dqkv) {
-    extern __shared__ float smem[];
+                                                           int heads, int nd, int NQ, int stage, float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                     // [T][QT] softmax weights
     float* dw = sc + (size_t)T * QT;      // [T][QT] d weights -> d scores
     float* dsum = dw + (size_t)T * QT;    // [QT]
     float* red = dsum + QT;               // [8][QT]
     const int b = blockIdx.z, h = blockIdx.y, s0 = blockIdx.x * QT, c = hid / heads;
     const int tid = threadIdx.x;
+    bf16_raw* tiles = reinterpret_cast<bf16_raw*>(red + 8 * QT);      // keys [T] | content [T] | queries [QT] | d result [QT]
     const bf16_raw* qb = qkv + (long)b * T * NQ;
     const bf16_raw* db = dres + (long)b * T * hid + h * c;
     float* gq = dqkv + (long)b * T * NQ;
-    attn_weights(qb, T, c, NQ, hid, h, nd, s0, sc, dsum, red);
+    const int nq = T - s0 < QT ? T - s0 : QT;
+    const size_t tp = (size_t)(c + 8);
+    const Rows K = stage_rows(qb + hid + h * c, NQ, T, T, c, tiles, stage);
+    const Rows Cn = stage_rows(qb + 2 * hid + h * c, NQ, T, T, c, tiles + T * tp, stage);
+    const Rows Q = stage_rows(qb + (long)s0 * NQ + h * c, NQ, QT, nq, c, tiles + 2 * T * tp, stage);
+    const Rows D = stage_rows(db + (long)s0 * hid, hid, QT, nq, c, tiles + (2 * T + QT) * tp, stage);
+    if (stage) __syncthreads();
+    attn_weights(K, Q, qb + (long)s0 * NQ + 3 * hid + h * nd, NQ, T, c, nd, s0, sc, dsum, red);
     for (int p = tid; p < T * QT; p += 256) {
         const int t = p / QT, sl = p % QT, s = s0 + sl;
-        dw[p] = s < T ? dot_chunks(db + (long)s * hid, qb + (long)t * NQ + 2 * hid + h * c, c) : 0.f;
+        dw[p] = s < T ? dot_chunks(D.p + (long)sl * D.stride, Cn.p + (long)t * Cn.stride, c) : 0.f;
     }
     __syncthreads();
     const int sl = tid % QT, sub = tid / QT;
@@ -871,10 +903,10 @@ __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __res
     for (int it = tid; it < T * nch; it += 256) {
         const int t = it / nch, j = it % nch;
         float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ac[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < QT && s0 + q < T; ++q) {
+        for (int q = 0; q < nq; ++q) {
             const float wv = sc[t * QT + q], dv = dw[t * QT + q] * isq;
-            const D8 qv = ld8(qb + (long)(s0 + q) * NQ + h * c + 8 * j);
-            const D8 rv = ld8(db + (long)(s0 + q) * hid + 8 * j);
+            const D8 qv = ld8(Q.p + (long)q * Q.stride + 8 * j);
+            const D8 rv = ld8(D.p + (long)q * D.stride + 8 * j);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { ak[i] += dv * qv.v[i]; ac[i] += wv * rv.v[i]; }
         }
@@ -890,7 +922,7 @@ __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __res
         float aq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < T; ++t) {
             const float dv = dw[t * QT + q] * isq;
-            const D8 kv = ld8(qb + (long)t * NQ + hid + h * c + 8 * j);
+            const D8 kv = ld8(K.p + (long)t * K.stride + 8 * j);
 #pragma unroll
             for (int i = 0; i < 8; ++i) aq[i] += dv * kv.v[i];
         }
@@ -1131,22 +1163,27 @@ static int attn_check(const char* who, int B, int T, int hid, int heads, int nd,
 }
 
 extern "C" int sehip_dmx_attn_fwd(const void* qkv, int B, int T, int hid, int heads, int nd, int NQ, void* out, void* stream) {
-    const size_t lds = ((size_t)T * QT + QT + 8 * QT) * sizeof(float);
-    if (int e = attn_check("dmx_attn_fwd", B, T, hid, heads, nd, NQ, lds)) return e;
+    const size_t base = ((size_t)T * QT + QT + 8 * QT) * sizeof(float);
+    if (int e = attn_check("dmx_attn_fwd", B, T, hid, heads, nd, NQ, base)) return e;
+    const size_t tiles = ((size_t)2 * T + QT) * (hid / heads + 8) * sizeof(bf16_raw);
+    const int stage = base + tiles <= 150 * 1024;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-    dmx_attn_fwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, lds, (hipStream_t)stream>>>((const bf16_raw*)qkv, T, hid, heads, nd, NQ, (bf16_raw*)out);
+    dmx_attn_fwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, stage ? base + tiles : base, (hipStream_t)stream>>>((const bf16_raw*)qkv, T, hid, heads, nd, NQ,
+                                                                                                                       stage, (bf16_raw*)out);
     SEHIP_CHECK_LAUNCH("dmx_attn_fwd");
     return 0;
 }
 
 extern "C" int sehip_dmx_attn_bwd(const void* qkv, const void* dres, int B, int T, int hid, int heads, int nd, int NQ, float* dqkv, void* stream) {
-    const size_t lds = ((size_t)2 * T * QT + QT + 8 * QT) * sizeof(float);
-    if (int e = attn_check("dmx_attn_bwd", B, T, hid, heads, nd, NQ, lds)) return e;
+    const size_t base = ((size_t)2 * T * QT + QT + 8 * QT) * sizeof(float);
+    if (int e = attn_check("dmx_attn_bwd", B, T, hid, heads, nd, NQ, base)) return e;
+    const size_t tiles = ((size_t)2 * T + 2 * QT) * (hid / heads + 8) * sizeof(bf16_raw);
+    const int stage = base + tiles <= 150 * 1024;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-    dmx_attn_bwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, lds, (hipStream_t)stream>>>((const bf16_raw*)qkv, (const bf16_raw*)dres, T, hid, heads, nd, NQ,
-                                                                                           dqkv);
+    dmx_attn_bwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, stage ? base + tiles : base, (hipStream_t)stream>>>((const bf16_raw*)qkv, (const bf16_raw*)dres, T,
+                                                                                                                       hid, heads, nd, NQ, stage, dqkv);
     SEHIP_CHECK_LAUNCH("dmx_attn_bwd");
     return 0;
 }

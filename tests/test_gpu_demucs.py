@@ -278,7 +278,7 @@ def test_bidirectional_lstm_layer(Bn, T, H, persistent):
     assert rel_err(dG.float().cpu(), dpre_ref) < 1.5e-2
 
 
-@pytest.mark.parametrize("B,T,hid", [(2, 50, 32), (1, 187, 256), (3, 33, 64)])
+@pytest.mark.parametrize("B,T,hid", [(2, 50, 32), (1, 187, 256), (3, 33, 64), (2, 47, 512), (1, 500, 64)])     # (the last: rows straight from memory, the score tiles fill the LDS)
 def test_local_state_attention(B, T, hid):
     """The attention between LocalState's 1x1 convolutions against the oracle's local_state (identity convolutions feed it the same
     query / key / content / decay rows): output and the gradient of every row."""
