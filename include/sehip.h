@@ -200,6 +200,14 @@ int sehip_wgrad_group(const void* dev_buf, int n, int total_blocks, void* stream
 int sehip_pack_bf16(const float* params, const int* table, long n, void* out_bf16, void* stream);
 int sehip_pack_f32(const float* params, const int* table2 /*[n][2]*/, long n, float* out, void* stream);
 int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n, float* grads, void* stream);
+/* compact forms for large models (Demucs: 133.7 M parameters):
+ *   unpack_grad1    : one entry per parameter (table1 [n]); unpack_grad_list: grads[list[i]] = sum of table4[i] for the few
+ *                     parameters with several entries (run after unpack_grad1, which leaves their first entry there)
+ *   pack_bf16_runs  : out[8 i + j] = params[base_i + j * stride_i] from one (base, stride) pair per 8 outputs; base -1 = zeros;
+ *                     base <= -2 = the 8 ordinary entries at side[8 * (-2 - base)] */
+int sehip_unpack_grad1(const float* packed, const int* table1, long n, float* grads, void* stream);
+int sehip_unpack_grad_list(const float* packed, const int* list, const int* table4, long m, float* grads, void* stream);
+int sehip_pack_bf16_runs(const float* params, const int* runs2 /*[n/8][2]*/, const int* side, long n, void* out_bf16, void* stream);
 
 /* ---- ComplexBatchNorm + PReLU: src/model/dccrn.py:457-634 (training branch :549-611, whitening :593-602,
  *      running statistics :555-556,577-579) fused with nn.PReLU() (:79,122).  Activations are [rows][2*Cr] bf16.

@@ -50,6 +50,52 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restric
     }
 }
 
+// The common case of the above -- ONE entry per parameter -- with a 4-byte table entry instead of 16 (133.7 M parameters of Demucs:
+// 0.54 GB of table instead of 2.1 GB per step); four parameters per thread.
+__global__ __launch_bounds__(256) void unpack_grad1_kernel(const float* __restrict__ packed, const int* __restrict__ tab, long n,
+                                                           float* __restrict__ grads) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int4 e = *reinterpret_cast<const int4*>(tab + 4 * i);
+        *reinterpret_cast<float4*>(grads + 4 * i) = make_float4(term(packed, e.x), term(packed, e.y), term(packed, e.z), term(packed, e.w));
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) grads[i] = term(packed, tab[i]);
+}
+// ... and the parameters with several entries, by index: grads[list[i]] = sum of the 4 entries of tab[i]
+__global__ __launch_bounds__(256) void unpack_grad_list_kernel(const float* __restrict__ packed, const int* __restrict__ list,
+                                                               const int4* __restrict__ tab, long m, float* __restrict__ grads) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
+        const int4 e = tab[i];
+        grads[list[i]] = term(packed, e.x) + term(packed, e.y) + term(packed, e.z) + term(packed, e.w);
+    }
+}
+
+// Packing from run descriptors: 8 consecutive outputs = 8 parameters at base + j * stride (one int2 per 16 bytes of output instead
+// of eight 4-byte indices: the layouts are permutations with long regular runs -- taps / channels swapped, transposes).
+// run.x >= 0: base index, run.y = stride; run.x == -1: eight zeros (padding); run.x <= -2: irregular, the eight ordinary
+// entries ((index << 1) | negate, -1 = absent) are at side[8 * (-2 - run.x)].
+__global__ __launch_bounds__(256) void pack_bf16_runs_kernel(const float* __restrict__ params, const int2* __restrict__ runs,
+                                                             const int* __restrict__ side, long n8, bf16_raw* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const int2 r = runs[i];
+        float v[8];
+        if (r.x >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = params[(long)r.x + (long)j * r.y];
+        } else if (r.x == -1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        } else {
+            const int* e = side + 8L * (-2 - r.x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = term(params, e[j]);
+        }
+        *reinterpret_cast<uint4*>(out + 8 * i) =
+            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    }
+}
+
 static int grid_of(long n) { long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
 
 extern "C" int sehip_pack_bf16(const float* params, const int* table, long n, void* out_bf16, void* stream) {
@@ -74,5 +120,31 @@ extern "C" int sehip_unpack_grad(const float* packed, const int* table4, long n,
     if (n == 0) return 0;
     unpack_grad_kernel<<<grid_of(n), 256, 0, (hipStream_t)stream>>>(packed, (const int4*)table4, n, grads);
     SEHIP_CHECK_LAUNCH("unpack_grad");
+    return 0;
+}
+
+extern "C" int sehip_unpack_grad1(const float* packed, const int* table1, long n, float* grads, void* stream) {
+    SEHIP_REQUIRE(n >= 0, "unpack_grad1: negative size");
+    if (n == 0) return 0;
+    SEHIP_REQUIRE(((((uintptr_t)table1) | ((uintptr_t)grads)) & 15) == 0, "unpack_grad1: table / gradients must be 16-byte aligned");
+    unpack_grad1_kernel<<<grid_of(n >> 2), 256, 0, (hipStream_t)stream>>>(packed, table1, n, grads);
+    SEHIP_CHECK_LAUNCH("unpack_grad1");
+    return 0;
+}
+
+extern "C" int sehip_unpack_grad_list(const float* packed, const int* list, const int* table4, long m, float* grads, void* stream) {
+    SEHIP_REQUIRE(m >= 0, "unpack_grad_list: negative size");
+    if (m == 0) return 0;
+    unpack_grad_list_kernel<<<grid_of(m), 256, 0, (hipStream_t)stream>>>(packed, list, (const int4*)table4, m, grads);
+    SEHIP_CHECK_LAUNCH("unpack_grad_list");
+    return 0;
+}
+
+extern "C" int sehip_pack_bf16_runs(const float* params, const int* runs2, const int* side, long n, void* out_bf16, void* stream) {
+    SEHIP_REQUIRE(n >= 0 && (n & 7) == 0, "pack_bf16_runs: n=%ld must be a multiple of 8", n);
+    if (n == 0) return 0;
+    SEHIP_REQUIRE(((((uintptr_t)runs2) & 7) | (((uintptr_t)out_bf16) & 15)) == 0, "pack_bf16_runs: run table / output misaligned");
+    pack_bf16_runs_kernel<<<grid_of(n >> 3), 256, 0, (hipStream_t)stream>>>(params, (const int2*)runs2, side, n >> 3, (bf16_raw*)out_bf16);
+    SEHIP_CHECK_LAUNCH("pack_bf16_runs");
     return 0;
 }

@@ -414,7 +414,8 @@ class DemucsStatic:
         for p in self.prods.values():
             p.wtab = None        # the arena holds the only copy from here on
         wa.pieces = []
-        self.utab = self._build_unpack_table()
+        self.utab1, self.ulist, self.utab4 = self._build_unpack_table()
+        self.runs, self.side = self._build_pack_runs()
         if cfg.resample:
             self.kup, self.wup = resample_kernels(1, 2)
             self.kdn, self.wdn = resample_kernels(2, 1)
@@ -470,13 +471,47 @@ class DemucsStatic:
             off, shape = L.param_off[name]
             used[off:off + int(np.prod(shape))] = True
         assert (fill[used] >= 1).all(), "every Demucs parameter has a packed-gradient entry"
-        return tab
+        # compact form: one 4-byte entry per parameter + the few parameters with several entries (the biases of the transposed
+        # convolutions: one per output phase) as an index list with 16-byte entries
+        self.unpack_entries = fill
+        multi = np.flatnonzero(fill > 1).astype(np.int32)
+        return np.ascontiguousarray(tab[:, 0]), multi, np.ascontiguousarray(tab[multi])
+
+    def _build_pack_runs(self):
+        """(base, stride) per 8 packed elements where they are an affine run of parameters, (-1, 0) for 8 padding zeros, otherwise
+        (-2 - k, 0) and the 8 ordinary entries in row k of the side table (sehip_pack_bf16_runs)."""
+        n = self.n_wpack_dev
+        assert n % 8 == 0
+        w = self.wtab[:n].reshape(-1, 8)                       # int32 throughout (indices < 2^30), in slabs of 4 M rows
+        runs = np.zeros((w.shape[0], 2), dtype=np.int32)
+        affine = np.zeros(w.shape[0], dtype=bool)
+        nonev = np.zeros(w.shape[0], dtype=bool)
+        for a in range(0, w.shape[0], 1 << 22):
+            ws = w[a:a + (1 << 22)]
+            valid = ws >= 0
+            idx = ws >> 1
+            d = idx[:, 1:] - idx[:, :-1]
+            af = valid.all(axis=1) & (d == d[:, :1]).all(axis=1)
+            affine[a:a + ws.shape[0]] = af
+            nonev[a:a + ws.shape[0]] = ~valid.any(axis=1)
+            r = runs[a:a + ws.shape[0]]
+            r[af, 0] = idx[af, 0]
+            r[af, 1] = d[af, 0]
+        runs[nonev, 0] = -1
+        irr = np.flatnonzero(~affine & ~nonev)
+        runs[irr, 0] = -2 - np.arange(irr.size)
+        side = np.ascontiguousarray(self.wtab[:n].reshape(-1, 8)[irr]).reshape(-1)
+        if side.size == 0:
+            side = np.full(8, -1, dtype=np.int32)
+        return runs, side.astype(np.int32)
 
 
 class DemucsDeviceTables:
     def __init__(self, st: DemucsStatic, device):
         f = lambda a: torch.from_numpy(a).to(device)
-        self.wtab, self.btab, self.utab, self.ntab = f(st.wtab), f(st.btab), f(st.utab), f(st.ntab)
+        self.btab, self.ntab = f(st.btab), f(st.ntab)
+        self.runs, self.side = f(st.runs), f(st.side)                  # weight packing: (base, stride) per 8 elements
+        self.utab1, self.ulist, self.utab4 = f(st.utab1), f(st.ulist), f(st.utab4 if st.utab4.size else np.full((1, 4), -1, dtype=np.int32))
         self.tensor_offsets = f(st.layout.tensor_offsets)
         self.wpack = torch.zeros(st.n_wpack, dtype=BF16, device=device)
         self.bpack = torch.zeros(st.n_bpack, dtype=torch.float32, device=device)
@@ -678,13 +713,13 @@ class DemucsWorkspace:
         # latency-bound and ran 3x slower next to a packing kernel.
         two = self.side is not None and not torch.cuda.is_current_stream_capturing()
         head = st.n_wpack_head if two else st.n_wpack_dev
-        call("sehip_pack_bf16", ptr(params), ptr(tb.wtab), head, ptr(tb.wpack), stream())
+        self._pack(params, 0, head, stream())
         call("sehip_pack_f32", ptr(params), ptr(tb.btab), st.n_bpack, ptr(tb.bpack), stream())
         self._late_pack_event = self._bwd_pack_events = None
         if two:
             sd = self.side.cuda_stream
             call("sehip_stream_depend", sd, stream(), self._event())
-            call("sehip_pack_bf16", ptr(params), tb.wtab.data_ptr() + 4 * head, st.n_wpack_fwd - head, tb.wpack.data_ptr() + 2 * head, sd)
+            self._pack(params, head, st.n_wpack_fwd, sd)
             self._late_pack_event = self._own_event(0)
             call("sehip_event_record", self._late_pack_event, sd)
         up = 1 if cfg.resample else 0
@@ -753,8 +788,22 @@ class DemucsWorkspace:
         call("sehip_stream_depend", cs, stream(), self._event())
         if self.side is not None:
             call("sehip_stream_depend", cs, self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), self.tb.utab.data_ptr() + 16 * lo, hi - lo, grads.data_ptr() + 4 * lo, cs)
+        self._unpack(lo, hi, grads, cs)
         range_ready(lo, hi, self.comm)
+
+    def _pack(self, params, lo, hi, on_stream):
+        """packed bf16 operands [lo, hi) (multiples of 8) from the flat parameters"""
+        tb = self.tb
+        call("sehip_pack_bf16_runs", ptr(params), tb.runs.data_ptr() + lo, ptr(tb.side), hi - lo, tb.wpack.data_ptr() + 2 * lo, on_stream)
+
+    def _unpack(self, lo, hi, grads, on_stream):
+        """flat parameter gradients [lo, hi) (multiples of 4) from the packed-gradient buffer"""
+        tb, st = self.tb, self.st
+        call("sehip_unpack_grad1", ptr(self.gpack), tb.utab1.data_ptr() + 4 * lo, hi - lo, grads.data_ptr() + 4 * lo, on_stream)
+        a, b = np.searchsorted(st.ulist, [lo, hi])
+        if b > a:
+            call("sehip_unpack_grad_list", ptr(self.gpack), tb.ulist.data_ptr() + 4 * int(a), tb.utab4.data_ptr() + 16 * int(a), int(b - a),
+                 ptr(grads), on_stream)
 
     def _pack_backward_operands(self, params):
         """Second stream: the shallow levels' backward operands, then the deep levels' (an event after each)."""
@@ -763,7 +812,7 @@ class DemucsWorkspace:
         ev = []
         for j, (lo, hi) in enumerate(((a, m), (m, z))):
             if hi > lo:
-                call("sehip_pack_bf16", ptr(params), tb.wtab.data_ptr() + 4 * lo, hi - lo, tb.wpack.data_ptr() + 2 * lo, sd)
+                self._pack(params, lo, hi, sd)
             e = self._own_event(1 + j)
             call("sehip_event_record", e, sd)
             ev.append(e)
@@ -856,7 +905,7 @@ class DemucsWorkspace:
                 done_from = enc_off[i]
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), done_from, ptr(grads), stream())
+        self._unpack(0, done_from, grads, stream())
         if range_ready is not None:
             range_ready(0, done_from, torch.cuda.current_stream())
             call("sehip_stream_depend", stream(), self.comm.cuda_stream, self._event())

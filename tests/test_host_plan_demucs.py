@@ -35,7 +35,7 @@ def test_every_parameter_is_packed_and_unpacked_once(static):
     for name in L.param_names:
         off, shape = L.param_off[name]
         used[off:off + int(np.prod(shape))] = True
-    entries = (st.utab >= 0).sum(axis=1)
+    entries = st.unpack_entries
     assert (entries[used] >= 1).all() and (entries[~used] == 0).all()
     # weights and GroupNorm / LayerScale terms have one packed-gradient entry, the bias of a transposed convolution four (one per
     # output phase), everything else one
@@ -45,7 +45,11 @@ def test_every_parameter_is_packed_and_unpacked_once(static):
             off, shape = L.param_off[name]
             four[off:off + int(np.prod(shape))] = True
     assert (entries[four] == 4).all() and (entries[used & ~four] == 1).all()
-    g = st.utab[st.utab >= 0] >> 1
+    # compact tables: one entry per parameter + an index list for the four-entry ones
+    assert st.utab1.shape == (L.n_params,) and (st.utab1[used] >= 0).all() and (st.utab1[~used] == -1).all()
+    assert np.array_equal(st.ulist, np.flatnonzero(four)) and st.utab4.shape == (int(four.sum()), 4) and (st.utab4 >= 0).all()
+    assert np.array_equal(st.utab4[:, 0], st.utab1[st.ulist])
+    g = np.concatenate([st.utab1[st.utab1 >= 0], st.utab4[:, 1:].reshape(-1)]) >> 1
     assert g.max() < st.n_gpack
     # every weight element appears in exactly one forward product's packed operand
     fwd = np.zeros(L.n_params, dtype=np.int32)
@@ -57,6 +61,21 @@ def test_every_parameter_is_packed_and_unpacked_once(static):
         off, shape = L.param_off[name]
         if len(shape) >= 2:
             assert (fwd[off:off + int(np.prod(shape))] == 1).all(), name
+
+
+def test_pack_run_descriptors_reproduce_the_index_table(static):
+    """sehip_pack_bf16_runs' (base, stride) pairs / side entries decode to exactly the per-element table."""
+    P, cfg, st = static
+    n = st.n_wpack_dev
+    want = st.wtab[:n].reshape(-1, 8)
+    runs, side = st.runs, st.side.reshape(-1, 8)
+    got = np.full_like(want, -1)
+    aff = runs[:, 0] >= 0
+    got[aff] = (runs[aff, :1].astype(np.int64) + np.arange(8)[None] * runs[aff, 1:].astype(np.int64)) << 1
+    irr = runs[:, 0] <= -2
+    got[irr] = side[-2 - runs[irr, 0]]
+    assert np.array_equal(got, want)
+    assert aff.mean() > 0.9                                   # the layouts are long regular runs
 
 
 def test_quad_view_weight_layouts(static):
