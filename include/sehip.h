@@ -332,7 +332,7 @@ int sehip_lstm_bwd_chunk(const void* dh_a_bf16, const void* dh_b_bf16, const voi
  *                  x W_ih^T + b_ih + b_hh on entry and the activated gates on exit; whh bf16 [2][4H][H]; hs bf16 [Bn][T][2H]; cs fp32 [Bn][T][2H]
  *      lstm_bwd  : dG bf16 [Bn][T][2][4H] pre-activation gate gradients from dhs bf16 [Bn][T][2H]; whhT bf16 [2][H][4H]; dc fp32 [2][Bn][H] scratch
  *      attn_fwd  : LocalState (:210-269, nfreqs = 0) between its 1x1 convolutions: qkv bf16 [B][T][NQ] = query | key | content | decay
- *                  (heads*nd) columns -> out bf16 [B][T][hid];  attn_bwd: dqkv fp32 [B][T][NQ] += (caller zeroes) from dres bf16 [B][T][hid] */
+ *                  (heads*nd) columns -> out bf16 [B][T][hid];  attn_bwd: dqkv bf16 [B][T][NQ] from dres bf16 [B][T][hid] */
 int sehip_dmx_prep(const float* mix, int B, int ac, int acp, int T, int padl, int Tv, int normalize, int up, const float* kup, int width,
                    int KL, double* acc /*[B][2] scratch*/, float* ms, void* x_bf16, void* stream);
 int sehip_dmx_post(const float* y, const float* ms, int B, int co, int cop, long Tf, int padl, int T, int down, const float* kdn, int width,
@@ -360,7 +360,11 @@ int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, int H, void* 
 int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const float* cs, const void* dhs, int Bn, int T, int H, void* dG, float* dc,
                        unsigned* sync, void* stream);
 int sehip_dmx_attn_fwd(const void* qkv, int B, int T, int hid, int heads, int nd, int NQ, void* out, void* stream);
-int sehip_dmx_attn_bwd(const void* qkv, const void* dres, int B, int T, int hid, int heads, int nd, int NQ, float* dqkv, void* stream);
+/* slabs: sehip_dmx_attn_bwd_scratch_floats() floats of scratch (the key / content gradients per tile of 32 queries, summed by a second
+ * launch); dqkv bf16 [B][T][NQ]: columns [0, 3 hid + heads nd) are written, the padding columns are left as they are */
+long sehip_dmx_attn_bwd_scratch_floats(int B, int T, int hid);
+int sehip_dmx_attn_bwd(const void* qkv, const void* dres, int B, int T, int hid, int heads, int nd, int NQ, float* slabs, void* dqkv_bf16,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,13 +107,14 @@ _PROTOS = {
     "sehip_dmx_lstm_fwd": [P, P, I, I, I, P, P, P, P],
     "sehip_dmx_lstm_bwd": [P, P, P, P, I, I, I, P, P, P, P],
     "sehip_dmx_attn_fwd": [P, I, I, I, I, I, I, P, P],
-    "sehip_dmx_attn_bwd": [P, P, I, I, I, I, I, I, P, P],
+    "sehip_dmx_attn_bwd_scratch_floats": [I, I, I],
+    "sehip_dmx_attn_bwd": [P, P, I, I, I, I, I, I, P, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
+_RESTYPE = {"sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
 
 
 def lib():

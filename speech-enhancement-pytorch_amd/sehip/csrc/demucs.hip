@@ -754,14 +754,40 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------------------------------
 #define QT 32
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// dot product of two rows of c bf16 elements, fp32 accumulation: v_dot2c_f32_bf16 takes the pairs as they are stored (4 instructions
+// per 8 elements instead of 16 unpacking + 8 multiply-adds: these loops are VALU-bound)
+template <int NCH>     // NCH = c / 8 known at compile time (1 .. 16): all row chunks are requested before the first use
 __device__ __forceinline__ float dot_chunks(const bf16_raw* a, const bf16_raw* b, int c) {
-    float s = 0.f;
-    for (int j = 0; j < c; j += 8) {
-        const D8 x = ld8(a + j), y = ld8(b + j);
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += x.v[i] * y.v[i];
+    for (int j = 0; j < (NCH ? 8 * NCH : c); j += 8) {
+        const uint4 x = *reinterpret_cast<const uint4*>(a + j), y = *reinterpret_cast<const uint4*>(b + j);
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.x), __builtin_bit_cast(bf16x2, y.x), s0, false);
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.y), __builtin_bit_cast(bf16x2, y.y), s1, false);
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.z), __builtin_bit_cast(bf16x2, y.z), s0, false);
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.w), __builtin_bit_cast(bf16x2, y.w), s1, false);
     }
-    return s;
+    return s0 + s1;
+}
+// acc[0..8) += w * row[0..8) on packed pairs (v_pk_fma_f32: 4 multiply-add instructions per 8 elements)
+struct Acc8 { f32x2 v[4]; };
+__device__ __forceinline__ void axpy8(Acc8& acc, float w, const bf16_raw* row) {
+    const uint4 u = *reinterpret_cast<const uint4*>(row);
+    const unsigned d[4] = {u.x, u.y, u.z, u.w};
+    const f32x2 ww = {w, w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 x = {__uint_as_float(d[i] << 16), __uint_as_float(d[i] & 0xffff0000u)};
+        acc.v[i] = __builtin_elementwise_fma(ww, x, acc.v[i]);
+    }
+}
+__device__ __forceinline__ Acc8 acc8_zero() {
+    Acc8 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.v[i] = (f32x2){0.f, 0.f};
+    return a;
 }
 
 // Rows of one head as the kernels read them: row r at p + r * stride.  Either straight from the tensors or, where the LDS has
@@ -783,6 +809,7 @@ __device__ __forceinline__ Rows stage_rows(const bf16_raw* __restrict__ src, int
 
 // scores -> softmax weights in sc (columns of queries beyond T hold zeros); dsum[sl] = sum_f (f+1) sigmoid(raw_f)/2 / sqrt(nd)
 // K: key rows 0..T; Q: the tile's query rows 0..QT; raw: decay logits of query s0 at raw + 0, row stride NQ
+template <int NCH>
 __device__ __forceinline__ void attn_weights(Rows K, Rows Q, const bf16_raw* __restrict__ raw, int NQ, int T, int c, int nd, int s0,
                                              float* __restrict__ sc, float* __restrict__ dsum, float* __restrict__ red) {
     const int tid = threadIdx.x;
@@ -799,7 +826,7 @@ __device__ __forceinline__ void attn_weights(Rows K, Rows Q, const bf16_raw* __r
         const int t = p / QT, sl = p % QT, s = s0 + sl;
         float v = 0.f;
         if (s < T) {
-            v = dot_chunks(K.p + (long)t * K.stride, Q.p + (long)sl * Q.stride, c) * isq - fabsf((float)(t - s)) * dsum[sl];
+            v = dot_chunks<NCH>(K.p + (long)t * K.stride, Q.p + (long)sl * Q.stride, c) * isq - fabsf((float)(t - s)) * dsum[sl];
             if (t == s) v = -100.f;
         }
         sc[p] = v;
@@ -827,6 +854,7 @@ __device__ __forceinline__ void attn_weights(Rows K, Rows Q, const bf16_raw* __r
     __syncthreads();
 }
 
+template <int NCH>
 __global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __restrict__ qkv, int T, int hid, int heads, int nd, int NQ, int stage,
                                                            bf16_raw* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -841,25 +869,26 @@ __global__ __launch_bounds__(256) void dmx_attn_fwd_kernel(const bf16_raw* __res
     const Rows Cn = stage_rows(qb + 2 * hid + h * c, NQ, T, T, c, tiles + (size_t)T * (c + 8), stage);
     const Rows Q = stage_rows(qb + (long)s0 * NQ + h * c, NQ, QT, nq, c, tiles + (size_t)2 * T * (c + 8), stage);
     if (stage) __syncthreads();
-    attn_weights(K, Q, qb + (long)s0 * NQ + 3 * hid + h * nd, NQ, T, c, nd, s0, sc, dsum, red);
+    attn_weights<NCH>(K, Q, qb + (long)s0 * NQ + 3 * hid + h * nd, NQ, T, c, nd, s0, sc, dsum, red);
     const int nch = c >> 3;
     for (int it = threadIdx.x; it < QT * nch; it += 256) {
         const int sl = it % QT, j = it / QT, s = s0 + sl;
         if (s >= T) continue;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) {
-            const float wv = sc[t * QT + sl];
-            const D8 x = ld8(Cn.p + (long)t * Cn.stride + 8 * j);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += wv * x.v[i];
-        }
+        Acc8 a8 = acc8_zero();
+#pragma unroll 8
+        for (int t = 0; t < T; ++t) axpy8(a8, sc[t * QT + sl], Cn.p + (long)t * Cn.stride + 8 * j);
+        const float acc[8] = {a8.v[0][0], a8.v[0][1], a8.v[1][0], a8.v[1][1], a8.v[2][0], a8.v[2][1], a8.v[3][0], a8.v[3][1]};
         st8(out + ((long)b * T + s) * hid + h * c + 8 * j, acc);
     }
 }
 
-// dqkv fp32 [B][T][NQ] += gradients of query / key / content / decay (caller zeroes; keys and content collect over query tiles)
+// dqkv bf16 [B][T][NQ]: the query and decay columns get their final gradients here (a query tile belongs to one workgroup); the
+// key / content gradients of this tile's queries go to slab[tile][b][t][key hid | content hid] fp32 (plain stores, every element
+// written exactly once) and dmx_attn_bwd_sum_kernel adds the tiles up.  (fp32 atomics onto [B][T][2 hid] instead: 170 of 325 us.)
+template <int NCH>
 __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dres, int T, int hid,
-                                                           int heads, int nd, int NQ, int stage, float* __restrict__ dqkv) {
+                                                           int heads, int nd, int NQ, int stage, float* __restrict__ slab,
+                                                           bf16_raw* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                     // [T][QT] softmax weights
     float* dw = sc + (size_t)T * QT;      // [T][QT] d weights -> d scores
@@ -870,18 +899,19 @@ __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __res
     bf16_raw* tiles = reinterpret_cast<bf16_raw*>(red + 8 * QT);      // keys [T] | content [T] | queries [QT] | d result [QT]
     const bf16_raw* qb = qkv + (long)b * T * NQ;
     const bf16_raw* db = dres + (long)b * T * hid + h * c;
-    float* gq = dqkv + (long)b * T * NQ;
+    bf16_raw* gq = dqkv + (long)b * T * NQ;
+    float* sl_out = slab + (((long)blockIdx.x * gridDim.z + b) * T) * 2 * hid;      // [t][key hid | content hid] of this tile
     const int nq = T - s0 < QT ? T - s0 : QT;
     const size_t tp = (size_t)(c + 8);
-    const Rows K = stage_rows(qb + hid + h * c, NQ, T, T, c, tiles, stage);
-    const Rows Cn = stage_rows(qb + 2 * hid + h * c, NQ, T, T, c, tiles + T * tp, stage);
-    const Rows Q = stage_rows(qb + (long)s0 * NQ + h * c, NQ, QT, nq, c, tiles + 2 * T * tp, stage);
-    const Rows D = stage_rows(db + (long)s0 * hid, hid, QT, nq, c, tiles + (2 * T + QT) * tp, stage);
-    if (stage) __syncthreads();
-    attn_weights(K, Q, qb + (long)s0 * NQ + 3 * hid + h * nd, NQ, T, c, nd, s0, sc, dsum, red);
+    const Rows K = stage_rows(qb + hid + h * c, NQ, T, T, c, tiles, stage & 1);
+    const Rows Cn = stage_rows(qb + 2 * hid + h * c, NQ, T, T, c, tiles + T * tp, stage & 1);
+    const Rows Q = stage_rows(qb + (long)s0 * NQ + h * c, NQ, QT, nq, c, tiles + 2 * T * tp, stage & 1);
+    const Rows D = stage_rows(db + (long)s0 * hid, hid, QT, nq, c, tiles + (2 * T + QT) * tp, stage & 1);
+    if (stage & 1) __syncthreads();
+    attn_weights<NCH>(K, Q, qb + (long)s0 * NQ + 3 * hid + h * nd, NQ, T, c, nd, s0, sc, dsum, red);
     for (int p = tid; p < T * QT; p += 256) {
         const int t = p / QT, sl = p % QT, s = s0 + sl;
-        dw[p] = s < T ? dot_chunks(D.p + (long)sl * D.stride, Cn.p + (long)t * Cn.stride, c) : 0.f;
+        dw[p] = s < T ? dot_chunks<NCH>(D.p + (long)sl * D.stride, Cn.p + (long)t * Cn.stride, c) : 0.f;
     }
     __syncthreads();
     const int sl = tid % QT, sub = tid / QT;
@@ -902,33 +932,28 @@ __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __res
     // keys and content: item (t, chunk j)
     for (int it = tid; it < T * nch; it += 256) {
         const int t = it / nch, j = it % nch;
-        float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ac[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        Acc8 ak = acc8_zero(), ac = acc8_zero();
+#pragma unroll 4
         for (int q = 0; q < nq; ++q) {
-            const float wv = sc[t * QT + q], dv = dw[t * QT + q] * isq;
-            const D8 qv = ld8(Q.p + (long)q * Q.stride + 8 * j);
-            const D8 rv = ld8(D.p + (long)q * D.stride + 8 * j);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { ak[i] += dv * qv.v[i]; ac[i] += wv * rv.v[i]; }
+            axpy8(ak, dw[t * QT + q] * isq, Q.p + (long)q * Q.stride + 8 * j);
+            axpy8(ac, sc[t * QT + q], D.p + (long)q * D.stride + 8 * j);
         }
-        float* gk = gq + (long)t * NQ + hid + h * c + 8 * j;
-        float* gc = gq + (long)t * NQ + 2 * hid + h * c + 8 * j;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { atomicAdd(&gk[i], ak[i]); atomicAdd(&gc[i], ac[i]); }
+        float* gk = sl_out + (long)t * 2 * hid + h * c + 8 * j;
+        float* gc = gk + hid;
+        *reinterpret_cast<float4*>(gk) = make_float4(ak.v[0][0], ak.v[0][1], ak.v[1][0], ak.v[1][1]);
+        *reinterpret_cast<float4*>(gk + 4) = make_float4(ak.v[2][0], ak.v[2][1], ak.v[3][0], ak.v[3][1]);
+        *reinterpret_cast<float4*>(gc) = make_float4(ac.v[0][0], ac.v[0][1], ac.v[1][0], ac.v[1][1]);
+        *reinterpret_cast<float4*>(gc + 4) = make_float4(ac.v[2][0], ac.v[2][1], ac.v[3][0], ac.v[3][1]);
     }
     // queries: item (sl, chunk j), owned by this workgroup alone
     for (int it = tid; it < QT * nch; it += 256) {
         const int q = it % QT, j = it / QT, s = s0 + q;
         if (s >= T) continue;
-        float aq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) {
-            const float dv = dw[t * QT + q] * isq;
-            const D8 kv = ld8(K.p + (long)t * K.stride + 8 * j);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) aq[i] += dv * kv.v[i];
-        }
-        float* g = gq + (long)s * NQ + h * c + 8 * j;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = aq[i];
+        Acc8 aq = acc8_zero();
+#pragma unroll 8
+        for (int t = 0; t < T; ++t) axpy8(aq, dw[t * QT + q] * isq, K.p + (long)t * K.stride + 8 * j);
+        const float o[8] = {aq.v[0][0], aq.v[0][1], aq.v[1][0], aq.v[1][1], aq.v[2][0], aq.v[2][1], aq.v[3][0], aq.v[3][1]};
+        st8(gq + (long)s * NQ + h * c + 8 * j, o);
     }
     // decay: d raw_f[s] = -(f+1)/sqrt(nd) * (sum_t dscore[t][s] |t - s|) * sigmoid'(raw_f) / 2
     if (tid < QT && s0 + tid < T) {
@@ -938,8 +963,26 @@ __global__ __launch_bounds__(256) void dmx_attn_bwd_kernel(const bf16_raw* __res
         a *= -rsqrtf((float)nd);
         for (int f = 0; f < nd; ++f) {
             const float sg = sigm(bf2f(qb[(long)s * NQ + 3 * hid + h * nd + f]));
-            gq[(long)s * NQ + 3 * hid + h * nd + f] = a * (float)(f + 1) * 0.5f * sg * (1.f - sg);
+            gq[(long)s * NQ + 3 * hid + h * nd + f] = f2bf(a * (float)(f + 1) * 0.5f * sg * (1.f - sg));
         }
+    }
+}
+
+// dqkv[b][t][hid .. 3 hid) = sum over the query tiles of slab[tile][b][t][0 .. 2 hid)
+__global__ __launch_bounds__(256) void dmx_attn_bwd_sum_kernel(const float* __restrict__ slab, int ntiles, long rows /*B T*/, int hid, int NQ,
+                                                               bf16_raw* __restrict__ dqkv) {
+    const int nq = (2 * hid) >> 3;
+    const long total = rows * nq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / nq;
+        const int q = (int)(i % nq);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < ntiles; ++k) {
+            const float* p = slab + ((long)k * rows + r) * 2 * hid + 8 * q;
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        st8(dqkv + r * NQ + hid + 8 * q, v);
     }
 }
 
@@ -1167,23 +1210,59 @@ extern "C" int sehip_dmx_attn_fwd(const void* qkv, int B, int T, int hid, int he
     if (int e = attn_check("dmx_attn_fwd", B, T, hid, heads, nd, NQ, base)) return e;
     const size_t tiles = ((size_t)2 * T + QT) * (hid / heads + 8) * sizeof(bf16_raw);
     const int stage = base + tiles <= 150 * 1024;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-    dmx_attn_fwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, stage ? base + tiles : base, (hipStream_t)stream>>>((const bf16_raw*)qkv, T, hid, heads, nd, NQ,
-                                                                                                                       stage, (bf16_raw*)out);
+    const dim3 grid((T + QT - 1) / QT, heads, B);
+    const size_t lds = stage ? base + tiles : base;
+#define DMX_ATTN_FWD(NCH)                                                                                                              \
+    do {                                                                                                                               \
+        static bool attr = false;                                                                                                      \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_fwd_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
+        dmx_attn_fwd_kernel<NCH><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)qkv, T, hid, heads, nd, NQ, stage, (bf16_raw*)out);     \
+    } while (0)
+    switch (hid / heads / 8) {
+        case 1: DMX_ATTN_FWD(1); break;
+        case 2: DMX_ATTN_FWD(2); break;
+        case 4: DMX_ATTN_FWD(4); break;
+        case 8: DMX_ATTN_FWD(8); break;
+        case 16: DMX_ATTN_FWD(16); break;
+        default: DMX_ATTN_FWD(0); break;
+    }
+#undef DMX_ATTN_FWD
     SEHIP_CHECK_LAUNCH("dmx_attn_fwd");
     return 0;
 }
 
-extern "C" int sehip_dmx_attn_bwd(const void* qkv, const void* dres, int B, int T, int hid, int heads, int nd, int NQ, float* dqkv, void* stream) {
+extern "C" long sehip_dmx_attn_bwd_scratch_floats(int B, int T, int hid) { return (long)((T + QT - 1) / QT) * B * T * 2 * hid; }
+
+extern "C" int sehip_dmx_attn_bwd(const void* qkv, const void* dres, int B, int T, int hid, int heads, int nd, int NQ, float* slabs, void* dqkv_bf16,
+                                  void* stream) {
     const size_t base = ((size_t)2 * T * QT + QT + 8 * QT) * sizeof(float);
     if (int e = attn_check("dmx_attn_bwd", B, T, hid, heads, nd, NQ, base)) return e;
+    SEHIP_REQUIRE(slabs && dqkv_bf16, "dmx_attn_bwd: null output");
     const size_t tiles = ((size_t)2 * T + 2 * QT) * (hid / heads + 8) * sizeof(bf16_raw);
     const int stage = base + tiles <= 150 * 1024;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-    dmx_attn_bwd_kernel<<<dim3((T + QT - 1) / QT, heads, B), 256, stage ? base + tiles : base, (hipStream_t)stream>>>((const bf16_raw*)qkv, (const bf16_raw*)dres, T,
-                                                                                                                       hid, heads, nd, NQ, stage, dqkv);
+    const dim3 grid((T + QT - 1) / QT, heads, B);
+    const size_t lds = stage ? base + tiles : base;
+#define DMX_ATTN_BWD(NCH)                                                                                                              \
+    do {                                                                                                                               \
+        static bool attr = false;                                                                                                      \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_bwd_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
+        dmx_attn_bwd_kernel<NCH><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)qkv, (const bf16_raw*)dres, T, hid, heads, nd, NQ, stage, slabs, \
+                                                                          (bf16_raw*)dqkv_bf16);                                       \
+    } while (0)
+    switch (hid / heads / 8) {
+        case 1: DMX_ATTN_BWD(1); break;
+        case 2: DMX_ATTN_BWD(2); break;
+        case 4: DMX_ATTN_BWD(4); break;
+        case 8: DMX_ATTN_BWD(8); break;
+        case 16: DMX_ATTN_BWD(16); break;
+        default: DMX_ATTN_BWD(0); break;
+    }
+#undef DMX_ATTN_BWD
     SEHIP_CHECK_LAUNCH("dmx_attn_bwd");
+    const long items = (long)B * T * ((2 * hid) >> 3);
+    long g = (items + 255) / 256;
+    if (g > 2048) g = 2048;
+    dmx_attn_bwd_sum_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(slabs, (T + QT - 1) / QT, (long)B * T, hid, NQ, (bf16_raw*)dqkv_bf16);
+    SEHIP_CHECK_LAUNCH("dmx_attn_bwd_sum");
     return 0;
 }

@@ -320,7 +320,7 @@ class DemucsStatic:
                 if "attn" in lay:
                     a = f"{p}{lay['attn']}."
                     nq = 3 * hid + HEADS * NDECAY
-                    buf(k + "qkv", i, nq); buf(k + "dqkv", i, nq); buf(k + "dqkv32", i, nq, torch.float32)
+                    buf(k + "qkv", i, nq); buf(k + "dqkv", i, nq)
                     buf(k + "r", i, hid); buf(k + "dr", i, hid); buf(k + "h3", i, hid); buf(k + "dh3", i, hid)
                     names = ("query", "key", "content", "query_decay")
                     w = np.concatenate([ia(f"{a}{n}.weight")[:, :, 0] for n in names])
@@ -557,6 +557,8 @@ class DemucsWorkspace:
         self.sums = torch.zeros(nn_, B, 8, 2, dtype=torch.float64, device=device)
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
         self.dc = torch.zeros(2 * B * max([ls["H"] * self.chunks[ls["level"]][0] for ls in st.lstms] + [1]), dtype=torch.float32, device=device)
+        self.attn_slabs = torch.empty(max([int(_lib.lib().sehip_dmx_attn_bwd_scratch_floats(B, lens[a["level"]], a["hid"])) for a in st.attns] + [1]),
+                                      dtype=torch.float32, device=device)      # key / content gradients per query tile (LocalState backward)
         self.lstm_sync = torch.zeros(int(_lib.lib().sehip_dmx_lstm_sync_bytes()) // 4, dtype=torch.int32, device=device)   # arrival counters + time-out word
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self.comm = None     # third stream: early un-pack + all-reduce of finished gradient ranges (data-parallel runs only)
@@ -869,9 +871,8 @@ class DemucsWorkspace:
                     hid, T = b[k + "r"].C, b[k + "r"].Tst
                     self.wgrad(k + "proj")
                     self.gemm(k + "proj.dg")
-                    b[k + "dqkv32"].t.zero_()
-                    call("sehip_dmx_attn_bwd", b[k + "qkv"].ptr, b[k + "dr"].ptr, B, T, hid, HEADS, NDECAY, b[k + "qkv"].C, b[k + "dqkv32"].ptr, stream())
-                    call("sehip_dmx_f32_to_bf16", b[k + "dqkv32"].ptr, b[k + "dqkv32"].t.numel(), b[k + "dqkv"].ptr, stream())
+                    call("sehip_dmx_attn_bwd", b[k + "qkv"].ptr, b[k + "dr"].ptr, B, T, hid, HEADS, NDECAY, b[k + "qkv"].C, ptr(self.attn_slabs),
+                         b[k + "dqkv"].ptr, stream())
                     self._chain_dirty = True
                     self.wgrad(k + "qkv")
                     self.gemm(k + "qkv.dg")

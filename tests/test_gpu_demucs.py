@@ -305,15 +305,16 @@ def test_local_state_attention(B, T, hid):
     dev = "cuda"
     qd = qkv.to(dev)
     out = torch.zeros(B, T, hid, dtype=BF, device=dev)
-    dqkv = torch.zeros(B, T, nq, device=dev)
+    dqkv = torch.zeros(B, T, nq, dtype=BF, device=dev)
+    slabs = torch.empty(L.lib().sehip_dmx_attn_bwd_scratch_floats(B, T, hid), device=dev)
     L.call("sehip_dmx_attn_fwd", qd.data_ptr(), B, T, hid, heads, nd, nq, out.data_ptr(), None)
     dres_d = dres.to(dev)
-    L.call("sehip_dmx_attn_bwd", qd.data_ptr(), dres_d.data_ptr(), B, T, hid, heads, nd, nq, dqkv.data_ptr(), None)
+    L.call("sehip_dmx_attn_bwd", qd.data_ptr(), dres_d.data_ptr(), B, T, hid, heads, nd, nq, slabs.data_ptr(), dqkv.data_ptr(), None)
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu(), res.detach().transpose(1, 2)) < 4e-3
-    got = dqkv.cpu()
+    got = dqkv.float().cpu()
     for name, a, b in (("query", 0, hid), ("key", hid, 2 * hid), ("content", 2 * hid, 3 * hid), ("decay", 3 * hid, nq)):
-        assert rel_err(got[..., a:b], dref[..., a:b]) < 5e-3, name
+        assert rel_err(got[..., a:b], dref[..., a:b]) < 6e-3, name      # (bf16 output)
 
 
 @pytest.mark.parametrize("ac,S,resample,normalize,T", [(2, 2, True, True, 5000), (1, 1, True, False, 3001), (2, 1, False, True, 4000)])
