@@ -2454,10 +2454,11 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     const int ktiles = cdiv(d->K, 64 * kq);
     // split m so that the grid has ~2048 workgroups, at least 256 rows each
     static const int gw_env = getenv("SEHIP_GW_WGS") ? atoi(getenv("SEHIP_GW_WGS")) : 0;
-    // every m-split adds its whole dW tile with fp32 atomics: with 10^5 .. 10^6 rows and a few output tiles (Demucs' shallow
-    // levels: 775 488 rows onto 128 x 64 weights) 2048 splits spend more time in those atomics than streaming -- 275 us at
-    // 2048 workgroups, 150 us at 512, 161 us at 256 (e0.rw); the narrow (<= 32 columns) kernels still want the 2048
-    const int gw_wgs = gw_env ? gw_env : ((d->J == 1 && d->cv_nf == 0 && d->cv2_nkt == 0 && d->M >= 100000 && bnw >= 64) ? 512 : 2048);
+    // every m-split adds its whole dW tile with fp32 atomics, and the weight gradients run beside the step's dependent chain on the
+    // second stream: for the dense row spaces of the 1-D models (J == 1: ConvTasNet's 51 168 rows, Demucs' 736 .. 775 488) ~256
+    // workgroups with 1 500 - 3 000 rows each beat 2048 small ones -- Demucs 25.35 -> 24.03 ms per step (128: 26.65), ConvTasNet
+    // 5.19 -> 4.88 (128: 4.79, 96: 5.28), e0.rw of Demucs alone 275 -> 161 us; DCUnet's 2-D products keep the 2048 (512: +1 %)
+    const int gw_wgs = gw_env ? gw_env : ((d->J == 1 && d->cv_nf == 0 && d->cv2_nkt == 0) ? 256 : 2048);
     long want = gw_wgs / ((long)ntiles * ktiles);
     if (want < 1) want = 1;
     long mpb = ((d->M + want - 1) / want + 63) / 64 * 64;
