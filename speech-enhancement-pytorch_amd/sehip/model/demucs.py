@@ -22,7 +22,7 @@ class _DemucsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, mix, anchor):
         ctx.model = model
-        ctx.ws = model._run_forward(mix)
+        ctx.ws = model._run_forward(mix, need_backward=True)      # (grad mode is off inside Function.forward: say it explicitly)
         ctx.generation = ctx.ws.generation
         return ctx.ws.out.clone()
 
@@ -113,10 +113,10 @@ class Demucs(FlatModule):
             self._tables = P.DemucsDeviceTables(self.static, dev)
         return self._lru_get((batch, nsample), self._ws_cap, lambda: P.DemucsWorkspace(self.static, self._tables, batch, nsample, dev))
 
-    def _run_forward(self, mix):
+    def _run_forward(self, mix, need_backward):
         ws = self.workspace(mix.shape[0], mix.shape[-1])
         ws.generation += 1
-        ws.forward(mix.contiguous().float(), self._flat)
+        ws.forward(mix.contiguous().float(), self._flat, need_backward=need_backward)
         return ws
 
     def _run_backward(self, ws, grad_out):
@@ -133,4 +133,4 @@ class Demucs(FlatModule):
             if self._anchor is None or self._anchor.device != mix.device:
                 self._anchor = torch.zeros(1, device=mix.device, requires_grad=True)
             return _DemucsFunction.apply(self, mix, self._anchor)
-        return self._run_forward(mix).out.clone()
+        return self._run_forward(mix, need_backward=False).out.clone()

@@ -701,8 +701,9 @@ class DemucsWorkspace:
             raise SehipError("Demucs: a hand-off spin of the persistent LSTM kernels timed out (results since then are invalid); "
                              "set SEHIP_DMX_LSTM_STEPS=1 to use one launch per time step")
 
-    def forward(self, mix, params):
-        """mix [B, ac, T] fp32 on device -> self.out [B, S, ac, T]."""
+    def forward(self, mix, params, need_backward=True):
+        """mix [B, ac, T] fp32 on device -> self.out [B, S, ac, T].  need_backward=False (inference): the operands only the backward
+        pass reads are not packed."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
         if st.lstms and self.generation % 64 == 2 and not torch.cuda.is_current_stream_capturing():
@@ -714,7 +715,7 @@ class DemucsWorkspace:
         # (the transposed copies) under the shallow decoder levels -- never beside the deep levels' own products, which are
         # latency-bound and ran 3x slower next to a packing kernel.
         two = self.side is not None and not torch.cuda.is_current_stream_capturing()
-        head = st.n_wpack_head if two else st.n_wpack_dev
+        head = st.n_wpack_head if two else (st.n_wpack_dev if need_backward else st.n_wpack_fwd)
         self._pack(params, 0, head, stream())
         call("sehip_pack_f32", ptr(params), ptr(tb.btab), st.n_bpack, ptr(tb.bpack), stream())
         up = 1 if cfg.resample else 0
@@ -767,14 +768,14 @@ class DemucsWorkspace:
         call("sehip_dmx_add", b[top].ptr, b[top].ptr, b[top].t.numel(), b[f"d{D - 1}.in"].ptr, stream())
         for i in range(D - 1, -1, -1):
             k = f"d{i}."
-            if two and i == st.late_level - 1 or (two and st.late_level == 0 and i == 0 and self._bwd_pack_events is None):
+            if need_backward and two and (i == st.late_level - 1 or (st.late_level == 0 and i == 0 and self._bwd_pack_events is None)):
                 self._pack_backward_operands(params)
             self.gemm(k + "rw")
             self._norm_fwd(k + "n0", params, k + "g")
             self.gemm(k + "ct")
             if i > 0:
                 self._norm_fwd(k + "n1", params, f"d{i - 1}.in", add=f"e{i - 1}.out")
-        if two and self._bwd_pack_events is None:
+        if need_backward and two and self._bwd_pack_events is None:
             self._pack_backward_operands(params)
         yt = b["d0.yt"]
         call("sehip_dmx_post", yt.ptr, ptr(self.ms), B, cfg.co, cfg.cop, yt.Tst, self.padl, self.T, up, ptr(tb.kdn) if up else None,
