@@ -2,7 +2,9 @@
 // implicit-GEMM engine over channels-last bf16 activations [B][T][C]):
 //   prep / post   normalise + pad + julius-style x2 up-sampling, and /2 down-sampling + de-normalise + center_trim (:453-470, :485-490)
 //   gn / act      GroupNorm (:176, :382) fused with GELU or GLU, LayerScale (:52-71) and the residual / skip additions (:204-207, :483)
-//   lstm          one time step of a bidirectional nn.LSTM layer (:83) per launch, both directions in the launch
+//   lstm          a bidirectional nn.LSTM layer (:83): ONE persistent launch whose workgroups hand h(t) / the gate gradients over once
+//                 per time step (dmx_lstm_seq_*), or one launch per time step (dmx_lstm_step_*: fallback and cross-check)
+//   frames        the BLSTM's overlapping chunks of max_steps frames (:91-117): gather, middle-part pick and their adjoints
 //   attn          LocalState (:210-269, nfreqs = 0): scores, distance penalty, softmax over the key axis, weighted content
 // Thread layout of the streaming kernels: a thread owns ONE piece of 8 output channels for all its frames (the launch's thread
 // count is a multiple of the number of pieces, so piece = global thread id % pieces), hence per-channel affine terms and the
