@@ -80,3 +80,43 @@ def test_dcunet_patch_weight_gradient_matches_generic():
     assert float((fast["out"] - slow["out"]).abs().max()) == 0.0            # the forward pass is untouched
     d = (fast["grads"] - slow["grads"]).norm() / slow["grads"].norm()
     assert 0.0 < float(d) < 5e-3, float(d)                                   # not bit-identical: it really is the other kernel
+
+
+CHILD_DMX = r"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(%(root)r, "speech-enhancement-pytorch_amd")); sys.path.insert(0, %(root)r)
+from sehip.model import Demucs
+dev = torch.device("cuda:0")
+torch.manual_seed(41)
+model = Demucs(sources=["a", "b"], audio_channels=2, channels=32, depth=4, norm_starts=2, dconv_lstm=2, dconv_attn=2).to(dev).train()
+with torch.no_grad():
+    for name, prm in model.named_parameters():
+        if name.endswith(".scale"):
+            prm.fill_(0.3)
+g = torch.Generator().manual_seed(42)
+x = (0.3 * torch.randn(2, 2, 16000, generator=g)).to(dev)
+out = model(x)
+out.backward(1e-3 * torch.ones_like(out))
+torch.cuda.synchronize()
+model.workspace(2, 16000).check_lstm_handoffs()
+torch.save({"out": out.detach().cpu(), "grads": model.flat_grads.cpu()}, sys.argv[1])
+"""
+
+
+def test_demucs_persistent_lstm_and_second_stream_match_the_plain_schedule():
+    """Demucs with a chunked and an unchunked BLSTM level: the persistent hand-off LSTM kernels + second-stream packing / weight
+    gradients against one launch per time step on a single stream (SEHIP_DMX_LSTM_STEPS, SEHIP_NO_SIDE_STREAM)."""
+    def run_dmx(env_extra):
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "r.pt")
+            env = dict(os.environ)
+            env.update(env_extra)
+            r = subprocess.run([sys.executable, "-c", CHILD_DMX % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            return torch.load(path)
+    fast = run_dmx({})
+    slow = run_dmx({"SEHIP_DMX_LSTM_STEPS": "1", "SEHIP_NO_SIDE_STREAM": "1"})
+    eo = float((fast["out"] - slow["out"]).norm() / slow["out"].norm())
+    eg = float((fast["grads"] - slow["grads"]).norm() / slow["grads"].norm())
+    assert eo < 2e-2, eo        # same arithmetic; the fp64 / fp32 atomics' order flips bf16 roundings from run to run
+    assert eg < 5e-2, eg
