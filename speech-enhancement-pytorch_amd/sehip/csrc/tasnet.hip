@@ -487,7 +487,24 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
                                                                 const float* __restrict__ slope, const double* __restrict__ stats,
                                                                 const float* __restrict__ gamma, const float* __restrict__ Wd, int dil,
                                                                 const double* __restrict__ sums, int K, int C, bf16_raw* __restrict__ dh,
-                                                                float* __restrict__ dslope) {
+                                                                float* __restrict__ dslope, const float* __restrict__ part, int nrows,
+                                                                int ncols, float* __restrict__ gch) {
+    // first: the column sums of the reduce kernel's partial rows (gch += sum_r part[r][c]; it was a launch of its own, 28 per step, on
+    // the dependent chain), spread over this launch's workgroups as units of (256 columns, one of <= 64 row groups)
+    {
+        const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int ncb = (ncols + 255) >> 8;
+        int rg = nrows >> 3;
+        rg = rg > 64 ? 64 : (rg < 1 ? 1 : rg);
+        for (int u = bid; u < ncb * rg; u += nblk) {
+            const int c = (u % ncb) * 256 + threadIdx.x, r0 = u / ncb;
+            if (c < ncols) {
+                float acc = 0.f;
+                for (int r = r0; r < nrows; r += rg) acc += part[(size_t)r * ncols + c];
+                atomicAdd(&gch[c], acc);
+            }
+        }
+    }
     const int m = blockIdx.y, nq = C >> 3;
     const PieceMap pm = piece_map(nq);
     const float a = slope[0];
@@ -868,15 +885,14 @@ extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slop
     const dim3 grid = ctn_grid(M, K, C), rgrid = ctn_reduce_grid(M, K, C);
     const int ncols = (2 + (dw ? 3 : 0)) * C, nrows = (int)(rgrid.x * rgrid.y);
     const size_t lds = (size_t)ncols * sizeof(float);
-    const dim3 cgrid = ctn_colsum_grid(nrows, ncols);
     if (dw) {
         ctn_gln_bwd_reduce_kernel<3, true><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
-        ctn_colsum_kernel<<<cgrid, 256, 0, st>>>(scratch, nrows, ncols, gch);
-        ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
+        ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope,
+                                                                scratch, nrows, ncols, gch);
     } else {
         ctn_gln_bwd_reduce_kernel<3, false><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
-        ctn_colsum_kernel<<<cgrid, 256, 0, st>>>(scratch, nrows, ncols, gch);
-        ctn_gln_bwd_apply_kernel<3, false><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope);
+        ctn_gln_bwd_apply_kernel<3, false><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope,
+                                                                 scratch, nrows, ncols, gch);
     }
     SEHIP_CHECK_LAUNCH("ctn_gln_bwd");
     return 0;
