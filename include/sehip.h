@@ -351,7 +351,7 @@ int sehip_dmx_f32_to_bf16(const float* a, long n, void* out, void* stream);
  * 2: adjoint of 1 (a [B][T][C] -> out [B nf][W][C]); 3: adjoint of 0 plus b (a [B nf][W][C], b [B][T][C] -> out [B][T][C]).  bf16. */
 int sehip_dmx_frames(int mode, const void* a, const void* b, int B, int T, int C, int nf, int W, int S, void* out, void* stream);
 /* sync: sehip_dmx_lstm_sync_bytes() bytes of device memory at the start of an allocation (the caller zeroes it once; every call clears
- * the 60 arrival counters, word 60 is sticky): with it the layer is ONE
+ * the arrival counters behind word 64, word 60 is sticky): with it the layer is ONE
  * persistent launch whose workgroups hand h(t) / the gate gradients to each other once per step (write-through stores, arrival
  * counters, bounded spins: word 60 of the block is set when a spin timed out); NULL, a hidden size whose H/32 is not 1, 2, 4, 8 or 16,
  * more than 256 workgroups, or SEHIP_DMX_LSTM_STEPS in the environment: one launch per time step. */

@@ -556,8 +556,9 @@ __global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __r
 // units with its W_hh slice resident in registers -- hand h(t) (forward) / the gate gradients (backward) to each other through
 // global memory once per time step.  Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the table of
 // sc1 hand-offs): every handed-off byte is stored with an 8-byte agent-scope relaxed atomic store (sc1: write-through), every
-// storing wave drains vmcnt, a workgroup barrier, ONE lane adds to the group's arrival counter (agent-scope atomic); the consumer's
-// lane 0 polls that counter with sc1 loads (bounded spin: a time-out sets sync[TMO] and lets the kernel run to its end with
+// storing wave drains vmcnt, a workgroup barrier, then the group's arrival counter is advanced (agent-scope atomics; the counter is
+// kept in 8 replicas on cache lines of their own, one wave instruction adds to all of them and a member polls replica member % 8:
+// 32 pollers on one line cost 0.5 ms per Demucs step); the consumer's lane 0 polls its replica with sc1 loads (bounded spin: a time-out sets sync[TMO] and lets the kernel run to its end with
 // garbage instead of hanging; the word is sticky: the call clears the counters only, the owner of the block reads it when it
 // likes), a workgroup barrier, then EVERY load of handed-off bytes is an sc1 load to registers.
 // No fence, no L2 write-back.  Results never depend on placement; for speed the members of a group are given equal
@@ -567,8 +568,11 @@ __global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __r
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define DMX_SYNC_WORDS 64          // sync block: [0, 60) arrival counters of the groups, [60] time-out word
+#define DMX_SYNC_WORDS 4096        // sync block: word 60 = time-out (sticky); from word 64: per group 8 replicas of its arrival counter, 128 B apart
 #define DMX_TMO 60
+#define DMX_CNT0 64
+#define DMX_REPL 8
+#define DMX_RSTRIDE 32
 #define DMX_SPIN_LIMIT (1u << 20)  // polls of >= 0.3 us each: a fraction of a second, once (the time-out is sticky)
 
 struct SeqMap { int dir, bz, member; bool active; };
@@ -619,7 +623,8 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_fwd_kernel(float* __restrict
     const SeqMap sm = seq_map(H / 16, btiles);
     if (!sm.active) return;
     const int dir = sm.dir, u0 = sm.member * 16, bt = sm.bz * 16, nb = H / 16;
-    gu32* cnt = (gu32*)sync + (sm.bz * 2 + dir);
+    gu32* cnt0 = (gu32*)sync + DMX_CNT0 + (sm.bz * 2 + dir) * DMX_REPL * DMX_RSTRIDE;      // every member adds to all replicas,
+    gu32* cnt = cnt0 + (sm.member % DMX_REPL) * DMX_RSTRIDE;                                    // and polls its own
     gu32* tmo = (gu32*)sync + DMX_TMO;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, ug = lane >> 4;
     bf16x8 wf[KS];
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_fwd_kernel(float* __restrict
                 __hip_atomic_store((gu64*)(hs + ((long)(bt + r) * T + t) * 2 * H + dir * H + u0 + 4 * part),
                                    *reinterpret_cast<const unsigned long long*>(&hrow[r][4 * part]), RLX_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, RLX_AGENT);
+            if (lane < DMX_REPL) __hip_atomic_fetch_add(cnt0 + lane * DMX_RSTRIDE, 1u, RLX_AGENT);
         }
     }
 }
@@ -692,7 +697,8 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __re
     const SeqMap sm = seq_map(H / 16, btiles);
     if (!sm.active) return;
     const int dir = sm.dir, u0 = sm.member * 16, bt = sm.bz * 16, nb = H / 16;
-    gu32* cnt = (gu32*)sync + (sm.bz * 2 + dir);
+    gu32* cnt0 = (gu32*)sync + DMX_CNT0 + (sm.bz * 2 + dir) * DMX_REPL * DMX_RSTRIDE;      // every member adds to all replicas,
+    gu32* cnt = cnt0 + (sm.member % DMX_REPL) * DMX_RSTRIDE;                                    // and polls its own
     gu32* tmo = (gu32*)sync + DMX_TMO;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, ug = lane >> 4;
     bf16x8 wf[KS];      // W_hh^T rows u0 + m, K quarter of gate w
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __re
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, RLX_AGENT);
+        if (threadIdx.x < DMX_REPL) __hip_atomic_fetch_add(cnt0 + threadIdx.x * DMX_RSTRIDE, 1u, RLX_AGENT);
     }
 }
 
@@ -1144,7 +1150,7 @@ static void lstm_seq_bwd_launch(dim3 g, hipStream_t st, const float* gates, cons
 static bool lstm_seq_ok(int Bn, int T, int H, const unsigned* sync) {
     static const bool off = getenv("SEHIP_DMX_LSTM_STEPS") != nullptr;
     const int ks = H / 32, btiles = (Bn + 15) / 16;
-    return sync && !off && (ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16) && 2 * btiles * (H / 16) <= 256 && 2 * btiles <= DMX_TMO &&
+    return sync && !off && (ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16) && 2 * btiles * (H / 16) <= 256 && DMX_CNT0 + 2 * btiles * DMX_REPL * DMX_RSTRIDE <= DMX_SYNC_WORDS &&
            (long)Bn * T * 8 * H * 2 < (1L << 31);      // 32-bit byte offsets into the handed-off tensors
 }
 extern "C" int sehip_dmx_lstm_sync_bytes(void) { return DMX_SYNC_WORDS * 4; }
@@ -1154,7 +1160,7 @@ extern "C" int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, in
     hipStream_t st = (hipStream_t)stream;
     const int btiles = (Bn + 15) / 16;
     if (lstm_seq_ok(Bn, T, H, sync)) {
-        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_TMO * 4, st) == hipSuccess, "dmx_lstm_fwd: clearing the sync block failed");
+        SEHIP_REQUIRE(hipMemsetAsync(sync + DMX_CNT0, 0, (size_t)2 * btiles * DMX_REPL * DMX_RSTRIDE * 4, st) == hipSuccess, "dmx_lstm_fwd: clearing the sync block failed");
         const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
         switch (H / 32) {
             case 1: lstm_seq_fwd_launch<1>(g, st, pre, whh, hs, cs, Bn, T, btiles, sync); break;
@@ -1179,7 +1185,7 @@ extern "C" int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const fl
     hipStream_t st = (hipStream_t)stream;
     const int btiles = (Bn + 15) / 16;
     if (lstm_seq_ok(Bn, T, H, sync)) {
-        SEHIP_REQUIRE(hipMemsetAsync(sync, 0, DMX_TMO * 4, st) == hipSuccess, "dmx_lstm_bwd: clearing the sync block failed");
+        SEHIP_REQUIRE(hipMemsetAsync(sync + DMX_CNT0, 0, (size_t)2 * btiles * DMX_REPL * DMX_RSTRIDE * 4, st) == hipSuccess, "dmx_lstm_bwd: clearing the sync block failed");
         const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
         switch (H / 32) {
             case 1: lstm_seq_bwd_launch<1>(g, st, gates, whhT, cs, dhs, dG, Bn, T, btiles, sync); break;
