@@ -557,8 +557,8 @@ __global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __r
 // global memory once per time step.  Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the table of
 // sc1 hand-offs): every handed-off byte is stored with an 8-byte agent-scope relaxed atomic store (sc1: write-through), every
 // storing wave drains vmcnt, a workgroup barrier, then the group's arrival counter is advanced (agent-scope atomics; the counter is
-// kept in 8 replicas on cache lines of their own, one wave instruction adds to all of them and a member polls replica member % 8:
-// 32 pollers on one line cost 0.5 ms per Demucs step); the consumer's lane 0 polls its replica with sc1 loads (bounded spin: a time-out sets sync[TMO] and lets the kernel run to its end with
+// kept in 32 replicas on cache lines of their own, one wave instruction adds to all of them and a member polls replica member % 32:
+// 32 pollers on ONE line cost 0.8 ms per Demucs step: 23.6 ms with one counter, 23.1 with 8 replicas, 22.8 with 32); the consumer's lane 0 polls its replica with sc1 loads (bounded spin: a time-out sets sync[TMO] and lets the kernel run to its end with
 // garbage instead of hanging; the word is sticky: the call clears the counters only, the owner of the block reads it when it
 // likes), a workgroup barrier, then EVERY load of handed-off bytes is an sc1 load to registers.
 // No fence, no L2 write-back.  Results never depend on placement; for speed the members of a group are given equal
@@ -568,10 +568,10 @@ __global__ __launch_bounds__(256) void dmx_lstm_step_bwd_kernel(const float* __r
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define DMX_SYNC_WORDS 4096        // sync block: word 60 = time-out (sticky); from word 64: per group 8 replicas of its arrival counter, 128 B apart
+#define DMX_SYNC_WORDS 16384       // sync block: word 60 = time-out (sticky); from word 64: per group 32 replicas of its arrival counter, 128 B apart
 #define DMX_TMO 60
 #define DMX_CNT0 64
-#define DMX_REPL 8
+#define DMX_REPL 32
 #define DMX_RSTRIDE 32
 #define DMX_SPIN_LIMIT (1u << 20)  // polls of >= 0.3 us each: a fraction of a second, once (the time-out is sticky)
 
