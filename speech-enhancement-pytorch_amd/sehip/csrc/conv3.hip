@@ -1,0 +1,498 @@
+// conv_gemm_v3_kernel: the implicit-GEMM convolution of the deep DCCRN layers (ComplexConv2d / ComplexConvTranspose2d forward
+// and input gradients, src/model/dccrn.py:316-450, C >= 16 channels per source, >= 128 output columns), third design.
+//
+// What bounded conv_gemm_v2 (round 2: 0.26 of the dense bf16 MFMA peak): 64 x 64 wave tiles (16 fragment reads per 32 MFMAs),
+// a 32-channel input patch staged through registers with ds_write_b128 and a ~3 200-cycle stall at every chunk boundary,
+// 16 KB of weights per 2.1 MFLOP.  Here, per 256-thread workgroup (two per CU), tile = 256 rows x 128 output channels:
+//   * 4 waves as 2 (m) x 2 (n), wave tile 128 rows x 64 channels = 8 x 4 MFMA tiles (16x16x32 bf16): 12 fragment reads per 32
+//     MFMAs, one barrier per 32 MFMAs, 8 KB of weights + ~4 KB of patch per 2.1 MFLOP;
+//   * K runs over 16-channel chunks; an MFMA's k = 32 is (tap pair) x (16 channels): k group g = lane >> 4 is tap 2j + (g >> 1),
+//     8-channel piece g & 1, for the weight AND the activation operand -- every LDS row is 32 bytes, and 16 rows x 32 B is
+//     exactly what one 16-lane group of ds_read_b128 serves without bank conflicts;
+//   * BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA writes lane-linear
+//     images but reads per-lane sources, so the patch image is a free permutation of 16-byte pieces: frames x [parity planes of
+//     a stride-2 layer] x rows, frame stride S and the frame order inside a 16-column MFMA tile chosen per geometry so that every
+//     fragment read is conflict free (tools/c3_census.py); padding frames / rows come from a zero page;
+//   * the patch is double buffered by 16-channel chunk: chunk c + 1 lands while chunk c is multiplied (no chunk-boundary
+//     stall); weights: ring of FOUR 8 KB tiles, tile s + 3 issued at step s; counted s_waitcnt vmcnt, ONE raw s_barrier per
+//     K step.  The DMA stream is strictly periodic (it runs past the end into unused slots) so that the counts are constants.
+// Operand / epilogue conventions as conv_gemm_v2 (weights are the MFMA A operand, a lane ends up with 4 consecutive output
+// channels of a row, dense 64-channel runs leave through a wave-private LDS image, optional fused ComplexBatchNorm sums).
+#include <stdlib.h>
+#include "common.h"
+#include "../../../include/sehip.h"
+
+typedef __attribute__((address_space(3))) void c3_lds_void;
+typedef __attribute__((address_space(1))) const void c3_gvoid;
+
+__device__ uint4 c3_zero16 = {0u, 0u, 0u, 0u};   // source of every padding piece
+
+#define C3_WSLOT 8192
+#define C3_NSLOT 4
+#define C3_RING (C3_WSLOT * C3_NSLOT)
+
+// geometry of the patch image (tools/c3_census.py: conflict-free frame stride per (row stride, taps, rows per frame))
+template <int NF, int FM, int J>
+struct C3Geo {
+    static constexpr int FR = (J - 1) * FM + NF;                       // patch rows per frame
+    static constexpr int S = FM == 2 ? (J == 4 ? 11 : J == 8 ? 20 : J == 16 ? 35 : 67)
+                             : NF == 3 ? (J == 4 ? 7 : J == 8 ? 12 : J == 16 ? 18 : 34)
+                                       : (J == 4 ? 5 : J == 8 ? 12 : J == 16 ? 17 : 33);
+    static constexpr int P1 = FM == 2 ? (FR + 1) / 2 : 0;              // first physical row of the odd-row plane
+    static constexpr int TB = 256 / J;                                 // frames per tile
+    static constexpr int NPIECE = (TB + 1) * S * 2;                    // 16-byte pieces per buffer
+    static constexpr int MAXP = (NPIECE + 255) / 256;                  // DMA instructions per thread and chunk
+    static constexpr int PBYTES = ((TB + 1) * S * 32 + 1023) / 1024 * 1024;
+    static constexpr int LDS_MAIN = C3_RING + 2 * PBYTES + 1024 + 2 * (TB + 1) * 4;
+    static_assert(S >= FR && (FM == 1 || P1 + FR / 2 <= S), "frame stride");
+    static_assert(J == 4 || J == 8 || J == 16 || J == 32, "rows per frame");
+};
+
+// row rw (= 16 mi + column c) of M-wave wm -> frame inside the tile and row inside the frame
+template <int J>
+__device__ __forceinline__ void c3_row(int wm, int rw, int& tl, int& jl) {
+    const int mi = rw >> 4, c = rw & 15;
+    if (J >= 16) {
+        constexpr int per = J >= 16 ? J / 16 : 1;
+        tl = wm * (128 / J) + mi / per;
+        jl = (mi % per) * 16 + c;
+    } else if (J == 8) {
+        tl = wm * 16 + (mi >> 1) * 4 + (mi & 1) + 2 * (c >> 3);
+        jl = c & 7;
+    } else {
+        const int q = c >> 2;
+        tl = wm * 32 + (mi >> 1) * 8 + (mi & 1) * 2 + ((q & 2) ? 4 : 0) + ((q ^ (q >> 1)) & 1);
+        jl = c & 3;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void c3_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// DMA instructions issued behind the youngest item step (.., j) needs (its weight tile, and the patch buffer when j == 0):
+// per step [weight tile s + 3: 2], then at j == 0 [next chunk's patch: MAXP]
+template <int H, int MAXP>
+constexpr int c3_count(int j) {
+    if (j == 0 && H <= 3) return 2 * (H - 1);
+    int n = 4;
+    for (int back = 1; back <= 3; ++back)
+        if (((j - back) % H + H) % H == 0) n += MAXP;
+    return n;
+}
+
+template <int H, int MAXP>
+__device__ __forceinline__ void c3_wait_step(int j) {          // j is a constant after unrolling: the switch folds
+    switch (j) {
+        case 0: c3_wait_vm<c3_count<H, MAXP>(0)>(); break;
+        case 1: c3_wait_vm<c3_count<H, MAXP>(1)>(); break;
+        case 2: c3_wait_vm<c3_count<H, MAXP>(2)>(); break;
+        case 3: c3_wait_vm<c3_count<H, MAXP>(3)>(); break;
+        default: c3_wait_vm<c3_count<H, MAXP>(4)>(); break;
+    }
+}
+
+template <int NF, int FM, int J>
+__global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B) {
+    using G = C3Geo<NF, FM, J>;
+    constexpr int TB = G::TB, S = G::S, P1 = G::P1, FR = G::FR, H = NF, MAXP = G::MAXP, NPIECE = G::NPIECE, PBYTES = G::PBYTES;
+    constexpr int TN = 4, TM = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* pbuf = smem + C3_RING;
+    unsigned char* dump = pbuf + 2 * PBYTES;
+    int* ftab = reinterpret_cast<int*>(dump + 1024);                           // [2][TB + 1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int ntn = d.Npad >> 7;
+    const int TV = d.TT + 2;
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = logical % ntn, mt = logical / ntn;
+    const int g0 = mt * TB, n0 = nt * 128;
+    const int f0 = d.cv_fadd;
+
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    const int Ctot = C0 + C1;
+    const int nch = Ctot >> 4;
+    const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
+    const bf16_raw* s0p = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
+    const bf16_raw* s1p = reinterpret_cast<const bf16_raw*>(d.src[1].ptr);
+    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&c3_zero16);
+
+    // ---- frame table: element offset of patch frame p in source s, -1 = padding
+    if (tid < 2 * (TB + 1)) {
+        const int s = tid / (TB + 1), p = tid - s * (TB + 1);
+        const sehip_src& Sr = s ? d.src[1] : d.src[0];
+        const int sv = g0 + p + (s ? tmin1 : tmin0);
+        int v = -1;
+        if (sv >= 0 && (s == 0 || C1)) {
+            const int b = sv / TV, x = sv - b * TV;
+            if (b < B && x >= Sr.tlo && x < Sr.thi) v = (b * Sr.T + x) * Sr.F * Sr.C;
+        }
+        ftab[tid] = v;
+    }
+    __syncthreads();
+    // ---- patch pieces of this thread: piece P = (4 u + wave) * 64 + lane of a buffer = physical row P >> 1, half P & 1
+    int off0[MAXP], off1[MAXP];
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+        const int P = (u * 4 + wave) * 64 + lane;
+        const int prow = P >> 1, half = P & 1;
+        const int p = prow / S, rr = prow - p * S;
+        int r;
+        bool ok = P < NPIECE;
+        if (FM == 2) {
+            if (rr < P1) { r = 2 * rr; } else { r = 2 * (rr - P1) + 1; }
+        } else r = rr;
+        ok = ok && r < FR;
+        const int f = f0 + r;
+        const int fa = ok ? ftab[p] : -1, fb = (ok && C1) ? ftab[(TB + 1) + p] : -1;
+        off0[u] = (fa >= 0 && (unsigned)f < (unsigned)d.src[0].F) ? fa + f * C0 + half * 8 : -1;
+        off1[u] = (fb >= 0 && (unsigned)f < (unsigned)d.src[1].F) ? fb + f * C1 + half * 8 : -1;
+    }
+    auto issue_p = [&](int ch, int buf) {
+        const int second = ch * 16 >= C0 ? 1 : 0;
+        const bf16_raw* base = second ? s1p + (ch * 16 - C0) : s0p + ch * 16;
+        unsigned char* dst = pbuf + buf * PBYTES + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u) {
+            const int o = second ? off1[u] : off0[u];
+            const bf16_raw* q = o >= 0 ? base + o : zero_page;
+            unsigned char* dd = ((u * 4 + wave) * 64 < NPIECE) ? dst + u * 4096 : dump;     // wave-uniform
+            __builtin_amdgcn_global_load_lds((c3_gvoid*)q, (c3_lds_void*)dd, 16, 0, 0);
+        }
+    };
+    // ---- weight tile of step (ch, j): [tap 2j + u][128 n][16 channels]; instruction u of wave w: rows 32 w .. 32 w + 31
+    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;
+    const unsigned woff = (unsigned)((wave * 32 + (lane >> 1)) * d.K + (lane & 1) * 8);
+    auto issue_w = [&](int ch, int j, int slot) {
+        const bf16_raw* wb = Wb + (2 * j * Ctot + ch * 16);
+        unsigned char* dst = smem + slot * C3_WSLOT + wave * 1024;
+        __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + woff), (c3_lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + Ctot + woff), (c3_lds_void*)(dst + 4096), 16, 0, 0);
+    };
+
+    // ---- fragment addresses
+    const int g = lane >> 4, c = lane & 15;
+    const int wrd = (g >> 1) * 4096 + (wn * 64 + c) * 32 + (g & 1) * 16;        // + ni * 512
+    int vbase;
+    {
+        int tl, jl;
+        c3_row<J>(wm, c, tl, jl);                                               // mi = 0
+        vbase = (tl * S + jl) * 32 + (g & 1) * 16;
+    }
+    auto imm_of = [](int mi) constexpr {
+        if (J >= 16) { constexpr int per = J >= 16 ? J / 16 : 1; return ((mi / per) * S + (mi % per) * 16) * 32; }
+        if (J == 8) return ((mi >> 1) * 4 + (mi & 1)) * S * 32;
+        return ((mi >> 1) * 8 + (mi & 1) * 2) * S * 32;
+    };
+    auto tap_off = [](int tap) constexpr { return (FM == 2 ? ((tap & 1) * P1 + (tap >> 1)) : tap) * 32; };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int Stot = nch * H;
+    // prologue: patch of chunk 0, weight tiles 0..2 (the periodic stream from here on: step s issues tile s + 3, a chunk's first
+    // step also the next chunk's patch)
+    issue_p(0, 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int cc = s / H, jj = s % H;
+        issue_w(cc < nch ? cc : 0, jj, s);
+    }
+    int slot = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool second = ch * 16 >= C0;
+        const int dtA = second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0;
+        const int dtB = second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0;
+        const int bufoff = C3_RING + (ch & 1) * PBYTES;
+        int aoff[H];                         // per K step: this lane's patch address (its tap of the pair, frame offset, buffer)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int itA = 2 * j, itB = 2 * j + 1;
+            const int oA = (itA / NF ? dtB : dtA) * (S * 32) + tap_off(itA % NF);
+            const int oB = (itB / NF ? dtB : dtA) * (S * 32) + tap_off(itB % NF);
+            aoff[j] = vbase + bufoff + (g >= 2 ? oB : oA);
+        }
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            c3_wait_step<H, MAXP>(j);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            {   // tile s + 3 -> the slot tile s - 1 has left; past the end: re-load something harmless (keeps the counts constant)
+                const int jj = (j + 3) % H, dc = (j + 3) / H;
+                const int cc = ch + dc < nch ? ch + dc : 0;
+                issue_w(cc, jj, (slot + 3) & 3);
+            }
+            if (j == 0) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1);
+            const unsigned char* wslot = smem + slot * C3_WSLOT + wrd;
+            const unsigned char* ap = smem + aoff[j];
+            bf16x8 wf[TN], af[TM];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wslot + ni * 512));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + imm_of(mi)));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);   // DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);   // MFMAs
+            slot = (slot + 1) & 3;
+        }
+    }
+    (void)Stot;
+
+    // ---- epilogue: every DMA has landed and every wave has finished reading before the LDS is reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int WROWS = 128, WCOLS = 64, TP = WCOLS + 8;
+    const int nw0 = n0 + wn * WCOLS;
+    sehip_nchunk first = d.ntab[nw0 >> 2];
+    bool dense;
+    {
+        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + (lane & 15)];
+        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * (lane & 15);
+        dense = __all(ok) && !(first.dst ? d.dst[1].is_f32 : d.dst[0].is_f32) && ((first.coff & 7) == 0) &&
+                (((first.dst ? d.dst[1].C : d.dst[0].C) & 7) == 0);
+    }
+    bool with_stats = false;
+    if (d.stats) {
+        int* flag = reinterpret_cast<int*>(smem + 4 * (WROWS * TP * 2));
+        if (lane == 0) flag[wave] = dense ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        with_stats = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) with_stats = with_stats && flag[i] != 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (dense) {
+        bf16_raw* tb_ = reinterpret_cast<bf16_raw*>(smem) + wave * (WROWS * TP);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const f32x4 v = acc[ni][mi];
+                *reinterpret_cast<uint2*>(&tb_[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * (lane >> 4)]) =
+                    make_uint2(pack_bf2(v[0] + bv.x, v[1] + bv.y), pack_bf2(v[2] + bv.z, v[3] + bv.w));
+            }
+        }
+        const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
+        if (with_stats) {
+            // batch statistics of the ComplexBatchNorm that follows (see conv_gemm_v2): wave (wm, 0) holds the real halves and wave
+            // (wm, 1) the imaginary halves of the tile's 64 complex channels for the same 128 rows; wave (wm, wn) takes channels
+            // 32 wn .. 32 wn + 31: lane = channel pair (lane & 15) x row group (lane >> 4, 32 rows each)
+            unsigned long long rmask[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                int tl, jl;
+                c3_row<J>(wm, hh * 64 + lane, tl, jl);
+                const int gv = g0 + tl;
+                const int b = gv / TV, t = gv - b * TV;
+                rmask[hh] = __ballot(b < B && t < d.TT);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bf16_raw* imr = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * 0) * (WROWS * TP);
+            const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * 1) * (WROWS * TP);
+            const int cp = 32 * wn + 2 * (lane & 15), rg = lane >> 4;
+            float sr[2] = {0.f, 0.f}, si[2] = {0.f, 0.f}, srr[2] = {0.f, 0.f}, sri[2] = {0.f, 0.f}, sii[2] = {0.f, 0.f};
+            const unsigned long long rm = rmask[rg >> 1] >> (32 * (rg & 1));
+#pragma unroll 4
+            for (int it = 0; it < 32; ++it) {
+                const int r = 32 * rg + it;
+                const unsigned ur = *reinterpret_cast<const unsigned*>(&imr[r * TP + cp]);
+                const unsigned ui = *reinterpret_cast<const unsigned*>(&imi[r * TP + cp]);
+                const float ok = (rm >> it) & 1ull ? 1.f : 0.f;
+                const float yr[2] = {__uint_as_float(ur << 16) * ok, __uint_as_float(ur & 0xffff0000u) * ok};
+                const float yi[2] = {__uint_as_float(ui << 16) * ok, __uint_as_float(ui & 0xffff0000u) * ok};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    sr[e] += yr[e]; si[e] += yi[e];
+                    srr[e] += yr[e] * yr[e]; sri[e] += yr[e] * yi[e]; sii[e] += yi[e] * yi[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    sr[e] += __shfl_xor(sr[e], o, 64); si[e] += __shfl_xor(si[e], o, 64);
+                    srr[e] += __shfl_xor(srr[e], o, 64); sri[e] += __shfl_xor(sri[e], o, 64); sii[e] += __shfl_xor(sii[e], o, 64);
+                }
+            }
+            if (lane < 16) {
+                const int Cr = d.stats_cr;
+                float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + cp;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    atomicAdd(sp + e, sr[e]); atomicAdd(sp + Cr + e, si[e]);
+                    atomicAdd(sp + 2 * Cr + e, srr[e]); atomicAdd(sp + 3 * Cr + e, sri[e]); atomicAdd(sp + 4 * Cr + e, sii[e]);
+                }
+            }
+        }
+        bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
+        const bf16_raw* rptr = (d.res && first.dst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + first.coff : nullptr;
+        const int tsz = dd.F * dd.C, bsz = dd.T * dd.F * dd.C, jsz = dd.fmul * dd.C;
+        const int base0 = (dd.toff * dd.F + dd.fadd) * dd.C + (lane & 7) * 8;
+#pragma unroll
+        for (int itr = 0; itr < WROWS / 8; ++itr) {
+            const int row = itr * 8 + (lane >> 3);
+            int tl, jl;
+            c3_row<J>(wm, row, tl, jl);
+            const int gv = g0 + tl;
+            const int b = gv / TV, t = gv - b * TV;
+            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + (lane & 7) * 8]);
+            if (b < B && t < d.TT) {
+                const int off = b * bsz + t * tsz + jl * jsz + base0;
+                if (rptr) {
+                    const uint4 r4 = *reinterpret_cast<const uint4*>(rptr + off);
+                    const unsigned av[4] = {v.x, v.y, v.z, v.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        o[i] = pack_bf2(__uint_as_float(av[i] << 16) + __uint_as_float(rv[i] << 16),
+                                        __uint_as_float(av[i] & 0xffff0000u) + __uint_as_float(rv[i] & 0xffff0000u));
+                    v = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                *reinterpret_cast<uint4*>(dptr + off) = v;
+            }
+        }
+        return;
+    }
+    // direct scatter, 4 consecutive channels per lane (fp32 destinations, narrow or split column groups)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        int tl, jl;
+        c3_row<J>(wm, mi * 16 + (lane & 15), tl, jl);
+        const int gv = g0 + tl;
+        const int b = gv / TV, t = gv - b * TV;
+        if (b >= B || t >= d.TT) continue;
+        size_t ro[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const sehip_dst& q = d.dst[s];
+            ro[s] = q.ptr ? (((size_t)b * q.T + t + q.toff) * q.F + (size_t)jl * q.fmul + q.fadd) * q.C : 0;
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = nw0 + ni * 16 + 4 * (lane >> 4);
+            const sehip_nchunk nc = d.ntab[n >> 2];
+            if (nc.nvalid <= 0) continue;
+            f32x4 v = acc[ni][mi];
+            if (d.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(d.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            const size_t off = (nc.dst ? ro[1] : ro[0]) + nc.coff;
+            void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
+            const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
+            if (d.res && nc.dst == 0 && nc.nvalid == 4) {
+                const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_raw*>(d.res) + off);
+                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+            }
+            if (is_f32) {
+                float* q = reinterpret_cast<float*>(dptr) + off;
+                if (nc.nvalid == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nc.nvalid; ++e) q[e] = v[e];
+            } else {
+                bf16_raw* q = reinterpret_cast<bf16_raw*>(dptr) + off;
+                if (nc.nvalid == 4) *reinterpret_cast<uint2*>(q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else
+                    for (int e = 0; e < nc.nvalid; ++e) q[e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+template <int NF, int FM, int J>
+static size_t c3_lds_bytes() {
+    using G = C3Geo<NF, FM, J>;
+    const size_t epi = 4 * (128 * 72 * 2) + 64;
+    return (size_t)G::LDS_MAIN > epi ? (size_t)G::LDS_MAIN : epi;
+}
+template <int NF, int FM, int J>
+static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d>", NF, FM, J);
+    conv_gemm_v3_kernel<NF, FM, J><<<grid, 256, c3_lds_bytes<NF, FM, J>(), st>>>(d, B);
+}
+template <int NF, int FM>
+static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
+    const long vframes = (long)B * (d.TT + 2);
+    const int ntn = d.Npad / 128;
+#define C3_CASE(J_)                                                                     \
+    case J_: {                                                                          \
+        const int TB = 256 / J_;                                                        \
+        c3_launch<NF, FM, J_>(d, B, (int)((vframes + TB - 1) / TB) * ntn, st);          \
+        return 1;                                                                       \
+    }
+    switch (d.J) {
+        C3_CASE(4) C3_CASE(8) C3_CASE(16) C3_CASE(32)
+        default: return 0;
+    }
+#undef C3_CASE
+}
+
+// returns 1 if the kernel was launched, 0 if the descriptor does not qualify (the caller falls back to conv_gemm_v2 / v1)
+int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_CONV_V3") != nullptr || getenv("SEHIP_NO_PATCH") != nullptr;
+    if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
+    if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return 0;
+    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    if ((C0 & 15) || (C1 & 15) || (d.Npad & 127)) return 0;
+    if (d.J != 4 && d.J != 8 && d.J != 16 && d.J != 32) return 0;
+    if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
+    if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return 0;
+    if (d.M % (d.TT * d.J)) return 0;
+    const int B = d.M / (d.TT * d.J);
+    for (int s = 0; s < 2; ++s) {
+        if (!d.src[s].ptr) continue;
+        for (int kt = 0; kt < 2; ++kt)
+            if (d.cv_toff[s][kt] < -1 || d.cv_toff[s][kt] > 1) return 0;
+        if (abs(d.cv_toff[s][0] - d.cv_toff[s][1]) > 1) return 0;
+        if (d.src[s].thi > d.TT + 1) return 0;
+        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 31)) return 0;      // 32-bit piece offsets
+    }
+    for (int s = 0; s < 2; ++s)
+        if (d.dst[s].ptr && (long)B * d.dst[s].T * d.dst[s].F * d.dst[s].C >= (1L << 31)) return 0;
+    if ((long)d.Npad * d.K >= (1L << 31)) return 0;
+    if (d.cv_nf == 5 && d.fmul == 2) return c3_launch_j<5, 2>(d, B, st);
+    if (d.cv_nf == 3 && d.fmul == 1) return c3_launch_j<3, 1>(d, B, st);
+    if (d.cv_nf == 2 && d.fmul == 1) return c3_launch_j<2, 1>(d, B, st);
+    return 0;
+}
+
+template <int NF, int FM, int J>
+static void c3_init_one() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+}
+template <int NF, int FM>
+static void c3_init_nf() {
+    c3_init_one<NF, FM, 4>(); c3_init_one<NF, FM, 8>(); c3_init_one<NF, FM, 16>(); c3_init_one<NF, FM, 32>();
+}
+void sehip_conv3_init(void) {
+    c3_init_nf<5, 2>(); c3_init_nf<3, 1>(); c3_init_nf<2, 1>();
+}

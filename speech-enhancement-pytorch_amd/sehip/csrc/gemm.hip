@@ -637,11 +637,14 @@ static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int gri
 
 int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st);   // conv2.hip
 void sehip_conv2_init(void);
+int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st);   // conv3.hip
+void sehip_conv3_init(void);
 
 // returns 1 if the LDS-patch kernel was launched, 0 if the descriptor does not qualify
 static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
+    if (sehip_try_conv_gemm_v3(d, st)) return 1;
     if (sehip_try_conv_gemm_v2(d, st)) return 1;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.J > 64 || (128 % d.J)) return 0;
@@ -1466,7 +1469,7 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
     if (d->stats) {   // only the LDS-DMA convolution kernel accumulates the BatchNorm statistics (sehip.h): no silent omission
-        if (sehip_try_conv_gemm_v2(*d, st)) {
+        if (sehip_try_conv_gemm_v3(*d, st) || sehip_try_conv_gemm_v2(*d, st)) {
             SEHIP_CHECK_LAUNCH("gemm(conv+stats)");
             return 0;
         }
@@ -2554,6 +2557,7 @@ extern "C" int sehip_init(void) {
     INIT_SW(64, 1) INIT_SW(64, 2) INIT_SW(64, 3) INIT_SW(64, 4) INIT_SW(64, 5)
 #undef INIT_SW
     sehip_conv2_init();
+    sehip_conv3_init();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sehip_set_error(-2, "init: %s", hipGetErrorString(e));
     return 0;
