@@ -69,6 +69,17 @@ int sehip_sisdr_metric(const float* reference, const float* estimation, int rows
 int sehip_sisnr_bwd(const float* est, const float* ref, const float* rowstat, const float* upstream /*scalar or NULL*/,
                     int rows, int n, float* dest, void* stream);
 
+/* ---- permutation-invariant SI-SNR: src/loss.py:58-100 (UtterenceBaasedPermutationInvariantTraining around loss_sisdr; the
+ *      reference's call site src/solver.py:469-478 computes it and then overwrites it, so this is reached only through the
+ *      opt-in config.optim.pit_apply).  est / ref [B][S][C][n] fp32, speakers on axis 1 (S <= 6).  The permutation is chosen on
+ *      the BATCH-mean pair losses exactly as the reference does, first minimum in itertools.permutations order.
+ *      rowstat: [S*S][B*C][4] fp32 (kept for bwd), pairloss [S*S], perm [S] int32 (perm[j] = estimated speaker matched with
+ *      target j), loss [1] = mean over the matched pairs of -si_snr. */
+int sehip_sisnr_pit_fwd(const float* est, const float* ref, int B, int S, int C, int n, float* rowstat, float* pairloss,
+                        int* perm, float* loss, void* stream);
+int sehip_sisnr_pit_bwd(const float* est, const float* ref, const float* rowstat, const int* perm, const float* upstream /*or NULL*/,
+                        int B, int S, int C, int n, float* dest, void* stream);
+
 /* ---- l1 / mse with reduction 'mean' (torch.nn.functional.l1_loss / mse_loss in src/distrib.py:263-268); mode 0 = l1, 1 = mse */
 int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, int mode, double* acc_scratch, float* loss, void* stream);
 int sehip_pointwise_loss_bwd(const float* x, const float* y, long n, int mode, const float* upstream, float* dx, void* stream);
@@ -172,7 +183,12 @@ typedef struct {
      * src/model/dcunet.py:341-371): stride 1 in both directions, K ordered (time tap, row tap, source, channel), time taps at
      * source frames t + cv2_t0 + 0..cv2_nkt-1 (both sources), row taps at rows j + cv2_fadd + 0..cv2_nf-1.  cv2_nkt == 0: absent. */
     int32_t cv2_nkt, cv2_nf, cv2_fadd, cv2_t0;
-    int32_t pad2_;
+    /* 1: W is stored in the tile order of the LDS-DMA convolution kernel (conv_gemm_v3) instead of [Npad][K]: for output tile
+     * nt (128 columns), 16-channel chunk ch of the concatenated sources and tap pair j (taps 2j, 2j + 1 of the K order above)
+     * one contiguous 8 KB block [2 taps][128 n][16 channels] at element ((nt * (Ctot / 16) + ch) * cv_nf + j) * 4096 -- every
+     * LDS-DMA instruction then reads 1 KB of whole cache lines.  Only that kernel reads such a W: sehip_gemm fails loudly when
+     * the descriptor does not qualify for it. */
+    int32_t w_tiled;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);

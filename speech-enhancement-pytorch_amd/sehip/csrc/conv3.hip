@@ -93,7 +93,9 @@ __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constan
     }
 }
 
-template <int NF, int FM, int J>
+// ABL: ablation builds for tools/ (never launched by the product path unless SEHIP_C3_ABL is set): 1 = no DMA inside the loop,
+// 2 = no MFMA, 4 = no fragment reads
+template <int NF, int FM, int J, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B) {
     using G = C3Geo<NF, FM, J>;
     constexpr int TB = G::TB, S = G::S, P1 = G::P1, FR = G::FR, H = NF, MAXP = G::MAXP, NPIECE = G::NPIECE, PBYTES = G::PBYTES;
@@ -167,14 +169,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             __builtin_amdgcn_global_load_lds((c3_gvoid*)q, (c3_lds_void*)dd, 16, 0, 0);
         }
     };
-    // ---- weight tile of step (ch, j): [tap 2j + u][128 n][16 channels]; instruction u of wave w: rows 32 w .. 32 w + 31
-    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;
-    const unsigned woff = (unsigned)((wave * 32 + (lane >> 1)) * d.K + (lane & 1) * 8);
+    // ---- weight tile of step (ch, j): [tap 2j + u][128 n][16 channels]; instruction u of wave w: rows 32 w .. 32 w + 31.
+    // W in tile order (w_tiled): the step's 8 KB are contiguous, an instruction reads 1 KB of whole lines; otherwise [Npad][K]
+    // (32-byte pieces of 5 KB rows: four times the L2 -> L1 line traffic)
+    const bool tiled = d.w_tiled != 0;
+    const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;     // tile order: the n-tile's K * 128 elements
+    const unsigned woff = tiled ? (unsigned)(wave * 512 + lane * 8) : (unsigned)((wave * 32 + (lane >> 1)) * d.K + (lane & 1) * 8);
+    const int wstep_u = tiled ? 2048 : Ctot;
     auto issue_w = [&](int ch, int j, int slot) {
-        const bf16_raw* wb = Wb + (2 * j * Ctot + ch * 16);
+        const bf16_raw* wb = Wb + (tiled ? (ch * H + j) * 4096 : 2 * j * Ctot + ch * 16);
         unsigned char* dst = smem + slot * C3_WSLOT + wave * 1024;
         __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + woff), (c3_lds_void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + Ctot + woff), (c3_lds_void*)(dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + wstep_u + woff), (c3_lds_void*)(dst + 4096), 16, 0, 0);
     };
 
     // ---- fragment addresses
@@ -231,23 +237,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             {   // tile s + 3 -> the slot tile s - 1 has left; past the end: re-load something harmless (keeps the counts constant)
                 const int jj = (j + 3) % H, dc = (j + 3) / H;
                 const int cc = ch + dc < nch ? ch + dc : 0;
-                issue_w(cc, jj, (slot + 3) & 3);
+                if (!(ABL & 1)) issue_w(cc, jj, (slot + 3) & 3);
             }
-            if (j == 0) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1);
+            if (j == 0 && !(ABL & 1)) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1);
             const unsigned char* wslot = smem + slot * C3_WSLOT + wrd;
             const unsigned char* ap = smem + aoff[j];
             bf16x8 wf[TN], af[TM];
+            if (ABL & 4) {
+                const uint4 cst = make_uint4(0x3f803f80u + j, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + lane);
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wslot + ni * 512));
+                for (int ni = 0; ni < TN; ++ni) wf[ni] = __builtin_bit_cast(bf16x8, cst);
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + imm_of(mi)));
+                for (int mi = 0; mi < TM; ++mi) af[mi] = __builtin_bit_cast(bf16x8, cst);
+            } else {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
+                for (int ni = 0; ni < TN; ++ni) wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wslot + ni * 512));
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);   // DS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);   // MFMAs
+                for (int mi = 0; mi < TM; ++mi) af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + imm_of(mi)));
+            }
+            if (ABL & 2) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(wf[ni]));
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) asm volatile("" ::"v"(af[mi]));
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                if (!(ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);   // DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);   // MFMAs
+            }
             slot = (slot + 1) & 3;
         }
     }
@@ -438,10 +459,23 @@ static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st)
     sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d>", NF, FM, J);
     conv_gemm_v3_kernel<NF, FM, J><<<grid, 256, c3_lds_bytes<NF, FM, J>(), st>>>(d, B);
 }
+template <int J, int ABL>
+static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, ABL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    conv_gemm_v3_kernel<5, 2, J, ABL><<<grid, 256, c3_lds_bytes<5, 2, J>(), st>>>(d, B);
+}
 template <int NF, int FM>
 static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     const long vframes = (long)B * (d.TT + 2);
     const int ntn = d.Npad / 128;
+    static const int abl = getenv("SEHIP_C3_ABL") ? atoi(getenv("SEHIP_C3_ABL")) : 0;     // tools/ only: timing ablations, wrong results
+    if (abl && NF == 5 && (d.J == 4 || d.J == 8)) {
+        const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * ntn;
+#define C3_ABL(A_) case A_: if (d.J == 4) c3_launch_abl<4, A_>(d, B, grid, st); else c3_launch_abl<8, A_>(d, B, grid, st); return 1;
+        switch (abl) { C3_ABL(1) C3_ABL(2) C3_ABL(3) C3_ABL(4) C3_ABL(5) C3_ABL(6) default: break; }
+#undef C3_ABL
+    }
 #define C3_CASE(J_)                                                                     \
     case J_: {                                                                          \
         const int TB = 256 / J_;                                                        \

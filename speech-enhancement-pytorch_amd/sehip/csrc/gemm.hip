@@ -645,6 +645,7 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
     if (sehip_try_conv_gemm_v3(d, st)) return 1;
+    if (d.w_tiled) return 0;                     // nobody else reads the tile order (sehip_gemm reports it)
     if (sehip_try_conv_gemm_v2(d, st)) return 1;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.J > 64 || (128 % d.J)) return 0;
@@ -1469,7 +1470,7 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
     if (d->stats) {   // only the LDS-DMA convolution kernel accumulates the BatchNorm statistics (sehip.h): no silent omission
-        if (sehip_try_conv_gemm_v3(*d, st) || sehip_try_conv_gemm_v2(*d, st)) {
+        if (sehip_try_conv_gemm_v3(*d, st) || (!d->w_tiled && sehip_try_conv_gemm_v2(*d, st))) {
             SEHIP_CHECK_LAUNCH("gemm(conv+stats)");
             return 0;
         }
@@ -1480,6 +1481,8 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("gemm(conv)");
         return 0;
     }
+    SEHIP_REQUIRE(!d->w_tiled, "gemm: W is in conv_gemm_v3's tile order (w_tiled) but the product does not qualify for that kernel "
+                               "(Npad=%d, J=%d, cv_nf=%d, fmul=%d)", d->Npad, d->J, d->cv_nf, d->fmul);
     if (try_conv_small(*d, nullptr, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv-small)");
         return 0;

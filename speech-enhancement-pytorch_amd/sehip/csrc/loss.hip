@@ -149,6 +149,123 @@ extern "C" int sehip_sisnr_bwd(const float* est, const float* ref, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Permutation-invariant SI-SNR: src/loss.py:58-100 (UtterenceBaasedPermutationInvariantTraining with loss_function =
+// loss_sisdr).  est / ref are [B][S][C][n] (speaker axis 1).  The reference fills an S x S matrix with the BATCH-mean loss of
+// (estimated speaker i, target speaker j) (:70-71), takes the permutation with the smallest sum, walking
+// itertools.permutations in its lexicographic order with a strict '<' (:73-86), and returns the mean of the chosen pairs'
+// losses (:88-96).  One launch computes the S*S*B*C row records, one single-wave launch the matrix, the permutation and the
+// loss; the backward pass reads the permutation from device memory (no host round trip).
+//   rowstat [S*S][R] float4 (R = B*C rows per pair; pair index i*S + j), pairloss [S*S], perm [S] (perm[j] = estimated speaker
+//   matched with target j), loss [1]
+// ------------------------------------------------------------------------------------------------
+#define PIT_MAXS 6
+__global__ __launch_bounds__(256) void sisnr_pit_rows_kernel(const float* __restrict__ est, const float* __restrict__ ref, int B, int S,
+                                                             int C, int n, float4* __restrict__ rowstat) {
+    __shared__ float red[4];
+    const int R = B * C;
+    const int r = blockIdx.x, pair = blockIdx.y;
+    const int i = pair / S, j = pair - i * S;
+    const int b = r / C, c = r - b * C;
+    const float* x = est + (((size_t)b * S + i) * C + c) * n;
+    const float* s = ref + (((size_t)b * S + j) * C + c) * n;
+    float xs = 0.f, ss = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) { xs += x[k] * s[k]; ss += s[k] * s[k]; }
+    xs = block_sum<4>(xs, red);
+    ss = block_sum<4>(ss, red);
+    const float alpha = xs / (ss + EPS);
+    float et = 0.f, en = 0.f, es = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float t = alpha * s[k], e = x[k] - t;
+        et += t * t; en += e * e; es += e * s[k];
+    }
+    et = block_sum<4>(et, red);
+    en = block_sum<4>(en, red);
+    es = block_sum<4>(es, red);
+    if (threadIdx.x == 0) {
+        const float ratio = et / (en + EPS);
+        const float l = 10.f * log10f(ratio + EPS);
+        // loss = (1/S) sum over chosen pairs of -mean_rows(l): d loss / d l = -1 / (S R)
+        const float cc = -(1.0f / ((float)S * (float)R)) * 10.f / (2.302585092994046f * (ratio + EPS));
+        const float q = et / ((en + EPS) * (en + EPS));
+        const float a = cc * (-2.f * q);
+        const float bb = cc * (2.f * alpha * ss / ((ss + EPS) * (en + EPS)) + 2.f * q * alpha + 2.f * q * es / (ss + EPS));
+        rowstat[(size_t)pair * R + r] = make_float4(a, bb, l, alpha);
+    }
+}
+
+__global__ void sisnr_pit_select_kernel(const float4* __restrict__ rowstat, int R, int S, float* __restrict__ pairloss,
+                                        int* __restrict__ perm, float* __restrict__ loss) {
+    __shared__ float m[PIT_MAXS * PIT_MAXS];
+    for (int pair = 0; pair < S * S; ++pair) {            // single wave, fixed summation order
+        float acc = 0.f;
+        for (int r = threadIdx.x; r < R; r += 64) acc += rowstat[(size_t)pair * R + r].z;
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) { m[pair] = -acc / R; pairloss[pair] = -acc / R; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int cur[PIT_MAXS], best[PIT_MAXS];
+    for (int k = 0; k < S; ++k) cur[k] = best[k] = k;
+    float lmin = 1e9f;
+    for (;;) {
+        float l = 0.f;
+        for (int j = 0; j < S; ++j) l += m[cur[j] * S + j];
+        if (lmin > l) {
+            lmin = l;
+            for (int k = 0; k < S; ++k) best[k] = cur[k];
+        }
+        // next permutation in lexicographic order (the order of itertools.permutations(range(S)))
+        int k = S - 2;
+        while (k >= 0 && cur[k] > cur[k + 1]) --k;
+        if (k < 0) break;
+        int l2 = S - 1;
+        while (cur[l2] < cur[k]) --l2;
+        int t = cur[k]; cur[k] = cur[l2]; cur[l2] = t;
+        for (int a = k + 1, b = S - 1; a < b; ++a, --b) { t = cur[a]; cur[a] = cur[b]; cur[b] = t; }
+    }
+    float tot = 0.f;
+    for (int j = 0; j < S; ++j) { perm[j] = best[j]; tot += m[best[j] * S + j]; }
+    loss[0] = tot / S;
+}
+
+__global__ __launch_bounds__(256) void sisnr_pit_bwd_kernel(const float* __restrict__ est, const float* __restrict__ ref,
+                                                            const float4* __restrict__ rowstat, const int* __restrict__ perm,
+                                                            const float* __restrict__ upstream, int B, int S, int C, int n,
+                                                            float* __restrict__ dest) {
+    const int R = B * C;
+    const int r = blockIdx.y, i = blockIdx.z;
+    int j = 0;
+    for (int k = 0; k < S; ++k)
+        if (perm[k] == i) j = k;                           // the target this estimated speaker was matched with
+    const int b = r / C, c = r - b * C;
+    const float4 st = rowstat[(size_t)(i * S + j) * R + r];
+    const float up = upstream ? upstream[0] : 1.f;
+    const float a = st.x * up, bb = st.y * up;
+    const size_t xb = (((size_t)b * S + i) * C + c) * n, sb = (((size_t)b * S + j) * C + c) * n;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) dest[xb + k] = a * est[xb + k] + bb * ref[sb + k];
+}
+
+extern "C" int sehip_sisnr_pit_fwd(const float* est, const float* ref, int B, int S, int C, int n, float* rowstat, float* pairloss,
+                                   int* perm, float* loss, void* stream) {
+    SEHIP_REQUIRE(B > 0 && C > 0 && n > 0 && S >= 1 && S <= PIT_MAXS, "sisnr_pit_fwd: bad shape (B=%d S=%d C=%d n=%d; S <= %d)", B, S,
+                  C, n, PIT_MAXS);
+    hipStream_t st = (hipStream_t)stream;
+    sisnr_pit_rows_kernel<<<dim3(B * C, S * S), 256, 0, st>>>(est, ref, B, S, C, n, (float4*)rowstat);
+    sisnr_pit_select_kernel<<<1, 64, 0, st>>>((const float4*)rowstat, B * C, S, pairloss, perm, loss);
+    SEHIP_CHECK_LAUNCH("sisnr_pit_fwd");
+    return 0;
+}
+
+extern "C" int sehip_sisnr_pit_bwd(const float* est, const float* ref, const float* rowstat, const int* perm, const float* upstream,
+                                   int B, int S, int C, int n, float* dest, void* stream) {
+    SEHIP_REQUIRE(B > 0 && C > 0 && n > 0 && S >= 1 && S <= PIT_MAXS, "sisnr_pit_bwd: bad shape (B=%d S=%d C=%d n=%d)", B, S, C, n);
+    dim3 grid(cdiv(n, 256 * 8), B * C, S);
+    sisnr_pit_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(est, ref, (const float4*)rowstat, perm, upstream, B, S, C, n, dest);
+    SEHIP_CHECK_LAUNCH("sisnr_pit_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // l1 / mse (the reference uses torch.nn.functional.l1_loss / mse_loss with reduction 'mean', src/distrib.py:263-268)
 // mode 0: mean |x - y|     mode 1: mean (x - y)^2
 // ------------------------------------------------------------------------------------------------

@@ -35,6 +35,61 @@ def si_snr(s1, s2):
     return -loss_sisdr(s1, s2)
 
 
+class _PitSiSdrLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, ref):
+        b, s = est.shape[0], est.shape[1]
+        n = est.shape[-1]
+        e4 = est.reshape(b, s, -1, n).contiguous().float()
+        r4 = ref.reshape(b, s, -1, n).contiguous().float()
+        loss, rowstat, pairloss, perm = ops.sisnr_pit_fwd(e4, r4)
+        ctx.save_for_backward(e4, r4, rowstat, perm)
+        ctx.shape = est.shape
+        ctx.mark_non_differentiable(perm, pairloss)
+        return loss.reshape(()), perm, pairloss
+
+    @staticmethod
+    def backward(ctx, g, _gp, _gl):
+        e4, r4, rowstat, perm = ctx.saved_tensors
+        d = ops.sisnr_pit_bwd(e4, r4, rowstat, perm, g.reshape(1).contiguous().float())
+        return d.view(ctx.shape), None
+
+
+def pit_loss_sisdr(enhance, target, return_comb=False):
+    """UtterenceBaasedPermutationInvariantTraining(enhance, target, loss_function=loss_sisdr) of src/loss.py:58-100 on the
+    device: enhance / target [B, S, ...], speakers on axis 1.  As in the reference the permutation is chosen once per BATCH
+    (on the batch-mean pair losses, no gradient through the choice) and the result is the mean of the matched pairs' losses.
+    With return_comb the device tensor perm [S] (perm[j] = estimated speaker matched with target j) is returned as well --
+    the reference's list of (ienhance, itarget) pairs without the host round trip."""
+    if enhance.shape != target.shape:
+        raise SehipError(f"enhance and target shape did not match...{tuple(enhance.shape)}, {tuple(target.shape)}")
+    if enhance.dim() < 3:
+        raise SehipError("pit_loss_sisdr: expected [batch, speakers, ..., samples]")
+    loss, perm, _ = _PitSiSdrLoss.apply(enhance, target)
+    return (loss, perm) if return_comb else loss
+
+
+def pit_loss(enhance, target, loss_function, return_comb=False):
+    """The same for any loss function of this module.  si-sdr runs fused on the device; the other losses evaluate the S x S
+    pair matrix with S*S small launches and read it back once to pick the permutation (src/loss.py:67-86)."""
+    if loss_function is loss_sisdr:
+        return pit_loss_sisdr(enhance, target, return_comb)
+    if enhance.shape != target.shape:
+        raise SehipError(f"enhance and target shape did not match...{tuple(enhance.shape)}, {tuple(target.shape)}")
+    from itertools import permutations
+    s = enhance.shape[1]
+    with torch.no_grad():
+        m = torch.stack([torch.stack([loss_function(enhance[:, i].contiguous(), target[:, j].contiguous()) for j in range(s)])
+                         for i in range(s)]).cpu()
+    best, lmin = None, 1e9
+    for pe in permutations(range(s)):
+        l = sum(float(m[pe[j], j]) for j in range(s))
+        if lmin > l:
+            best, lmin = [(pe[j], j) for j in range(s)], l
+    loss = sum(loss_function(enhance[:, i].contiguous(), target[:, j].contiguous()) for i, j in best) / s
+    return (loss, best) if return_comb else loss
+
+
 class _PointwiseLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, mode):

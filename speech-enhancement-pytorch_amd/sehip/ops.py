@@ -79,3 +79,23 @@ def sisnr_bwd(est, ref, rowstat, upstream=None):
     dest = torch.empty_like(est)
     call("sehip_sisnr_bwd", ptr(est), ptr(ref), ptr(rowstat), ptr(upstream), r, n, ptr(dest), stream())
     return dest
+
+
+def sisnr_pit_fwd(est, ref):
+    """est/ref [B,S,C,N] fp32 contiguous -> (loss [1], rowstat [S*S,B*C,4], pairloss [S*S], perm [S] int32): the
+    permutation-invariant SI-SNR of src/loss.py:58-100 (batch-level permutation, first minimum in itertools order)."""
+    require_gpu(est, "sisnr_pit_fwd")
+    b, s, c, n = est.shape
+    rowstat = torch.empty(s * s, b * c, 4, device=est.device, dtype=torch.float32)
+    pairloss = torch.empty(s * s, device=est.device, dtype=torch.float32)
+    perm = torch.empty(s, device=est.device, dtype=torch.int32)
+    loss = torch.empty(1, device=est.device, dtype=torch.float32)
+    call("sehip_sisnr_pit_fwd", ptr(est), ptr(ref), b, s, c, n, ptr(rowstat), ptr(pairloss), ptr(perm), ptr(loss), stream())
+    return loss, rowstat, pairloss, perm
+
+
+def sisnr_pit_bwd(est, ref, rowstat, perm, upstream=None):
+    b, s, c, n = est.shape
+    dest = torch.empty_like(est)
+    call("sehip_sisnr_pit_bwd", ptr(est), ptr(ref), ptr(rowstat), ptr(perm), ptr(upstream), b, s, c, n, ptr(dest), stream())
+    return dest

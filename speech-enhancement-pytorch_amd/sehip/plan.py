@@ -44,12 +44,14 @@ class CGemmDesc(C.Structure):
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
                 ("tmul", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
                 ("res", C.c_void_p), ("stats", C.c_void_p), ("stats_cr", C.c_int32), ("cv2_nkt", C.c_int32), ("cv2_nf", C.c_int32),
-                ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("pad2_", C.c_int32)]
+                ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient
 # (descriptor field `res`), so the BatchNorm backward kernels read one gradient tensor instead of two.
 FUSE_SKIP_GRAD = not os.environ.get("SEHIP_NO_FUSE_SKIP")
+# Products that conv_gemm_v3 takes get their packed weights in its tile order (the switches that take the kernel away keep [Npad][K])
+TILE_WEIGHTS = not any(os.environ.get(k) for k in ("SEHIP_NO_CONV_V3", "SEHIP_NO_PATCH", "SEHIP_NO_TILE_WEIGHTS"))
 
 
 def npad_of(n):
@@ -317,6 +319,38 @@ class GemmSpec:
         self.w_off = self.b_off = self.dw_off = self.db_off = None
         self.kt_off = self.nt_off = None
         self.stats_of = None   # BatchNorm prefix whose batch statistics this forward product accumulates (sehip_gemm_desc.stats)
+        self.w_tiled = False   # packed weights in conv_gemm_v3's tile order (sehip_gemm_desc.w_tiled)
+
+    def v3_channels(self):
+        """(C0, C1) of the sources when conv_gemm_v3 (csrc/conv3.hip, sehip_try_conv_gemm_v3) takes this product, else None:
+        regular convolution with (taps, row stride) in {(5, 2), (3, 1), (2, 1)}, 4 / 8 / 16 / 32 rows per frame, 16-multiple
+        source channels, 128-multiple outputs, frame offsets within one frame of each other."""
+        if self.conv is None or self.kind == "wgrad_only" or self.Npad % 128 or self.J not in (4, 8, 16, 32):
+            return None
+        nf, _, toff = self.conv
+        if (nf, self.fmul) not in ((5, 2), (3, 1), (2, 1)):
+            return None
+        cs = [int((self.ktab[:, 0] == q).sum()) * 8 // (2 * nf) for q in (0, 1)]
+        if cs[0] == 0 or cs[0] % 16 or cs[1] % 16 or self.K != 2 * nf * (cs[0] + cs[1]):
+            return None
+        for q in range(2 if cs[1] else 1):
+            if max(abs(toff[q][0]), abs(toff[q][1])) > 1 or abs(toff[q][0] - toff[q][1]) > 1:
+                return None
+        return cs
+
+    def tile_weights(self):
+        """Moves the packed weights [Npad][K] (K ordered (tap, concatenated channel)) into the tile order conv_gemm_v3 streams:
+        [n tile][16-channel chunk][tap pair][tap of the pair][128 n][16 channels]; a pure permutation of the packing table."""
+        cs = self.v3_channels()
+        assert cs is not None and not self.w_tiled
+        nf, ctot = self.conv[0], cs[0] + cs[1]
+        ntn, nch = self.Npad // 128, ctot // 16
+
+        def perm(a):
+            a = a.reshape(ntn, 128, nf, 2, nch, 16)           # [nt][n][j][u][ch][c]   (tap index = 2 j + u)
+            return a.transpose(0, 4, 2, 3, 1, 5).reshape(self.Npad, self.K)
+        self.widx_packed, self.wneg_packed = perm(self.widx), perm(self.wneg)
+        self.w_tiled = True
 
     def tile_complex_columns(self):
         """Re-orders the output columns [re 0..Cr) | im 0..Cr) so that every 128-column tile holds [64 re | 64 im] of the SAME 64
@@ -566,7 +600,11 @@ class DCCRNStatic:
             s.kt_off = kta.add(s.ktab)
             s.nt_off = nta.add(s.ntab)
             if s.kind != "wgrad_only":
-                s.w_off = wa.add(enc_entry(s.widx, s.wneg).reshape(-1))
+                if TILE_WEIGHTS and s.v3_channels() is not None:
+                    s.tile_weights()      # (widx / wneg themselves keep the [Npad][K] order: the weight-gradient un-packing uses them)
+                    s.w_off = wa.add(enc_entry(s.widx_packed, s.wneg_packed).reshape(-1))
+                else:
+                    s.w_off = wa.add(enc_entry(s.widx, s.wneg).reshape(-1))
             if s.bias_pairs is not None:
                 s.b_off = ba.add(s.bias_pairs)
             if s.kind in ("fwd", "wgrad_only"):
@@ -811,6 +849,7 @@ class DCCRNWorkspace:
                 d.bias = tb.bpack.data_ptr() + 4 * s.b_off
             d.M, d.N, d.Npad, d.K = B * tt * s.J, s.N, s.Npad, s.K
             d.TT, d.J, d.fmul = tt, s.J, s.fmul
+            d.w_tiled = 1 if s.w_tiled else 0
             if s.stats_of is not None:
                 d.stats = self.bn_stats[s.stats_of].data_ptr()
                 d.stats_cr = s.N // 2

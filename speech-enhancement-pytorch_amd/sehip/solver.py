@@ -230,8 +230,15 @@ class Solver(object):
         if not self.model.training:
             self.model.train()
         enhanced = self.model(mixture)
-        # (the reference computes a PIT loss here and then overwrites it, src/solver.py:469-480)
-        loss = self.loss_function(enhanced, sources)
+        # The reference computes a PIT loss here and then overwrites it with the plain loss (src/solver.py:469-480; its shipped
+        # config has optim.pit: True), so optim.pit alone changes nothing here either.  The opt-in optim.pit_apply keeps the
+        # permutation-invariant value (src/loss.py:58-100) for models that return [batch, speakers, ...].
+        if _cfg(self.config.optim, "pit_apply", False) and sources.dim() >= 3 and sources.shape[1] >= 2 and \
+                self.config.model.name in MULTI_SPEECH_SEPERATION_MODELS:
+            from .loss import pit_loss
+            loss = pit_loss(enhanced, sources, self.loss_function)
+        else:
+            loss = self.loss_function(enhanced, sources)
         self.optimizer.zero_grad()
         fused = isinstance(self.optimizer, FlatOptimizer)
         if self.world_size > 1 and self.flat_model and fused:
