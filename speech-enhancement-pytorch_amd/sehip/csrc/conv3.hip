@@ -25,43 +25,49 @@
 typedef __attribute__((address_space(3))) void c3_lds_void;
 typedef __attribute__((address_space(1))) const void c3_gvoid;
 
-__device__ uint4 c3_zero16 = {0u, 0u, 0u, 0u};   // source of every padding piece
+// Both operands are fetched with buffer_load_dwordx4 ... lds through raw buffer descriptors: the per-lane byte offset is a
+// register computed once per workgroup, what changes per K step / channel chunk is the scalar offset (no vector arithmetic in
+// the loop), and padding pieces carry an offset beyond num_records -- the hardware range check returns zeros without a read.
+#define C3_OOB 0x7ffffff0u
+#define C3_RECORDS 0x7fff0000u
 
 #define C3_WSLOT 8192
 #define C3_NSLOT 4
 #define C3_RING (C3_WSLOT * C3_NSLOT)
 
 // geometry of the patch image (tools/c3_census.py: conflict-free frame stride per (row stride, taps, rows per frame))
-template <int NF, int FM, int J>
+template <int NF, int FM, int J, int TM>
 struct C3Geo {
     static constexpr int FR = (J - 1) * FM + NF;                       // patch rows per frame
     static constexpr int S = FM == 2 ? (J == 4 ? 11 : J == 8 ? 20 : J == 16 ? 35 : 67)
                              : NF == 3 ? (J == 4 ? 7 : J == 8 ? 12 : J == 16 ? 18 : 34)
                                        : (J == 4 ? 5 : J == 8 ? 12 : J == 16 ? 17 : 33);
     static constexpr int P1 = FM == 2 ? (FR + 1) / 2 : 0;              // first physical row of the odd-row plane
-    static constexpr int TB = 256 / J;                                 // frames per tile
+    static constexpr int TB = 32 * TM / J;                             // frames per tile (2 M-waves x TM x 16 rows)
     static constexpr int NPIECE = (TB + 1) * S * 2;                    // 16-byte pieces per buffer
     static constexpr int MAXP = (NPIECE + 255) / 256;                  // DMA instructions per thread and chunk
     static constexpr int PBYTES = ((TB + 1) * S * 32 + 1023) / 1024 * 1024;
     static constexpr int LDS_MAIN = C3_RING + 2 * PBYTES + 1024 + 2 * (TB + 1) * 4;
     static_assert(S >= FR && (FM == 1 || P1 + FR / 2 <= S), "frame stride");
     static_assert(J == 4 || J == 8 || J == 16 || J == 32, "rows per frame");
+    static_assert(TM == 8 || TM == 6 || TM == 4, "MFMA row tiles per wave (even: the frame order of J = 4 / 8 pairs them)");
 };
 
 // row rw (= 16 mi + column c) of M-wave wm -> frame inside the tile and row inside the frame
-template <int J>
+template <int J, int TM>
 __device__ __forceinline__ void c3_row(int wm, int rw, int& tl, int& jl) {
     const int mi = rw >> 4, c = rw & 15;
+    constexpr int FW = 16 * TM / J;                                    // frames per M-wave
     if (J >= 16) {
         constexpr int per = J >= 16 ? J / 16 : 1;
-        tl = wm * (128 / J) + mi / per;
+        tl = wm * FW + mi / per;
         jl = (mi % per) * 16 + c;
     } else if (J == 8) {
-        tl = wm * 16 + (mi >> 1) * 4 + (mi & 1) + 2 * (c >> 3);
+        tl = wm * FW + (mi >> 1) * 4 + (mi & 1) + 2 * (c >> 3);
         jl = c & 7;
     } else {
         const int q = c >> 2;
-        tl = wm * 32 + (mi >> 1) * 8 + (mi & 1) * 2 + ((q & 2) ? 4 : 0) + ((q ^ (q >> 1)) & 1);
+        tl = wm * FW + (mi >> 1) * 8 + (mi & 1) * 2 + ((q & 2) ? 4 : 0) + ((q ^ (q >> 1)) & 1);
         jl = c & 3;
     }
 }
@@ -95,11 +101,11 @@ __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constan
 
 // ABL: ablation builds for tools/ (never launched by the product path unless SEHIP_C3_ABL is set): 1 = no DMA inside the loop,
 // 2 = no MFMA, 4 = no fragment reads
-template <int NF, int FM, int J, int ABL = 0>
+template <int NF, int FM, int J, int TM, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B) {
-    using G = C3Geo<NF, FM, J>;
+    using G = C3Geo<NF, FM, J, TM>;
     constexpr int TB = G::TB, S = G::S, P1 = G::P1, FR = G::FR, H = NF, MAXP = G::MAXP, NPIECE = G::NPIECE, PBYTES = G::PBYTES;
-    constexpr int TN = 4, TM = 8;
+    constexpr int TN = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* pbuf = smem + C3_RING;
     unsigned char* dump = pbuf + 2 * PBYTES;
@@ -124,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
     const bf16_raw* s0p = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
     const bf16_raw* s1p = reinterpret_cast<const bf16_raw*>(d.src[1].ptr);
-    const bf16_raw* zero_page = reinterpret_cast<const bf16_raw*>(&c3_zero16);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(s0p), 0, C3_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(C1 ? s1p : s0p), 0, C3_RECORDS, 0x00020000);
 
     // ---- frame table: element offset of patch frame p in source s, -1 = padding
     if (tid < 2 * (TB + 1)) {
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     }
     __syncthreads();
     // ---- patch pieces of this thread: piece P = (4 u + wave) * 64 + lane of a buffer = physical row P >> 1, half P & 1
-    int off0[MAXP], off1[MAXP];
+    unsigned off0[MAXP], off1[MAXP];                                             // byte offsets; C3_OOB = padding
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
         const int P = (u * 4 + wave) * 64 + lane;
@@ -154,19 +161,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         ok = ok && r < FR;
         const int f = f0 + r;
         const int fa = ok ? ftab[p] : -1, fb = (ok && C1) ? ftab[(TB + 1) + p] : -1;
-        off0[u] = (fa >= 0 && (unsigned)f < (unsigned)d.src[0].F) ? fa + f * C0 + half * 8 : -1;
-        off1[u] = (fb >= 0 && (unsigned)f < (unsigned)d.src[1].F) ? fb + f * C1 + half * 8 : -1;
+        off0[u] = (fa >= 0 && (unsigned)f < (unsigned)d.src[0].F) ? 2u * (unsigned)(fa + f * C0 + half * 8) : C3_OOB;
+        off1[u] = (fb >= 0 && (unsigned)f < (unsigned)d.src[1].F) ? 2u * (unsigned)(fb + f * C1 + half * 8) : C3_OOB;
     }
     auto issue_p = [&](int ch, int buf) {
         const int second = ch * 16 >= C0 ? 1 : 0;
-        const bf16_raw* base = second ? s1p + (ch * 16 - C0) : s0p + ch * 16;
+        const int soff = 2 * (second ? ch * 16 - C0 : ch * 16);                 // bytes, scalar
         unsigned char* dst = pbuf + buf * PBYTES + wave * 1024;
 #pragma unroll
         for (int u = 0; u < MAXP; ++u) {
-            const int o = second ? off1[u] : off0[u];
-            const bf16_raw* q = o >= 0 ? base + o : zero_page;
             unsigned char* dd = ((u * 4 + wave) * 64 < NPIECE) ? dst + u * 4096 : dump;     // wave-uniform
-            __builtin_amdgcn_global_load_lds((c3_gvoid*)q, (c3_lds_void*)dd, 16, 0, 0);
+            unsigned vo = second ? off1[u] : off0[u];
+            if (ABL & 8) vo = (unsigned)(((blockIdx.x & 1023) * 16384 + ((u * 4 + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (c3_lds_void*)dd, 16, vo, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (c3_lds_void*)dd, 16, vo, soff, 0, 0);
         }
     };
     // ---- weight tile of step (ch, j): [tap 2j + u][128 n][16 channels]; instruction u of wave w: rows 32 w .. 32 w + 31.
@@ -174,13 +182,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     // (32-byte pieces of 5 KB rows: four times the L2 -> L1 line traffic)
     const bool tiled = d.w_tiled != 0;
     const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;     // tile order: the n-tile's K * 128 elements
-    const unsigned woff = tiled ? (unsigned)(wave * 512 + lane * 8) : (unsigned)((wave * 32 + (lane >> 1)) * d.K + (lane & 1) * 8);
-    const int wstep_u = tiled ? 2048 : Ctot;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(Wb), 0, C3_RECORDS, 0x00020000);
+    const unsigned woff = 2u * (tiled ? (unsigned)(wave * 512 + lane * 8) : (unsigned)((wave * 32 + (lane >> 1)) * d.K + (lane & 1) * 8));
+    const int wstep_u = 2 * (tiled ? 2048 : Ctot);
     auto issue_w = [&](int ch, int j, int slot) {
-        const bf16_raw* wb = Wb + (tiled ? (ch * H + j) * 4096 : 2 * j * Ctot + ch * 16);
+        const int soff = 2 * (tiled ? (ch * H + j) * 4096 : 2 * j * Ctot + ch * 16);
         unsigned char* dst = smem + slot * C3_WSLOT + wave * 1024;
-        __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + woff), (c3_lds_void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((c3_gvoid*)(wb + wstep_u + woff), (c3_lds_void*)(dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)dst, 16, woff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + 4096), 16, woff, soff + wstep_u, 0, 0);
     };
 
     // ---- fragment addresses
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     int vbase;
     {
         int tl, jl;
-        c3_row<J>(wm, c, tl, jl);                                               // mi = 0
+        c3_row<J, TM>(wm, c, tl, jl);                                               // mi = 0
         vbase = (tl * S + jl) * 32 + (g & 1) * 16;
     }
     auto imm_of = [](int mi) constexpr {
@@ -205,15 +214,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
 #pragma unroll
         for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int Stot = nch * H;
     // prologue: patch of chunk 0, weight tiles 0..2 (the periodic stream from here on: step s issues tile s + 3, a chunk's first
-    // step also the next chunk's patch)
+    // step also the next chunk's patch), then the first step's wait + barrier
     issue_p(0, 0);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int cc = s / H, jj = s % H;
         issue_w(cc < nch ? cc : 0, jj, s);
     }
+    c3_wait_step<H, MAXP>(0);
+    __builtin_amdgcn_s_barrier();
     int slot = 0;
     for (int ch = 0; ch < nch; ++ch) {
         const bool second = ch * 16 >= C0;
@@ -230,16 +240,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         }
 #pragma unroll
         for (int j = 0; j < H; ++j) {
-            c3_wait_step<H, MAXP>(j);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            // Step s = (ch, j); its weight tile and patch are visible (the wait + barrier sit in front of the LAST four MFMAs of
+            // the previous step: by then every fragment read of that step has returned, so the barrier also frees its slot).
+            // Order: 12 fragment reads, the DMA of tile s + 3 (and the next chunk's patch) behind them, 28 MFMAs with the
+            // compiler's counted lgkmcnt waits, then wait for step s + 1's operands + barrier, then the last 4 MFMAs.
             __builtin_amdgcn_sched_barrier(0);
-            {   // tile s + 3 -> the slot tile s - 1 has left; past the end: re-load something harmless (keeps the counts constant)
-                const int jj = (j + 3) % H, dc = (j + 3) / H;
-                const int cc = ch + dc < nch ? ch + dc : 0;
-                if (!(ABL & 1)) issue_w(cc, jj, (slot + 3) & 3);
-            }
-            if (j == 0 && !(ABL & 1)) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1);
             const unsigned char* wslot = smem + slot * C3_WSLOT + wrd;
             const unsigned char* ap = smem + aoff[j];
             bf16x8 wf[TN], af[TM];
@@ -255,6 +260,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) af[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + imm_of(mi)));
             }
+            if (!(ABL & 1)) {   // tile s + 3 -> the slot tile s - 1 has left; past the end: re-load something harmless (constant counts)
+                const int jj = (j + 3) % H, dc = (j + 3) / H;
+                const int cc = ch + dc < nch ? ch + dc : 0;
+                issue_w(cc, jj, (slot + 3) & 3);
+                if (j == 0) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1);
+            }
             if (ABL & 2) {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(wf[ni]));
@@ -262,23 +273,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
                 for (int mi = 0; mi < TM; ++mi) asm volatile("" ::"v"(af[mi]));
             } else {
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
+                for (int mi = 0; mi < TM - 1; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-                if (!(ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);   // DS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);   // MFMAs
+            }
+            if (!(ABL & 6)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                       // DS reads
+                if (j == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2 + MAXP, 0);          // the DMAs
+                else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TN * (TM - 1), 0);                 // MFMAs
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else c3_wait_step<H, MAXP>((j + 1) % H);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 2)) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[ni][TM - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[TM - 1], acc[ni][TM - 1], 0, 0, 0);
             }
             slot = (slot + 1) & 3;
         }
     }
-    (void)Stot;
 
     // ---- epilogue: every DMA has landed and every wave has finished reading before the LDS is reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int WROWS = 128, WCOLS = 64, TP = WCOLS + 8;
+    constexpr int WROWS = 16 * TM, WCOLS = 64, TP = WCOLS + 8;
     const int nw0 = n0 + wn * WCOLS;
     sehip_nchunk first = d.ntab[nw0 >> 2];
     bool dense;
@@ -322,10 +346,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 int tl, jl;
-                c3_row<J>(wm, hh * 64 + lane, tl, jl);
+                c3_row<J, TM>(wm, hh * 64 + lane, tl, jl);
                 const int gv = g0 + tl;
                 const int b = gv / TV, t = gv - b * TV;
-                rmask[hh] = __ballot(b < B && t < d.TT);
+                rmask[hh] = __ballot(hh * 64 + lane < WROWS && b < B && t < d.TT);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -333,13 +357,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * 1) * (WROWS * TP);
             const int cp = 32 * wn + 2 * (lane & 15), rg = lane >> 4;
             float sr[2] = {0.f, 0.f}, si[2] = {0.f, 0.f}, srr[2] = {0.f, 0.f}, sri[2] = {0.f, 0.f}, sii[2] = {0.f, 0.f};
-            const unsigned long long rm = rmask[rg >> 1] >> (32 * (rg & 1));
+            constexpr int RG = WROWS / 4;                          // rows per row group
 #pragma unroll 4
-            for (int it = 0; it < 32; ++it) {
-                const int r = 32 * rg + it;
+            for (int it = 0; it < RG; ++it) {
+                const int r = RG * rg + it;
                 const unsigned ur = *reinterpret_cast<const unsigned*>(&imr[r * TP + cp]);
                 const unsigned ui = *reinterpret_cast<const unsigned*>(&imi[r * TP + cp]);
-                const float ok = (rm >> it) & 1ull ? 1.f : 0.f;
+                const float ok = ((r < 64 ? rmask[0] >> r : rmask[1] >> (r - 64)) & 1ull) ? 1.f : 0.f;
                 const float yr[2] = {__uint_as_float(ur << 16) * ok, __uint_as_float(ur & 0xffff0000u) * ok};
                 const float yi[2] = {__uint_as_float(ui << 16) * ok, __uint_as_float(ui & 0xffff0000u) * ok};
 #pragma unroll
@@ -374,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         for (int itr = 0; itr < WROWS / 8; ++itr) {
             const int row = itr * 8 + (lane >> 3);
             int tl, jl;
-            c3_row<J>(wm, row, tl, jl);
+            c3_row<J, TM>(wm, row, tl, jl);
             const int gv = g0 + tl;
             const int b = gv / TV, t = gv - b * TV;
             uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + (lane & 7) * 8]);
@@ -399,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         int tl, jl;
-        c3_row<J>(wm, mi * 16 + (lane & 15), tl, jl);
+        c3_row<J, TM>(wm, mi * 16 + (lane & 15), tl, jl);
         const int gv = g0 + tl;
         const int b = gv / TV, t = gv - b * TV;
         if (b >= B || t >= d.TT) continue;
@@ -442,28 +466,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     }
 }
 
-template <int NF, int FM, int J>
+template <int NF, int FM, int J, int TM>
 static size_t c3_lds_bytes() {
-    using G = C3Geo<NF, FM, J>;
-    const size_t epi = 4 * (128 * 72 * 2) + 64;
+    using G = C3Geo<NF, FM, J, TM>;
+    const size_t epi = 4 * (16 * TM * 72 * 2) + 64;
     return (size_t)G::LDS_MAIN > epi ? (size_t)G::LDS_MAIN : epi;
 }
-template <int NF, int FM, int J>
+template <int NF, int FM, int J, int TM>
 static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d>", NF, FM, J);
-    conv_gemm_v3_kernel<NF, FM, J><<<grid, 256, c3_lds_bytes<NF, FM, J>(), st>>>(d, B);
+    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d>", NF, FM, J, TM);
+    conv_gemm_v3_kernel<NF, FM, J, TM><<<grid, 256, c3_lds_bytes<NF, FM, J, TM>(), st>>>(d, B);
 }
 template <int J, int ABL>
 static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    conv_gemm_v3_kernel<5, 2, J, ABL><<<grid, 256, c3_lds_bytes<5, 2, J>(), st>>>(d, B);
+    conv_gemm_v3_kernel<5, 2, J, 8, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8>(), st>>>(d, B);
+}
+// Rows per tile: 256 (TM 8) or 192 (TM 6).  Tiles run two per CU (512 slots).  Measured at the headline shapes (B (T + 2) = 10400
+// frames): where 256-row tiles do not even fill one round (326 tiles) 192-row tiles (434) take 10-15 % less time; from 650 tiles
+// up the launch is bound by the LDS-DMA rate of the CUs that hold two workgroups and the smaller tile (more weight bytes per
+// FLOP) is the same or slower although its last round is fuller.
+static int c3_pick_tm(long vframes, int J, int ntn) {
+    static const int force = getenv("SEHIP_C3_TM") ? atoi(getenv("SEHIP_C3_TM")) : 0;
+    if (force == 8 || force == 6) return force;
+    const int TB = 256 / J;
+    return (vframes + TB - 1) / TB * ntn < 512 ? 6 : 8;
 }
 template <int NF, int FM>
 static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
@@ -473,14 +507,15 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     if (abl && NF == 5 && (d.J == 4 || d.J == 8)) {
         const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * ntn;
 #define C3_ABL(A_) case A_: if (d.J == 4) c3_launch_abl<4, A_>(d, B, grid, st); else c3_launch_abl<8, A_>(d, B, grid, st); return 1;
-        switch (abl) { C3_ABL(1) C3_ABL(2) C3_ABL(3) C3_ABL(4) C3_ABL(5) C3_ABL(6) default: break; }
+        switch (abl) { C3_ABL(1) C3_ABL(2) C3_ABL(3) C3_ABL(4) C3_ABL(5) C3_ABL(6) C3_ABL(8) C3_ABL(14) default: break; }
 #undef C3_ABL
     }
-#define C3_CASE(J_)                                                                     \
-    case J_: {                                                                          \
-        const int TB = 256 / J_;                                                        \
-        c3_launch<NF, FM, J_>(d, B, (int)((vframes + TB - 1) / TB) * ntn, st);          \
-        return 1;                                                                       \
+    const int tm = c3_pick_tm(vframes, d.J, ntn);
+#define C3_CASE(J_)                                                                                       \
+    case J_: {                                                                                            \
+        const int TB = 32 * tm / J_, grid = (int)((vframes + TB - 1) / TB) * ntn;                         \
+        if (tm == 8) c3_launch<NF, FM, J_, 8>(d, B, grid, st); else c3_launch<NF, FM, J_, 6>(d, B, grid, st); \
+        return 1;                                                                                         \
     }
     switch (d.J) {
         C3_CASE(4) C3_CASE(8) C3_CASE(16) C3_CASE(32)
@@ -507,11 +542,11 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
             if (d.cv_toff[s][kt] < -1 || d.cv_toff[s][kt] > 1) return 0;
         if (abs(d.cv_toff[s][0] - d.cv_toff[s][1]) > 1) return 0;
         if (d.src[s].thi > d.TT + 1) return 0;
-        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 31)) return 0;      // 32-bit piece offsets
+        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 30) - (1L << 20)) return 0;      // byte offsets below C3_RECORDS
     }
     for (int s = 0; s < 2; ++s)
         if (d.dst[s].ptr && (long)B * d.dst[s].T * d.dst[s].F * d.dst[s].C >= (1L << 31)) return 0;
-    if ((long)d.Npad * d.K >= (1L << 31)) return 0;
+    if ((long)d.Npad * d.K >= (1L << 30) - (1L << 20)) return 0;
     if (d.cv_nf == 5 && d.fmul == 2) return c3_launch_j<5, 2>(d, B, st);
     if (d.cv_nf == 3 && d.fmul == 1) return c3_launch_j<3, 1>(d, B, st);
     if (d.cv_nf == 2 && d.fmul == 1) return c3_launch_j<2, 1>(d, B, st);
@@ -520,7 +555,9 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
 
 template <int NF, int FM, int J>
 static void c3_init_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               80 * 1024);
 }
 template <int NF, int FM>
