@@ -93,6 +93,14 @@ int sehip_grad_sumsq(const float* grads, long n, double* sumsq_out, void* stream
 int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
                    float lr, float beta1, float beta2, float eps, int step, const int* step_dev /*device counter or NULL*/,
                    float weight_decay, int mode, float grad_scale, void* stream);
+/* The same with a device-side guard: when guard is not NULL and *guard != 0 at execution time the launch applies nothing
+ * (parameters, moments and the step counter keep their values).  Demucs passes the sticky time-out word of its persistent LSTM
+ * kernels (sehip_dmx_lstm_fwd / _bwd, word 60 of the sync block): an optimizer step is never taken on gradients computed after
+ * a hand-off time-out, without a host round trip. */
+int sehip_opt_step_g(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
+                     float lr, float beta1, float beta2, float eps, int step, const int* step_dev, float weight_decay, int mode,
+                     float grad_scale, const unsigned* guard, void* stream);
+int sehip_opt_begin_g(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, const unsigned* guard, void* stream);
 int sehip_counter_add(int* counter, int value, void* stream);
 /* sets the dynamic-LDS attributes of every kernel up front (call once before capturing a hipGraph) */
 int sehip_init(void);

@@ -46,6 +46,8 @@ _PROTOS = {
     "sehip_pointwise_loss_bwd": [P, P, L, I, P, P, P],
     "sehip_grad_sumsq": [P, L, P, P],
     "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P],
+    "sehip_opt_step_g": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P, P],
+    "sehip_opt_begin_g": [P, I, P, P, I, P, P],
     "sehip_counter_add": [P, I, P],
     "sehip_init": [],
     "sehip_grad_metric": [P, P, I, L, P, P, P, P],

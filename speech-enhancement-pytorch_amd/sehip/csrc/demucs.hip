@@ -570,6 +570,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define DMX_SYNC_WORDS 16384       // sync block: word 60 = time-out (sticky); from word 64: per group 32 replicas of its arrival counter, 128 B apart
 #define DMX_TMO 60
+#define DMX_LIM 61                 // test hook: a non-zero word here replaces DMX_SPIN_LIMIT (tests/test_gpu_demucs.py forces a time-out)
 #define DMX_CNT0 64
 #define DMX_REPL 32
 #define DMX_RSTRIDE 32
@@ -587,12 +588,12 @@ __device__ __forceinline__ SeqMap seq_map(int nb, int btiles) {
     return m;
 }
 // lane 0 of wave 0 waits until the group's counter has reached `target`, then the workgroup barrier
-__device__ __forceinline__ void group_wait(gu32* cnt, unsigned target, gu32* tmo, bool& dead) {
+__device__ __forceinline__ void group_wait(gu32* cnt, unsigned target, gu32* tmo, bool& dead, unsigned limit) {
     if (threadIdx.x == 0 && !dead) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, RLX_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > DMX_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(tmo, RLX_AGENT) != 0)) {
+            if (++spins > limit || ((spins & 1023u) == 0 && __hip_atomic_load(tmo, RLX_AGENT) != 0)) {
                 __hip_atomic_store(tmo, 1u, RLX_AGENT);
                 dead = true;      // give up for the rest of the sequence: garbage out, but the launch ends
                 break;
@@ -637,13 +638,14 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_fwd_kernel(float* __restrict
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(hs, 0, (int)((long)Bn * T * 2 * H * 2), 0x00020000);
     float c = 0.f;
     bool dead = false;
+    const unsigned spin_limit = sync[DMX_LIM] ? sync[DMX_LIM] : DMX_SPIN_LIMIT;
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
         float* pg = pre + (((long)(bok ? b : Bn - 1) * T + t) * 2 + dir) * 4 * H + u0 + u;
         const float p0 = pg[0], p1 = pg[H], p2 = pg[2 * H], p3 = pg[3 * H];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            group_wait(cnt, (unsigned)(nb * s), tmo, dead);
+            group_wait(cnt, (unsigned)(nb * s), tmo, dead, spin_limit);
             const long hp = ((long)brow * T + tp) * 2 * H + dir * H + 8 * ug;
             uint4 av[KS];
             if constexpr (KS >= 4) {
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __re
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dG, 0, (int)((long)Bn * T * 8 * H * 2), 0x00020000);
     float dcs = 0.f;
     bool dead = false;
+    const unsigned spin_limit = sync[DMX_LIM] ? sync[DMX_LIM] : DMX_SPIN_LIMIT;
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : T - 1 - s, tn = dir ? t - 1 : t + 1, tp = dir ? t + 1 : t - 1;
         const bool has_prev = dir ? (t < T - 1) : (t > 0);
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(256) void dmx_lstm_seq_bwd_kernel(const float* __re
         const float dh_up = bf2f(dhs[o]);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            group_wait(cnt, (unsigned)(nb * s), tmo, dead);
+            group_wait(cnt, (unsigned)(nb * s), tmo, dead, spin_limit);
             const long ap = (((long)brow * T + tn) * 2 + dir) * 4 * H + w * H + 8 * ug;
             uint4 av[KS];
             ld16_sc1_n<KS>(rsrc, ap, 32, av);

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, fl
                                                        float* __restrict__ v, long n, const double* __restrict__ sumsq,
                                                        float max_norm, float lr, float b1, float b2, float eps, float bc1,
                                                        float sqrt_bc2, float wd, int mode, int first_step,
-                                                       const int* __restrict__ step_dev, float gscale) {
+                                                       const int* __restrict__ step_dev, float gscale,
+                                                       const unsigned* __restrict__ guard) {
+    if (guard && guard[0] != 0u) return;   // the step's gradients were declared invalid on the device: nothing is applied
     if (step_dev) {  // step counter lives on the device (graph replay): bias corrections computed here
         const int step = step_dev[0];
         first_step = step == 1;
@@ -121,19 +123,23 @@ __global__ void counter_add_kernel(int* p, int v) { p[0] += v; }
 
 // One launch in front of the optimizer kernels: step counter += value, sumsq = 0, tensor_sums[0 .. ntensors) = 0.  (Each of the
 // three was a launch of its own -- two of them runtime memsets, each a 20-25 us bubble on the step's dependent chain.)
-__global__ void opt_begin_kernel(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors) {
+__global__ void opt_begin_kernel(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, const unsigned* guard) {
     if (threadIdx.x == 0) {
-        if (counter) counter[0] += value;
+        if (counter && !(guard && guard[0] != 0u)) counter[0] += value;   // a guarded-out step does not count
         if (sumsq) sumsq[0] = 0.0;
     }
     if (tensor_sums)
         for (int i = threadIdx.x; i < ntensors; i += blockDim.x) tensor_sums[i] = 0.f;
 }
-extern "C" int sehip_opt_begin(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, void* stream) {
+extern "C" int sehip_opt_begin_g(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, const unsigned* guard,
+                                 void* stream) {
     SEHIP_REQUIRE(ntensors >= 0, "opt_begin: negative tensor count");
-    opt_begin_kernel<<<1, 256, 0, (hipStream_t)stream>>>(counter, value, sumsq, tensor_sums, ntensors);
+    opt_begin_kernel<<<1, 256, 0, (hipStream_t)stream>>>(counter, value, sumsq, tensor_sums, ntensors, guard);
     SEHIP_CHECK_LAUNCH("opt_begin");
     return 0;
+}
+extern "C" int sehip_opt_begin(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, void* stream) {
+    return sehip_opt_begin_g(counter, value, sumsq, tensor_sums, ntensors, nullptr, stream);
 }
 
 extern "C" int sehip_counter_add(int* counter, int value, void* stream) {
@@ -143,9 +149,9 @@ extern "C" int sehip_counter_add(int* counter, int value, void* stream) {
     return 0;
 }
 
-extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
-                              float max_norm, float lr, float beta1, float beta2, float eps, int step, const int* step_dev,
-                              float weight_decay, int mode, float grad_scale, void* stream) {
+extern "C" int sehip_opt_step_g(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
+                                float max_norm, float lr, float beta1, float beta2, float eps, int step, const int* step_dev,
+                                float weight_decay, int mode, float grad_scale, const unsigned* guard, void* stream) {
     SEHIP_REQUIRE(n >= 0 && (step >= 1 || step_dev != nullptr), "opt_step: bad n/step (n=%ld step=%d)", n, step);
     if (step < 1) step = 1;
     SEHIP_REQUIRE(mode == 0 || mode == 1, "opt_step: mode must be 0 (adam) or 1 (sgd)");
@@ -158,9 +164,15 @@ extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, l
     if (grid > 2048) grid = 2048;
     opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
                                                            (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev,
-                                                           grad_scale);
+                                                           grad_scale, guard);
     SEHIP_CHECK_LAUNCH("opt_step");
     return 0;
+}
+extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
+                              float max_norm, float lr, float beta1, float beta2, float eps, int step, const int* step_dev,
+                              float weight_decay, int mode, float grad_scale, void* stream) {
+    return sehip_opt_step_g(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, step, step_dev, weight_decay, mode,
+                            grad_scale, nullptr, stream);
 }
 
 static int grad_metric_impl(const float* grads, const long* offsets, int ntensors, long max_tensor, const double* sumsq,

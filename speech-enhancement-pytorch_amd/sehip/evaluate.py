@@ -119,4 +119,9 @@ def evaluate(mixture, model, device, config, max_segments_per_call=None):
             enhanced = enhanced * (std_ + 1e-9) + mean_
         elif norm == "linear-scale":
             enhanced = enhanced * (hi - lo + 1e-9) + lo
+    health = getattr(model, "check_health", None)
+    if health is not None and health():
+        # a hand-off time-out of Demucs' persistent LSTM kernels invalidated this output: the model has switched to the per-step
+        # launches, run the utterance again
+        return evaluate(mixture, model, device, config, max_segments_per_call)
     return enhanced

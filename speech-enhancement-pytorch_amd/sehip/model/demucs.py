@@ -113,8 +113,21 @@ class Demucs(FlatModule):
             self._tables = P.DemucsDeviceTables(self.static, dev)
         return self._lru_get((batch, nsample), self._ws_cap, lambda: P.DemucsWorkspace(self.static, self._tables, batch, nsample, dev))
 
+    def step_guard(self):
+        """Device word the fused optimizer checks (sehip_opt_step_g): the sticky hand-off time-out word of the workspace the last
+        forward ran in -- an optimizer step computed after a time-out is a no-op on the device."""
+        ws = getattr(self, "_last_ws", None)
+        return None if ws is None or not self.static.lstms else ws.lstm_sync[60:61]
+
+    def check_health(self):
+        """Called by the Solver wherever it synchronises anyway (loss read-back, checkpoints, end of evaluate()): True if steps were
+        lost to a hand-off time-out (the model has switched to the per-step LSTM launches)."""
+        ws = getattr(self, "_last_ws", None)
+        return bool(ws is not None and self.static.lstms and ws.check_lstm_handoffs(recover=True))
+
     def _run_forward(self, mix, need_backward):
         ws = self.workspace(mix.shape[0], mix.shape[-1])
+        self._last_ws = ws
         ws.generation += 1
         ws.forward(mix.contiguous().float(), self._flat, need_backward=need_backward)
         return ws

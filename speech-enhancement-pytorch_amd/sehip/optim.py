@@ -71,7 +71,10 @@ class FlatOptimizer(torch.optim.Optimizer):
         self._step += 1  # host mirror; the kernel reads the device counter (valid under hipGraph replay)
         s = self._scratch
         # one launch: step counter, and the accumulators of the clipping norm and of the grad_norm metric cleared
-        call("sehip_opt_begin", ptr(self._step_dev), 1, ptr(s["sumsq"]), ptr(s["tsums"]), s["tsums"].numel(), stream())
+        # guard: device word that, when non-zero, turns this step into a no-op (model.step_guard(): Demucs' hand-off time-out word)
+        gfn = getattr(model, "step_guard", None)
+        guard = gfn() if gfn is not None else None
+        call("sehip_opt_begin_g", ptr(self._step_dev), 1, ptr(s["sumsq"]), ptr(s["tsums"]), s["tsums"].numel(), ptr(guard), stream())
         self._tsums_clear = True
         if self.max_norm > 0:
             call("sehip_grad_sumsq_acc", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
@@ -80,9 +83,9 @@ class FlatOptimizer(torch.optim.Optimizer):
             mode = 0
         else:
             b1, b2, mode = g["momentum"], 0.0, 1
-        call("sehip_opt_step", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq"]),
+        call("sehip_opt_step_g", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq"]),
              self.max_norm, g["lr"], b1, b2, g["eps"], self._step, ptr(self._step_dev), g["weight_decay"], mode, float(self.grad_scale),
-             stream())
+             ptr(guard), stream())
         self.max_norm = 0.0
 
     def grad_metric(self):
@@ -95,6 +98,10 @@ class FlatOptimizer(torch.optim.Optimizer):
         self._tsums_clear = False
         call(fn, ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), int((offs[1:] - offs[:-1]).max()),
              ptr(s["sumsq"]), ptr(s["tsums"]), ptr(s["metric"]), stream())
+        if self.grad_scale != 1.0:
+            # metric[1] is sqrt(sumsq) of the all-reduced SUM; the mean's norm is 1/world of it (metric[0] already is: the step
+            # wrote the scaled gradient back)
+            s["metric"][1].mul_(float(self.grad_scale))
         return s["metric"]
 
     def zero_grad(self, set_to_none=True):

@@ -695,11 +695,27 @@ class DemucsWorkspace:
              self.bufs[dy].ptr, stream())
         self._chain_dirty = True
 
-    def check_lstm_handoffs(self):
-        """Raises if a hand-off spin of the persistent LSTM kernels ever timed out (sticky word; reading it waits for the stream)."""
-        if int(self.lstm_sync[60]) != 0:
-            raise SehipError("Demucs: a hand-off spin of the persistent LSTM kernels timed out (results since then are invalid); "
-                             "set SEHIP_DMX_LSTM_STEPS=1 to use one launch per time step")
+    def check_lstm_handoffs(self, recover=False):
+        """Reads the sticky time-out word of the persistent LSTM kernels (the read waits for the stream).  A time-out means the
+        launches since then produced garbage; the fused optimizer never applied it (the word is its device-side guard,
+        sehip_opt_step_g).  recover=False raises; recover=True switches THIS model to one launch per time step
+        (dmx_lstm_step_*: no inter-workgroup hand-offs), clears the word and returns True -- the caller lost the steps since the
+        time-out and carries on from unchanged parameters."""
+        if int(self.lstm_sync[60]) == 0:
+            return False
+        if not recover:
+            raise SehipError("Demucs: a hand-off spin of the persistent LSTM kernels timed out (results since then are invalid and no "
+                             "optimizer step was applied); set SEHIP_DMX_LSTM_STEPS=1 to use one launch per time step")
+        import warnings
+        warnings.warn("sehip Demucs: a hand-off spin of the persistent LSTM kernels timed out; the optimizer steps since then were "
+                      "skipped on the device; falling back to one launch per LSTM time step for this model")
+        self.st.lstm_per_step = True
+        self.lstm_sync[60:62].zero_()
+        return True
+
+    def _sync_arg(self):
+        """sync block for sehip_dmx_lstm_fwd / _bwd: NULL selects the per-step launches"""
+        return None if getattr(self.st, "lstm_per_step", False) else ptr(self.lstm_sync)
 
     def forward(self, mix, params, need_backward=True):
         """mix [B, ac, T] fp32 on device -> self.out [B, S, ac, T].  need_backward=False (inference): the operands only the backward
@@ -707,7 +723,8 @@ class DemucsWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
         if st.lstms and self.generation % 64 == 2 and not torch.cuda.is_current_stream_capturing():
-            self.check_lstm_handoffs()       # (every 64th call: the read waits for the previous step)
+            self.check_lstm_handoffs(recover=True)       # (every 64th call: the read waits for the previous step; the Solver also
+                                                         #  asks at each of its own synchronisation points, model.check_health())
         self.stats.zero_()
         # weight packing (134 M parameters in both operand orientations: 2.5 ms of table-driven gathers).  Only the shallow levels'
         # forward operands are packed on the chain's stream; the two deepest levels' (94 % of the weights, reached after most of
@@ -750,7 +767,7 @@ class DemucsWorkspace:
                         self.gemm(f"{k}ih{l}")
                         woff = st.whh[(k, l)][0]
                         call("sehip_dmx_lstm_fwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, B * nf, W, H, b[f"{k}hs{l}"].ptr,
-                             b[f"{k}cs{l}"].ptr, ptr(self.lstm_sync), stream())
+                             b[f"{k}cs{l}"].ptr, self._sync_arg(), stream())
                     self.gemm(k + "lin")
                     call("sehip_dmx_frames", 1, b[k + "h2f"].ptr, b[k + "h1"].ptr, B, T, H, nf, W, S, b[k + "h2"].ptr, stream())
                     last = k + "h2"
@@ -888,7 +905,7 @@ class DemucsWorkspace:
                     for l in (1, 0):
                         woff = st.whh[(k, l)][1]
                         call("sehip_dmx_lstm_bwd", b[f"{k}pre{l}"].ptr, tb.wpack.data_ptr() + 2 * woff, b[f"{k}cs{l}"].ptr, b[f"{k}dhs{l}"].ptr, B * nf, W, H,
-                             b[f"{k}dG{l}"].ptr, ptr(self.dc), ptr(self.lstm_sync), stream())
+                             b[f"{k}dG{l}"].ptr, ptr(self.dc), self._sync_arg(), stream())
                         self._chain_dirty = True
                         self.wgrad(f"{k}ih{l}")
                         self.wgrad(f"{k}hh{l}.0")

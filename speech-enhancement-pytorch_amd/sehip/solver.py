@@ -150,7 +150,16 @@ class Solver(object):
             total += n
         print(f"The amount of parameters in the project is {total / 1e6} million.")
 
+    def _model_health(self):
+        """Models with device-side failure words (Demucs: the hand-off time-out of its persistent LSTM kernels) are asked at every
+        point where the Solver waits for the device anyway; the affected optimizer steps were already no-ops on the device."""
+        fn = getattr(self.model, "check_health", None)
+        if fn is not None and fn():
+            self.lost_steps = getattr(self, "lost_steps", 0) + 1
+            self.writer.add_scalar("Train/lost_steps", self.lost_steps, -1)
+
     def _save_checkpoint(self, epoch, is_best=False):
+        self._model_health()
         if not self.is_main:
             return
         state_dict = {"epoch": epoch, "best_score": self.score["best_score"], "optimizer": self.optimizer.state_dict()}
@@ -354,6 +363,7 @@ class Solver(object):
                 else:
                     self.writer.add_scalar("Validation/Loss_step", loss, epoch * total_step + step_)
             pending.clear()
+            self._model_health()
 
         for step, batch in enumerate(dataloader):
             if step >= total_step:
