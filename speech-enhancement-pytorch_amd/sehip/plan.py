@@ -1132,6 +1132,17 @@ class DCCRNWorkspace:
         n_params = st.layout.n_params
         lo = st.layout.param_off["decoder.0.0.real_conv.weight"][0] if range_ready is not None else 0
         if range_ready is not None:
+            # the early hand-over rests on the flat layout: [0, lo) = encoder parameters only (their gradients are written
+            # below), [lo, n) = LSTM + decoder parameters only (final by now).  A layout change must fail here, not all-reduce
+            # half-written gradients.
+            L = st.layout
+            if not getattr(st, "_dp_layout_checked", False):
+                for nm in L.param_names:
+                    early = L.param_off[nm][0] >= lo
+                    if early != (not nm.startswith("encoder.")):
+                        raise SehipError(f"DCCRN data-parallel hand-over: parameter {nm} at offset {L.param_off[nm][0]} is on the wrong "
+                                         f"side of the decoder/LSTM split {lo}")
+                st._dp_layout_checked = True
             # decoder / LSTM gradients: un-packed and handed over on a third stream that waits for the chain (BatchNorm / PReLU
             # gradients) and for the weight-gradient stream as they stand now -- the chain itself does not wait
             if self.comm is None:

@@ -849,6 +849,24 @@ class DemucsWorkspace:
         n_params = st.layout.n_params
         enc_off = [st.layout.param_off[f"encoder.{i}.0.weight"][0] for i in range(D)] + [st.layout.param_off["decoder.0.0.weight"][0]]
         done_from = n_params
+        handed = []                                    # (lo, hi) of every range given to range_ready: must tile [0, n_params)
+        if range_ready is not None:
+            # the early hand-overs rest on the flat layout: encoder.i contiguous and increasing, the decoder the tail.  A layout
+            # change must fail here, not all-reduce half-written gradients.
+            if not getattr(st, "_dp_layout_checked", False):
+                if any(a >= b_ for a, b_ in zip(enc_off[:-1], enc_off[1:])) or enc_off[0] != 0:
+                    raise SehipError(f"Demucs data-parallel hand-over: encoder offsets {enc_off} are not strictly increasing from 0")
+                for nm in st.layout.param_names:
+                    off = st.layout.param_off[nm][0]
+                    want = "decoder." if off >= enc_off[D] else f"encoder.{max(i for i in range(D) if enc_off[i] <= off)}."
+                    if not nm.startswith(want):
+                        raise SehipError(f"Demucs data-parallel hand-over: parameter {nm} at offset {off} is outside its layer's range")
+                st._dp_layout_checked = True
+            inner = range_ready
+
+            def range_ready(lo_, hi_, st_):
+                handed.append((lo_, hi_))
+                inner(lo_, hi_, st_)
         up = 1 if cfg.resample else 0
         self.gpack.zero_()
         self.sums.zero_()
@@ -929,4 +947,7 @@ class DemucsWorkspace:
         if range_ready is not None:
             range_ready(0, done_from, torch.cuda.current_stream())
             call("sehip_stream_depend", stream(), self.comm.cuda_stream, self._event())
+            ends = sorted(handed)
+            if ends[0][0] != 0 or ends[-1][1] != n_params or any(a[1] != b_[0] for a, b_ in zip(ends[:-1], ends[1:])):
+                raise SehipError(f"Demucs data-parallel hand-over: the ranges {ends} do not tile [0, {n_params})")
         return grads

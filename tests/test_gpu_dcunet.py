@@ -306,3 +306,44 @@ def test_c2_headline_shape_one_step(tmp_path):
     sdv = y.var(dim=(0, 1, 2), unbiased=True)[:62]
     rv = model.state_dict()["encoder1.bn.bn_re.running_var"]
     assert rel_err(rv.cpu(), (0.9 + 0.1 * sdv).cpu()) < 1e-2 and float(m.abs().max()) < 10
+
+
+def test_full_width_gradients_vs_oracle():
+    """complexity 45 (31 / 62 complex channels stored as 32 / 64 -- the shapes conv_wgrad2_kernel and the
+    table-gathered products were written for), [2, 1, 257, 65, 2] spectra: the forward output and, under a FIXED upstream gradient
+    G (loss = <est, G>: the comparison does not amplify the forward's bf16 error through a data-dependent d loss / d est), EVERY
+    parameter gradient against the oracle's autograd.  Bounds: output 1.5e-2, global gradient 1e-2, every tensor that holds
+    more than 3 % of the gradient norm 5e-2; BatchNorm running statistics against the oracle's."""
+    from sehip.model import DCUnet
+    torch.manual_seed(11)
+    model = DCUnet(data_type=True, model_complexity=45, model_depth=10)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith(("encoders.", "decoders."))}
+    model = model.cuda().train()
+    g = torch.Generator().manual_seed(12)
+    x = 0.5 * torch.randn(2, 1, 257, 65, 2, generator=g)
+    names = sorted(k for k in p if D.is_trainable(k))
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    stats = {}
+    ref = D.dcunet_forward(work, x, model_complexity=45, model_depth=10, training=True, stats_out=stats)
+    G = torch.randn(ref.shape, generator=g) / ref.numel() ** 0.5
+    grads = torch.autograd.grad((ref * G).sum(), [leaves[k] for k in names])
+    est = model(x.cuda())
+    out_err = rel_err(est.detach().cpu(), ref.detach())
+    est.backward(G.cuda())
+    torch.cuda.synchronize()
+    got = {k: v.grad.detach().cpu() for k, v in model.named_parameters() if not k.startswith(("encoders.", "decoders."))}
+    num = sum(float(((got[k].double() - gr.double()) ** 2).sum()) for k, gr in zip(names, grads))
+    den = sum(float((gr.double() ** 2).sum()) for gr in grads)
+    rows = sorted(((float((got[k].double() - gr.double()).norm() / (gr.double().norm() + 1e-30)), float(gr.norm()) / den ** 0.5, k)
+                   for k, gr in zip(names, grads)), reverse=True)
+    big = [r for r in rows if r[1] > 0.03]
+    print(f"DCUnet full width: output rel {out_err:.3e}, global grad rel {(num / den) ** 0.5:.3e}, worst large tensors {big[:3]}, "
+          f"worst of all {rows[:3]}")
+    assert out_err < 1.5e-2
+    assert (num / den) ** 0.5 < 1e-2
+    assert all(r[0] < 5e-2 for r in big), big[:5]
+    sd = model.state_dict()
+    for k, v in stats.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert rel_err(sd[k].cpu().float(), v.float()) < 2e-2, k
