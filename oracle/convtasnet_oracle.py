@@ -41,22 +41,32 @@ def overlap_and_add(frames, step):
     return out.reshape(*lead, -1)
 
 
-def temporal_block(x, p, pre, dilation, P):
+def _prelu(h, a, mask):
+    """nn.PReLU() (one slope).  With ``mask`` (tests only: a boolean tensor, True = the identity branch) the branch of every element is
+    GIVEN instead of taken from the sign of h, so that a backward pass can be compared through the same branches as the run the mask
+    came from (near-zero pre-activations change sign under a 1 % forward error of a bf16 path)."""
+    if mask is None:
+        return F.prelu(h, a)
+    return h * torch.where(mask, torch.ones((), dtype=h.dtype), a.reshape(()))
+
+
+def temporal_block(x, p, pre, dilation, P, masks=None):
     """1x1 B->H, PReLU, gLN, depthwise dilated conv (groups=H, 'same' padding), PReLU, gLN, 1x1 H->B, + residual
-    (src/model/conv_tasnet.py:307-402 with skip=False)."""
+    (src/model/conv_tasnet.py:307-402 with skip=False).  masks: (mask1, mask2) for the two PReLUs, see _prelu."""
     h = F.conv1d(x, p[pre + "net.0.weight"])
-    h = F.prelu(h, p[pre + "net.1.weight"])
+    h = _prelu(h, p[pre + "net.1.weight"], None if masks is None else masks[0])
     h = gln(h, p[pre + "net.2.gamma"], p[pre + "net.2.beta"])
     q = pre + "net.3."
     pad = (P - 1) * dilation // 2
     h = F.conv1d(h, p[q + "net.0.weight"], padding=pad, dilation=dilation, groups=h.shape[1])
-    h = F.prelu(h, p[q + "net.1.weight"])
+    h = _prelu(h, p[q + "net.1.weight"], None if masks is None else masks[1])
     h = gln(h, p[q + "net.2.gamma"], p[q + "net.2.beta"])
     return F.conv1d(h, p[q + "pointwise_conv.weight"]) + x
 
 
-def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2, audio_channels=1, taps=None):
-    """mixture [M, ac, T] -> separated sources [M, C, ac, T] (src/model/conv_tasnet.py:136-154)."""
+def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2, audio_channels=1, taps=None, act_masks=None):
+    """mixture [M, ac, T] -> separated sources [M, C, ac, T] (src/model/conv_tasnet.py:136-154).
+    act_masks (tests only): {"block{r}.{i}": (mask1, mask2), "mask": mask} -- given branches of the PReLUs / the mask ReLU."""
     w = F.relu(F.conv1d(mixture, p["encoder.conv1d_U.weight"], stride=L // 2))           # [M, N, K]
     net = "separator.network."
     x = cln(w, p[net + "0.gamma"], p[net + "0.beta"])
@@ -65,11 +75,12 @@ def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2
         taps["bottleneck"] = x
     for r in range(R):
         for i in range(X):
-            x = temporal_block(x, p, f"{net}2.{r}.{i}.", 2 ** i, P)
+            x = temporal_block(x, p, f"{net}2.{r}.{i}.", 2 ** i, P, None if act_masks is None else act_masks[f"block{r}.{i}"])
             if taps is not None:
                 taps[f"block{r}.{i}"] = x
     m, n, k = w.shape
-    mask = F.relu(F.conv1d(x, p[net + "3.weight"]).view(m, C, n, k))
+    score = F.conv1d(x, p[net + "3.weight"]).view(m, C, n, k)
+    mask = F.relu(score) if act_masks is None else score * act_masks["mask"].to(score.dtype)
     src_w = (w.unsqueeze(1) * mask).transpose(2, 3)                                        # [M, C, K, N]
     est = F.linear(src_w, p["decoder.basis_signals.weight"])                               # [M, C, K, ac*L]
     est = est.view(m, C, k, audio_channels, L).transpose(2, 3)
