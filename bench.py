@@ -176,9 +176,139 @@ def cbn_roofline(ws, model, reps=3):
 
 
 def _weight_entries(ws, name):
+    key = name[:-3] if name.endswith(".wg") else name
+    if hasattr(ws.st, "prods"):                       # Demucs keeps its packing table flat
+        return int((ws.st.prods[key].wtab >= 0).sum())
     specs = ws.pl.specs if hasattr(ws, "pl") else ws.st.specs
-    s = specs[name[:-3] if name.endswith(".wg") else name]
-    return int((s.widx >= 0).sum())
+    return int((specs[key].widx >= 0).sum())
+
+
+# ---- the other three BASELINE configurations: CPU baseline + parity on a stated SUB-batch of the same synthetic batch ----------
+SUB_BATCH = {"dcunet": 4, "convtasnet": 4, "demucs": 2}      # clips of the CPU leg / parity block (full batches: 64 / 32 / 16)
+SUB_STEPS = 3                                                # 1 warm-up + 2 timed oracle train steps
+TOL_GENERIC = {"dcunet": {"out_rel": 3e-2, "loss_rel": 3e-2}, "convtasnet": {"out_rel": 3e-2, "dloss_db": 0.15},
+               "demucs": {"out_rel": 3e-2, "dloss_db": 0.15}}
+
+
+def workload_batch(workload, b, rank, device):
+    """(noisy [B, C, n], clean [B, S, C, n]) exactly as main() builds them for the timed run."""
+    n = {"dcunet": 32768, "convtasnet": 32000, "demucs": 96000}[workload]
+    noisy, clean = make_batch(b, n, rank, device)
+    if workload == "demucs":
+        n2, c2 = make_batch(b, n, rank + 1000, device)
+        noisy = torch.cat([noisy, 0.8 * clean[:, 0] + (n2 - c2[:, 0])], dim=1)
+        clean = torch.cat([clean, 0.8 * clean], dim=2)
+    if workload == "convtasnet":
+        clean = torch.cat([clean, noisy.unsqueeze(1) - clean], dim=1)
+    return noisy, clean
+
+
+def oracle_problem(workload, p, noisy, clean):
+    """forward(params, stats_out) -> estimate, loss function, model-domain target and the trainable keys of the fp32 CPU oracle."""
+    import torch.nn.functional as F
+    from oracle import dccrn_oracle as O
+    if workload == "dcunet":
+        from oracle import dcunet_oracle as D, stft_oracle as S
+        x = torch.from_numpy(S.stft_custom(noisy.numpy(), 512, 128, 512))
+        tgt = torch.from_numpy(S.stft_custom(clean[:, 0].numpy(), 512, 128, 512))
+        fwd = lambda prm, st: D.dcunet_forward(prm, x, model_complexity=45, model_depth=10, training=True, stats_out=st)
+        return fwd, F.mse_loss, tgt, [k for k in p if D.is_trainable(k)]
+    if workload == "convtasnet":
+        from oracle import convtasnet_oracle as CT
+        fwd = lambda prm, st: CT.convtasnet_forward(prm, noisy, audio_channels=1)
+        return fwd, O.loss_sisdr, clean, [k for k in p if CT.is_trainable(k)]
+    from oracle import demucs_oracle as DM
+    cfg = DM.DemucsConfig(sources=["clean"], audio_channels=2)
+    fwd = lambda prm, st: DM.demucs_forward(prm, noisy, cfg)
+    return fwd, O.loss_sisdr, clean, [k for k in p if DM.is_trainable(k)]
+
+
+def cpu_worker_generic(workload, state_path, out_path, threads):
+    """Child process: the workload's fp32 CPU oracle on the first SUB_BATCH clips of the bench batch, from the same initial weights:
+    training-mode forward (step-0 estimate), SUB_STEPS train steps (loss, backward, clip 5, Adam 3e-4), forward again."""
+    torch.set_num_threads(threads)
+    b = SUB_BATCH[workload]
+    p = torch.load(state_path)
+    noisy, clean = workload_batch(workload, b, 0, "cpu")
+    fwd, loss_fn, tgt, names = oracle_problem(workload, p, noisy, clean)
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    opt = torch.optim.Adam([leaves[k] for k in names], lr=3e-4)
+    with torch.no_grad():
+        est0 = fwd(work, None)
+    losses, times = [], []
+    for _ in range(SUB_STEPS):
+        t0 = time.time()
+        stats = {}
+        loss = loss_fn(fwd(work, stats), tgt)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([leaves[k] for k in names], 5.0)
+        opt.step()
+        work.update(stats)
+        times.append(time.time() - t0)
+        losses.append(float(loss.detach()))
+    with torch.no_grad():
+        estk = fwd(work, None)
+    torch.save({"est0": est0, "estk": estk, "losses": losses}, out_path)
+    dt = sum(times[1:]) / len(times[1:])
+    clip_s = {"dcunet": 32768 / SR, "convtasnet": 4.0, "demucs": 2.0}[workload]
+    print(json.dumps({"value": b * clip_s / dt, "unit": "audio-s/s", "cores": threads, "kind": "port",
+                      "host_cores": len(os.sched_getaffinity(0)), "s_per_step": dt,
+                      "sample": f"{len(times) - 1} timed train steps after 1 warm-up on the first {b} clips of the bench batch "
+                                f"(fp32 oracle of this network, torch CPU, {threads} threads), {dt:.2f} s/step; a sub-batch because the "
+                                f"full batch does not fit the bench's CPU time bound"}))
+
+
+def hip_parity_generic(solver, model, noisy, clean, workload):
+    """The HIP side on the same sub-batch, from the freshly initialised weights."""
+    b = SUB_BATCH[workload]
+    mix, src = solver._prepare_batch(noisy[:b], clean[:b])
+    model.train()
+    with torch.no_grad():
+        est0 = model(mix).cpu()
+    losses = []
+    for _ in range(SUB_STEPS):
+        loss, _ = solver.train_step(mix, src)
+        losses.append(float(loss))
+    with torch.no_grad():
+        estk = model(mix).cpu()
+    return {"est0": est0, "estk": estk, "losses": losses}
+
+
+def parity_generic(hip, cpu_path, workload):
+    cpu = torch.load(cpu_path)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    tol = TOL_GENERIC[workload]
+    out = {"against": f"fp32 CPU oracle of this network (oracle/, pinned to the reference by tests/golden), identical initial weights and "
+                      f"the first {SUB_BATCH[workload]} clips of the bench batch", "batch": SUB_BATCH[workload], "train_steps": SUB_STEPS,
+           "loss_hip": hip["losses"], "loss_cpu": cpu["losses"], "output_step0_rel": rel(hip["est0"], cpu["est0"]),
+           f"output_after_{SUB_STEPS}_steps_rel": rel(hip["estk"], cpu["estk"]), "tolerance": tol}
+    if "dloss_db" in tol:
+        out["max_abs_dloss_db"] = max(abs(a - b) for a, b in zip(hip["losses"], cpu["losses"]))
+        ok = out["max_abs_dloss_db"] < tol["dloss_db"]
+    else:
+        out["max_loss_rel"] = max(abs(a - b) / abs(b) for a, b in zip(hip["losses"], cpu["losses"]))
+        ok = out["max_loss_rel"] < tol["loss_rel"]
+    out["pass"] = bool(ok and out["output_step0_rel"] < tol["out_rel"] and out[f"output_after_{SUB_STEPS}_steps_rel"] < 2 * tol["out_rel"])
+    return out
+
+
+def activation_bytes(workload, ws, batch):
+    """A = bytes of the layer-boundary activations of one forward pass in their stored types; the compulsory-traffic model of
+    SURVEY section 8d (forward write + read 2 A, skip re-reads, backward read-saved + write-grad + read-grad 3 A => 5.5 A per step)
+    gives the algorithmic HBM bytes of a train step."""
+    if workload == "convtasnet":
+        cfg, M, K = ws.st.cfg, ws.M, ws.K
+        nb = len(ws.st.blocks)
+        per_frame = cfg.N * 4 + cfg.N * 2 + cfg.B * 2 + nb * (4 * cfg.H + cfg.B) * 2 + cfg.C * cfg.N * 2
+        return M * K * per_frame + 2 * M * cfg.C * ws.T * 4
+    if workload == "demucs":     # forward buffers = every workspace buffer that is not the gradient twin ("d" + name) of another
+        names = set(ws.bufs)
+        fwd = [k for k in names if not (k.rsplit(".", 1)[-1].startswith("d") and
+                                        (k.rsplit(".", 1)[0] + "." if "." in k else "") + k.rsplit(".", 1)[-1][1:] in names)]
+        return sum(ws.bufs[k].t.numel() * ws.bufs[k].t.element_size() for k in fwd)
+    return 0
 
 
 PARITY_STEPS = 4           # 1 warm-up + 3 timed oracle steps (BASELINE.md section 3); the HIP side runs the same 4
@@ -220,12 +350,12 @@ def cpu_baseline_worker(state_path, out_path, batch, threads):
                                 f"(fp32 oracle, torch CPU, {threads} threads), {dt:.2f} s/step"}))
 
 
-def cpu_baseline(state_path, out_path, batch, threads, timeout_s=900):
+def cpu_baseline(state_path, out_path, batch, threads, timeout_s=900, workload="dccrn"):
     """Runs the worker as a child process (own thread pool, hard timeout) so a slow host cannot stall the bench."""
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", state_path, out_path,
-                            "--batch", str(batch), "--cpu-threads", str(threads)], capture_output=True,
+                            "--batch", str(batch), "--cpu-threads", str(threads), "--workload", workload], capture_output=True,
                            text=True, timeout=timeout_s, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
@@ -316,8 +446,11 @@ def main():
     if not args.batch:
         args.batch = 64 if dcu else 16 if dmx else BATCH
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], args.batch,
-                            args.cpu_threads or min(len(os.sched_getaffinity(0)), 32))
+        threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
+        if args.workload == "dccrn":
+            cpu_baseline_worker(args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], args.batch, threads)
+        else:
+            cpu_worker_generic(args.workload, args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], threads)
         return
 
     from sehip import distrib
@@ -331,8 +464,6 @@ def main():
         n, clip_s, cfg = 32000, 4.0, convtasnet_config()       # 4 s at 8 kHz
     if dmx:
         n, clip_s, cfg = 96000, 2.0, demucs_config()           # 2 s at 48 kHz
-    if dcu or ctn or dmx:
-        args.no_cpu_baseline = True               # the CPU baseline / parity block belong to the headline workload (tests pin C2)
     torch.manual_seed(cfg.seed)
     model = distrib.get_model(cfg.model)
     opt = distrib.get_optimizer(cfg.optim, model)
@@ -364,10 +495,11 @@ def main():
         tmpd = tempfile.mkdtemp(prefix="sehip_bench_")
         state_path, cpu_out = os.path.join(tmpd, "state0.pt"), os.path.join(tmpd, "cpu.pt")
         torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()
-                    if not k.startswith(("stft.", "istft."))}, state_path)
+                    if not k.startswith(("stft.", "istft.", "encoders.", "decoders."))}, state_path)
         if not args.no_parity:
-            note(f"parity leg on the GPU: step-0 waveform + {PARITY_STEPS} train steps from the initial weights")
-            hip_par = hip_parity_run(solver, model, mixture, sources)
+            note(f"parity leg on the GPU: step-0 output + train steps from the initial weights")
+            hip_par = (hip_parity_generic(solver, model, noisy, clean, args.workload) if (dcu or ctn or dmx)
+                       else hip_parity_run(solver, model, mixture, sources))
     note(f"model built, batch staged on {dev}; warm-up {args.warmup} steps")
     args.eager = not args.graph
     step_fn = base_step(solver.train_step if args.eager else solver.train_step_graphed)
@@ -425,19 +557,20 @@ def main():
                    "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step" if args.h2d else "resident in HBM"},
         "final_loss": float(loss),
     }
-    if rank == 0 and not args.no_roofline and not dmx:
+    if rank == 0 and not args.no_roofline:
         ws = model.workspace(args.batch, 257, 257) if dcu else model.workspace(args.batch, n)
-        if ctn:
-            ws.st.specs = ws.st.specs   # (TasNetWorkspace keeps its products in ws.st.specs like the DCCRN workspace)
         note("per-kernel roofline pass")
         rows = gemm_roofline(ws)
         top = rows[0]
         total_ms = sum(r["ms"] for r in rows)
         total_gf = sum(r["gflop"] for r in rows)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")  # PMC passes over the real step (FETCH_SIZE / WRITE_SIZE), tools/collect_traffic.sh
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")  # PMC passes over the real step (FETCH_SIZE / WRITE_SIZE), tools/collect_round.sh
+        for older in ("r2_traffic.json", "r1_traffic.json"):
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", older)
+        if dcu or ctn or dmx:
+            tpath = os.path.join(ROOT, "profiles", f"r3_traffic_{args.workload}.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
@@ -446,7 +579,16 @@ def main():
                            "gflop_per_launch": top["gflop"] / top["launches"],
                            "all_product_kernels": {"ms_per_step": total_ms, "tflops": total_gf / total_ms,
                                                    "frac": total_gf / total_ms / PEAK_BF16_TFLOPS}}
-        if not dcu and not ctn:
+        if ctn or dmx:
+            # second entry, HBM: the whole step against the compulsory-traffic model (these two networks are bound by their
+            # activation streams: normalisation / activation / depthwise kernels, not by the products)
+            A = activation_bytes(args.workload, ws, args.batch)
+            out["roofline_hbm"] = {"bound": "hbm", "scope": "whole train step", "achieved": 5.5 * A / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": 5.5 * A / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                   "algorithmic_bytes_per_step": 5.5 * A,
+                                   "model": "5.5 x the bytes of the layer-boundary activations of one forward pass in their stored "
+                                            "types (SURVEY section 8d: forward write + read, backward read-saved + write-grad + read-grad)"}
+        if not dcu and not ctn and not dmx:
             out["roofline_hbm"] = cbn_roofline(ws, model)   # second entry: the largest HBM-bound class of the step
             if os.path.exists(tpath):   # PMC bytes of the same passes over the real step (finalize launches excluded)
                 tj = json.load(open(tpath))
@@ -454,15 +596,16 @@ def main():
                          if k.startswith("cbn_") and "finalize" not in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v)
                 out["roofline_hbm"]["traffic"] = tb or None
         # algorithmic FLOPs per clip-step (SURVEY section 8d / BASELINE.md): DCCRN 45.96 GF, DCUnet-10 111.9 GF (fwd + bwd)
-        out["step_tflops"] = (111.9e9 if dcu else 3 * 3.2e9 if ctn else 45.96e9) * args.batch / (ms * 1e-3) / 1e12
+        out["step_tflops"] = ((111.9e9 if dcu else 3 * 3.2e9 if ctn else 45.96e9) * args.batch if not dmx else total_gf * 1e9) / (ms * 1e-3) / 1e12
         out["kernel_classes"] = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["avg_us"], 1),
                                   "tflops": round(r["tflops"], 1)} for r in rows[:10]]
     if do_cpu:
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
         note(f"cpu baseline + parity reference (oracle, B={args.batch}, {threads} threads)")
-        out["cpu_baseline"] = cpu_baseline(state_path, cpu_out, args.batch, threads)
+        out["cpu_baseline"] = cpu_baseline(state_path, cpu_out, args.batch, threads, workload=args.workload)
         if hip_par is not None and os.path.exists(cpu_out):
-            out["parity"] = parity_block(hip_par, cpu_out, args.batch)
+            out["parity"] = (parity_generic(hip_par, cpu_out, args.workload) if (dcu or ctn or dmx)
+                             else parity_block(hip_par, cpu_out, args.batch))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -61,6 +61,19 @@ int sehip_stft_custom_fwd(const float* wav, int rows, int n_samples, int n_fft, 
 int sehip_istft_custom_fwd(const float* spec, int rows, int n_frames, int n_fft, int hop, int win_length, int center,
                            int length, float* frames_ws, float* wav, void* stream);
 
+/* ---- the data path in front of the step, on the device: WavDataset.__getitem__ (src/dataset.py:95-170: z-score :147-152 with
+ *      torch.std's Bessel correction, linear-scale :154-160, aligned random crop src/utils.py:63-87) and collate_fn_pad
+ *      (src/distrib.py:38-98).  raw: the batch's utterances as ONE flat fp32 buffer, row r (a channel of the mixture or of a source
+ *      of one utterance) = raw[row_off[r] .. row_off[r + 1]).
+ *      wav_row_stats: stats [rows][4] = {mean, unbiased std, min, max}.
+ *      wav_collate:   out [out_rows][seg]; output row o = samples out_start[o] .. + seg of raw row out_row[o], normalised
+ *                     (mode 0 none, 1 z-score (x - mean) / (std + eps), 2 linear (x - min) / (max - min + eps)), zeros past the row's
+ *                     end and past out_valid[o] samples (what pad_last writes).  The host lays the output rows out in the order
+ *                     of the reference's batch tensors (sehip/data.py). */
+int sehip_wav_row_stats(const float* raw, const long* row_off, int rows, float* stats, void* stream);
+int sehip_wav_collate(const float* raw, const long* row_off, const int* out_row, const long* out_start, const int* out_valid,
+                      const float* stats, int mode, float eps, int seg, int out_rows, float* out, void* stream);
+
 /* ---- SI-SNR loss: src/loss.py:14-29 (si_snr, loss_sisdr).  rowstat is [rows][4] fp32 scratch kept for bwd. */
 int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int n, float* rowstat, float* loss, void* stream);
 /* SI-SDR validation metric of src/metric.py:92-123 (SI_SDR) on device rows [rows][n]: out[0] = 10 log10(mean ratio + eps);

@@ -37,6 +37,8 @@ _PROTOS = {
     "sehip_stft_custom_frames": [I, I, I, I],
     "sehip_stft_custom_fwd": [P, I, I, I, I, I, I, P, P],
     "sehip_istft_custom_fwd": [P, I, I, I, I, I, I, I, P, P, P],
+    "sehip_wav_row_stats": [P, P, I, P, P],
+    "sehip_wav_collate": [P, P, P, P, P, P, I, F, I, I, P, P],
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],
     "sehip_sisdr_metric": [P, P, I, I, P, P, P],
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
