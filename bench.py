@@ -177,8 +177,10 @@ def cbn_roofline(ws, model, reps=3):
 
 def _weight_entries(ws, name):
     key = name[:-3] if name.endswith(".wg") else name
-    if hasattr(ws.st, "prods"):                       # Demucs keeps its packing table flat
-        return int((ws.st.prods[key].wtab >= 0).sum())
+    st = getattr(ws, "st", None)
+    if st is not None and hasattr(st, "prods"):       # Demucs: dense weights (channel counts are multiples of 16, K = taps x channels);
+        d = ws.desc[name]                             # its packing tables are freed after the build
+        return int(d.N) * int(d.K)
     specs = ws.pl.specs if hasattr(ws, "pl") else ws.st.specs
     return int((specs[key].widx >= 0).sum())
 
@@ -194,6 +196,8 @@ def workload_batch(workload, b, rank, device):
     """(noisy [B, C, n], clean [B, S, C, n]) exactly as main() builds them for the timed run."""
     n = {"dcunet": 32768, "convtasnet": 32000, "demucs": 96000}[workload]
     noisy, clean = make_batch(b, n, rank, device)
+    if workload == "dcunet":      # SURVEY section 8d, C2: unit-variance clips (randn(64, 1, 32768)), not the 0.1-scale of C1
+        noisy, clean = 10.0 * noisy, 10.0 * clean
     if workload == "demucs":
         n2, c2 = make_batch(b, n, rank + 1000, device)
         noisy = torch.cat([noisy, 0.8 * clean[:, 0] + (n2 - c2[:, 0])], dim=1)
@@ -229,7 +233,9 @@ def cpu_worker_generic(workload, state_path, out_path, threads):
     torch.set_num_threads(threads)
     b = SUB_BATCH[workload]
     p = torch.load(state_path)
-    noisy, clean = workload_batch(workload, b, 0, "cpu")
+    full = {"dcunet": 64, "convtasnet": 32, "demucs": 16}[workload]
+    noisy, clean = workload_batch(workload, full, 0, "cpu")       # the bench batch (same generator sequence), then its first clips
+    noisy, clean = noisy[:b].contiguous(), clean[:b].contiguous()
     fwd, loss_fn, tgt, names = oracle_problem(workload, p, noisy, clean)
     leaves = {k: p[k].clone().requires_grad_(True) for k in names}
     work = dict(p); work.update(leaves)
@@ -469,13 +475,12 @@ def main():
     opt = distrib.get_optimizer(cfg.optim, model)
     solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
     dev = solver.device
-    noisy, clean = make_batch(args.batch, n, rank, dev)
-    if dmx:   # stereo: the second channel is an attenuated, differently-noised copy; one source [B, 1, 2, N]
-        n2, c2 = make_batch(args.batch, n, rank + 1000, dev)
-        noisy = torch.cat([noisy, 0.8 * clean[:, 0] + (n2 - c2[:, 0])], dim=1)
-        clean = torch.cat([clean, 0.8 * clean], dim=2)
-    if ctn:   # two sources per clip, the mixture is their sum (sources [B, S, 1, N] stay 4-D for this model, src/solver.py:443-452)
-        clean = torch.cat([clean, noisy.unsqueeze(1) - clean], dim=1)
+    if dcu or ctn or dmx:
+        # dcunet: unit-variance clips; demucs: stereo, the second channel an attenuated, differently-noised copy, one source [B, 1, 2, N];
+        # convtasnet: two sources per clip whose sum is the mixture (sources [B, S, 1, N] stay 4-D for this model, src/solver.py:443-452)
+        noisy, clean = workload_batch(args.workload, args.batch, rank, dev)
+    else:
+        noisy, clean = make_batch(args.batch, n, rank, dev)
     mixture, sources = solver._prepare_batch(noisy, clean)
     if dcu:
         # the reference transforms mixture and sources inside every step (src/solver.py:454-458): timed with the step

@@ -278,6 +278,13 @@ int sehip_rbn_stats(const void* y, long rows, int Cs, int Cr, float* part, void*
 int sehip_rbn_finalize(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im, float* rm_re,
                        float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows, int Cs, int Cr, float eps,
                        float momentum, int training, float* coef, void* stream);
+/* the same for a tensor stored WITHOUT a per-channel constant `shift` [2*Cs] (fp32; the convolution's effective bias, which the
+ * normalisation cancels: src/model/dcunet.py:323-338 adds it, :374-386 removes it again): y_reference = y_stored + shift.  The
+ * running mean tracks mean + shift, inference normalises with running_mean - shift.  A bias far above the signal (small-amplitude
+ * spectra) would otherwise take most of the bf16 mantissa of the stored tensor. */
+int sehip_rbn_finalize_s(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im, float* rm_re,
+                         float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows, int Cs, int Cr, float eps,
+                         float momentum, int training, const float* shift, float* coef, void* stream);
 int sehip_rbn_apply(const void* y, const float* coef, long rows, int Cs, int Cr, void* z, void* stream);
 int sehip_rbn_bwd_reduce(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part, void* stream);
 int sehip_rbn_bwd_finalize(const float* part, const float* coef, long rows, int Cs, int Cr, float* gw_re, float* gb_re, float* gw_im,

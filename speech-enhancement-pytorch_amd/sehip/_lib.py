@@ -83,6 +83,7 @@ _PROTOS = {
     "sehip_rbn_scratch_floats": [L, I],
     "sehip_rbn_stats": [P, L, I, I, P, P],
     "sehip_rbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, F, I, P, P],
+    "sehip_rbn_finalize_s": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, F, I, P, P, P],
     "sehip_rbn_apply": [P, P, L, I, I, P, P],
     "sehip_rbn_bwd_reduce": [P, P, P, L, I, I, P, P],
     "sehip_rbn_bwd_finalize": [P, P, L, I, I, P, P, P, P, P, P],

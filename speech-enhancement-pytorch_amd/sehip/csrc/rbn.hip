@@ -109,8 +109,12 @@ __global__ void rbn_finalize_kernel(const float* __restrict__ part, int nblk, co
                                     const float* __restrict__ w_im, const float* __restrict__ b_im, float* __restrict__ rm_re,
                                     float* __restrict__ rv_re, float* __restrict__ rm_im, float* __restrict__ rv_im,
                                     long* __restrict__ nbt_re, long* __restrict__ nbt_im, long rows, int Cs, int Cr, float eps,
-                                    float momentum, int training, float4* __restrict__ coef) {
+                                    float momentum, int training, float4* __restrict__ coef, const float* __restrict__ shift) {
     const int c = blockIdx.x, C = 2 * Cs;
+    // shift[c]: a per-channel constant the producer left OUT of the stored tensor (the convolution's bias: BatchNorm cancels it, and
+    // a bias 50x the signal would cost the bf16 tensor 5-6 of its 8 mantissa bits).  y_reference = y_stored + shift: the
+    // normalisation is unchanged, the running mean tracks mean + shift, the inference mean is running_mean - shift.
+    const float sh = shift ? shift[c] : 0.f;
     const int half = c / Cs, i = c - half * Cs;
     if (i >= Cr) {
         if (threadIdx.x == 0) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,12 +134,12 @@ __global__ void rbn_finalize_kernel(const float* __restrict__ part, int nblk, co
         double v = a[1] / n - m * m;
         if (v < 0.0) v = 0.0;
         mean = (float)m; var = (float)v;
-        rm[i] = rmo + momentum * (mean - rmo);
+        rm[i] = rmo + momentum * (mean + sh - rmo);
         rv[i] = rvo + momentum * ((float)(v * n / (n - 1.0)) - rvo);   // nn.BatchNorm2d: running_var takes the UNBIASED variance
         if (i == 0) { long* nb = half ? nbt_im : nbt_re; if (nb) nb[0] += 1; }
     } else {
         if (threadIdx.x != 0) return;
-        mean = rmo; var = rvo;
+        mean = rmo - sh; var = rvo;
     }
     const float rstd = 1.f / sqrtf(var + eps);
     coef[c] = make_float4(w * rstd, b - mean * w * rstd, mean, rstd);
@@ -302,15 +306,22 @@ extern "C" int sehip_rbn_stats(const void* y, long rows, int Cs, int Cr, float* 
     return 0;
 }
 
-extern "C" int sehip_rbn_finalize(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im,
-                                  float* rm_re, float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows,
-                                  int Cs, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
+extern "C" int sehip_rbn_finalize_s(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im,
+                                    float* rm_re, float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows,
+                                    int Cs, int Cr, float eps, float momentum, int training, const float* shift, float* coef,
+                                    void* stream) {
     if (int e = check_rbn("rbn_finalize", rows, Cs, Cr)) return e;
     rbn_finalize_kernel<<<2 * Cs, 64, 0, (hipStream_t)stream>>>(part, rbn_stat_blocks(rows, 2 * Cs), w_re, b_re, w_im, b_im, rm_re, rv_re,
                                                              rm_im, rv_im, nbt_re, nbt_im, rows, Cs, Cr, eps, momentum, training,
-                                                             (float4*)coef);
+                                                             (float4*)coef, shift);
     SEHIP_CHECK_LAUNCH("rbn_finalize");
     return 0;
+}
+extern "C" int sehip_rbn_finalize(const float* part, const float* w_re, const float* b_re, const float* w_im, const float* b_im,
+                                  float* rm_re, float* rv_re, float* rm_im, float* rv_im, long* nbt_re, long* nbt_im, long rows,
+                                  int Cs, int Cr, float eps, float momentum, int training, float* coef, void* stream) {
+    return sehip_rbn_finalize_s(part, w_re, b_re, w_im, b_im, rm_re, rv_re, rm_im, rv_im, nbt_re, nbt_im, rows, Cs, Cr, eps, momentum,
+                                training, nullptr, coef, stream);
 }
 
 extern "C" int sehip_rbn_apply(const void* y, const float* coef, long rows, int Cs, int Cr, void* z, void* stream) {

@@ -106,8 +106,10 @@ class DeviceBatcher:
         if self.mode:
             call("sehip_wav_row_stats", ptr(raw), ptr(d_off), R, ptr(stats), stream())
         out = torch.empty((n_mix + n_src) * self.seg, dtype=torch.float32, device=dev)
-        call("sehip_wav_collate", ptr(raw), ptr(d_off), ptr(torch.from_numpy(out_row).to(dev)), ptr(torch.from_numpy(out_start).to(dev)),
-             ptr(torch.from_numpy(out_valid).to(dev)), ptr(stats), self.mode, EPS, self.seg, n_mix + n_src, ptr(out), stream())
+        # (named, so that the three index tables stay allocated until the launch has been enqueued behind their copies)
+        d_row, d_start, d_valid = torch.from_numpy(out_row).to(dev), torch.from_numpy(out_start).to(dev), torch.from_numpy(out_valid).to(dev)
+        call("sehip_wav_collate", ptr(raw), ptr(d_off), ptr(d_row), ptr(d_start), ptr(d_valid), ptr(stats), self.mode, EPS, self.seg,
+             n_mix + n_src, ptr(out), stream())
         mixture = out[:n_mix * self.seg].view(G, C, self.seg)
         sources = out[n_mix * self.seg:].view(G, S, C, self.seg)
         zero = 0
