@@ -205,8 +205,8 @@ typedef struct {
      * source frames t + cv2_t0 + 0..cv2_nkt-1 (both sources), row taps at rows j + cv2_fadd + 0..cv2_nf-1.  cv2_nkt == 0: absent. */
     int32_t cv2_nkt, cv2_nf, cv2_fadd, cv2_t0;
     /* 1: W is stored in the tile order of the LDS-DMA convolution kernel (conv_gemm_v3) instead of [Npad][K]: for output tile
-     * nt (128 columns), 16-channel chunk ch of the concatenated sources and tap pair j (taps 2j, 2j + 1 of the K order above)
-     * one contiguous 8 KB block [2 taps][128 n][16 channels] at element ((nt * (Ctot / 16) + ch) * cv_nf + j) * 4096 -- every
+     * nt (128 columns; 64 when Npad is not a multiple of 128), 16-channel chunk ch of the concatenated sources and tap pair j (taps 2j, 2j + 1 of the K order above)
+     * one contiguous block [2 taps][128 (64) n][16 channels] at element ((nt * (Ctot / 16) + ch) * cv_nf + j) * 4096 (2048) -- every
      * LDS-DMA instruction then reads 1 KB of whole cache lines.  Only that kernel reads such a W: sehip_gemm fails loudly when
      * the descriptor does not qualify for it. */
     int32_t w_tiled;

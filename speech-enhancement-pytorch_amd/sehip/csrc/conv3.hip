@@ -4,7 +4,8 @@
 // What bounded conv_gemm_v2 (round 2: 0.26 of the dense bf16 MFMA peak): 64 x 64 wave tiles (16 fragment reads per 32 MFMAs),
 // a 32-channel input patch staged through registers with ds_write_b128 and a ~3 200-cycle stall at every chunk boundary,
 // 16 KB of weights per 2.1 MFLOP.  Here, per 256-thread workgroup (two per CU), tile = 256 rows x 128 output channels:
-//   * 4 waves as 2 (m) x 2 (n), wave tile 128 rows x 64 channels = 8 x 4 MFMA tiles (16x16x32 bf16): 12 fragment reads per 32
+//   * 4 waves as 2 (m) x 2 (n), wave tile 128 rows x 64 channels = 8 x 4 MFMA tiles (16x16x32 bf16; 192-row and 64-column
+//     variants for under-filled grids / 64-output layers): 12 fragment reads per 32
 //     MFMAs, one barrier per 32 MFMAs, 8 KB of weights + ~4 KB of patch per 2.1 MFLOP;
 //   * K runs over 16-channel chunks; an MFMA's k = 32 is (tap pair) x (16 channels): k group g = lane >> 4 is tap 2j + (g >> 1),
 //     8-channel piece g & 1, for the weight AND the activation operand -- every LDS row is 32 bytes, and 16 rows x 32 B is
@@ -78,34 +79,37 @@ __device__ __forceinline__ void c3_wait_vm() {
 }
 
 // DMA instructions issued behind the youngest item step (.., j) needs (its weight tile, and the patch buffer when j == 0):
-// per step [weight tile s + 3: 2], then at j == 0 [next chunk's patch: MAXP]
-template <int H, int MAXP>
+// per step [weight tile s + 3: DW], then at j == 0 [next chunk's patch: MAXP]
+template <int H, int MAXP, int DW>
 constexpr int c3_count(int j) {
-    if (j == 0 && H <= 3) return 2 * (H - 1);
-    int n = 4;
+    if (j == 0 && H <= 3) return DW * (H - 1);
+    int n = 2 * DW;
     for (int back = 1; back <= 3; ++back)
         if (((j - back) % H + H) % H == 0) n += MAXP;
     return n;
 }
 
-template <int H, int MAXP>
+template <int H, int MAXP, int DW>
 __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constant after unrolling: the switch folds
     switch (j) {
-        case 0: c3_wait_vm<c3_count<H, MAXP>(0)>(); break;
-        case 1: c3_wait_vm<c3_count<H, MAXP>(1)>(); break;
-        case 2: c3_wait_vm<c3_count<H, MAXP>(2)>(); break;
-        case 3: c3_wait_vm<c3_count<H, MAXP>(3)>(); break;
-        default: c3_wait_vm<c3_count<H, MAXP>(4)>(); break;
+        case 0: c3_wait_vm<c3_count<H, MAXP, DW>(0)>(); break;
+        case 1: c3_wait_vm<c3_count<H, MAXP, DW>(1)>(); break;
+        case 2: c3_wait_vm<c3_count<H, MAXP, DW>(2)>(); break;
+        case 3: c3_wait_vm<c3_count<H, MAXP, DW>(3)>(); break;
+        default: c3_wait_vm<c3_count<H, MAXP, DW>(4)>(); break;
     }
 }
 
 // ABL: ablation builds for tools/ (never launched by the product path unless SEHIP_C3_ABL is set): 1 = no DMA inside the loop,
 // 2 = no MFMA, 4 = no fragment reads
-template <int NF, int FM, int J, int TM, int ABL = 0>
+// TN = 16-column MFMA tiles per wave: 4 -> 128 output channels per workgroup, 2 -> 64 (the layers with 64 outputs)
+template <int NF, int FM, int J, int TM, int TN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B) {
     using G = C3Geo<NF, FM, J, TM>;
     constexpr int TB = G::TB, S = G::S, P1 = G::P1, FR = G::FR, H = NF, MAXP = G::MAXP, NPIECE = G::NPIECE, PBYTES = G::PBYTES;
-    constexpr int TN = 4;
+    constexpr int BN = 32 * TN;                       // output channels per workgroup (2 N-waves x TN x 16)
+    constexpr int DW = TN / 2;                        // weight-tile DMA instructions per wave and K step: BN rows x 2 taps x 32 B
+    constexpr int WPL = BN * 32;                      // bytes of one tap plane of a weight tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* pbuf = smem + C3_RING;
     unsigned char* dump = pbuf + 2 * PBYTES;
@@ -114,14 +118,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
-    const int ntn = d.Npad >> 7;
+    const int ntn = d.Npad / BN;
     const int TV = d.TT + 2;
     const int nwg = gridDim.x;
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     const int nt = logical % ntn, mt = logical / ntn;
-    const int g0 = mt * TB, n0 = nt * 128;
+    const int g0 = mt * TB, n0 = nt * BN;
     const int f0 = d.cv_fadd;
 
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
@@ -183,18 +187,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     const bool tiled = d.w_tiled != 0;
     const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;     // tile order: the n-tile's K * 128 elements
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(Wb), 0, C3_RECORDS, 0x00020000);
-    const unsigned woff = 2u * (tiled ? (unsigned)(wave * 512 + lane * 8) : (unsigned)((wave * 32 + (lane >> 1)) * d.K + (lane & 1) * 8));
-    const int wstep_u = 2 * (tiled ? 2048 : Ctot);
+    // piece i = 256 u + 64 wave + lane of a tile: tap plane i / (2 BN), row (i / 2) % BN, half i & 1
+    // (two named registers, not an array: hipcc's host pass silently dropped the whole kernel when a lambda passed an element of a
+    //  captured array to the buffer-load builtin -- no diagnostic, undefined kernel symbol at load time)
+    auto woff_of = [&](int u) {
+        const int i = 256 * u + 64 * wave + lane;
+        const int pl = i / (2 * BN), n = (i >> 1) % BN;
+        return 2u * (tiled ? (unsigned)(i * 8) : (unsigned)(n * d.K + pl * Ctot + (i & 1) * 8));
+    };
+    const unsigned woff0 = woff_of(0), woff1 = woff_of(DW - 1);
     auto issue_w = [&](int ch, int j, int slot) {
-        const int soff = 2 * (tiled ? (ch * H + j) * 4096 : 2 * j * Ctot + ch * 16);
+        const int soff = 2 * (tiled ? (ch * H + j) * (2 * BN * 16) : 2 * j * Ctot + ch * 16);
         unsigned char* dst = smem + slot * C3_WSLOT + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)dst, 16, woff, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + 4096), 16, woff, soff + wstep_u, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)dst, 16, woff0, soff, 0, 0);
+        if (DW > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + 4096), 16, woff1, soff, 0, 0);
     };
 
     // ---- fragment addresses
     const int g = lane >> 4, c = lane & 15;
-    const int wrd = (g >> 1) * 4096 + (wn * 64 + c) * 32 + (g & 1) * 16;        // + ni * 512
+    const int wrd = (g >> 1) * WPL + (wn * (16 * TN) + c) * 32 + (g & 1) * 16;     // + ni * 512
     int vbase;
     {
         int tl, jl;
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         const int cc = s / H, jj = s % H;
         issue_w(cc < nch ? cc : 0, jj, s);
     }
-    c3_wait_step<H, MAXP>(0);
+    c3_wait_step<H, MAXP, DW>(0);
     __builtin_amdgcn_s_barrier();
     int slot = 0;
     for (int ch = 0; ch < nch; ++ch) {
@@ -280,12 +291,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             }
             if (!(ABL & 6)) {
                 __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                       // DS reads
-                if (j == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2 + MAXP, 0);          // the DMAs
-                else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (j == 0) __builtin_amdgcn_sched_group_barrier(0x020, DW + MAXP, 0);         // the DMAs
+                else __builtin_amdgcn_sched_group_barrier(0x020, DW, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TN * (TM - 1), 0);                 // MFMAs
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else c3_wait_step<H, MAXP>((j + 1) % H);
+            if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else c3_wait_step<H, MAXP, DW>((j + 1) % H);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -302,18 +313,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int WROWS = 16 * TM, WCOLS = 64, TP = WCOLS + 8;
+    constexpr int WROWS = 16 * TM, WCOLS = 16 * TN, TP = WCOLS + 8, PPR = WCOLS / 8, RPI = 64 / PPR;   // 16-byte pieces per row, rows per store trip
     const int nw0 = n0 + wn * WCOLS;
     sehip_nchunk first = d.ntab[nw0 >> 2];
     bool dense;
     {
-        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + (lane & 15)];
-        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * (lane & 15);
+        const int qc = (lane & 15) % (WCOLS / 4);
+        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + qc];
+        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * qc;
         dense = __all(ok) && !(first.dst ? d.dst[1].is_f32 : d.dst[0].is_f32) && ((first.coff & 7) == 0) &&
                 (((first.dst ? d.dst[1].C : d.dst[0].C) & 7) == 0);
     }
     bool with_stats = false;
-    if (d.stats) {
+    if (d.stats && TN == 4) {
         int* flag = reinterpret_cast<int*>(smem + 4 * (WROWS * TP * 2));
         if (lane == 0) flag[wave] = dense ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -393,15 +405,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
         const bf16_raw* rptr = (d.res && first.dst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + first.coff : nullptr;
         const int tsz = dd.F * dd.C, bsz = dd.T * dd.F * dd.C, jsz = dd.fmul * dd.C;
-        const int base0 = (dd.toff * dd.F + dd.fadd) * dd.C + (lane & 7) * 8;
+        const int base0 = (dd.toff * dd.F + dd.fadd) * dd.C + (lane % PPR) * 8;
 #pragma unroll
-        for (int itr = 0; itr < WROWS / 8; ++itr) {
-            const int row = itr * 8 + (lane >> 3);
+        for (int itr = 0; itr < WROWS / RPI; ++itr) {
+            const int row = itr * RPI + lane / PPR;
             int tl, jl;
             c3_row<J, TM>(wm, row, tl, jl);
             const int gv = g0 + tl;
             const int b = gv / TV, t = gv - b * TV;
-            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + (lane & 7) * 8]);
+            uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + (lane % PPR) * 8]);
             if (b < B && t < d.TT) {
                 const int off = b * bsz + t * tsz + jl * jsz + base0;
                 if (rptr) {
@@ -466,28 +478,32 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     }
 }
 
-template <int NF, int FM, int J, int TM>
+template <int NF, int FM, int J, int TM, int TN>
 static size_t c3_lds_bytes() {
     using G = C3Geo<NF, FM, J, TM>;
-    const size_t epi = 4 * (16 * TM * 72 * 2) + 64;
+    const size_t epi = 4 * (16 * TM * (16 * TN + 8) * 2) + 64;
     return (size_t)G::LDS_MAIN > epi ? (size_t)G::LDS_MAIN : epi;
 }
-template <int NF, int FM, int J, int TM>
-static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
+template <int NF, int FM, int J, int TM, int TN>
+static void c3_set_attr() {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM, TN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d>", NF, FM, J, TM);
-    conv_gemm_v3_kernel<NF, FM, J, TM><<<grid, 256, c3_lds_bytes<NF, FM, J, TM>(), st>>>(d, B);
+}
+template <int NF, int FM, int J, int TM, int TN>
+static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
+    c3_set_attr<NF, FM, J, TM, TN>();
+    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d, %d, 0>", NF, FM, J, TM, TN);
+    conv_gemm_v3_kernel<NF, FM, J, TM, TN><<<grid, 256, c3_lds_bytes<NF, FM, J, TM, TN>(), st>>>(d, B);
 }
 template <int J, int ABL>
 static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    conv_gemm_v3_kernel<5, 2, J, 8, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8>(), st>>>(d, B);
+    conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8, 4>(), st>>>(d, B);
 }
 // Rows per tile: 256 (TM 8) or 192 (TM 6).  Tiles run two per CU (512 slots).  Measured at the headline shapes (B (T + 2) = 10400
 // frames): where 256-row tiles do not even fill one round (326 tiles) 192-row tiles (434) take 10-15 % less time; from 650 tiles
@@ -502,9 +518,10 @@ static int c3_pick_tm(long vframes, int J, int ntn) {
 template <int NF, int FM>
 static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     const long vframes = (long)B * (d.TT + 2);
-    const int ntn = d.Npad / 128;
+    const int BN = (d.Npad & 127) ? 64 : 128;             // 64-column tiles only for the layers whose width is not a multiple of 128
+    const int ntn = d.Npad / BN;
     static const int abl = getenv("SEHIP_C3_ABL") ? atoi(getenv("SEHIP_C3_ABL")) : 0;     // tools/ only: timing ablations, wrong results
-    if (abl && NF == 5 && (d.J == 4 || d.J == 8)) {
+    if (abl && NF == 5 && BN == 128 && (d.J == 4 || d.J == 8)) {
         const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * ntn;
 #define C3_ABL(A_) case A_: if (d.J == 4) c3_launch_abl<4, A_>(d, B, grid, st); else c3_launch_abl<8, A_>(d, B, grid, st); return 1;
         switch (abl) { C3_ABL(1) C3_ABL(2) C3_ABL(3) C3_ABL(4) C3_ABL(5) C3_ABL(6) C3_ABL(8) C3_ABL(14) default: break; }
@@ -514,7 +531,11 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
 #define C3_CASE(J_)                                                                                       \
     case J_: {                                                                                            \
         const int TB = 32 * tm / J_, grid = (int)((vframes + TB - 1) / TB) * ntn;                         \
-        if (tm == 8) c3_launch<NF, FM, J_, 8>(d, B, grid, st); else c3_launch<NF, FM, J_, 6>(d, B, grid, st); \
+        if (BN == 128) {                                                                                  \
+            if (tm == 8) c3_launch<NF, FM, J_, 8, 4>(d, B, grid, st); else c3_launch<NF, FM, J_, 6, 4>(d, B, grid, st); \
+        } else {                                                                                          \
+            if (tm == 8) c3_launch<NF, FM, J_, 8, 2>(d, B, grid, st); else c3_launch<NF, FM, J_, 6, 2>(d, B, grid, st); \
+        }                                                                                                 \
         return 1;                                                                                         \
     }
     switch (d.J) {
@@ -530,7 +551,8 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
     if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
     if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
-    if ((C0 & 15) || (C1 & 15) || (d.Npad & 127)) return 0;
+    if ((C0 & 15) || (C1 & 15) || (d.Npad & 63)) return 0;
+    if (d.stats && (d.Npad & 127)) return 0;
     if (d.J != 4 && d.J != 8 && d.J != 16 && d.J != 32) return 0;
     if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
     if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return 0;
@@ -553,12 +575,13 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
     return 0;
 }
 
+template <int NF, int FM, int J, int TM, int TN>
+static void c3_init_k() {
+    c3_set_attr<NF, FM, J, TM, TN>();
+}
 template <int NF, int FM, int J>
 static void c3_init_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              80 * 1024);
+    c3_init_k<NF, FM, J, 8, 4>(); c3_init_k<NF, FM, J, 6, 4>(); c3_init_k<NF, FM, J, 8, 2>(); c3_init_k<NF, FM, J, 6, 2>();
 }
 template <int NF, int FM>
 static void c3_init_nf() {

@@ -325,7 +325,9 @@ class GemmSpec:
         """(C0, C1) of the sources when conv_gemm_v3 (csrc/conv3.hip, sehip_try_conv_gemm_v3) takes this product, else None:
         regular convolution with (taps, row stride) in {(5, 2), (3, 1), (2, 1)}, 4 / 8 / 16 / 32 rows per frame, 16-multiple
         source channels, 128-multiple outputs, frame offsets within one frame of each other."""
-        if self.conv is None or self.kind == "wgrad_only" or self.Npad % 128 or self.J not in (4, 8, 16, 32):
+        if self.conv is None or self.kind == "wgrad_only" or self.Npad % 64 or self.J not in (4, 8, 16, 32):
+            return None
+        if self.stats_of is not None and self.Npad % 128:
             return None
         nf, _, toff = self.conv
         if (nf, self.fmul) not in ((5, 2), (3, 1), (2, 1)):
@@ -340,14 +342,15 @@ class GemmSpec:
 
     def tile_weights(self):
         """Moves the packed weights [Npad][K] (K ordered (tap, concatenated channel)) into the tile order conv_gemm_v3 streams:
-        [n tile][16-channel chunk][tap pair][tap of the pair][128 n][16 channels]; a pure permutation of the packing table."""
+        [n tile][16-channel chunk][tap pair][tap of the pair][128 (or 64) n][16 channels]; a pure permutation of the packing table."""
         cs = self.v3_channels()
         assert cs is not None and not self.w_tiled
         nf, ctot = self.conv[0], cs[0] + cs[1]
-        ntn, nch = self.Npad // 128, ctot // 16
+        bn = 64 if self.Npad % 128 else 128                  # the kernel's column tile
+        ntn, nch = self.Npad // bn, ctot // 16
 
         def perm(a):
-            a = a.reshape(ntn, 128, nf, 2, nch, 16)           # [nt][n][j][u][ch][c]   (tap index = 2 j + u)
+            a = a.reshape(ntn, bn, nf, 2, nch, 16)            # [nt][n][j][u][ch][c]   (tap index = 2 j + u)
             return a.transpose(0, 4, 2, 3, 1, 5).reshape(self.Npad, self.K)
         self.widx_packed, self.wneg_packed = perm(self.widx), perm(self.wneg)
         self.w_tiled = True
