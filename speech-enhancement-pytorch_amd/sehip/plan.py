@@ -818,6 +818,7 @@ class DCCRNWorkspace:
     def _bind(self):
         st, tb, B, T = self.st, self.tb, self.B, self.T
         self.desc = {}
+        self._wgrad_on_chain = set((os.environ.get("SEHIP_WGRAD_ON_CHAIN", "") or "").split(",")) - {""}
         self._chunk_cache = {}
         self._wg_groups = {}
         # chunk table bound to this workspace's source geometry: [src, (toff<<16)|(fadd&0xffff), element delta, npieces]
@@ -944,7 +945,10 @@ class DCCRNWorkspace:
         four hh products, and every event record costs the chain a bubble; backward() joins the two streams before the
         gradients are un-packed."""
         main = torch.cuda.current_stream()
-        if self.side is None:
+        if self.side is None or name in self._wgrad_on_chain:
+            # (SEHIP_WGRAD_ON_CHAIN=enc0.fwd,...: named weight gradients on the chain's own stream.  Measured in round 3 for the last
+            #  one / two / three of the backward pass, whose side-stream backlog the chain waits 88 us for: 4.23-4.29 ms per step
+            #  against 4.23-4.25 without -- no gain, off by default)
             call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), main.cuda_stream)
             return
         if self._chain_dirty:
