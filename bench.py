@@ -96,6 +96,11 @@ def gemm_roofline(ws, reps=5):
         flops = 2.0 * d.M * _weight_entries(ws, name)   # algorithmic: padding channels / padded K columns do not count
         call(fn, C.byref(d), stream())
         kname = lib().sehip_last_kernel().decode()
+        if kname.startswith("conv_gemm_v3_kernel<"):
+            # one class per (taps, row stride): the instantiations by rows per frame / tile rows / tile columns are the same code
+            # (csrc/conv3.hip), picked per layer shape -- the successor of round 2's conv_gemm_v2_kernel<taps, ...> classes
+            a = kname[len("conv_gemm_v3_kernel<"):].split(",")
+            kname = f"conv_gemm_v3_kernel<{a[0].strip()}, {a[1].strip()}, *>"
         torch.cuda.synchronize()
         times = []
         for _ in range(reps):

@@ -36,18 +36,29 @@ def stored_channels(c):
 def dcunet_tables(model_complexity, model_depth, audio_channels):
     """Channel / kernel / stride / padding tables of the reference (src/model/dcunet.py:165-307), (time, frequency) pairs."""
     mc = model_complexity
-    if model_depth != 10:
-        raise SehipError(f"sehip DCUnet: model_depth={model_depth}: only the depth-10 network is built")
-    enc_ch = [audio_channels, mc, mc * 2, mc * 2, mc * 2, mc * 2]
-    enc_k = [(7, 5), (7, 5), (5, 3), (5, 3), (5, 3)]
-    enc_s = [(2, 2), (2, 2), (2, 2), (2, 2), (2, 1)]
-    enc_p = [(2, 1), None, None, None, None]
-    enc_p = [tuple((k - 1) // 2 for k in ks) if p is None else p for ks, p in zip(enc_k, enc_p)]   # 'SAME' (:12-13)
-    dec_ch = [0, mc * 2, mc * 2, mc * 2, mc * 2, mc * 2]
-    dec_k = [(4, 3), (4, 4), (6, 4), (6, 4), (7, 5)]
-    dec_s = [(2, 1), (2, 2), (2, 2), (2, 2), (2, 2)]
-    dec_p = [(1, 1), (1, 1), (2, 1), (2, 1), (2, 1)]
-    return dict(n=5, enc_ch=enc_ch, enc_k=enc_k, enc_s=enc_s, enc_p=enc_p, dec_ch=dec_ch, dec_k=dec_k, dec_s=dec_s, dec_p=dec_p)
+    same = lambda ks, ps: [tuple((k - 1) // 2 for k in kk) if p is None else p for kk, p in zip(ks, ps)]   # 'SAME' (:12-13)
+    if model_depth == 10:
+        enc_ch = [audio_channels, mc, mc * 2, mc * 2, mc * 2, mc * 2]
+        enc_k = [(7, 5), (7, 5), (5, 3), (5, 3), (5, 3)]
+        enc_s = [(2, 2), (2, 2), (2, 2), (2, 2), (2, 1)]
+        enc_p = same(enc_k, [(2, 1), None, None, None, None])
+        dec_ch = [0, mc * 2, mc * 2, mc * 2, mc * 2, mc * 2]
+        dec_k = [(4, 3), (4, 4), (6, 4), (6, 4), (7, 5)]
+        dec_s = [(2, 1), (2, 2), (2, 2), (2, 2), (2, 2)]
+        dec_p = [(1, 1), (1, 1), (2, 1), (2, 1), (2, 1)]
+    elif model_depth == 20:      # src/model/dcunet.py:215-305
+        enc_ch = [audio_channels, mc, mc] + [mc * 2] * 7 + [128]
+        enc_k = [(7, 1), (1, 7), (6, 4), (7, 5)] + [(5, 3)] * 6
+        enc_s = [(1, 1), (1, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1)]
+        enc_p = same(enc_k, [(3, 0), (0, 3)] + [None] * 8)
+        dec_ch = [0] + [mc * 2] * 11
+        dec_k = [(4, 3), (4, 2), (4, 3), (4, 2), (4, 3), (4, 2), (6, 3), (7, 5), (1, 7), (7, 1)]
+        dec_s = [(2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (1, 1), (1, 1)]
+        dec_p = [(1, 1), (1, 0), (1, 1), (1, 0), (1, 1), (1, 0), (2, 1), (2, 1), (0, 3), (3, 0)]
+    else:
+        raise SehipError(f"Unknown model depth : {model_depth}")
+    return dict(n=model_depth // 2, enc_ch=enc_ch, enc_k=enc_k, enc_s=enc_s, enc_p=enc_p, dec_ch=dec_ch, dec_k=dec_k, dec_s=dec_s,
+                dec_p=dec_p)
 
 
 class DCUNetConfig:
@@ -66,9 +77,9 @@ class DCUNetConfig:
         self.audio_channels, self.model_depth, self.masking_mode = audio_channels, model_depth, masking_mode
         self.model_complexity = int(model_complexity // 1.414)          # src/model/dcunet.py:64-65
         self.tab = dcunet_tables(self.model_complexity, model_depth, audio_channels)
-        if stored_channels(2 * self.model_complexity) > 64:
+        if stored_channels(max(self.tab["enc_ch"][1:] + self.tab["dec_ch"][1:])) > 128:
             raise SehipError(f"sehip DCUnet: model_complexity {model_complexity} gives {2 * self.model_complexity} complex channels; "
-                             "up to 64 are built")
+                             "up to 128 are built")
 
     def key(self):
         return (self.model_complexity, self.model_depth, self.masking_mode)
@@ -184,7 +195,7 @@ class DCUNetPlan:
             want = self.enc_dims[n - 2 - j] if j < n - 1 else (T0, F0)
             if (T, F) != want:
                 raise SehipError(f"DCUnet: decoder {j} produces {T} x {F} (frames x bins) but its skip connection / the input is "
-                                 f"{want[0]} x {want[1]}: the depth-10 network needs 257 bins and frames = 1 mod 32 "
+                                 f"{want[0]} x {want[1]}: the depth-10 network needs 257 bins and frames = 1 mod 32, depth 20 frames = 1 mod 16 "
                                  f"(got {F0} bins x {T0} frames)")
         self.specs = {}
         self.bn = []       # (prefix, buffer tag, Cs, Cr)
