@@ -78,7 +78,7 @@ __device__ __forceinline__ void rbn_wave_reduce(const float* __restrict__ part, 
 }
 
 __global__ __launch_bounds__(256) void rbn_stats_kernel(const bf16_raw* __restrict__ y, long rows, int C, float* __restrict__ part) {
-    __shared__ float lds[4 * 2 * 8 * 16];
+    __shared__ float lds[4 * 2 * 8 * 32];        // [4 waves][NS * 8][nq <= 32]
     const int nq = C >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     float s[2][8];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void rbn_apply_kernel(const bf16_raw* __restri
 __global__ __launch_bounds__(256) void rbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
                                                              const float4* __restrict__ coef, long rows, int C,
                                                              float* __restrict__ part) {
-    __shared__ float lds[4 * 2 * 8 * 16];
+    __shared__ float lds[4 * 2 * 8 * 32];        // [4 waves][NS * 8][nq <= 32]
     const int nq = C >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
     float4 k[8];
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void rbn_bwd_apply_kernel(const bf16_raw* __re
 // ---------------------------------------------------------------------------------------------
 static int check_rbn(const char* who, long rows, int Cs, int Cr) {
     SEHIP_REQUIRE(rows > 1, "%s: BatchNorm needs more than one value per channel (rows=%ld)", who, rows);
-    SEHIP_REQUIRE(Cs >= 8 && Cs <= 64 && (Cs & (Cs - 1)) == 0, "%s: stored channels per half Cs=%d must be 8, 16, 32 or 64", who, Cs);
+    SEHIP_REQUIRE(Cs >= 8 && Cs <= 128 && (Cs & (Cs - 1)) == 0, "%s: stored channels per half Cs=%d must be 8, 16, 32, 64 or 128", who, Cs);
     SEHIP_REQUIRE(Cr >= 1 && Cr <= Cs, "%s: Cr=%d must be in [1, Cs=%d]", who, Cr, Cs);
     return 0;
 }
