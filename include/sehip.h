@@ -127,6 +127,17 @@ int sehip_grad_sumsq_acc(const float* grads, long n, double* sumsq_out, void* st
 int sehip_grad_metric_acc(const float* grads, const long* offsets, int ntensors, long max_tensor_numel, const double* sumsq,
                           float* tensor_sums, float* metric, void* stream);
 
+/* ---- data-parallel gradient exchange: RCCL over xGMI directly behind the C ABI (one process per GPU; replaces the reference's
+ *      single-process nn.DataParallel, src/solver.py:144-145).  librccl is loaded on first use.
+ *      comm_unique_id: rank 0 fills 128 bytes (ncclGetUniqueId) and shares them with the other ranks by any means
+ *      comm_init:      ncclCommInitRank on the CURRENT HIP device -> opaque communicator
+ *      allreduce_f32:  in-place SUM of buf[0 .. n) over the ranks, enqueued on `stream` (the step exchanges ranges of the flat fp32
+ *                      gradient buffer as the backward pass finishes them; 1/world is folded into sehip_opt_step's grad_scale) */
+int sehip_comm_unique_id(void* id128);
+int sehip_comm_init(const void* id128, int world, int rank, void** comm_out);
+int sehip_allreduce_f32(void* comm, float* buf, long n, void* stream);
+int sehip_comm_destroy(void* comm);
+
 /* ---- implicit-GEMM engine (bf16 MFMA, fp32 accumulate) used for
  *        ComplexConv2d            src/model/dccrn.py:316-384      (fwd, dgrad, wgrad)
  *        ComplexConvTranspose2d   src/model/dccrn.py:387-450      (fwd incl. complex_cat :304-314 and the frame

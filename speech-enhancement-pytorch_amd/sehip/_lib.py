@@ -37,6 +37,10 @@ _PROTOS = {
     "sehip_stft_custom_frames": [I, I, I, I],
     "sehip_stft_custom_fwd": [P, I, I, I, I, I, I, P, P],
     "sehip_istft_custom_fwd": [P, I, I, I, I, I, I, I, P, P, P],
+    "sehip_comm_unique_id": [P],
+    "sehip_comm_init": [P, I, I, P],
+    "sehip_allreduce_f32": [P, P, L, P],
+    "sehip_comm_destroy": [P],
     "sehip_wav_row_stats": [P, P, I, P, P],
     "sehip_wav_collate": [P, P, P, P, P, P, I, F, I, I, P, P],
     "sehip_sisnr_fwd": [P, P, I, I, P, P, P],

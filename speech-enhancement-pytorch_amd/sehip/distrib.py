@@ -73,13 +73,67 @@ def init_distributed(backend=None):
     backend = backend or os.environ.get("SEHIP_DIST_BACKEND")
     if "SEHIP_LOCAL_DEVICE" in os.environ:
         local = int(os.environ["SEHIP_LOCAL_DEVICE"])
+    direct = backend == "sehip-rccl"
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if direct else backend, rank=rank, world_size=world)
+    if direct:
+        global _direct
+        if _direct is None:
+            _direct = DirectComm(rank, world, torch.device("cuda", local))
     return rank, world, local
+
+
+class DirectComm:
+    """The gradient exchange through libsehip's own RCCL entry points (sehip_comm_init / sehip_allreduce_f32, include/sehip.h)
+    instead of torch.distributed's collectives: selected with SEHIP_DIST_BACKEND=sehip-rccl.  torch.distributed (gloo) then only
+    carries the control plane: the 128-byte RCCL id from rank 0, barriers, the epoch score."""
+
+    def __init__(self, rank, world, device):
+        import ctypes as C
+        from ._lib import call
+        self.rank, self.world, self.device = rank, world, device
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            call("sehip_comm_unique_id", ident.data_ptr())
+        if world > 1:
+            dist.broadcast(ident, 0)
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            call("sehip_comm_init", ident.data_ptr(), world, rank, C.byref(h))
+        self.handle = h
+
+    def all_reduce_(self, flat, lo=0, hi=None, stream=None):
+        """in-place SUM of flat[lo:hi] (fp32, contiguous) on `stream` (torch.cuda.Stream; None = current); returns an object whose
+        wait() makes the CURRENT stream wait for the exchange (like a torch.distributed work handle)."""
+        from ._lib import call
+        hi = flat.numel() if hi is None else hi
+        st = stream if stream is not None else torch.cuda.current_stream()
+        call("sehip_allreduce_f32", self.handle, flat.data_ptr() + 4 * lo, hi - lo, st.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(st)
+
+        class _Work:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_event(ev)
+        return _Work()
+
+    def close(self):
+        from ._lib import call
+        if self.handle:
+            call("sehip_comm_destroy", self.handle)
+            self.handle = None
+
+
+_direct = None
+
+
+def direct_comm():
+    """The DirectComm of this process (SEHIP_DIST_BACKEND=sehip-rccl), or None."""
+    return _direct
 
 
 def broadcast_parameters(flat_params, flat_buffers=None, src=0):
@@ -107,7 +161,10 @@ def allreduce_gradients(flat_grads, scale=True):
     Clipping happens after this (src/solver.py:487-490 clips the reduced gradients).  scale=False leaves the SUM: the fused
     optimizer applies 1/world itself (FlatOptimizer.grad_scale, no extra pass over the buffer)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        if _direct is not None and flat_grads.is_cuda:
+            _direct.all_reduce_(flat_grads).wait()
+        else:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
         if scale:
             flat_grads.mul_(1.0 / dist.get_world_size())
     return flat_grads
@@ -118,6 +175,8 @@ def allreduce_range_async(flat_grads, lo, hi, stream=None):
     returns the work handle (.wait() makes the CURRENT stream wait for it).  Used by the Solver to start the exchange of
     the decoder / LSTM gradients while the encoder's backward pass still runs (the reference has no overlap: DataParallel
     reduces during its single backward, src/solver.py:144-145, 485)."""
+    if _direct is not None and flat_grads.is_cuda:
+        return _direct.all_reduce_(flat_grads, lo, hi, stream)
     view = flat_grads[lo:hi]
     if stream is not None and flat_grads.is_cuda:
         with torch.cuda.stream(stream):

@@ -246,3 +246,20 @@ def test_two_ranks_equal_one_rank_with_per_replica_batchnorm(tmp_path):
     ref_g, ref_p = model.flat_grads.cpu(), model.flat_params.cpu()
     assert rel_err(got["grads"], ref_g) < 2e-3                     # fp32 atomics of the weight gradients: run-to-run noise only
     assert max_abs(got["params"], ref_p) < 2.1 * 3e-4 and float((got["params"] - ref_p).abs().mean()) < 0.05 * 3e-4
+
+
+def test_rccl_entry_points_of_the_c_abi_single_rank():
+    """sehip_comm_unique_id / sehip_comm_init / sehip_allreduce_f32 / sehip_comm_destroy (include/sehip.h): a one-rank communicator on
+    this GPU, an in-place SUM of a range of a flat buffer on a side stream (identity at world 1), and sehip.distrib.DirectComm
+    around them.  (RCCL refuses two ranks on ONE device, so the 2-rank path of this backend cannot run on a 1-GPU box; the
+    torch.distributed path is what the 2-rank tests above exercise.)"""
+    from sehip import distrib
+    c = distrib.DirectComm(0, 1, torch.device("cuda:0"))
+    x = torch.arange(1000, dtype=torch.float32, device="cuda")
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    c.all_reduce_(x, 100, 900, side).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    c.close()
