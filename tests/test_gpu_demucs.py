@@ -562,4 +562,45 @@ def test_forced_handoff_timeout_skips_the_step_and_falls_back(tmp_path):
     loss_r, _ = r.train_step(*r._prepare_batch(mix, clean))
     # (not bit-identical: the statistics / weight-gradient accumulators are fp32 / fp64 atomics whose order varies between launches)
     assert abs(float(loss) - float(loss_r)) < 1e-3 * max(1.0, abs(float(loss_r)))
-    assert rel_err(s.model.flat_params.detach().cpu(), r.model.flat_params.detach().cpu()) < 1e-4
+    assert rel_err(s.model.flat_params.detach().cpu(), r.model.flat_params.detach().cpu()) < 1e-3      # (first Adam step = lr * sign(g): a few signs of ~0 gradients differ)
+
+
+def test_gradient_ranges_are_final_while_the_backward_pass_still_runs():
+    """the early ranges of the data-parallel exchange are handed over BEFORE the backward pass ends -- on the device
+    timeline, not in host order.  The full-width network (133.7 M parameters), one clip: every hand-over records an event on the
+    stream it is final on (the third stream for the early ranges), an event closes the backward pass on the chain's stream.  Asserted:
+    at least three ranges, the decoder's (47 % of the parameters) first; every early range's event precedes the end of the
+    backward pass, the first by at least a third of the pass; the early ranges hold more than 70 % of the gradient bytes."""
+    from sehip.model import Demucs
+    torch.manual_seed(0)
+    model = Demucs(sources=["clean"], audio_channels=2).cuda().train()
+    g = torch.Generator().manual_seed(1)
+    mix = (0.1 * torch.randn(1, 2, 24000, generator=g)).cuda()
+    G = torch.randn(1, 1, 2, 24000, generator=g).cuda() / 100
+    for _ in range(2):                                    # warm-up (allocations, first-use initialisation), then the measured pass
+        ranges = []
+
+        def hook(lo, hi, st):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            ranges.append((lo, hi, e))
+        est = model(mix)
+        model.grad_range_hook = hook
+        t0 = torch.cuda.Event(enable_timing=True); t0.record()
+        est.backward(G)
+        t1 = torch.cuda.Event(enable_timing=True); t1.record()
+        model.grad_range_hook = None
+        torch.cuda.synchronize()
+        model.flat_grads.zero_()
+        for _, prm in model._params:
+            prm.grad = None
+        model._grads_live = False
+    n = model.flat_grads.numel()
+    total = t0.elapsed_time(t1)
+    early = ranges[:-1]
+    lead = [e.elapsed_time(t1) for _, _, e in early]      # ms between a range being final and the end of the backward pass
+    share = sum(hi - lo for lo, hi, _ in early) / n
+    print(f"Demucs backward {total:.2f} ms; ranges {[(lo, hi) for lo, hi, _ in ranges]}; final {['%.2f' % v for v in lead]} ms before the end; "
+          f"early share {share:.2f}")
+    assert len(ranges) >= 3 and ranges[0][1] == n and ranges[0][0] == model.static.layout.param_off["decoder.0.0.weight"][0]
+    assert all(v > 0 for v in lead) and lead[0] > total / 3 and share > 0.7
