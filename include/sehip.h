@@ -256,6 +256,10 @@ int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n,
 int sehip_unpack_grad1(const float* packed, const int* table1, long n, float* grads, void* stream);
 int sehip_unpack_grad_list(const float* packed, const int* list, const int* table4, long m, float* grads, void* stream);
 int sehip_pack_bf16_runs(const float* params, const int* runs2 /*[n/8][2]*/, const int* side, long n, void* out_bf16, void* stream);
+/*   pack_bf16_runs_to: the run table in any order (sorted by base address: the lanes of a wave then gather from neighbouring
+ *                     parameters); entry i produces out_base[8 * dst_run[i] + j], dst_run = absolute run numbers */
+int sehip_pack_bf16_runs_to(const float* params, const int* runs2 /*[n/8][2]*/, const int* dst_run /*[n/8]*/, const int* side, long n,
+                            void* out_base, void* stream);
 
 /* ---- ComplexBatchNorm + PReLU: src/model/dccrn.py:457-634 (training branch :549-611, whitening :593-602,
  *      running statistics :555-556,577-579) fused with nn.PReLU() (:79,122).  Activations are [rows][2*Cr] bf16.

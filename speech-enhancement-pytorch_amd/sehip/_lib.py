@@ -77,6 +77,7 @@ _PROTOS = {
     "sehip_unpack_grad1": [P, P, L, P, P],
     "sehip_unpack_grad_list": [P, P, P, L, P, P],
     "sehip_pack_bf16_runs": [P, P, P, L, P, P],
+    "sehip_pack_bf16_runs_to": [P, P, P, P, L, P, P],
     "sehip_cbn_stats": [P, L, I, P, P],
     "sehip_cbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],
     "sehip_cbn_finalize_n": [P, I, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],

@@ -104,7 +104,7 @@ __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constan
 // 2 = no MFMA, 4 = no fragment reads
 // TN = 16-column MFMA tiles per wave: 4 -> 128 output channels per workgroup, 2 -> 64 (the layers with 64 outputs)
 template <int NF, int FM, int J, int TM, int TN, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B, int order) {
     using G = C3Geo<NF, FM, J, TM>;
     constexpr int TB = G::TB, S = G::S, P1 = G::P1, FR = G::FR, H = NF, MAXP = G::MAXP, NPIECE = G::NPIECE, PBYTES = G::PBYTES;
     constexpr int BN = 32 * TN;                       // output channels per workgroup (2 N-waves x TN x 16)
@@ -124,7 +124,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const int nt = logical % ntn, mt = logical / ntn;
+    // tile order.  0 (default): n-tile fastest.  1: the n-tiles of one m-tile 32 logical places apart -- under round-robin dispatch
+    // (blocks b, b + 8, ... on one XCD, its 32 CUs filled in order) the two workgroups of a CU then stream the SAME patch
+    int nt = logical % ntn, mt = logical / ntn;
+    if (order == 1 && ntn > 1) {
+        const int span = 32 * ntn, grp = logical / span, r = logical - grp * span;
+        const int mtiles = nwg / ntn;
+        const int m_ = grp * 32 + (r & 31);
+        if (grp * span + span <= nwg && m_ < mtiles) { nt = r >> 5; mt = m_; }     // (the ragged tail keeps the default order)
+    }
     const int g0 = mt * TB, n0 = nt * BN;
     const int f0 = d.cv_fadd;
 
@@ -478,6 +486,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     }
 }
 
+static int c3_order() {
+    static const int o = getenv("SEHIP_C3_ORDER") ? atoi(getenv("SEHIP_C3_ORDER")) : 0;
+    return o;
+}
 template <int NF, int FM, int J, int TM, int TN>
 static size_t c3_lds_bytes() {
     using G = C3Geo<NF, FM, J, TM>;
@@ -497,13 +509,13 @@ template <int NF, int FM, int J, int TM, int TN>
 static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
     c3_set_attr<NF, FM, J, TM, TN>();
     sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d, %d, 0>", NF, FM, J, TM, TN);
-    conv_gemm_v3_kernel<NF, FM, J, TM, TN><<<grid, 256, c3_lds_bytes<NF, FM, J, TM, TN>(), st>>>(d, B);
+    conv_gemm_v3_kernel<NF, FM, J, TM, TN><<<grid, 256, c3_lds_bytes<NF, FM, J, TM, TN>(), st>>>(d, B, c3_order());
 }
 template <int J, int ABL>
 static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8, 4>(), st>>>(d, B);
+    conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8, 4>(), st>>>(d, B, c3_order());
 }
 // Rows per tile: 256 (TM 8) or 192 (TM 6).  Tiles run two per CU (512 slots).  Measured at the headline shapes (B (T + 2) = 10400
 // frames): where 256-row tiles do not even fill one round (326 tiles) 192-row tiles (434) take 10-15 % less time; from 650 tiles

@@ -503,6 +503,16 @@ class DemucsStatic:
         side = np.ascontiguousarray(self.wtab[:n].reshape(-1, 8)[irr]).reshape(-1)
         if side.size == 0:
             side = np.full(8, -1, dtype=np.int32)
+        # The table is stored sorted by base address inside each separately packed segment (sehip_pack_bf16_runs_to): neighbouring
+        # lanes then read neighbouring parameters.  pack_dst[i] = the run entry i produces.
+        self.pack_dst = np.arange(runs.shape[0], dtype=np.int32)
+        if not os.environ.get("SEHIP_NO_PACK_SORT"):
+            cuts = sorted({0, self.n_wpack_head // 8, self.n_wpack_fwd // 8, self.n_wpack_bwd_head // 8, n // 8})
+            for a, b_ in zip(cuts[:-1], cuts[1:]):
+                key = np.where(runs[a:b_, 0] >= 0, runs[a:b_, 0].astype(np.int64), np.int64(1) << 40)
+                order = np.argsort(key, kind="stable")
+                runs[a:b_] = runs[a:b_][order]
+                self.pack_dst[a:b_] = (order + a).astype(np.int32)
         return runs, side.astype(np.int32)
 
 
@@ -511,6 +521,7 @@ class DemucsDeviceTables:
         f = lambda a: torch.from_numpy(a).to(device)
         self.btab, self.ntab = f(st.btab), f(st.ntab)
         self.runs, self.side = f(st.runs), f(st.side)                  # weight packing: (base, stride) per 8 elements
+        self.pack_dst = f(st.pack_dst)
         self.utab1, self.ulist, self.utab4 = f(st.utab1), f(st.ulist), f(st.utab4 if st.utab4.size else np.full((1, 4), -1, dtype=np.int32))
         self.tensor_offsets = f(st.layout.tensor_offsets)
         self.wpack = torch.zeros(st.n_wpack, dtype=BF16, device=device)
@@ -815,7 +826,8 @@ class DemucsWorkspace:
     def _pack(self, params, lo, hi, on_stream):
         """packed bf16 operands [lo, hi) (multiples of 8) from the flat parameters"""
         tb = self.tb
-        call("sehip_pack_bf16_runs", ptr(params), tb.runs.data_ptr() + lo, ptr(tb.side), hi - lo, tb.wpack.data_ptr() + 2 * lo, on_stream)
+        call("sehip_pack_bf16_runs_to", ptr(params), tb.runs.data_ptr() + lo, tb.pack_dst.data_ptr() + lo // 2, ptr(tb.side), hi - lo,
+             tb.wpack.data_ptr(), on_stream)
 
     def _unpack(self, lo, hi, grads, on_stream):
         """flat parameter gradients [lo, hi) (multiples of 4) from the packed-gradient buffer"""

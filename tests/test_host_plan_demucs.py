@@ -68,13 +68,21 @@ def test_pack_run_descriptors_reproduce_the_index_table(static):
     P, cfg, st = static
     n = st.n_wpack_dev
     want = st.wtab[:n].reshape(-1, 8)
-    runs, side = st.runs, st.side.reshape(-1, 8)
-    got = np.full_like(want, -1)
+    runs, side, dst = st.runs, st.side.reshape(-1, 8), st.pack_dst
+    dec = np.full_like(want, -1)                              # entry i of the (sorted) table ...
     aff = runs[:, 0] >= 0
-    got[aff] = (runs[aff, :1].astype(np.int64) + np.arange(8)[None] * runs[aff, 1:].astype(np.int64)) << 1
+    dec[aff] = (runs[aff, :1].astype(np.int64) + np.arange(8)[None] * runs[aff, 1:].astype(np.int64)) << 1
     irr = runs[:, 0] <= -2
-    got[irr] = side[-2 - runs[irr, 0]]
+    dec[irr] = side[-2 - runs[irr, 0]]
+    got = np.full_like(want, -1)
+    got[dst] = dec                                            # ... produces run dst[i] (sehip_pack_bf16_runs_to)
     assert np.array_equal(got, want)
+    assert np.array_equal(np.sort(dst), np.arange(dst.size))  # a permutation ...
+    for a, b in zip([0, st.n_wpack_head // 8, st.n_wpack_fwd // 8, st.n_wpack_bwd_head // 8],
+                    [st.n_wpack_head // 8, st.n_wpack_fwd // 8, st.n_wpack_bwd_head // 8, n // 8]):
+        assert b == a or (dst[a:b].min() == a and dst[a:b].max() == b - 1)   # ... inside every separately packed segment
+        key = np.where(runs[a:b, 0] >= 0, runs[a:b, 0].astype(np.int64), 1 << 40)
+        assert (np.diff(key) >= 0).all()                      # sorted by base address: neighbouring lanes, neighbouring parameters
     assert aff.mean() > 0.9                                   # the layouts are long regular runs
 
 
