@@ -37,6 +37,10 @@ int sehip_stream_depend(void* to_stream, void* from_stream, void* event);
 /* the same in two halves: `stream`'s work so far is recorded now, another stream waits for it later */
 int sehip_event_record(void* event, void* stream);
 int sehip_stream_wait_event(void* stream, void* event);
+/* a non-blocking stream of a priority class: -1 the device's highest, 0 default, 1 the device's lowest (the weight-gradient
+ * stream: filler work, a freed CU goes to the dependent chain first); NULL on error */
+void* sehip_stream_create(int priority_class);
+int sehip_stream_destroy(void* stream);
 
 /* ---- STFT / iSTFT front-end: src/model/dccrn.py:649-747 (init_kernels, ConvSTFT, ConviSTFT) fused with the
  *      glue of DCCRN.forward src/model/dccrn.py:145-154 and :198-229 (mask E/C/R, clamp).  fft_len must be 512. */

@@ -29,6 +29,8 @@ _PROTOS = {
     "sehip_version": [],
     "sehip_check_device": [I],
     "sehip_event_create": [],
+    "sehip_stream_create": [C.c_int],
+    "sehip_stream_destroy": [P],
     "sehip_event_destroy": [P],
     "sehip_stream_depend": [P, P, P],
     "sehip_event_record": [P, P],
@@ -126,7 +128,7 @@ _PROTOS = {
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p}
+_RESTYPE = {"sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
 
 
 def lib():

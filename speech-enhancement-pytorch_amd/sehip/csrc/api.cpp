@@ -65,6 +65,32 @@ extern "C" int sehip_stream_depend(void* to_stream, void* from_stream, void* eve
     return 0;
 }
 
+// A stream of a given priority class: -1 = the device's highest, 0 = default, 1 = the device's lowest.  The weight-gradient side
+// stream is filler work beside the dependent chain; with the lowest priority the dispatcher hands a freed CU to the chain first.
+extern "C" void* sehip_stream_create(int priority_class) {
+    int least = 0, greatest = 0;
+    hipError_t st = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (st != hipSuccess) {
+        sehip_set_error(-2, "stream_create: priority range: %s", hipGetErrorString(st));
+        return nullptr;
+    }
+    const int prio = priority_class < 0 ? greatest : (priority_class > 0 ? least : 0);
+    hipStream_t s = nullptr;
+    st = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+    if (st != hipSuccess) {
+        sehip_set_error(-2, "stream_create: %s", hipGetErrorString(st));
+        return nullptr;
+    }
+    return (void*)s;
+}
+
+extern "C" int sehip_stream_destroy(void* stream) {
+    if (!stream) return 0;
+    hipError_t st = hipStreamDestroy((hipStream_t)stream);
+    if (st != hipSuccess) return sehip_set_error(-2, "stream_destroy: %s", hipGetErrorString(st));
+    return 0;
+}
+
 // the two halves of sehip_stream_depend, for a dependency that is recorded now and waited for later
 extern "C" int sehip_event_record(void* event, void* stream) {
     if (!event) return sehip_set_error(-1, "event_record: null event");

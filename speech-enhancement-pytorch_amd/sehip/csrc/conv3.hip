@@ -32,12 +32,10 @@ typedef __attribute__((address_space(1))) const void c3_gvoid;
 #define C3_OOB 0x7ffffff0u
 #define C3_RECORDS 0x7fff0000u
 
-#define C3_WSLOT 8192
 #define C3_NSLOT 4
-#define C3_RING (C3_WSLOT * C3_NSLOT)
 
 // geometry of the patch image (tools/c3_census.py: conflict-free frame stride per (row stride, taps, rows per frame))
-template <int NF, int FM, int J, int TM>
+template <int NF, int FM, int J, int TM, int NWN = 2>
 struct C3Geo {
     static constexpr int FR = (J - 1) * FM + NF;                       // patch rows per frame
     static constexpr int S = FM == 2 ? (J == 4 ? 11 : J == 8 ? 20 : J == 16 ? 35 : 67)
@@ -46,9 +44,11 @@ struct C3Geo {
     static constexpr int P1 = FM == 2 ? (FR + 1) / 2 : 0;              // first physical row of the odd-row plane
     static constexpr int TB = 32 * TM / J;                             // frames per tile (2 M-waves x TM x 16 rows)
     static constexpr int NPIECE = (TB + 1) * S * 2;                    // 16-byte pieces per buffer
-    static constexpr int MAXP = (NPIECE + 255) / 256;                  // DMA instructions per thread and chunk
+    static constexpr int NTH = 128 * NWN;                              // threads: 2 (m) x NWN (n) waves
+    static constexpr int MAXP = (NPIECE + NTH - 1) / NTH;              // DMA instructions per thread and chunk
     static constexpr int PBYTES = ((TB + 1) * S * 32 + 1023) / 1024 * 1024;
-    static constexpr int LDS_MAIN = C3_RING + 2 * PBYTES + 1024 + 2 * (TB + 1) * 4;
+    static constexpr int RING = C3_NSLOT * 1024 * 2 * NWN * 2;         // four weight tiles of 32 TN NWN rows x 64 B (TN = 4)
+    static constexpr int LDS_MAIN = RING + 2 * PBYTES + 1024 + 2 * (TB + 1) * 4;
     static_assert(S >= FR && (FM == 1 || P1 + FR / 2 <= S), "frame stride");
     static_assert(J == 4 || J == 8 || J == 16 || J == 32, "rows per frame");
     static_assert(TM == 8 || TM == 6 || TM == 4, "MFMA row tiles per wave (even: the frame order of J = 4 / 8 pairs them)");
@@ -103,15 +103,19 @@ __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constan
 // ABL: ablation builds for tools/ (never launched by the product path unless SEHIP_C3_ABL is set): 1 = no DMA inside the loop,
 // 2 = no MFMA, 4 = no fragment reads
 // TN = 16-column MFMA tiles per wave: 4 -> 128 output channels per workgroup, 2 -> 64 (the layers with 64 outputs)
-template <int NF, int FM, int J, int TM, int TN, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B, int order) {
-    using G = C3Geo<NF, FM, J, TM>;
+// NWN = waves along n: 2 -> 256 threads, two workgroups per CU; 4 -> 512 threads, 256 output channels, one workgroup per CU
+template <int NF, int FM, int J, int TM, int TN, int NWN = 2, int ABL = 0>
+__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B, int order) {
+    using G = C3Geo<NF, FM, J, TM, NWN>;
+    constexpr int NWV = 2 * NWN, NTH = 64 * NWV;     // waves, threads
+    constexpr int WSLOT = 16 * TN * NWN * 64, RING = G::RING;
+    static_assert(NWN == 2 || TN == 4, "the 8-wave build is for 256-column tiles");
     constexpr int TB = G::TB, S = G::S, P1 = G::P1, FR = G::FR, H = NF, MAXP = G::MAXP, NPIECE = G::NPIECE, PBYTES = G::PBYTES;
-    constexpr int BN = 32 * TN;                       // output channels per workgroup (2 N-waves x TN x 16)
+    constexpr int BN = 16 * TN * NWN;                 // output channels per workgroup (NWN N-waves x TN x 16)
     constexpr int DW = TN / 2;                        // weight-tile DMA instructions per wave and K step: BN rows x 2 taps x 32 B
     constexpr int WPL = BN * 32;                      // bytes of one tap plane of a weight tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* pbuf = smem + C3_RING;
+    unsigned char* pbuf = smem + RING;
     unsigned char* dump = pbuf + 2 * PBYTES;
     int* ftab = reinterpret_cast<int*>(dump + 1024);                           // [2][TB + 1]
 
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     unsigned off0[MAXP], off1[MAXP];                                             // byte offsets; C3_OOB = padding
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
-        const int P = (u * 4 + wave) * 64 + lane;
+        const int P = (u * NWV + wave) * 64 + lane;
         const int prow = P >> 1, half = P & 1;
         const int p = prow / S, rr = prow - p * S;
         int r;
@@ -182,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         unsigned char* dst = pbuf + buf * PBYTES + wave * 1024;
 #pragma unroll
         for (int u = 0; u < MAXP; ++u) {
-            unsigned char* dd = ((u * 4 + wave) * 64 < NPIECE) ? dst + u * 4096 : dump;     // wave-uniform
+            unsigned char* dd = ((u * NWV + wave) * 64 < NPIECE) ? dst + u * (NWV * 1024) : dump;     // wave-uniform
             unsigned vo = second ? off1[u] : off0[u];
-            if (ABL & 8) vo = (unsigned)(((blockIdx.x & 1023) * 16384 + ((u * 4 + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
+            if (ABL & 8) vo = (unsigned)(((blockIdx.x & 1023) * 16384 + ((u * NWV + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (c3_lds_void*)dd, 16, vo, soff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (c3_lds_void*)dd, 16, vo, soff, 0, 0);
         }
@@ -199,16 +203,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     // (two named registers, not an array: hipcc's host pass silently dropped the whole kernel when a lambda passed an element of a
     //  captured array to the buffer-load builtin -- no diagnostic, undefined kernel symbol at load time)
     auto woff_of = [&](int u) {
-        const int i = 256 * u + 64 * wave + lane;
+        const int i = NTH * u + 64 * wave + lane;
         const int pl = i / (2 * BN), n = (i >> 1) % BN;
+        if (NWN == 4)       // the tile order is by 128 columns: a 256-column tile is two of them, d.K * 128 elements apart
+            return 2u * (tiled ? (unsigned)((n >> 7) * 128 * d.K + pl * 2048 + (n & 127) * 16 + (i & 1) * 8)
+                               : (unsigned)(n * d.K + pl * Ctot + (i & 1) * 8));
         return 2u * (tiled ? (unsigned)(i * 8) : (unsigned)(n * d.K + pl * Ctot + (i & 1) * 8));
     };
     const unsigned woff0 = woff_of(0), woff1 = woff_of(DW - 1);
     auto issue_w = [&](int ch, int j, int slot) {
-        const int soff = 2 * (tiled ? (ch * H + j) * (2 * BN * 16) : 2 * j * Ctot + ch * 16);
-        unsigned char* dst = smem + slot * C3_WSLOT + wave * 1024;
+        const int soff = 2 * (tiled ? (ch * H + j) * (2 * (NWN == 4 ? 128 : BN) * 16) : 2 * j * Ctot + ch * 16);
+        unsigned char* dst = smem + slot * WSLOT + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)dst, 16, woff0, soff, 0, 0);
-        if (DW > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + 4096), 16, woff1, soff, 0, 0);
+        if (DW > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + NWV * 1024), 16, woff1, soff, 0, 0);
     };
 
     // ---- fragment addresses
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
         const bool second = ch * 16 >= C0;
         const int dtA = second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0;
         const int dtB = second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0;
-        const int bufoff = C3_RING + (ch & 1) * PBYTES;
+        const int bufoff = RING + (ch & 1) * PBYTES;
         int aoff[H];                         // per K step: this lane's patch address (its tap of the pair, frame offset, buffer)
 #pragma unroll
         for (int j = 0; j < H; ++j) {
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             // Order: 12 fragment reads, the DMA of tile s + 3 (and the next chunk's patch) behind them, 28 MFMAs with the
             // compiler's counted lgkmcnt waits, then wait for step s + 1's operands + barrier, then the last 4 MFMAs.
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* wslot = smem + slot * C3_WSLOT + wrd;
+            const unsigned char* wslot = smem + slot * WSLOT + wrd;
             const unsigned char* ap = smem + aoff[j];
             bf16x8 wf[TN], af[TM];
             if (ABL & 4) {
@@ -334,13 +341,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
     }
     bool with_stats = false;
     if (d.stats && TN == 4) {
-        int* flag = reinterpret_cast<int*>(smem + 4 * (WROWS * TP * 2));
+        int* flag = reinterpret_cast<int*>(smem + NWV * (WROWS * TP * 2));
         if (lane == 0) flag[wave] = dense ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         with_stats = true;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) with_stats = with_stats && flag[i] != 0;
+        for (int i = 0; i < NWV; ++i) with_stats = with_stats && flag[i] != 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -373,9 +380,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const bf16_raw* imr = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * 0) * (WROWS * TP);
-            const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * 1) * (WROWS * TP);
-            const int cp = 32 * wn + 2 * (lane & 15), rg = lane >> 4;
+            const bf16_raw* imr = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * (wn & ~1)) * (WROWS * TP);
+            const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * (wn | 1)) * (WROWS * TP);
+            const int cp = 32 * (wn & 1) + 2 * (lane & 15), rg = lane >> 4;
             float sr[2] = {0.f, 0.f}, si[2] = {0.f, 0.f}, srr[2] = {0.f, 0.f}, sri[2] = {0.f, 0.f}, sii[2] = {0.f, 0.f};
             constexpr int RG = WROWS / 4;                          // rows per row group
 #pragma unroll 4
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_v3_kernel(const sehip_gemm_d
             }
             if (lane < 16) {
                 const int Cr = d.stats_cr;
-                float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + cp;
+                float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + 64 * (wn >> 1) + cp;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     atomicAdd(sp + e, sr[e]); atomicAdd(sp + Cr + e, si[e]);
@@ -490,32 +497,32 @@ static int c3_order() {
     static const int o = getenv("SEHIP_C3_ORDER") ? atoi(getenv("SEHIP_C3_ORDER")) : 0;
     return o;
 }
-template <int NF, int FM, int J, int TM, int TN>
+template <int NF, int FM, int J, int TM, int TN, int NWN = 2>
 static size_t c3_lds_bytes() {
-    using G = C3Geo<NF, FM, J, TM>;
-    const size_t epi = 4 * (16 * TM * (16 * TN + 8) * 2) + 64;
+    using G = C3Geo<NF, FM, J, TM, NWN>;
+    const size_t epi = 2 * NWN * (16 * TM * (16 * TN + 8) * 2) + 64;
     return (size_t)G::LDS_MAIN > epi ? (size_t)G::LDS_MAIN : epi;
 }
-template <int NF, int FM, int J, int TM, int TN>
+template <int NF, int FM, int J, int TM, int TN, int NWN = 2>
 static void c3_set_attr() {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM, TN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (NWN == 2 ? 80 : 160) * 1024);
         attr_set = true;
     }
 }
-template <int NF, int FM, int J, int TM, int TN>
+template <int NF, int FM, int J, int TM, int TN, int NWN = 2>
 static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
-    c3_set_attr<NF, FM, J, TM, TN>();
-    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d, %d, 0>", NF, FM, J, TM, TN);
-    conv_gemm_v3_kernel<NF, FM, J, TM, TN><<<grid, 256, c3_lds_bytes<NF, FM, J, TM, TN>(), st>>>(d, B, c3_order());
+    c3_set_attr<NF, FM, J, TM, TN, NWN>();
+    sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d, %d, %d, 0>", NF, FM, J, TM, TN, NWN);
+    conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN><<<grid, 128 * NWN, c3_lds_bytes<NF, FM, J, TM, TN, NWN>(), st>>>(d, B, c3_order());
 }
 template <int J, int ABL>
 static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, 4, 2, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    conv_gemm_v3_kernel<5, 2, J, 8, 4, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8, 4>(), st>>>(d, B, c3_order());
+    conv_gemm_v3_kernel<5, 2, J, 8, 4, 2, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8, 4>(), st>>>(d, B, c3_order());
 }
 // Rows per tile: 256 (TM 8) or 192 (TM 6).  Tiles run two per CU (512 slots).  Measured at the headline shapes (B (T + 2) = 10400
 // frames): where 256-row tiles do not even fill one round (326 tiles) 192-row tiles (434) take 10-15 % less time; from 650 tiles
@@ -538,6 +545,13 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
 #define C3_ABL(A_) case A_: if (d.J == 4) c3_launch_abl<4, A_>(d, B, grid, st); else c3_launch_abl<8, A_>(d, B, grid, st); return 1;
         switch (abl) { C3_ABL(1) C3_ABL(2) C3_ABL(3) C3_ABL(4) C3_ABL(5) C3_ABL(6) C3_ABL(8) C3_ABL(14) default: break; }
 #undef C3_ABL
+    }
+    // 8-wave build (tools/ experiment, SEHIP_C3_W8): 256 x 256 tiles, one workgroup per CU
+    static const int w8 = getenv("SEHIP_C3_W8") ? atoi(getenv("SEHIP_C3_W8")) : 0;
+    if (w8 && NF == 5 && (d.Npad & 255) == 0 && (d.J == 4 || d.J == 8)) {
+        const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * (d.Npad / 256);
+        if (d.J == 4) c3_launch<5, 2, 4, 8, 4, 4>(d, B, grid, st); else c3_launch<5, 2, 8, 8, 4, 4>(d, B, grid, st);
+        return 1;
     }
     const int tm = c3_pick_tm(vframes, d.J, ntn);
 #define C3_CASE(J_)                                                                                       \

@@ -639,6 +639,8 @@ int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st);   // conv2
 void sehip_conv2_init(void);
 int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st);   // conv3.hip
 void sehip_conv3_init(void);
+int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
+void sehip_wgrad3_init(void);
 
 // returns 1 if the LDS-patch kernel was launched, 0 if the descriptor does not qualify
 static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
@@ -2436,6 +2438,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("wgrad(narrow)");
         return 0;
     }
+    if (sehip_try_conv_wgrad_v3(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(conv v3)");
+        return 0;
+    }
     if (try_conv_wgrad(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv)");
         return 0;
@@ -2561,6 +2567,7 @@ extern "C" int sehip_init(void) {
 #undef INIT_SW
     sehip_conv2_init();
     sehip_conv3_init();
+    sehip_wgrad3_init();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sehip_set_error(-2, "init: %s", hipGetErrorString(e));
     return 0;

@@ -771,7 +771,18 @@ class DCCRNWorkspace:
         self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
         import os
-        self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        # the weight-gradient stream.  SEHIP_SIDE_PRIORITY=1: created through the C ABI with the device's lowest priority
+        self.side, self._side_handle = None, None
+        if not os.environ.get("SEHIP_NO_SIDE_STREAM"):
+            if os.environ.get("SEHIP_SIDE_PRIORITY"):
+                with torch.cuda.device(device):
+                    h = _lib.lib().sehip_stream_create(int(os.environ["SEHIP_SIDE_PRIORITY"]))
+                if not h:
+                    raise SehipError("sehip_stream_create: " + _lib.lib().sehip_last_error().decode())
+                self._side_handle = h
+                self.side = torch.cuda.ExternalStream(h, device=device)
+            else:
+                self.side = torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self.comm = None     # third stream: early un-pack + all-reduce of the decoder / LSTM gradients (data-parallel runs only)
         # The two stacked complex LSTM layers are pipelined over chunks of time steps: layer 2 (and the input product that
@@ -807,6 +818,9 @@ class DCCRNWorkspace:
         for e in self._events:
             lib.sehip_event_destroy(e)
         self._events = []
+        if self._side_handle:
+            lib.sehip_stream_destroy(self._side_handle)
+            self._side_handle = None
 
     def __del__(self):
         try:

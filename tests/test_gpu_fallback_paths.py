@@ -24,7 +24,8 @@ x = (0.1 * torch.randn(4, 1, 6000, generator=g)).to(dev)
 out = model(x)
 out.backward(1e-3 * torch.ones_like(out))
 torch.cuda.synchronize()
-torch.save({"out": out.detach().cpu(), "grads": model.flat_grads.cpu()}, sys.argv[1])
+named = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+torch.save({"out": out.detach().cpu(), "grads": model.flat_grads.cpu(), "named": named}, sys.argv[1])
 """
 
 
@@ -47,6 +48,28 @@ def test_specialised_kernels_match_generic_fallback():
     eg = float((fast["grads"] - slow["grads"]).norm() / slow["grads"].norm())
     assert eo < 2e-2, eo
     assert eg < 5e-2, eg
+
+
+def test_conv_wgrad_v3_all_layer_classes_and_both_flushes_match_conv_wgrad():
+    """conv_wgrad_v3_kernel (csrc/wgrad3.hip: LDS-DMA stages, one CU per workgroup, partial arrays + reduction) takes the 5-tap encoder
+    layers by default; here every class it is built for (3- / 2-tap decoder products too), one workgroup per CU, with the store
+    flush and with the atomic flush, against conv_wgrad_kernel on the same operands (enc3 / enc4 / enc5, dec0 / dec1 of this model
+    qualify: >= 64 input channels, 128 output columns, 16 / 8 / 4 rows per frame)."""
+    old, old2 = run({"SEHIP_NO_WGRAD_V3": "1"}), run({"SEHIP_NO_WGRAD_V3": "1"})
+    convs = [n for n in old["named"] if n.endswith("conv.weight") and old["named"][n].dim() == 4]
+    assert len(convs) >= 20
+
+    def worst(a, b):
+        return max(float((a["named"][n] - b["named"][n]).norm() / b["named"][n].norm()) for n in convs)
+
+    # the forward pass's BatchNorm sums are fp32 atomics: two runs of the SAME build differ by the bf16 roundings that flips -- the
+    # yardstick for "same operands, different summation order"
+    noise = worst(old2, old)
+    bound = max(5 * noise, 5e-3)
+    for extra in ({}, {"SEHIP_W3_ATOMIC_FLUSH": "1"}, {"SEHIP_W3_NB": "3", "SEHIP_W3_WGS": "96"}):
+        new = run(dict({"SEHIP_W3_CLASSES": "7", "SEHIP_W3_WGS": "256"}, **extra))
+        assert worst(new, old) < bound, (extra, worst(new, old), noise)      # every convolution weight tensor on its own
+    assert worst(run({}), old) < bound
 
 
 CHILD_DCU = r"""

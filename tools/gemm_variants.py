@@ -26,6 +26,35 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         for _ in range(20): call(fn, C.byref(d), stream())
         e1.record(); torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 20
+        if os.environ.get("SEHIP_VARIANT_SUMS") and fn == "sehip_gemm":      # digest of what ONE call writes (outputs + fused sums)
+            B = 32
+            for q in (0, 1):
+                t = d.dst[q]
+                if not t.ptr: continue
+                n = B * t.T * t.F * t.C
+                buf = (C.c_uint32 if t.is_f32 else C.c_uint16) * n
+                # a view on the arena through the CUDA array interface
+                class V: pass
+                v = V(); v.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4" if t.is_f32 else "<i2", "data": (t.ptr, False), "version": 2}
+                x_ = torch.as_tensor(v, device=dev)
+                x_ = x_ if t.is_f32 else x_.view(torch.bfloat16)
+                x_.zero_()
+            if d.stats:
+                v = V(); v.__cuda_array_interface__ = {"shape": (8 * 5 * d.stats_cr,), "typestr": "<f4", "data": (d.stats, False), "version": 2}
+                st_ = torch.as_tensor(v, device=dev); st_.zero_()
+            call(fn, C.byref(d), stream()); torch.cuda.synchronize()
+            sums = []
+            for q in (0, 1):
+                t = d.dst[q]
+                if not t.ptr: continue
+                v = V(); v.__cuda_array_interface__ = {"shape": (B * t.T * t.F * t.C,), "typestr": "<f4" if t.is_f32 else "<i2", "data": (t.ptr, False), "version": 2}
+                x_ = torch.as_tensor(v, device=dev)
+                x_ = (x_ if t.is_f32 else x_.view(torch.bfloat16)).double()
+                w_ = torch.arange(x_.numel(), device=dev, dtype=torch.float64) % 977 + 1
+                sums += [float(x_.abs().sum()), float((x_ * w_).sum())]
+            if d.stats:
+                sums += [float(st_.double().abs().sum())]
+            res[name + ".sum"] = sums
     print("RES " + json.dumps(res))
 else:
     names = os.environ.get("SEHIP_NAMES", "").split(",") if os.environ.get("SEHIP_NAMES") else ["dec1.dg", "dec0.fwd0", "enc5.fwd", "dec0.fwd0.wg", "enc4.fwd.wg", "enc1.fwd", "enc2.fwd", "enc1.dg0", "enc2.dg0", "dec3.fwd0", "dec4.fwd0", "dec5.fwd0", "dec4.dg", "enc0.fwd", "dec5.dg", "enc1.fwd.wg", "enc2.fwd.wg", "dec4.fwd0.wg", "dec3.fwd0.wg", "dec5.fwd0.wg", "enc0.fwd.wg"]
@@ -39,4 +68,10 @@ else:
             env[k] = v
         r = subprocess.run([sys.executable, __file__, "--child"] + names, env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RES ")]
-        print(flags, {k: round(v * 1e3) for k, v in json.loads(line[0][4:]).items()} if line else r.stderr[-500:])
+        if line:
+            out = json.loads(line[0][4:])
+            print(flags, {k: round(v * 1e3) for k, v in out.items() if not k.endswith(".sum")})
+            for k, v in out.items():
+                if k.endswith(".sum"): print("   ", k, ["%.6e" % q for q in v])
+        else:
+            print(flags, r.stderr[-1500:])
