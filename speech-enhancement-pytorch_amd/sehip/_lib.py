@@ -173,30 +173,36 @@ def ptr(t):
     return t.data_ptr()
 
 
-_stream_handle = None
+import threading
+
+_tls = threading.local()      # per thread: autograd's backward thread (and any user thread) never sees another thread's cached stream
 
 
 def stream():
-    """hipStream_t of torch's current stream (cached inside a stream_scope)."""
-    if _stream_handle is not None:
-        return _stream_handle
+    """hipStream_t of torch's current stream (cached inside a stream_scope of the calling thread)."""
+    h = getattr(_tls, "handle", None)
+    if h is not None:
+        return h
     return torch.cuda.current_stream().cuda_stream
 
 
 class stream_scope:
-    """Looks torch's current stream up ONCE for all library calls made inside the scope: the lookup costs ~8 us of host time
-    and a training step makes ~110 of them (a quarter of the step's launch time).  Code inside must not switch torch's
-    current stream and then expect stream() to follow (the side streams of sehip/plan.py are passed as explicit handles)."""
+    """Looks torch's current stream up ONCE for all library calls the calling thread makes inside the scope: the lookup costs
+    ~8 us of host time and a training step makes ~110 of them (a quarter of the step's launch time).  Code inside must not
+    switch torch's current stream and then expect stream() to follow (the side streams of sehip/plan.py are passed as explicit
+    handles): with SEHIP_DEBUG_STREAMS set the exit checks that torch's current stream is still the cached one."""
 
     def __enter__(self):
-        global _stream_handle
-        self._prev = _stream_handle
-        _stream_handle = torch.cuda.current_stream().cuda_stream
+        self._prev = getattr(_tls, "handle", None)
+        _tls.handle = torch.cuda.current_stream().cuda_stream
         return self
 
     def __exit__(self, *exc):
-        global _stream_handle
-        _stream_handle = self._prev
+        cached = _tls.handle
+        _tls.handle = self._prev
+        if exc[0] is None and os.environ.get("SEHIP_DEBUG_STREAMS") and torch.cuda.current_stream().cuda_stream != cached:
+            raise SehipError("stream_scope: torch's current stream changed inside the scope; library calls went to the stream "
+                             "that was current at entry")
         return False
 
 

@@ -1150,10 +1150,44 @@ static void lstm_seq_bwd_launch(dim3 g, hipStream_t st, const float* gates, cons
                                 int btiles, unsigned* sync) {
     dmx_lstm_seq_bwd_kernel<KS><<<g, 256, 0, st>>>(gates, (const bf16_raw*)whhT, cs, (const bf16_raw*)dhs, (bf16_raw*)dG, Bn, T, btiles, sync);
 }
-static bool lstm_seq_ok(int Bn, int T, int H, const unsigned* sync) {
+// Co-residency bound of the spinning kernels: every workgroup of the grid must be resident at once (the members of a group wait
+// for each other), and they share the GPU with the weight-gradient, packing and communication streams.  The bound is what the
+// runtime reports for the kernel (workgroups per CU x CUs), halved: the other streams' workgroups may hold a CU's LDS / registers
+// when a member is dispatched, and a member that is dispatched late only makes the others spin, while one that cannot be
+// dispatched until they finish is a time-out (sehip_dmx_lstm_* then report it through the sticky word, plan_demucs falls back).
+template <typename K>
+static int lstm_seq_capacity(K kernel) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) return 0;
+    return per_cu * cus / 2;
+}
+static int lstm_seq_capacity_for(int ks, bool bwd) {
+    static int cap[2][5] = {{-1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1}};
+    const int i = ks == 1 ? 0 : ks == 2 ? 1 : ks == 4 ? 2 : ks == 8 ? 3 : 4;
+    int& c = cap[bwd ? 1 : 0][i];
+    if (c < 0) {
+        switch (ks * 2 + (bwd ? 1 : 0)) {
+            case 2: c = lstm_seq_capacity(dmx_lstm_seq_fwd_kernel<1>); break;
+            case 3: c = lstm_seq_capacity(dmx_lstm_seq_bwd_kernel<1>); break;
+            case 4: c = lstm_seq_capacity(dmx_lstm_seq_fwd_kernel<2>); break;
+            case 5: c = lstm_seq_capacity(dmx_lstm_seq_bwd_kernel<2>); break;
+            case 8: c = lstm_seq_capacity(dmx_lstm_seq_fwd_kernel<4>); break;
+            case 9: c = lstm_seq_capacity(dmx_lstm_seq_bwd_kernel<4>); break;
+            case 16: c = lstm_seq_capacity(dmx_lstm_seq_fwd_kernel<8>); break;
+            case 17: c = lstm_seq_capacity(dmx_lstm_seq_bwd_kernel<8>); break;
+            case 32: c = lstm_seq_capacity(dmx_lstm_seq_fwd_kernel<16>); break;
+            default: c = lstm_seq_capacity(dmx_lstm_seq_bwd_kernel<16>); break;
+        }
+    }
+    return c;
+}
+static bool lstm_seq_ok(int Bn, int T, int H, const unsigned* sync, bool bwd) {
     static const bool off = getenv("SEHIP_DMX_LSTM_STEPS") != nullptr;
     const int ks = H / 32, btiles = (Bn + 15) / 16;
-    return sync && !off && (ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16) && 2 * btiles * (H / 16) <= 256 && DMX_CNT0 + 2 * btiles * DMX_REPL * DMX_RSTRIDE <= DMX_SYNC_WORDS &&
+    if (!sync || off || !(ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16)) return false;
+    const int grid = 8 * (H / 16) * ((2 * btiles + 7) / 8);          // incl. the inactive workgroups that pad a group to one XCD
+    return grid <= lstm_seq_capacity_for(ks, bwd) && DMX_CNT0 + 2 * btiles * DMX_REPL * DMX_RSTRIDE <= DMX_SYNC_WORDS &&
            (long)Bn * T * 8 * H * 2 < (1L << 31);      // 32-bit byte offsets into the handed-off tensors
 }
 extern "C" int sehip_dmx_lstm_sync_bytes(void) { return DMX_SYNC_WORDS * 4; }
@@ -1162,7 +1196,7 @@ extern "C" int sehip_dmx_lstm_fwd(float* pre, const void* whh, int Bn, int T, in
     SEHIP_REQUIRE(Bn > 0 && T > 0 && H >= 32 && (H & 31) == 0, "dmx_lstm_fwd: hidden size H=%d must be a multiple of 32 (Bn=%d T=%d)", H, Bn, T);
     hipStream_t st = (hipStream_t)stream;
     const int btiles = (Bn + 15) / 16;
-    if (lstm_seq_ok(Bn, T, H, sync)) {
+    if (lstm_seq_ok(Bn, T, H, sync, false)) {
         SEHIP_REQUIRE(hipMemsetAsync(sync + DMX_CNT0, 0, (size_t)2 * btiles * DMX_REPL * DMX_RSTRIDE * 4, st) == hipSuccess, "dmx_lstm_fwd: clearing the sync block failed");
         const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
         switch (H / 32) {
@@ -1187,7 +1221,7 @@ extern "C" int sehip_dmx_lstm_bwd(const float* gates, const void* whhT, const fl
     SEHIP_REQUIRE(Bn > 0 && T > 0 && H >= 32 && (H & 31) == 0, "dmx_lstm_bwd: hidden size H=%d must be a multiple of 32", H);
     hipStream_t st = (hipStream_t)stream;
     const int btiles = (Bn + 15) / 16;
-    if (lstm_seq_ok(Bn, T, H, sync)) {
+    if (lstm_seq_ok(Bn, T, H, sync, true)) {
         SEHIP_REQUIRE(hipMemsetAsync(sync + DMX_CNT0, 0, (size_t)2 * btiles * DMX_REPL * DMX_RSTRIDE * 4, st) == hipSuccess, "dmx_lstm_bwd: clearing the sync block failed");
         const dim3 g(8 * (H / 16) * ((2 * btiles + 7) / 8));
         switch (H / 32) {

@@ -472,7 +472,10 @@ def test_gradient_ranges_for_the_data_parallel_exchange():
     assert ranges[0][0] == model.static.layout.param_off["decoder.0.0.weight"][0]
     err = rel_err(model.flat_grads.cpu(), want.cpu())
     print(f"Demucs gradient ranges {[(lo, hi) for lo, hi, _ in ranges]}: difference to the run without hook {err:.2e}, run-to-run {noise:.2e}")
-    assert err < max(3 * noise, 2e-3)
+    # run-to-run differences of this model measure 2e-3 ... 9e-3 (eight repetitions), the difference with the hook 5e-3 ... 9e-3: one noise
+    # sample is a poor yardstick on its own (3 x 2.1e-3 < 6.6e-3 failed once), so the floor is twice the largest noise seen.  A range
+    # handed over before its last weight gradient has landed misses whole tensors: tens of percent
+    assert err < max(3 * noise, 2e-2)
 
 
 def test_bench_two_ranks_on_one_gpu_demucs():
