@@ -69,5 +69,53 @@ def main():
     print("wrote dcunet_tiny.npz:", len(out), "arrays, loss", loss.item(), "grads", len(seen))
 
 
+def main20():
+    """tests/golden/dcunet20_tiny.npz: the depth-20 tables (src/model/dcunet.py:215-305) on the one spectrum shape the reference
+    network accepts at that depth, [1, 1, 257, 257, 2]: state_dict, input / target, train and eval output, mse loss, every
+    parameter gradient, updated running statistics."""
+    from src.model.dcunet import DCUnet
+    torch.manual_seed(20)
+    model = DCUnet(audio_channels=1, data_type=True, model_complexity=8, model_depth=20, masking_mode="E")
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if ".bn." in name:
+                prm.copy_((1.0 if name.endswith("weight") else 0.0) + 0.2 * torch.randn(prm.shape, generator=g))
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.copy_(0.1 * torch.randn(buf.shape, generator=g))
+            if name.endswith("running_var"):
+                buf.copy_(1.0 + 0.3 * torch.rand(buf.shape, generator=g))
+    x = (0.5 * torch.randn(1, 1, 257, 257, 2, generator=g)).half().float()      # fp16-representable values: stored as fp16, exact
+    tgt = (0.5 * torch.randn(1, 1, 257, 257, 2, generator=g)).half().float()
+    out = {}
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in sd0.items():
+        if not k.startswith(("encoders.", "decoders.")):
+            out["sd." + k] = v.numpy()
+    out["n_state_dict_keys"] = np.array(len(sd0))
+    model.eval()
+    with torch.no_grad():
+        out["eval_out"] = model(x).numpy()
+    model.train()
+    est = model(x)
+    loss = torch.nn.functional.mse_loss(est, tgt)
+    loss.backward()
+    out["x"], out["target"] = x.numpy().astype(np.float16), tgt.numpy().astype(np.float16)
+    out["train_out"], out["loss"] = est.detach().numpy(), np.array(loss.item())
+    n = 0
+    for name, prm in model.named_parameters():
+        out["grad." + name] = prm.grad.numpy()
+        n += 1
+    for k, v in model.state_dict().items():
+        if k.endswith(("running_mean", "running_var")) and not k.startswith(("encoders.", "decoders.")):
+            out["stat." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "dcunet20_tiny.npz"), **out)
+    print("wrote dcunet20_tiny.npz:", len(out), "arrays, loss", loss.item(), "grads", n)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "20":
+        main20()
+    else:
+        main()

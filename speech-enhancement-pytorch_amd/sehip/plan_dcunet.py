@@ -46,11 +46,7 @@ def dcunet_tables(model_complexity, model_depth, audio_channels):
         dec_k = [(4, 3), (4, 4), (6, 4), (6, 4), (7, 5)]
         dec_s = [(2, 1), (2, 2), (2, 2), (2, 2), (2, 2)]
         dec_p = [(1, 1), (1, 1), (2, 1), (2, 1), (2, 1)]
-    elif model_depth == 20 and os.environ.get("SEHIP_DCUNET20"):      # src/model/dcunet.py:215-305
-        # NOT RELEASED (round 3): with these tables the forward pass of the complexity-8 network agrees with the oracle (1.3e-2 at
-        # [1, 1, 257, 257, 2], the only frame count the reference itself accepts at depth 20), but the weight gradients of the three
-        # stride-1 / even-kernel encoder layers come out wrong and the full-width network faults -- behind a switch for whoever
-        # picks it up (tools/debug_dcunet20.py), otherwise depth 20 raises below
+    elif model_depth == 20:      # src/model/dcunet.py:215-305
         enc_ch = [audio_channels, mc, mc] + [mc * 2] * 7 + [128]
         enc_k = [(7, 1), (1, 7), (6, 4), (7, 5)] + [(5, 3)] * 6
         enc_s = [(1, 1), (1, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1)]
@@ -59,8 +55,6 @@ def dcunet_tables(model_complexity, model_depth, audio_channels):
         dec_k = [(4, 3), (4, 2), (4, 3), (4, 2), (4, 3), (4, 2), (6, 3), (7, 5), (1, 7), (7, 1)]
         dec_s = [(2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (1, 1), (1, 1)]
         dec_p = [(1, 1), (1, 0), (1, 1), (1, 0), (1, 1), (1, 0), (2, 1), (2, 1), (0, 3), (3, 0)]
-    elif model_depth == 20:
-        raise SehipError("sehip DCUnet: model_depth=20 is not built (the depth-10 network is; see DESIGN.md section 7)")
     else:
         raise SehipError(f"Unknown model depth : {model_depth}")
     return dict(n=model_depth // 2, enc_ch=enc_ch, enc_k=enc_k, enc_s=enc_s, enc_p=enc_p, dec_ch=dec_ch, dec_k=dec_k, dec_s=dec_s,
@@ -478,7 +472,7 @@ class DCUNetWorkspace:
             need = max(need, int(lib.sehip_rbn_scratch_floats(rows, cs)))
         self.bn_acc = torch.zeros(need, dtype=torch.float32, device=device)
         self.bn_coef = {pre: torch.zeros(2 * cs, 4, dtype=torch.float32, device=device) for pre, tag, cs, cr in pl.bn}
-        self.bn_bcoef = torch.zeros(128, 4, dtype=torch.float32, device=device)
+        self.bn_bcoef = torch.zeros(2 * max(cs for _, _, cs, _ in pl.bn), 4, dtype=torch.float32, device=device)     # sehip_rbn_bwd_finalize: [2 cs][4]
         self.mode = {"E": 0, "C": 1, "R": 2}[st.cfg.masking_mode]
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True

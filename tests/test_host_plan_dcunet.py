@@ -206,4 +206,17 @@ def test_module_schema_matches_reference_checkpoint():
     with pytest.raises(SehipError):
         m(torch.zeros(1, 1, 257, 33, 2))                           # CPU tensor: no fallback
     with pytest.raises(SehipError):
-        DCUnet(data_type=True, model_depth=20)
+        DCUnet(data_type=True, model_depth=12)                     # "Unknown model depth"
+
+
+def test_depth_20_state_dict_matches_the_reference():
+    """model_depth=20 (src/model/dcunet.py:215-305): names and shapes of the reference's state_dict (tests/golden/dcunet20_tiny.npz)."""
+    from sehip.model import DCUnet
+    g = load_golden("dcunet20_tiny.npz")
+    m = DCUnet(data_type=True, model_complexity=8, model_depth=20)
+    sd = m.state_dict()
+    assert len(sd) == int(g["n_state_dict_keys"])
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    assert set(ref) <= set(sd) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in ref.items())
+    assert tuple(sd["encoder9.conv.conv_re.weight"].shape) == (128, 10, 5, 3)      # the fixed 128-channel bottleneck (:226)
+    assert tuple(sd["encoder0.conv.conv_re.weight"].shape[2:]) == (7, 1) and tuple(sd["decoder9.transconv.tconv_re.weight"].shape[2:]) == (7, 1)

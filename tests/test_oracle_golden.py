@@ -223,6 +223,32 @@ def test_dcunet_oracle_matches_reference():
     assert len(stats) == 40
 
 
+def test_dcunet20_oracle_matches_reference():
+    """The depth-20 tables (src/model/dcunet.py:215-305) on [1, 1, 257, 257, 2], the one shape the reference accepts at that depth."""
+    from oracle import dcunet_oracle as D
+    g = load_golden("dcunet20_tiny.npz")
+    p = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    x, tgt = torch.from_numpy(g["x"]).float(), torch.from_numpy(g["target"]).float()      # stored as fp16, exactly representable
+    out_eval = D.dcunet_forward(p, x, model_complexity=8, model_depth=20, training=False)
+    assert rel_err(out_eval, torch.from_numpy(g["eval_out"])) < 2e-5
+    names = [k for k in p if D.is_trainable(k)]
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    work = dict(p); work.update(leaves)
+    stats = {}
+    est = D.dcunet_forward(work, x, model_complexity=8, model_depth=20, training=True, stats_out=stats)
+    assert rel_err(est.detach(), torch.from_numpy(g["train_out"])) < 2e-5
+    loss = torch.nn.functional.mse_loss(est, tgt)
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    assert len(names) == 164
+    for k, gr in zip(names, grads):
+        ref = torch.from_numpy(g["grad." + k])
+        assert float((gr - ref).norm()) <= 5e-4 * float(ref.norm()) + 1e-7, k
+    for k, v in stats.items():
+        assert rel_err(v, torch.from_numpy(g["stat." + k])) < 1e-5, k
+    assert len(stats) == 80
+
+
 # ---- ConvTasNet (SURVEY section 8a row a15, config C4): oracle/convtasnet_oracle.py vs the reference's activations / gradients
 def test_convtasnet_oracle_matches_reference():
     from oracle import convtasnet_oracle as CT
