@@ -582,7 +582,14 @@ def main():
         if dcu or ctn or dmx:
             tpath = os.path.join(ROOT, "profiles", f"r3_traffic_{args.workload}.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(top["kernel"], {}).get("hbm_bytes_per_launch")
+            if traffic is None and top["kernel"].endswith("*>"):      # a class of instantiations: launch-weighted mean over its members
+                pre = top["kernel"][:-2]
+                mem = [v for k, v in tj.items() if k.startswith(pre) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+                nl = sum(v["launches_per_step"] for v in mem)
+                if nl > 0:
+                    traffic = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in mem) / nl
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                            "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
