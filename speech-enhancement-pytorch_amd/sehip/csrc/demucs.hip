@@ -570,7 +570,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define DMX_SYNC_WORDS 16384       // sync block: word 60 = time-out (sticky); from word 64: per group 32 replicas of its arrival counter, 128 B apart
 #define DMX_TMO 60
-#define DMX_LIM 61                 // test hook: a non-zero word here replaces DMX_SPIN_LIMIT (tests/test_gpu_demucs.py forces a time-out)
+#define DMX_LIM 61                 // test hook: a non-zero word here replaces DMX_SPIN_LIMIT; 0xffffffff = time out at the first wait (tests/test_gpu_demucs.py)
 #define DMX_CNT0 64
 #define DMX_REPL 32
 #define DMX_RSTRIDE 32
@@ -589,6 +589,10 @@ __device__ __forceinline__ SeqMap seq_map(int nb, int btiles) {
 }
 // lane 0 of wave 0 waits until the group's counter has reached `target`, then the workgroup barrier
 __device__ __forceinline__ void group_wait(gu32* cnt, unsigned target, gu32* tmo, bool& dead, unsigned limit) {
+    if (threadIdx.x == 0 && !dead && limit == 0xffffffffu) {      // test hook: the first wait of the launch "times out" whatever the timing
+        __hip_atomic_store(tmo, 1u, RLX_AGENT);
+        dead = true;
+    }
     if (threadIdx.x == 0 && !dead) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, RLX_AGENT) < target) {

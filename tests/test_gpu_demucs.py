@@ -548,7 +548,7 @@ def test_forced_handoff_timeout_skips_the_step_and_falls_back(tmp_path):
     mx, sr = s._prepare_batch(mix, clean)
     p0 = s.model.flat_params.detach().clone()
     ws = s.model.workspace(2, 8000)
-    ws.lstm_sync[61] = 1                                   # spin limit: one poll
+    ws.lstm_sync[61] = -1                                  # 0xffffffff: the first hand-off wait of every persistent launch times out
     s.train_step(mx, sr)
     torch.cuda.synchronize()
     assert int(ws.lstm_sync[60]) != 0, "the forced time-out did not fire"

@@ -39,3 +39,10 @@ for r in rs:
     per[k][0] += 1; per[k][1] += (r["e"] - r["s"]) / 1e3
 print("main queue, time by kernel (us):")
 for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:22]: print(f"  {t:9.1f}  x{n:4d}  {k}")
+
+# SEHIP_TRACE_TIMELINE=1: every kernel of the step on every queue in start order (queue tag, start, duration) -- who overlaps whom
+if os.environ.get("SEHIP_TRACE_TIMELINE"):
+    qn = {q: i for i, q in enumerate(sorted(byq, key=lambda q: -len(byq[q])))}
+    print("timeline (us from the step's first kernel): queue start dur name")
+    for r in step:
+        print(f"  q{qn[r['Queue_Id']]} {(r['s'] - t0) / 1e3:9.1f} {(r['e'] - r['s']) / 1e3:8.1f}  {r['Kernel_Name'].replace('void ', '')[:64]}")
