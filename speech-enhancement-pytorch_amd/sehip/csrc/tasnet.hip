@@ -607,6 +607,114 @@ __global__ __launch_bounds__(256) void ctn_decoder_fwd_kernel(const float* __res
     }
 }
 
+// The same on the MFMA pipe (N = 32 KS channels, one audio channel, L <= 16 TA samples per frame, 16 % speakers == 0):
+//   D[l][row] = sum_n V[l][n] sw[row][n],   rows = (frame, speaker) pairs, 16 per tile,
+// with V as the A operand (held in registers for the whole launch) and sw built in registers from w (fp32) and relu(mlin) (bf16)
+// as the B operand -- no serial dot products (the wave-per-frame kernel above spends 128 dependent LDS-read + FMA steps per frame
+// and speaker on 40 of its 64 lanes: 162 us at the C4 shape against 60 MB of operands).  Both operands are split into bf16 high
+// and low parts (hi hi + lo hi + hi lo: three MFMAs, error ~2^-16): this is the network's output, it stays at fp32 accuracy.
+// Overlap-add WITHOUT atomics: a tile holds FT = 16 / speakers consecutive frames of one utterance, first frame 7j - 1 for tile
+// j (FT = 8), and emits the FT - 1 hops of L / 2 samples that lie completely inside it (hop b = upper half of frame b - 1 + lower half
+// of frame b, through a wave-private LDS image): every output sample is written exactly once with plain, contiguous stores, so
+// `out` needs no zeroing.  (With 4.1 M scattered fp32 atomics the kernel took 96 us, with stores in their place 29 us.)
+template <int KS, int TA>
+__global__ __launch_bounds__(256) void ctn_decoder_fwd_mfma_kernel(const float* __restrict__ w, const bf16_raw* __restrict__ mlin,
+                                                                   const float* __restrict__ V /*[L][N]*/, int M, int K, int L, int Cs, int T,
+                                                                   float* __restrict__ out /*[M][Cs][T]*/) {
+    constexpr int N = 32 * KS, LP = 16 * TA + 1;
+    __shared__ float img[4][16][LP];
+    const int lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    auto split8 = [](const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_raw h0 = f2bf(x[2 * i]), h1 = f2bf(x[2 * i + 1]);
+            h[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+            l[i] = pack_bf2(x[2 * i] - bf2f(h0), x[2 * i + 1] - bf2f(h1));
+        }
+        hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+        lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    };
+    bf16x8 vhi[TA][KS], vlo[TA][KS];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int al = 16 * ta + c16;
+            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (al < L) {
+                const float4 v0 = *reinterpret_cast<const float4*>(V + (size_t)al * N + 32 * ks + 8 * g);
+                const float4 v1 = *reinterpret_cast<const float4*>(V + (size_t)al * N + 32 * ks + 8 * g + 4);
+                x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+            }
+            split8(x, vhi[ta][ks], vlo[ta][ks]);
+        }
+    const int step = L / 2, FT = 16 / Cs, HT = FT - 1;              // frames per tile, hops emitted per tile
+    const int tpu = (K + 1 + HT - 1) / HT;                          // tiles per utterance: hops 0 .. K
+    const long ntiles = (long)M * tpu;
+    const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
+    const int fi = c16 / Cs, c = c16 - fi * Cs;                     // this lane's row: frame inside the tile, speaker
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const int m = (int)(tile / tpu), j = (int)(tile - (long)m * tpu);
+        const int k = j * HT - 1 + fi;                              // frame of this lane's row
+        const bool rok = k >= 0 && k < K;
+        const long fr = (long)m * K + (rok ? k : 0);
+        f32x4 acc[TA];
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta) acc[ta] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 wa[KS][2];
+        uint4 ma[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {            // all of the row's loads first
+            const float* wp = w + fr * N + 32 * ks + 8 * g;
+            wa[ks][0] = *reinterpret_cast<const float4*>(wp);
+            wa[ks][1] = *reinterpret_cast<const float4*>(wp + 4);
+            ma[ks] = *reinterpret_cast<const uint4*>(mlin + fr * ((long)Cs * N) + (long)c * N + 32 * ks + 8 * g);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned mm[4] = {ma[ks].x, ma[ks].y, ma[ks].z, ma[ks].w};
+            const float ww[8] = {wa[ks][0].x, wa[ks][0].y, wa[ks][0].z, wa[ks][0].w, wa[ks][1].x, wa[ks][1].y, wa[ks][1].z, wa[ks][1].w};
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float m0 = __uint_as_float(mm[i] << 16), m1 = __uint_as_float(mm[i] & 0xffff0000u);
+                x[2 * i] = rok ? ww[2 * i] * (m0 > 0.f ? m0 : 0.f) : 0.f;
+                x[2 * i + 1] = rok ? ww[2 * i + 1] * (m1 > 0.f ? m1 : 0.f) : 0.f;
+            }
+            bf16x8 shi, slo;
+            split8(x, shi, slo);
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) {
+                acc[ta] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vhi[ta][ks], shi, acc[ta], 0, 0, 0);
+                acc[ta] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo[ta][ks], shi, acc[ta], 0, 0, 0);
+                acc[ta] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vhi[ta][ks], slo, acc[ta], 0, 0, 0);
+            }
+        }
+        // D row = sample 16 ta + 4 g + q, D column = this lane's row: the tile's frames as an image [row][sample]
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) img[wave][c16][16 * ta + 4 * g + q] = acc[ta][q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // hop b = 7 j + bi (bi < HT): samples [b step, (b + 1) step) = frame b - 1 (tile frame bi), upper half + frame b (tile frame bi + 1), lower half
+        const int nout = Cs * HT * step;
+        for (int o = lane; o < nout; o += 64) {
+            const int cc = o / (HT * step), rem = o - cc * (HT * step);
+            const int bi = rem / step, sidx = rem - bi * step;
+            const int b = j * HT + bi;
+            const long t = (long)b * step + sidx;
+            if (b <= K && t < T)
+                out[((long)m * Cs + cc) * T + t] = img[wave][bi * Cs + cc][step + sidx] + img[wave][(bi + 1) * Cs + cc][sidx];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // gacc: dV [AL][N] (fp32 atomics, caller zeroes).  dmlin [M][K][Cs*N] bf16, dw_dec [M][K][N] fp32 (overwritten)
 __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                                               const bf16_raw* __restrict__ mlin, const float* __restrict__ V, int M, int K,
@@ -904,6 +1012,18 @@ extern "C" int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, cons
     SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC, "ctn_decoder_fwd: bad N=%d", N);
     const size_t lds = ((size_t)ac * L * (N + 1) + 4 * N) * sizeof(float);
     SEHIP_REQUIRE(lds <= 64 * 1024, "ctn_decoder_fwd: %zu bytes of LDS needed", lds);
+    static const bool no_mfma = getenv("SEHIP_CTN_NO_MFMA_DECODER") != nullptr;
+    if (!no_mfma && N == 128 && ac == 1 && L <= 48 && (L & 1) == 0 && Cs >= 1 && Cs <= 8 && 16 % Cs == 0) {
+        const int HT = 16 / Cs - 1;
+        const long tiles = (long)M * ((K + 1 + HT - 1) / HT);
+        // the basis is loaded into registers once per wave: few, long-lived waves
+        static const int cap = getenv("SEHIP_CTN_DEC_WGS") ? atoi(getenv("SEHIP_CTN_DEC_WGS")) : 512;
+        long gm = (tiles + 3) / 4;
+        if (gm > cap) gm = cap;
+        ctn_decoder_fwd_mfma_kernel<4, 3><<<(int)gm, 256, 0, (hipStream_t)stream>>>(w, (const bf16_raw*)mlin_bf16, V, M, K, L, Cs, T, out);
+        SEHIP_CHECK_LAUNCH("ctn_decoder_fwd(mfma)");
+        return 0;
+    }
     long g = ((long)M * K + 3) / 4;
     if (g > 2048) g = 2048;
     ctn_decoder_fwd_kernel<<<(int)g, 256, lds, (hipStream_t)stream>>>(w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, out);
