@@ -98,6 +98,112 @@ __global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __res
     }
 }
 
+// The same on the MFMA pipe (one audio channel, N = 128, L <= 64): 16 frames per tile,
+//   D[n][frame] = sum_l U[n][l] x[frame][l]   (U = A operand, in registers for the whole launch; x = B operand, 8 consecutive
+// samples per lane straight from the waveform), both split into bf16 high + low parts (three MFMAs, ~2^-16: `w` multiplies the
+// mask at the decoder, it stays at fp32 accuracy).  A lane ends up with 32 of its frame's 128 channels (4 consecutive ones per
+// 16-channel tile); the channel-wise LayerNorm sums meet the other three lanes of the frame through two xor-shuffles.  The
+// wave-per-frame kernel above walks 40 taps with a dependent waveform load and two LDS reads each: 84 us against 43 MB of traffic.
+template <int KS>
+__global__ __launch_bounds__(256) void ctn_encoder_fwd_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ U /*[128][L]*/,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int M,
+                                                                   int T, int K, int L, float* __restrict__ w, bf16_raw* __restrict__ cln) {
+    constexpr int N = 128, TNN = 8;
+    const int lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4;
+    auto split8 = [](const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_raw h0 = f2bf(x[2 * i]), h1 = f2bf(x[2 * i + 1]);
+            h[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+            l[i] = pack_bf2(x[2 * i] - bf2f(h0), x[2 * i + 1] - bf2f(h1));
+        }
+        hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+        lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    };
+    bf16x8 uhi[TNN][KS], ulo[TNN][KS];
+#pragma unroll
+    for (int tn = 0; tn < TNN; ++tn)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int l0 = 32 * ks + 8 * g;
+            if (l0 + 8 <= L && (L & 3) == 0) {          // (rows of U are 16-byte aligned when L is a multiple of 4)
+                const float4 v0 = *reinterpret_cast<const float4*>(U + (size_t)(16 * tn + c16) * L + l0);
+                const float4 v1 = *reinterpret_cast<const float4*>(U + (size_t)(16 * tn + c16) * L + l0 + 4);
+                x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (l0 + j < L) x[j] = U[(size_t)(16 * tn + c16) * L + l0 + j];
+            }
+            split8(x, uhi[tn][ks], ulo[tn][ks]);
+        }
+    float4 gm[TNN], bt[TNN];
+#pragma unroll
+    for (int tn = 0; tn < TNN; ++tn) {
+        gm[tn] = *reinterpret_cast<const float4*>(gamma + 16 * tn + 4 * g);
+        bt[tn] = *reinterpret_cast<const float4*>(beta + 16 * tn + 4 * g);
+    }
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    const long ntiles = (frames + 15) / 16;
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long tile = wave_id; tile < ntiles; tile += nwaves) {
+        const long fr = tile * 16 + c16;
+        const bool rok = fr < frames;
+        const long frc = rok ? fr : 0;
+        const int m = (int)(frc / K), k = (int)(frc - (long)m * K);
+        const float* x0 = wav + (long)m * T + (long)k * step;
+        bf16x8 xhi[KS], xlo[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int l = 32 * ks + 8 * g + j;
+                x[j] = (rok && l < L) ? x0[l] : 0.f;
+            }
+            split8(x, xhi[ks], xlo[ks]);
+        }
+        f32x4 acc[TNN];
+#pragma unroll
+        for (int tn = 0; tn < TNN; ++tn) {
+            acc[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uhi[tn][ks], xhi[ks], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ulo[tn][ks], xhi[ks], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uhi[tn][ks], xlo[ks], acc[tn], 0, 0, 0);
+            }
+        }
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < TNN; ++tn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[tn][e] > 0.f ? acc[tn][e] : 0.f;
+                acc[tn][e] = v; s += v; q += v * v;
+            }
+        s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+        const float mean = s / N;
+        float var = q / N - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rs = 1.f / sqrtf(var + CTN_EPS);
+        if (rok) {
+#pragma unroll
+            for (int tn = 0; tn < TNN; ++tn) {
+                const f32x4 v = acc[tn];
+                *reinterpret_cast<float4*>(w + fr * N + 16 * tn + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint2*>(cln + fr * N + 16 * tn + 4 * g) =
+                    make_uint2(pack_bf2(gm[tn].x * (v[0] - mean) * rs + bt[tn].x, gm[tn].y * (v[1] - mean) * rs + bt[tn].y),
+                               pack_bf2(gm[tn].z * (v[2] - mean) * rs + bt[tn].z, gm[tn].w * (v[3] - mean) * rs + bt[tn].w));
+            }
+        }
+    }
+}
+
 // backward of cLN + ReLU + encoder conv:  dw = dw_dec + cLN'(dcln);  dpre = dw [w > 0];  dU[n][l] += dpre x[l]
 // gacc: dU [N][ac*L] | dgamma [N] | dbeta [N]   (fp32, atomics; caller zeroes)
 __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w,
@@ -900,6 +1006,15 @@ extern "C" int sehip_ctn_encoder_fwd(const float* wav, const float* U, const flo
     const int K = (T - L) / (L / 2) + 1;
     const size_t lds = (size_t)N * ac * L * sizeof(float);
     SEHIP_REQUIRE(lds <= 64 * 1024, "ctn_encoder_fwd: basis of %zu bytes does not fit the LDS budget", lds);
+    static const bool no_mfma = getenv("SEHIP_CTN_NO_MFMA_ENCODER") != nullptr;
+    if (!no_mfma && N == 128 && ac == 1 && L <= 64) {
+        static const int cap = getenv("SEHIP_CTN_ENC_WGS") ? atoi(getenv("SEHIP_CTN_ENC_WGS")) : 512;
+        long gm = (((long)M * K + 15) / 16 + 3) / 4;
+        if (gm > cap) gm = cap;
+        ctn_encoder_fwd_mfma_kernel<2><<<(int)gm, 256, 0, (hipStream_t)stream>>>(wav, U, gamma, beta, M, T, K, L, w, (bf16_raw*)cln_bf16);
+        SEHIP_CHECK_LAUNCH("ctn_encoder_fwd(mfma)");
+        return 0;
+    }
     long g = ((long)M * K + 3) / 4;
     if (g > 2048) g = 2048;
     ctn_encoder_fwd_kernel<<<(int)g, 256, lds, (hipStream_t)stream>>>(wav, U, gamma, beta, M, ac, T, K, N, L, w, (bf16_raw*)cln_bf16);
