@@ -365,6 +365,151 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_reg_kernel(const float* _
     for (int i = threadIdx.x; i < ncols; i += 256) row[i] = srow[i];
 }
 
+// The same pass on the MFMA pipe (one audio channel, N = 128, L <= 16 TL): tiles of 32 frames,
+//   dU[n][l] += sum_frames dpre[frame][n] x[frame][l]   as   D[n][l] = A[n][frame] B[frame][l].
+// Lane (c16, g) does the elementwise part (cLN backward + ReLU mask) for channels 16 tn + c16 (tn < 8) of frames 8 g .. 8 g + 7 --
+// exactly the 8 consecutive k values of the MFMA's A operand row n, so dpre goes from registers straight into the MFMA; the
+// per-frame sums over the 128 channels are four xor-shuffles over the 16 lanes that share g.  B: 8 samples x[frame][l] per lane,
+// strided loads from the waveform, split into bf16 high + low parts (dpre is rounded to bf16 once: a weight gradient).  One
+// partial row per workgroup as above.
+// (The register kernel above walks the frames one by one, 40 v_readlane + 80 FMA steps each: 195 us at the C4 shape.)
+template <int TL, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void ctn_encoder_bwd_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                                      const bf16_raw* __restrict__ dcln, const float* __restrict__ dw_dec,
+                                                                      const float* __restrict__ gamma, int M, int T, int K, int L,
+                                                                      float* __restrict__ part) {
+    constexpr int N = 128, TNN = 8;
+    // per wave: the A operand as it is built, [tn][lane][8 frames] bf16, and the B operand's samples, [tl][lane][8 frames] fp32 -- a
+    // lane reads back exactly what it wrote (the frame loop is a real loop: unrolled, its 216 loads per tile took 512 registers)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ebw_smem[];
+    const int lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    constexpr int WBYTES = TNN * 64 * 16 + TL * 64 * 32;
+    bf16_raw* sdp = reinterpret_cast<bf16_raw*>(ebw_smem + wave * WBYTES);
+    float* sxs = reinterpret_cast<float*>(ebw_smem + wave * WBYTES + TNN * 64 * 16);
+    float* srow = reinterpret_cast<float*>(ebw_smem + 4 * WBYTES);          // [N*L + 2N]
+    auto split8 = [](const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_raw h0 = f2bf(x[2 * i]), h1 = f2bf(x[2 * i + 1]);
+            h[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+            l[i] = pack_bf2(x[2 * i] - bf2f(h0), x[2 * i + 1] - bf2f(h1));
+        }
+        hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+        lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    };
+    auto sum16 = [](float v) {          // over the 16 lanes that share g
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        return v;
+    };
+    float gam[TNN], dgl[TNN], dbl[TNN];
+#pragma unroll
+    for (int tn = 0; tn < TNN; ++tn) { gam[tn] = gamma[16 * tn + c16]; dgl[tn] = 0.f; dbl[tn] = 0.f; }
+    f32x4 acc[TNN][TL];
+#pragma unroll
+    for (int tn = 0; tn < TNN; ++tn)
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) acc[tn][tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int step = L / 2;
+    const long frames = (long)M * K;
+    const long ntiles = (frames + 31) / 32;
+    const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
+    for (long tile = wave_id; tile < ((ABL & 2) ? 0 : ntiles); tile += nwaves) {
+        const long f0 = tile * 32 + 8 * g;
+#pragma unroll 2
+        for (int j = 0; j < 8; ++j) {
+            const long f = f0 + j;
+            const bool ok = f < frames;
+            const long fc = ok ? f : 0;
+            float wv[TNN], dy[TNN], dd[TNN];
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TNN; ++tn) {
+                wv[tn] = w[fc * N + 16 * tn + c16];
+                dy[tn] = bf2f(dcln[fc * N + 16 * tn + c16]);
+                dd[tn] = dw_dec[fc * N + 16 * tn + c16];
+                s += wv[tn]; q += wv[tn] * wv[tn];
+            }
+            const int m = (int)(fc / K), k = (int)(fc - (long)m * K);
+            const float* x0 = wav + (long)m * T + (long)k * step;
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) {
+                const int l = 16 * tl + c16;
+                sxs[(tl * 64 + lane) * 8 + j] = (ok && l < L) ? x0[l] : 0.f;
+            }
+            s = sum16(s); q = sum16(q);
+            const float mean = s / N;
+            float var = q / N - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float rs = 1.f / sqrtf(var + CTN_EPS);
+            float s1 = 0.f, s2 = 0.f, xh[TNN];
+#pragma unroll
+            for (int tn = 0; tn < TNN; ++tn) {
+                xh[tn] = (wv[tn] - mean) * rs;
+                s1 += gam[tn] * dy[tn]; s2 += gam[tn] * dy[tn] * xh[tn];
+                if (ok) { dgl[tn] += dy[tn] * xh[tn]; dbl[tn] += dy[tn]; }
+            }
+            s1 = sum16(s1) / N; s2 = sum16(s2) / N;
+#pragma unroll
+            for (int tn = 0; tn < TNN; ++tn) {
+                const float dwv = (gam[tn] * dy[tn] - s1 - xh[tn] * s2) * rs + dd[tn];
+                sdp[(tn * 64 + lane) * 8 + j] = f2bf((ok && wv[tn] > 0.f) ? dwv : 0.f);
+            }
+        }
+        // (a lane reads its own LDS words: the LDS queue of a wave is in order, no barrier)
+        bf16x8 xhi[TL], xlo[TL];
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) {
+            const float4 a = *reinterpret_cast<const float4*>(&sxs[(tl * 64 + lane) * 8]);
+            const float4 b = *reinterpret_cast<const float4*>(&sxs[(tl * 64 + lane) * 8 + 4]);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            split8(x, xhi[tl], xlo[tl]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TNN; ++tn) {
+            const bf16x8 a8 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sdp[(tn * 64 + lane) * 8]));
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) {
+                acc[tn][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, xhi[tl], acc[tn][tl], 0, 0, 0);
+                acc[tn][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, xlo[tl], acc[tn][tl], 0, 0, 0);
+            }
+        }
+    }
+    // the four waves' sums meet in LDS, one wave after the other with plain read-add-write (inside a wave every address is touched
+    // by one lane).  With ds_add_f32 from all four waves at once the 112 atomics per lane took 78 of this kernel's 98 us (~200
+    // cycles per wave instruction); one row per workgroup in gacc layout (dU [N][L] | dgamma [N] | dbeta [N])
+    const int ncols = N * L + 2 * N;
+    for (int i = threadIdx.x; i < ncols; i += 256) srow[i] = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < TNN; ++tn) {          // dgamma / dbeta: the four g lanes of a wave hold different frames of the same channel
+        dgl[tn] += __shfl_xor(dgl[tn], 16, 64); dgl[tn] += __shfl_xor(dgl[tn], 32, 64);
+        dbl[tn] += __shfl_xor(dbl[tn], 16, 64); dbl[tn] += __shfl_xor(dbl[tn], 32, 64);
+    }
+    __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn && !(ABL & 1)) {
+#pragma unroll
+            for (int tn = 0; tn < TNN; ++tn) {
+#pragma unroll
+                for (int tl = 0; tl < TL; ++tl) {
+                    const int l = 16 * tl + c16;          // D row = channel 16 tn + 4 g + e, D column = sample l
+                    if (l < L) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) srow[(16 * tn + 4 * g + e) * L + l] += acc[tn][tl][e];
+                    }
+                }
+                if (g == 0) {
+                    srow[N * L + 16 * tn + c16] += dgl[tn];
+                    srow[N * L + N + 16 * tn + c16] += dbl[tn];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* row = part + (size_t)blockIdx.x * ncols;
+    for (int i = threadIdx.x; i < ncols; i += 256) row[i] = srow[i];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // global LayerNorm pieces.  Rows of utterance m: [m*K, (m+1)*K).  grid = (blocks per utterance, M).
 // ------------------------------------------------------------------------------------------------------------------
@@ -1051,6 +1196,22 @@ extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const voi
     const int ncols = ac * L * N + 2 * N;
     const int AL = ac * L, NC = (N + 63) / 64;
     const size_t rlds = (size_t)ncols * sizeof(float);
+    static const bool no_mfma = getenv("SEHIP_CTN_NO_MFMA_ENCODER") != nullptr;
+    if (!no_mfma && N == 128 && ac == 1 && L <= 48 && rlds <= 64 * 1024) {
+        static const int cap = getenv("SEHIP_CTN_ENCB_WGS") ? atoi(getenv("SEHIP_CTN_ENCB_WGS")) : 512;
+        static bool attr_m = false;
+        if (!attr_m) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_m = true; }
+        long tiles4 = ((frames + 31) / 32 + 3) / 4;
+        const int gm = (int)(tiles4 < cap ? tiles4 : cap) < grid ? (int)(tiles4 < cap ? tiles4 : cap) : grid;   // rows of `scratch`: at most the old grid
+        static const int abl = getenv("SEHIP_CTN_ENCB_ABL") ? atoi(getenv("SEHIP_CTN_ENCB_ABL")) : 0;
+        if (abl == 1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_mfma_kernel<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); ctn_encoder_bwd_mfma_kernel<3, 1><<<gm, 256, rlds + 4 * (8 * 64 * 16 + 3 * 64 * 32), st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, T, K, L, scratch); }
+        else if (abl == 2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_mfma_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); ctn_encoder_bwd_mfma_kernel<3, 2><<<gm, 256, rlds + 4 * (8 * 64 * 16 + 3 * 64 * 32), st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, T, K, L, scratch); }
+        else
+        ctn_encoder_bwd_mfma_kernel<3><<<gm, 256, rlds + 4 * (8 * 64 * 16 + 3 * 64 * 32), st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, T, K, L, scratch);
+        ctn_colsum_kernel<<<ctn_colsum_grid(gm, ncols), 256, 0, st>>>(scratch, gm, ncols, gacc);
+        SEHIP_CHECK_LAUNCH("ctn_encoder_bwd(mfma)");
+        return 0;
+    }
 #define ENC_REG(AL_, NC_) ctn_encoder_bwd_reg_kernel<AL_, NC_><<<grid, 256, rlds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch)
     if (AL == 40 && NC == 2 && rlds <= 64 * 1024) ENC_REG(40, 2);
     else if (AL == 40 && NC == 1) ENC_REG(40, 1);
