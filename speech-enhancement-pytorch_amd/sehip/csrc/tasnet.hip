@@ -1098,15 +1098,21 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_reg_kernel(const float* _
     __syncthreads();                                   // everybody is done with V
     for (int i = threadIdx.x; i < AL * N; i += 256) sV[i] = 0.f;
     __syncthreads();
+    // one wave after the other, plain read-add-write (a wave's lanes touch distinct words): ds_add_f32 from four waves at once on the
+    // same words costs ~200 cycles per wave instruction (measured in ctn_encoder_bwd_mfma_kernel)
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int n = lane + 64 * i;
-        if (n < N) {
+            for (int i = 0; i < NC; ++i) {
+                const int n = lane + 64 * i;
+                if (n < N) {
 #pragma unroll
-            for (int al = 0; al < AL; ++al) atomicAdd(&sV[al * N + n], acc[i][al]);
+                    for (int al = 0; al < AL; ++al) sV[al * N + n] += acc[i][al];
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float* row = part + (size_t)blockIdx.x * (AL * N);
     for (int i = threadIdx.x; i < AL * N; i += 256) row[i] = sV[i];
 }
