@@ -659,15 +659,20 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
     const bf16_raw* gb = g + (long)m * K * C + pm.c0;
     const bf16_raw* hb = h + (long)m * K * C + pm.c0;
     float s1 = 0.f, s2 = 0.f;
+    float dg[8], db[8], dw[DW ? P : 1][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dg[j] = 0.f; db[j] = 0.f;
+#pragma unroll
+        for (int p = 0; p < (DW ? P : 1); ++p) dw[p][j] = 0.f;
+    }
     if (pm.active) {
         float gm[8], bt[8], wd[DW ? P : 1][8];
-        float dg[8], db[8], dw[DW ? P : 1][8];
         ld8f(gamma + pm.c0, gm); ld8f(beta + pm.c0, bt);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            dg[j] = 0.f; db[j] = 0.f;
 #pragma unroll
-            for (int p = 0; p < (DW ? P : 1); ++p) { dw[p][j] = 0.f; wd[p][j] = DW ? Wd[(pm.c0 + j) * P + p] : 0.f; }
+            for (int p = 0; p < (DW ? P : 1); ++p) wd[p][j] = DW ? Wd[(pm.c0 + j) * P + p] : 0.f;
         }
         for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
             const C8 x = ld8(hb + (long)t * C);
@@ -709,6 +714,38 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
                 dg[j] += dy.v[j] * xh; db[j] += dy.v[j];
             }
         }
+    }
+    // per-channel partials of the block.  nq a power of two <= 64: the lanes of a wave that hold the same channels (nq apart) meet by
+    // xor-shuffles, then the four waves add their words one after the other with plain read-add-write (ds_add_f32 from all lanes
+    // at once: 8 lanes per word, ~200 cycles per wave instruction, 40 of them); otherwise LDS atomics
+    if ((nq & (nq - 1)) == 0 && nq <= 64) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            for (int o = nq; o < 64; o <<= 1) {
+                dg[j] += __shfl_xor(dg[j], o, 64); db[j] += __shfl_xor(db[j], o, 64);
+                if (DW) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) dw[p][j] += __shfl_xor(dw[p][j], o, 64);
+                }
+            }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int c0 = (lane % nq) * 8;                     // (= pm.c0 for the lanes below nq)
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wave == turn && lane < nq) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    lds[c0 + j] += dg[j];
+                    lds[C + c0 + j] += db[j];
+                    if (DW) {
+#pragma unroll
+                        for (int p = 0; p < P; ++p) lds[2 * C + (c0 + j) * P + p] += dw[p][j];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else if (pm.active) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             atomicAdd(&lds[pm.c0 + j], dg[j]);
