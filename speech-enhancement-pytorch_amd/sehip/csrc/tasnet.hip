@@ -659,6 +659,7 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
     const bf16_raw* gb = g + (long)m * K * C + pm.c0;
     const bf16_raw* hb = h + (long)m * K * C + pm.c0;
     float s1 = 0.f, s2 = 0.f;
+    float qa = 0.f, qb = 0.f, qc = 0.f;      // slope gradient, see below: sums over the elements with h <= 0 of gamma dy h, h, xh h
     float dg[8], db[8], dw[DW ? P : 1][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
                 const float gd = gm[j] * dy.v[j];
                 s1 += gd; s2 += gd * xh;
                 dg[j] += dy.v[j] * xh; db[j] += dy.v[j];
+                if (!(x.v[j] > 0.f)) { qa += gd * x.v[j]; qb += x.v[j]; qc += xh * x.v[j]; }
             }
         }
     }
@@ -759,6 +761,18 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
     block_add2_double(s1, s2, sums + 2 * m);      // (contains a __syncthreads: the LDS partials are complete after it)
     float* row = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NV * C);
     for (int i = threadIdx.x; i < NV * C; i += 256) row[i] = lds[i];
+    // The PReLU slope's gradient is sum over h <= 0 of dv h with dv = (gamma dy - S1/n - xh S2/n) / sigma, i.e. LINEAR in the three
+    // sums taken here; the apply pass used to add it with one fp32 atomic per workgroup on ONE address (1 600 per launch, 28
+    // launches: 0.33 ms of the 4.05-ms step went into that queue).  Three floats per workgroup behind the partial rows instead.
+    __shared__ float qred[3][4];
+    qa = wave_sum(qa); qb = wave_sum(qb); qc = wave_sum(qc);
+    if ((threadIdx.x & 63) == 0) { qred[0][threadIdx.x >> 6] = qa; qred[1][threadIdx.x >> 6] = qb; qred[2][threadIdx.x >> 6] = qc; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float* extra = part + (size_t)gridDim.x * gridDim.y * (NV * C);
+        extra[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+            qred[threadIdx.x][0] + qred[threadIdx.x][1] + qred[threadIdx.x][2] + qred[threadIdx.x][3];
+    }
 }
 
 // out[c] += sum over rows of part[row][c]   (grid = (ceil(ncols / 256), row splits); out zeroed by the caller)
@@ -803,7 +817,27 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
     const bf16_raw* gb = g + (long)m * K * C + pm.c0;
     const bf16_raw* hb = h + (long)m * K * C + pm.c0;
     bf16_raw* out = dh + (long)m * K * C + pm.c0;
-    float da = 0.f;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        // slope gradient from the reduce pass's three sums per workgroup (rows of `part` = M utterances x gx workgroups each)
+        const int M_ = gridDim.y, gx = nrows / M_;
+        const float* extra = part + (size_t)nrows * ncols;
+        double acc = 0.0;
+        for (int mm = threadIdx.x; mm < M_; mm += 256) {
+            double qa = 0.0, qb = 0.0, qc = 0.0;
+            for (int i = 0; i < gx; ++i) {
+                const float* e = extra + ((size_t)mm * gx + i) * 3;
+                qa += e[0]; qb += e[1]; qc += e[2];
+            }
+            float mu_, rs_;
+            gln_moments(stats, mm, (long)K * C, mu_, rs_);
+            acc += (double)rs_ * (qa - sums[2 * mm] / n * qb - sums[2 * mm + 1] / n * qc);
+        }
+        __shared__ double dred[4];
+        acc = wave_sum_d(acc);
+        if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dslope, (float)(dred[0] + dred[1] + dred[2] + dred[3]));
+    }
     if (pm.active) {
         float gm[8], wd[DW ? P : 1][8];
         ld8f(gamma + pm.c0, gm);
@@ -838,17 +872,11 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
             for (int j = 0; j < 8; ++j) {
                 const float xh = (prelu(x.v[j], a) - mu) * rs;
                 const float dv = (gm[j] * dy.v[j] - k1 - xh * k2) * rs;
-                if (x.v[j] > 0.f) o[j] = dv;
-                else { o[j] = a * dv; da += dv * x.v[j]; }
+                o[j] = x.v[j] > 0.f ? dv : a * dv;
             }
             st8(out + (long)t * C, o);
         }
     }
-    __shared__ float red[4];
-    da = wave_sum(da);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = da;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dslope, red[0] + red[1] + red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1298,7 +1326,7 @@ extern "C" int sehip_ctn_gln_apply(const void* h, const float* slope, const doub
 // sehip_ctn_gln_bwd_scratch_floats(M, K, C) floats (the blocks' per-channel partial rows).
 extern "C" long sehip_ctn_gln_bwd_scratch_floats(int M, int K, int C) {
     const dim3 grid = ctn_reduce_grid(M, K, C);
-    return (long)grid.x * grid.y * 5L * C;
+    return (long)grid.x * grid.y * (5L * C + 3);          // partial rows + three slope-gradient sums per workgroup
 }
 
 extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
