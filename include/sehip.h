@@ -225,6 +225,9 @@ typedef struct {
      * LDS-DMA instruction then reads 1 KB of whole cache lines.  Only that kernel reads such a W: sehip_gemm fails loudly when
      * the descriptor does not qualify for it. */
     int32_t w_tiled;
+    /* sehip_wgrad, generic kernel only: workgroups to aim for (0: the library's rule).  The weight gradients run beside the step's
+     * dependent chain, and how many workgroups are best depends on that chain, which only the plan knows (ConvTasNet: 160). */
+    int32_t wg_hint;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);

@@ -2470,7 +2470,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     // second stream: for the dense row spaces of the 1-D models (J == 1: ConvTasNet's 51 168 rows, Demucs' 736 .. 775 488) ~256
     // workgroups with 1 500 - 3 000 rows each beat 2048 small ones -- Demucs 25.35 -> 24.03 ms per step (128: 26.65), ConvTasNet
     // 5.19 -> 4.88 (128: 4.79, 96: 5.28), e0.rw of Demucs alone 275 -> 161 us; DCUnet's 2-D products keep the 2048 (512: +1 %)
-    const int gw_wgs = gw_env ? gw_env : ((d->J == 1 && d->cv_nf == 0 && d->cv2_nkt == 0) ? 256 : 2048);
+    // (round 3, with ConvTasNet's chain 20 % shorter, its small products -- four (n, k) tiles -- are best at ~160: 96: 4.28, 128: 3.68,
+    //  160: 3.59, 192: 3.79, 256: 3.75 ms per step; Demucs keeps 256: 128: 23.5, 192: 21.1, 256: 20.7)
+    //  -- the plan says so through the descriptor's wg_hint)
+    const int gw_wgs = gw_env ? gw_env : (d->wg_hint > 0 ? d->wg_hint : ((d->J == 1 && d->cv_nf == 0 && d->cv2_nkt == 0) ? 256 : 2048));
     long want = gw_wgs / ((long)ntiles * ktiles);
     if (want < 1) want = 1;
     long mpb = ((d->M + want - 1) / want + 63) / 64 * 64;
