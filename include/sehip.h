@@ -228,6 +228,11 @@ typedef struct {
     /* sehip_wgrad, generic kernel only: workgroups to aim for (0: the library's rule).  The weight gradients run beside the step's
      * dependent chain, and how many workgroups are best depends on that chain, which only the plan knows (ConvTasNet: 160). */
     int32_t wg_hint;
+    /* 1: the caller vouches that the product is a plain dense one -- ONE source whose row m is the K contiguous elements at m K
+     * (J = 1, F = 1, C = K, every frame valid, trivial chunk table) and ONE bf16 destination / dOut whose row m is the N = Npad
+     * contiguous elements at m N: the 1x1 convolutions of ConvTasNet (src/model/conv_tasnet.py:307-402).  sehip_wgrad may then take
+     * dense_wgrad_kernel (N, K in {128, 256}); whatever it does not take runs as before. */
+    int32_t dense_rows;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);

@@ -641,6 +641,7 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st);   // conv3
 void sehip_conv3_init(void);
 int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 void sehip_wgrad3_init(void);
+int sehip_try_dense_wgrad(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 
 // returns 1 if the LDS-patch kernel was launched, 0 if the descriptor does not qualify
 static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
@@ -2452,6 +2453,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     }
     if (try_conv_small_wgrad(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv-small)");
+        return 0;
+    }
+    if (d->dense_rows && sehip_try_dense_wgrad(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(dense)");
         return 0;
     }
     int ntiles, bnw;

@@ -316,6 +316,156 @@ static void w3_launch(const sehip_gemm_desc& d, int grid, int tiles_per_wg, int 
         conv_wgrad_v3_kernel<NF, FM, J, 3><<<grid, 512, w3_lds_bytes<NF, FM, J, 3>(), st>>>(d, tiles_per_wg, splits, scratch);
     }
 }
+// ------------------------------------------------------------------------------------------------------------------------------
+// dense_wgrad_kernel: dW[N][K] += dOut[M][N]^T A[M][K] for plain dense products (J = 1, one source whose row m is K contiguous
+// elements, one bf16 dOut whose row m is N contiguous elements): the 1x1 convolutions of ConvTasNet (src/model/conv_tasnet.py:307-402),
+// N, K in {128, 256}, M = 51 168 rows.  The table-gathered wgrad_kernel walks 64-row slabs with two barriers and a register-staged
+// tile each: 52 us per launch for 39 MB of operands.  Here ONE workgroup holds the whole dW (N K = 32 768 accumulators = 64 per
+// lane of 8 waves) and streams its share of the rows in 64-row stages: both operands by LDS-DMA into [16 columns][64 rows][32 B]
+// planes (conflict-free transposed reads, as conv_wgrad_v3_kernel), one barrier per stage; the flush is the store + reduction of
+// conv_wgrad_v3.  Rows past M are beyond num_records: zeros.
+template <int N, int K, int NB>
+__global__ __launch_bounds__(512, 2) void dense_wgrad_kernel(const sehip_gemm_desc d, int stages_per_wg, float* scratch) {
+    constexpr int WN = N >= 256 ? 4 : 2, WK = 8 / WN;               // waves along n / along k
+    constexpr int TN = N / WN / 16, TK = K / WK / 16;               // MFMA tiles per wave
+    constexpr int GB = N * 64 * 2, XB = K * 64 * 2, STAGE = GB + XB;
+    constexpr int GI = GB / 16 / 512, XI = XB / 16 / 512, NI = GI + XI;
+    static_assert(GB % (16 * 512) == 0 && XB % (16 * 512) == 0, "whole DMA instructions");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv % WN, wk = wv / WN;
+    const int nstages = (d.M + 63) / 64;
+    const int s_begin = blockIdx.x * stages_per_wg, s_end = min(nstages, s_begin + stages_per_wg);
+    const int ns = s_end - s_begin;
+    if (ns <= 0) return;
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d.dst[0].ptr)), 0, (unsigned)((size_t)d.M * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d.src[0].ptr)), 0, (unsigned)((size_t)d.M * K * 2), 0x00020000);
+    // piece i = (8 u + wave) * 64 + lane of an image: plane i >> 7, row (i >> 1) & 63, half i & 1  <-  X[m0 + row][16 plane + 8 half]
+    unsigned goff[GI], xoff[XI];
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+        const int i = (u * 8 + wv) * 64 + lane;
+        goff[u] = 2u * (unsigned)(((i >> 1) & 63) * N + (i >> 7) * 16 + (i & 1) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+        const int i = (u * 8 + wv) * 64 + lane;
+        xoff[u] = 2u * (unsigned)(((i >> 1) & 63) * K + (i >> 7) * 16 + (i & 1) * 8);
+    }
+    auto issue = [&](int stage, int buf) {            // past the end: offsets beyond num_records, zeros (constant DMA count)
+        unsigned char* base = smem + buf * STAGE + wv * 1024;
+        const unsigned gs = (unsigned)stage * (64u * N * 2u), xs = (unsigned)stage * (64u * K * 2u);
+#pragma unroll
+        for (int u = 0; u < GI; ++u) {
+            const unsigned vo = goff[u] + gs;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (w3_lds_void*)(base + u * 8192), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < XI; ++u) {
+            const unsigned vo = xoff[u] + xs;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (w3_lds_void*)(base + GB + u * 8192), 16, vo, 0, 0, 0);
+        }
+    };
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+    const int ga = (wn * TN) * 2048 + (4 * g + q) * 32 + 8 * p4;              // + tn * 2048 + ks * 1024 + h * 512
+    const int xa = GB + (wk * TK) * 2048 + (4 * g + q) * 32 + 8 * p4;
+    f32x4 acc[TN][TK];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NB - 1; ++s) issue(s_begin + s < s_end ? s_begin + s : nstages, s);
+    int buf = 0;
+    for (int s = 0; s < ns; ++s) {
+        w3_wait_vm<(NB - 2) * NI>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int nx = s_begin + s + NB - 1;
+            issue(nx < s_end ? nx : nstages, buf == 0 ? NB - 1 : buf - 1);
+        }
+        const unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 gf[TN], xf[TK];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_s16x4*)(sb + ga + tn * 2048 + ks * 1024));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_s16x4*)(sb + ga + tn * 2048 + ks * 1024 + 512));
+                gf[tn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int tk = 0; tk < TK; ++tk) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_s16x4*)(sb + xa + tk * 2048 + ks * 1024));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_s16x4*)(sb + xa + tk * 2048 + ks * 1024 + 512));
+                xf[tk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tk = 0; tk < TK; ++tk)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[tn], xf[tk], acc[tn][tk], 0, 0, 0);
+        }
+        buf = buf == NB - 1 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* out = scratch ? scratch + (size_t)blockIdx.x * N * K : d.dW;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) {
+            const int n = (wn * TN + tn) * 16 + 4 * (lane >> 4);
+            const int k = (wk * TK + tk) * 16 + (lane & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (scratch) out[(size_t)(n + u) * K + k] = acc[tn][tk][u];
+                else atomicAdd(&out[(size_t)(n + u) * K + k], acc[tn][tk][u]);
+            }
+        }
+}
+
+template <int N, int K>
+static int dw_launch(const sehip_gemm_desc& d, hipStream_t st) {
+    constexpr int NB = 2;
+    constexpr size_t lds = (size_t)NB * (N + K) * 64 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_wgrad_kernel<N, K, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    static const int env_wgs = getenv("SEHIP_DW_WGS") ? atoi(getenv("SEHIP_DW_WGS")) : 0;
+    const int want = env_wgs ? env_wgs : (d.wg_hint > 0 ? d.wg_hint : 128);
+    const int nstages = (d.M + 63) / 64;
+    int spw = (nstages + want - 1) / want;
+    if (spw < 2) spw = 2;
+    const int grid = (nstages + spw - 1) / spw;
+    const size_t n = (size_t)N * K;
+    float* scratch = w3_scratch_for(st, (size_t)grid * n * sizeof(float));
+    sehip_note_kernel("dense_wgrad_kernel<%d, %d>", N, K);
+    dense_wgrad_kernel<N, K, NB><<<grid, 512, lds, st>>>(d, spw, scratch);
+    if (scratch) w3_reduce_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, grid, n / 4, d.dW);
+    return 1;
+}
+
+// returns 1 if the kernel was launched, 0 if the descriptor does not qualify (the caller goes on to wgrad_kernel)
+int sehip_try_dense_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_DENSE_WGRAD") != nullptr;
+    if (disabled || d.cv_nf > 0 || d.cv2_nkt > 0 || d.J != 1 || d.tmul > 1 || d.dbias) return 0;
+    if (d.src[1].ptr || d.dst[1].ptr || d.dst[0].is_f32) return 0;
+    if (d.N != d.Npad || d.src[0].C != d.K || d.src[0].F != 1 || d.dst[0].C != d.Npad || d.dst[0].F != 1) return 0;
+    if (d.src[0].T != d.TT || d.src[0].tlo != 0 || d.src[0].thi != d.TT || d.dst[0].T != d.TT || d.dst[0].toff || d.dst[0].fadd ||
+        d.dst[0].tmul > 1) return 0;
+    if ((size_t)d.M * 256 * 2 >= (1ull << 32) - (1u << 20)) return 0;
+    if (d.Npad == 256 && d.K == 128) return dw_launch<256, 128>(d, st);
+    if (d.Npad == 128 && d.K == 256) return dw_launch<128, 256>(d, st);
+    if (d.Npad == 128 && d.K == 128) return dw_launch<128, 128>(d, st);
+    return 0;
+}
+
 template <int NF, int FM>
 static int w3_launch_j(const sehip_gemm_desc& d, hipStream_t st) {
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;

@@ -44,7 +44,7 @@ class CGemmDesc(C.Structure):
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
                 ("tmul", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
                 ("res", C.c_void_p), ("stats", C.c_void_p), ("stats_cr", C.c_int32), ("cv2_nkt", C.c_int32), ("cv2_nf", C.c_int32),
-                ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32), ("wg_hint", C.c_int32)]
+                ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32), ("wg_hint", C.c_int32), ("dense_rows", C.c_int32)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient

@@ -242,6 +242,7 @@ class TasNetWorkspace:
                 w.dW = self.gpack.data_ptr() + 4 * s.dw_off
                 w.dst[0].ptr = self.bufs[st.dout_of[name]].ptr
                 w.res = None
+                w.dense_rows = 1 if (b.C == s.K and o.C == s.Npad == s.N) else 0     # every product here is a 1x1 convolution over dense rows
                 w.wg_hint = 160          # measured at the C4 shape (ms per step): 96: 4.28, 128: 3.68, 160: 3.59, 192: 3.79, 256: 3.75
                 self.desc[name + ".wg"] = w
 
