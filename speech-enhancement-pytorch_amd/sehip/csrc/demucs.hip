@@ -190,6 +190,118 @@ __global__ __launch_bounds__(256) void dmx_post_bwd_kernel(const float* __restri
     }
 }
 
+// The resampling paths of the three kernels above through LDS: a workgroup stages the window of its 256 positions once per channel
+// (channel-major, so that the stride-2 reads of the decimator are 2-way bank conflicts at most) and the taps run from LDS with
+// the filter coefficient as a scalar load.  The per-thread versions gather every tap from global memory at a stride of
+// 2 cop floats: 104 taps x 3 M positions of uncoalesced 4-byte loads, 287 / 214 / 128 us at the C3 shape.
+__global__ __launch_bounds__(256) void dmx_prep_up_kernel(const float* __restrict__ mix, const float* __restrict__ ms, const float* __restrict__ kup,
+                                                          int ac, int acp, int T, int padl, int Tv, int width, int KL,
+                                                          bf16_raw* __restrict__ x) {
+    extern __shared__ float win[];                       // [ac][128 + KL]
+    const int b = blockIdx.y;
+    const long T0 = 2L * Tv;
+    const long u0 = (long)blockIdx.x * 256;              // even
+    const long n0 = u0 >> 1;
+    const int WL = 128 + KL;
+    const float mean = ms[2 * b], inv = 1.f / (1e-5f + ms[2 * b + 1]);
+    for (int i = threadIdx.x; i < ac * WL; i += 256) {
+        const int c = i / WL, idx = i - c * WL;
+        long p = n0 + idx - width;
+        p = p < 0 ? 0 : (p >= Tv ? Tv - 1 : p);
+        p -= padl;
+        win[i] = (p >= 0 && p < T) ? (mix[((long)b * ac + c) * T + p] - mean) * inv : 0.f;
+    }
+    __syncthreads();
+    const long u = u0 + threadIdx.x;
+    if (u >= T0) return;
+    const int nl = threadIdx.x >> 1;
+    const float* k = kup + (threadIdx.x & 1) * KL;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    for (int c = 0; c < ac && c < 8; ++c) {
+        const float* wc = win + c * WL + nl;
+        float acc = 0.f;
+        for (int j = 0; j < KL; ++j) acc += k[j] * wc[j];
+        v[c] = acc;
+    }
+    bf16_raw* dst = x + ((long)b * T0 + u) * acp;
+    for (int c = 0; c < acp; ++c) dst[c] = f2bf(c < 8 ? v[c] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void dmx_post_down_kernel(const float* __restrict__ y /*[B][Tf][cop]*/, const float* __restrict__ ms,
+                                                            const float* __restrict__ kdn, int co, int cop, long Tf, int padl, int T,
+                                                            int width, int KL, float* __restrict__ out /*[B][co][T]*/) {
+    extern __shared__ float win[];                       // [co][512 + KL]
+    const int b = blockIdx.y;
+    const long nb = (long)blockIdx.x * 256;
+    const int WL = 512 + KL;
+    const float* yb = y + (long)b * Tf * cop;
+    const long p0 = 2 * (nb + padl) - width;
+    for (int i = threadIdx.x; i < WL; i += 256) {
+        long p = p0 + i;
+        p = p < 0 ? 0 : (p >= Tf ? Tf - 1 : p);
+        for (int c = 0; c < co; ++c) win[c * WL + i] = yb[p * cop + c];
+    }
+    __syncthreads();
+    const long n = nb + threadIdx.x;
+    if (n >= T) return;
+    const float mean = ms[2 * b], sd = ms[2 * b + 1];
+    for (int c = 0; c < co; ++c) {
+        const float* wc = win + c * WL + 2 * threadIdx.x;
+        float acc = 0.f;
+        for (int j = 0; j < KL; ++j) acc += kdn[j] * wc[j];
+        out[((long)b * co + c) * T + n] = acc * sd + mean;
+    }
+}
+
+__global__ __launch_bounds__(256) void dmx_post_bwd_down_kernel(const float* __restrict__ dout /*[B][co][T]*/, const float* __restrict__ ms,
+                                                                const float* __restrict__ kdn, int co, int cop, long Tf, int padl, int T,
+                                                                int width, int KL, bf16_raw* __restrict__ dy) {
+    extern __shared__ float win[];                       // [co][WL]: d[m - padl] for m in [mbase, mbase + WL)
+    const int b = blockIdx.y;
+    const long u0 = (long)blockIdx.x * 256;
+    const int WL = 128 + KL / 2 + 4;
+    long mbase = u0 + width - KL + 1;                    // smallest m any interior position of the block needs: ceil(. / 2)
+    mbase = mbase <= 0 ? 0 : (mbase + 1) / 2;
+    for (int i = threadIdx.x; i < co * WL; i += 256) {
+        const int c = i / WL, idx = i - c * WL;
+        const long m = mbase + idx;
+        win[i] = (m >= padl && m <= padl + T - 1) ? dout[((long)b * co + c) * T + (m - padl)] : 0.f;
+    }
+    __syncthreads();
+    const long u = u0 + threadIdx.x;
+    if (u >= Tf) return;
+    const float sd = ms[2 * b + 1];
+    bf16_raw* dst = dy + ((long)b * Tf + u) * cop;
+    for (int c = 0; c < cop; ++c) {
+        float v = 0.f;
+        if (c < co) {
+            if (u == 0 || u == Tf - 1) {                 // the clamped ends collect the padded positions too: the general loop
+                const float* d = dout + ((long)b * co + c) * T;
+                long plo = u, phi = u;
+                if (u == 0) plo = -width;
+                if (u == Tf - 1) phi = Tf + width + 1;
+                for (long p = plo; p <= phi; ++p) {
+                    long mlo = p + width - KL + 1;
+                    mlo = mlo <= 0 ? 0 : (mlo + 1) / 2;
+                    long mhi = (p + width) / 2;
+                    if (mlo < padl) mlo = padl;
+                    if (mhi > padl + T - 1) mhi = padl + T - 1;
+                    for (long m = mlo; m <= mhi; ++m) v += kdn[p + width - 2 * m] * d[m - padl];
+                }
+            } else {
+                long mlo = u + width - KL + 1;
+                mlo = mlo <= 0 ? 0 : (mlo + 1) / 2;
+                const long mhi = (u + width) / 2;
+                const float* wc = win + c * WL;
+                for (long m = mlo; m <= mhi; ++m) v += kdn[u + width - 2 * m] * wc[m - mbase];     // (rows outside the clip are zeros)
+            }
+        }
+        dst[c] = f2bf(v * sd);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // GroupNorm + activation family.  mode 0: z = gelu(n(y)) over C channels; mode 1: z = n(y)[:C/2] * sigmoid(n(y)[C/2:]) (GLU).
 // Optional LayerScale + residual: z <- resid + scale[c] * z; optional addend: z <- z + add.  n = GroupNorm(G) or identity.
@@ -1062,6 +1174,11 @@ extern "C" int sehip_dmx_prep(const float* mix, int B, int ac, int acp, int T, i
     }
     dmx_moments_finish_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(acc, B, T, normalize, ms);
     const long T0 = up ? 2L * Tv : Tv;
+    static const bool no_tiled = getenv("SEHIP_DMX_NO_TILED_RESAMPLE") != nullptr;
+    if (up && !no_tiled && ac <= 8 && (size_t)ac * (128 + KL) * 4 <= 60 * 1024)
+        dmx_prep_up_kernel<<<dim3((unsigned)((T0 + 255) / 256), B), 256, (size_t)ac * (128 + KL) * 4, (hipStream_t)stream>>>(
+            mix, ms, kup, ac, acp, T, padl, Tv, width, KL, (bf16_raw*)x_bf16);
+    else
     dmx_prep_kernel<<<dim3((unsigned)((T0 + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(mix, ms, kup, ac, acp, T, padl, Tv, up, width, KL,
                                                                                            (bf16_raw*)x_bf16);
     SEHIP_CHECK_LAUNCH("dmx_prep");
@@ -1072,6 +1189,11 @@ extern "C" int sehip_dmx_post(const float* y, const float* ms, int B, int co, in
                               int width, int KL, float* out, void* stream) {
     SEHIP_REQUIRE(B > 0 && co > 0 && cop >= co && T > 0 && Tf > 0, "dmx_post: bad sizes");
     SEHIP_REQUIRE((down ? Tf / 2 : Tf) >= padl + T, "dmx_post: the network output (%ld) is shorter than pad + clip (%d + %d)", Tf, padl, T);
+    static const bool no_tiled = getenv("SEHIP_DMX_NO_TILED_RESAMPLE") != nullptr;
+    if (down && !no_tiled && (size_t)co * (512 + KL) * 4 <= 60 * 1024)
+        dmx_post_down_kernel<<<dim3((unsigned)((T + 255) / 256), B), 256, (size_t)co * (512 + KL) * 4, (hipStream_t)stream>>>(
+            y, ms, kdn, co, cop, Tf, padl, T, width, KL, out);
+    else
     dmx_post_kernel<<<dim3((unsigned)((T + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(y, ms, kdn, co, cop, Tf, padl, T, down, width, KL, out);
     SEHIP_CHECK_LAUNCH("dmx_post");
     return 0;
@@ -1080,6 +1202,11 @@ extern "C" int sehip_dmx_post(const float* y, const float* ms, int B, int co, in
 extern "C" int sehip_dmx_post_bwd(const float* dout, const float* ms, int B, int co, int cop, long Tf, int padl, int T, int down,
                                   const float* kdn, int width, int KL, void* dy_bf16, void* stream) {
     SEHIP_REQUIRE(B > 0 && co > 0 && cop >= co && T > 0 && Tf > 0, "dmx_post_bwd: bad sizes");
+    static const bool no_tiled = getenv("SEHIP_DMX_NO_TILED_RESAMPLE") != nullptr;
+    if (down && !no_tiled && (size_t)co * (128 + KL / 2 + 4) * 4 <= 60 * 1024)
+        dmx_post_bwd_down_kernel<<<dim3((unsigned)((Tf + 255) / 256), B), 256, (size_t)co * (128 + KL / 2 + 4) * 4, (hipStream_t)stream>>>(
+            dout, ms, kdn, co, cop, Tf, padl, T, width, KL, (bf16_raw*)dy_bf16);
+    else
     dmx_post_bwd_kernel<<<dim3((unsigned)((Tf + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(dout, ms, kdn, co, cop, Tf, padl, T, down, width, KL,
                                                                                               (bf16_raw*)dy_bf16);
     SEHIP_CHECK_LAUNCH("dmx_post_bwd");
