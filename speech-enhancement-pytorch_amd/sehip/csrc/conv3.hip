@@ -340,7 +340,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
                 (((first.dst ? d.dst[1].C : d.dst[0].C) & 7) == 0);
     }
     bool with_stats = false;
-    if (d.stats && TN == 4) {
+    if (d.stats) {
         int* flag = reinterpret_cast<int*>(smem + NWV * (WROWS * TP * 2));
         if (lane == 0) flag[wave] = dense ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -382,25 +382,27 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             __builtin_amdgcn_s_barrier();
             const bf16_raw* imr = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * (wn & ~1)) * (WROWS * TP);
             const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * (wn | 1)) * (WROWS * TP);
-            const int cp = 32 * (wn & 1) + 2 * (lane & 15), rg = lane >> 4;
+            // TN = 4: the tile is [64 re | 64 im], a lane takes two channels; TN = 2 (64-output layers): [32 re | 32 im], one channel
+            constexpr int CPL = TN / 2;
+            const int cp = (16 * CPL) * (wn & 1) + CPL * (lane & 15), rg = lane >> 4;
             float sr[2] = {0.f, 0.f}, si[2] = {0.f, 0.f}, srr[2] = {0.f, 0.f}, sri[2] = {0.f, 0.f}, sii[2] = {0.f, 0.f};
             constexpr int RG = WROWS / 4;                          // rows per row group
 #pragma unroll 4
             for (int it = 0; it < RG; ++it) {
                 const int r = RG * rg + it;
-                const unsigned ur = *reinterpret_cast<const unsigned*>(&imr[r * TP + cp]);
-                const unsigned ui = *reinterpret_cast<const unsigned*>(&imi[r * TP + cp]);
+                const unsigned ur = CPL == 2 ? *reinterpret_cast<const unsigned*>(&imr[r * TP + cp]) : (unsigned)imr[r * TP + cp];
+                const unsigned ui = CPL == 2 ? *reinterpret_cast<const unsigned*>(&imi[r * TP + cp]) : (unsigned)imi[r * TP + cp];
                 const float ok = ((r < 64 ? rmask[0] >> r : rmask[1] >> (r - 64)) & 1ull) ? 1.f : 0.f;
                 const float yr[2] = {__uint_as_float(ur << 16) * ok, __uint_as_float(ur & 0xffff0000u) * ok};
                 const float yi[2] = {__uint_as_float(ui << 16) * ok, __uint_as_float(ui & 0xffff0000u) * ok};
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < CPL; ++e) {
                     sr[e] += yr[e]; si[e] += yi[e];
                     srr[e] += yr[e] * yr[e]; sri[e] += yr[e] * yi[e]; sii[e] += yi[e] * yi[e];
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < CPL; ++e) {
 #pragma unroll
                 for (int o = 16; o <= 32; o <<= 1) {
                     sr[e] += __shfl_xor(sr[e], o, 64); si[e] += __shfl_xor(si[e], o, 64);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
                 const int Cr = d.stats_cr;
                 float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + 64 * (wn >> 1) + cp;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < CPL; ++e) {
                     atomicAdd(sp + e, sr[e]); atomicAdd(sp + Cr + e, si[e]);
                     atomicAdd(sp + 2 * Cr + e, srr[e]); atomicAdd(sp + 3 * Cr + e, sri[e]); atomicAdd(sp + 4 * Cr + e, sii[e]);
                 }
@@ -578,7 +580,6 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
     if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     if ((C0 & 15) || (C1 & 15) || (d.Npad & 63)) return 0;
-    if (d.stats && (d.Npad & 127)) return 0;
     if (d.J != 4 && d.J != 8 && d.J != 16 && d.J != 32) return 0;
     if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
     if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return 0;

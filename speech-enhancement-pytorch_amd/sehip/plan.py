@@ -327,7 +327,7 @@ class GemmSpec:
         source channels, 128-multiple outputs, frame offsets within one frame of each other."""
         if self.conv is None or self.kind == "wgrad_only" or self.Npad % 64 or self.J not in (4, 8, 16, 32):
             return None
-        if self.stats_of is not None and self.Npad % 128:
+        if self.stats_of is not None and self.Npad % 128 and self.Npad != 64:
             return None
         nf, _, toff = self.conv
         if (nf, self.fmul) not in ((5, 2), (3, 1), (2, 1)):
@@ -376,7 +376,10 @@ class DCCRNStatic:
         accumulate the batch statistics of the ComplexBatchNorm behind them: no cbn_stats pass for these layers."""
         if any(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_PATCH", "SEHIP_NO_CONV_V2")):
             return      # (the experiment switches that take conv_gemm_v2 away also take its statistics away)
-        if co % 128 or any(c % 64 for c in cins) or J > 64 or 128 % J:
+        # (round 3: conv_gemm_v3 also takes the sums of a 64-output layer -- one [32 re | 32 im] tile; only that kernel does, so not
+        #  when one of its switches is set)
+        v3_only = co == 64 and all(c % 16 == 0 for c in cins) and J in (4, 8, 16, 32) and TILE_WEIGHTS and not os.environ.get("SEHIP_NO_FUSE_STATS64")
+        if (co % 128 or any(c % 64 for c in cins) or J > 64 or 128 % J) and not v3_only:
             return
         for nm in names:
             sp = self.specs[nm]

@@ -219,7 +219,13 @@ def test_fused_statistics_column_tiles():
     from sehip import plan
     kw = dict(kernel_num=[16, 32, 64, 128, 256, 256], rnn_units=128, length=1200)
     st = plan.DCCRNStatic(plan.DCCRNConfig(**kw))
-    assert st.fused_stats == {"encoder.3.", "encoder.4.", "encoder.5.", "decoder.0.", "decoder.1."}
+    # (round 3: conv_gemm_v3 also takes the sums of the two 64-output layers -- a single [32 re | 32 im] tile, no re-ordering)
+    assert st.fused_stats == {"encoder.2.", "encoder.3.", "encoder.4.", "encoder.5.", "decoder.0.", "decoder.1.", "decoder.2."}
+    for name in ("enc2.fwd", "dec2.fwd0", "dec2.fwd1"):
+        sp = st.specs[name]
+        assert sp.stats_of is not None and sp.N == sp.Npad == 64 and sp.v3_channels() is not None
+        chan = np.concatenate([sp.ntab[q, 1] + np.arange(4) for q in range(16)])
+        assert (chan == np.arange(64)).all()                    # natural column order: [32 re | 32 im]
     for name, co in (("enc3.fwd", 128), ("enc4.fwd", 256), ("enc5.fwd", 256), ("dec0.fwd0", 256), ("dec0.fwd1", 256), ("dec1.fwd1", 128)):
         sp = st.specs[name]
         assert sp.stats_of is not None and sp.N == co
