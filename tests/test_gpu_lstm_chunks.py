@@ -12,6 +12,10 @@ def run_once(chunk, B, N):
     from sehip.model import DCCRN
     old = os.environ.get("SEHIP_LSTM_CHUNK")
     os.environ["SEHIP_LSTM_CHUNK"] = str(chunk)
+    # bit equality needs a bit-reproducible network around the LSTM: the BatchNorm sums that the convolution epilogues take with
+    # fp32 atomics (64-output layers here) vary in the last bit from run to run, the separate passes do not
+    fused = {k: os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_BWD_STATS")}
+    os.environ.update({k: "1" for k in fused})
     try:
         dev = torch.device("cuda:0")
         torch.manual_seed(3)
@@ -25,6 +29,11 @@ def run_once(chunk, B, N):
         keep = {k: ws.bufs[k].t.clone() for k in ("P", "h1", "h2", "dz5l", "dpre1_r", "dpre2_i")}
         return keep, model.flat_grads.clone(), len(ws.lstm_chunks)
     finally:
+        for k, v in fused.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         if old is None:
             os.environ.pop("SEHIP_LSTM_CHUNK", None)
         else:
