@@ -2406,6 +2406,139 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
     }
 }
 
+
+// narrow_wgrad_mfma_kernel: the same product on the matrix cores.  dW[16 n][(kt, tap, c)] = sum over rows of dOut[row][n] *
+// x[frame + kt offset][FMUL j + tap][c] is a 16 x (2 x 16) x rows GEMM: per 32 rows of the frame one transposed LDS read pair
+// gives the dOut operand ([n][32 rows]), and for each kt the lane of column (tap, c) gathers its 8 rows of the input column
+// (dwords FMUL rows apart, the channel's half picked with v_perm) -- 12 MFMAs and ~80 LDS / VALU instructions per frame
+// instead of ~1 300 VALU instructions, so the launch is bound by reading dOut (the VALU kernel above: 68 us at the headline
+// shape, 5x its HBM time; it stays for frames that are not a multiple of 32 rows).
+template <int NF, int FMUL>
+__global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const sehip_gemm_desc d, int FRA, int fa, int frames_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int J = d.J;
+    const int gbytes = J * 16 * 2, xbytes = 2 * FRA * 2 * 2;
+    unsigned char* wbase = smem + (size_t)w * (gbytes + xbytes);
+    bf16_raw* sG = reinterpret_cast<bf16_raw*>(wbase);             // [J][16]
+    bf16_raw* sX = reinterpret_cast<bf16_raw*>(wbase + gbytes);    // [2 (kt)][FRA][2]
+    const int g = lane >> 4, i16 = lane & 15;
+    const int tap = (i16 >> 1) < NF ? (i16 >> 1) : NF - 1;         // columns >= 2 NF are not stored
+    const unsigned sel = (i16 & 1) ? 0x07060302u : 0x05040100u;    // the channel's half of two consecutive rows' dwords
+
+    const int sT = d.src[0].T, sF = d.src[0].F;
+    const bf16_raw* xsrc = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
+    const bf16_raw* gsrc = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr);
+    const int gpieces = J * 2;              // 16-byte pieces of a dOut frame (8 channels each)
+    const int xpieces = FRA >> 2;           // 16-byte pieces (4 rows x 2 ch) of one input frame
+    constexpr int GPL = 4, XPL = 2;         // pieces per lane: J <= 128, FRA <= 512
+
+    f32x4 acc[2], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[0] = acc[1] = accb;
+
+    const int wave_id = blockIdx.x * NW_WAVES + w, nwaves = gridDim.x * NW_WAVES;
+    uint4 gr[GPL], xr[2][XPL];
+#define NWM_FETCH(fr_)                                                                                             \
+    {                                                                                                              \
+        const int b_ = (fr_) / d.TT, t_ = (fr_) - b_ * d.TT;                                                       \
+        _Pragma("unroll") for (int u = 0; u < GPL; ++u) {                                                          \
+            const int idx = lane + 64 * u;                                                                         \
+            gr[u] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
+            if (idx < gpieces) {                                                                                   \
+                const int j = idx >> 1, h = idx & 1;                                                               \
+                const long off = (((long)b_ * d.dst[0].T + t_ + d.dst[0].toff) * d.dst[0].F + (long)j * d.dst[0].fmul + d.dst[0].fadd) * d.dst[0].C; \
+                gr[u] = *reinterpret_cast<const uint4*>(gsrc + off + 8 * h);                                       \
+            }                                                                                                      \
+        }                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                            \
+            const int ts = t_ + d.cv_toff[0][k];                                                                   \
+            const bool tok = ts >= d.src[0].tlo && ts < d.src[0].thi;                                              \
+            _Pragma("unroll") for (int u = 0; u < XPL; ++u) {                                                      \
+                const int idx = lane + 64 * u;                                                                     \
+                const int f = fa + 4 * idx;                                                                        \
+                xr[k][u] = make_uint4(0u, 0u, 0u, 0u);                                                             \
+                if (tok && idx < xpieces && f >= 0 && f + 3 < sF)                                                  \
+                    xr[k][u] = *reinterpret_cast<const uint4*>(xsrc + (((long)b_ * sT + ts) * sF + f) * 2);        \
+                else if (tok && idx < xpieces && f + 3 >= 0 && f < sF) {  /* piece straddles the edge: row by row */ \
+                    unsigned q[4];                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                        q[r] = (f + r >= 0 && f + r < sF) ? *reinterpret_cast<const unsigned*>(xsrc + (((long)b_ * sT + ts) * sF + f + r) * 2) : 0u; \
+                    xr[k][u] = make_uint4(q[0], q[1], q[2], q[3]);                                                 \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+
+    int fr = wave_id;
+    if (fr < frames_total) NWM_FETCH(fr)
+    for (; fr < frames_total; fr += nwaves) {
+        // registers -> this wave's LDS region (only this wave reads it: no barrier, the LDS pipe is in order per wave)
+#pragma unroll
+        for (int u = 0; u < GPL; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < gpieces) *reinterpret_cast<uint4*>(&sG[(idx >> 1) * 16 + 8 * (idx & 1)]) = gr[u];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int u = 0; u < XPL; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < xpieces) *reinterpret_cast<uint4*>(&sX[(k * FRA + 4 * idx) * 2]) = xr[k][u];
+            }
+        asm volatile("" ::: "memory");
+        if (fr + nwaves < frames_total) NWM_FETCH(fr + nwaves)
+
+        const unsigned* xcol = reinterpret_cast<const unsigned*>(sX) + (d.cv_fadd - fa) + tap;
+        for (int ks = 0; ks < (J >> 5); ++ks) {
+            const int m0 = 32 * ks + 8 * g;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[(m0 + (i16 >> 2)) * 16 + 4 * (i16 & 3)]);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&sG[(m0 + 4 + (i16 >> 2)) * 16 + 4 * (i16 & 3)]);
+            const bf16x8 gf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, BF16_ONES, accb, 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const unsigned* xc = xcol + kt * FRA + FMUL * m0;
+                unsigned q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = xc[FMUL * i];
+                const uint4 xv = make_uint4(__builtin_amdgcn_perm(q[1], q[0], sel), __builtin_amdgcn_perm(q[3], q[2], sel),
+                                            __builtin_amdgcn_perm(q[5], q[4], sel), __builtin_amdgcn_perm(q[7], q[6], sel));
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, __builtin_bit_cast(bf16x8, xv), acc[kt], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+#undef NWM_FETCH
+
+    // a lane holds D[channel 4 g + q][column i16] of both kt and the channel sums: reduce the workgroup's waves through LDS,
+    // then one atomic per dW entry and workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [NW_WAVES][12][64]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        red[(w * 12 + q) * 64 + lane] = acc[0][q];
+        red[(w * 12 + 4 + q) * 64 + lane] = acc[1][q];
+        red[(w * 12 + 8 + q) * 64 + lane] = accb[q];
+    }
+    __syncthreads();
+    for (int e = w; e < 12; e += NW_WAVES) {
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW_WAVES; ++ww) v += red[(ww * 12 + e) * 64 + lane];
+        const int q = e & 3, ch = 4 * g + q;            // dOut channel -> packed row of dW (the column table maps rows to channels)
+        int n = -1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (d.ntab[m].coff == 4 * g) n = 4 * m + q;
+        (void)ch;
+        if (n < 0) continue;
+        if (e < 8) {
+            const int kt = e >> 2;
+            if (i16 < 2 * NF) atomicAdd(&d.dW[(size_t)n * d.K + kt * 16 + i16], v);   // K order of a 2-channel source: kt*16 + tap*2 + c
+        } else if (i16 == 0 && d.dbias) atomicAdd(&d.dbias[n], v);
+    }
+}
+
 static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
     if (disabled || d.cv_nf <= 0 || d.src[0].C != 2 || d.src[1].ptr || d.dst[1].ptr) return 0;
@@ -2423,10 +2556,18 @@ static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     if (lds < red) lds = red;
     if (lds > 64 * 1024) return 0;
     int grid = (frames + NW_WAVES - 1) / NW_WAVES;
-    if (grid > 256) grid = 256;
+    static const int cap = getenv("SEHIP_NARROW_WGS") ? atoi(getenv("SEHIP_NARROW_WGS")) : 256;
+    if (grid > cap) grid = cap;
+    if (d.cv_nf != 5 || d.fmul != 2 || (d.J & 1)) return 0;
+    static const bool no_mfma = getenv("SEHIP_NO_NARROW_MFMA") != nullptr;
+    // (the MFMA build gathers 8 rows FMUL apart above a 32-row block's first tap: inside the staged FRA rows for J % 32 == 0)
+    if (!no_mfma && (d.J & 31) == 0) {
+        sehip_note_kernel("narrow_wgrad_mfma_kernel<%d>", d.cv_nf);
+        narrow_wgrad_mfma_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
+        return 1;
+    }
     sehip_note_kernel("narrow_wgrad_kernel<%d>", d.cv_nf);
-    if (d.cv_nf == 5 && d.fmul == 2 && !(d.J & 1)) narrow_wgrad_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
-    else return 0;
+    narrow_wgrad_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
     return 1;
 }
 
