@@ -2407,6 +2407,21 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
 }
 
 
+// sum e (0-3: kt 0, 4-7: kt 1, 8-11: channel sums; q = e & 3) of lane (g = lane >> 4, column i16 = lane & 15) of the MFMA kernel
+// below = D[dOut channel 4 g + q][column]: added to the packed row of dW that the column table maps to that channel
+template <int NF>
+__device__ __forceinline__ void narrow_wgrad_add(const sehip_gemm_desc& d, int e, int lane, float v) {
+    const int g = lane >> 4, i16 = lane & 15, q = e & 3;
+    int n = -1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (d.ntab[m].coff == 4 * g) n = 4 * m + q;
+    if (n < 0) return;
+    if (e < 8) {
+        if (i16 < 2 * NF) atomicAdd(&d.dW[(size_t)n * d.K + (e >> 2) * 16 + i16], v);   // K order of a 2-channel source: kt*16 + tap*2 + c
+    } else if (i16 == 0 && d.dbias) atomicAdd(&d.dbias[n], v);
+}
+
 // narrow_wgrad_mfma_kernel: the same product on the matrix cores.  dW[16 n][(kt, tap, c)] = sum over rows of dOut[row][n] *
 // x[frame + kt offset][FMUL j + tap][c] is a 16 x (2 x 16) x rows GEMM: per 32 rows of the frame one transposed LDS read pair
 // gives the dOut operand ([n][32 rows]), and for each kt the lane of column (tap, c) gathers its 8 rows of the input column
@@ -2414,7 +2429,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_kernel(const sehip
 // instead of ~1 300 VALU instructions, so the launch is bound by reading dOut (the VALU kernel above: 68 us at the headline
 // shape, 5x its HBM time; it stays for frames that are not a multiple of 32 rows).
 template <int NF, int FMUL>
-__global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const sehip_gemm_desc d, int FRA, int fa, int frames_total) {
+__global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const sehip_gemm_desc d, int FRA, int fa, int frames_total,
+                                                                           float* __restrict__ parts /* [workgroups][12][64] or NULL */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int J = d.J;
@@ -2437,8 +2453,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
     acc[0] = acc[1] = accb;
 
     const int wave_id = blockIdx.x * NW_WAVES + w, nwaves = gridDim.x * NW_WAVES;
-    uint4 gr[GPL], xr[2][XPL];
-#define NWM_FETCH(fr_)                                                                                             \
+    uint4 grA[GPL], xrA[2][XPL], grB[GPL], xrB[2][XPL];     // two frames in flight per wave
+#define NWM_FETCH(fr_, gr, xr)                                                                                             \
     {                                                                                                              \
         const int b_ = (fr_) / d.TT, t_ = (fr_) - b_ * d.TT;                                                       \
         _Pragma("unroll") for (int u = 0; u < GPL; ++u) {                                                          \
@@ -2469,9 +2485,7 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
         }                                                                                                          \
     }
 
-    int fr = wave_id;
-    if (fr < frames_total) NWM_FETCH(fr)
-    for (; fr < frames_total; fr += nwaves) {
+    auto stage = [&](const uint4 (&gr)[GPL], const uint4 (&xr)[2][XPL]) {
         // registers -> this wave's LDS region (only this wave reads it: no barrier, the LDS pipe is in order per wave)
 #pragma unroll
         for (int u = 0; u < GPL; ++u) {
@@ -2486,8 +2500,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
                 if (idx < xpieces) *reinterpret_cast<uint4*>(&sX[(k * FRA + 4 * idx) * 2]) = xr[k][u];
             }
         asm volatile("" ::: "memory");
-        if (fr + nwaves < frames_total) NWM_FETCH(fr + nwaves)
-
+    };
+    auto multiply = [&]() {
         const unsigned* xcol = reinterpret_cast<const unsigned*>(sX) + (d.cv_fadd - fa) + tap;
         for (int ks = 0; ks < (J >> 5); ++ks) {
             const int m0 = 32 * ks + 8 * g;
@@ -2507,11 +2521,25 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
             }
         }
         asm volatile("" ::: "memory");
+    };
+    int fr = wave_id;
+    if (fr < frames_total) NWM_FETCH(fr, grA, xrA)
+    if (fr + nwaves < frames_total) NWM_FETCH(fr + nwaves, grB, xrB)
+    for (; fr < frames_total; fr += 2 * nwaves) {
+        stage(grA, xrA);
+        if (fr + 2 * nwaves < frames_total) NWM_FETCH(fr + 2 * nwaves, grA, xrA)
+        multiply();
+        if (fr + nwaves >= frames_total) break;
+        stage(grB, xrB);
+        if (fr + 3 * nwaves < frames_total) NWM_FETCH(fr + 3 * nwaves, grB, xrB)
+        multiply();
     }
 #undef NWM_FETCH
 
-    // a lane holds D[channel 4 g + q][column i16] of both kt and the channel sums: reduce the workgroup's waves through LDS,
-    // then one atomic per dW entry and workgroup
+    // a lane holds D[channel 4 g + q][column i16] of both kt and the channel sums: reduce the workgroup's waves through LDS; then
+    // the workgroup's 12 x 64 sums go to its row of the partial array (narrow_wgrad_reduce_kernel adds the rows into dW).  Without
+    // a partial array: one atomic per dW entry and workgroup -- 256 workgroups x 16 entries per cache line, and atomics on one
+    // line are served one after the other: 28 of this kernel's 33 us were that queue.
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [NW_WAVES][12][64]
 #pragma unroll
@@ -2525,19 +2553,29 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
         float v = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW_WAVES; ++ww) v += red[(ww * 12 + e) * 64 + lane];
-        const int q = e & 3, ch = 4 * g + q;            // dOut channel -> packed row of dW (the column table maps rows to channels)
-        int n = -1;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (d.ntab[m].coff == 4 * g) n = 4 * m + q;
-        (void)ch;
-        if (n < 0) continue;
-        if (e < 8) {
-            const int kt = e >> 2;
-            if (i16 < 2 * NF) atomicAdd(&d.dW[(size_t)n * d.K + kt * 16 + i16], v);   // K order of a 2-channel source: kt*16 + tap*2 + c
-        } else if (i16 == 0 && d.dbias) atomicAdd(&d.dbias[n], v);
+        if (parts) parts[((size_t)blockIdx.x * 12 + e) * 64 + lane] = v;
+        else narrow_wgrad_add<NF>(d, e, lane, v);
     }
 }
+
+// rows of the partial array -> dW / dbias: workgroup = 16 sums x 16 groups of rows
+template <int NF>
+__global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const sehip_gemm_desc d, const float* __restrict__ parts, int nparts) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int out = blockIdx.x * 16 + o;                 // (e, lane) = (out >> 6, out & 63)
+    float v = 0.f;
+    for (int p = grp; p < nparts; p += 16) v += parts[(size_t)p * 768 + out];
+    red[grp][o] = v;
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += red[i][o];
+        narrow_wgrad_add<NF>(d, out >> 6, out & 63, v);
+    }
+}
+
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
 
 static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
@@ -2563,7 +2601,10 @@ static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     // (the MFMA build gathers 8 rows FMUL apart above a 32-row block's first tap: inside the staged FRA rows for J % 32 == 0)
     if (!no_mfma && (d.J & 31) == 0) {
         sehip_note_kernel("narrow_wgrad_mfma_kernel<%d>", d.cv_nf);
-        narrow_wgrad_mfma_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
+        static const bool atomic_flush = getenv("SEHIP_NARROW_ATOMIC_FLUSH") != nullptr;
+        float* parts = atomic_flush ? nullptr : sehip_wgrad_scratch(st, (size_t)grid * 768 * sizeof(float));
+        narrow_wgrad_mfma_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames, parts);
+        if (parts) narrow_wgrad_reduce_kernel<5><<<48, 256, 0, st>>>(d, parts, grid);
         return 1;
     }
     sehip_note_kernel("narrow_wgrad_kernel<%d>", d.cv_nf);

@@ -284,6 +284,9 @@ static float* w3_scratch_for(hipStream_t st, size_t bytes) {
     return p;
 }
 
+// (the same pool for the other weight-gradient kernels that keep partial arrays: csrc/gemm.hip's narrow_wgrad_mfma_kernel)
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes) { return w3_scratch_for(st, bytes); }
+
 template <int NF, int FM, int J, int NB>
 static size_t w3_lds_bytes() {
     return (size_t)NB * W3Geo<NF, FM, J>::STAGE + 1024;
