@@ -2565,7 +2565,13 @@ __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const sehip_ge
     const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int out = blockIdx.x * 16 + o;                 // (e, lane) = (out >> 6, out & 63)
     float v = 0.f;
-    for (int p = grp; p < nparts; p += 16) v += parts[(size_t)p * 768 + out];
+    for (int p0 = grp; p0 < nparts; p0 += 256) {          // 16 independent loads in flight per thread
+        float t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = p0 + 16 * i < nparts ? parts[(size_t)(p0 + 16 * i) * 768 + out] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += t[i];
+    }
     red[grp][o] = v;
     __syncthreads();
     if (grp == 0) {
