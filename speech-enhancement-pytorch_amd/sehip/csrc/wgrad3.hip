@@ -247,8 +247,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
 __global__ __launch_bounds__(256) void w3_reduce_kernel(const float* parts, int nparts, size_t n4, float* dW) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    // gridDim.y slices of the partial arrays: a 32-K-entry dW is 32 workgroups of columns, which alone keep ~0.5 MB of loads in
-    // flight (ConvTasNet's 1x1 products, 160 arrays: 16.5 us per launch, 1.2 TB/s); the slices add their sums with atomics
+    // gridDim.y slices of the partial arrays (their sums meet with atomics).  One slice by default: a 32-K-entry dW is then 32
+    // workgroups of columns (ConvTasNet's 1x1 products, 160 arrays: 16.5 us per launch at 1.2 TB/s), and that is what the step
+    // wants -- the reduction runs on the weight-gradient stream beside an HBM-bound chain, and 16 slices (512 workgroups, a third
+    // of the time per launch) made the C4 step 3.75 ms instead of 3.51 (DCCRN: no difference).  SEHIP_W3_REDUCE_WGS=<workgroups>
     const int per = (nparts + gridDim.y - 1) / gridDim.y;
     const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void w3_reduce_kernel(const float* parts, int 
 }
 static void w3_reduce_launch(const float* parts, int nparts, size_t n, float* dW, hipStream_t st) {
     const unsigned gx = (unsigned)((n / 4 + 255) / 256);
-    static const int target = getenv("SEHIP_W3_REDUCE_WGS") ? atoi(getenv("SEHIP_W3_REDUCE_WGS")) : 512;
+    static const int target = getenv("SEHIP_W3_REDUCE_WGS") ? atoi(getenv("SEHIP_W3_REDUCE_WGS")) : 1;
     int gy = (int)(target / gx);
     if (gy > nparts / 8) gy = nparts / 8;              // at least eight arrays per slice
     if (gy < 1) gy = 1;
