@@ -211,8 +211,9 @@ typedef struct {
      * the layer's batch statistics from the bf16 values it stores, so that no separate pass reads the tensor back.
      * stats: fp32 [8 replicas][5][stats_cr] (sum re, sum im, sum re^2, sum re*im, sum im^2 per complex channel; atomics, the
      * caller zeroes it; the replica is the workgroup's XCD).  Requires Npad a multiple of 128 with every 128-column tile
-     * holding [64 real | 64 imaginary] columns of the SAME 64 complex channels (tile t <-> channels 64 t ..), a bf16 dense
-     * destination, and is honoured by the LDS-DMA convolution kernel only: sehip_gemm fails loudly when it cannot honour it. */
+     * holding [64 real | 64 imaginary] columns of the SAME 64 complex channels (tile t <-> channels 64 t ..) -- or Npad == 64 / 32
+     * with [32 | 32] / [16 | 16] -- a bf16 dense destination, and is honoured by the LDS-DMA convolution kernel (and, for 32 outputs,
+     * by the small-channel kernel: sehip_conv_small_takes) only: sehip_gemm fails loudly when it cannot honour it. */
     float* stats;
     int32_t stats_cr;
     /* Optional second convolution description (weight gradients only; the parity classes of DCUnet's transposed convolutions,
@@ -241,6 +242,11 @@ int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
 /* two products over the same sources (the output-row parities of ComplexConvTranspose2d, src/model/dccrn.py:387-450):
  * one launch that stages the input once where the library can, otherwise the two launches */
 int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream);
+/* 1 when the small-channel convolution kernel (conv_small2_kernel: <= 128 concatenated input channels, a power of two; its patch
+ * must fit into LDS, which depends on the frame geometry) takes the product a (b == NULL) or the pair (a, b) exactly as described,
+ * the `stats` field included (32-output layers: [16 re | 16 im] in natural column order, 8 replicas as above).  Lets a plan ask
+ * before it relies on fused statistics for such a layer; no launch. */
+int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b /* or NULL */);
 /* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */
 int sehip_wgrad(const sehip_gemm_desc* desc, void* stream);
 /* n (<= 16) plain weight-gradient products (no convolution description, Npad a multiple of 128: the LSTM input / recurrent

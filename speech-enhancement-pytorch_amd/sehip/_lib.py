@@ -73,6 +73,7 @@ _PROTOS = {
     "sehip_wgrad_group_prepare": [P, I, P, P],
     "sehip_wgrad_group": [P, I, I, P],
     "sehip_gemm_desc_size": [],
+    "sehip_conv_small_takes": [P, P],
     "sehip_pack_bf16": [P, P, L, P, P],
     "sehip_pack_f32": [P, P, L, P, P],
     "sehip_unpack_grad": [P, P, L, P, P],

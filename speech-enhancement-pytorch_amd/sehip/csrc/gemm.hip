@@ -763,7 +763,8 @@ __device__ __forceinline__ void cs2_load_weights(const sehip_gemm_desc& d, bf16_
 template <int TN, int MI>
 __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, const sehip_gemm_desc& d, const bf16_raw* patch,
                                                    bf16_raw* obuf /* wave-private [16 MI][16 TN + 8] */, const int (&abase)[MI],
-                                                   const int (&e_tl)[MI], int FR, int PP, int CT, int C0, int b, int t0, int lane) {
+                                                   const int (&e_tl)[MI], int FR, int PP, int CT, int C0, int b, int t0, int lane,
+                                                   float (&st)[20], bool do_stats) {
     const int g = lane >> 4;
     const int wrow = (lane & 15) * sd.KP + 8 * g;  // this lane's weight fragment: row (lane & 15) of each 16-row tile, k chunk g
     f32x4 acc[TN][MI];
@@ -825,6 +826,23 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    if (TN == 2 && do_stats) {
+        // batch statistics of the ComplexBatchNorm behind a 32-output layer (sehip_gemm_desc.stats): the lane holds the real parts
+        // (column tile 0) and the imaginary parts (tile 1) of complex channels 4 g .. 4 g + 3 for its MI rows, as they are stored
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (t0 + e_tl[mi] >= d.TT) continue;
+            const f32x4 vr = acc[0][mi], vi = acc[TN - 1][mi];
+            const float br[4] = {sd.bias4[0].x, sd.bias4[0].y, sd.bias4[0].z, sd.bias4[0].w};
+            const float bi[4] = {sd.bias4[TN - 1].x, sd.bias4[TN - 1].y, sd.bias4[TN - 1].z, sd.bias4[TN - 1].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float yr = bf2f(f2bf(vr[q] + br[q])), yi = bf2f(f2bf(vi[q] + bi[q]));
+                st[5 * q] += yr; st[5 * q + 1] += yi;
+                st[5 * q + 2] += yr * yr; st[5 * q + 3] += yr * yi; st[5 * q + 4] += yi * yi;
+            }
         }
     }
     if (sd.dense) {
@@ -950,6 +968,10 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
     const Cs2Side<TN, MI> sb = cs2_side_init<TN, MI>(PAIR ? d2 : d, sW2, tmin0, tmin1, fadd_u, JB, w, lane);
 
     const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    float st[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) st[i] = 0.f;
+    const bool do_stats = TN == 2 && d.stats != nullptr;
     RegTile<NPC> pr;
 #define CS_FETCH(mt_)                                                                                             \
     {                                                                                                             \
@@ -966,18 +988,42 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
         for (int u = 0; u < NPC; ++u) *reinterpret_cast<uint4*>(&patch[p_lds[u]]) = pr.v[u];
         __syncthreads();
         if (mt + 1 < mt_end) CS_FETCH(mt + 1)   // in flight while this tile is multiplied and stored
-        cs2_multiply_store<TN, MI>(sa, d, patch, obuf, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
-        if (PAIR) cs2_multiply_store<TN, MI>(sb, d2, patch, obuf, abase, e_tl, FR, PP, CT, C0, b, t0, lane);
+        cs2_multiply_store<TN, MI>(sa, d, patch, obuf, abase, e_tl, FR, PP, CT, C0, b, t0, lane, st, do_stats);
+        if (PAIR) cs2_multiply_store<TN, MI>(sb, d2, patch, obuf, abase, e_tl, FR, PP, CT, C0, b, t0, lane, st, do_stats);
         __syncthreads();  // every read of this tile's patch is done before the next one is written
     }
 #undef CS_FETCH
+    if (TN == 2 && do_stats) {
+        // the 16 lanes of a k group hold different rows: xor-shuffles; then the four waves through LDS, 80 atomics per workgroup
+        // (the patch area is free: the tile loop ends with a barrier; the pair build has no LDS left for a static array)
+        float* sred = reinterpret_cast<float*>(patch);       // [wave][k group][20]
+#pragma unroll
+        for (int i = 0; i < 20; ++i)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < 20; ++i) sred[(w * 4 + (lane >> 4)) * 20 + i] = st[i];
+        }
+        __syncthreads();
+        if (tid < 80) {
+            const int gg = tid / 20, i = tid - gg * 20, q = i / 5, k = i - 5 * q;
+            const float v = sred[gg * 20 + i] + sred[(4 + gg) * 20 + i] + sred[(8 + gg) * 20 + i] + sred[(12 + gg) * 20 + i];
+            const int Cr = d.stats_cr;
+            atomicAdd(d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + 4 * gg + q, v);
+        }
+    }
 }
 
 // d2 == nullptr: one product.  d2 != nullptr: the pair (d, *d2) over one staged patch; returns 0 when the pair does not
 // qualify (the caller then launches the two products separately).
-static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, hipStream_t st) {
+// dry: only say whether the kernel would take the product(s)
+static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, hipStream_t st, bool dry = false) {
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_SMALL") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
+    // fused BatchNorm sums: the 32-output build only ([16 re | 16 im] in natural column order, one bf16 destination)
+    if (d.stats && (d.Npad != 32 || d.N != 32 || d.stats_cr != 16 || d.dst[1].ptr || d.dst[0].is_f32 || d.dst[0].C != 32)) return 0;
+    if (d2 && (d2->stats != d.stats || (d.stats && (d2->stats_cr != 16 || d2->dst[1].ptr || d2->dst[0].is_f32 || d2->dst[0].C != 32)))) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int CT = C0 + C1;
     if ((C0 & 7) || (C1 & 7) || CT > 128 || (CT & (CT - 1)) || d.Npad > 128 || CT < 16) return 0;
@@ -1026,6 +1072,7 @@ static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, h
     const bool few = pieces(MI) <= 6 * 256;
 #define CS2_CASE(BN_, NPC_, MI_, PAIR_)                                                                             \
     if (d.Npad == BN_ && MI == MI_ && few == (NPC_ == 6) && (d2 != nullptr) == PAIR_) {                              \
+        if (dry) return 1;                                                                                          \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small2_kernel<BN_, NPC_, MI_, PAIR_>),    \
@@ -1473,7 +1520,7 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
     if (d->stats) {   // only the LDS-DMA convolution kernel accumulates the BatchNorm statistics (sehip.h): no silent omission
-        if (sehip_try_conv_gemm_v3(*d, st) || (!d->w_tiled && sehip_try_conv_gemm_v2(*d, st))) {
+        if (sehip_try_conv_gemm_v3(*d, st) || (!d->w_tiled && sehip_try_conv_gemm_v2(*d, st)) || (!d->w_tiled && try_conv_small(*d, nullptr, st))) {
             SEHIP_CHECK_LAUNCH("gemm(conv+stats)");
             return 0;
         }
@@ -1520,6 +1567,13 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
 
 // Two products over the SAME sources (the two output-row parities of a transposed convolution, src/model/dccrn.py:387-450):
 // one launch that stages the input once when the small-channel kernel takes the pair, otherwise the two launches.
+// 1 when conv_small2_kernel takes the product (b == NULL) or the pair as described, fused BatchNorm sums (field stats) included:
+// the plan asks before it relies on them (workspace-dependent: the kernel must fit its patch into LDS)
+extern "C" int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b) {
+    if (!a) return 0;
+    return try_conv_small(*a, b, nullptr, true);
+}
+
 extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream) {
     if (int e = check_desc("gemm_pair", a)) return e;
     if (int e = check_desc("gemm_pair", b)) return e;

@@ -379,6 +379,11 @@ class DCCRNStatic:
         # (round 3: conv_gemm_v3 also takes the sums of a 64-output layer -- one [32 re | 32 im] tile; only that kernel does, so not
         #  when one of its switches is set)
         v3_only = co == 64 and all(c % 16 == 0 for c in cins) and J in (4, 8, 16, 32) and TILE_WEIGHTS and not os.environ.get("SEHIP_NO_FUSE_STATS64")
+        if co == 32 and not os.environ.get("SEHIP_NO_FUSE_STATS32"):
+            # a 32-output layer on the small-channel kernel: whether that kernel takes the product (its patch must fit into LDS)
+            # depends on the workspace, so the workspace asks the library when it binds the descriptors (small_stats)
+            self.small_stats[pre] = list(names)
+            return
         if (co % 128 or any(c % 64 for c in cins) or J > 64 or 128 % J) and not v3_only:
             return
         for nm in names:
@@ -390,6 +395,7 @@ class DCCRNStatic:
 
     def __init__(self, cfg: DCCRNConfig):
         self.fused_stats = set()
+        self.small_stats = {}  # BatchNorm prefix -> forward products of a 32-output layer (fused sums if conv_small2 takes them)
         self.cfg = cfg
         self.layout = L = ParamLayout(cfg)
         kn = cfg.kernel_num
@@ -766,7 +772,7 @@ class DCCRNWorkspace:
         # [8 replicas][5][Cr] sums per fused layer (sehip_gemm_desc.stats), one allocation so that one memset clears them all
         offs, tot = {}, 0
         for pre, cr in st.bn:
-            if pre in st.fused_stats:
+            if pre in st.fused_stats or pre in st.small_stats:
                 offs[pre] = tot
                 tot += 8 * 5 * cr
         self.bn_stats_all = torch.zeros(max(tot, 1), dtype=torch.float32, device=device)
@@ -894,6 +900,21 @@ class DCCRNWorkspace:
                     w.dst[0].ptr = gb.ptr
                     w.dst[0].is_f32 = 0
                 self.desc[name + ".wg"] = w
+        # 32-output layers: fused BatchNorm sums if the small-channel kernel takes the forward product(s) as the step launches them
+        # (encoder: one product; decoder: the pair of output-row parities)
+        self.fused_small = set()
+        lib = _lib.lib()
+        for pre, names in st.small_stats.items():
+            ds = [self.desc[nm] for nm in names]
+            for d in ds:
+                d.stats = self.bn_stats[pre].data_ptr()
+                d.stats_cr = 16
+            if lib.sehip_conv_small_takes(C.byref(ds[0]), C.byref(ds[1]) if len(ds) == 2 else None):
+                self.fused_small.add(pre)
+            else:
+                for d in ds:
+                    d.stats = None
+                    d.stats_cr = 0
         if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
             for layers in ((1,), (2,), (2, 1)):
                 self._wgrad_group_handle(self._lstm_wgrad_names(layers))
@@ -1018,7 +1039,7 @@ class DCCRNWorkspace:
         rows = y.t.numel() // (2 * cr)
         pp, bp, nb = self._bn_ptrs(pre, params, buffers, nbt)
         coef = self.bn_coef[pre]
-        if pre in self.st.fused_stats:     # the producing convolution accumulated the sums (8 replicas)
+        if pre in self.st.fused_stats or pre in self.fused_small:     # the producing convolution accumulated the sums (8 replicas)
             call("sehip_cbn_finalize_n", ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
                  bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
                  1 if training else 0, ptr(coef), stream())
@@ -1111,7 +1132,7 @@ class DCCRNWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, T, h = self.B, self.T, cfg.hid
         self.pack_weights(params)
-        if self.st.fused_stats:
+        if self.st.fused_stats or self.fused_small:
             self.bn_stats_all.zero_()
         call("sehip_stft_fwd", ptr(wav_in), ptr(tb.window), B, self.N, cfg.win_len, cfg.win_inc, cfg.fft_len,
              ptr(self.spec), b["enc_in"].ptr, stream())

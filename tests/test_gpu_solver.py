@@ -106,8 +106,11 @@ def test_eval_forward_and_cpu_rejection():
         model(noisy)  # CPU tensor: no fallback
 
 
-def test_graph_replay_matches_eager_steps(tmp_path):
+def test_graph_replay_matches_eager_steps(tmp_path, monkeypatch):
     """Three optimisation steps through the captured hipGraphs == three eager steps (same kernels, same order)."""
+    # (bit-equal first losses need a bit-reproducible forward pass: BatchNorm sums from the separate passes, not from the fp32
+    #  atomics of the convolution epilogues)
+    monkeypatch.setenv("SEHIP_NO_FUSE_STATS", "1")
     from sehip import distrib
     from sehip.solver import Solver, ScalarLog
     batches = [make_batch(300 + s, 2, 4000) for s in range(3)]
