@@ -244,7 +244,7 @@ int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
 int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream);
 /* 1 when the small-channel convolution kernel (conv_small2_kernel: <= 128 concatenated input channels, a power of two; its patch
  * must fit into LDS, which depends on the frame geometry) takes the product a (b == NULL) or the pair (a, b) exactly as described,
- * the `stats` field included (32-output layers: [16 re | 16 im] in natural column order, 8 replicas as above).  Lets a plan ask
+ * the `stats` field included (32-output layers: [16 re | 16 im] or 16-output layers [8 re | 8 im] in natural column order, 8 replicas as above).  Lets a plan ask
  * before it relies on fused statistics for such a layer; no launch. */
 int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b /* or NULL */);
 /* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */

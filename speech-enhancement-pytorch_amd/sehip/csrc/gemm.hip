@@ -828,20 +828,26 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
     }
-    if (TN == 2 && do_stats) {
-        // batch statistics of the ComplexBatchNorm behind a 32-output layer (sehip_gemm_desc.stats): the lane holds the real parts
-        // (column tile 0) and the imaginary parts (tile 1) of complex channels 4 g .. 4 g + 3 for its MI rows, as they are stored
+    if (TN <= 2 && do_stats) {
+        // batch statistics of the ComplexBatchNorm behind a 32- / 16-output layer (sehip_gemm_desc.stats), from the values as they
+        // are stored.  32 outputs: the lane holds the real parts (column tile 0) and the imaginary parts (tile 1) of complex channels
+        // 4 g .. 4 g + 3 for its MI rows.  16 outputs: k groups 0-1 hold the real parts of channels 4 g .., groups 2-3 the imaginary
+        // parts of channels 4 (g - 2) ..: the lower half fetches its partner's values (lane + 32, same row)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            if (t0 + e_tl[mi] >= d.TT) continue;
+            const bool ok = t0 + e_tl[mi] < d.TT;
             const f32x4 vr = acc[0][mi], vi = acc[TN - 1][mi];
             const float br[4] = {sd.bias4[0].x, sd.bias4[0].y, sd.bias4[0].z, sd.bias4[0].w};
             const float bi[4] = {sd.bias4[TN - 1].x, sd.bias4[TN - 1].y, sd.bias4[TN - 1].z, sd.bias4[TN - 1].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float yr = bf2f(f2bf(vr[q] + br[q])), yi = bf2f(f2bf(vi[q] + bi[q]));
-                st[5 * q] += yr; st[5 * q + 1] += yi;
-                st[5 * q + 2] += yr * yr; st[5 * q + 3] += yr * yi; st[5 * q + 4] += yi * yi;
+                const float yr = bf2f(f2bf(vr[q] + br[q]));
+                float yi = bf2f(f2bf(vi[q] + bi[q]));
+                if (TN == 1) yi = __shfl_xor(yi, 32, 64);          // (the upper half accumulates garbage that is never flushed)
+                if (ok) {
+                    st[5 * q] += yr; st[5 * q + 1] += yi;
+                    st[5 * q + 2] += yr * yr; st[5 * q + 3] += yr * yi; st[5 * q + 4] += yi * yi;
+                }
             }
         }
     }
@@ -971,7 +977,7 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
     float st[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) st[i] = 0.f;
-    const bool do_stats = TN == 2 && d.stats != nullptr;
+    const bool do_stats = TN <= 2 && d.stats != nullptr;
     RegTile<NPC> pr;
 #define CS_FETCH(mt_)                                                                                             \
     {                                                                                                             \
@@ -993,8 +999,9 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
         __syncthreads();  // every read of this tile's patch is done before the next one is written
     }
 #undef CS_FETCH
-    if (TN == 2 && do_stats) {
-        // the 16 lanes of a k group hold different rows: xor-shuffles; then the four waves through LDS, 80 atomics per workgroup
+    if (TN <= 2 && do_stats) {
+        // the 16 lanes of a k group hold different rows: xor-shuffles; then the four waves through LDS, 20 atomics per k group that
+        // holds sums (4 groups for 32 outputs, the lower 2 for 16) and workgroup
         // (the patch area is free: the tile loop ends with a barrier; the pair build has no LDS left for a static array)
         float* sred = reinterpret_cast<float*>(patch);       // [wave][k group][20]
 #pragma unroll
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
             for (int i = 0; i < 20; ++i) sred[(w * 4 + (lane >> 4)) * 20 + i] = st[i];
         }
         __syncthreads();
-        if (tid < 80) {
+        if (tid < 40 * TN) {
             const int gg = tid / 20, i = tid - gg * 20, q = i / 5, k = i - 5 * q;
             const float v = sred[gg * 20 + i] + sred[(4 + gg) * 20 + i] + sred[(8 + gg) * 20 + i] + sred[(12 + gg) * 20 + i];
             const int Cr = d.stats_cr;
@@ -1022,8 +1029,11 @@ static int try_conv_small(const sehip_gemm_desc& d, const sehip_gemm_desc* d2, h
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_SMALL") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
     // fused BatchNorm sums: the 32-output build only ([16 re | 16 im] in natural column order, one bf16 destination)
-    if (d.stats && (d.Npad != 32 || d.N != 32 || d.stats_cr != 16 || d.dst[1].ptr || d.dst[0].is_f32 || d.dst[0].C != 32)) return 0;
-    if (d2 && (d2->stats != d.stats || (d.stats && (d2->stats_cr != 16 || d2->dst[1].ptr || d2->dst[0].is_f32 || d2->dst[0].C != 32)))) return 0;
+    // (and the 16-output build: [8 re | 8 im])
+    if (d.stats && ((d.Npad != 32 && d.Npad != 16) || d.N != d.Npad || d.stats_cr * 2 != d.Npad || d.dst[1].ptr || d.dst[0].is_f32 ||
+                    d.dst[0].C != d.Npad)) return 0;
+    if (d2 && (d2->stats != d.stats || (d.stats && (d2->stats_cr != d.stats_cr || d2->dst[1].ptr || d2->dst[0].is_f32 || d2->dst[0].C != d.Npad))))
+        return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int CT = C0 + C1;
     if ((C0 & 7) || (C1 & 7) || CT > 128 || (CT & (CT - 1)) || d.Npad > 128 || CT < 16) return 0;

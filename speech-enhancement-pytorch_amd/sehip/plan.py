@@ -379,8 +379,8 @@ class DCCRNStatic:
         # (round 3: conv_gemm_v3 also takes the sums of a 64-output layer -- one [32 re | 32 im] tile; only that kernel does, so not
         #  when one of its switches is set)
         v3_only = co == 64 and all(c % 16 == 0 for c in cins) and J in (4, 8, 16, 32) and TILE_WEIGHTS and not os.environ.get("SEHIP_NO_FUSE_STATS64")
-        if co == 32 and not os.environ.get("SEHIP_NO_FUSE_STATS32"):
-            # a 32-output layer on the small-channel kernel: whether that kernel takes the product (its patch must fit into LDS)
+        if co in (16, 32) and all(c >= 8 for c in cins) and not os.environ.get("SEHIP_NO_FUSE_STATS32"):
+            # a 32- / 16-output layer on the small-channel kernel: whether that kernel takes the product (its patch must fit into LDS)
             # depends on the workspace, so the workspace asks the library when it binds the descriptors (small_stats)
             self.small_stats[pre] = list(names)
             return
@@ -908,7 +908,7 @@ class DCCRNWorkspace:
             ds = [self.desc[nm] for nm in names]
             for d in ds:
                 d.stats = self.bn_stats[pre].data_ptr()
-                d.stats_cr = 16
+                d.stats_cr = d.Npad // 2
             if lib.sehip_conv_small_takes(C.byref(ds[0]), C.byref(ds[1]) if len(ds) == 2 else None):
                 self.fused_small.add(pre)
             else:
