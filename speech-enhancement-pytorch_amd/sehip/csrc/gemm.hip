@@ -676,6 +676,54 @@ static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
 // (branch-free, see sw_fetch_patch) while the current one is multiplied and stored, the store addressing (row
 // offsets, n-chunk table entries, bias) is computed once per workgroup, and the K loop walks taps with scalar offsets.
 // ------------------------------------------------------------------------------------------------
+// Fused ComplexBatchNorm sums of the small-channel kernels (sehip_gemm_desc.stats; conv_small2_kernel, conv_narrow_kernel), from
+// the accumulators, of the values as they are stored.  A lane holds D[row (lane & 15) of tile mi][columns 16 ni + 4 g ..].
+// 32 outputs (TN = 2): column tile 0 = real parts, tile 1 = imaginary parts of complex channels 4 g .. 4 g + 3.  16 outputs
+// (TN = 1): k groups 0-1 hold the real parts of channels 4 g .., groups 2-3 the imaginary parts of channels 4 (g - 2) ..: the
+// lower half fetches its partner's values (lane + 32, same row); the upper half accumulates garbage that is never flushed.
+// st[5 q + k]: sum re, sum im, sum re^2, sum re im, sum im^2 of channel 4 g + q.
+template <int TN, int MI>
+__device__ __forceinline__ void small_stats_add(const f32x4 (&acc)[TN][MI], const float4 (&bias4)[TN], const int (&e_tl)[MI], int t0,
+                                                int TT, float (&st)[20]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const bool ok = t0 + e_tl[mi] < TT;
+        const f32x4 vr = acc[0][mi], vi = acc[TN - 1][mi];
+        const float br[4] = {bias4[0].x, bias4[0].y, bias4[0].z, bias4[0].w};
+        const float bi[4] = {bias4[TN - 1].x, bias4[TN - 1].y, bias4[TN - 1].z, bias4[TN - 1].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float yr = bf2f(f2bf(vr[q] + br[q]));
+            float yi = bf2f(f2bf(vi[q] + bi[q]));
+            if (TN == 1) yi = __shfl_xor(yi, 32, 64);
+            if (ok) {
+                st[5 * q] += yr; st[5 * q + 1] += yi;
+                st[5 * q + 2] += yr * yr; st[5 * q + 3] += yr * yi; st[5 * q + 4] += yi * yi;
+            }
+        }
+    }
+}
+// end of the workgroup (after a barrier; sred: 320 floats of LDS nobody uses any more): the 16 lanes of a k group hold different rows
+// -> xor-shuffles; the four waves meet in LDS; 20 atomics per k group that holds sums (4 for 32 outputs, the lower 2 for 16)
+template <int TN>
+__device__ __forceinline__ void small_stats_flush(float (&st)[20], float* sred, float* stats, int Cr, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 20; ++i)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) sred[(w * 4 + (lane >> 4)) * 20 + i] = st[i];
+    }
+    __syncthreads();
+    if (tid < 40 * TN) {
+        const int gg = tid / 20, i = tid - gg * 20, q = i / 5, k = i - 5 * q;
+        const float v = sred[gg * 20 + i] + sred[(4 + gg) * 20 + i] + sred[(8 + gg) * 20 + i] + sred[(12 + gg) * 20 + i];
+        atomicAdd(stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + 4 * gg + q, v);
+    }
+}
+
 // Everything of one product over a staged patch that depends on the descriptor: weights in LDS, tap geometry, store
 // addressing.  A launch carries one side, or two (the two output-row parities of a transposed convolution read the same
 // input: staged once, multiplied by both weight sets -- see sehip_gemm_pair).
@@ -828,28 +876,8 @@ __device__ __forceinline__ void cs2_multiply_store(const Cs2Side<TN, MI> sd, con
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
     }
-    if (TN <= 2 && do_stats) {
-        // batch statistics of the ComplexBatchNorm behind a 32- / 16-output layer (sehip_gemm_desc.stats), from the values as they
-        // are stored.  32 outputs: the lane holds the real parts (column tile 0) and the imaginary parts (tile 1) of complex channels
-        // 4 g .. 4 g + 3 for its MI rows.  16 outputs: k groups 0-1 hold the real parts of channels 4 g .., groups 2-3 the imaginary
-        // parts of channels 4 (g - 2) ..: the lower half fetches its partner's values (lane + 32, same row)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const bool ok = t0 + e_tl[mi] < d.TT;
-            const f32x4 vr = acc[0][mi], vi = acc[TN - 1][mi];
-            const float br[4] = {sd.bias4[0].x, sd.bias4[0].y, sd.bias4[0].z, sd.bias4[0].w};
-            const float bi[4] = {sd.bias4[TN - 1].x, sd.bias4[TN - 1].y, sd.bias4[TN - 1].z, sd.bias4[TN - 1].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float yr = bf2f(f2bf(vr[q] + br[q]));
-                float yi = bf2f(f2bf(vi[q] + bi[q]));
-                if (TN == 1) yi = __shfl_xor(yi, 32, 64);          // (the upper half accumulates garbage that is never flushed)
-                if (ok) {
-                    st[5 * q] += yr; st[5 * q + 1] += yi;
-                    st[5 * q + 2] += yr * yr; st[5 * q + 3] += yr * yi; st[5 * q + 4] += yi * yi;
-                }
-            }
-        }
+    if constexpr (TN <= 2) {
+        if (do_stats) small_stats_add<TN, MI>(acc, sd.bias4, e_tl, t0, d.TT, st);
     }
     if (sd.dense) {
         constexpr int TP = 16 * TN + 8;
@@ -999,26 +1027,9 @@ __global__ __launch_bounds__(256) void conv_small2_kernel(const sehip_gemm_desc 
         __syncthreads();  // every read of this tile's patch is done before the next one is written
     }
 #undef CS_FETCH
-    if (TN <= 2 && do_stats) {
-        // the 16 lanes of a k group hold different rows: xor-shuffles; then the four waves through LDS, 20 atomics per k group that
-        // holds sums (4 groups for 32 outputs, the lower 2 for 16) and workgroup
+    if constexpr (TN <= 2) {
         // (the patch area is free: the tile loop ends with a barrier; the pair build has no LDS left for a static array)
-        float* sred = reinterpret_cast<float*>(patch);       // [wave][k group][20]
-#pragma unroll
-        for (int i = 0; i < 20; ++i)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int i = 0; i < 20; ++i) sred[(w * 4 + (lane >> 4)) * 20 + i] = st[i];
-        }
-        __syncthreads();
-        if (tid < 40 * TN) {
-            const int gg = tid / 20, i = tid - gg * 20, q = i / 5, k = i - 5 * q;
-            const float v = sred[gg * 20 + i] + sred[(4 + gg) * 20 + i] + sred[(8 + gg) * 20 + i] + sred[(12 + gg) * 20 + i];
-            const int Cr = d.stats_cr;
-            atomicAdd(d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + 4 * gg + q, v);
-        }
+        if (do_stats) small_stats_flush<TN>(st, reinterpret_cast<float*>(patch), d.stats, d.stats_cr, tid);
     }
 }
 
@@ -1431,6 +1442,10 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const sehip_gemm_desc 
     }
 
     const int mt_begin = blockIdx.x * tiles_per_wg, mt_end = min(MT, mt_begin + tiles_per_wg);
+    float st[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) st[i] = 0.f;
+    const bool do_stats = d.stats != nullptr;          // (fused BatchNorm sums: small_stats_add)
     uint4 pr[NPL];
 #define CN_FETCH(mt_)                                                                                              \
     {                                                                                                              \
@@ -1468,6 +1483,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const sehip_gemm_desc 
             for (int ni = 0; ni < TN; ++ni)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
+        if (do_stats) small_stats_add<TN, MI>(acc, bias4, e_tl, t0, d.TT, st);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             if (t0 + e_tl[mi] >= d.TT) continue;
@@ -1498,11 +1514,13 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const sehip_gemm_desc 
         __syncthreads();
     }
 #undef CN_FETCH
+    if (do_stats) small_stats_flush<TN>(st, reinterpret_cast<float*>(smem), d.stats, d.stats_cr, tid);
 }
 
-static int try_conv_narrow(const sehip_gemm_desc& d, hipStream_t st) {
+static int try_conv_narrow(const sehip_gemm_desc& d, hipStream_t st, bool dry = false) {
     static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
     if (disabled || d.cv_nf <= 0 || d.cv_nf > 5 || d.src[0].C != 2 || d.src[1].ptr || d.res) return 0;
+    if (d.stats && (d.N != d.Npad || d.stats_cr * 2 != d.Npad || d.dst[1].ptr || d.dst[0].is_f32 || d.dst[0].C != d.Npad)) return 0;
     if ((d.Npad != 16 && d.Npad != 32) || d.K < 32 || d.J > 128 || (128 % d.J)) return 0;
     const int fa = (d.cv_fadd >= 0 ? d.cv_fadd / 4 : -((-d.cv_fadd + 3) / 4)) * 4;
     if ((d.cv_fadd - fa) & 1) return 0;  // 8-byte aligned operand reads
@@ -1512,7 +1530,9 @@ static int try_conv_narrow(const sehip_gemm_desc& d, hipStream_t st) {
     // staged rows per frame: the lane of the last row reads taps 4..7 as well (zero weights): (J-1)*fmul + 8 rows
     const int FRA = ((d.cv_fadd - fa) + (d.J - 1) * d.fmul + 8 + 3) / 4 * 4;
     if ((TB + 1) * (FRA >> 2) > 4 * 256 || (d.src[0].F & 3)) return 0;
-    const size_t lds = (size_t)(TB + 1) * FRA * 4;
+    size_t lds = (size_t)(TB + 1) * FRA * 4;
+    if (lds < 320 * sizeof(float)) lds = 320 * sizeof(float);      // small_stats_flush
+    if (dry) return 1;
     const int B = d.M / (d.TT * d.J);
     const int MT = B * ((d.TT + TB - 1) / TB);
     int wgs = 1024;
@@ -1530,7 +1550,7 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
     if (d->stats) {   // only the LDS-DMA convolution kernel accumulates the BatchNorm statistics (sehip.h): no silent omission
-        if (sehip_try_conv_gemm_v3(*d, st) || (!d->w_tiled && sehip_try_conv_gemm_v2(*d, st)) || (!d->w_tiled && try_conv_small(*d, nullptr, st))) {
+        if (sehip_try_conv_gemm_v3(*d, st) || (!d->w_tiled && sehip_try_conv_gemm_v2(*d, st)) || (!d->w_tiled && (try_conv_small(*d, nullptr, st) || try_conv_narrow(*d, st)))) {
             SEHIP_CHECK_LAUNCH("gemm(conv+stats)");
             return 0;
         }
@@ -1581,7 +1601,8 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
 // the plan asks before it relies on them (workspace-dependent: the kernel must fit its patch into LDS)
 extern "C" int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b) {
     if (!a) return 0;
-    return try_conv_small(*a, b, nullptr, true);
+    if (try_conv_small(*a, b, nullptr, true)) return 1;
+    return b ? 0 : try_conv_narrow(*a, nullptr, true);          // (2-channel input: conv_narrow_kernel)
 }
 
 extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream) {

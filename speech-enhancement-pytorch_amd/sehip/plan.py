@@ -379,7 +379,7 @@ class DCCRNStatic:
         # (round 3: conv_gemm_v3 also takes the sums of a 64-output layer -- one [32 re | 32 im] tile; only that kernel does, so not
         #  when one of its switches is set)
         v3_only = co == 64 and all(c % 16 == 0 for c in cins) and J in (4, 8, 16, 32) and TILE_WEIGHTS and not os.environ.get("SEHIP_NO_FUSE_STATS64")
-        if co in (16, 32) and all(c >= 8 for c in cins) and not os.environ.get("SEHIP_NO_FUSE_STATS32"):
+        if co in (16, 32) and not os.environ.get("SEHIP_NO_FUSE_STATS32"):
             # a 32- / 16-output layer on the small-channel kernel: whether that kernel takes the product (its patch must fit into LDS)
             # depends on the workspace, so the workspace asks the library when it binds the descriptors (small_stats)
             self.small_stats[pre] = list(names)
