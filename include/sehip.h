@@ -292,6 +292,12 @@ int sehip_cbn_finalize_n(const float* part, int nblk, const float* Wrr, const fl
                        const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, long* nbt,
                        long rows, int Cr, float eps, float momentum, int training, float* coef /*[Cr][16]*/, void* stream);
 int sehip_cbn_apply(const void* y, const float* coef, const float* slope, long rows, int Cr, void* z, void* stream);
+/* sehip_cbn_finalize_n followed by sehip_cbn_apply, in one launch (nblk <= 64 rows of sums: every workgroup of the apply pass derives
+ * the coefficient records itself, the first one also stores them in `coef` and moves the running statistics) */
+int sehip_cbn_finalize_apply_n(const void* y, const float* part, int nblk, const float* Wrr, const float* Wri, const float* Wii,
+                               const float* Br, const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii,
+                               long* nbt, long rows, int Cr, float eps, float momentum, int training, float* coef /*[Cr][16]*/,
+                               const float* slope, void* z, void* stream);
 int sehip_cbn_bwd_reduce(const void* dz, const void* dz2 /*or NULL*/, const void* y, const float* coef, const float* slope,
                          long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream);
 int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri, const float* Wii,

@@ -85,6 +85,7 @@ _PROTOS = {
     "sehip_cbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],
     "sehip_cbn_finalize_n": [P, I, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P],
     "sehip_cbn_apply": [P, P, P, L, I, P, P],
+    "sehip_cbn_finalize_apply_n": [P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P, P, P, P],
     "sehip_cbn_bwd_reduce": [P, P, P, P, P, L, I, I, I, I, P, P],
     "sehip_cbn_bwd_finalize": [P, P, P, P, P, L, I, P, P, P, P, P, P, P, P],
     "sehip_cbn_bwd_apply": [P, P, P, P, P, P, L, I, I, I, I, P, P],

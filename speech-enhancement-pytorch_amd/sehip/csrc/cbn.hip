@@ -143,6 +143,24 @@ __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restri
     block_partials<5, CH>(s, nq, Cr, part, 5 * Cr, lds);
 }
 
+// the forward coefficient record of one channel from its moments (covariance WITHOUT eps) and affine parameters
+__device__ __forceinline__ void cbn_fwd_record(float mr, float mi, float vrr, float vri, float vii, float eps, float wrr, float wri,
+                                               float wii, float br_, float bi_, float (&o)[14]) {
+    vrr += eps; vii += eps;
+    const float tau = vrr + vii;
+    const float delta = vrr * vii - vri * vri;
+    const float s = sqrtf(delta);
+    const float t = sqrtf(tau + 2.f * s);
+    const float rst = 1.f / (s * t);
+    const float urr = (s + vii) * rst, uii = (s + vrr) * rst, uri = -vri * rst;
+    o[0] = wrr * urr + wri * uri;
+    o[1] = wrr * uri + wri * uii;
+    o[2] = wri * urr + wii * uri;
+    o[3] = wri * uri + wii * uii;
+    o[4] = mr; o[5] = mi; o[6] = br_; o[7] = bi_;
+    o[8] = urr; o[9] = uri; o[10] = uii; o[11] = vrr; o[12] = vri; o[13] = vii;
+}
+
 // one wave per complex channel
 __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ Wrr, const float* __restrict__ Wri,
                                     const float* __restrict__ Wii, const float* __restrict__ Br, const float* __restrict__ Bi,
@@ -175,20 +193,11 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
         if (threadIdx.x != 0) return;
         mr = rmr; mi = rmi; vrr = rvrr; vri = rvri; vii = rvii;
     }
-    vrr += eps; vii += eps;
-    const float tau = vrr + vii;
-    const float delta = vrr * vii - vri * vri;
-    const float s = sqrtf(delta);
-    const float t = sqrtf(tau + 2.f * s);
-    const float rst = 1.f / (s * t);
-    const float urr = (s + vii) * rst, uii = (s + vrr) * rst, uri = -vri * rst;
+    float rec[14];
+    cbn_fwd_record(mr, mi, vrr, vri, vii, eps, wrr, wri, wii, br_, bi_, rec);
     float* o = coef + (size_t)c * COEF_STRIDE;
-    o[0] = wrr * urr + wri * uri;
-    o[1] = wrr * uri + wri * uii;
-    o[2] = wri * urr + wii * uri;
-    o[3] = wri * uri + wii * uii;
-    o[4] = mr; o[5] = mi; o[6] = br_; o[7] = bi_;
-    o[8] = urr; o[9] = uri; o[10] = uii; o[11] = vrr; o[12] = vri; o[13] = vii;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) o[i] = rec[i];
 }
 
 // The per-channel coefficient records reach the threads through LDS: every thread needs the records of its CH complex
@@ -217,6 +226,105 @@ __global__ __launch_bounds__(256, 2) void cbn_apply_kernel(const bf16_raw* __res
     const float a = slope[0];
     stage_coef<CH>(coef, Cr, 2, cl);
     __syncthreads();
+    float4 zc[CH], mb[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { zc[j] = cl[j * nq + q]; mb[j] = cl[Cr + j * nq + q]; }
+    auto row = [&](const raw_t& ur, const raw_t& ui, long r) {
+        const Chunk<CH> xr = unpack(ur), xi = unpack(ui);
+        float orr[CH], oii[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
+            const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
+            const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
+            orr[j] = vr > 0.f ? vr : a * vr;
+            oii[j] = vi > 0.f ? vi : a * vi;
+        }
+        pack_store(z + r * C + q * CH, orr);
+        pack_store(z + r * C + Cr + q * CH, oii);
+    };
+    const long stride = (long)gridDim.x * rpb;
+    const bf16_raw* p = y + q * CH;
+    long r = (long)blockIdx.x * rpb + rl;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+        raw_t ur[U], ui[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ur[u] = *reinterpret_cast<const raw_t*>(p + (r + u * stride) * C);
+            ui[u] = *reinterpret_cast<const raw_t*>(p + (r + u * stride) * C + Cr);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(ur[u], ui[u], r + u * stride);
+    }
+    if (U > 1)
+        for (; r < rows; r += stride)
+            row(*reinterpret_cast<const raw_t*>(p + r * C), *reinterpret_cast<const raw_t*>(p + r * C + Cr), r);
+}
+
+// cbn_finalize_kernel + cbn_apply_kernel in one launch, for the layers whose sums arrive as a few replica rows (the convolution
+// epilogues' `stats`: nblk = 8): every workgroup derives the coefficient records of all Cr channels itself (thread c: 5 nblk loads
+// that hit L2, the moments in double precision, the closed-form inverse square root) straight into the LDS slots the streaming
+// loop reads them from; workgroup 0 also writes the records for the backward pass and moves the running statistics.  Saves the
+// 5-6 us finalize launch and a kernel boundary per layer on the dependent chain for ~1 us more per apply workgroup.
+template <int U, int CH>
+__global__ __launch_bounds__(256, 2) void cbn_apply_fin_kernel(const bf16_raw* __restrict__ y, const float* __restrict__ part, int nblk,
+                                                               const float* __restrict__ Wrr, const float* __restrict__ Wri,
+                                                               const float* __restrict__ Wii, const float* __restrict__ Br,
+                                                               const float* __restrict__ Bi, float* __restrict__ RMr, float* __restrict__ RMi,
+                                                               float* __restrict__ RVrr, float* __restrict__ RVri, float* __restrict__ RVii,
+                                                               long* __restrict__ nbt, long rows, int Cr, float eps, float momentum,
+                                                               int training, float* __restrict__ coef, const float* __restrict__ slope,
+                                                               bf16_raw* __restrict__ z) {
+    typedef typename Raw<CH>::type raw_t;
+    __shared__ float4 cl[2 * 256];
+    const int nq = Cr / CH;
+    const int C = 2 * Cr;
+    for (int c = threadIdx.x; c < Cr; c += 256) {
+        const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c], br_ = Br[c], bi_ = Bi[c];
+        const float rmr = RMr[c], rmi = RMi[c], rvrr = RVrr[c], rvri = RVri[c], rvii = RVii[c];
+        float mr = rmr, mi = rmi, vrr = rvrr, vri = rvri, vii = rvii;
+        if (training) {
+            double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int r0 = 0; r0 < nblk; r0 += 8) {               // 40 independent loads per trip
+                float v[8][5];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) v[r][k] = part[(size_t)(r0 + r < nblk ? r0 + r : 0) * 5 * Cr + k * Cr + c];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) a[k] += r0 + r < nblk ? (double)v[r][k] : 0.0;
+            }
+            const double n = (double)rows;
+            const double dmr = a[0] / n, dmi = a[1] / n;
+            mr = (float)dmr; mi = (float)dmi;
+            vrr = (float)(a[2] / n - dmr * dmr);
+            vri = (float)(a[3] / n - dmr * dmi);
+            vii = (float)(a[4] / n - dmi * dmi);
+            if (blockIdx.x == 0) {
+                RMr[c] = rmr + momentum * (mr - rmr);
+                RMi[c] = rmi + momentum * (mi - rmi);
+                RVrr[c] = rvrr + momentum * (vrr - rvrr);
+                RVri[c] = rvri + momentum * (vri - rvri);
+                RVii[c] = rvii + momentum * (vii - rvii);
+                if (c == 0 && nbt) nbt[0] += 1;
+            }
+        }
+        float rec[14];
+        cbn_fwd_record(mr, mi, vrr, vri, vii, eps, wrr, wri, wii, br_, bi_, rec);
+        const int slot = (c % CH) * nq + (c / CH);               // the layout stage_coef gives the streaming loop
+        cl[slot] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        cl[Cr + slot] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        if (blockIdx.x == 0) {
+            float* o = coef + (size_t)c * COEF_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 14; ++i) o[i] = rec[i];
+        }
+    }
+    __syncthreads();
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    const float a = slope[0];
     float4 zc[CH], mb[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) { zc[j] = cl[j * nq + q]; mb[j] = cl[Cr + j * nq + q]; }
@@ -572,6 +680,29 @@ extern "C" int sehip_cbn_apply(const void* y, const float* coef, const float* sl
     }
 #undef CBN_APPLY
     SEHIP_CHECK_LAUNCH("cbn_apply");
+    return 0;
+}
+
+// sehip_cbn_finalize_n + sehip_cbn_apply in one launch (cbn_apply_fin_kernel): for sums that arrive as a few rows (nblk <= 64)
+extern "C" int sehip_cbn_finalize_apply_n(const void* y, const float* part, int nblk, const float* Wrr, const float* Wri, const float* Wii,
+                                          const float* Br, const float* Bi, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii,
+                                          long* nbt, long rows, int Cr, float eps, float momentum, int training, float* coef,
+                                          const float* slope, void* z, void* stream) {
+    if (int e = check_cbn("cbn_finalize_apply_n", rows, Cr)) return e;
+    SEHIP_REQUIRE(nblk >= 1 && nblk <= 64, "cbn_finalize_apply_n: %d rows of sums (1..64)", nblk);
+#define CBN_FAPP(U, CH) cbn_apply_fin_kernel<U, CH><<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(                 \
+        (const bf16_raw*)y, part, nblk, Wrr, Wri, Wii, Br, Bi, RMr, RMi, RVrr, RVri, RVii, nbt, rows, Cr, eps, momentum, training, coef, \
+        slope, (bf16_raw*)z)
+    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+        case 1 * 16 + 8: CBN_FAPP(1, 8); break;
+        case 2 * 16 + 8: CBN_FAPP(2, 8); break;
+        case 4 * 16 + 8: CBN_FAPP(4, 8); break;
+        case 1 * 16 + 4: CBN_FAPP(1, 4); break;
+        case 4 * 16 + 4: CBN_FAPP(4, 4); break;
+        default: CBN_FAPP(2, 4); break;
+    }
+#undef CBN_FAPP
+    SEHIP_CHECK_LAUNCH("cbn_finalize_apply_n");
     return 0;
 }
 

@@ -51,6 +51,8 @@ class CGemmDesc(C.Structure):
 # (descriptor field `res`), so the BatchNorm backward kernels read one gradient tensor instead of two.
 FUSE_SKIP_GRAD = not os.environ.get("SEHIP_NO_FUSE_SKIP")
 # Products that conv_gemm_v3 takes get their packed weights in its tile order (the switches that take the kernel away keep [Npad][K])
+# the apply pass of a layer with fused sums also finalizes them (sehip_cbn_finalize_apply_n)
+FUSE_FINALIZE = not os.environ.get("SEHIP_NO_FUSE_FINALIZE")
 TILE_WEIGHTS = not any(os.environ.get(k) for k in ("SEHIP_NO_CONV_V3", "SEHIP_NO_PATCH", "SEHIP_NO_TILE_WEIGHTS"))
 
 
@@ -1040,6 +1042,11 @@ class DCCRNWorkspace:
         pp, bp, nb = self._bn_ptrs(pre, params, buffers, nbt)
         coef = self.bn_coef[pre]
         if pre in self.st.fused_stats or pre in self.fused_small:     # the producing convolution accumulated the sums (8 replicas)
+            if FUSE_FINALIZE:               # ... and the apply pass derives the coefficients itself: one launch
+                call("sehip_cbn_finalize_apply_n", y.ptr, ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"),
+                     pp("1.Bi"), bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
+                     1 if training else 0, ptr(coef), pp("2.weight"), z.ptr, stream())
+                return
             call("sehip_cbn_finalize_n", ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
                  bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
                  1 if training else 0, ptr(coef), stream())
