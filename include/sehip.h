@@ -303,6 +303,14 @@ int sehip_cbn_bwd_reduce(const void* dz, const void* dz2 /*or NULL*/, const void
 int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri, const float* Wii,
                            long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope,
                            float* bcoef /*[Cr][16]*/, void* stream);
+/* the backward pass of the layer in two launches: sehip_cbn_bwd_reduce adding its block sums to `rep` ([nrep][6 Cr + 1] fp32, zero
+ * on entry, nrep <= 64) with atomics, then an apply pass that finalizes them itself (parameter gradients written as by
+ * sehip_cbn_bwd_finalize) and clears `rep_next` -- a second set of rows, to be passed as `rep` by the layer's next call (the two
+ * sets alternate; both zero before the first call) */
+int sehip_cbn_bwd_fused(const void* dz, const void* dz2 /*or NULL*/, const void* y, const float* coef, const float* Wrr, const float* Wri,
+                        const float* Wii, const float* slope, long rows, int Cr, int F, int Tst, int tfirst, float* rep, float* rep_next,
+                        int nrep,
+                        float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope, void* dy, void* stream);
 int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
                         const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream);
 

@@ -50,11 +50,13 @@ __device__ __forceinline__ void pack_store(bf16_raw* p, const float (&v)[4]) {
 // Reduce NS per-thread sums (for 8 channels each) over the threads of the block that share a chunk column q and
 // store the block's partial sums at part[blockIdx.x][a*Cr + channel] (no atomics: a later per-channel wave adds the
 // partials of all blocks in double precision).
+// nrep > 0: `part` holds nrep zeroed rows instead and the block ADDS its sums to row blockIdx.x % nrep with atomics (so few rows
+// that the pass that needs the totals can add them up itself: cbn_bwd_apply_fin_kernel).
 template <int NS, int CH>
 __device__ __forceinline__ void block_partials(float (&s)[NS][CH], int nq, int Cr, float* __restrict__ part, int stride,
-                                               float* lds /* [4][NS*CH][nq] floats */) {
+                                               float* lds /* [4][NS*CH][nq] floats */, int nrep = 0) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* out = part + (size_t)blockIdx.x * stride;
+    float* out = part + (size_t)(nrep > 0 ? blockIdx.x % nrep : blockIdx.x) * stride;
     // fold the lanes of a wave that share a chunk column (nq divides 64), park the wave partials in LDS, ONE barrier,
     // then NS*CH*nq threads add the four waves
 #pragma unroll
@@ -70,7 +72,8 @@ __device__ __forceinline__ void block_partials(float (&s)[NS][CH], int nq, int C
     for (int i = tid; i < n; i += 256) {
         const float t = lds[i] + lds[n + i] + lds[2 * n + i] + lds[3 * n + i];
         const int aj = i / nq, q = i - aj * nq;
-        out[(size_t)(aj / CH) * Cr + q * CH + (aj % CH)] = t;
+        if (nrep > 0) atomicAdd(&out[(size_t)(aj / CH) * Cr + q * CH + (aj % CH)], t);
+        else out[(size_t)(aj / CH) * Cr + q * CH + (aj % CH)] = t;
     }
 }
 
@@ -386,7 +389,7 @@ template <int U, int CH, bool HAS2>
 __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
                                                                 const bf16_raw* __restrict__ y, const float* __restrict__ coef,
                                                                 const float* __restrict__ slope, long rows, int Cr, int F,
-                                                                int Tst, int tfirst, float* __restrict__ part) {
+                                                                int Tst, int tfirst, float* __restrict__ part, int nrep) {
     __shared__ float lds[4 * 6 * 8 * 32];
     const int nq = Cr / CH;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
@@ -440,45 +443,26 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* 
     }
     if (U > 1)
         for (; r < rows; r += stride) row(load_row<CH, HAS2>(y, dz, dz2, r * C + q * CH, Cr), r);
-    block_partials<6, CH>(s, nq, Cr, part, 6 * Cr + 1, lds);
+    block_partials<6, CH>(s, nq, Cr, part, 6 * Cr + 1, lds, nrep);
     da = wave_sum(da);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = da;
     __syncthreads();
-    if (threadIdx.x == 0) part[(size_t)blockIdx.x * (6 * Cr + 1) + 6 * Cr] = lds[0] + lds[1] + lds[2] + lds[3];
+    if (threadIdx.x == 0) {
+        const float t = lds[0] + lds[1] + lds[2] + lds[3];
+        if (nrep > 0) atomicAdd(&part[(size_t)(blockIdx.x % nrep) * (6 * Cr + 1) + 6 * Cr], t);
+        else part[(size_t)blockIdx.x * (6 * Cr + 1) + 6 * Cr] = t;
+    }
 }
 
-// one wave per channel: parameter gradients + coefficients of the apply pass
-__global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ coef,
-                                        const float* __restrict__ Wrr, const float* __restrict__ Wri,
-                                        const float* __restrict__ Wii, long rows, int Cr, float* __restrict__ gWrr,
-                                        float* __restrict__ gWri, float* __restrict__ gWii, float* __restrict__ gBr,
-                                        float* __restrict__ gBi, float* __restrict__ gslope, float* __restrict__ bcoef) {
-    const int c = blockIdx.x;
-    const int st = 6 * Cr + 1;
-    if (c == Cr) {  // extra block: the PReLU slope gradient (its own block, so that channel 0 is not a straggler)
-        double ds[1];
-        wave_reduce_partials<1>(part, nblk, st, 6 * Cr, Cr, ds);
-        if (threadIdx.x == 0) gslope[0] = (float)ds[0];
-        return;
-    }
-    // the per-channel constants are requested before the reduction, not after it (one memory round trip less on the chain)
-    const float* k = coef + (size_t)c * COEF_STRIDE;
-    const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
-    const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
-    double a[6];
-    wave_reduce_partials<6>(part, nblk, st, c, Cr, a);
-    const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
-    if (threadIdx.x != 0) return;
-    const float n = (float)rows;
+// parameter gradients (g5: dWrr dWri dWii dBr dBi) and the apply pass's record of one channel from its six sums
+__device__ __forceinline__ void cbn_bwd_record(float sdr, float sdi, float qrr, float qri, float qir, float qii, float urr, float uri,
+                                               float uii, float vrr, float vri, float vii, float wrr, float wri, float wii, float n,
+                                               float (&g5)[5], float (&o)[9]) {
     // P = Q U  (sum d xh^T)
     const float prr = qrr * urr + qri * uri, pri = qrr * uri + qri * uii;
     const float pir = qir * urr + qii * uri, pii = qir * uri + qii * uii;
-    gWrr[c] = prr;
-    gWri[c] = pri + pir;
-    gWii[c] = pii;
-    gBr[c] = sdr;
-    gBi[c] = sdi;
+    g5[0] = prr; g5[1] = pri + pir; g5[2] = pii; g5[3] = sdr; g5[4] = sdi;
     // H = Wm Q  (sum dxh c^T)
     const float hrr = wrr * qrr + wri * qir, hri = wrr * qri + wri * qii;
     const float hir = wri * qrr + wii * qir, hii = wri * qri + wii * qii;
@@ -503,11 +487,40 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
     // A = U Wm
     const float arr = urr * wrr + uri * wri, ari = urr * wri + uri * wii;
     const float air = uri * wrr + uii * wri, aii = uri * wri + uii * wii;
-    float* o = bcoef + (size_t)c * COEF_STRIDE;
     o[0] = arr; o[1] = ari; o[2] = air; o[3] = aii;
     o[4] = 2.f * d_vrr / n; o[5] = d_vri / n; o[6] = 2.f * d_vii / n;
     o[7] = -(arr * sdr + ari * sdi) / n;
     o[8] = -(air * sdr + aii * sdi) / n;
+}
+
+// one wave per channel: parameter gradients + coefficients of the apply pass
+__global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ coef,
+                                        const float* __restrict__ Wrr, const float* __restrict__ Wri,
+                                        const float* __restrict__ Wii, long rows, int Cr, float* __restrict__ gWrr,
+                                        float* __restrict__ gWri, float* __restrict__ gWii, float* __restrict__ gBr,
+                                        float* __restrict__ gBi, float* __restrict__ gslope, float* __restrict__ bcoef) {
+    const int c = blockIdx.x;
+    const int st = 6 * Cr + 1;
+    if (c == Cr) {  // extra block: the PReLU slope gradient (its own block, so that channel 0 is not a straggler)
+        double ds[1];
+        wave_reduce_partials<1>(part, nblk, st, 6 * Cr, Cr, ds);
+        if (threadIdx.x == 0) gslope[0] = (float)ds[0];
+        return;
+    }
+    // the per-channel constants are requested before the reduction, not after it (one memory round trip less on the chain)
+    const float* k = coef + (size_t)c * COEF_STRIDE;
+    const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
+    const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
+    double a[6];
+    wave_reduce_partials<6>(part, nblk, st, c, Cr, a);
+    const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
+    if (threadIdx.x != 0) return;
+    float g5[5], rec[9];
+    cbn_bwd_record(sdr, sdi, qrr, qri, qir, qii, urr, uri, uii, vrr, vri, vii, wrr, wri, wii, (float)rows, g5, rec);
+    gWrr[c] = g5[0]; gWri[c] = g5[1]; gWii[c] = g5[2]; gBr[c] = g5[3]; gBi[c] = g5[4];
+    float* o = bcoef + (size_t)c * COEF_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = rec[i];
 }
 
 template <int U, int CH, bool HAS2>
@@ -524,6 +537,108 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_apply_kernel(const bf16_raw* _
     // per-channel coefficients of this thread's CH complex channels, in registers for the whole pass
     stage_coef<CH>(coef, Cr, 2, cl);
     stage_coef<CH>(bcoef, Cr, 3, cl + 2 * Cr);
+    __syncthreads();
+    float4 zc[CH], mb[CH], A[CH], E[CH];
+    float ki[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        zc[j] = cl[j * nq + q];
+        mb[j] = cl[Cr + j * nq + q];
+        A[j] = cl[2 * Cr + j * nq + q];
+        E[j] = cl[3 * Cr + j * nq + q];  // Err Eri Eii kr
+        ki[j] = cl[4 * Cr + j * nq + q].x;
+    }
+    auto row = [&](const RowIn<CH, HAS2>& v, long r) {
+        const bool dropped = tfirst > 0 && (int)(((unsigned)r / (unsigned)F) % (unsigned)Tst) < tfirst;
+        const Chunk<CH> xr = unpack(v.yr), xi = unpack(v.yi);
+        Chunk<CH> gr = unpack(v.gr), gi = unpack(v.gi);
+        if (HAS2) {
+            const Chunk<CH> hr = unpack(v.hr), hi = unpack(v.hi);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { gr.v[j] += hr.v[j]; gi.v[j] += hi.v[j]; }
+        }
+        float orr[CH], oii[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float cr = xr.v[j] - mb[j].x, ci = xi.v[j] - mb[j].y;
+            const float vr = zc[j].x * cr + zc[j].y * ci + mb[j].z;
+            const float vi = zc[j].z * cr + zc[j].w * ci + mb[j].w;
+            float dr = dropped ? 0.f : gr.v[j], di = dropped ? 0.f : gi.v[j];
+            if (!(vr > 0.f)) dr *= a;
+            if (!(vi > 0.f)) di *= a;
+            orr[j] = A[j].x * dr + A[j].y * di + E[j].x * cr + E[j].y * ci + E[j].w;
+            oii[j] = A[j].z * dr + A[j].w * di + E[j].y * cr + E[j].z * ci + ki[j];
+        }
+        pack_store(dy + r * C + q * CH, orr);
+        pack_store(dy + r * C + Cr + q * CH, oii);
+    };
+    const long stride = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + rl;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+        RowIn<CH, HAS2> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load_row<CH, HAS2>(y, dz, dz2, (r + u * stride) * C + q * CH, Cr);
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(v[u], r + u * stride);
+    }
+    if (U > 1)
+        for (; r < rows; r += stride) row(load_row<CH, HAS2>(y, dz, dz2, r * C + q * CH, Cr), r);
+}
+
+// cbn_bwd_finalize_kernel + cbn_bwd_apply_kernel in one launch, for sums that the reduce pass left in a few rows (nrep <= 64, fp32
+// atomics: cbn_bwd_reduce_kernel with nrep > 0).  As cbn_apply_fin_kernel does for the forward pass.
+template <int U, int CH, bool HAS2>
+__global__ __launch_bounds__(256, 2) void cbn_bwd_apply_fin_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
+                                                               const bf16_raw* __restrict__ y, const float* __restrict__ coef,
+                                                               const float* __restrict__ rep /* [nrep][6 Cr + 1] */, int nrep,
+                                                               float* __restrict__ rep_next /* the other set of rows: cleared here */,
+                                                               const float* __restrict__ Wrr, const float* __restrict__ Wri,
+                                                               const float* __restrict__ Wii, float* __restrict__ gWrr,
+                                                               float* __restrict__ gWri, float* __restrict__ gWii, float* __restrict__ gBr,
+                                                               float* __restrict__ gBi, float* __restrict__ gslope,
+                                                               const float* __restrict__ slope, long rows, int Cr, int F, int Tst,
+                                                               int tfirst, bf16_raw* __restrict__ dy) {
+    __shared__ float4 cl[5 * 256];
+    const int nq = Cr / CH;
+    const int C = 2 * Cr;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    const float a = slope[0];
+    // per-channel coefficients of this thread's CH complex channels, in registers for the whole pass
+    // (the rows the NEXT backward pass of this layer will add to: nobody reads them now, so no memset on the chain)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nrep * (6 * Cr + 1); i += gridDim.x * 256) rep_next[i] = 0.f;
+    stage_coef<CH>(coef, Cr, 2, cl);
+    // cbn_bwd_finalize_kernel's work, by every workgroup for itself: thread c adds the nrep rows of channel c's six sums (L2 hits) and
+    // derives the channel's record straight into the slots the streaming loop reads; workgroup 0 stores the parameter gradients
+    for (int c = threadIdx.x; c < Cr; c += 256) {
+        const float* k = coef + (size_t)c * COEF_STRIDE;
+        const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
+        const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
+        double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int r0 = 0; r0 < nrep; r0 += 8) {                   // 48 independent loads per trip
+            float v[8][6];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) v[r][kk] = rep[(size_t)(r0 + r < nrep ? r0 + r : 0) * (6 * Cr + 1) + kk * Cr + c];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) a6[kk] += r0 + r < nrep ? (double)v[r][kk] : 0.0;
+        }
+        float g5[5], rec[9];
+        cbn_bwd_record((float)a6[0], (float)a6[1], (float)a6[2], (float)a6[3], (float)a6[4], (float)a6[5], urr, uri, uii, vrr, vri, vii,
+                       wrr, wri, wii, (float)rows, g5, rec);
+        const int slot = (c % CH) * nq + (c / CH);
+        cl[2 * Cr + slot] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        cl[3 * Cr + slot] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        cl[4 * Cr + slot] = make_float4(rec[8], 0.f, 0.f, 0.f);
+        if (blockIdx.x == 0) { gWrr[c] = g5[0]; gWri[c] = g5[1]; gWii[c] = g5[2]; gBr[c] = g5[3]; gBi[c] = g5[4]; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 255) {                 // the PReLU slope gradient
+        double ds = 0.0;
+        for (int r = 0; r < nrep; ++r) ds += (double)rep[(size_t)r * (6 * Cr + 1) + 6 * Cr];
+        gslope[0] = (float)ds;
+    }
     __syncthreads();
     float4 zc[CH], mb[CH], A[CH], E[CH];
     float ki[CH];
@@ -604,9 +719,12 @@ static int unroll_rows() {
     return u == 1 || u == 4 ? u : 2;
 }
 // streaming passes: rows-per-thread target -> grid (the coefficient preamble is paid per workgroup)
+// Cap: 768 since the forward apply pass also finalizes the sums (every workgroup pays ~1 us for the records of all channels): B = 32
+// step, ms, two runs each: 2048: 4.157 / 4.184, 1536: 4.167 / 4.178, 1024: 4.146 / 4.158, 768: 4.138 / 4.149, 512: 4.142 / 4.164,
+// 384: 4.175 / 4.178 (2048 was the optimum of the three-launch version)
 static int apply_blocks(long rows, int Cr) {
     static const int rpt = env_int("SEHIP_CBN_APPLY_ROWS", 8);
-    static const int cap = env_int("SEHIP_CBN_APPLY_BLOCKS", 2048);
+    static const int cap = env_int("SEHIP_CBN_APPLY_BLOCKS", 768);
     const int rpb = 256 / (Cr / cbn_ch(Cr));
     long g = (rows + (long)rpb * rpt - 1) / ((long)rpb * rpt);
     if (g > cap) g = cap;
@@ -706,12 +824,12 @@ extern "C" int sehip_cbn_finalize_apply_n(const void* y, const float* part, int 
     return 0;
 }
 
-extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
-                                    long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream) {
+static int cbn_bwd_reduce_launch(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
+                                 long rows, int Cr, int F, int Tst, int tfirst, float* part, int nrep, void* stream) {
     if (int e = check_cbn("cbn_bwd_reduce", rows, Cr)) return e;
     SEHIP_REQUIRE(rows < (1L << 31), "cbn_bwd_reduce: %ld rows exceed the 32-bit frame arithmetic", rows);
 #define CBN_RED(U, CH, H2) cbn_bwd_reduce_kernel<U, CH, H2><<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>( \
-        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part)
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part, nrep)
 #define CBN_RED2(U, CH) do { if (dz2) CBN_RED(U, CH, true); else CBN_RED(U, CH, false); } while (0)
     switch (unroll_rows() * 16 + cbn_ch(Cr)) {
         case 1 * 16 + 8: CBN_RED2(1, 8); break;
@@ -725,6 +843,10 @@ extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void*
 #undef CBN_RED
     SEHIP_CHECK_LAUNCH("cbn_bwd_reduce");
     return 0;
+}
+extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
+                                    long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream) {
+    return cbn_bwd_reduce_launch(dz, dz2, y, coef, slope, rows, Cr, F, Tst, tfirst, part, 0, stream);
 }
 
 extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri,
@@ -755,5 +877,34 @@ extern "C" int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* 
 #undef CBN_BAPP2
 #undef CBN_BAPP
     SEHIP_CHECK_LAUNCH("cbn_bwd_apply");
+    return 0;
+}
+
+// backward pass of the layer in two launches instead of three: the reduce pass adds its block sums to `rep` ([nrep][6 Cr + 1] fp32,
+// zero on entry, nrep <= 64), the apply pass finalizes them itself (cbn_bwd_apply_fin_kernel) and clears `rep_next`, the rows the
+// caller hands in as `rep` next time (two sets used alternately: no memset on the dependent chain; both zero before the first call)
+extern "C" int sehip_cbn_bwd_fused(const void* dz, const void* dz2, const void* y, const float* coef, const float* Wrr, const float* Wri,
+                                   const float* Wii, const float* slope, long rows, int Cr, int F, int Tst, int tfirst, float* rep,
+                                   float* rep_next, int nrep, float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope, void* dy, void* stream) {
+    if (int e = check_cbn("cbn_bwd_fused", rows, Cr)) return e;
+    SEHIP_REQUIRE(rows < (1L << 31), "cbn_bwd_fused: %ld rows exceed the 32-bit frame arithmetic", rows);
+    SEHIP_REQUIRE(nrep >= 1 && nrep <= 64 && rep != nullptr && rep_next != nullptr && rep_next != rep,
+                  "cbn_bwd_fused: %d rows of sums (1..64), two distinct sets", nrep);
+    if (int e = cbn_bwd_reduce_launch(dz, dz2, y, coef, slope, rows, Cr, F, Tst, tfirst, rep, nrep, stream)) return e;
+#define CBN_BFIN(U, CH, H2) cbn_bwd_apply_fin_kernel<U, CH, H2><<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(              \
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, rep, nrep, rep_next, Wrr, Wri, Wii, gWrr, gWri, gWii, gBr, gBi, gslope, \
+        slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy)
+#define CBN_BFIN2(U, CH) do { if (dz2) CBN_BFIN(U, CH, true); else CBN_BFIN(U, CH, false); } while (0)
+    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+        case 1 * 16 + 8: CBN_BFIN2(1, 8); break;
+        case 2 * 16 + 8: CBN_BFIN2(2, 8); break;
+        case 4 * 16 + 8: CBN_BFIN2(4, 8); break;
+        case 1 * 16 + 4: CBN_BFIN2(1, 4); break;
+        case 4 * 16 + 4: CBN_BFIN2(4, 4); break;
+        default: CBN_BFIN2(2, 4); break;
+    }
+#undef CBN_BFIN2
+#undef CBN_BFIN
+    SEHIP_CHECK_LAUNCH("cbn_bwd_fused");
     return 0;
 }

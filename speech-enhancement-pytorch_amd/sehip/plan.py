@@ -52,7 +52,8 @@ class CGemmDesc(C.Structure):
 FUSE_SKIP_GRAD = not os.environ.get("SEHIP_NO_FUSE_SKIP")
 # Products that conv_gemm_v3 takes get their packed weights in its tile order (the switches that take the kernel away keep [Npad][K])
 # the apply pass of a layer with fused sums also finalizes them (sehip_cbn_finalize_apply_n)
-FUSE_FINALIZE = not os.environ.get("SEHIP_NO_FUSE_FINALIZE")
+# (read when a workspace is built: DCCRNWorkspace.fuse_finalize / fuse_bwd_finalize / BWD_REPLICAS rows of backward sums)
+BWD_REPLICAS = int(os.environ.get("SEHIP_BWD_REPLICAS", "8"))
 TILE_WEIGHTS = not any(os.environ.get(k) for k in ("SEHIP_NO_CONV_V3", "SEHIP_NO_PATCH", "SEHIP_NO_TILE_WEIGHTS"))
 
 
@@ -778,10 +779,17 @@ class DCCRNWorkspace:
                 offs[pre] = tot
                 tot += 8 * 5 * cr
         self.bn_stats_all = torch.zeros(max(tot, 1), dtype=torch.float32, device=device)
+        # two sets of [BWD_REPLICAS][6 Cr + 1] sums of the backward reduce pass per layer (sehip_cbn_bwd_fused: a call adds to one set
+        # and clears the other for the next call)
+        self.fuse_finalize = not os.environ.get("SEHIP_NO_FUSE_FINALIZE")
+        # (the same for the backward pass -- sehip_cbn_bwd_fused -- measured no gain: B = 32 step 4.129 ms with 8 rows of sums, 4.159
+        #  with 16, against 4.131 without it; opt-in)
+        self.fuse_bwd_finalize = bool(os.environ.get("SEHIP_FUSE_BWD_FINALIZE")) and self.fuse_finalize
+        self.bn_brep = {pre: torch.zeros(2, BWD_REPLICAS * (6 * cr + 1), dtype=torch.float32, device=device) for pre, cr in st.bn}
+        self._brep_turn = {pre: 0 for pre, _ in st.bn}
         self.bn_stats = {pre: self.bn_stats_all[o:o + 8 * 5 * cr] for (pre, cr) in st.bn if pre in offs for o in [offs[pre]]}
         self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
-        import os
         # the weight-gradient stream.  SEHIP_SIDE_PRIORITY=1: created through the C ABI with the device's lowest priority
         self.side, self._side_handle = None, None
         if not os.environ.get("SEHIP_NO_SIDE_STREAM"):
@@ -1042,7 +1050,7 @@ class DCCRNWorkspace:
         pp, bp, nb = self._bn_ptrs(pre, params, buffers, nbt)
         coef = self.bn_coef[pre]
         if pre in self.st.fused_stats or pre in self.fused_small:     # the producing convolution accumulated the sums (8 replicas)
-            if FUSE_FINALIZE:               # ... and the apply pass derives the coefficients itself: one launch
+            if self.fuse_finalize:          # ... and the apply pass derives the coefficients itself: one launch
                 call("sehip_cbn_finalize_apply_n", y.ptr, ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"),
                      pp("1.Bi"), bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
                      1 if training else 0, ptr(coef), pp("2.weight"), z.ptr, stream())
@@ -1067,6 +1075,20 @@ class DCCRNWorkspace:
         coef = self.bn_coef[pre]
         dz2p = dz2.ptr if dz2 is not None else None
         self._chain_dirty = True
+        if self.fuse_bwd_finalize:  # the reduce pass leaves its sums in a few rows, the apply pass finalizes them: two launches
+            rep = self.bn_brep[pre]
+            if torch.cuda.is_current_stream_capturing():
+                # a captured step replays the same pointers every time: the alternation cannot be captured, so the graph clears
+                # its set with a memset node of its own (and leaves the eager turn where it is)
+                turn = 0
+                rep[0].zero_()
+            else:
+                turn = self._brep_turn[pre]
+                self._brep_turn[pre] = turn ^ 1
+            call("sehip_cbn_bwd_fused", dz.ptr, dz2p, y.ptr, ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("2.weight"), rows, cr,
+                 y.F, y.Tst, tfirst, ptr(rep[turn]), ptr(rep[turn ^ 1]), BWD_REPLICAS, g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"),
+                 g("slope"), dy.ptr, stream())
+            return
         call("sehip_cbn_bwd_reduce", dz.ptr, dz2p, y.ptr, ptr(coef), pp("2.weight"), rows, cr, y.F, y.Tst, tfirst,
              ptr(self.bn_acc), stream())
         call("sehip_cbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,

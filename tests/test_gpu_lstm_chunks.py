@@ -13,8 +13,8 @@ def run_once(chunk, B, N):
     old = os.environ.get("SEHIP_LSTM_CHUNK")
     os.environ["SEHIP_LSTM_CHUNK"] = str(chunk)
     # bit equality needs a bit-reproducible network around the LSTM: the BatchNorm sums that the convolution epilogues take with
-    # fp32 atomics (64-output layers here) vary in the last bit from run to run, the separate passes do not
-    fused = {k: os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS",)}
+    # fp32 atomics (and the backward sums that meet in a few rows the same way) vary in the last bit from run to run, the separate passes do not
+    fused = {k: os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_FINALIZE")}
     os.environ.update({k: "1" for k in fused})
     try:
         dev = torch.device("cuda:0")

@@ -210,7 +210,7 @@ def test_workspace_generation_and_lru():
     assert len(model._ws) <= model._ws_cap
 
 
-def test_two_ranks_equal_one_rank_with_per_replica_batchnorm(tmp_path):
+def test_two_ranks_equal_one_rank_with_per_replica_batchnorm(tmp_path, monkeypatch):
     """Data parallel = DataParallel's semantics (src/solver.py:144-145): two ranks with 2 clips each give the parameters of ONE
     process that runs the two halves separately (per-replica BatchNorm statistics), averages the gradients, clips and steps.
     Exercises the overlapped two-range all-reduce (decoder / LSTM range first) and the 1/world folded into the optimizer.
@@ -218,6 +218,9 @@ def test_two_ranks_equal_one_rank_with_per_replica_batchnorm(tmp_path):
     import os, socket, subprocess, sys
     from sehip import distrib
     from sehip.solver import Solver, ScalarLog
+    # the comparison is between processes: BatchNorm sums from the separate passes (the convolution epilogues' fp32 atomics differ
+    # in the last bit from run to run, and the network amplifies that beyond the bound below) -- here and in the workers
+    monkeypatch.setenv("SEHIP_NO_FUSE_STATS", "1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp.pt")
