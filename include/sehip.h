@@ -265,6 +265,9 @@ int sehip_wgrad_group(const void* dev_buf, int n, int total_blocks, void* stream
  *      unpack_grad: grads[j] = sum of up to 4 signed entries of the packed-gradient buffer. */
 int sehip_pack_bf16(const float* params, const int* table, long n, void* out_bf16, void* stream);
 int sehip_pack_f32(const float* params, const int* table2 /*[n][2]*/, long n, float* out, void* stream);
+/* sehip_pack_bf16 + sehip_pack_f32 + clearing `nz` floats at `zero` (NULL / 0: nothing) in one launch: the head of a train step */
+int sehip_pack_head(const float* params, const int* wtable, long nw, void* wout_bf16, const int* btable2, long nb, float* bout,
+                    float* zero, long nz, void* stream);
 int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n, float* grads, void* stream);
 /* compact forms for large models (Demucs: 133.7 M parameters):
  *   unpack_grad1    : one entry per parameter (table1 [n]); unpack_grad_list: grads[list[i]] = sum of table4[i] for the few

@@ -76,6 +76,7 @@ _PROTOS = {
     "sehip_conv_small_takes": [P, P],
     "sehip_pack_bf16": [P, P, L, P, P],
     "sehip_pack_f32": [P, P, L, P, P],
+    "sehip_pack_head": [P, P, L, P, P, L, P, P, L, P],
     "sehip_unpack_grad": [P, P, L, P, P],
     "sehip_unpack_grad1": [P, P, L, P, P],
     "sehip_unpack_grad_list": [P, P, P, L, P, P],

@@ -13,9 +13,10 @@
 #define EPS 1e-8f
 
 // rowstat[r] = {a, b, l_row, unused}; d loss / d x_j = upstream * (a*x_j + b*s_j)
-__global__ __launch_bounds__(256) void sisnr_fwd_kernel(const float* __restrict__ est, const float* __restrict__ ref,
+// (1024 threads: a row is two dependent passes of one workgroup, 32 rows per step -- latency, not bandwidth: 23.6 us with 256 threads)
+__global__ __launch_bounds__(1024) void sisnr_fwd_kernel(const float* __restrict__ est, const float* __restrict__ ref,
                                                         int n, int rows, float4* __restrict__ rowstat) {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int r = blockIdx.x;
     const float* x = est + (size_t)r * n;
     const float* s = ref + (size_t)r * n;
@@ -25,20 +26,20 @@ __global__ __launch_bounds__(256) void sisnr_fwd_kernel(const float* __restrict_
     const float4* s4 = reinterpret_cast<const float4*>(s);
     const bool vec = ((n & 3) == 0) && ((((uintptr_t)x | (uintptr_t)s) & 15) == 0);
     if (vec) {
-        for (int i = threadIdx.x; i < n4; i += 256) {
+        for (int i = threadIdx.x; i < n4; i += 1024) {
             float4 a = x4[i], b = s4[i];
             xs += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
             ss += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
         }
     } else {
-        for (int i = threadIdx.x; i < n; i += 256) { xs += x[i] * s[i]; ss += s[i] * s[i]; }
+        for (int i = threadIdx.x; i < n; i += 1024) { xs += x[i] * s[i]; ss += s[i] * s[i]; }
     }
-    xs = block_sum<4>(xs, red);
-    ss = block_sum<4>(ss, red);
+    xs = block_sum<16>(xs, red);
+    ss = block_sum<16>(ss, red);
     const float alpha = xs / (ss + EPS);
     float et = 0.f, en = 0.f, es = 0.f;
     if (vec) {
-        for (int i = threadIdx.x; i < n4; i += 256) {
+        for (int i = threadIdx.x; i < n4; i += 1024) {
             float4 a = x4[i], b = s4[i];
             float t0 = alpha * b.x, t1 = alpha * b.y, t2 = alpha * b.z, t3 = alpha * b.w;
             float e0 = a.x - t0, e1 = a.y - t1, e2 = a.z - t2, e3 = a.w - t3;
@@ -47,14 +48,14 @@ __global__ __launch_bounds__(256) void sisnr_fwd_kernel(const float* __restrict_
             es += e0 * b.x + e1 * b.y + e2 * b.z + e3 * b.w;
         }
     } else {
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += 1024) {
             float t = alpha * s[i], e = x[i] - t;
             et += t * t; en += e * e; es += e * s[i];
         }
     }
-    et = block_sum<4>(et, red);
-    en = block_sum<4>(en, red);
-    es = block_sum<4>(es, red);
+    et = block_sum<16>(et, red);
+    en = block_sum<16>(en, red);
+    es = block_sum<16>(es, red);
     if (threadIdx.x == 0) {
         const float ratio = et / (en + EPS);
         const float l = 10.f * log10f(ratio + EPS);
@@ -133,7 +134,7 @@ extern "C" int sehip_sisnr_fwd(const float* est, const float* ref, int rows, int
                                void* stream) {
     SEHIP_REQUIRE(rows > 0 && n > 0, "sisnr_fwd: empty input (rows=%d n=%d)", rows, n);
     hipStream_t st = (hipStream_t)stream;
-    sisnr_fwd_kernel<<<rows, 256, 0, st>>>(est, ref, n, rows, (float4*)rowstat);
+    sisnr_fwd_kernel<<<rows, 1024, 0, st>>>(est, ref, n, rows, (float4*)rowstat);
     sisnr_finalize_kernel<<<1, 64, 0, st>>>((const float4*)rowstat, rows, loss);
     SEHIP_CHECK_LAUNCH("sisnr_fwd");
     return 0;

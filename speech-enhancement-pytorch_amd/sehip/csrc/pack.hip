@@ -43,6 +43,31 @@ __global__ __launch_bounds__(256) void pack_f32_kernel(const float* __restrict__
     }
 }
 
+// the head of a step in one launch: both packings and the clearing of an accumulator region (three kernel boundaries -> one)
+__global__ __launch_bounds__(256) void pack_head_kernel(const float* __restrict__ params, const int* __restrict__ wtab, long nw,
+                                                        bf16_raw* __restrict__ wout, const int2* __restrict__ btab, long nb,
+                                                        float* __restrict__ bout, float* __restrict__ zero, long nz) {
+    const long nw8 = nw >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nw8; i += (long)gridDim.x * 256) {
+        const int4 e0 = *reinterpret_cast<const int4*>(wtab + 8 * i), e1 = *reinterpret_cast<const int4*>(wtab + 8 * i + 4);
+        const int e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = params[e[j] < 0 ? 0 : e[j] >> 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = e[j] < 0 ? 0.f : ((e[j] & 1) ? -v[j] : v[j]);
+        *reinterpret_cast<uint4*>(wout + 8 * i) =
+            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    }
+    if (blockIdx.x == 0)
+        for (long i = (nw8 << 3) + threadIdx.x; i < nw; i += 256) wout[i] = f2bf(term(params, wtab[i]));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) {
+        const int2 e = btab[i];
+        bout[i] = term(params, e.x) + term(params, e.y);
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nz; i += (long)gridDim.x * 256) zero[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restrict__ packed, const int4* __restrict__ tab, long n,
                                                           float* __restrict__ grads) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -111,6 +136,18 @@ extern "C" int sehip_pack_bf16(const float* params, const int* table, long n, vo
     SEHIP_REQUIRE(((((uintptr_t)table) | ((uintptr_t)out_bf16)) & 15) == 0, "pack_bf16: table / output must be 16-byte aligned");
     pack_bf16_kernel<<<grid_of(n >> 3), 256, 0, (hipStream_t)stream>>>(params, table, n, (bf16_raw*)out_bf16);
     SEHIP_CHECK_LAUNCH("pack_bf16");
+    return 0;
+}
+
+// sehip_pack_bf16 + sehip_pack_f32 + clearing nz floats at `zero` (may be NULL / 0) in ONE launch
+extern "C" int sehip_pack_head(const float* params, const int* wtable, long nw, void* wout_bf16, const int* btable2, long nb, float* bout,
+                               float* zero, long nz, void* stream) {
+    SEHIP_REQUIRE(nw >= 0 && nb >= 0 && nz >= 0, "pack_head: negative size");
+    SEHIP_REQUIRE(((((uintptr_t)wtable) | ((uintptr_t)wout_bf16)) & 15) == 0, "pack_head: table / output must be 16-byte aligned");
+    if (nw + nb + nz == 0) return 0;
+    pack_head_kernel<<<grid_of((nw >> 3) + 1), 256, 0, (hipStream_t)stream>>>(params, wtable, nw, (bf16_raw*)wout_bf16, (const int2*)btable2,
+                                                                            nb, bout, zero, nz);
+    SEHIP_CHECK_LAUNCH("pack_head");
     return 0;
 }
 

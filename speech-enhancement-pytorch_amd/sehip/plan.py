@@ -1160,9 +1160,10 @@ class DCCRNWorkspace:
         """wav_in [B,N] fp32 on device -> self.wav [B,length]."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, T, h = self.B, self.T, cfg.hid
-        self.pack_weights(params)
-        if self.st.fused_stats or self.fused_small:
-            self.bn_stats_all.zero_()
+        # both packings and the clearing of the fused BatchNorm sums: one launch
+        zero = self.bn_stats_all if (self.st.fused_stats or self.fused_small) else None
+        call("sehip_pack_head", ptr(params), ptr(tb.wtab), st.n_wpack, ptr(tb.wpack), ptr(tb.btab), st.n_bpack, ptr(tb.bpack),
+             ptr(zero) if zero is not None else None, zero.numel() if zero is not None else 0, stream())
         call("sehip_stft_fwd", ptr(wav_in), ptr(tb.window), B, self.N, cfg.win_len, cfg.win_inc, cfg.fft_len,
              ptr(self.spec), b["enc_in"].ptr, stream())
         for i in range(6):
