@@ -722,9 +722,10 @@ static int unroll_rows() {
 // Cap: 768 since the forward apply pass also finalizes the sums (every workgroup pays ~1 us for the records of all channels): B = 32
 // step, ms, two runs each: 2048: 4.157 / 4.184, 1536: 4.167 / 4.178, 1024: 4.146 / 4.158, 768: 4.138 / 4.149, 512: 4.142 / 4.164,
 // 384: 4.175 / 4.178 (2048 was the optimum of the three-launch version)
-static int apply_blocks(long rows, int Cr) {
+static int apply_blocks(long rows, int Cr, bool bwd = false) {
     static const int rpt = env_int("SEHIP_CBN_APPLY_ROWS", 8);
-    static const int cap = env_int("SEHIP_CBN_APPLY_BLOCKS", 768);
+    static const int capf = env_int("SEHIP_CBN_APPLY_BLOCKS", 768), capb = env_int("SEHIP_CBN_BAPPLY_BLOCKS", 768);
+    const int cap = bwd ? capb : capf;
     const int rpb = 256 / (Cr / cbn_ch(Cr));
     long g = (rows + (long)rpb * rpt - 1) / ((long)rpb * rpt);
     if (g > cap) g = cap;
@@ -863,7 +864,7 @@ extern "C" int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* 
                                    const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream) {
     if (int e = check_cbn("cbn_bwd_apply", rows, Cr)) return e;
     SEHIP_REQUIRE(rows < (1L << 31), "cbn_bwd_apply: %ld rows exceed the 32-bit frame arithmetic", rows);
-#define CBN_BAPP(U, CH, H2) cbn_bwd_apply_kernel<U, CH, H2><<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>( \
+#define CBN_BAPP(U, CH, H2) cbn_bwd_apply_kernel<U, CH, H2><<<apply_blocks(rows, Cr, true), 256, 0, (hipStream_t)stream>>>( \
         (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, bcoef, slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy)
 #define CBN_BAPP2(U, CH) do { if (dz2) CBN_BAPP(U, CH, true); else CBN_BAPP(U, CH, false); } while (0)
     switch (unroll_rows() * 16 + cbn_ch(Cr)) {
