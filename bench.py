@@ -445,6 +445,8 @@ def main():
                     "every kernel from Python (measured slower: graph replay serialises the side-stream weight gradients)")
     ap.add_argument("--h2d", action="store_true", help="stage every batch from pinned host memory inside the timed region "
                     "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
+    ap.add_argument("--h2d-overlap", action="store_true", help="as --h2d, but the NEXT batch is copied on a stream of its own while the "
+                    "step runs (two device buffers): what sehip.solver.DevicePrefetcher does for the Solver's epoch loop")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle parity block (it needs the CPU baseline leg)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="host threads of the CPU baseline (0 = min(cores of the affinity mask, 32): on the 256-core host of the GPU "
@@ -519,23 +521,44 @@ def main():
     main_stream = torch.cuda.Stream(device=dev, priority=hi) if os.environ.get("SEHIP_BENCH_PRIO", "1") == "1" else torch.cuda.current_stream()
     main_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_stream)
-    if args.h2d:
+    if args.h2d or args.h2d_overlap:
         h_mix, h_src = mixture.cpu().pin_memory(), sources.cpu().pin_memory()
+    if args.h2d_overlap:
+        bufs = [(mixture, sources), (mixture.clone(), sources.clone())]
+        cstream = torch.cuda.Stream(device=dev)
+        done = [None, None]                 # event after the last step that read buffer i
+        state = {"k": 0}
 
-    def stage():
+        def copy_into(i):
+            with torch.cuda.stream(cstream):
+                if done[i] is not None:
+                    cstream.wait_event(done[i])
+                bufs[i][0].copy_(h_mix, non_blocking=True)
+                bufs[i][1].copy_(h_src, non_blocking=True)
+        copy_into(0)
+
+    def one_step():
+        if args.h2d_overlap:
+            i = state["k"] & 1
+            state["k"] += 1
+            torch.cuda.current_stream().wait_stream(cstream)      # batch k has landed
+            copy_into(i ^ 1)                                      # batch k + 1 travels while step k computes
+            out = step_fn(*bufs[i])
+            done[i] = torch.cuda.Event()
+            done[i].record()
+            return out
         if args.h2d:
             mixture.copy_(h_mix, non_blocking=True)
             sources.copy_(h_src, non_blocking=True)
+        return step_fn(mixture, sources)
 
     for _ in range(args.warmup):
-        stage()
-        step_fn(mixture, sources)
+        one_step()
     sync()
     note(f"timing {args.steps} steps ({'eager launches' if args.eager else 'hipGraph replay'})")
     t0 = time.time()
     for _ in range(args.steps):
-        stage()
-        loss, metric = step_fn(mixture, sources)
+        loss, metric = one_step()
     t_enq = time.time() - t0            # host time to enqueue the steps; close to dt = the launches, not the GPU, set the pace
     sync()
     dt = time.time() - t0
@@ -564,7 +587,8 @@ def main():
                                 "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
                                 "clips, SI-SNR, Adam 3e-4, clip 5"), "per_gpu_batch": args.batch,
                    "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
-                   "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step" if args.h2d else "resident in HBM"},
+                   "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step, overlapped with the previous step" if args.h2d_overlap else
+                   "pinned host -> HBM every step" if args.h2d else "resident in HBM"},
         "final_loss": float(loss),
     }
     if rank == 0 and not args.no_roofline:

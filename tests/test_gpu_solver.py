@@ -188,6 +188,29 @@ def test_deferred_logging_under_graph_replay(tmp_path):
     assert abs(mean_e - mean_g) < 0.05
 
 
+def test_device_prefetcher_yields_the_loader_in_order_and_stops_at_the_step_cap():
+    """sehip.solver.DevicePrefetcher (the epoch loop's one-batch-ahead host -> HBM staging): same batches, same order, tensors on the
+    device, non-tensors untouched, and with a step cap it never pulls a batch the epoch will not use."""
+    from sehip.solver import DevicePrefetcher
+    dev = torch.device("cuda:0")
+    pulled = []
+
+    def loader():
+        for s in range(6):
+            pulled.append(s)
+            noisy, clean = make_batch(500 + s, 2, 4000)
+            yield (noisy.pin_memory(), clean, [None], ["name"], s)
+
+    ref = [make_batch(500 + s, 2, 4000) for s in range(6)]
+    got = list(DevicePrefetcher(loader(), dev, limit=4))
+    assert len(got) == 4 and pulled == [0, 1, 2, 3]
+    for s, batch in enumerate(got):
+        assert batch[0].is_cuda and batch[1].is_cuda and batch[2] == [None] and batch[3] == ["name"] and batch[4] == s
+        assert torch.equal(batch[0].cpu(), ref[s][0]) and torch.equal(batch[1].cpu(), ref[s][1])
+    pulled.clear()
+    assert len(list(DevicePrefetcher(loader(), dev))) == 6 and pulled == list(range(6))
+
+
 def test_workspace_generation_and_lru():
     from sehip.model import DCCRN
     from sehip import SehipError
