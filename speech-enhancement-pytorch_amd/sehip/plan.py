@@ -851,7 +851,10 @@ class DCCRNWorkspace:
     def _bind(self):
         st, tb, B, T = self.st, self.tb, self.B, self.T
         self.desc = {}
-        self._wgrad_on_chain = set((os.environ.get("SEHIP_WGRAD_ON_CHAIN", "") or "").split(",")) - {""}
+        # the LAST weight gradient of the pass (enc0: narrow_wgrad_mfma, 28 us) runs on the chain's own stream: nothing is left to
+        # overlap it with, and two event hops less sit in front of the un-pack (4.125-4.131 against 4.132-4.137 ms; enc1 too: 4.16).
+        # SEHIP_WGRAD_ON_CHAIN=<names> / none
+        self._wgrad_on_chain = set((os.environ.get("SEHIP_WGRAD_ON_CHAIN", "enc0.fwd") or "").split(",")) - {"", "none"}
         self._chunk_cache = {}
         self._wg_groups = {}
         # chunk table bound to this workspace's source geometry: [src, (toff<<16)|(fadd&0xffff), element delta, npieces]
@@ -994,9 +997,9 @@ class DCCRNWorkspace:
         gradients are un-packed."""
         main = torch.cuda.current_stream()
         if self.side is None or name in self._wgrad_on_chain:
-            # (SEHIP_WGRAD_ON_CHAIN=enc0.fwd,...: named weight gradients on the chain's own stream.  Measured in round 3 for the last
-            #  one / two / three of the backward pass, whose side-stream backlog the chain waits 88 us for: 4.23-4.29 ms per step
-            #  against 4.23-4.25 without -- no gain, off by default)
+            # (SEHIP_WGRAD_ON_CHAIN=enc0.fwd,...: named weight gradients on the chain's own stream.  With the 68-us VALU kernel for
+            #  enc0 this was no gain (4.23-4.29 against 4.23-4.25 ms for the last one / two / three of the pass); with
+            #  narrow_wgrad_mfma the last one is worth 6 us and is the default)
             call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), main.cuda_stream)
             return
         if self._chain_dirty:
