@@ -2,7 +2,9 @@
 """Headline benchmark: audio-seconds/second of DCCRN training (16 kHz, 2-s clips, batch 32 per GPU) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -- or
+     plain: without WORLD_SIZE in the environment bench.py starts the N ranks itself as child processes and relays rank 0's line;
+     fewer than N visible devices is a named error, "needs N devices")
 
 A step = Solver.train_step on one pre-staged synthetic batch: forward (STFT -> encoder -> complex LSTM -> decoder ->
 mask -> iSTFT), SI-SNR loss, full backward, gradient all-reduce (N>1), global-norm clip and Adam -- nothing skipped.
@@ -424,6 +426,38 @@ def build_for_profile(batch=BATCH):
     return solver, model, mixture, sources
 
 
+class NeedsDevices(RuntimeError):
+    """`--gpus N` asked for more devices than this node shows."""
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves (one process per GPU, the data-parallel
+    replacement of the reference's single-process nn.DataParallel, src/solver.py:144-145) as CHILD processes of
+    `python -m torch.distributed.run`, relay rank 0's JSON line and return the launcher's exit code.  This parent never touches the
+    GPU (torch.cuda.device_count() does not initialise it on this image), and nothing is exec'ed from a process that did."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "SEHIP_LOCAL_DEVICE" not in os.environ:     # (test hook: several ranks on one device over gloo)
+        raise NeedsDevices(f"bench.py --gpus {n}: needs {n} devices, this node shows {have}")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or not lines:
+        print(f"bench.py --gpus {n}: the ranks failed (launcher exit code {r.returncode})", file=sys.stderr)
+        return r.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def note(msg):
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -466,10 +500,14 @@ def main():
             cpu_worker_generic(args.workload, args.cpu_baseline_worker[0], args.cpu_baseline_worker[1], threads)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # plain `python bench.py --gpus N`: this process only starts the ranks
+
     from sehip import distrib
     from sehip.solver import Solver, ScalarLog
     rank, world, local = distrib.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     n = 32768 if dcu else int(SR * CLIP_S)        # C2: 257 frames (= 1 mod 32, the depth-10 constraint) at hop 128
     clip_s = n / SR
     cfg = dcunet_config() if dcu else bench_config(n)

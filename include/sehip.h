@@ -136,10 +136,13 @@ int sehip_grad_metric_acc(const float* grads, const long* offsets, int ntensors,
  *      comm_unique_id: rank 0 fills 128 bytes (ncclGetUniqueId) and shares them with the other ranks by any means
  *      comm_init:      ncclCommInitRank on the CURRENT HIP device -> opaque communicator
  *      allreduce_f32:  in-place SUM of buf[0 .. n) over the ranks, enqueued on `stream` (the step exchanges ranges of the flat fp32
- *                      gradient buffer as the backward pass finishes them; 1/world is folded into sehip_opt_step's grad_scale) */
+ *                      gradient buffer as the backward pass finishes them; 1/world is folded into sehip_opt_step's grad_scale)
+ *      allreduce_i32_max: in-place MAX of int32 words over the ranks: the step guard of sehip_opt_begin_g / sehip_opt_step_g made global
+ *                      before the optimizer launch, so that a device-side failure on one rank skips the step on all of them */
 int sehip_comm_unique_id(void* id128);
 int sehip_comm_init(const void* id128, int world, int rank, void** comm_out);
 int sehip_allreduce_f32(void* comm, float* buf, long n, void* stream);
+int sehip_allreduce_i32_max(void* comm, int* buf, long n, void* stream);
 int sehip_comm_destroy(void* comm);
 
 /* ---- implicit-GEMM engine (bf16 MFMA, fp32 accumulate) used for

@@ -42,6 +42,7 @@ _PROTOS = {
     "sehip_comm_unique_id": [P],
     "sehip_comm_init": [P, I, I, P],
     "sehip_allreduce_f32": [P, P, L, P],
+    "sehip_allreduce_i32_max": [P, P, L, P],
     "sehip_comm_destroy": [P],
     "sehip_wav_row_stats": [P, P, I, P, P],
     "sehip_wav_collate": [P, P, P, P, P, P, I, F, I, I, P, P],

@@ -82,6 +82,17 @@ extern "C" int sehip_allreduce_f32(void* comm, float* buf, long n, void* stream)
     return 0;
 }
 
+// in-place MAX over the ranks of buf[0 .. n) (int32): the data-parallel step guard (a device-side failure word such as Demucs'
+// hand-off time-out must stop the optimizer step of EVERY replica, or the replicas diverge)
+extern "C" int sehip_allreduce_i32_max(void* comm, int* buf, long n, void* stream) {
+    SEHIP_REQUIRE(comm && buf && n >= 0, "allreduce_i32_max: bad arguments (n=%ld)", n);
+    if (int e = load_rccl("allreduce_i32_max")) return e;
+    if (n == 0) return 0;
+    const int r = g_rccl.all_reduce(buf, buf, (size_t)n, 2 /*ncclInt32*/, 2 /*ncclMax*/, (rccl_comm)comm, (hipStream_t)stream);
+    SEHIP_REQUIRE(r == 0, "allreduce_i32_max: ncclAllReduce(n=%ld): %s", n, err_text(r));
+    return 0;
+}
+
 extern "C" int sehip_comm_destroy(void* comm) {
     if (!comm) return 0;
     if (int e = load_rccl("comm_destroy")) return e;

@@ -121,6 +121,12 @@ class DirectComm:
                 torch.cuda.current_stream().wait_event(ev)
         return _Work()
 
+    def all_reduce_max_i32_(self, words, stream=None):
+        """in-place MAX of an int32 device tensor over the ranks on `stream` (None = current): the global step guard."""
+        from ._lib import call
+        st = stream if stream is not None else torch.cuda.current_stream()
+        call("sehip_allreduce_i32_max", self.handle, words.data_ptr(), words.numel(), st.cuda_stream)
+
     def close(self):
         from ._lib import call
         if self.handle:
@@ -168,6 +174,21 @@ def allreduce_gradients(flat_grads, scale=True):
         if scale:
             flat_grads.mul_(1.0 / dist.get_world_size())
     return flat_grads
+
+
+def allreduce_step_guard(guard):
+    """Makes a model's device-side step guard (model.step_guard(): int32 word(s), non-zero = this step's gradients are invalid, e.g.
+    Demucs' hand-off time-out word) GLOBAL before the optimizer launch: MAX over the ranks, in place, on the current stream.  Without
+    it a time-out on one rank sends that rank's garbage into the SUM all-reduce and only that rank skips its update -- the replicas
+    diverge in parameters, Adam moments and step count.  With it every rank's sehip_opt_*_g sees the same word, every
+    rank skips the same step and model.check_health() takes the same fall-back on all of them."""
+    if guard is None or not (dist.is_initialized() and dist.get_world_size() > 1):
+        return guard
+    if _direct is not None and guard.is_cuda:
+        _direct.all_reduce_max_i32_(guard)
+    else:
+        dist.all_reduce(guard, op=dist.ReduceOp.MAX)
+    return guard
 
 
 def allreduce_range_async(flat_grads, lo, hi, stream=None):

@@ -317,6 +317,10 @@ class Solver(object):
                     distrib.allreduce_gradients(self.model.flat_grads)
                 else:
                     distrib.allreduce_module_gradients(self.model)
+        if self.world_size > 1 and hasattr(self.model, "step_guard"):
+            # a device-side failure word (Demucs: hand-off time-out) must stop the update on EVERY rank: the all-reduced gradients
+            # already contain the failing rank's contribution
+            distrib.allreduce_step_guard(self.model.step_guard())
         if self.config.optim.clip_grad:
             if fused:
                 self.optimizer.clip_grad_norm_(self.config.optim.clip_grad)
@@ -348,6 +352,8 @@ class Solver(object):
         g["fb"].replay()
         if self.world_size > 1:
             distrib.allreduce_gradients(self.model.flat_grads, scale=False)   # 1/world is baked into the captured optimizer launch
+            if hasattr(self.model, "step_guard"):
+                distrib.allreduce_step_guard(self.model.step_guard())
         g["upd"].replay()
         return g["loss"], g["metric"]
 

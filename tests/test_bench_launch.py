@@ -1,0 +1,111 @@
+"""`python bench.py --gpus N` without a launcher: the process starts the N ranks itself as child processes of
+torch.distributed.run and relays rank 0's JSON line; fewer than N visible devices is a named error, not an assert.  Semantics being
+replaced: the reference's single-process nn.DataParallel (src/solver.py:144-145)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=600):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_more_gpus_than_devices_is_a_named_error():
+    """Runs wherever it is started: 0 devices in the build container, 1 on the GPU box -- asking for 64 never fits."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEHIP_LOCAL_DEVICE")}
+    r = _run(["--gpus", "64", "--steps", "1", "--warmup", "0"], env=env, timeout=300)
+    assert r.returncode != 0
+    assert "needs 64 devices" in r.stderr and "AssertionError" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_gpus_on_a_one_gpu_box_is_a_named_error():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two devices: the request is satisfiable")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEHIP_LOCAL_DEVICE")}
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, timeout=300)
+    assert r.returncode != 0 and "needs 2 devices" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_prints_one_line():
+    """The self-launch path end to end: two ranks share cuda:0 over gloo (test hook SEHIP_LOCAL_DEVICE; RCCL refuses two ranks on one
+    device), the parent relays exactly one JSON line with n_gpus 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SEHIP_DIST_BACKEND="gloo", SEHIP_LOCAL_DEVICE="0")
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-roofline", "--no-cpu-baseline"], env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_makes_the_launcher_exit_nonzero():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SEHIP_DIST_BACKEND="gloo", SEHIP_LOCAL_DEVICE="0", SEHIP_LIB="/nonexistent/libsehip.so")   # every rank fails to load the library
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-roofline", "--no-cpu-baseline"], env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join({root!r}, "speech-enhancement-pytorch_amd"))
+import torch
+from sehip import distrib
+from sehip._lib import SehipError
+try:
+    rank, world, local = distrib.init_distributed()
+except SehipError as e:
+    print("CLEAN-FAILURE rank", os.environ["RANK"], str(e)[:200], flush=True)
+    sys.exit(7)
+comm = distrib.direct_comm()
+g = torch.full((1000,), float(rank + 1), device=f"cuda:{{local}}")
+comm.all_reduce_(g).wait()
+torch.cuda.synchronize()
+print("ALLREDUCE-OK rank", rank, float(g[0]), flush=True)
+'''
+
+
+@pytest.mark.gpu
+def test_sehip_rccl_backend_reaches_comm_init_with_world_two(tmp_path):
+    """SEHIP_DIST_BACKEND=sehip-rccl, two processes: the rendezvous (gloo control plane, 128-byte RCCL id broadcast from rank 0) runs and
+    both ranks reach sehip_comm_init(world=2).  With two devices the all-reduce must give 3.0; on ONE device RCCL refuses the duplicate
+    and both ranks must fail CLEANLY (SehipError carrying RCCL's text, exit code 7) instead of hanging or crashing."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = torch.cuda.device_count() >= 2
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SEHIP_DIST_BACKEND="sehip-rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if not two:
+            env["SEHIP_LOCAL_DEVICE"] = "0"
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += "\nTIMEOUT"
+        outs.append((p.returncode, o))
+    if two:
+        for rc, o in outs:
+            assert rc == 0 and "ALLREDUCE-OK" in o and " 3.0" in o, o[-1500:]
+    else:
+        for rc, o in outs:
+            assert "TIMEOUT" not in o, "ncclCommInitRank with a duplicate device hung:\n" + o[-1500:]
+            assert rc == 7 and "CLEAN-FAILURE" in o and "comm_init" in o, o[-1500:]

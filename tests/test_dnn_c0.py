@@ -88,6 +88,32 @@ def test_c0_runs_through_main_on_cpu(tmp_path):
     assert any(k.startswith("model.0.model.0.") for k in tar["model"]) and "ema_in.ema0" in tar["model"]
 
 
+def test_main_has_the_reference_positional_signature(tmp_path):
+    """src/train.py:18-23: main(obj_config, return_solver, mode, save, dev, device); :87-90: mode "validation" runs
+    Solver._run_one_epoch(1, 1, train=False).  A reference-style positional call must bind `device` in the sixth position."""
+    import inspect
+    from sehip import SehipError
+    from sehip.train import main
+    from sehip.solver import ScalarLog
+    names = list(inspect.signature(main).parameters)
+    assert names[:6] == ["obj_config", "return_solver", "mode", "save", "dev", "device"]
+    g = torch.Generator().manual_seed(2)
+    clean = 0.1 * torch.randn(2, 1, 1, 16000, generator=g)
+    noisy = clean[:, 0] + 0.05 * torch.randn(2, 1, 16000, generator=g)
+    batches = [(noisy, clean, [None], [None], ["x"], [0])]
+    log = ScalarLog()
+    solver = main(c0_config(tmp_path), False, "validation", False, False, "cpu", train_dataloader=batches,
+                  validation_dataloader=batches, writer=log)
+    tags = [t for (t, _v, _s) in log.scalars]
+    assert "Validation/Loss_step" in tags and "Validation/Loss" in tags and "Train/Loss_step" not in tags
+    assert np.isfinite(solver.score["loss_valid"]) and solver.score["loss_valid"] > 0
+    with pytest.raises(SehipError):
+        main(c0_config(tmp_path), False, "test", False, False, "cpu", train_dataloader=batches, validation_dataloader=batches,
+             writer=ScalarLog())
+    with pytest.raises(TypeError):
+        main(c0_config(tmp_path), False, "train", False, False, False)      # a non-device in the device position is refused by name
+
+
 def test_hip_models_refuse_the_cpu_solver(tmp_path):
     from sehip import distrib, SehipError
     from sehip.solver import Solver, ScalarLog

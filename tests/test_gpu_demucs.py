@@ -568,6 +568,28 @@ def test_forced_handoff_timeout_skips_the_step_and_falls_back(tmp_path):
     assert rel_err(s.model.flat_params.detach().cpu(), r.model.flat_params.detach().cpu()) < 1e-3      # (first Adam step = lr * sign(g): a few signs of ~0 gradients differ)
 
 
+def test_handoff_timeout_on_one_rank_skips_the_step_on_every_rank(tmp_path):
+    """the step guard is a per-rank device word, but the gradients are all-reduced -- a time-out on ONE rank must
+    turn the optimizer step into a no-op on EVERY rank (Solver: MAX all-reduce of the word before the optimizer launch,
+    distrib.allreduce_step_guard), every rank must take the per-step fall-back at the same health check, and the replicas must
+    still hold identical parameters after the next step.  Two ranks share cuda:0 over gloo; rank 1 alone gets the forced time-out."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SEHIP_DIST_BACKEND="gloo", SEHIP_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dp_guard_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (torch.load(tmp_path / f"guard_r{k}.pt") for k in (0, 1))
+    for o in (a, b):
+        assert o["guard_after_step"] != 0, "the time-out word did not reach this rank"
+        assert o["unchanged"] and o["step_dev"] == 0, "an optimizer step was applied from gradients that contain a timed-out rank's"
+        assert o["per_step_after_health"] and o["lost_steps"] == 1
+        assert o["moved"] and o["step_dev_2"] == 1 and np.isfinite(o["loss"])
+    assert torch.equal(a["params"], b["params"]), "the replicas diverged"
+
+
 def test_gradient_ranges_are_final_while_the_backward_pass_still_runs():
     """the early ranges of the data-parallel exchange are handed over BEFORE the backward pass ends -- on the device
     timeline, not in host order.  The full-width network (133.7 M parameters), one clip: every hand-over records an event on the
