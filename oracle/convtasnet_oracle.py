@@ -15,6 +15,8 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from .dccrn_oracle import Bf16Sim, NoSim   # bf16 round-trips at the HIP path's storage points (tests only)
+
 EPS = 1e-8   # src/model/conv_tasnet.py:207
 
 
@@ -50,36 +52,41 @@ def _prelu(h, a, mask):
     return h * torch.where(mask, torch.ones((), dtype=h.dtype), a.reshape(()))
 
 
-def temporal_block(x, p, pre, dilation, P, masks=None):
+def temporal_block(x, p, pre, dilation, P, masks=None, sim=NoSim):
     """1x1 B->H, PReLU, gLN, depthwise dilated conv (groups=H, 'same' padding), PReLU, gLN, 1x1 H->B, + residual
-    (src/model/conv_tasnet.py:307-402 with skip=False).  masks: (mask1, mask2) for the two PReLUs, see _prelu."""
-    h = F.conv1d(x, p[pre + "net.0.weight"])
+    (src/model/conv_tasnet.py:307-402 with skip=False).  masks: (mask1, mask2) for the two PReLUs, see _prelu.
+    sim=Bf16Sim: bf16 round-trips of the five tensors the HIP path stores per block (1x1 output, PReLU + gLN output, depthwise
+    output, PReLU + gLN output, block output) and of the two 1x1 weights."""
+    h = sim.act(F.conv1d(x, sim.weight(p[pre + "net.0.weight"])))
     h = _prelu(h, p[pre + "net.1.weight"], None if masks is None else masks[0])
-    h = gln(h, p[pre + "net.2.gamma"], p[pre + "net.2.beta"])
+    h = sim.act(gln(h, p[pre + "net.2.gamma"], p[pre + "net.2.beta"]))
     q = pre + "net.3."
     pad = (P - 1) * dilation // 2
-    h = F.conv1d(h, p[q + "net.0.weight"], padding=pad, dilation=dilation, groups=h.shape[1])
+    h = sim.act(F.conv1d(h, p[q + "net.0.weight"], padding=pad, dilation=dilation, groups=h.shape[1]))
     h = _prelu(h, p[q + "net.1.weight"], None if masks is None else masks[1])
-    h = gln(h, p[q + "net.2.gamma"], p[q + "net.2.beta"])
-    return F.conv1d(h, p[q + "pointwise_conv.weight"]) + x
+    h = sim.act(gln(h, p[q + "net.2.gamma"], p[q + "net.2.beta"]))
+    return sim.act(F.conv1d(h, sim.weight(p[q + "pointwise_conv.weight"])) + x)
 
 
-def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2, audio_channels=1, taps=None, act_masks=None):
+def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2, audio_channels=1, taps=None, act_masks=None,
+                       sim=NoSim):
     """mixture [M, ac, T] -> separated sources [M, C, ac, T] (src/model/conv_tasnet.py:136-154).
-    act_masks (tests only): {"block{r}.{i}": (mask1, mask2), "mask": mask} -- given branches of the PReLUs / the mask ReLU."""
+    act_masks (tests only): {"block{r}.{i}": (mask1, mask2), "mask": mask} -- given branches of the PReLUs / the mask ReLU.
+    sim=Bf16Sim (tests only): bf16 storage at the HIP path's layer boundaries (cLN output, bottleneck, the five tensors of every
+    temporal block, the mask scores) and bf16 1x1 weights; the encoder output w and the decoder stay fp32 on both sides."""
     w = F.relu(F.conv1d(mixture, p["encoder.conv1d_U.weight"], stride=L // 2))           # [M, N, K]
     net = "separator.network."
-    x = cln(w, p[net + "0.gamma"], p[net + "0.beta"])
-    x = F.conv1d(x, p[net + "1.weight"])
+    x = sim.act(cln(w, p[net + "0.gamma"], p[net + "0.beta"]))
+    x = sim.act(F.conv1d(x, sim.weight(p[net + "1.weight"])))
     if taps is not None:
         taps["bottleneck"] = x
     for r in range(R):
         for i in range(X):
-            x = temporal_block(x, p, f"{net}2.{r}.{i}.", 2 ** i, P, None if act_masks is None else act_masks[f"block{r}.{i}"])
+            x = temporal_block(x, p, f"{net}2.{r}.{i}.", 2 ** i, P, None if act_masks is None else act_masks[f"block{r}.{i}"], sim)
             if taps is not None:
                 taps[f"block{r}.{i}"] = x
     m, n, k = w.shape
-    score = F.conv1d(x, p[net + "3.weight"]).view(m, C, n, k)
+    score = sim.act(F.conv1d(x, sim.weight(p[net + "3.weight"]))).view(m, C, n, k)
     mask = F.relu(score) if act_masks is None else score * act_masks["mask"].to(score.dtype)
     src_w = (w.unsqueeze(1) * mask).transpose(2, 3)                                        # [M, C, K, N]
     est = F.linear(src_w, p["decoder.basis_signals.weight"])                               # [M, C, K, ac*L]

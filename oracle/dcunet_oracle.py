@@ -19,6 +19,8 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from .dccrn_oracle import Bf16Sim, NoSim   # bf16 round-trips at the HIP path's storage points (tests only)
+
 
 def dcunet_sizes(model_complexity: int, model_depth: int, audio_channels: int = 1, complex_: bool = True):
     """Channel / kernel / stride / padding tables (src/model/dcunet.py:164-321); complex halves the width by sqrt(2) (:64-65)."""
@@ -48,21 +50,35 @@ def dcunet_sizes(model_complexity: int, model_depth: int, audio_channels: int = 
                 dec_s=dec_s, dec_p=dec_p)
 
 
-def complex_conv2d(x, p, pre, stride, padding):
+def complex_conv2d(x, p, pre, stride, padding, sim=NoSim):
     """src/model/dcunet.py:323-338: real = Wre*xr - Wim*xi, imag = Wre*xi + Wim*xr, each conv with its own bias
-    (so the real part carries b_re - b_im and the imaginary part b_re + b_im)."""
+    (so the real part carries b_re - b_im and the imaginary part b_re + b_im).
+    sim=Bf16Sim: bf16 weights, and the bias-free product is what is stored in bf16 (the HIP path keeps its pre-BatchNorm tensors
+    without the bias, which the BatchNorm cancels); the bias terms are added to the rounded value."""
     xr, xi = x[..., 0], x[..., 1]
-    cre = lambda t: F.conv2d(t, p[pre + "conv_re.weight"], p[pre + "conv_re.bias"], stride=stride, padding=padding)
-    cim = lambda t: F.conv2d(t, p[pre + "conv_im.weight"], p[pre + "conv_im.bias"], stride=stride, padding=padding)
-    return torch.stack((cre(xr) - cim(xi), cre(xi) + cim(xr)), dim=-1)
+    if sim is NoSim:
+        cre = lambda t: F.conv2d(t, p[pre + "conv_re.weight"], p[pre + "conv_re.bias"], stride=stride, padding=padding)
+        cim = lambda t: F.conv2d(t, p[pre + "conv_im.weight"], p[pre + "conv_im.bias"], stride=stride, padding=padding)
+        return torch.stack((cre(xr) - cim(xi), cre(xi) + cim(xr)), dim=-1)
+    wre, wim = sim.weight(p[pre + "conv_re.weight"]), sim.weight(p[pre + "conv_im.weight"])
+    cre = lambda t: F.conv2d(t, wre, None, stride=stride, padding=padding)
+    cim = lambda t: F.conv2d(t, wim, None, stride=stride, padding=padding)
+    bre, bim = p[pre + "conv_re.bias"][None, :, None, None], p[pre + "conv_im.bias"][None, :, None, None]
+    return torch.stack((sim.act(cre(xr) - cim(xi)) + (bre - bim), sim.act(cre(xi) + cim(xr)) + (bre + bim)), dim=-1)
 
 
-def complex_conv_transpose2d(x, p, pre, stride, padding):
-    """src/model/dcunet.py:341-371 (output_padding 0, dilation 1)."""
+def complex_conv_transpose2d(x, p, pre, stride, padding, sim=NoSim):
+    """src/model/dcunet.py:341-371 (output_padding 0, dilation 1).  sim: as complex_conv2d."""
     xr, xi = x[..., 0], x[..., 1]
-    tre = lambda t: F.conv_transpose2d(t, p[pre + "tconv_re.weight"], p[pre + "tconv_re.bias"], stride=stride, padding=padding)
-    tim = lambda t: F.conv_transpose2d(t, p[pre + "tconv_im.weight"], p[pre + "tconv_im.bias"], stride=stride, padding=padding)
-    return torch.stack((tre(xr) - tim(xi), tre(xi) + tim(xr)), dim=-1)
+    if sim is NoSim:
+        tre = lambda t: F.conv_transpose2d(t, p[pre + "tconv_re.weight"], p[pre + "tconv_re.bias"], stride=stride, padding=padding)
+        tim = lambda t: F.conv_transpose2d(t, p[pre + "tconv_im.weight"], p[pre + "tconv_im.bias"], stride=stride, padding=padding)
+        return torch.stack((tre(xr) - tim(xi), tre(xi) + tim(xr)), dim=-1)
+    wre, wim = sim.weight(p[pre + "tconv_re.weight"]), sim.weight(p[pre + "tconv_im.weight"])
+    tre = lambda t: F.conv_transpose2d(t, wre, None, stride=stride, padding=padding)
+    tim = lambda t: F.conv_transpose2d(t, wim, None, stride=stride, padding=padding)
+    bre, bim = p[pre + "tconv_re.bias"][None, :, None, None], p[pre + "tconv_im.bias"][None, :, None, None]
+    return torch.stack((sim.act(tre(xr) - tim(xi)) + (bre - bim), sim.act(tre(xi) + tim(xr)) + (bre + bim)), dim=-1)
 
 
 def complex_batchnorm2d(x, p, pre, training, stats_out=None, momentum=0.1, eps=1e-5):
@@ -96,25 +112,29 @@ def _lrelu(h, tag, act_masks):
 
 
 def dcunet_forward(p, x, model_complexity=45, model_depth=10, masking_mode="E", training=True, stats_out=None, taps=None,
-                   act_masks=None):
+                   act_masks=None, sim=NoSim):
     """x [B, C, F, T, 2] -> enhanced spectrum of the same shape (src/model/dcunet.py:102-162).  ``taps``: optional dict that
-    receives the output of every encoder / decoder block; ``act_masks``: see _lrelu."""
+    receives the output of every encoder / decoder block; ``act_masks``: see _lrelu.
+    ``sim=Bf16Sim`` (tests only): bf16 round-trips where the HIP path stores bf16 -- the packed input spectrum, every (bias-free)
+    convolution output, every BatchNorm + LeakyReLU output, the convolution weights as MFMA operands, and (through the autograd
+    twins of those round-trips) the activation gradients at the same points; the final 1x1 convolution / tanh / mask is fp32 on
+    both sides.  It answers ONE question: how far does bf16 STORAGE alone move the gradients of this non-smooth network?"""
     sz = dcunet_sizes(model_complexity, model_depth, x.shape[1])
     real, imag = x[..., 0], x[..., 1]
-    h = x.transpose(2, 3)
+    h = sim.act(x.transpose(2, 3))
     xs = []
     for i in range(sz["n"]):
         xs.append(h)
-        h = complex_conv2d(h, p, f"encoder{i}.conv.", sz["enc_s"][i], sz["enc_p"][i])
+        h = complex_conv2d(h, p, f"encoder{i}.conv.", sz["enc_s"][i], sz["enc_p"][i], sim)
         h = complex_batchnorm2d(h, p, f"encoder{i}.bn.", training, stats_out)
-        h = _lrelu(h, f"encoder{i}", act_masks)
+        h = sim.act(_lrelu(h, f"encoder{i}", act_masks))
         if taps is not None:
             taps[f"encoder{i}"] = h
     q = h
     for i in range(sz["n"]):
-        q = complex_conv_transpose2d(q, p, f"decoder{i}.transconv.", sz["dec_s"][i], sz["dec_p"][i])
+        q = complex_conv_transpose2d(q, p, f"decoder{i}.transconv.", sz["dec_s"][i], sz["dec_p"][i], sim)
         q = complex_batchnorm2d(q, p, f"decoder{i}.bn.", training, stats_out)
-        q = _lrelu(q, f"decoder{i}", act_masks)
+        q = sim.act(_lrelu(q, f"decoder{i}", act_masks))
         if taps is not None:
             taps[f"decoder{i}"] = q
         if i == sz["n"] - 1:

@@ -143,6 +143,12 @@ def test_full_width_model_vs_oracle():
     # ReLU and of the 28 PReLUs: ~1 % of the near-zero pre-activations have the other sign in the bf16 forward, and under a random G
     # the reference gradient is an incoherent sum that such flips perturb by sqrt(fraction flipped)
     assert glob < 8e-2 and worst < 0.25
+    # round 4: against the oracle with bf16 round-trips at the HIP path's storage points (tests/test_bf16_storage_oracles.py: storage
+    # alone moves the fp32 oracle's gradients by the same 5 %)
+    leaves_s = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref_s = CT.convtasnet_forward(leaves_s, mix, audio_channels=1, sim=CT.Bf16Sim)
+    glob_s, worst_s = compare(got, torch.autograd.grad((ref_s * G).sum(), [leaves_s[k] for k in names]), "fixed upstream gradient, bf16-storage oracle")
+    print(f"ConvTasNet full width: output vs bf16-storage oracle {rel_err(est.detach().cpu(), ref_s.detach()):.3e}")
     # the same comparison through the SAME branches (oracle/convtasnet_oracle.py:_prelu, act_masks from the HIP path's stored
     # pre-activations): what is left is the backward arithmetic itself
     ws = model.workspace(2, 8000)

@@ -412,6 +412,15 @@ def test_full_width_gradients_vs_oracle(depth, frames, batch):
         return (num / den) ** 0.5, big
     print(f"DCUnet-{depth} full width: output rel {out_err:.3e}; kink-aligned oracle output vs plain {rel_err(ref2.detach(), ref.detach()):.3e}")
     glob_plain, _ = compare(grads, "plain oracle")
+    # round 4: the oracle with bf16 round-trips at the HIP path's storage points (oracle Bf16Sim; tests/test_bf16_storage_oracles.py
+    # shows on the CPU that storage ALONE moves the fp32 oracle's gradients by the 13 % / 28 % seen above)
+    leaves_s = {k: p[k].clone().requires_grad_(True) for k in names}
+    work_s = dict(p); work_s.update(leaves_s)
+    ref_s = D.dcunet_forward(work_s, x, model_complexity=45, model_depth=depth, training=True, sim=D.Bf16Sim)
+    grads_s = torch.autograd.grad((ref_s * G).sum(), [leaves_s[k] for k in names])
+    out_sim = rel_err(est.detach().cpu(), ref_s.detach())
+    glob_sim, big_sim = compare(grads_s, "bf16-storage oracle")
+    print(f"DCUnet-{depth} full width: output vs bf16-storage oracle {out_sim:.3e}")
     glob, big = compare(grads2, "kink-aligned oracle")
     # twenty bf16 layers instead of ten, and the last encoders normalise over 16 ... 64 positions: about twice the noise
     out_tol, glob_tol, big_tol, plain_tol = (1.5e-2, 1.5e-2, 5e-2, 0.3) if depth == 10 else (2.5e-2, 3e-2, 6e-2, 0.4)       # depth 20 measured: output 1.75e-2, kink-aligned 1.88e-2 (worst large tensor 3.7e-2), plain 0.277
