@@ -411,6 +411,24 @@ int sehip_lstm_fwd_chunk(const float* pre_r, const float* pre_i, const void* whh
 int sehip_lstm_bwd_chunk(const void* dh_a_bf16, const void* dh_b_bf16, const void* whhT_bf16, const void* gates_bf16,
                          const float* c, int B, int T, int hidden, int t0, int t1, float* state, void* dpre_r_bf16,
                          void* dpre_i_bf16, void* stream);
+/* BOTH stacked complex LSTM layers (src/model/dccrn.py:264-302 wired as in :170-191: layer 2's input is the complex combination
+ * x2_r = h1[r,real] - h1[i,imag], x2_i = h1[i,real] + h1[r,imag] of layer 1's outputs) as ONE persistent launch per direction
+ * (csrc/lstm2.hip): 8 workgroups per tile of 4 batch rows, layer 2 runs a dozen steps behind layer 1; layer 2's input product
+ * (forward) and input gradient (backward) are part of the recurrence.  Inter-workgroup hand-off by data-tagged 8-byte granules.
+ *   pre_r / pre_i : layer 1's pre-gates fp32 [B][T][512];  whh1 / whh2 / wih2 : bf16 [2 lstm][256][64];  bias2 : fp32 [2][256] = b_ih + b_hh
+ *   whhT1 / whhT2 / wihT2 : bf16 [2][64][256];  h* / gates* / c* / dpre* / dh_* : as sehip_lstm_fwd / sehip_lstm_bwd, per layer
+ *   gran : sehip_lstm2_gran_bytes(B, T, backward) bytes of device memory, zeroed once at allocation (one array per direction)
+ *   sync : sehip_lstm2_sync_bytes() bytes, zeroed at allocation; word 0 = sticky hand-off time-out (non-zero: the results since
+ *          then are invalid; pass it as the guard of sehip_opt_begin_g / sehip_opt_step_g), word 1 = test hook (spin limit)
+ *   epoch: 1 .. 65535, different from the previous call's on the same gran array (the granule tag; never cleared between calls) */
+long sehip_lstm2_gran_bytes(int B, int T, int backward);
+int sehip_lstm2_sync_bytes(void);
+int sehip_lstm2_fwd(const float* pre_r, const float* pre_i, const void* whh1, const void* whh2, const void* wih2, const float* bias2,
+                    int B, int T, int hidden, void* h1, void* gates1, float* c1, void* h2, void* gates2, float* c2, void* gran,
+                    unsigned* sync, unsigned epoch, void* stream);
+int sehip_lstm2_bwd(const void* dh_a, const void* dh_b, const void* whhT1, const void* whhT2, const void* wihT2, const void* gates1,
+                    const float* c1, const void* gates2, const float* c2, int B, int T, int hidden, void* dpre1_r, void* dpre1_i,
+                    void* dpre2_r, void* dpre2_i, void* gran, unsigned* sync, unsigned epoch, void* stream);
 
 /* ---- Demucs, everything that is not a convolution / linear product (those are sehip_gemm products): src/model/demucs.py:272-501.
  *      Activations are channels-last bf16 [B][T][C].

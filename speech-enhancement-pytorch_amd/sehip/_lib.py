@@ -23,6 +23,7 @@ P = C.c_void_p
 I = C.c_int
 L = C.c_long
 F = C.c_float
+U = C.c_uint
 
 # name -> argtypes (all return int status unless listed in _RESTYPE)
 _PROTOS = {
@@ -130,10 +131,14 @@ _PROTOS = {
     "sehip_dmx_attn_bwd": [P, P, I, I, I, I, I, I, P, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
+    "sehip_lstm2_gran_bytes": [I, I, I],
+    "sehip_lstm2_sync_bytes": [],
+    "sehip_lstm2_fwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, U, P],
+    "sehip_lstm2_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, U, P],
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
+_RESTYPE = {"sehip_lstm2_gran_bytes": C.c_long, "sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
 
 
 def lib():

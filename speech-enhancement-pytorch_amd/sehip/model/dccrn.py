@@ -111,8 +111,21 @@ class DCCRN(FlatModule):
         return self._lru_get((batch, nsample), self._ws_cap,
                              lambda: plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev))
 
+    def step_guard(self):
+        """Device word the fused optimizer checks (sehip_opt_begin_g / sehip_opt_step_g): the sticky hand-off time-out word of the fused
+        two-layer LSTM kernels of the workspace the last forward ran in (None when that workspace runs the unfused launches)."""
+        ws = getattr(self, "_last_ws", None)
+        return ws.l2_sync[0:1] if ws is not None and ws.lstm_fused else None
+
+    def check_health(self):
+        """Called by the Solver wherever it synchronises anyway: True if steps were lost to a hand-off time-out (the workspace has
+        returned to one launch per LSTM layer)."""
+        ws = getattr(self, "_last_ws", None)
+        return bool(ws is not None and ws.check_lstm_handoffs(recover=True))
+
     def _run_forward(self, wav):
         ws = self.workspace(wav.shape[0], wav.shape[-1])
+        self._last_ws = ws
         ws.generation += 1
         x = wav.reshape(wav.shape[0], wav.shape[-1]).contiguous().float()
         ws.forward(x, self._flat, self._bflat, self._nbt, training=self.training)

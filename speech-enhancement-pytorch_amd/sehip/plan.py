@@ -632,6 +632,10 @@ class DCCRNStatic:
             hh = np.stack([ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0") for l in (0, 1)])
             self.whh_off[layer] = wa.add(enc_entry(hh, 0).reshape(-1))
             self.whhT_off[layer] = wa.add(enc_entry(hh.transpose(0, 2, 1), 0).reshape(-1))
+        # layer 2's input weights for the fused two-layer recurrence (csrc/lstm2.hip): wih2 [lstm][256][64], wihT2 [lstm][64][256]
+        ih2 = np.stack([ia(f"enhance.1.{lstm[l]}.weight_ih_l0") for l in (0, 1)])
+        self.wih2_off = wa.add(enc_entry(ih2, 0).reshape(-1))
+        self.wihT2_off = wa.add(enc_entry(ih2.transpose(0, 2, 1), 0).reshape(-1))
         # BatchNorm / PReLU gradients land in the packed-gradient buffer too
         self.bn_g_off = {}
         for pre, cr in self.bn:
@@ -826,6 +830,16 @@ class DCCRNWorkspace:
             # the small products between the layers get their own stream: chunk c's product overlaps layer 2's chunk c-1
             self.lstm_gemm_stream = torch.cuda.Stream(device=device, priority=hi)
         self.lstm_state = {layer: torch.zeros(4 * ((B + 15) // 16) * 2048, dtype=torch.float32, device=device) for layer in (1, 2)}
+        # fused two-layer recurrence (csrc/lstm2.hip, round 4): both layers in ONE persistent launch per direction, layer 2 a dozen steps
+        # behind layer 1, hand-off by data-tagged granules.  Default when the whole sequence runs as one chunk; SEHIP_NO_LSTM_FUSE or a
+        # hand-off time-out (check_lstm_handoffs) return to the two launches per direction of round 3.
+        self.lstm_fused = len(self.lstm_chunks) == 1 and not os.environ.get("SEHIP_NO_LSTM_FUSE") and T < 65535
+        self.l2_epoch = 0
+        if self.lstm_fused:
+            lib_ = _lib.lib()
+            self.l2_gran_f = torch.zeros(int(lib_.sehip_lstm2_gran_bytes(B, T, 0)) // 8, dtype=torch.int64, device=device)
+            self.l2_gran_b = torch.zeros(int(lib_.sehip_lstm2_gran_bytes(B, T, 1)) // 8, dtype=torch.int64, device=device)
+            self.l2_sync = torch.zeros(int(lib_.sehip_lstm2_sync_bytes()) // 4, dtype=torch.int32, device=device)
         self._bind()
 
     def close(self):
@@ -1106,10 +1120,43 @@ class DCCRNWorkspace:
         call("sehip_lstm_fwd_chunk", b[f"pre{layer}_r"].ptr, b[f"pre{layer}_i"].ptr, whh, self.B, self.T, cfg.hid, t0, t1,
              b[f"h{layer}"].ptr, b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, st_)
 
+    def _l2_next_epoch(self):
+        """Epoch of the granule tags of one forward (+ its backward).  Eager: a new value per call, the granule arrays are never cleared.
+        Under stream capture the value is frozen into the graph, so the graph clears the arrays itself (memset nodes)."""
+        if torch.cuda.is_current_stream_capturing():
+            self.l2_gran_f.zero_(); self.l2_gran_b.zero_()
+            return self.l2_epoch if self.l2_epoch else 1
+        self.l2_epoch = self.l2_epoch % 65535 + 1
+        return self.l2_epoch
+
+    def check_lstm_handoffs(self, recover=True):
+        """Reads the sticky time-out word of the fused recurrence (the read waits for the stream).  A time-out means the launches since
+        then produced garbage; the fused optimizer did not apply it (the word is its device-side guard, model.step_guard()).
+        recover=True: this workspace returns to one launch per layer and direction, the word is cleared, True is returned."""
+        if not self.lstm_fused or int(self.l2_sync[0]) == 0:
+            return False
+        if not recover:
+            raise SehipError("DCCRN: a hand-off wait of the fused two-layer LSTM kernels timed out (results since then are invalid and "
+                             "no optimizer step was applied); set SEHIP_NO_LSTM_FUSE=1 to use one launch per layer")
+        import warnings
+        warnings.warn("sehip DCCRN: a hand-off wait of the fused two-layer LSTM kernels timed out; the optimizer steps since then were "
+                      "skipped on the device; falling back to one launch per LSTM layer for this workspace")
+        self.lstm_fused = False
+        self.l2_sync.zero_()
+        return True
+
     def _lstm_forward(self, B, T, h):
         self._chain_dirty = True
         main = stream()
         self.gemm_pair("ih1_r", "ih1_i")
+        if self.lstm_fused:
+            b, st, tb = self.bufs, self.st, self.tb
+            wp = tb.wpack.data_ptr()
+            self._l2_cur_epoch = self._l2_next_epoch()
+            call("sehip_lstm2_fwd", b["pre1_r"].ptr, b["pre1_i"].ptr, wp + 2 * st.whh_off[1], wp + 2 * st.whh_off[2],
+                 wp + 2 * st.wih2_off, self.desc["ih2_r"].bias, B, T, h, b["h1"].ptr, b["gates1"].ptr, b["c1"].ptr, b["h2"].ptr,
+                 b["gates2"].ptr, b["c2"].ptr, ptr(self.l2_gran_f), ptr(self.l2_sync), self._l2_cur_epoch, main)
+            return
         if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():  # graph replay serialises the streams
             self._lstm_fwd_call(1, 0, T, main)
             self.gemm_pair("ih2_r", "ih2_i")
@@ -1134,6 +1181,17 @@ class DCCRNWorkspace:
     def _lstm_backward(self, B, T, h):
         self._chain_dirty = True
         main = stream()
+        if self.lstm_fused:
+            b, st, tb = self.bufs, self.st, self.tb
+            wp = tb.wpack.data_ptr()
+            call("sehip_lstm2_bwd", b["dxo_r"].ptr, b["dxo_i"].ptr, wp + 2 * st.whhT_off[1], wp + 2 * st.whhT_off[2],
+                 wp + 2 * st.wihT2_off, b["gates1"].ptr, b["c1"].ptr, b["gates2"].ptr, b["c2"].ptr, B, T, h, b["dpre1_r"].ptr,
+                 b["dpre1_i"].ptr, b["dpre2_r"].ptr, b["dpre2_i"].ptr, ptr(self.l2_gran_b), ptr(self.l2_sync),
+                 getattr(self, "_l2_cur_epoch", 1), main)
+            self._chain_dirty = True
+            self.wgrad_group(self._lstm_wgrad_names((2, 1)))
+            self.gemm_pair("dx1_r", "dx1_i")
+            return
         if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():
             for layer in (2, 1):
                 self._lstm_bwd_call(layer, 0, T, main)

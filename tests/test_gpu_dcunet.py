@@ -399,6 +399,21 @@ def test_full_width_gradients_vs_oracle(depth, frames, batch):
     for i in range(depth // 2):
         masks[f"encoder{i}"] = to_ref(ws.bufs[f"ze{i}"], sz["enc_ch"][i + 1]) > 0
         masks[f"decoder{i}"] = to_ref(ws.bufs[f"zd{i}"], sz["dec_ch"][i + 1]) > 0
+    # The kink-aligned comparison takes the LeakyReLU branches from the HIP run's own stored activations; so that this is not
+    # self-referential, those branches are first checked against the fp32 oracle's: they may differ only on a small
+    # fraction of the elements, and only where the oracle's activation is near zero.
+    taps = {}
+    D.dcunet_forward(p, x, model_complexity=45, model_depth=depth, training=True, taps=taps)
+    worst_frac, worst_mag = 0.0, 0.0
+    for tag, mk in masks.items():
+        h = taps[tag]
+        diff = mk != (h > 0)
+        frac = float(diff.float().mean())
+        mag = float(h[diff].abs().mean() / h.abs().mean()) if bool(diff.any()) else 0.0
+        worst_frac, worst_mag = max(worst_frac, frac), max(worst_mag, mag)
+    print(f"DCUnet-{depth} full width: LeakyReLU branches of the HIP run vs the fp32 oracle: worst layer {worst_frac:.3%} of the elements "
+          f"differ, their mean |activation| is {worst_mag:.3f} of the layer's mean")
+    assert worst_frac < 0.03 and worst_mag < 0.15, (worst_frac, worst_mag)
     ref2, leaves2, _ = oracle(masks)
     grads2 = torch.autograd.grad((ref2 * G).sum(), [leaves2[k] for k in names])
 
@@ -420,12 +435,21 @@ def test_full_width_gradients_vs_oracle(depth, frames, batch):
     grads_s = torch.autograd.grad((ref_s * G).sum(), [leaves_s[k] for k in names])
     out_sim = rel_err(est.detach().cpu(), ref_s.detach())
     glob_sim, big_sim = compare(grads_s, "bf16-storage oracle")
-    print(f"DCUnet-{depth} full width: output vs bf16-storage oracle {out_sim:.3e}")
+    sim_dev = (sum(float(((a.double() - b_.double()) ** 2).sum()) for a, b_ in zip(grads_s, grads)) /
+               sum(float((b_.double() ** 2).sum()) for b_ in grads)) ** 0.5
+    print(f"DCUnet-{depth} full width: output vs bf16-storage oracle {out_sim:.3e}; bf16-storage oracle vs fp32 oracle gradients {sim_dev:.3e}")
+    # The plain comparison is gated by what bf16 STORAGE ALONE does to the oracle (measured here, no HIP code involved): the HIP path
+    # may deviate from the fp32 oracle about as much as the bf16-storage oracle does (13 % / 28 %), and it must be CLOSER to the
+    # bf16-storage oracle than that oracle is to the fp32 one (the two bf16 evaluations share most of their flipped branches; what
+    # is left differs by summation order only).  Measured: plain 1.35e-1 vs storage-alone 1.33e-1, HIP vs bf16-storage oracle 8.7e-2
+    # (depth 20: 2.77e-1 / 2.80e-1 / 1.86e-1).
+    assert glob_plain < 1.3 * sim_dev and glob_sim < sim_dev, (glob_plain, glob_sim, sim_dev)
+    assert out_sim < 0.8 * out_err + 1e-3                   # the output is closer to the bf16-storage oracle too (5.9e-3 vs 9.9e-3)
     glob, big = compare(grads2, "kink-aligned oracle")
     # twenty bf16 layers instead of ten, and the last encoders normalise over 16 ... 64 positions: about twice the noise
     out_tol, glob_tol, big_tol, plain_tol = (1.5e-2, 1.5e-2, 5e-2, 0.3) if depth == 10 else (2.5e-2, 3e-2, 6e-2, 0.4)       # depth 20 measured: output 1.75e-2, kink-aligned 1.88e-2 (worst large tensor 3.7e-2), plain 0.277
     assert out_err < out_tol
-    assert glob_plain < plain_tol
+    assert glob_plain < plain_tol      # (absolute backstop; the binding gate on the plain comparison is the measured storage-alone figure above)
     assert glob < glob_tol          # depth 10 measured 1.10e-2 (plain: 1.33e-1), worst large tensor 1.4e-2
     assert all(r[0] < big_tol for r in big), big[:5]
     sd = model.state_dict()

@@ -14,7 +14,9 @@ def run_once(chunk, B, N):
     os.environ["SEHIP_LSTM_CHUNK"] = str(chunk)
     # bit equality needs a bit-reproducible network around the LSTM: the BatchNorm sums that the convolution epilogues take with
     # fp32 atomics (and the backward sums that meet in a few rows the same way) vary in the last bit from run to run, the separate passes do not
-    fused = {k: os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_FINALIZE")}
+    # (and the comparison is between the chunked and the whole-sequence launches of the SAME per-layer kernels: the fused two-layer
+    #  kernel of round 4, csrc/lstm2.hip, rounds layer 2's input once more and has its own test, tests/test_gpu_lstm_fused.py)
+    fused = {k: os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_FINALIZE", "SEHIP_NO_LSTM_FUSE")}
     os.environ.update({k: "1" for k in fused})
     try:
         dev = torch.device("cuda:0")
