@@ -21,6 +21,7 @@
 // tag = (epoch << 16) | (step index + 1) with a per-call epoch from the host, so the granule arrays are never cleared between calls
 // (every slot is rewritten by every call); under stream capture the host clears them with a memset node instead (a captured epoch is
 // frozen).
+#include <stdlib.h>
 #include "common.h"
 
 #define H 64
@@ -42,6 +43,20 @@ __device__ __forceinline__ void l2_lds_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// s_waitcnt vmcnt(0) the compiler KNOWS about (the builtin, not inline asm).  Placed once in front of a software-pipelined loop: hipcc's
+// counted waits inside the loop merge the loop-entry state with the back-edge state per register and keep the more recent one; the
+// prologue's ring loads are recent on the entry path, so without this the first step of every unrolled group of PD steps drained the
+// wave's whole memory queue (one full memory latency per PD steps: fused forward 158 us instead of ~125).
+__device__ __forceinline__ void l2_drain_known() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) expcnt(7) lgkmcnt(15)
+// Explicit guard for the register rings of plain loads (pre-gates, gate / cell records): inside these software-pipelined loops hipcc
+// emits NO vmcnt wait for a value requested PD steps earlier (lstm.hip's loops have none either), so a load slower than PD steps
+// would be read before it lands.  N = memory instructions a wave issues in PD - 2 steps, rounded down: in steady state the wait is
+// already satisfied (everything older than ~6 steps has returned) and costs nothing; if memory is slower than that it stalls
+// instead of reading a register in flight.  (The granule rings need none: a value read too early fails its tag check.  The backward
+// kernels carry none: vmcnt retires in order, their sc1 granule loads take ~2 us and held the counter above any useful N -- with
+// a guard of 36 the fused backward launch took 187 us instead of 174.)
+template <int N>
+__device__ __forceinline__ void l2_guard() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ float l2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float l2_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 __device__ __forceinline__ float l2_pick(const f32x4& a, int rs) { return rs == 0 ? a[0] : rs == 1 ? a[1] : rs == 2 ? a[2] : a[3]; }
@@ -52,26 +67,33 @@ __device__ __forceinline__ void l2_store_granule(unsigned long long* g, unsigned
 __device__ __forceinline__ unsigned long long l2_load_granule(const unsigned long long* g) {
     return __hip_atomic_load((l2_gu64*)g, L2_RLX_AGENT);                                           // sc1: never served by this CU's L1
 }
-// wave-uniform bounded wait: re-loads the wave's two granules until both carry `tag` in every active lane
+// wave-uniform bounded wait for the wave's two granules of one step.  (a, b) arrive from the prefetch ring; the FIRST check is
+// straight-line code, so that the compiler's counted s_waitcnt for those ring loads is exact (with the check at the head of the spin
+// loop it merged the ring loads' state with the re-loads' and drained the wave's whole memory queue every time step: fused kernel
+// 222 us instead of ~130).  The spin itself works on its own temporaries.
 __device__ __forceinline__ void l2_wait_pair(const unsigned long long* ga, const unsigned long long* gb, unsigned tag,
                                              unsigned long long& a, unsigned long long& b, unsigned* sync, bool& dead, unsigned limit) {
     if (dead) return;
-    unsigned spins = 0;
-    if (limit == 0xffffffffu) {          // test hook: "time out" at the first wait whatever the timing
+    if (__builtin_expect(__all((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag), 1)) return;
+    if (limit == 0xffffffffu) {          // test hook: "time out" at the first wait that is not already satisfied
         __hip_atomic_store((l2_gu32*)(sync + L2_TMO), 1u, L2_RLX_AGENT);
         dead = true;
         return;
     }
-    while (!__all((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag)) {
+    unsigned spins = 0;
+    unsigned long long x, y;
+    do {
         if (++spins > limit || ((spins & 255u) == 0 && __hip_atomic_load((l2_gu32*)(sync + L2_TMO), L2_RLX_AGENT) != 0)) {
             __hip_atomic_store((l2_gu32*)(sync + L2_TMO), 1u, L2_RLX_AGENT);
             dead = true;          // give up for the rest of the sequence: garbage out, but the launch ends and the guard word is set
             return;
         }
         __builtin_amdgcn_s_sleep(2);
-        a = l2_load_granule(ga);
-        b = l2_load_granule(gb);
-    }
+        x = l2_load_granule(ga);
+        y = l2_load_granule(gb);
+    } while (!__all((unsigned)(x >> 32) == tag && (unsigned)(y >> 32) == tag));
+    a = x;
+    b = y;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -126,6 +148,8 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
         unsigned long long* gout = gran + ((size_t)(combo * ntiles + tile) * T) * 128 + gi_;
         int cur = 0;
         auto step = [&](int t, float (&pq)[4]) {
+            l2_guard<42>();                      // 7-8 memory instructions per step
+            if (t + PD >= T && t + PD < T + 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last requests: nothing is issued behind them
             const float p0 = pq[0], p1 = pq[1], p2 = pq[2], p3 = pq[3];
             if (t + PD < T) {
 #pragma unroll
@@ -190,25 +214,30 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
     bool dead = false;
     const unsigned limit = sync[L2_LIM] ? sync[L2_LIM] : L2_SPIN_LIMIT;
     // stager lanes: waves 0 and 1; lane's granule i = 64 w + lane of both sources
+    // (every wave stages: waves 2 and 3 repeat the loads and the LDS writes of waves 0 and 1 with the same values.  Nothing about the
+    //  memory instructions of a step is conditional -- step indices are clamped instead of branched on -- because hipcc's counted
+    //  s_waitcnt for a ring load assumes that conditionally issued instructions behind it were NOT issued: with `if (stager && s < T)`
+    //  around the loads it waited for all but the newest five operations, i.e. for the previous step's loads, on every time step)
     const int gi_ = 64 * (w & 1) + lane, prow = gi_ >> 5, ppair = gi_ & 31;
-    const bool stager = w < 2;
     const unsigned long long* ga = gran + ((size_t)(ca * ntiles + tile) * T) * 128 + gi_;
     const unsigned long long* gb = gran + ((size_t)(cb * ntiles + tile) * T) * 128 + gi_;
     unsigned long long ra[PD], rb[PD];      // granules of steps s .. s + PD - 1 (ring indexed by s % PD after unrolling)
 #pragma unroll
     for (int k = 0; k < PD; ++k) {
-        ra[k] = 0; rb[k] = 0;
-        if (stager && k < T) { ra[k] = l2_load_granule(ga + (size_t)k * 128); rb[k] = l2_load_granule(gb + (size_t)k * 128); }
+        const int kk = k < T ? k : T - 1;
+        ra[k] = l2_load_granule(ga + (size_t)kk * 128); rb[k] = l2_load_granule(gb + (size_t)kk * 128);
     }
-    // stage(s, slot): x2(s) -> xbuf[s & 1]; then the slot is re-armed with the granules of step s + PD
+    // stage(s, slot): x2(s) -> xbuf[s & 1]; then the slot is re-armed with the granules of step s + PD (past the end: the last step's again)
     auto stage = [&](int s, unsigned long long& qa, unsigned long long& qb) {
-        if (!stager || s >= T) return;
-        l2_wait_pair(ga + (size_t)s * 128, gb + (size_t)s * 128, tag0 | (unsigned)(s + 1), qa, qb, sync, dead, limit);
-        const unsigned va = (unsigned)qa, vb = (unsigned)qb;
+        const int sc = s < T ? s : T - 1;
+        unsigned long long ua = qa, ub = qb;
+        l2_wait_pair(ga + (size_t)sc * 128, gb + (size_t)sc * 128, tag0 | (unsigned)(sc + 1), ua, ub, sync, dead, limit);
+        const unsigned va = (unsigned)ua, vb = (unsigned)ub;
         const float x0 = __uint_as_float(va << 16) + sgn * __uint_as_float(vb << 16);
         const float x1 = __uint_as_float(va & 0xffff0000u) + sgn * __uint_as_float(vb & 0xffff0000u);
         *reinterpret_cast<unsigned*>(&xbuf[s & 1][prow * HP + 2 * ppair]) = pack_bf2(x0, x1);
-        if (s + PD < T) { qa = l2_load_granule(ga + (size_t)(s + PD) * 128); qb = l2_load_granule(gb + (size_t)(s + PD) * 128); }
+        const int sn = s + PD < T ? s + PD : T - 1;
+        qa = l2_load_granule(ga + (size_t)sn * 128); qb = l2_load_granule(gb + (size_t)sn * 128);
     };
     // ih(s): W_ih x2(s) + b  (reads xbuf[s & 1])
     auto ih = [&](int s, f32x4 (&out)[4]) {
@@ -229,18 +258,23 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
     ih(0, accih);
     stage(1, ra[1 % PD], rb[1 % PD]);
     l2_lds_barrier();
+    l2_drain_known();
     int cur = 0;
     auto step = [&](int t, unsigned long long& qa, unsigned long long& qb) {      // (qa, qb): ring slot of step t + 2
         bf16x8 hf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             hf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&hbuf[cur][bl * HP + 32 * s + 8 * ug]));
-        f32x4 acc[4];
+        f32x4 acc[4], nxt[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][0], hf[0], accih[g], 0, 0, 0);
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][1], hf[1], acc[g], 0, 0, 0);
         }
+        // off the dependent chain: the input product of step t + 1 (x2(t + 1) was staged in step t - 1) goes into the matrix pipe right
+        // behind the recurrent MFMAs and runs under the gate arithmetic below (issued after the stores it delayed the barrier by its
+        // whole 8 x 32 cycles: 154 us per launch instead of ~125)
+        ih(t + 1, nxt);
         const float gi = l2_sigmoid(l2_pick(acc[0], rs));
         const float gf = l2_sigmoid(l2_pick(acc[1], rs));
         const float gg = l2_tanh(l2_pick(acc[2], rs));
@@ -248,13 +282,14 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
         c = gf * c + gi * gg;
         const bf16_raw hb = f2bf(go * l2_tanh(c));
         hbuf[cur ^ 1][bl * HP + unit] = hb;
-        if (bvalid) h2out[(obase + t) * H + unit] = hb;
+        h2out[(obase + t) * H + unit] = hb;        // (rows past the batch repeat row B - 1 with the same value: no branch, see above)
         const size_t rec = (rbase + t) * 256 + threadIdx.x;
         c2out[rec] = c;
         *reinterpret_cast<uint2*>(gates2 + rec * 4) = make_uint2(pack_bf2(gi, gf), pack_bf2(gg, go));
-        // off the dependent chain: the input product of step t + 1 (x2(t + 1) was staged in step t - 1) and the staging of x2(t + 2)
-        if (t + 1 < T) ih(t + 1, accih);
+        // the staging of x2(t + 2)
         stage(t + 2, qa, qb);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) accih[g] = nxt[g];
         l2_lds_barrier();
         cur ^= 1;
     };
@@ -278,7 +313,7 @@ __global__ __launch_bounds__(256) void lstm2_bwd_kernel(const bf16_raw* __restri
                                                         const float* __restrict__ c2, int B, int T, bf16_raw* __restrict__ dpre1_0,
                                                         bf16_raw* __restrict__ dpre1_1, bf16_raw* __restrict__ dpre2_0,
                                                         bf16_raw* __restrict__ dpre2_1, unsigned long long* gran, unsigned* sync,
-                                                        unsigned epoch) {
+                                                        unsigned epoch, int abl) {
     __shared__ __attribute__((aligned(16))) bf16_raw dgbuf[2][NBT * DGP];
     const int ntiles = gridDim.x >> 3;
     const int cl = blockIdx.x / ntiles, tile = blockIdx.x - cl * ntiles;
@@ -330,6 +365,7 @@ __global__ __launch_bounds__(256) void lstm2_bwd_kernel(const bf16_raw* __restri
 #pragma unroll
         for (int k = 0; k < PD; ++k)
             if (T - 1 - k >= 0) ring[k] = load_step(T - 1 - k);
+        f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = x0;       // the input-gradient partial of the step before (stored one step late)
         auto step = [&](int t, StepIn& slot) {
             const StepIn in = slot;
             if (t - PD >= 0) slot = load_step(t - PD);
@@ -346,22 +382,33 @@ __global__ __launch_bounds__(256) void lstm2_bwd_kernel(const bf16_raw* __restri
             bf16_raw* lb = &dgbuf[cur][bl * DGP + unit];
             lb[0] = di; lb[H] = df; lb[2 * H] = dg; lb[3 * H] = dob;
             l2_lds_barrier();
-            f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0, x0 = r0, x1 = r0;
+            // the previous step's input-gradient partial leaves now (its MFMAs ran under this step's gate arithmetic)
+            if (t < T - 1 && !(abl & 2)) l2_store_granule(gout + (size_t)(t + 1) * 256, tag0 | (unsigned)(T - t - 1), __float_as_uint(l2_pick(x0, rs) + l2_pick(x1, rs)));
+            bf16x8 gq[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                gq[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&dgbuf[cur][bl * DGP + 32 * s + 8 * ug]));
+            f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
+            x0 = r0; x1 = r0;
+            // the recurrent product first (its result is the next step's dh), the input gradient's partial behind it on the same B
+            // operands (interleaved with it the partial delayed dhrec by six MFMAs per step)
 #pragma unroll
             for (int s = 0; s < 8; s += 2) {
-                const bf16x8 g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&dgbuf[cur][bl * DGP + 32 * s + 8 * ug]));
-                const bf16x8 g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&dgbuf[cur][bl * DGP + 32 * s + 32 + 8 * ug]));
-                r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], g0, r0, 0, 0, 0);
-                r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], g1, r1, 0, 0, 0);
-                x0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx[s], g0, x0, 0, 0, 0);      // same B operand: the input gradient's partial
-                x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx[s + 1], g1, x1, 0, 0, 0);
+                r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], gq[s], r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], gq[s + 1], r1, 0, 0, 0);
+            }
+            if (!(abl & 1)) {
+#pragma unroll
+            for (int s = 0; s < 8; s += 2) {
+                x0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx[s], gq[s], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx[s + 1], gq[s + 1], x1, 0, 0, 0);
+            }
             }
             {
                 const uint2 row = *reinterpret_cast<const uint2*>(&dgbuf[cur][w * DGP + lane * 4]);
                 if (svalid) *reinterpret_cast<uint2*>(dpre + (size_t)t * (2 * G4)) = row;
             }
             dhrec = l2_pick(r0, rs) + l2_pick(r1, rs);
-            l2_store_granule(gout + (size_t)t * 256, tag0 | (unsigned)(T - t), __float_as_uint(l2_pick(x0, rs) + l2_pick(x1, rs)));
             cur ^= 1;
         };
         for (int t = T - 1; t >= 0; t -= PD) {
@@ -369,6 +416,7 @@ __global__ __launch_bounds__(256) void lstm2_bwd_kernel(const bf16_raw* __restri
             for (int k = 0; k < PD; ++k)
                 if (t - k >= 0) step(t - k, ring[k]);
         }
+        l2_store_granule(gout, tag0 | (unsigned)T, __float_as_uint(l2_pick(x0, rs) + l2_pick(x1, rs)));     // step 0's partial
         return;
     }
 
@@ -390,12 +438,12 @@ __global__ __launch_bounds__(256) void lstm2_bwd_kernel(const bf16_raw* __restri
     };
     StepIn1 ring[PD];
 #pragma unroll
-    for (int k = 0; k < PD; ++k)
-        if (T - 1 - k >= 0) ring[k] = load_step(T - 1 - k);
+    for (int k = 0; k < PD; ++k) ring[k] = load_step(T - 1 - k >= 0 ? T - 1 - k : 0);
+    l2_drain_known();
     auto step = [&](int t, StepIn1& slot) {
         StepIn1 in = slot;
-        l2_wait_pair(ga + (size_t)t * 256, gb + (size_t)t * 256, tag0 | (unsigned)(T - t), in.qa, in.qb, sync, dead, limit);
-        if (t - PD >= 0) slot = load_step(t - PD);
+        if (!(abl & 4)) l2_wait_pair(ga + (size_t)t * 256, gb + (size_t)t * 256, tag0 | (unsigned)(T - t), in.qa, in.qb, sync, dead, limit);
+        slot = load_step(t - PD >= 0 ? t - PD : 0);       // (clamped, not branched on: see the forward consumer)
         const float gi = bf2f(in.g.x & 0xffff), gf = bf2f(in.g.x >> 16), gg = bf2f(in.g.y & 0xffff), go = bf2f(in.g.y >> 16);
         const float dx = __uint_as_float((unsigned)in.qa) + __uint_as_float((unsigned)in.qb);
         const float dhv = sign * dx + dhrec;
@@ -475,7 +523,7 @@ extern "C" int sehip_lstm2_bwd(const void* dh_a, const void* dh_b, const void* w
     lstm2_bwd_kernel<<<8 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>(
         (const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT1, (const bf16_raw*)whhT2, (const bf16_raw*)wihT2,
         (const bf16_raw*)gates1, c1, (const bf16_raw*)gates2, c2, B, T, (bf16_raw*)dpre1_r, (bf16_raw*)dpre1_i, (bf16_raw*)dpre2_r,
-        (bf16_raw*)dpre2_i, (unsigned long long*)gran, sync, epoch);
+        (bf16_raw*)dpre2_i, (unsigned long long*)gran, sync, epoch, getenv("SEHIP_L2_ABL") ? atoi(getenv("SEHIP_L2_ABL")) : 0);
     SEHIP_CHECK_LAUNCH("lstm2_bwd");
     return 0;
 }

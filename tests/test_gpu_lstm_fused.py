@@ -54,9 +54,15 @@ def run_once(fuse, B, N, kernel_num=(16, 16, 32, 32, 64, 64), hook=None, steps=1
 
 @pytest.mark.parametrize("B,N", [(2, 6000), (3, 4000), (17, 3000), (32, 32000)])
 def test_fused_equals_the_two_launches(B, N):
-    """Layer 1 is the same arithmetic in the same order: bit-equal h1 / gates / c.  Layer 2 sees x2 = bf16(h1_a +- h1_b) as ONE operand
-    instead of the two bf16 operands of the ih2 product (one more rounding of its input, 2^-9 relative) and fp32 instead of bf16 dx2 in
-    the backward pass: equal to a few 1e-3.  Ragged batch tiles (B = 2, 3, 17) and the headline shape (B = 32, T = 323)."""
+    """Forward, through the model: layer 1 is the same arithmetic in the same order -- bit-equal h1 / gates / c.  Layer 2 sees
+    x2 = bf16(h1_a +- h1_b) as ONE operand instead of the two bf16 operands of the ih2 product (one more rounding of its input, 2^-9
+    relative): h2 / c2 / the projection equal to a few 1e-3.
+    Backward, in isolation (the fused kernel on the UNFUSED run's own records and upstream gradient -- through the whole network the
+    0.2 % difference of P moves the decoder's PReLU branches and with them the gradient that arrives here by a few per cent, which
+    says nothing about these kernels): layer 2's gate gradients are the same arithmetic -- bit-equal; layer 1 receives dx2 as the fp32
+    sum of two partials instead of the bf16 output of the dx2 product: equal to a few 1e-3.
+    Ragged batch tiles (B = 2, 3, 17) and the headline shape (B = 32, T = 323)."""
+    from sehip import _lib
     kn = (16, 32, 64, 128, 256, 256) if N == 32000 else (16, 16, 32, 32, 64, 64)
     a, ga, wa, _ = run_once(True, B, N, kn, steps=2)        # (two calls: the second runs on granule arrays the first has written)
     b, gb, wb, _ = run_once(False, B, N, kn, steps=2)
@@ -64,12 +70,31 @@ def test_fused_equals_the_two_launches(B, N):
     T = wa.T
     for k in ("h1", "gates1", "c1"):
         assert torch.equal(a[k], b[k]), k
-    errs = {k: rel_err(a[k], b[k]) for k in KEYS}
-    print(f"fused vs two launches, B={B} T={T}:", {k: f"{v:.2e}" for k, v in errs.items()})
-    assert errs["h2"] < 5e-3 and errs["c2"] < 5e-3 and errs["P"] < 5e-3
-    for k in ("dpre2_r", "dpre2_i", "dpre1_r", "dpre1_i", "dz5l"):
-        assert errs[k] < 1.5e-2, (k, errs[k])
-    assert rel_err(ga, gb) < 1e-2
+    errs = {k: rel_err(a[k], b[k]) for k in ("P", "h2", "gates2", "c2")}
+    print(f"fused vs two launches, forward, B={B} T={T}:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["h2"] < 5e-3 and errs["c2"] < 5e-3 and errs["P"] < 5e-3 and errs["gates2"] < 5e-3
+    assert rel_err(ga, gb) < 3e-2                        # whole-network parameter gradients (see above: the decoder's kinks)
+    # backward in isolation, on the unfused workspace
+    lib = _lib.lib()
+    names = ("dpre1_r", "dpre1_i", "dpre2_r", "dpre2_i", "dz5l")
+    ref = {k: wb.bufs[k].t.float().cpu().clone() for k in names}
+    dev = wb.bufs["h1"].t.device
+    wb.l2_gran_f = torch.zeros(int(lib.sehip_lstm2_gran_bytes(B, T, 0)) // 8, dtype=torch.int64, device=dev)
+    wb.l2_gran_b = torch.zeros(int(lib.sehip_lstm2_gran_bytes(B, T, 1)) // 8, dtype=torch.int64, device=dev)
+    wb.l2_sync = torch.zeros(int(lib.sehip_lstm2_sync_bytes()) // 4, dtype=torch.int32, device=dev)
+    wb.lstm_fused, wb._l2_cur_epoch = True, 7
+    for rep in range(2):                                 # the second call reads granule slots the first has written
+        wb._l2_cur_epoch = 7 + rep
+        wb._lstm_backward(B, T, 64)
+    torch.cuda.synchronize()
+    wb.lstm_fused = False
+    assert int(wb.l2_sync[0]) == 0
+    got = {k: wb.bufs[k].t.float().cpu() for k in names}
+    for k in ("dpre2_r", "dpre2_i"):
+        assert torch.equal(got[k], ref[k]), k
+    berr = {k: rel_err(got[k], ref[k]) for k in ("dpre1_r", "dpre1_i", "dz5l")}
+    print(f"fused vs two launches, backward in isolation, B={B} T={T}:", {k: f"{v:.2e}" for k, v in berr.items()})
+    assert max(berr.values()) < 6e-3, berr
 
 
 def test_forced_handoff_timeout_sets_the_guard_and_falls_back(tmp_path):
