@@ -237,9 +237,21 @@ typedef struct {
      * contiguous elements at m N: the 1x1 convolutions of ConvTasNet (src/model/conv_tasnet.py:307-402).  sehip_wgrad may then take
      * dense_wgrad_kernel (N, K in {128, 256}); whatever it does not take runs as before. */
     int32_t dense_rows;
+    /* Deterministic schedule (sehip_set_deterministic): the launcher points dW / dbias at ONE PRIVATE ARRAY PER M-SPLIT of the launch
+     * (floats between two splits' arrays; 0 = all splits add to the same dW with fp32 atomics, the default) and adds the arrays in
+     * split order afterwards.  Set by the library on its own copy of the descriptor; callers leave it 0. */
+    int64_t dw_split_stride;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);
+/* Deterministic reductions, process-wide (the reference's switch is config.solver.cudnn_deterministic -> src/utils.py:108-111): with
+ * on != 0 every floating-point sum whose order depends on scheduling takes a fixed-order form -- weight gradients through per-split
+ * partial arrays added in split order (sehip_wgrad; grouped launches run one by one; the store-flush kernels already do), the
+ * clipping norm / per-tensor sums / l1-mse loss in one workgroup, and the DCCRN plan takes its BatchNorm sums from the separate
+ * passes instead of the convolution epilogues' atomics.  Two runs of the same step are then bit-identical.  Built for the DCCRN step;
+ * the other networks' own atomics (GroupNorm / gLN sums, real-BatchNorm sums) are not covered.  Not inside a stream capture. */
+int sehip_set_deterministic(int on);
+int sehip_get_deterministic(void);
 /* forward / dgrad style product */
 int sehip_gemm(const sehip_gemm_desc* desc, void* stream);
 /* two products over the same sources (the output-row parities of ComplexConvTranspose2d, src/model/dccrn.py:387-450):

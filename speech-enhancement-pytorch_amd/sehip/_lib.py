@@ -29,6 +29,8 @@ U = C.c_uint
 _PROTOS = {
     "sehip_version": [],
     "sehip_check_device": [I],
+    "sehip_set_deterministic": [I],
+    "sehip_get_deterministic": [],
     "sehip_event_create": [],
     "sehip_stream_create": [C.c_int],
     "sehip_stream_destroy": [P],

@@ -24,6 +24,11 @@ void sehip_note_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_deterministic = 0;
+int sehip_deterministic(void) { return g_deterministic; }
+extern "C" int sehip_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return 0; }
+extern "C" int sehip_get_deterministic(void) { return g_deterministic; }
+
 extern "C" const char* sehip_last_error(void) { return g_err; }
 extern "C" const char* sehip_last_kernel(void) { return g_kernel; }
 extern "C" int sehip_version(void) { return 100; }

@@ -14,6 +14,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 int sehip_set_error(int code, const char* fmt, ...);
 // records which kernel instantiation the last product launch used (read back by sehip_last_kernel(), for bench/profiles)
 void sehip_note_kernel(const char* fmt, ...);
+// 1 while the deterministic schedule is on (sehip_set_deterministic, include/sehip.h)
+int sehip_deterministic(void);
 #define SEHIP_CHECK_LAUNCH(name)                                                      \
     do {                                                                              \
         hipError_t e__ = hipGetLastError();                                           \

@@ -1308,7 +1308,10 @@ __device__ __forceinline__ void wgrad_body(const sehip_gemm_desc& d, const int b
         __syncthreads();
     }
 
-    // D rows = n (4*(lane>>4)+q), cols = k (lane&15)
+    // D rows = n (4*(lane>>4)+q), cols = k (lane&15).  Deterministic schedule: m-split bz adds to its own zeroed array (every entry
+    // then has ONE contributor: the waves of a workgroup own disjoint (n, k) ranges), det_finish adds the arrays in split order
+    float* dWs = d.dW + (size_t)bz * d.dw_split_stride;
+    float* dbs = d.dbias ? d.dbias + (size_t)bz * d.dw_split_stride : nullptr;
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
@@ -1319,7 +1322,7 @@ __device__ __forceinline__ void wgrad_body(const sehip_gemm_desc& d, const int b
                 const int k = k0 + kq * 64 + wk * (64 / WNK) + ki * 16 + (lane & 15);
                 if (k < d.K) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) atomicAdd(&d.dW[(size_t)(n + q) * d.K + k], acc[kq][ni][ki][q]);
+                    for (int q = 0; q < 4; ++q) atomicAdd(&dWs[(size_t)(n + q) * d.K + k], acc[kq][ni][ki][q]);
                 }
             }
     if (do_bias && (lane & 15) == 0) {
@@ -1327,7 +1330,7 @@ __device__ __forceinline__ void wgrad_body(const sehip_gemm_desc& d, const int b
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                atomicAdd(&d.dbias[n0 + wn * (BNW / WNN) + ni * 16 + 4 * (lane >> 4) + q], accb[ni][q]);
+                atomicAdd(&dbs[n0 + wn * (BNW / WNN) + ni * 16 + 4 * (lane >> 4) + q], accb[ni][q]);
     }
 }
 
@@ -1799,6 +1802,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
         __syncthreads();
     }
 
+    float* dWs = d.dW + (size_t)split * d.dw_split_stride;        // (deterministic schedule: one array per m-split, see wgrad_body)
+    float* dbs = d.dbias ? d.dbias + (size_t)split * d.dw_split_stride : nullptr;
     // D rows = n (4*(lane>>4)+u), cols = channel (lane&15)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -1807,18 +1812,57 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d
             const int n = n0 + 32 * nh + ni * 16 + 4 * (lane >> 4);
             const int k = it * Ctot + cc * 64 + 16 * w + (lane & 15);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][it][u]);
+            for (int u = 0; u < 4; ++u) atomicAdd(&dWs[(size_t)(n + u) * d.K + k], acc[ni][it][u]);
         }
     if (do_bias && (lane & 15) == 0) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) atomicAdd(&d.dbias[n0 + 32 * nh + ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
+            for (int u = 0; u < 4; ++u) atomicAdd(&dbs[n0 + 32 * nh + ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
     }
 #undef CW_FETCH
 }
 
-static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
+// ---- deterministic schedule of the atomic-flush weight-gradient kernels (sehip_set_deterministic) -------------------------------
+// det_begin: a private zeroed [Npad K + Npad] array per m-split (the kernel adds to d.dW + split * dw_split_stride); det_finish: the
+// arrays are added into the caller's dW / dbias in split order by ONE thread per entry.  Returns false (error set) when no scratch
+// can be had (inside a stream capture).
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ parts, int nparts, size_t stride, size_t nw, int nb,
+                                                         float* __restrict__ dW, float* __restrict__ dbias) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nw + (size_t)nb) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += parts[(size_t)p * stride + i];
+    if (i < nw) dW[i] += s; else dbias[i - nw] += s;
+}
+static bool det_begin(const sehip_gemm_desc& d, int splits, hipStream_t st, sehip_gemm_desc& out) {
+    out = d;
+    if (!sehip_deterministic()) return true;
+    const size_t stride = (size_t)d.Npad * d.K + d.Npad;
+    float* sc = sehip_wgrad_scratch(st, (size_t)splits * stride * sizeof(float));
+    if (!sc) {
+        sehip_set_error(-2, "wgrad: the deterministic schedule needs its partial arrays (not available inside a stream capture)");
+        return false;
+    }
+    if (hipMemsetAsync(sc, 0, (size_t)splits * stride * sizeof(float), st) != hipSuccess) {
+        sehip_set_error(-2, "wgrad: clearing the deterministic partial arrays failed");
+        return false;
+    }
+    out.dW = sc;
+    out.dbias = d.dbias ? sc + (size_t)d.Npad * d.K : nullptr;
+    out.dw_split_stride = (int64_t)stride;
+    return true;
+}
+static void det_finish(const sehip_gemm_desc& d, const sehip_gemm_desc& used, int splits, hipStream_t st) {
+    if (!used.dw_split_stride) return;
+    const size_t nw = (size_t)d.Npad * d.K;
+    const int nb = d.dbias ? d.Npad : 0;
+    det_reduce_kernel<<<(unsigned)((nw + nb + 255) / 256), 256, 0, st>>>(used.dW, splits, (size_t)used.dw_split_stride, nw, nb, d.dW, d.dbias);
+}
+
+static int try_conv_wgrad(const sehip_gemm_desc& d_in, hipStream_t st) {
+    const sehip_gemm_desc& d = d_in;
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr;
     if (disabled || d.cv_nf <= 0) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
@@ -1852,7 +1896,10 @@ static int try_conv_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
             attr_set = true;                                                                                      \
         }                                                                                                         \
         sehip_note_kernel("conv_wgrad_kernel<%d>", NF_);                                                         \
-        conv_wgrad_kernel<NF_><<<grid, 512, lds, st>>>(d, TB, JB, FR, tiles_per_wg, splits);                              \
+        sehip_gemm_desc dd;                                                                                       \
+        if (!det_begin(d, splits, st, dd)) return -1;                                                             \
+        conv_wgrad_kernel<NF_><<<grid, 512, lds, st>>>(dd, TB, JB, FR, tiles_per_wg, splits);                             \
+        det_finish(d, dd, splits, st);                                                                            \
         return 1;                                                                                                 \
     }
     switch (d.cv_nf) {
@@ -2288,6 +2335,8 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
         }
         __syncthreads();
     }
+    float* dWs = d.dW + (size_t)blockIdx.x * d.dw_split_stride;   // (deterministic schedule: one array per workgroup = m-split)
+    float* dbs = d.dbias ? d.dbias + (size_t)blockIdx.x * d.dw_split_stride : nullptr;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -2296,13 +2345,13 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const sehip_gemm_
             const int n = ni * 16 + 4 * (lane >> 4);
             const int k = 16 * (w + 4 * i) + (lane & 15);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) atomicAdd(&d.dW[(size_t)(n + u) * d.K + k], acc[ni][i][u]);
+            for (int u = 0; u < 4; ++u) atomicAdd(&dWs[(size_t)(n + u) * d.K + k], acc[ni][i][u]);
         }
     if (do_bias && (lane & 15) == 0) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) atomicAdd(&d.dbias[ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
+            for (int u = 0; u < 4; ++u) atomicAdd(&dbs[ni * 16 + 4 * (lane >> 4) + u], accb[ni][u]);
     }
 #undef SW_FETCH
 }
@@ -2317,7 +2366,10 @@ static int launch_small_wgrad(const sehip_gemm_desc& d, int TB, int JB, int FR, 
         attr_set = true;
     }
     sehip_note_kernel("conv_small_wgrad_kernel<%d, %d, %d>", BN, KPW, NPC);
-    conv_small_wgrad_kernel<BN, KPW, NPC><<<grid, 256, lds, st>>>(d, TB, JB, FR, tiles_per_wg);
+    sehip_gemm_desc dd;
+    if (!det_begin(d, grid, st, dd)) return -1;
+    conv_small_wgrad_kernel<BN, KPW, NPC><<<grid, 256, lds, st>>>(dd, TB, JB, FR, tiles_per_wg);
+    det_finish(d, dd, grid, st);
     return 1;
 }
 
@@ -2712,23 +2764,28 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("wgrad(narrow)");
         return 0;
     }
-    if (sehip_try_conv_wgrad_v3(*d, st)) {
+    const bool det = sehip_deterministic() != 0;
+    // (deterministic schedule: conv_wgrad_v3's bias sums and conv_wgrad2 / dense_wgrad flush with plain atomics: those products take
+    //  the kernels below, which keep one array per m-split)
+    if (!det && sehip_try_conv_wgrad_v3(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv v3)");
         return 0;
     }
-    if (try_conv_wgrad(*d, st)) {
+    if (int r = try_conv_wgrad(*d, st)) {
+        if (r < 0) return -2;
         SEHIP_CHECK_LAUNCH("wgrad(conv)");
         return 0;
     }
-    if (try_conv_wgrad2(*d, st)) {
+    if (!det && try_conv_wgrad2(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv2)");
         return 0;
     }
-    if (try_conv_small_wgrad(*d, st)) {
+    if (int r = try_conv_small_wgrad(*d, st)) {
+        if (r < 0) return -2;
         SEHIP_CHECK_LAUNCH("wgrad(conv-small)");
         return 0;
     }
-    if (d->dense_rows && sehip_try_dense_wgrad(*d, st)) {
+    if (!det && d->dense_rows && sehip_try_dense_wgrad(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(dense)");
         return 0;
     }
@@ -2759,6 +2816,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     const int splits = cdiv(d->M, mpb);
     dim3 grid(ntiles, ktiles, splits);
     sehip_note_kernel("wgrad_kernel<%d, %d, %d, %d>", bnw, bnw >= 64 ? 2 : 1, bnw >= 64 ? 2 : 4, kq);
+    sehip_gemm_desc dd_;
+    if (!det_begin(*d, splits, st, dd_)) return -2;
+    const sehip_gemm_desc* dorig = d;
+    d = &dd_;
     if (kq == 2) {
         if (bnw == 64) wgrad_kernel<64, 2, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
         else if (bnw == 128) wgrad_kernel<128, 2, 2, 2><<<grid, 256, 0, st>>>(*d, (int)mpb);
@@ -2774,6 +2835,7 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
         else if (bnw == 64) wgrad_kernel<64, 2, 2, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
         else wgrad_kernel<128, 2, 2, 1><<<grid, 256, 0, st>>>(*d, (int)mpb);
     }
+    det_finish(*dorig, dd_, splits, st);
     SEHIP_CHECK_LAUNCH("wgrad");
     return 0;
 }
@@ -2814,6 +2876,7 @@ extern "C" int sehip_wgrad_group_prepare(const sehip_gemm_desc* descs, int n, vo
 }
 
 extern "C" int sehip_wgrad_group(const void* dev_buf, int n, int total_blocks, void* stream) {
+    SEHIP_REQUIRE(!sehip_deterministic(), "wgrad_group: not part of the deterministic schedule (launch the products one by one: sehip_wgrad)");
     SEHIP_REQUIRE(dev_buf && n >= 1 && n <= SEHIP_WGRAD_GROUP_MAX && total_blocks > 0, "wgrad_group: bad arguments");
     sehip_note_kernel("wgrad_group_kernel<128, 2, 2>");
     wgrad_group_kernel<128, 2, 2><<<total_blocks, 256, 0, (hipStream_t)stream>>>(

@@ -304,6 +304,7 @@ extern "C" int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, 
     SEHIP_REQUIRE(e == hipSuccess, "pointwise_loss_fwd: memset failed: %s", hipGetErrorString(e));
     int grid = cdiv(n, 256 * 16);
     if (grid > 1024) grid = 1024;
+    if (sehip_deterministic()) grid = 1;
     pointwise_loss_fwd_kernel<<<grid, 256, 0, st>>>(x, y, n, mode, acc);
     pointwise_loss_finalize_kernel<<<1, 1, 0, st>>>(acc, n, loss);
     SEHIP_CHECK_LAUNCH("pointwise_loss_fwd");

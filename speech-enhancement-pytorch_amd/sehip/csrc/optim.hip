@@ -149,6 +149,7 @@ static int grad_sumsq_impl(const float* grads, long n, double* sumsq_out, bool c
     SEHIP_REQUIRE((((uintptr_t)grads) & 15) == 0, "grad_sumsq: gradient buffer must be 16-byte aligned");
     int grid = cdiv(n, 256 * 16);
     if (grid > 1024) grid = 1024;
+    if (sehip_deterministic()) grid = 1;          // one workgroup: one contribution, a fixed order of additions
     sumsq_kernel<<<grid, 256, 0, st>>>(grads, n, sumsq_out);
     SEHIP_CHECK_LAUNCH("grad_sumsq");
     return 0;
@@ -227,8 +228,8 @@ static int grad_metric_impl(const float* grads, const long* offsets, int ntensor
         SEHIP_REQUIRE(e == hipSuccess, "grad_metric: memset failed: %s", hipGetErrorString(e));
     }
     static const bool chunked = getenv("SEHIP_TENSOR_SUMS_CHUNKED") != nullptr;
-    if (chunked) tensor_sums_kernel<<<dim3(ntensors, cdiv(max_tensor, TS_CHUNK)), 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
-    else tensor_sums_flat_kernel<<<1024, 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
+    if (chunked && !sehip_deterministic()) tensor_sums_kernel<<<dim3(ntensors, cdiv(max_tensor, TS_CHUNK)), 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
+    else tensor_sums_flat_kernel<<<sehip_deterministic() ? 1 : 1024, 256, 0, st>>>(grads, offsets, ntensors, tensor_sums);
     grad_metric_kernel<<<1, 64, 0, st>>>(tensor_sums, ntensors, sumsq, metric);
     SEHIP_CHECK_LAUNCH("grad_metric");
     return 0;

@@ -19,12 +19,13 @@ from .flat import FlatModule, _Node
 _STATIC_CACHE = {}
 
 
-def _static_for(cfg):
+def _static_for(cfg, deterministic=False):
     # (the experiment switches that DCCRNStatic reads when it is built are part of the key)
     switches = tuple(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_STATS64", "SEHIP_NO_FUSE_STATS32"))
-    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, switches)
+    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, switches,
+           bool(deterministic))
     if key not in _STATIC_CACHE:
-        _STATIC_CACHE[key] = plan.DCCRNStatic(cfg)
+        _STATIC_CACHE[key] = plan.DCCRNStatic(cfg, deterministic=deterministic)
     return _STATIC_CACHE[key]
 
 
@@ -110,6 +111,23 @@ class DCCRN(FlatModule):
             self._tables = plan.DeviceTables(self.static, dev)
         return self._lru_get((batch, nsample), self._ws_cap,
                              lambda: plan.DCCRNWorkspace(self.static, self._tables, batch, nsample, dev))
+
+    def set_deterministic(self, on=True):
+        """The reference's `solver.cudnn_deterministic` switch (src/conf/config.yaml:130, src/utils.py:108-111) for this model: the plan
+        is rebuilt without the BatchNorm sums of the convolution epilogues (fp32 atomics) and without grouped weight-gradient launches;
+        the library side (per-split partial arrays for every weight gradient, one-workgroup norms) is the process-wide
+        sehip_set_deterministic, which sehip.utils.prepare_device / the Solver switch on.  Same parameters, same checkpoints; every
+        workspace is rebuilt.  Two runs of the same steps are then bit-identical (tests/test_gpu_deterministic.py)."""
+        on = bool(on)
+        if on == self.static.deterministic:
+            return self
+        self.static = _static_for(self.cfg, deterministic=on)
+        self._tables = None
+        for ws in list(self._ws.values()):
+            ws.close()
+        self._ws.clear()
+        self._last_ws = None
+        return self
 
     def step_guard(self):
         """Device word the fused optimizer checks (sehip_opt_begin_g / sehip_opt_step_g): the sticky hand-off time-out word of the fused

@@ -44,7 +44,8 @@ class CGemmDesc(C.Structure):
                 ("Npad", C.c_int32), ("K", C.c_int32), ("TT", C.c_int32), ("J", C.c_int32), ("fmul", C.c_int32),
                 ("tmul", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
                 ("res", C.c_void_p), ("stats", C.c_void_p), ("stats_cr", C.c_int32), ("cv2_nkt", C.c_int32), ("cv2_nf", C.c_int32),
-                ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32), ("wg_hint", C.c_int32), ("dense_rows", C.c_int32)]
+                ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32), ("wg_hint", C.c_int32), ("dense_rows", C.c_int32),
+                ("dw_split_stride", C.c_int64)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient
@@ -377,8 +378,9 @@ class DCCRNStatic:
     def _maybe_fuse_stats(self, pre, names, co, cins, J):
         """Forward products that conv_gemm_v2 takes (64-multiple source channels, 128-multiple outputs, J | 128, J <= 64) also
         accumulate the batch statistics of the ComplexBatchNorm behind them: no cbn_stats pass for these layers."""
-        if any(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_PATCH", "SEHIP_NO_CONV_V2")):
-            return      # (the experiment switches that take conv_gemm_v2 away also take its statistics away)
+        if self.deterministic or any(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_PATCH", "SEHIP_NO_CONV_V2")):
+            return      # (the experiment switches that take conv_gemm_v2 away also take its statistics away; the deterministic
+                        #  schedule takes the sums from the separate pass: the epilogues add them with fp32 atomics)
         # (round 3: conv_gemm_v3 also takes the sums of a 64-output layer -- one [32 re | 32 im] tile; only that kernel does, so not
         #  when one of its switches is set)
         v3_only = co == 64 and all(c % 16 == 0 for c in cins) and J in (4, 8, 16, 32) and TILE_WEIGHTS and not os.environ.get("SEHIP_NO_FUSE_STATS64")
@@ -396,7 +398,8 @@ class DCCRNStatic:
             sp.stats_of = pre
         self.fused_stats.add(pre)
 
-    def __init__(self, cfg: DCCRNConfig):
+    def __init__(self, cfg: DCCRNConfig, deterministic=False):
+        self.deterministic = bool(deterministic)
         self.fused_stats = set()
         self.small_stats = {}  # BatchNorm prefix -> forward products of a 32-output layer (fused sums if conv_small2 takes them)
         self.cfg = cfg
@@ -942,7 +945,7 @@ class DCCRNWorkspace:
                 for d in ds:
                     d.stats = None
                     d.stats_cr = 0
-        if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+        if not os.environ.get("SEHIP_NO_WGRAD_GROUP") and not st.deterministic:
             for layers in ((1,), (2,), (2, 1)):
                 self._wgrad_group_handle(self._lstm_wgrad_names(layers))
 
@@ -1041,7 +1044,7 @@ class DCCRNWorkspace:
     def wgrad_group(self, names):
         """The weight gradients of several plain products as ONE launch on the side stream (sehip_wgrad_group): the LSTM
         products are small grids that took ~30 us each back to back."""
-        if os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+        if os.environ.get("SEHIP_NO_WGRAD_GROUP") or self.st.deterministic:
             for nm in names:
                 self.wgrad(nm)
             return

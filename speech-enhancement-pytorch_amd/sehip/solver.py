@@ -122,6 +122,19 @@ class Solver(object):
                 raise SehipError(f"Solver(device='cpu'): model '{config.model.name}' runs on the HIP path only; the CPU "
                                  f"plumbing configuration exists for {plumbing.TORCH_MODELS} (BASELINE config C0)")
         self.is_main = self.rank == 0
+        # src/solver.py:133 hands config.solver.cudnn_deterministic to prepare_device (src/utils.py:108-111; the shipped YAML sets it
+        # True).  Here it selects the fixed-order reductions of libsehip and of the model's plan: two runs of the same steps are
+        # bit-identical.  Built for DCCRN; a model without set_deterministic() keeps its own atomics and says so once.
+        self.deterministic = bool(_cfg(config.solver, "cudnn_deterministic", False)) and device == "gpu"
+        if self.deterministic:
+            from .utils import set_deterministic
+            set_deterministic(True)
+            if hasattr(model, "set_deterministic"):
+                model.set_deterministic(True)
+            else:
+                import warnings
+                warnings.warn(f"solver.cudnn_deterministic: model '{config.model.name}' has no deterministic plan yet (its normalisation "
+                              f"sums use fp32 atomics); the library-level reductions are deterministic, run-to-run bit equality is not guaranteed")
 
         self.optimizer = optimizer
         self.loss_function = loss_function

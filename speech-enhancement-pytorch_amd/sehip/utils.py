@@ -37,8 +37,19 @@ def load_yaml(path, *args, **kwargs):
     return dict2obj(cfg)
 
 
+def set_deterministic(on=True):
+    """Process-wide deterministic reductions of libsehip (sehip_set_deterministic, include/sehip.h): what the reference's
+    `cudnn_deterministic` flag asks of cuDNN (src/utils.py:108-111) asked of this library."""
+    from ._lib import call
+    call("sehip_set_deterministic", 1 if on else 0)
+
+
 def prepare_device(n_gpu, cudnn_deterministic=False):
-    """src/utils.py:92-115: 'cuda:0' when GPUs are visible, else CPU (cudnn flags have no ROCm meaning here)."""
+    """src/utils.py:92-115: 'cuda:0' when GPUs are visible, else CPU.  cudnn_deterministic (src/conf/config.yaml:130 ships True):
+    there is no cuDNN here; the flag selects libsehip's deterministic schedule instead (fixed-order reductions, set_deterministic)."""
     if n_gpu == 0:
         return torch.device("cpu")
+    if cudnn_deterministic:
+        print("Using libsehip's deterministic schedule in the experiment.")
+        set_deterministic(True)
     return torch.device("cuda:0")

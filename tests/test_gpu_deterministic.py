@@ -1,0 +1,68 @@
+"""GPU: the deterministic schedule behind the reference's own switch.  src/conf/config.yaml:130 ships `cudnn_deterministic: True`,
+src/solver.py:133 hands it to prepare_device, src/utils.py:108-111 honours it.  Here the flag selects fixed-order reductions
+(sehip_set_deterministic + DCCRN.set_deterministic): weight gradients through per-split partial arrays added in split order,
+BatchNorm sums from the separate passes instead of the convolution epilogues' atomics, one-workgroup clipping norm / per-tensor sums.
+Asserted: two independent runs of the same three optimizer steps are BIT-identical (losses, logged gradient metric, every parameter,
+Adam moments), at the reduced width and at the headline width; and the deterministic gradients agree with the default schedule's."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def run(tmp_path, deterministic, kernel_num, n, b, steps=3):
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    from sehip.utils import set_deterministic
+    from test_gpu_solver import solver_config, make_batch
+    cfg = solver_config(tmp_path)
+    cfg.model.kernel_num, cfg.model.length = list(kernel_num), n
+    cfg.solver.cudnn_deterministic = deterministic
+    try:
+        torch.manual_seed(cfg.seed)
+        model = distrib.get_model(cfg.model)
+        opt = distrib.get_optimizer(cfg.optim, model)
+        solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+        assert solver.deterministic == deterministic and model.static.deterministic == deterministic
+        out = []
+        for s in range(steps):
+            noisy, clean = make_batch(40 + s, b, n)
+            loss, metric = solver.train_step(*solver._prepare_batch(noisy, clean))
+            out.append((float(loss), float(metric[0]), float(metric[1])))
+        torch.cuda.synchronize()
+        grads = model.flat_grads.detach().cpu().clone()
+        return out, model.flat_params.detach().cpu().clone(), opt._m.cpu().clone(), opt._v.cpu().clone(), grads
+    finally:
+        set_deterministic(False)
+
+
+@pytest.mark.parametrize("kernel_num,n,b", [((16, 16, 32, 32, 64, 64), 4000, 3), ((16, 32, 64, 128, 256, 256), 16000, 4)])
+def test_two_deterministic_runs_are_bit_identical(tmp_path, kernel_num, n, b):
+    a = run(tmp_path, True, kernel_num, n, b)
+    c = run(tmp_path, True, kernel_num, n, b)
+    assert a[0] == c[0], (a[0], c[0])                      # losses and both gradient metrics, every step
+    for x, y, what in zip(a[1:], c[1:], ("parameters", "exp_avg", "exp_avg_sq", "gradients")):
+        assert torch.equal(x, y), what
+    # and it is the same computation as the default schedule: one step's gradients agree to summation-order noise
+    d1 = run(tmp_path, True, kernel_num, n, b, steps=1)
+    d0 = run(tmp_path, False, kernel_num, n, b, steps=1)
+    assert abs(d1[0][0][0] - d0[0][0][0]) < 2e-3
+    rel = float((d1[4] - d0[4]).norm() / d0[4].norm())
+    print(f"deterministic vs default schedule, one step: gradient rel {rel:.2e}")
+    assert rel < 2e-3
+
+
+def test_the_library_flag_round_trips_and_refuses_grouped_launches():
+    from sehip import _lib
+    from sehip.utils import set_deterministic
+    lib = _lib.lib()
+    assert lib.sehip_get_deterministic() == 0
+    set_deterministic(True)
+    try:
+        assert lib.sehip_get_deterministic() == 1
+        buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+        assert lib.sehip_wgrad_group(buf.data_ptr(), 1, 1, None) != 0 and b"deterministic" in lib.sehip_last_error()
+    finally:
+        set_deterministic(False)
+    assert lib.sehip_get_deterministic() == 0
