@@ -1842,7 +1842,7 @@ static bool det_begin(const sehip_gemm_desc& d, int splits, hipStream_t st, sehi
     const size_t stride = (size_t)d.Npad * d.K + d.Npad;
     float* sc = sehip_wgrad_scratch(st, (size_t)splits * stride * sizeof(float));
     if (!sc) {
-        sehip_set_error(-2, "wgrad: the deterministic schedule needs its partial arrays (not available inside a stream capture)");
+        sehip_set_error(-2, "wgrad: the deterministic schedule could not get its partial arrays (allocation failed, or inside a stream capture)");
         return false;
     }
     if (hipMemsetAsync(sc, 0, (size_t)splits * stride * sizeof(float), st) != hipSuccess) {

@@ -280,7 +280,7 @@ static void w3_reduce_launch(const float* parts, int nparts, size_t n, float* dW
 // Scratch for the splits' partial arrays: one per stream that launches weight gradients (launches on one stream are ordered; two
 // streams must not share).  Allocated on first use, never inside a stream capture (the caller then takes the atomic flush).
 struct W3Scratch { hipStream_t st; float* p; size_t bytes; };
-static W3Scratch w3_pool[4];
+static W3Scratch w3_pool[16];
 static float* w3_scratch_for(hipStream_t st, size_t bytes) {
     static const bool off = getenv("SEHIP_W3_ATOMIC_FLUSH") != nullptr;
     if (off) return nullptr;
@@ -293,7 +293,16 @@ static float* w3_scratch_for(hipStream_t st, size_t bytes) {
     if (!e)
         for (auto& q : w3_pool)
             if (!q.p) { e = &q; break; }
-    if (!e) return nullptr;
+    if (!e) {
+        // every slot belongs to some stream (workspaces come and go, each with a weight-gradient stream of its own): give all of
+        // them back once the device is idle and start over -- rare, outside any capture
+        if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        for (auto& q : w3_pool) {
+            if (q.p) (void)hipFree(q.p);
+            q.p = nullptr; q.bytes = 0; q.st = nullptr;
+        }
+        e = &w3_pool[0];
+    }
     if (e->p) {                       // grow: the old array may still be in use on the stream
         if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
         (void)hipFree(e->p);
