@@ -505,20 +505,27 @@ static size_t c3_lds_bytes() {
     const size_t epi = 2 * NWN * (16 * TM * (16 * TN + 8) * 2) + 64;
     return (size_t)G::LDS_MAIN > epi ? (size_t)G::LDS_MAIN : epi;
 }
+// The dynamic-LDS limit of a kernel is a PER-DEVICE attribute: set once per (instantiation, device), the result checked (a
+// process-wide flag set it on whichever device was current first, and a failure surfaced as an unexplained launch error).
 template <int NF, int FM, int J, int TM, int TN, int NWN = 2>
-static void c3_set_attr() {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (NWN == 2 ? 80 : 160) * 1024);
-        attr_set = true;
+static bool c3_set_attr() {
+    static unsigned char state[64] = {};      // per device: 0 = not tried, 1 = set, 2 = failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (NWN == 2 ? 80 : 160) * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
     }
+    return state[dev] == 1;
 }
 template <int NF, int FM, int J, int TM, int TN, int NWN = 2>
-static void c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
-    c3_set_attr<NF, FM, J, TM, TN, NWN>();
+static int c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
+    if (!c3_set_attr<NF, FM, J, TM, TN, NWN>()) return 0;      // sehip_gemm then reports that the tile-ordered weights found no kernel
     sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d, %d, %d, 0>", NF, FM, J, TM, TN, NWN);
     conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN><<<grid, 128 * NWN, c3_lds_bytes<NF, FM, J, TM, TN, NWN>(), st>>>(d, B, c3_order());
+    return 1;
 }
 template <int J, int ABL>
 static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
@@ -552,19 +559,15 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     static const int w8 = getenv("SEHIP_C3_W8") ? atoi(getenv("SEHIP_C3_W8")) : 0;
     if (w8 && NF == 5 && (d.Npad & 255) == 0 && (d.J == 4 || d.J == 8)) {
         const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * (d.Npad / 256);
-        if (d.J == 4) c3_launch<5, 2, 4, 8, 4, 4>(d, B, grid, st); else c3_launch<5, 2, 8, 8, 4, 4>(d, B, grid, st);
-        return 1;
+        return d.J == 4 ? c3_launch<5, 2, 4, 8, 4, 4>(d, B, grid, st) : c3_launch<5, 2, 8, 8, 4, 4>(d, B, grid, st);
     }
     const int tm = c3_pick_tm(vframes, d.J, ntn);
 #define C3_CASE(J_)                                                                                       \
     case J_: {                                                                                            \
         const int TB = 32 * tm / J_, grid = (int)((vframes + TB - 1) / TB) * ntn;                         \
-        if (BN == 128) {                                                                                  \
-            if (tm == 8) c3_launch<NF, FM, J_, 8, 4>(d, B, grid, st); else c3_launch<NF, FM, J_, 6, 4>(d, B, grid, st); \
-        } else {                                                                                          \
-            if (tm == 8) c3_launch<NF, FM, J_, 8, 2>(d, B, grid, st); else c3_launch<NF, FM, J_, 6, 2>(d, B, grid, st); \
-        }                                                                                                 \
-        return 1;                                                                                         \
+        if (BN == 128)                                                                                    \
+            return tm == 8 ? c3_launch<NF, FM, J_, 8, 4>(d, B, grid, st) : c3_launch<NF, FM, J_, 6, 4>(d, B, grid, st); \
+        return tm == 8 ? c3_launch<NF, FM, J_, 8, 2>(d, B, grid, st) : c3_launch<NF, FM, J_, 6, 2>(d, B, grid, st);     \
     }
     switch (d.J) {
         C3_CASE(4) C3_CASE(8) C3_CASE(16) C3_CASE(32)

@@ -1564,8 +1564,9 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("gemm(conv)");
         return 0;
     }
-    SEHIP_REQUIRE(!d->w_tiled, "gemm: W is in conv_gemm_v3's tile order (w_tiled) but the product does not qualify for that kernel "
-                               "(Npad=%d, J=%d, cv_nf=%d, fmul=%d)", d->Npad, d->J, d->cv_nf, d->fmul);
+    SEHIP_REQUIRE(!d->w_tiled, "gemm: W is in conv_gemm_v3's tile order (w_tiled) but that kernel did not take the product: it does not "
+                               "qualify (Npad=%d, J=%d, cv_nf=%d, fmul=%d), or the kernel's dynamic-LDS limit could not be raised on "
+                               "the current device", d->Npad, d->J, d->cv_nf, d->fmul);
     if (try_conv_small(*d, nullptr, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv-small)");
         return 0;

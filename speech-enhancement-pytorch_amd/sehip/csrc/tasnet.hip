@@ -1226,7 +1226,9 @@ extern "C" int sehip_ctn_encoder_fwd(const float* wav, const float* U, const flo
     const size_t lds = (size_t)N * ac * L * sizeof(float);
     SEHIP_REQUIRE(lds <= 64 * 1024, "ctn_encoder_fwd: basis of %zu bytes does not fit the LDS budget", lds);
     static const bool no_mfma = getenv("SEHIP_CTN_NO_MFMA_ENCODER") != nullptr;
-    if (!no_mfma && N == 128 && ac == 1 && L <= 64) {
+    // (the MFMA kernel reads gamma, beta and the rows of U as float4: 16-byte aligned pointers and L % 4 == 0, else the scalar kernel)
+    const bool aligned16 = ((((uintptr_t)U) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0 && (L & 3) == 0;
+    if (!no_mfma && N == 128 && ac == 1 && L <= 64 && aligned16) {
         static const int cap = getenv("SEHIP_CTN_ENC_WGS") ? atoi(getenv("SEHIP_CTN_ENC_WGS")) : 512;
         long gm = (((long)M * K + 15) / 16 + 3) / 4;
         if (gm > cap) gm = cap;
