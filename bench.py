@@ -316,6 +316,10 @@ def activation_bytes(workload, ws, batch):
         nb = len(ws.st.blocks)
         per_frame = cfg.N * 4 + cfg.N * 2 + cfg.B * 2 + nb * (4 * cfg.H + cfg.B) * 2 + cfg.C * cfg.N * 2
         return M * K * per_frame + 2 * M * cfg.C * ws.T * 4
+    if workload == "dcunet":     # packed input spectrum, every pre-BatchNorm tensor and every BatchNorm + LeakyReLU output (bf16), the
+        #                           fp32 input / output spectra [B, 1, 257, 257, 2]
+        fwd = [k for k in ws.bufs if k == "x0" or k.startswith(("ye", "ze", "yd", "zd"))]
+        return sum(ws.bufs[k].t.numel() * ws.bufs[k].t.element_size() for k in fwd) + 2 * ws.out.numel() * 4
     if workload == "demucs":     # forward buffers = every workspace buffer that is not the gradient twin ("d" + name) of another
         names = set(ws.bufs)
         fwd = [k for k in names if not (k.rsplit(".", 1)[-1].startswith("d") and
@@ -426,6 +430,66 @@ def build_for_profile(batch=BATCH):
     return solver, model, mixture, sources
 
 
+def measure_traffic(workload, batch, timeout_s=420):
+    """HBM bytes per kernel class of THIS build, measured in this run: two child processes of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only beside them, as MI355X_MICROARCH.md's HBM
+    section prescribes) over 1 warm-up + 2 train steps.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half of the
+    bytes of wide (16 B per lane) coalesced reads, which is what these kernels issue: the read side is doubled.  Returns
+    {class name: {"launches_per_step", "hbm_bytes_per_launch"}, "_whole_step": {...}} or None (no rocprofv3 / a pass failed)."""
+    import collections, csv, glob, re, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    steps = 3
+    tmp = tempfile.mkdtemp(prefix="sehip_pmc_", dir="/tmp")
+    acc = {"fetch": collections.defaultdict(list), "write": collections.defaultdict(list)}
+    try:
+        for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            out = os.path.join(tmp, kind)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--batch", str(batch), "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-roofline", "--no-parity", "--no-traffic"]
+            env = {**os.environ, "TMPDIR": "/tmp"}
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                note(f"traffic pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}")
+                return None
+            for row in csv.DictReader(open(files[0])):
+                m = re.match(r"(?:void )?([\w:]+(?:<[^(]*>)?)", row["Kernel_Name"])
+                acc[kind][m.group(1) if m else row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    except Exception as e:  # timeout etc.: report, never fake
+        note(f"traffic measurement failed: {type(e).__name__}: {e}")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res, lib = {}, 0.0
+    for k in sorted(set(acc["fetch"]) | set(acc["write"])):
+        f, w = acc["fetch"].get(k, []), acc["write"].get(k, [])
+        fk, wk = (sum(f) / len(f) if f else 0.0), (sum(w) / len(w) if w else 0.0)
+        res[k] = {"launches_per_step": round(max(len(f), len(w)) / steps, 2), "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+        if not k.startswith(("at::", "__amd")):      # the library's own kernels (torch fills / copies of the allocations excluded)
+            lib += (2.0 * sum(f) + sum(w)) * 1024.0
+    res["_whole_step"] = {"library_kernels_hbm_bytes_per_step": lib / steps, "steps_profiled": steps}
+    return res
+
+
+def class_traffic(tj, kernel):
+    """bytes per launch of a kernel (class) from a traffic table: exact name, or the launch-weighted mean over the members of a class
+    written as 'name<a, b, *>'"""
+    if tj is None:
+        return None
+    v = tj.get(kernel, {}).get("hbm_bytes_per_launch") if isinstance(tj.get(kernel), dict) else None
+    if v is None and kernel.endswith("*>"):
+        pre = kernel[:-2]
+        mem = [x for k, x in tj.items() if k.startswith(pre) and isinstance(x, dict) and "hbm_bytes_per_launch" in x]
+        nl = sum(x["launches_per_step"] for x in mem)
+        if nl > 0:
+            v = sum(x["hbm_bytes_per_launch"] * x["launches_per_step"] for x in mem) / nl
+    return v
+
+
 class NeedsDevices(RuntimeError):
     """`--gpus N` asked for more devices than this node shows."""
 
@@ -481,6 +545,8 @@ def main():
                     "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--h2d-overlap", action="store_true", help="as --h2d, but the NEXT batch is copied on a stream of its own while the "
                     "step runs (two device buffers): what sehip.solver.DevicePrefetcher does for the Solver's epoch loop")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, "
+                    "~1 min); the line then carries the tracked profiles/ figure with the commit it was taken at")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle parity block (it needs the CPU baseline leg)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="host threads of the CPU baseline (0 = min(cores of the affinity mask, 32): on the 256-core host of the GPU "
@@ -636,41 +702,45 @@ def main():
         top = rows[0]
         total_ms = sum(r["ms"] for r in rows)
         total_gf = sum(r["gflop"] for r in rows)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")  # PMC passes over the real step (FETCH_SIZE / WRITE_SIZE), tools/collect_round.sh
-        for older in ("r2_traffic.json", "r1_traffic.json"):
-            if not os.path.exists(tpath):
-                tpath = os.path.join(ROOT, "profiles", older)
-        if dcu or ctn or dmx:
-            tpath = os.path.join(ROOT, "profiles", f"r3_traffic_{args.workload}.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj.get(top["kernel"], {}).get("hbm_bytes_per_launch")
-            if traffic is None and top["kernel"].endswith("*>"):      # a class of instantiations: launch-weighted mean over its members
-                pre = top["kernel"][:-2]
-                mem = [v for k, v in tj.items() if k.startswith(pre) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
-                nl = sum(v["launches_per_step"] for v in mem)
-                if nl > 0:
-                    traffic = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in mem) / nl
+        # roofline.traffic: measured in THIS run when rocprofv3 is there (a tracked file would silently go stale);
+        # otherwise the newest tracked table of this workload, with the commit it was taken at in the line
+        traffic, traffic_src, tj = None, None, None
+        if not args.no_traffic and world == 1:
+            note("PMC traffic passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, child processes)")
+            tj = measure_traffic(args.workload, args.batch)
+            if tj is not None:
+                traffic_src = {"how": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 1 + 2 train steps, "
+                                      "class mean per launch, FETCH_SIZE doubled (gfx950 wide-read correction)",
+                               "whole_step_bytes": tj["_whole_step"]["library_kernels_hbm_bytes_per_step"]}
+        if tj is None:
+            suffix = "" if args.workload == "dccrn" else f"_{args.workload}"
+            for rnd in ("r4", "r3", "r2", "r1"):
+                tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic{suffix}.json")
+                if os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    traffic_src = {"how": "tracked file, NOT measured in this run", "file": os.path.relpath(tpath, ROOT),
+                                   "commit": tj.get("_whole_step", {}).get("commit")}
+                    break
+        traffic = class_traffic(tj, top["kernel"])
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                           "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                            "launches_per_step": top["launches"], "avg_launch_us": top["avg_us"],
                            "gflop_per_launch": top["gflop"] / top["launches"],
                            "all_product_kernels": {"ms_per_step": total_ms, "tflops": total_gf / total_ms,
                                                    "frac": total_gf / total_ms / PEAK_BF16_TFLOPS}}
-        if ctn or dmx:
+        if ctn or dmx or dcu:
             # second entry, HBM: the whole step against the compulsory-traffic model (these two networks are bound by their
             # activation streams: normalisation / activation / depthwise kernels, not by the products)
             A = activation_bytes(args.workload, ws, args.batch)
             out["roofline_hbm"] = {"bound": "hbm", "scope": "whole train step", "achieved": 5.5 * A / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                                   "unit": "GB/s", "frac": 5.5 * A / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                   "unit": "GB/s", "frac": 5.5 * A / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "traffic": (tj or {}).get("_whole_step", {}).get("library_kernels_hbm_bytes_per_step"),
                                    "algorithmic_bytes_per_step": 5.5 * A,
                                    "model": "5.5 x the bytes of the layer-boundary activations of one forward pass in their stored "
                                             "types (SURVEY section 8d: forward write + read, backward read-saved + write-grad + read-grad)"}
         if not dcu and not ctn and not dmx:
             out["roofline_hbm"] = cbn_roofline(ws, model)   # second entry: the largest HBM-bound class of the step
-            if os.path.exists(tpath):   # PMC bytes of the same passes over the real step (finalize launches excluded)
-                tj = json.load(open(tpath))
+            if tj is not None:   # PMC bytes of the same passes over the real step (finalize launches excluded)
                 tb = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for k, v in tj.items()
                          if k.startswith("cbn_") and "finalize" not in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v)
                 out["roofline_hbm"]["traffic"] = tb or None

@@ -147,10 +147,10 @@ def test_full_width_model_vs_oracle():
     # alone moves the fp32 oracle's gradients by the same 5 %)
     leaves_s = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     ref_s = CT.convtasnet_forward(leaves_s, mix, audio_channels=1, sim=CT.Bf16Sim)
-    glob_s, worst_s = compare(got, torch.autograd.grad((ref_s * G).sum(), [leaves_s[k] for k in names]), "fixed upstream gradient, bf16-storage oracle")
+    g_sim = torch.autograd.grad((ref_s * G).sum(), [leaves_s[k] for k in names])
+    glob_s, worst_s = compare(got, g_sim, "fixed upstream gradient, bf16-storage oracle")
     print(f"ConvTasNet full width: output vs bf16-storage oracle {rel_err(est.detach().cpu(), ref_s.detach()):.3e}")
     g_plain = torch.autograd.grad((ref * G).sum(), [leaves[k] for k in names], retain_graph=True)
-    g_sim = torch.autograd.grad((ref_s * G).sum(), [leaves_s[k] for k in names], retain_graph=True)
     sim_dev = (sum(float(((a.double() - b_.double()) ** 2).sum()) for a, b_ in zip(g_sim, g_plain)) /
                sum(float((b_.double() ** 2).sum()) for b_ in g_plain)) ** 0.5
     print(f"ConvTasNet full width: bf16-storage oracle vs fp32 oracle gradients {sim_dev:.3e}")
