@@ -275,9 +275,6 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
         // behind the recurrent MFMAs and runs under the gate arithmetic below (issued after the stores it delayed the barrier by its
         // whole 8 x 32 cycles: 154 us per launch instead of ~125)
         ih(t + 1, nxt);
-        // ... and so does the staging of x2(t + 2) (tag check, two adds, one LDS write, two loads requested): vector / memory issue
-        // slots that are free while the sixteen MFMAs above run
-        stage(t + 2, qa, qb);
         const float gi = l2_sigmoid(l2_pick(acc[0], rs));
         const float gf = l2_sigmoid(l2_pick(acc[1], rs));
         const float gg = l2_tanh(l2_pick(acc[2], rs));
@@ -289,6 +286,9 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
         const size_t rec = (rbase + t) * 256 + threadIdx.x;
         c2out[rec] = c;
         *reinterpret_cast<uint2*>(gates2 + rec * 4) = make_uint2(pack_bf2(gi, gf), pack_bf2(gg, go));
+        // the staging of x2(t + 2) (in front of the gate arithmetic instead, "under the MFMAs", the launch took 154 us instead of 143:
+        // its tag check and LDS write then sit between the MFMA issue and the first use of their results)
+        stage(t + 2, qa, qb);
 #pragma unroll
         for (int g = 0; g < 4; ++g) accih[g] = nxt[g];
         l2_lds_barrier();
