@@ -191,6 +191,32 @@ def allreduce_step_guard(guard):
     return guard
 
 
+def allreduce_step_guard_async(guard, stream=None):
+    """The same MAX all-reduce enqueued behind `stream` (a torch.cuda.Stream; None = current), returning a work handle whose .wait()
+    makes the CURRENT stream wait for it: for models whose guard word is final before the backward pass ends (DCCRN: once the fused
+    LSTM backward launch is enqueued) the exchange then hides under the rest of the pass instead of sitting between the last
+    gradient and the optimizer."""
+    class _Done:
+        def wait(self_inner):
+            pass
+    if guard is None or not (dist.is_initialized() and dist.get_world_size() > 1):
+        return _Done()
+    if _direct is not None and guard.is_cuda:
+        st = stream if stream is not None else torch.cuda.current_stream()
+        _direct.all_reduce_max_i32_(guard, st)
+        ev = torch.cuda.Event()
+        ev.record(st)
+
+        class _Work:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_event(ev)
+        return _Work()
+    if stream is not None and guard.is_cuda:
+        with torch.cuda.stream(stream):
+            return dist.all_reduce(guard, op=dist.ReduceOp.MAX, async_op=True)
+    return dist.all_reduce(guard, op=dist.ReduceOp.MAX, async_op=True)
+
+
 def allreduce_range_async(flat_grads, lo, hi, stream=None):
     """all-reduce(sum) of flat_grads[lo:hi], enqueued behind `stream` (a torch.cuda.Stream, or None for the current one);
     returns the work handle (.wait() makes the CURRENT stream wait for it).  Used by the Solver to start the exchange of

@@ -129,6 +129,8 @@ class DCCRN(FlatModule):
         self._last_ws = None
         return self
 
+    step_guard_early = True      # the guard word is final once the fused LSTM backward launch is enqueued: before the first gradient range is handed over
+
     def step_guard(self):
         """Device word the fused optimizer checks (sehip_opt_begin_g / sehip_opt_step_g): the sticky hand-off time-out word of the fused
         two-layer LSTM kernels of the workspace the last forward ran in (None when that workspace runs the unfused launches)."""

@@ -292,6 +292,16 @@ class Solver(object):
                 return self._train_step(mixture, sources)
         return self._train_step(mixture, sources)
 
+    def _unit_grad(self, loss):
+        """d loss / d loss = 1 as a CACHED device tensor: `loss.backward()` alone makes autograd fill a fresh ones_like(loss) every step --
+        a 7-us kernel plus a boundary on the step's dependent chain for one float."""
+        if os.environ.get("SEHIP_NO_UNIT_GRAD"):
+            return None
+        g = getattr(self, "_unit", None)
+        if g is None or g.device != loss.device or g.dtype != loss.dtype or g.shape != loss.shape:
+            g = self._unit = torch.ones_like(loss)
+        return g
+
     def _train_step(self, mixture, sources):
         if not self.model.training:
             self.model.train()
@@ -307,15 +317,22 @@ class Solver(object):
             loss = self.loss_function(enhanced, sources)
         self.optimizer.zero_grad()
         fused = isinstance(self.optimizer, FlatOptimizer)
+        works, early_guard = [], False
         if self.world_size > 1 and self.flat_model and fused:
             # one SUM all-reduce of the flat buffer, in two ranges where the model hands them over early (the decoder / LSTM
             # range starts its exchange under the encoder's backward pass); 1/world is folded into the optimizer launch
             self.optimizer.grad_scale = 1.0 / self.world_size
             works = []
+            early_guard = bool(getattr(self.model, "step_guard_early", False)) and hasattr(self.model, "step_guard")
             if hasattr(self.model, "grad_range_hook"):
-                self.model.grad_range_hook = lambda lo, hi, st: works.append(
-                    distrib.allreduce_range_async(self.model.flat_grads, lo, hi, st))
-            loss.backward()
+                def hook(lo, hi, st):
+                    # (a model whose guard word is final when it hands over its first gradient range -- DCCRN: after the fused LSTM
+                    #  backward launch -- gets the guard's MAX all-reduce started there, on the same communication stream)
+                    if early_guard and not works:
+                        works.append(distrib.allreduce_step_guard_async(self.model.step_guard(), st))
+                    works.append(distrib.allreduce_range_async(self.model.flat_grads, lo, hi, st))
+                self.model.grad_range_hook = hook
+            loss.backward(self._unit_grad(loss))
             if hasattr(self.model, "grad_range_hook"):
                 self.model.grad_range_hook = None
             if works:
@@ -324,13 +341,13 @@ class Solver(object):
             else:
                 distrib.allreduce_gradients(self.model.flat_grads, scale=False)
         else:
-            loss.backward()
+            loss.backward(self._unit_grad(loss))
             if self.world_size > 1:
                 if self.flat_model:
                     distrib.allreduce_gradients(self.model.flat_grads)
                 else:
                     distrib.allreduce_module_gradients(self.model)
-        if self.world_size > 1 and hasattr(self.model, "step_guard"):
+        if self.world_size > 1 and hasattr(self.model, "step_guard") and not (fused and self.flat_model and works and early_guard):
             # a device-side failure word (Demucs: hand-off time-out) must stop the update on EVERY rank: the all-reduced gradients
             # already contain the failing rank's contribution
             distrib.allreduce_step_guard(self.model.step_guard())
