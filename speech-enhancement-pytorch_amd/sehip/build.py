@@ -43,7 +43,12 @@ def _compile(name, force):
     return obj, False
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tools=False):
+    """tools=True (--tools): also compiles the timing-ablation instantiations (SEHIP_C3_ABL, SEHIP_C3_W8, SEHIP_W3_ABL, SEHIP_L2_ABL:
+    wrong results by design) that the product library does not contain."""
+    if tools and "-DSEHIP_TOOLS_BUILD" not in FLAGS:
+        FLAGS.append("-DSEHIP_TOOLS_BUILD")
+        force = True
     os.makedirs(OBJ, exist_ok=True)
     with ThreadPoolExecutor(max_workers=6) as ex:
         res = list(ex.map(lambda n: _compile(n, force), sources()))
@@ -59,4 +64,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tools="--tools" in sys.argv)

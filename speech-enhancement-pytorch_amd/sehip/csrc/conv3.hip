@@ -527,12 +527,14 @@ static int c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) 
     conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN><<<grid, 128 * NWN, c3_lds_bytes<NF, FM, J, TM, TN, NWN>(), st>>>(d, B, c3_order());
     return 1;
 }
+#ifdef SEHIP_TOOLS_BUILD
 template <int J, int ABL>
 static void c3_launch_abl(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_kernel<5, 2, J, 8, 4, 2, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     conv_gemm_v3_kernel<5, 2, J, 8, 4, 2, ABL><<<grid, 256, c3_lds_bytes<5, 2, J, 8, 4>(), st>>>(d, B, c3_order());
 }
+#endif
 // Rows per tile: 256 (TM 8) or 192 (TM 6).  Tiles run two per CU (512 slots).  Measured at the headline shapes (B (T + 2) = 10400
 // frames): where 256-row tiles do not even fill one round (326 tiles) 192-row tiles (434) take 10-15 % less time; from 650 tiles
 // up the launch is bound by the LDS-DMA rate of the CUs that hold two workgroups and the smaller tile (more weight bytes per
@@ -548,6 +550,8 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     const long vframes = (long)B * (d.TT + 2);
     const int BN = (d.Npad & 127) ? 64 : 128;             // 64-column tiles only for the layers whose width is not a multiple of 128
     const int ntn = d.Npad / BN;
+#ifdef SEHIP_TOOLS_BUILD      // timing ablations (wrong results) and the 8-wave 256 x 256 experiment: tools builds only
+      // (python speech-enhancement-pytorch_amd/sehip/build.py --tools), never in the product library
     static const int abl = getenv("SEHIP_C3_ABL") ? atoi(getenv("SEHIP_C3_ABL")) : 0;     // tools/ only: timing ablations, wrong results
     if (abl && NF == 5 && BN == 128 && (d.J == 4 || d.J == 8)) {
         const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * ntn;
@@ -561,6 +565,7 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
         const int TB = 256 / d.J, grid = (int)((vframes + TB - 1) / TB) * (d.Npad / 256);
         return d.J == 4 ? c3_launch<5, 2, 4, 8, 4, 4>(d, B, grid, st) : c3_launch<5, 2, 8, 8, 4, 4>(d, B, grid, st);
     }
+#endif
     const int tm = c3_pick_tm(vframes, d.J, ntn);
 #define C3_CASE(J_)                                                                                       \
     case J_: {                                                                                            \

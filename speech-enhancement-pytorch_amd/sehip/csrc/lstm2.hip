@@ -524,7 +524,13 @@ extern "C" int sehip_lstm2_bwd(const void* dh_a, const void* dh_b, const void* w
     lstm2_bwd_kernel<<<8 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>(
         (const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT1, (const bf16_raw*)whhT2, (const bf16_raw*)wihT2,
         (const bf16_raw*)gates1, c1, (const bf16_raw*)gates2, c2, B, T, (bf16_raw*)dpre1_r, (bf16_raw*)dpre1_i, (bf16_raw*)dpre2_r,
-        (bf16_raw*)dpre2_i, (unsigned long long*)gran, sync, epoch, getenv("SEHIP_L2_ABL") ? atoi(getenv("SEHIP_L2_ABL")) : 0);
+        (bf16_raw*)dpre2_i, (unsigned long long*)gran, sync, epoch,
+#ifdef SEHIP_TOOLS_BUILD
+        getenv("SEHIP_L2_ABL") ? atoi(getenv("SEHIP_L2_ABL")) : 0      // timing ablations (wrong results), tools builds only
+#else
+        0
+#endif
+    );
     SEHIP_CHECK_LAUNCH("lstm2_bwd");
     return 0;
 }

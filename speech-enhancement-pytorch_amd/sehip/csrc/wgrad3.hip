@@ -333,6 +333,7 @@ static void w3_set_attr() {
 template <int NF, int FM, int J>
 static void w3_launch(const sehip_gemm_desc& d, int grid, int tiles_per_wg, int splits, int nb, float* scratch, hipStream_t st) {
     sehip_note_kernel("conv_wgrad_v3_kernel<%d, %d, %d, %d>", NF, FM, J, nb);
+#ifdef SEHIP_TOOLS_BUILD      // timing ablations (wrong results): tools builds only
     static const int abl = getenv("SEHIP_W3_ABL") ? atoi(getenv("SEHIP_W3_ABL")) : 0;
     if (abl && NF == 5 && J <= 8) {
         const size_t lds = w3_lds_bytes<NF, FM, J, 3>();
@@ -341,6 +342,7 @@ static void w3_launch(const sehip_gemm_desc& d, int grid, int tiles_per_wg, int 
         switch (abl) { W3_ABL(1) W3_ABL(2) W3_ABL(3) W3_ABL(4) W3_ABL(5) W3_ABL(6) W3_ABL(7) default: break; }
 #undef W3_ABL
     }
+#endif
     if (nb == 2) {
         w3_set_attr<NF, FM, J, 2>();
         conv_wgrad_v3_kernel<NF, FM, J, 2><<<grid, 512, w3_lds_bytes<NF, FM, J, 2>(), st>>>(d, tiles_per_wg, splits, scratch);
