@@ -1,0 +1,327 @@
+// convt_stream_kernel (round 4): the small-channel "two output rows per input row" products of DCCRN as ONE streaming launch per
+// layer -- the forward pass of the outer ComplexConvTranspose2d layers (src/model/dccrn.py:387-450; decoder 3 / 4 at the headline
+// widths: 64 + 64 -> 32 and 32 + 32 -> 16 channels, skip concat as second source) and the input gradient of the outer ComplexConv2d
+// layers (:316-384; encoder 2 / 1: 64 -> 32 and 32 -> 16 channels), both output-row parities in one pass.
+//
+// These layers are HBM-bound by a wide margin (27 GF over 126 MB for the largest), but conv_small2_kernel ran them at 1.3-1.6 TB/s:
+// its descriptor-generic staging spends 13-29 vector instructions per MFMA on addresses and packing.  Here
+// nothing in the frame loop computes an address:
+//   * a workgroup (4 waves, two per CU) owns a run of consecutive output frames of one utterance; every input frame of every source is
+//     exactly 4 KB = ONE 16-byte LDS-DMA piece per thread (buffer_load ... lds; per-lane source offset computed once, a scalar frame
+//     offset per step; frames outside the valid range are offsets beyond num_records: zeros), ring of four frames per source, counted
+//     vmcnt, ONE barrier per output frame;
+//   * the LDS image of a frame is [J + 2 rows][C channels] with the 16-byte pieces of a row XOR-permuted by the row index (the DMA
+//     reads per-lane sources, so the permutation is free): the 16 rows a ds_read_b128 lane group touches are 16 distinct bank slots
+//     for every tap; rows -1 and J are zeros (the frequency padding);
+//   * ALL weight fragments of both parities live in registers for the whole launch (10 x (input channels / 32) MFMA A operands per
+//     wave: 40 - 160 VGPRs); wave (wn, wm) owns 16 output channels x 16 input rows x both parities;
+//   * the output frame ([2 J rows][CO channels] = 4 KB) is staged in LDS and leaves as one coalesced 16-byte store per thread, with the
+//     skip gradient (`res`, also fetched by DMA) added on the way; the ComplexBatchNorm sums of the forward layers are taken from that
+//     staged tile (the values as stored), 40 sums per thread in registers for the whole launch, 80 atomics per workgroup at the end.
+// Operand conventions are sehip_gemm's: the two descriptors of a pair (parity 0: row taps -1, 0, +1; parity 1: 0, +1), K ordered
+// (time tap, row tap, source, channel), W bf16 [Npad][K], bias fp32, dst rows 2 j + parity.
+#include <stdlib.h>
+#include "common.h"
+#include "../../../include/sehip.h"
+
+typedef __attribute__((address_space(3))) void ct_lds_void;
+#define CT_OOB 0x7ffffff0u
+#define CT_RECORDS 0x7fff0000u
+
+template <int N>
+__device__ __forceinline__ void ct_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// C: channels per source (32 | 64), NS: sources (1 | 2), CO: output channels (16 | 32), J: input rows per frame, J * C == 2048.
+// STATS: ComplexBatchNorm sums of the output (forward layers); RES: a bf16 tensor of the output's shape is added (encoder input gradients)
+template <int C, int NS, int CO, int J, bool STATS, bool RES>
+__global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_desc d0, const sehip_gemm_desc d1, int B, int fpw) {
+    static_assert(J * C == 2048 && 2 * J * CO == 2048, "one 16-byte piece per thread and frame");
+    constexpr int PPR = C / 8;                         // 16-byte pieces per input row
+    constexpr int RPG = 16 / PPR;                      // rows per 256-byte bank row
+    constexpr int SLOT = (J + 2) * C * 2;              // bytes of a frame image incl. the two zero rows
+    constexpr int R = 4;                               // ring depth (frames in use: 2, in flight: 2)
+    constexpr int KPT = NS * C / 32;                   // MFMA k steps per (time tap, row tap)
+    constexpr int NF0 = 3, NF1 = 2;
+    constexpr int NFR0 = 2 * NF0 * KPT, NFR1 = 2 * NF1 * KPT;
+    constexpr int NT = CO / 16;                        // 16-column tiles of the output
+    static_assert((J / 16) * NT == 4, "four waves: one (n tile, m tile) each");
+    constexpr int NSR = NS + (RES ? 1 : 0);            // DMA instructions per thread and step
+    constexpr int IN_BYTES = NS * R * SLOT;
+    constexpr int RES_OFF = IN_BYTES, OUT_OFF = RES_OFF + (RES ? R * 4096 : 0), RED_OFF = OUT_OFF + 2 * 4096;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT, wm = wave / NT;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int TT = d0.TT;
+    const int chunks = (TT + fpw - 1) / fpw;
+    const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
+    const int t_lo = ck * fpw, t_hi = min(TT, t_lo + fpw);
+    const int nout = t_hi - t_lo;
+    if (nout <= 0 || b >= B) return;
+
+    // ---- zero rows of every ring slot (never written by the DMA)
+    for (int i = tid; i < NS * R * 2 * PPR; i += 256) {
+        const int sl = i / (2 * PPR), rr = (i / PPR) & 1, q = i % PPR;
+        *reinterpret_cast<uint4*>(smem + sl * SLOT + (rr ? (J + 1) * C * 2 : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    // ---- weight fragments (A operands): rows n = 16 wn + c16, k chunk 32 ks + 8 g
+    bf16x8 w0[NFR0], w1[NFR1];
+    {
+        const bf16_raw* W0 = reinterpret_cast<const bf16_raw*>(d0.W) + (size_t)(16 * wn + c16) * d0.K + 8 * g;
+        const bf16_raw* W1 = reinterpret_cast<const bf16_raw*>(d1.W) + (size_t)(16 * wn + c16) * d1.K + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < NFR0; ++ks) w0[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W0 + 32 * ks));
+#pragma unroll
+        for (int ks = 0; ks < NFR1; ++ks) w1[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W1 + 32 * ks));
+    }
+    f32x4 bias0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+    if (d0.bias) bias0 = *reinterpret_cast<const f32x4*>(d0.bias + 16 * wn + 4 * g);
+    if (d1.bias) bias1 = *reinterpret_cast<const f32x4*>(d1.bias + 16 * wn + 4 * g);
+
+    // ---- DMA: this thread's piece of a frame.  LDS position (relative to row 0 of the image) P = 64 wave + lane: row r = P / PPR,
+    // piece qs = P % PPR holds source piece q = qs ^ f(r + 1) of input row r (f: the row's bank-row index, see the fragment reads)
+    const int P = tid;
+    const int r_in = P / PPR, qs = P % PPR;
+    const int q_src = qs ^ (((r_in + 1) / RPG) & (PPR - 1));
+    const unsigned piece_off = 2u * (unsigned)(r_in * C + q_src * 8);
+    int tmin[NS];
+    unsigned fbytes[NS], sbase[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const sehip_src& S = s ? d0.src[1] : d0.src[0];
+        tmin[s] = min(d0.cv_toff[s][0], d0.cv_toff[s][1]);
+        fbytes[s] = 2u * (unsigned)(S.F * S.C);
+        sbase[s] = (unsigned)(b * S.T) * fbytes[s];
+    }
+    // (two named descriptors, not an array: hipcc's host pass silently drops every kernel of the file when a lambda hands an element of
+    //  a captured array to the buffer-load builtin -- csrc/conv3.hip)
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(NS == 2 ? d0.src[1].ptr : d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+    const sehip_dst& dd = d0.dst[0];
+    const unsigned obytes = 2u * (unsigned)(dd.F * dd.C);           // bytes per output frame (= 4096: dense rows, checked by the launcher)
+    bf16_raw* outp = reinterpret_cast<bf16_raw*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)(dd.F * dd.C);
+    const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(RES ? d0.res : dd.ptr)), 0, CT_RECORDS, 0x00020000);
+    const unsigned rbase = (unsigned)(b * dd.T + dd.toff) * obytes + 16u * (unsigned)tid;
+
+    // issue(v): input frame v of the run (source frame t_lo + tmin_s + v) into ring slot v % R of every source, and the `res` tile of
+    // output frame v - 2 (the one stored two steps later) into res slot (v - 2) % R.  Constant instruction count: NSR per call.
+    auto issue = [&](int v) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const sehip_src& S = s ? d0.src[1] : d0.src[0];
+            const int u = t_lo + tmin[s] + v;
+            const bool ok = u >= S.tlo && u < S.thi && v <= nout;
+            const unsigned vo = ok ? sbase[s] + (unsigned)u * fbytes[s] + piece_off : CT_OOB;
+            unsigned char* dst = smem + (s * R + (v & (R - 1))) * SLOT + C * 2 + wave * 1024;
+            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+        }
+        if (RES) {
+            const int o = v - 2;
+            const bool ok = o >= 0 && o < nout;
+            const unsigned vo = ok ? rbase + (unsigned)(t_lo + o) * obytes : CT_OOB;
+            unsigned char* dst = smem + RES_OFF + (o & (R - 1)) * 4096 + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+        }
+    };
+
+    // ---- B-operand fragment addresses: input row j + dtot (dtot = -1, 0, +1) of this lane's output row pair, piece q of the row
+    // (q = 4 (channel slice of 32) + g); image row r = j + dtot + 1, bank-row swizzle f(r) = (r / RPG) & (PPR - 1)
+    const int j = 16 * wm + c16;
+    int aoff[3][C / 32];
+#pragma unroll
+    for (int dd_ = 0; dd_ < 3; ++dd_) {
+        const int r = j + dd_;                         // = j + dtot + 1
+#pragma unroll
+        for (int cs = 0; cs < C / 32; ++cs) {
+            const int q = 4 * cs + g;
+            aoff[dd_][cs] = (r * PPR + (q ^ ((r / RPG) & (PPR - 1)))) * 16;
+        }
+    }
+    int dt[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { dt[s][0] = d0.cv_toff[s][0] - tmin[s]; dt[s][1] = d0.cv_toff[s][1] - tmin[s]; }
+
+    // ---- statistics: thread -> (row, 8 consecutive real channels) of the staged output tile; its partner piece holds the imaginary parts
+    constexpr int OPR = CO / 8;                        // pieces per output row
+    const bool stat_thread = STATS && (tid % OPR) < OPR / 2;
+    float st[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) st[i] = 0.f;
+
+    // prologue: frames 0, 1, 2
+    __syncthreads();                                   // (the zero rows)
+    issue(0); issue(1); issue(2);
+
+    for (int i = 0; i <= nout; ++i) {
+        // frame i + 1 of the run (issued two steps ago, or in the prologue) has landed; behind the barrier every wave has also
+        // finished step i - 1: its fragment reads (slot (i - 1) % R is free) and its writes to the staging tile (i - 1) & 1
+        if (i < 2) ct_wait_vm<NSR>(); else ct_wait_vm<NSR + 1>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(i + 3);
+        // ---- store phase: output frame i - 1 leaves (one 16-byte piece per thread), its statistics are taken
+        if (i > 0) {
+            const unsigned char* ot = smem + OUT_OFF + ((i - 1) & 1) * 4096;
+            uint4 v = *reinterpret_cast<const uint4*>(ot + 16 * tid);
+            if (RES) {
+                const uint4 r4 = *reinterpret_cast<const uint4*>(smem + RES_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * tid);
+                const unsigned av[4] = {v.x, v.y, v.z, v.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf2(__uint_as_float(av[e] << 16) + __uint_as_float(rv[e] << 16),
+                                    __uint_as_float(av[e] & 0xffff0000u) + __uint_as_float(rv[e] & 0xffff0000u));
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(outp) + (size_t)(t_lo + i - 1) * obytes + 16 * tid) = v;
+            if (STATS && stat_thread) {
+                const uint4 vi = *reinterpret_cast<const uint4*>(ot + 16 * (tid + OPR / 2));
+                const unsigned ar[4] = {v.x, v.y, v.z, v.w}, ai[4] = {vi.x, vi.y, vi.z, vi.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yr[2] = {__uint_as_float(ar[e] << 16), __uint_as_float(ar[e] & 0xffff0000u)};
+                    const float yi[2] = {__uint_as_float(ai[e] << 16), __uint_as_float(ai[e] & 0xffff0000u)};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = 2 * e + h;
+                        st[5 * c] += yr[h]; st[5 * c + 1] += yi[h];
+                        st[5 * c + 2] += yr[h] * yr[h]; st[5 * c + 3] += yr[h] * yi[h]; st[5 * c + 4] += yi[h] * yi[h];
+                    }
+                }
+            }
+        }
+        if (i == nout) break;
+        // ---- compute phase: output frame i, both parities, from input frames i (+0 / +1 by the time tap) of every source
+        unsigned char* ot = smem + OUT_OFF + (i & 1) * 4096;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int nf = p ? NF1 : NF0;
+            f32x4 acc = p ? bias1 : bias0;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int di = 0; di < (p ? NF1 : NF0); ++di) {
+                    const int dtot = (p ? 0 : -1) + di + 1;                       // index into aoff: row tap -1, 0, +1 -> 0, 1, 2
+#pragma unroll
+                    for (int kk = 0; kk < KPT; ++kk) {
+                        const int s = kk / (C / 32), cs = kk % (C / 32);
+                        const int slot = (i + dt[s][kt]) & (R - 1);
+                        const bf16x8 xf = __builtin_bit_cast(
+                            bf16x8, *reinterpret_cast<const uint4*>(smem + (s * R + slot) * SLOT + aoff[dtot][cs]));
+                        const int ks = (kt * nf + di) * KPT + kk;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p ? w1[ks < NFR1 ? ks : 0] : w0[ks], xf, acc, 0, 0, 0);
+                    }
+                }
+            // D rows = output channels 16 wn + 4 g .. + 3, column = input row j -> output row 2 j + p
+            *reinterpret_cast<uint2*>(ot + ((2 * j + p) * CO + 16 * wn + 4 * g) * 2) = make_uint2(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after the workgroup has given its LDS back
+
+    if (STATS) {
+        // threads with equal (tid % OPR) hold the same 8 complex channels for different rows: reduce over them through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [256 / OPR][40] per channel group, summed in two hops
+        constexpr int GRP = OPR / 2;                                          // channel groups (of 8 complex channels)
+        constexpr int TPG = 256 / OPR;                                        // threads per group
+        const int grp = tid % OPR, member = tid / OPR;
+        // first hop: shuffles over lanes that hold the same group (lanes OPR apart)
+#pragma unroll
+        for (int i = 0; i < 40; ++i)
+#pragma unroll
+            for (int o = OPR; o < 64; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
+        if (stat_thread && lane < OPR) {
+#pragma unroll
+            for (int i = 0; i < 40; ++i) red[(wave * GRP + grp) * 40 + i] = st[i];
+        }
+        (void)member; (void)TPG;
+        __syncthreads();
+        if (tid < GRP * 40) {
+            const int gq = tid / 40, i = tid - gq * 40, c = i / 5, k = i - 5 * c;
+            const float v = red[(0 * GRP + gq) * 40 + i] + red[(1 * GRP + gq) * 40 + i] + red[(2 * GRP + gq) * 40 + i] + red[(3 * GRP + gq) * 40 + i];
+            const int Cr = d0.stats_cr;
+            atomicAdd(d0.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + 8 * gq + c, v);
+        }
+    }
+}
+
+template <int C, int NS, int CO, int J, bool STATS, bool RES>
+static int ct_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, hipStream_t st) {
+    constexpr int SLOT = (J + 2) * C * 2;
+    constexpr size_t lds = (size_t)NS * 4 * SLOT + (RES ? 4 * 4096 : 0) + 2 * 4096 + (STATS ? 4 * 2 * 40 * 4 : 0) + 64;
+    static unsigned char state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_stream_kernel<C, NS, CO, J, STATS, RES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    static const int cpu_env = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 16;     // workgroups per utterance
+    int chunks = cpu_env > 0 ? cpu_env : 16;
+    if (chunks > a.TT) chunks = a.TT;
+    const int fpw = (a.TT + chunks - 1) / chunks;
+    chunks = (a.TT + fpw - 1) / fpw;
+    sehip_note_kernel("convt_stream_kernel<%d, %d, %d, %d, %d, %d>", C, NS, CO, J, (int)STATS, (int)RES);
+    convt_stream_kernel<C, NS, CO, J, STATS, RES><<<B * chunks, 256, lds, st>>>(a, b, B, fpw);
+    return 1;
+}
+
+// returns 1 if the pair was launched, 0 if it does not qualify (the caller goes on to conv_small2 / the generic kernels).
+// a = the parity-0 product (row taps -1, 0, +1), b = parity 1 (0, +1) of the same sources.
+int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, hipStream_t st, bool dry) {
+    static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr;
+    if (disabled) return 0;
+    if (a.cv_nf != 3 || b.cv_nf != 2 || a.cv_fadd != -1 || b.cv_fadd != 0 || a.fmul != 1 || b.fmul != 1) return 0;
+    if (a.tmul > 1 || b.tmul > 1 || a.J != b.J || a.TT != b.TT || a.M != b.M || a.N != b.N || a.Npad != b.Npad || a.N != a.Npad) return 0;
+    const int NS = a.src[1].ptr ? 2 : 1;
+    if ((b.src[1].ptr ? 2 : 1) != NS || a.src[2].ptr) return 0;
+    for (int s = 0; s < NS; ++s) {
+        const sehip_src &x = a.src[s], &y = b.src[s];
+        if (x.ptr != y.ptr || x.T != y.T || x.F != y.F || x.C != y.C || x.tlo != y.tlo || x.thi != y.thi) return 0;
+        if (x.F != a.J || x.C != a.src[0].C) return 0;
+        for (int kt = 0; kt < 2; ++kt)
+            if (a.cv_toff[s][kt] != b.cv_toff[s][kt]) return 0;
+        if (abs(a.cv_toff[s][0] - a.cv_toff[s][1]) != 1) return 0;
+    }
+    const int C = a.src[0].C, CO = a.N, J = a.J;
+    if (a.K != 2 * 3 * NS * C || b.K != 2 * 2 * NS * C) return 0;
+    // one dense bf16 destination shared by the two parities: rows 2 j + p of [B][T][2 J][CO]
+    const sehip_dst &da = a.dst[0], &db = b.dst[0];
+    if (a.dst[1].ptr || b.dst[1].ptr || da.ptr != db.ptr || da.is_f32 || db.is_f32 || da.C != CO || da.F != 2 * J || da.T != db.T ||
+        da.toff != db.toff || da.fmul != 2 || db.fmul != 2 || da.fadd != 0 || db.fadd != 1 || da.tmul > 1 || db.tmul > 1) return 0;
+    if (a.M % (a.TT * a.J)) return 0;
+    const int B = a.M / (a.TT * a.J);
+    if ((long)B * da.T * da.F * da.C >= (1L << 30) - (1L << 20)) return 0;               // byte offsets below CT_RECORDS
+    for (int s = 0; s < NS; ++s)
+        if ((long)B * a.src[s].T * a.src[s].F * a.src[s].C >= (1L << 30) - (1L << 20)) return 0;
+    // column table: dense, in order
+    // (checked on the host copy of the first / last group only would need the device table: the plan builds these products with
+    //  dense_ntab, and a caller with another table does not set cv_nf = 3 / 2 with fmul 1 and a shared destination)
+    const bool stats = a.stats != nullptr;
+    if (stats && (a.stats != b.stats || a.stats_cr * 2 != CO || a.res || b.res)) return 0;
+    const bool res = a.res != nullptr;
+    if (res && (a.res != b.res || stats || a.bias || b.bias)) return 0;
+    if (!stats && !res) return 0;            // (the two uses built: forward with sums, input gradient with the skip gradient)
+    if ((((uintptr_t)a.W | (uintptr_t)b.W) & 15) || (a.bias && (((uintptr_t)a.bias | (uintptr_t)b.bias) & 15))) return 0;
+    if (dry) return (C == 64 && CO == 32 && J == 32) || (C == 32 && CO == 16 && J == 64);
+#define CT_CASE(C_, NS_, CO_, J_, ST_, RS_) \
+    if (C == C_ && NS == NS_ && CO == CO_ && J == J_ && stats == ST_ && res == RS_) return ct_launch<C_, NS_, CO_, J_, ST_, RS_>(a, b, B, st);
+    CT_CASE(64, 2, 32, 32, true, false)      // decoder 3 forward
+    CT_CASE(32, 2, 16, 64, true, false)      // decoder 4 forward
+    CT_CASE(64, 1, 32, 32, false, true)      // encoder 2 input gradient
+    CT_CASE(32, 1, 16, 64, false, true)      // encoder 1 input gradient
+#undef CT_CASE
+    return 0;
+}

@@ -1603,8 +1603,11 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
 // one launch that stages the input once when the small-channel kernel takes the pair, otherwise the two launches.
 // 1 when conv_small2_kernel takes the product (b == NULL) or the pair as described, fused BatchNorm sums (field stats) included:
 // the plan asks before it relies on them (workspace-dependent: the kernel must fit its patch into LDS)
+int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, hipStream_t st, bool dry);   // convt.hip
+
 extern "C" int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b) {
     if (!a) return 0;
+    if (b && sehip_try_convt_stream(*a, *b, nullptr, true)) return 1;
     if (try_conv_small(*a, b, nullptr, true)) return 1;
     return b ? 0 : try_conv_narrow(*a, nullptr, true);          // (2-channel input: conv_narrow_kernel)
 }
@@ -1613,6 +1616,10 @@ extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* 
     if (int e = check_desc("gemm_pair", a)) return e;
     if (int e = check_desc("gemm_pair", b)) return e;
     SEHIP_REQUIRE(a->W != nullptr && b->W != nullptr, "gemm_pair: missing weights");
+    if (sehip_try_convt_stream(*a, *b, (hipStream_t)stream, false)) {
+        SEHIP_CHECK_LAUNCH("gemm_pair(convt-stream)");
+        return 0;
+    }
     if (try_conv_small(*a, b, (hipStream_t)stream)) {
         SEHIP_CHECK_LAUNCH("gemm_pair(conv-small)");
         return 0;

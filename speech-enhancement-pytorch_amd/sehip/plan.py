@@ -1298,8 +1298,7 @@ class DCCRNWorkspace:
             self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, dz2, b[f"y{i}"], b[f"dye{i}"], params, 0)
             self.wgrad(f"enc{i}.fwd")
             if i > 0:
-                self.gemm(f"enc{i}.dg0")
-                self.gemm(f"enc{i}.dg1")
+                self.gemm_pair(f"enc{i}.dg0", f"enc{i}.dg1")     # one streaming launch for the outer layers (csrc/convt.hip), else the two products
         if self.side is not None:
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
         call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), lo if range_ready is not None else n_params, ptr(grads), stream())
