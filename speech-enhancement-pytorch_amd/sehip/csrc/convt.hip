@@ -25,6 +25,12 @@
 #include "../../../include/sehip.h"
 
 typedef __attribute__((address_space(3))) void ct_lds_void;
+#ifdef CT_PHASE_TIMERS        // tools/micro/convt_bench.hip: core-clock cycles of wave 0 of workgroup 0 per phase of the frame loop
+__device__ unsigned long long ct_phase[8];
+#define CT_T(k_) do { if ((abl & 64) && blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ct_phase[k_] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define CT_T(k_) do { } while (0)
+#endif
 #define CT_OOB 0x7ffffff0u
 #define CT_RECORDS 0x7fff0000u
 
@@ -32,16 +38,50 @@ template <int N>
 __device__ __forceinline__ void ct_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// Every LDS access inside the frame loop is inline assembly.  hipcc's waitcnt insertion treats a buffer_load ... lds as a pending
+// write to ALL of LDS: in front of the first ds_read / ds_write it can see after one it puts s_waitcnt vmcnt(0) (a six-line kernel
+// shows it: DMA, counted asm wait, barrier, plain LDS load -> "s_waitcnt vmcnt(0)" before the load, whatever the order of issue and
+// read inside the step) -- the whole DMA ring drained on every frame, 62 us per launch.  What orders the DMA against these reads is
+// the counted vmcnt + the barrier at the top of the step, by construction; lgkmcnt is waited for by hand, the loaded registers tied to
+// the wait ("+v") and a sched_barrier behind it (cdna_hip_programming.md, rule 18).
+typedef unsigned ct_u4 __attribute__((ext_vector_type(4)));   // a register quad ("v" constraints refuse HIP's struct uint4)
+typedef unsigned ct_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ct_u4 ct_lds_read16(unsigned addr) {
+    ct_u4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void ct_lds_write8(unsigned addr, ct_u2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ct_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// (macros, not functions: "+v" on an element of an array passed by reference is a "tied indirect register input" hipcc refuses)
+#define CT_WAIT3(a, b, c) do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// all LDS operations but the youngest n_ have completed (they return in order)
+#define CT_WAIT4N(n_, a, b, c, d) do { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n_) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// The piece permutation of image row r (its 16-byte pieces are stored at piece index q ^ ct_swz(r)).  A ds_read_b128 is served in four
+// groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS) -- and a group of the
+// fragment read below is 16 consecutive rows, 8 of them at piece q and 8 at piece q + 1.  The obvious "row pair index" permutation
+// ((r / 2) & 7 for 128-byte rows) is 2-way on every read whose first row is 2 mod 4; these two (found by exhaustive search over the
+// GF(2)-linear maps of the row index) are conflict-free for all three row taps, every 16-row tile and both channel slices.
+template <int C>
+__device__ __forceinline__ constexpr int ct_swz(int r) { return C == 64 ? (r & 6) : ((r >> 1) & 2); }
 
 // C: channels per source (32 | 64), NS: sources (1 | 2), CO: output channels (16 | 32), J: input rows per frame, J * C == 2048.
 // STATS: ComplexBatchNorm sums of the output (forward layers); RES: a bf16 tensor of the output's shape is added (encoder input gradients)
 template <int C, int NS, int CO, int J, bool STATS, bool RES>
-__global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_desc d0, const sehip_gemm_desc d1, int B, int fpw) {
+__global__ __launch_bounds__(256, (NS * C > 64 ? 1 : 2)) void convt_stream_kernel(const sehip_gemm_desc d0, const sehip_gemm_desc d1, int B, int fpw, int abl_) {
+#ifdef SEHIP_TOOLS_BUILD      // timing ablations (wrong results): tools builds only.  1: no store phase, 2: no compute phase, 4: no DMA traffic,
+    const int abl = abl_;     // 8: no statistics arithmetic, 16: no global store, 32: no fragment reads (MFMAs on stale registers), 64: phase stamps
+#else
+    constexpr int abl = 0; (void)abl_;
+#endif
     static_assert(J * C == 2048 && 2 * J * CO == 2048, "one 16-byte piece per thread and frame");
     constexpr int PPR = C / 8;                         // 16-byte pieces per input row
-    constexpr int RPG = 16 / PPR;                      // rows per 256-byte bank row
     constexpr int SLOT = (J + 2) * C * 2;              // bytes of a frame image incl. the two zero rows
-    constexpr int R = 4;                               // ring depth (frames in use: 2, in flight: 2)
+    constexpr int R = 8;                               // ring depth (frames in use: 2, in flight: 6)
+    constexpr int D = R - 2;                           // prefetch distance in frames
     constexpr int KPT = NS * C / 32;                   // MFMA k steps per (time tap, row tap)
     constexpr int NF0 = 3, NF1 = 2;
     constexpr int NFR0 = 2 * NF0 * KPT, NFR1 = 2 * NF1 * KPT;
@@ -52,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     constexpr int RES_OFF = IN_BYTES, OUT_OFF = RES_OFF + (RES ? R * 4096 : 0), RED_OFF = OUT_OFF + 2 * 4096;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;          // LDS byte address of the dynamic array
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % NT, wm = wave / NT;
@@ -87,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     // piece qs = P % PPR holds source piece q = qs ^ f(r + 1) of input row r (f: the row's bank-row index, see the fragment reads)
     const int P = tid;
     const int r_in = P / PPR, qs = P % PPR;
-    const int q_src = qs ^ (((r_in + 1) / RPG) & (PPR - 1));
+    const int q_src = qs ^ ct_swz<C>(r_in + 1);
     const unsigned piece_off = 2u * (unsigned)(r_in * C + q_src * 8);
     int tmin[NS];
     unsigned fbytes[NS], sbase[NS];
@@ -112,13 +153,14 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     const unsigned rbase = (unsigned)(b * dd.T + dd.toff) * obytes + 16u * (unsigned)tid;
 
     // issue(v): input frame v of the run (source frame t_lo + tmin_s + v) into ring slot v % R of every source, and the `res` tile of
-    // output frame v - 2 (the one stored two steps later) into res slot (v - 2) % R.  Constant instruction count: NSR per call.
+    // output frame v - 2 (stored one step after input frame v - 1 is first used) into res slot (v - 2) % R.  Constant instruction
+    // count: NSR per call.
     auto issue = [&](int v) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const sehip_src& S = s ? d0.src[1] : d0.src[0];
             const int u = t_lo + tmin[s] + v;
-            const bool ok = u >= S.tlo && u < S.thi && v <= nout;
+            const bool ok = u >= S.tlo && u < S.thi && v <= nout && !(abl & 4);
             const unsigned vo = ok ? sbase[s] + (unsigned)u * fbytes[s] + piece_off : CT_OOB;
             unsigned char* dst = smem + (s * R + (v & (R - 1))) * SLOT + C * 2 + wave * 1024;
             if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
@@ -126,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
         }
         if (RES) {
             const int o = v - 2;
-            const bool ok = o >= 0 && o < nout;
+            const bool ok = o >= 0 && o < nout && !(abl & 4);
             const unsigned vo = ok ? rbase + (unsigned)(t_lo + o) * obytes : CT_OOB;
             unsigned char* dst = smem + RES_OFF + (o & (R - 1)) * 4096 + wave * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
@@ -134,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     };
 
     // ---- B-operand fragment addresses: input row j + dtot (dtot = -1, 0, +1) of this lane's output row pair, piece q of the row
-    // (q = 4 (channel slice of 32) + g); image row r = j + dtot + 1, bank-row swizzle f(r) = (r / RPG) & (PPR - 1)
+    // (q = 4 (channel slice of 32) + g); image row r = j + dtot + 1, piece permutation ct_swz(r)
     const int j = 16 * wm + c16;
     int aoff[3][C / 32];
 #pragma unroll
@@ -143,37 +185,59 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
 #pragma unroll
         for (int cs = 0; cs < C / 32; ++cs) {
             const int q = 4 * cs + g;
-            aoff[dd_][cs] = (r * PPR + (q ^ ((r / RPG) & (PPR - 1)))) * 16;
+            aoff[dd_][cs] = (r * PPR + (q ^ ct_swz<C>(r))) * 16;
         }
     }
     int dt[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { dt[s][0] = d0.cv_toff[s][0] - tmin[s]; dt[s][1] = d0.cv_toff[s][1] - tmin[s]; }
 
-    // ---- statistics: thread -> (row, 8 consecutive real channels) of the staged output tile; its partner piece holds the imaginary parts
+    // ---- statistics: an output row is [CO / 2 real | CO / 2 imaginary] channels = OPR pieces of 8; the thread of piece pi and the
+    // thread of its partner piece pi ^ (OPR / 2) (same 8 complex channels, other part) share the work: the real piece's thread takes
+    // channels 0-3 of the 8, the imaginary piece's thread channels 4-7 -- 20 running sums per thread, every thread busy
     constexpr int OPR = CO / 8;                        // pieces per output row
-    const bool stat_thread = STATS && (tid % OPR) < OPR / 2;
-    float st[40];
+    const bool im_thread = (tid % OPR) >= OPR / 2;
+    float st[20];
 #pragma unroll
-    for (int i = 0; i < 40; ++i) st[i] = 0.f;
+    for (int i = 0; i < 20; ++i) st[i] = 0.f;
 
-    // prologue: frames 0, 1, 2
+    // prologue: frames 0 .. D
     __syncthreads();                                   // (the zero rows)
-    issue(0); issue(1); issue(2);
+#pragma unroll
+    for (int v = 0; v <= D; ++v) issue(v);
 
+#ifdef CT_PHASE_TIMERS
+    unsigned long long tprev = (abl & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+    CT_T(0);                                           // (everything in front of the loop)
     for (int i = 0; i <= nout; ++i) {
-        // frame i + 1 of the run (issued two steps ago, or in the prologue) has landed; behind the barrier every wave has also
-        // finished step i - 1: its fragment reads (slot (i - 1) % R is free) and its writes to the staging tile (i - 1) & 1
-        if (i < 2) ct_wait_vm<NSR>(); else ct_wait_vm<NSR + 1>();
+        // frame i + 1 of the run (issued D steps ago, or in the prologue) has landed; behind the barrier every wave has also
+        // finished step i - 1: its fragment reads (slot (i - 1) % R is free) and its writes to the staging tile (i - 1) & 1.
+        // The count is EXACT: the D - 1 younger DMA batches plus the output stores issued since (one per step from step 1 on, each
+        // in front of its step's batch: at most D - 1 of them are younger than the batch waited for).  One short -- "NSR + 1" in the first version, which forgot a store -- and every
+        // step waits for the previous step's store to be acknowledged: 61 us per launch instead of what the DMA depth allows.
+        switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
+            case 0: ct_wait_vm<(D - 1) * NSR + 0>(); break;
+            case 1: ct_wait_vm<(D - 1) * NSR + 1>(); break;
+            case 2: ct_wait_vm<(D - 1) * NSR + 2>(); break;
+            case 3: ct_wait_vm<(D - 1) * NSR + 3>(); break;
+            case 4: ct_wait_vm<(D - 1) * NSR + 4>(); break;
+            default: ct_wait_vm<(D - 1) * NSR + D - 1>(); break;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CT_T(1);
         __builtin_amdgcn_s_barrier();
-        issue(i + 3);
+        CT_T(2);
         // ---- store phase: output frame i - 1 leaves (one 16-byte piece per thread), its statistics are taken
-        if (i > 0) {
-            const unsigned char* ot = smem + OUT_OFF + ((i - 1) & 1) * 4096;
-            uint4 v = *reinterpret_cast<const uint4*>(ot + 16 * tid);
+        if (i > 0 && !(abl & 1)) {
+            const unsigned ot = sm + OUT_OFF + ((i - 1) & 1) * 4096;
+            ct_u4 ld0 = ct_lds_read16(ot + 16 * tid);
+            ct_u4 ld1 = STATS ? ct_lds_read16(ot + 16 * (tid ^ (OPR / 2))) : ct_u4{0u, 0u, 0u, 0u};   // the partner piece (other part, same channels)
+            ct_u4 ld2 = RES ? ct_lds_read16(sm + RES_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * tid) : ct_u4{0u, 0u, 0u, 0u};
+            CT_WAIT3(ld0, ld1, ld2);
+            uint4 v = __builtin_bit_cast(uint4, ld0);
             if (RES) {
-                const uint4 r4 = *reinterpret_cast<const uint4*>(smem + RES_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * tid);
+                const uint4 r4 = __builtin_bit_cast(uint4, ld2);
                 const unsigned av[4] = {v.x, v.y, v.z, v.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
                 unsigned o[4];
 #pragma unroll
@@ -182,14 +246,16 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
                                     __uint_as_float(av[e] & 0xffff0000u) + __uint_as_float(rv[e] & 0xffff0000u));
                 v = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(outp) + (size_t)(t_lo + i - 1) * obytes + 16 * tid) = v;
-            if (STATS && stat_thread) {
-                const uint4 vi = *reinterpret_cast<const uint4*>(ot + 16 * (tid + OPR / 2));
-                const unsigned ar[4] = {v.x, v.y, v.z, v.w}, ai[4] = {vi.x, vi.y, vi.z, vi.w};
+            if (!(abl & 16)) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(outp) + (size_t)(t_lo + i - 1) * obytes + 16 * tid) = v;
+            if (STATS && !(abl & 8)) {
+                const uint4 vp = __builtin_bit_cast(uint4, ld1);
+                // words of channels 0-3 (real piece's thread) or 4-7 (imaginary piece's thread) of both parts
+                const unsigned own[2] = {im_thread ? v.z : v.x, im_thread ? v.w : v.y}, oth[2] = {im_thread ? vp.z : vp.x, im_thread ? vp.w : vp.y};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float yr[2] = {__uint_as_float(ar[e] << 16), __uint_as_float(ar[e] & 0xffff0000u)};
-                    const float yi[2] = {__uint_as_float(ai[e] << 16), __uint_as_float(ai[e] & 0xffff0000u)};
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned ar = im_thread ? oth[e] : own[e], ai = im_thread ? own[e] : oth[e];
+                    const float yr[2] = {__uint_as_float(ar << 16), __uint_as_float(ar & 0xffff0000u)};
+                    const float yi[2] = {__uint_as_float(ai << 16), __uint_as_float(ai & 0xffff0000u)};
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int c = 2 * e + h;
@@ -199,65 +265,93 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
                 }
             }
         }
+        CT_T(3);
         if (i == nout) break;
+        // (the DMA of frame i + D + 1 is issued at the END of the step, behind every LDS read of the step: with the issue in front of
+        //  them hipcc's waitcnt insertion treats the LDS-DMA as a pending write to whatever the next ds_read touches and puts an
+        //  s_waitcnt vmcnt(0) there -- every step then waited for the frames it had just requested: 62 us per launch.  The output
+        //  stores of a step are then OLDER than its batch: the counts above change accordingly)
         // ---- compute phase: output frame i, both parities, from input frames i (+0 / +1 by the time tap) of every source
-        unsigned char* ot = smem + OUT_OFF + (i & 1) * 4096;
+        const unsigned ot = sm + OUT_OFF + (i & 1) * 4096;
+        unsigned sl0[NS], sl1[NS];                     // LDS address of the frame image of (source, time tap 0 / 1)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int nf = p ? NF1 : NF0;
-            f32x4 acc = p ? bias1 : bias0;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int di = 0; di < (p ? NF1 : NF0); ++di) {
-                    const int dtot = (p ? 0 : -1) + di + 1;                       // index into aoff: row tap -1, 0, +1 -> 0, 1, 2
-#pragma unroll
-                    for (int kk = 0; kk < KPT; ++kk) {
-                        const int s = kk / (C / 32), cs = kk % (C / 32);
-                        const int slot = (i + dt[s][kt]) & (R - 1);
-                        const bf16x8 xf = __builtin_bit_cast(
-                            bf16x8, *reinterpret_cast<const uint4*>(smem + (s * R + slot) * SLOT + aoff[dtot][cs]));
-                        const int ks = (kt * nf + di) * KPT + kk;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p ? w1[ks < NFR1 ? ks : 0] : w0[ks], xf, acc, 0, 0, 0);
-                    }
-                }
-            // D rows = output channels 16 wn + 4 g .. + 3, column = input row j -> output row 2 j + p
-            *reinterpret_cast<uint2*>(ot + ((2 * j + p) * CO + 16 * wn + 4 * g) * 2) = make_uint2(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]));
+        for (int s = 0; s < NS; ++s) {
+            sl0[s] = sm + (s * R + ((i + dt[s][0]) & (R - 1))) * SLOT;
+            sl1[s] = sm + (s * R + ((i + dt[s][1]) & (R - 1))) * SLOT;
         }
+        // The 2 NF0 + 2 NF1 = 10 (parity, time tap, row tap) groups of KPT fragments each, in one software pipeline two groups deep:
+        // the reads of group n + 1 are in flight while the MFMAs of group n run (with one wave per SIMD -- 256 workgroups, one per CU --
+        // nothing else hides the LDS latency: read, wait, multiply in turn was 4200 cycles per frame for 640 cycles of MFMA).
+        // LDS operations return in order, so "all but the youngest KPT" = group n has landed; the parity-0 result's ds_write sits
+        // between two groups and is simply waited for with them.
+        constexpr int NG = 2 * NF0 + 2 * NF1;
+        ct_u4 xq[2][4];
+        auto rd = [&](int gi, ct_u4 (&x)[4]) {
+            const int p = gi >= 2 * NF0, w = gi - (p ? 2 * NF0 : 0), nf = p ? NF1 : NF0, kt = w / nf, di = w % nf;
+            const int dtot = (p ? 0 : -1) + di + 1;                               // index into aoff: row tap -1, 0, +1 -> 0, 1, 2
+            // fragment kk: source kk / (C / 32), channel slice kk % (C / 32)
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) x[kk] = ct_lds_read16((kt ? sl1[kk / (C / 32)] : sl0[kk / (C / 32)]) + aoff[dtot][kk % (C / 32)]);
+        };
+        rd(0, xq[0]);
+        f32x4 acc = bias0;
+#pragma unroll
+        for (int gi = 0; gi < NG && !(abl & 2); ++gi) {
+            const int cur = gi & 1;
+            if (gi + 1 < NG) {
+                if (!(abl & 32)) rd(gi + 1, xq[cur ^ 1]);
+                CT_WAIT4N(KPT, xq[cur][0], xq[cur][1], xq[cur][2], xq[cur][3]);
+            } else {
+                CT_WAIT4N(0, xq[cur][0], xq[cur][1], xq[cur][2], xq[cur][3]);
+            }
+            const int p = gi >= 2 * NF0;
+            const int ks = (gi - (p ? 2 * NF0 : 0)) * KPT;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p ? w1[ks + kk < NFR1 ? ks + kk : 0] : w0[ks + kk < NFR0 ? ks + kk : 0],
+                                                              __builtin_bit_cast(bf16x8, xq[cur][kk]), acc, 0, 0, 0);
+            if (gi == 2 * NF0 - 1 || gi == NG - 1) {
+                // D rows = output channels 16 wn + 4 g .. + 3, column = input row j -> output row 2 j + p
+                ct_lds_write8(ot + ((2 * j + p) * CO + 16 * wn + 4 * g) * 2, ct_u2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])});
+                acc = bias1;
+            }
+        }
+        CT_T(4);
+        issue(i + D + 1);
+        CT_T(5);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after the workgroup has given its LDS back
+    CT_T(6);
 
     if (STATS) {
-        // threads with equal (tid % OPR) hold the same 8 complex channels for different rows: reduce over them through LDS
+        // threads with equal (tid % OPR) hold the same 4 complex channels for different rows: shuffles over the lanes OPR apart, then
+        // the four waves through LDS
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [256 / OPR][40] per channel group, summed in two hops
-        constexpr int GRP = OPR / 2;                                          // channel groups (of 8 complex channels)
-        constexpr int TPG = 256 / OPR;                                        // threads per group
-        const int grp = tid % OPR, member = tid / OPR;
-        // first hop: shuffles over lanes that hold the same group (lanes OPR apart)
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [4 waves][OPR][20]
 #pragma unroll
-        for (int i = 0; i < 40; ++i)
+        for (int i = 0; i < 20; ++i)
 #pragma unroll
             for (int o = OPR; o < 64; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
-        if (stat_thread && lane < OPR) {
+        if (lane < OPR) {
 #pragma unroll
-            for (int i = 0; i < 40; ++i) red[(wave * GRP + grp) * 40 + i] = st[i];
+            for (int i = 0; i < 20; ++i) red[(wave * OPR + lane) * 20 + i] = st[i];
         }
-        (void)member; (void)TPG;
         __syncthreads();
-        if (tid < GRP * 40) {
-            const int gq = tid / 40, i = tid - gq * 40, c = i / 5, k = i - 5 * c;
-            const float v = red[(0 * GRP + gq) * 40 + i] + red[(1 * GRP + gq) * 40 + i] + red[(2 * GRP + gq) * 40 + i] + red[(3 * GRP + gq) * 40 + i];
+        if (tid < OPR * 20) {
+            const int pi = tid / 20, i = tid - pi * 20, c = i / 5, k = i - 5 * c;
+            const float v = red[(0 * OPR + pi) * 20 + i] + red[(1 * OPR + pi) * 20 + i] + red[(2 * OPR + pi) * 20 + i] + red[(3 * OPR + pi) * 20 + i];
             const int Cr = d0.stats_cr;
-            atomicAdd(d0.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + 8 * gq + c, v);
+            const int ch = 8 * (pi % (OPR / 2)) + (pi >= OPR / 2 ? 4 : 0) + c;
+            atomicAdd(d0.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + ch, v);
         }
     }
+    CT_T(7);
 }
 
 template <int C, int NS, int CO, int J, bool STATS, bool RES>
 static int ct_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, hipStream_t st) {
     constexpr int SLOT = (J + 2) * C * 2;
-    constexpr size_t lds = (size_t)NS * 4 * SLOT + (RES ? 4 * 4096 : 0) + 2 * 4096 + (STATS ? 4 * 2 * 40 * 4 : 0) + 64;
+    constexpr size_t lds = (size_t)NS * 8 * SLOT + (RES ? 8 * 4096 : 0) + 2 * 4096 + (STATS ? 4 * 2 * 40 * 4 : 0) + 64;
     static unsigned char state[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
@@ -268,13 +362,17 @@ static int ct_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, 
         state[dev] = e == hipSuccess ? 1 : 2;
     }
     if (state[dev] != 1) return 0;
-    static const int cpu_env = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 16;     // workgroups per utterance
-    int chunks = cpu_env > 0 ? cpu_env : 16;
+    // workgroups per utterance: two co-resident workgroups per CU (512 at B = 16) where the registers allow it -- one computes while
+    // the other stores / waits (decoder 4, encoder 2 / 1: 45 -> 36, 43 -> 34, 37 -> 27 us standalone); the 128-channel forward product
+    // keeps all 40 weight fragments in 160 registers, one workgroup per CU
+    static const int env_chunks = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 0;
+    int chunks = env_chunks > 0 ? env_chunks : (NS * C > 64 ? 16 : 32);
     if (chunks > a.TT) chunks = a.TT;
     const int fpw = (a.TT + chunks - 1) / chunks;
     chunks = (a.TT + fpw - 1) / fpw;
     sehip_note_kernel("convt_stream_kernel<%d, %d, %d, %d, %d, %d>", C, NS, CO, J, (int)STATS, (int)RES);
-    convt_stream_kernel<C, NS, CO, J, STATS, RES><<<B * chunks, 256, lds, st>>>(a, b, B, fpw);
+    static const int abl = getenv("SEHIP_CT_ABL") ? atoi(getenv("SEHIP_CT_ABL")) : 0;          // (read by tools builds only)
+    convt_stream_kernel<C, NS, CO, J, STATS, RES><<<B * chunks, 256, lds, st>>>(a, b, B, fpw, abl);
     return 1;
 }
 
