@@ -51,11 +51,17 @@ __device__ __forceinline__ ct_u4 ct_lds_read16(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+__device__ __forceinline__ ct_u2 ct_lds_read8(unsigned addr) {
+    ct_u2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
 __device__ __forceinline__ void ct_lds_write8(unsigned addr, ct_u2 v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ void ct_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // (macros, not functions: "+v" on an element of an array passed by reference is a "tied indirect register input" hipcc refuses)
+#define CT_WAIT1(a) do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define CT_WAIT3(a, b, c) do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // all LDS operations but the youngest n_ have completed (they return in order)
 #ifdef CT_NO_SCHED_BARRIER
@@ -70,9 +76,13 @@ __device__ __forceinline__ void ct_lds_wait() { asm volatile("s_waitcnt lgkmcnt(
 // ((r / 2) & 7 for 128-byte rows) is 2-way on every read whose first row is 2 mod 4; these two (found by exhaustive search over the
 // GF(2)-linear maps of the row index) are conflict-free for all three row taps, every 16-row tile and both channel slices.
 template <int C>
-__device__ __forceinline__ constexpr int ct_swz(int r) { return C == 64 ? (r & 6) : ((r >> 1) & 2); }
+__device__ __forceinline__ constexpr int ct_swz(int r) { return C == 64 ? (r & 6) : C == 32 ? ((r >> 1) & 2) : 0; }
+// (C == 16, two pieces per 32-byte row: the 16 rows of a group are 8 at piece 0 and 8 at piece 1, rows r and r + 8 -- the same banks --
+//  always on different pieces: conflict-free as stored)
 
-// C: channels per source (32 | 64), NS: sources (1 | 2), CO: output channels (16 | 32), J: input rows per frame, J * C == 2048.
+// C: channels per source (16 | 32 | 64), NS: sources (1 | 2), CO: output channels (2 | 16 | 32), J: input rows per frame, J * C == 2048.
+// CO == 2 (the network's last layer, src/model/dccrn.py:205-212: 16 + 16 channels -> the complex mask): W / bias padded to 16 rows, fp32
+// output [2 J rows][2], two 16-row tiles per wave.
 // STATS: ComplexBatchNorm sums of the output (forward layers); RES: a bf16 tensor of the output's shape is added (encoder input gradients)
 template <int C, int NS, int CO, int J, bool STATS, bool RES>
 __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_desc d0, const sehip_gemm_desc d1, int B, int fpw, int abl_) {
@@ -85,7 +95,12 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
 #else
     constexpr int abl = 0; (void)abl_;
 #endif
-    static_assert(J * C == 2048 && 2 * J * CO == 2048, "one 16-byte piece per thread and frame");
+    static_assert(J * C == 2048, "one 16-byte piece per thread and input frame");
+    constexpr bool F32OUT = CO == 2;
+    static_assert(F32OUT ? (!STATS && !RES && NS * C == 32) : 2 * J * CO == 2048, "output frame: 4 KB of bf16, or the fp32 mask");
+    constexpr int OUT_BYTES = 2 * J * CO * (F32OUT ? 4 : 2), OPB = OUT_BYTES / 256;          // bytes per output frame / per thread
+    static_assert(OPB == 16 || OPB == 8, "every thread stores once per frame (the vmcnt counts below are per wave)");
+    constexpr int CS = C >= 32 ? C / 32 : 1;           // 32-channel slices per source
     constexpr int PPR = C / 8;                         // 16-byte pieces per input row
     constexpr int SLOT = (J + 2) * C * 2;              // bytes of a frame image incl. the two zero rows
     constexpr int R = 8;                               // ring depth (frames in use: 2, in flight: 6)
@@ -93,8 +108,9 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     constexpr int KPT = NS * C / 32;                   // MFMA k steps per (time tap, row tap)
     constexpr int NF0 = 3, NF1 = 2;
     constexpr int NFR0 = 2 * NF0 * KPT, NFR1 = 2 * NF1 * KPT;
-    constexpr int NT = CO / 16;                        // 16-column tiles of the output
-    static_assert((J / 16) * NT == 4, "four waves: one (n tile, m tile) each");
+    constexpr int NT = CO >= 16 ? CO / 16 : 1;         // 16-column tiles of the output
+    constexpr int MTW = (J / 16) * NT / 4;             // 16-row tiles per wave: wave (wn, wm) owns rows 16 MTW wm .. of column tile wn
+    static_assert(MTW * 4 == (J / 16) * NT && (MTW == 1 || MTW == 2), "four waves share the (n tile, m tile) pairs evenly");
     constexpr int NSR = NS + (RES ? 1 : 0);            // DMA instructions per thread and step
     constexpr int IN_BYTES = NS * R * SLOT;
     constexpr int RES_OFF = IN_BYTES, OUT_OFF = RES_OFF + (RES ? R * 4096 : 0), RED_OFF = OUT_OFF + 2 * 4096;
@@ -154,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(NS == 2 ? d0.src[1].ptr : d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
     const sehip_dst& dd = d0.dst[0];
-    const unsigned obytes = 2u * (unsigned)(dd.F * dd.C);           // bytes per output frame (= 4096: dense rows, checked by the launcher)
-    bf16_raw* outp = reinterpret_cast<bf16_raw*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)(dd.F * dd.C);
+    const unsigned obytes = (F32OUT ? 4u : 2u) * (unsigned)(dd.F * dd.C);      // bytes per output frame (= OUT_BYTES: dense rows, checked by the launcher)
+    unsigned char* outp = reinterpret_cast<unsigned char*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)obytes;
     const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(RES ? d0.res : dd.ptr)), 0, CT_RECORDS, 0x00020000);
     const unsigned rbase = (unsigned)(b * dd.T + dd.toff) * obytes + 16u * (unsigned)tid;
@@ -185,17 +201,19 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
 
     // ---- B-operand fragment addresses: input row j + dtot (dtot = -1, 0, +1) of this lane's output row pair, piece q of the row
     // (q = 4 (channel slice of 32) + g); image row r = j + dtot + 1, piece permutation ct_swz(r)
-    const int j = 16 * wm + c16;
-    int aoff[3][C / 32];
+    // C == 16: the 32 k of a fragment are [source 0 | source 1], lane group g reads piece g & 1 of source g >> 1
+    int aoff[MTW][3][CS];
 #pragma unroll
-    for (int dd_ = 0; dd_ < 3; ++dd_) {
-        const int r = j + dd_;                         // = j + dtot + 1
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int cs = 0; cs < C / 32; ++cs) {
-            const int q = 4 * cs + g;
-            aoff[dd_][cs] = (r * PPR + (q ^ ct_swz<C>(r))) * 16;
+        for (int dd_ = 0; dd_ < 3; ++dd_) {
+            const int r = 16 * (MTW * wm + mt) + c16 + dd_;                     // = j + dtot + 1
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const int q = C == 16 ? (g & 1) : 4 * cs + g;
+                aoff[mt][dd_][cs] = (r * PPR + (q ^ ct_swz<C>(r))) * 16;
+            }
         }
-    }
     int dt[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { dt[s][0] = d0.cv_toff[s][0] - tmin[s]; dt[s][1] = d0.cv_toff[s][1] - tmin[s]; }
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     // ---- statistics: an output row is [CO / 2 real | CO / 2 imaginary] channels = OPR pieces of 8; the thread of piece pi and the
     // thread of its partner piece pi ^ (OPR / 2) (same 8 complex channels, other part) share the work: the real piece's thread takes
     // channels 0-3 of the 8, the imaginary piece's thread channels 4-7 -- 20 running sums per thread, every thread busy
-    constexpr int OPR = CO / 8;                        // pieces per output row
+    constexpr int OPR = CO >= 8 ? CO / 8 : 2;          // pieces per output row (unused for the fp32 mask)
     const bool im_thread = (tid % OPR) >= OPR / 2;
     float st[20];
 #pragma unroll
@@ -237,6 +255,13 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
         __builtin_amdgcn_s_barrier();
         CT_T(2);
         // ---- store phase: output frame i - 1 leaves (one 16-byte piece per thread), its statistics are taken
+        if (F32OUT) {
+            if (i > 0 && !(abl & 1)) {                 // the fp32 mask: 8 bytes per thread
+                ct_u2 l8 = ct_lds_read8(sm + OUT_OFF + ((i - 1) & 1) * 4096 + 8 * tid);
+                CT_WAIT1(l8);
+                if (!(abl & 16)) *reinterpret_cast<uint2*>(outp + (size_t)(t_lo + i - 1) * obytes + 8 * tid) = __builtin_bit_cast(uint2, l8);
+            }
+        } else
         if (i > 0 && !(abl & 1)) {
             const unsigned ot = sm + OUT_OFF + ((i - 1) & 1) * 4096;
             ct_u4 ld0 = ct_lds_read16(ot + 16 * tid);
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
                                     __uint_as_float(av[e] & 0xffff0000u) + __uint_as_float(rv[e] & 0xffff0000u));
                 v = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            if (!(abl & 16)) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(outp) + (size_t)(t_lo + i - 1) * obytes + 16 * tid) = v;
+            if (!(abl & 16)) *reinterpret_cast<uint4*>(outp + (size_t)(t_lo + i - 1) * obytes + 16 * tid) = v;
             if (STATS && !(abl & 8)) {
                 const uint4 vp = __builtin_bit_cast(uint4, ld1);
                 // words of channels 0-3 (real piece's thread) or 4-7 (imaginary piece's thread) of both parts
@@ -295,21 +320,25 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
         //  256 registers of two workgroups per CU.)
         constexpr int NFRAG = (2 * NF0 + 2 * NF1) * KPT, NU = NFRAG / 2, FR0 = 2 * NF0 * KPT;      // fragments, units, fragments of parity 0
         static_assert(NFRAG % 2 == 0 && FR0 % 2 == 0, "whole units per parity");
+        // A wave with two row tiles (MTW == 2) runs the 2 NU units of both through the same pipeline.
         ct_u4 xq[2][2];
-        auto rd1 = [&](int f) -> ct_u4 {
+        auto rd1 = [&](int fa) -> ct_u4 {
+            const int mt = fa / NFRAG, f = fa % NFRAG;
             const int gi = f / KPT, kk = f % KPT;
             const int p = gi >= 2 * NF0, w = gi - (p ? 2 * NF0 : 0), nf = p ? NF1 : NF0, kt = w / nf, di = w % nf;
             const int dtot = (p ? 0 : -1) + di + 1;                               // index into aoff: row tap -1, 0, +1 -> 0, 1, 2
-            // fragment kk of the group: source kk / (C / 32), channel slice kk % (C / 32)
-            return ct_lds_read16((kt ? sl1[kk / (C / 32)] : sl0[kk / (C / 32)]) + aoff[dtot][kk % (C / 32)]);
+            if (C == 16)           // both sources in one fragment: this lane's source is g >> 1
+                return ct_lds_read16(((g >> 1) ? (kt ? sl1[NS - 1] : sl0[NS - 1]) : (kt ? sl1[0] : sl0[0])) + aoff[mt][dtot][0]);
+            // fragment kk of the group: source kk / CS, channel slice kk % CS
+            return ct_lds_read16((kt ? sl1[kk / CS] : sl0[kk / CS]) + aoff[mt][dtot][kk % CS]);
         };
         xq[0][0] = rd1(0); xq[0][1] = rd1(1);
         f32x4 acc = bias0;
 #pragma unroll
-        for (int u = 0; u < NU && !(abl & 2); ++u) {
-            const int cur = u & 1;
-            if (u + 1 < NU) {
-                if (!(abl & 32)) { xq[cur ^ 1][0] = rd1(2 * u + 2); xq[cur ^ 1][1] = rd1(2 * u + 3); }
+        for (int ua = 0; ua < MTW * NU && !(abl & 2); ++ua) {
+            const int cur = ua & 1, mt = ua / NU, u = ua % NU;
+            if (ua + 1 < MTW * NU) {
+                if (!(abl & 32)) { xq[cur ^ 1][0] = rd1(2 * ua + 2); xq[cur ^ 1][1] = rd1(2 * ua + 3); }
                 CT_WAIT2N(2, xq[cur][0], xq[cur][1]);
             } else {
                 CT_WAIT2N(0, xq[cur][0], xq[cur][1]);
@@ -323,9 +352,14 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
             }
             if ((2 * u + 2 == FR0 || u == NU - 1) && !(abl & 256)) {
                 const int p = u == NU - 1;
+                const int j = 16 * (MTW * wm + mt) + c16;
                 // D rows = output channels 16 wn + 4 g .. + 3, column = input row j -> output row 2 j + p
-                ct_lds_write8(ot + ((2 * j + p) * CO + 16 * wn + 4 * g) * 2, ct_u2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])});
-                acc = bias1;
+                if (F32OUT) {                      // channels 0, 1 of the padded 16: lane group 0
+                    if (g == 0) ct_lds_write8(ot + (2 * j + p) * 8, ct_u2{__float_as_uint(acc[0]), __float_as_uint(acc[1])});
+                } else {
+                    ct_lds_write8(ot + ((2 * j + p) * CO + 16 * wn + 4 * g) * 2, ct_u2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])});
+                }
+                acc = p ? bias0 : bias1;
             }
         }
         CT_T(4);
@@ -394,7 +428,9 @@ int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, h
     static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr;
     if (disabled) return 0;
     if (a.cv_nf != 3 || b.cv_nf != 2 || a.cv_fadd != -1 || b.cv_fadd != 0 || a.fmul != 1 || b.fmul != 1) return 0;
-    if (a.tmul > 1 || b.tmul > 1 || a.J != b.J || a.TT != b.TT || a.M != b.M || a.N != b.N || a.Npad != b.Npad || a.N != a.Npad) return 0;
+    if (a.tmul > 1 || b.tmul > 1 || a.J != b.J || a.TT != b.TT || a.M != b.M || a.N != b.N || a.Npad != b.Npad) return 0;
+    const bool mask = a.N == 2 && a.Npad == 16;           // the last layer: 2 of 16 padded columns, fp32 destination
+    if (a.N != a.Npad && !mask) return 0;
     const int NS = a.src[1].ptr ? 2 : 1;
     if ((b.src[1].ptr ? 2 : 1) != NS || a.src[2].ptr) return 0;
     for (int s = 0; s < NS; ++s) {
@@ -409,11 +445,11 @@ int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, h
     if (a.K != 2 * 3 * NS * C || b.K != 2 * 2 * NS * C) return 0;
     // one dense bf16 destination shared by the two parities: rows 2 j + p of [B][T][2 J][CO]
     const sehip_dst &da = a.dst[0], &db = b.dst[0];
-    if (a.dst[1].ptr || b.dst[1].ptr || da.ptr != db.ptr || da.is_f32 || db.is_f32 || da.C != CO || da.F != 2 * J || da.T != db.T ||
+    if (a.dst[1].ptr || b.dst[1].ptr || da.ptr != db.ptr || (da.is_f32 != 0) != mask || (db.is_f32 != 0) != mask || da.C != CO || da.F != 2 * J || da.T != db.T ||
         da.toff != db.toff || da.fmul != 2 || db.fmul != 2 || da.fadd != 0 || db.fadd != 1 || da.tmul > 1 || db.tmul > 1) return 0;
     if (a.M % (a.TT * a.J)) return 0;
     const int B = a.M / (a.TT * a.J);
-    if ((long)B * da.T * da.F * da.C >= (1L << 30) - (1L << 20)) return 0;               // byte offsets below CT_RECORDS
+    if ((long)B * da.T * da.F * da.C >= (1L << 30) - (1L << 20)) return 0;               // byte offsets below CT_RECORDS (res: bf16)
     for (int s = 0; s < NS; ++s)
         if ((long)B * a.src[s].T * a.src[s].F * a.src[s].C >= (1L << 30) - (1L << 20)) return 0;
     // column table: dense, in order
@@ -423,15 +459,21 @@ int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, h
     if (stats && (a.stats != b.stats || a.stats_cr * 2 != CO || a.res || b.res)) return 0;
     const bool res = a.res != nullptr;
     if (res && (a.res != b.res || stats || a.bias || b.bias)) return 0;
-    if (!stats && !res) return 0;            // (the two uses built: forward with sums, input gradient with the skip gradient)
+    if (!stats && !res && !mask) return 0;   // (the uses built: forward with sums, input gradient with the skip gradient, the mask layer)
+    if (mask && (stats || res)) return 0;
     if ((((uintptr_t)a.W | (uintptr_t)b.W) & 15) || (a.bias && (((uintptr_t)a.bias | (uintptr_t)b.bias) & 15))) return 0;
-    if (dry) return (C == 64 && CO == 32 && J == 32) || (C == 32 && CO == 16 && J == 64);
-#define CT_CASE(C_, NS_, CO_, J_, ST_, RS_) \
-    if (C == C_ && NS == NS_ && CO == CO_ && J == J_ && stats == ST_ && res == RS_) return ct_launch<C_, NS_, CO_, J_, ST_, RS_>(a, b, B, st);
+    if (dry) return (C == 64 && CO == 32 && J == 32) || (C == 32 && CO == 16 && J == 64) || (mask && C == 16 && NS == 2 && J == 128);
+    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bit per variant below, for A/B timing
+    int bit = 1;
+#define CT_CASE(C_, NS_, CO_, J_, ST_, RS_)                                                      \
+    if (C == C_ && NS == NS_ && CO == CO_ && J == J_ && stats == ST_ && res == RS_)              \
+        return (skip & bit) ? 0 : ct_launch<C_, NS_, CO_, J_, ST_, RS_>(a, b, B, st);           \
+    bit <<= 1;
     CT_CASE(64, 2, 32, 32, true, false)      // decoder 3 forward
     CT_CASE(32, 2, 16, 64, true, false)      // decoder 4 forward
     CT_CASE(64, 1, 32, 32, false, true)      // encoder 2 input gradient
     CT_CASE(32, 1, 16, 64, false, true)      // encoder 1 input gradient
+    CT_CASE(16, 2, 2, 128, false, false)     // decoder 5 forward: the mask
 #undef CT_CASE
     return 0;
 }
