@@ -394,6 +394,258 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     CT_T(7);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// convs_stream_kernel: the same streaming construction for the stride-2 products with 16 input channels -- "two input rows per output
+// row": the forward pass of encoder 1 (ComplexConv2d 16 -> 32 channels, src/model/dccrn.py:316-384, with the ComplexBatchNorm sums)
+// and the input gradient of decoder 4 (ComplexConvTranspose2d, :387-450: 16 -> 32 + 32 channels, the second half to the skip
+// connection's gradient tensor).  One source, five row taps at input rows 2 j - 2 .. 2 j + 2, two time taps.
+//   * an input frame ([2 J rows][C] = 4 KB, one DMA piece per thread) lands as TWO PLANES -- even rows, odd rows, each [J + 2][C] with
+//     zero rows at both ends -- so that the 16 output rows of a fragment read touch 16 CONSECUTIVE plane rows (tap kf: plane kf & 1,
+//     plane row j + (kf >> 1)): conflict-free exactly as the frame image above (a stride-2 read of one image would be 4-way);
+//   * K is ordered (time tap, row tap, channel): with 16 channels an MFMA k step is two consecutive taps of that order -- lane groups
+//     0 / 1 read the first tap's two pieces, 2 / 3 the second's -- five k steps, no padding;
+//   * a wave owns one 16-row tile and ALL output channels (2 or 4 column tiles: 5 fragment reads feed 10 / 20 MFMAs; weights in
+//     40 / 80 registers); two destinations = the two channel halves, each a 4 KB frame = one 16-byte store per thread.
+// NDST: destinations (1: forward, bias + sums; 2: input gradient).
+template <int C, int CO, int J, int NDST, bool STATS>
+__global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_desc d0, int B, int fpw) {
+    static_assert(C == 16 && 2 * J * C == 2048 && J * CO * 2 == 4096 * NDST && J == 64, "4 KB frames in, 4 KB per destination out, four row tiles");
+    static_assert(!STATS || NDST == 1, "sums: the forward product");
+    constexpr int PPR = C / 8;                         // 16-byte pieces per row (2)
+    constexpr int PLANE = (J + 2) * C * 2;             // bytes of one parity plane incl. its zero rows
+    constexpr int SLOT = 2 * PLANE;
+    constexpr int R = 8, D = R - 2;
+    constexpr int NFRAG = 2 * 5 * C / 32;              // MFMA k steps (5)
+    constexpr int NTW = CO / 16;                       // column tiles (all of them per wave)
+    constexpr int OUT_OFF = R * SLOT, RED_OFF = OUT_OFF + 2 * NDST * 4096;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    const int TT = d0.TT;
+    const int chunks = (TT + fpw - 1) / fpw;
+    const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
+    const int t_lo = ck * fpw, t_hi = min(TT, t_lo + fpw);
+    const int nout = t_hi - t_lo;
+    if (nout <= 0 || b >= B) return;
+
+    // ---- zero rows of every plane (plane rows 0 and J + 1; never written by the DMA)
+    for (int i = tid; i < R * 2 * 2 * PPR; i += 256) {
+        const int pl = i / (2 * PPR), rr = (i / PPR) & 1, q = i % PPR;
+        *reinterpret_cast<uint4*>(smem + pl * PLANE + (rr ? (J + 1) * C * 2 : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // ---- weight fragments: rows n = 16 nt + c16, k chunk 32 f + 8 g
+    bf16x8 w[NTW][NFRAG];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const bf16_raw* W = reinterpret_cast<const bf16_raw*>(d0.W) + (size_t)(16 * nt + c16) * d0.K + 8 * g;
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) w[nt][f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W + 32 * f));
+    }
+    f32x4 bias[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) bias[nt] = d0.bias ? *reinterpret_cast<const f32x4*>(d0.bias + 16 * nt + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- DMA: waves 0, 1 fill the even plane's J data rows, waves 2, 3 the odd plane's (1 KB per wave instruction)
+    const int plane_w = wave >> 1;
+    const int pp = (wave & 1) * 64 + lane;             // piece position inside the plane's data rows
+    const int rho = pp / PPR, qs = pp % PPR;           // plane row (0-based data row), piece
+    const unsigned piece_off = 2u * (unsigned)((2 * rho + plane_w) * C + (qs ^ ct_swz<C>(rho + 1)) * 8);
+    const sehip_src& S = d0.src[0];
+    const int tmin = min(d0.cv_toff[0][0], d0.cv_toff[0][1]);
+    const unsigned fbytes = 2u * (unsigned)(S.F * S.C);
+    const unsigned sbase = (unsigned)(b * S.T) * fbytes;
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+    auto issue = [&](int v) {
+        const int u = t_lo + tmin + v;
+        const bool ok = u >= S.tlo && u < S.thi && v <= nout;
+        const unsigned vo = ok ? sbase + (unsigned)u * fbytes + piece_off : CT_OOB;
+        unsigned char* dst = smem + (v & (R - 1)) * SLOT + plane_w * PLANE + C * 2 + (wave & 1) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+    };
+    unsigned char* outp[NDST];
+    unsigned obytes[NDST];
+#pragma unroll
+    for (int q = 0; q < NDST; ++q) {
+        const sehip_dst& dd = q ? d0.dst[1] : d0.dst[0];
+        obytes[q] = 2u * (unsigned)(dd.F * dd.C);
+        outp[q] = reinterpret_cast<unsigned char*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)obytes[q] + 16 * tid;
+    }
+
+    // ---- fragment addresses: k step f, lane group g: flattened tap tau = 2 f + (g >> 1) = 5 kt + kf, piece g & 1
+    const int j = 16 * wave + c16;
+    int foff[NFRAG];                                   // offset inside a ring slot
+    bool second[NFRAG];                                // time tap kt of this lane's half of the k step
+#pragma unroll
+    for (int f = 0; f < NFRAG; ++f) {
+        const int tau = 2 * f + (g >> 1), kt = tau / 5, kf = tau - 5 * kt;
+        const int r = j + (kf >> 1);                   // plane row incl. the leading zero row
+        foff[f] = (kf & 1) * PLANE + (r * PPR + ((g & 1) ^ ct_swz<C>(r))) * 16;
+        second[f] = kt != 0;
+    }
+    const int dt0 = d0.cv_toff[0][0] - tmin, dt1 = d0.cv_toff[0][1] - tmin;
+
+    constexpr int OPR = CO / 8;
+    const bool im_thread = (tid % OPR) >= OPR / 2;
+    float st[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) st[i] = 0.f;
+
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v <= D; ++v) issue(v);
+
+    for (int i = 0; i <= nout; ++i) {
+        // exact count: the D - 1 younger DMA pieces and the NDST stores of each step since (convt_stream_kernel)
+        switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
+            case 0: ct_wait_vm<(D - 1) + 0 * NDST>(); break;
+            case 1: ct_wait_vm<(D - 1) + 1 * NDST>(); break;
+            case 2: ct_wait_vm<(D - 1) + 2 * NDST>(); break;
+            case 3: ct_wait_vm<(D - 1) + 3 * NDST>(); break;
+            case 4: ct_wait_vm<(D - 1) + 4 * NDST>(); break;
+            default: ct_wait_vm<(D - 1) + (D - 1) * NDST>(); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- store phase: output frame i - 1
+        if (i > 0) {
+            const unsigned ot = sm + OUT_OFF + ((i - 1) & 1) * (NDST * 4096);
+            ct_u4 ld0 = ct_lds_read16(ot + 16 * tid);
+            ct_u4 ld1 = (STATS || NDST == 2) ? ct_lds_read16(STATS ? ot + 16 * (tid ^ (OPR / 2)) : ot + 4096 + 16 * tid) : ct_u4{0u, 0u, 0u, 0u};
+            CT_WAIT2N(0, ld0, ld1);
+            const uint4 v = __builtin_bit_cast(uint4, ld0);
+            *reinterpret_cast<uint4*>(outp[0] + (size_t)(t_lo + i - 1) * obytes[0]) = v;
+            if (NDST == 2) *reinterpret_cast<uint4*>(outp[NDST - 1] + (size_t)(t_lo + i - 1) * obytes[NDST - 1]) = __builtin_bit_cast(uint4, ld1);
+            if (STATS) {
+                const uint4 vp = __builtin_bit_cast(uint4, ld1);
+                const unsigned own[2] = {im_thread ? v.z : v.x, im_thread ? v.w : v.y}, oth[2] = {im_thread ? vp.z : vp.x, im_thread ? vp.w : vp.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned ar = im_thread ? oth[e] : own[e], ai = im_thread ? own[e] : oth[e];
+                    const float yr[2] = {__uint_as_float(ar << 16), __uint_as_float(ar & 0xffff0000u)};
+                    const float yi[2] = {__uint_as_float(ai << 16), __uint_as_float(ai & 0xffff0000u)};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = 2 * e + h;
+                        st[5 * c] += yr[h]; st[5 * c + 1] += yi[h];
+                        st[5 * c + 2] += yr[h] * yr[h]; st[5 * c + 3] += yr[h] * yi[h]; st[5 * c + 4] += yi[h] * yi[h];
+                    }
+                }
+            }
+        }
+        if (i == nout) break;
+        // ---- compute phase: output frame i; all five fragments are requested at once (20 registers), each column tile's MFMAs follow
+        const unsigned ot = sm + OUT_OFF + (i & 1) * (NDST * 4096);
+        const unsigned sl0 = sm + ((i + dt0) & (R - 1)) * SLOT, sl1 = sm + ((i + dt1) & (R - 1)) * SLOT;
+        ct_u4 x0 = ct_lds_read16((second[0] ? sl1 : sl0) + foff[0]);
+        ct_u4 x1 = ct_lds_read16((second[1] ? sl1 : sl0) + foff[1]);
+        ct_u4 x2 = ct_lds_read16((second[2] ? sl1 : sl0) + foff[2]);
+        ct_u4 x3 = ct_lds_read16((second[3] ? sl1 : sl0) + foff[3]);
+        ct_u4 x4 = ct_lds_read16((second[4] ? sl1 : sl0) + foff[4]);
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = bias[nt];
+        CT_WAIT2N(3, x0, x1);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][0], __builtin_bit_cast(bf16x8, x0), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][1], __builtin_bit_cast(bf16x8, x1), acc[nt], 0, 0, 0);
+        }
+        CT_WAIT2N(1, x2, x3);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][2], __builtin_bit_cast(bf16x8, x2), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][3], __builtin_bit_cast(bf16x8, x3), acc[nt], 0, 0, 0);
+        }
+        CT_WAIT1(x4);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][4], __builtin_bit_cast(bf16x8, x4), acc[nt], 0, 0, 0);
+            // D rows = output channels 16 nt + 4 g .. + 3 of output row j; destination q holds channels q CO / NDST ..
+            constexpr int CD = CO / NDST;              // channels per destination
+            const int ch = 16 * nt + 4 * g, q = ch / CD;
+            ct_lds_write8(ot + q * 4096 + (j * CD + (ch - q * CD)) * 2, ct_u2{pack_bf2(acc[nt][0], acc[nt][1]), pack_bf2(acc[nt][2], acc[nt][3])});
+        }
+        issue(i + D + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after the workgroup has given its LDS back
+
+    if (STATS) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [4 waves][OPR][20]
+#pragma unroll
+        for (int i = 0; i < 20; ++i)
+#pragma unroll
+            for (int o = OPR; o < 64; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
+        if (lane < OPR) {
+#pragma unroll
+            for (int i = 0; i < 20; ++i) red[(wave * OPR + lane) * 20 + i] = st[i];
+        }
+        __syncthreads();
+        if (tid < OPR * 20) {
+            const int pi = tid / 20, i = tid - pi * 20, c = i / 5, k = i - 5 * c;
+            const float v = red[(0 * OPR + pi) * 20 + i] + red[(1 * OPR + pi) * 20 + i] + red[(2 * OPR + pi) * 20 + i] + red[(3 * OPR + pi) * 20 + i];
+            const int Cr = d0.stats_cr;
+            const int ch = 8 * (pi % (OPR / 2)) + (pi >= OPR / 2 ? 4 : 0) + c;
+            atomicAdd(d0.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + ch, v);
+        }
+    }
+}
+
+template <int C, int CO, int J, int NDST, bool STATS>
+static int cs_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)8 * 2 * (J + 2) * C * 2 + 2 * NDST * 4096 + (STATS ? 4 * (CO / 8) * 20 * 4 : 0) + 64;
+    static unsigned char state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convs_stream_kernel<C, CO, J, NDST, STATS>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    static const int env_chunks = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 0;
+    int chunks = env_chunks > 0 ? env_chunks : 32;
+    if (chunks > a.TT) chunks = a.TT;
+    const int fpw = (a.TT + chunks - 1) / chunks;
+    chunks = (a.TT + fpw - 1) / fpw;
+    sehip_note_kernel("convs_stream_kernel<%d, %d, %d, %d, %d>", C, CO, J, NDST, (int)STATS);
+    convs_stream_kernel<C, CO, J, NDST, STATS><<<B * chunks, 256, lds, st>>>(a, B, fpw);
+    return 1;
+}
+
+// returns 1 if the product was launched (dry: would be), 0 if it does not qualify (the caller goes on to conv_small2 / the generic kernels)
+int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) {
+    static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr;
+    if (disabled || a.w_tiled) return 0;
+    if (a.cv_nf != 5 || a.cv_fadd != -2 || a.fmul != 2 || a.tmul > 1 || a.N != a.Npad || a.res) return 0;
+    if (a.src[1].ptr || !a.src[0].ptr) return 0;
+    const sehip_src& x = a.src[0];
+    const int C = x.C, CO = a.N, J = a.J;
+    if (x.F != 2 * J || a.K != (2 * 5 * C + 63) / 64 * 64 || abs(a.cv_toff[0][0] - a.cv_toff[0][1]) != 1) return 0;     // (K: padded to 64, zero weights)
+    if (a.M % (a.TT * a.J)) return 0;
+    const int B = a.M / (a.TT * a.J);
+    if ((long)B * x.T * x.F * x.C >= (1L << 30) - (1L << 20)) return 0;                     // byte offsets below CT_RECORDS
+    const int ndst = a.dst[1].ptr ? 2 : 1;
+    for (int q = 0; q < ndst; ++q) {                      // dense bf16 destinations of CO / ndst channels, row j -> row j
+        const sehip_dst& dq = a.dst[q];
+        if (dq.is_f32 || dq.C * ndst != CO || dq.F != J || dq.fmul != 1 || dq.fadd != 0 || dq.tmul > 1) return 0;
+    }
+    // (the column table is the plan's dense one: first CO / ndst columns to destination 0, the rest to destination 1, in order)
+    const bool stats = a.stats != nullptr;
+    if (stats && (ndst != 1 || a.stats_cr * 2 != CO)) return 0;
+    if (ndst == 1 && !stats) return 0;                    // (the uses built: forward with sums, two-destination input gradient)
+    if (ndst == 2 && a.bias) return 0;
+    if (((uintptr_t)a.W & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
+    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bits 32, 64: these two variants
+    if (C == 16 && CO == 32 && J == 64 && ndst == 1) return (skip & 32) ? 0 : dry ? 1 : cs_launch<16, 32, 64, 1, true>(a, B, st);
+    if (C == 16 && CO == 64 && J == 64 && ndst == 2) return (skip & 64) ? 0 : dry ? 1 : cs_launch<16, 64, 64, 2, false>(a, B, st);
+    return 0;
+}
+
 template <int C, int NS, int CO, int J, bool STATS, bool RES>
 static int ct_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, hipStream_t st) {
     constexpr int SLOT = (J + 2) * C * 2;

@@ -640,6 +640,7 @@ void sehip_conv2_init(void);
 int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st);   // conv3.hip
 void sehip_conv3_init(void);
 int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
+int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry);   // convt.hip
 void sehip_wgrad3_init(void);
 int sehip_try_dense_wgrad(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 
@@ -1552,6 +1553,10 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("gemm", d)) return e;
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
     hipStream_t st = (hipStream_t)stream;
+    if (sehip_try_convs_stream(*d, st, false)) {
+        SEHIP_CHECK_LAUNCH("gemm(convs-stream)");
+        return 0;
+    }
     if (d->stats) {   // only the LDS-DMA convolution kernel accumulates the BatchNorm statistics (sehip.h): no silent omission
         if (sehip_try_conv_gemm_v3(*d, st) || (!d->w_tiled && sehip_try_conv_gemm_v2(*d, st)) || (!d->w_tiled && (try_conv_small(*d, nullptr, st) || try_conv_narrow(*d, st)))) {
             SEHIP_CHECK_LAUNCH("gemm(conv+stats)");
@@ -1608,6 +1613,7 @@ int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, h
 extern "C" int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b) {
     if (!a) return 0;
     if (b && sehip_try_convt_stream(*a, *b, nullptr, true)) return 1;
+    if (!b && sehip_try_convs_stream(*a, nullptr, true)) return 1;
     if (try_conv_small(*a, b, nullptr, true)) return 1;
     return b ? 0 : try_conv_narrow(*a, nullptr, true);          // (2-channel input: conv_narrow_kernel)
 }
