@@ -241,6 +241,18 @@ typedef struct {
      * (floats between two splits' arrays; 0 = all splits add to the same dW with fp32 atomics, the default) and adds the arrays in
      * split order afterwards.  Set by the library on its own copy of the descriptor; callers leave it 0. */
     int64_t dw_split_stride;
+    /* Optional (sehip_wgrad, products whose source has 2 channels: the first encoder layer, src/model/dccrn.py:139-167): dOut is not
+     * read from dst[0] but COMPUTED on the way in as the backward pass of ComplexBatchNorm + PReLU (src/model/dccrn.py:457-634) --
+     * what sehip_cbn_bwd_apply would have stored there -- from bn_dz (the gradient that arrives at the activation's output) and bn_y
+     * (the convolution's own output), both bf16 tensors laid out exactly as dst[0] describes, with the layer's forward coefficient
+     * records (bn_coef: sehip_cbn_finalize), backward records (bn_bcoef: sehip_cbn_bwd_finalize) and PReLU slope (bn_slope).  Nobody
+     * else reads that layer's dOut (there is no input gradient), so the tensor is never written: 84 MB less traffic per step.
+     * dst[0].ptr may then be NULL.  sehip_wgrad fails loudly when the product does not qualify for the kernel that can do this. */
+    const void* bn_dz;
+    const void* bn_y;
+    const float* bn_coef;
+    const float* bn_bcoef;
+    const float* bn_slope;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);

@@ -729,3 +729,256 @@ int sehip_try_convt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, h
 #undef CT_CASE
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wgrads_stream_kernel: the WEIGHT GRADIENT of the stride-2 small-channel convolutions (encoder 1 / 2, src/model/dccrn.py:316-384
+// backward: dW[co][(kt, kf, ci)] = sum over (b, t, j) of dOut[b][t][j][co] * x[b][t + dt_kt][2 j + kf - 2][ci]) by the same streaming
+// construction.  conv_small_wgrad_kernel ran these at 1.8 TB/s with 4-8 % of the MFMA busy (descriptor-generic staging through
+// registers); they sit at the very end of the weight-gradient stream, where the step waits for them.
+//   * a workgroup owns a run of frames of one utterance and keeps its WHOLE dW (32 x 160 or 64 x 320 fp32) in the accumulators of its
+//     four waves for the whole launch -- wave (m group, n group): CO / 32 row tiles x 5 C / 16 column tiles; at the end it stores them as
+//     one row of a partial array, which ws_reduce_kernel adds into dW / dbias (no atomics: 512 workgroups x 5 120 atomics on 320 cache
+//     lines would queue);
+//   * per frame one 4 KB dOut frame and one 4 KB input frame arrive by LDS-DMA (one piece per thread each, ring of 8, counted vmcnt,
+//     one barrier per frame); the input frame as two parity planes, so that row tap kf is plane kf & 1 at plane row j + (kf >> 1);
+//   * the contraction runs over ROWS: both MFMA operands are transposed reads (ds_read_b64_tr_b16: 4 rows x 16 channels per 16 lanes).
+//     The images are laid out for exactly that read -- 8 rows x 32 bytes per half wave must cover the 64 banks once: 32-byte rows
+//     (16 channels) permuted r -> r ^ ((r >> 3) & 1) << 2, 64-byte rows with their two 32-byte halves swapped on rows with bit 3 set,
+//     128-byte rows with the 32-byte quarter XORed by ((r >> 1) & 1) | ((r >> 3) & 1) << 1 -- all three exhaustively checked for every
+//     first row; plain row-major images are 2- to 4-way.
+//   * dbias = column sums of dOut: one more MFMA per row tile and k step against a register of ones (the n group 0 waves).
+template <int RB>
+__device__ __forceinline__ constexpr int ws_rowbyte(int r) {        // byte offset of (row r, 32-byte unit 0) incl. the unit swizzle (units: XOR 32 t later)
+    return RB == 32 ? (r ^ (((r >> 3) & 1) << 2)) * 32 : RB == 64 ? r * 64 + ((r >> 3) & 1) * 32 : r * 128 + ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) * 32);
+}
+__device__ __forceinline__ ct_u2 ws_tr_read(unsigned addr) {
+    ct_u2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// (volatile asm statements keep their order: a register tied behind the wait is not consumed in front of it)
+#define WS_TIE(v) asm volatile("" : "+v"(v))
+#define WS_ONES __builtin_bit_cast(bf16x8, ct_u4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u})
+
+// C: input channels (16 | 32), CO: output channels (32 | 64), J: output rows per frame (64 | 32); 2 J C == J CO == 2048
+template <int C, int CO, int J>
+__global__ __launch_bounds__(256, 2) void wgrads_stream_kernel(const sehip_gemm_desc d0, int B, int fpw, float* __restrict__ parts, int row_len) {
+    static_assert(2 * J * C == 2048 && J * CO == 2048 && (J == 32 || J == 64), "4 KB frames");
+    constexpr int RBX = 2 * C, RBG = 2 * CO;           // bytes per image row
+    constexpr int PLANE = (J + 2) * RBX, SLOTX = 2 * PLANE;
+    constexpr int R = 8, D = R - 2;
+    constexpr int KS = J / 32;                         // MFMA k steps per frame
+    constexpr int MTW = CO / 32;                       // row tiles (16 output channels) per wave: two m groups
+    constexpr int CSN = C / 16;                        // column tiles per (time tap, row tap)
+    constexpr int NTW = 5 * CSN;                       // column tiles per wave: n group = time tap kt
+    constexpr int G_OFF = R * SLOTX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wmg = wave & 1, kt = wave >> 1;          // this wave: row tiles MTW wmg .., the five row taps of time tap kt
+    const int g = lane >> 4, i16 = lane & 15;
+    const int TT = d0.TT;
+    const int chunks = (TT + fpw - 1) / fpw;
+    const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
+    const int t_lo = ck * fpw, t_hi = min(TT, t_lo + fpw);
+    const int nout = t_hi - t_lo;
+    if (b >= B) return;
+
+    // ---- zero rows of every plane (plane rows 0 and J + 1: both keep their place under the row permutation)
+    for (int i = tid; i < R * 2 * 2 * (RBX / 16); i += 256) {
+        const int pl = i / (2 * (RBX / 16)), rr = (i / (RBX / 16)) & 1, q = i % (RBX / 16);
+        *reinterpret_cast<uint4*>(smem + pl * PLANE + (rr ? (J + 1) * RBX : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // ---- DMA pieces.  Input frame: waves 0, 1 fill the even plane's J data rows (plane rows 1 .. J), waves 2, 3 the odd plane's;
+    // LDS position -> (plane row, 16-byte piece) by the inverse of the image's layout
+    const int plane_w = wave >> 1;
+    unsigned x_off, g_off;                             // source byte offsets inside a frame
+    {
+        const int pos = (wave & 1) * 64 + lane;        // 16-byte position inside the plane's data rows
+        const int prow_s = 1 + pos / (RBX / 16), q_s = pos % (RBX / 16);          // physical plane row slot, piece slot
+        int rho, q;
+        if (RBX == 32) { rho = prow_s ^ (((prow_s >> 3) & 1) << 2); q = q_s; }     // (an involution that keeps bit 3)
+        else { rho = prow_s; q = q_s ^ (((rho >> 3) & 1) << 1); }                  // 64-byte rows: halves (2 pieces) swapped
+        x_off = 2u * (unsigned)((2 * (rho - 1) + plane_w) * C + q * 8);
+        const int gp = tid;                            // 16-byte position inside the dOut frame image
+        const int grow = gp / (RBG / 16), gq_s = gp % (RBG / 16);
+        const int gq = RBG == 64 ? gq_s ^ (((grow >> 3) & 1) << 1) : gq_s ^ ((((grow >> 1) & 1) | (((grow >> 3) & 1) << 1)) << 1);
+        g_off = 2u * (unsigned)(grow * CO + gq * 8);
+    }
+    const sehip_src& S = d0.src[0];
+    const sehip_dst& Gd = d0.dst[0];
+    const int tmin = min(d0.cv_toff[0][0], d0.cv_toff[0][1]);
+    const unsigned xfbytes = 2u * (unsigned)(S.F * S.C), gfbytes = 2u * (unsigned)(Gd.F * Gd.C);
+    const unsigned xbase = (unsigned)(b * S.T) * xfbytes, gbase = (unsigned)(b * Gd.T + Gd.toff) * gfbytes;
+    const __amdgpu_buffer_rsrc_t rsx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_RECORDS, 0x00020000);
+    // issue(v): input frame v of the run (source frame t_lo + tmin + v) and dOut frame v (t_lo + v); two instructions per call
+    auto issue = [&](int v) {
+        const int u = t_lo + tmin + v;
+        const bool okx = u >= S.tlo && u < S.thi && v <= nout;
+        const unsigned vx = okx ? xbase + (unsigned)u * xfbytes + x_off : CT_OOB;
+        unsigned char* dx = smem + (v & (R - 1)) * SLOTX + plane_w * PLANE + RBX + (wave & 1) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (ct_lds_void*)dx, 16, vx, 0, 0, 0);
+        const bool okg = v < nout;
+        const unsigned vg = okg ? gbase + (unsigned)(t_lo + v) * gfbytes + g_off : CT_OOB;
+        unsigned char* dg = smem + G_OFF + (v & (R - 1)) * 4096 + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, 0);
+    };
+
+    // ---- transposed-read addresses of this lane: row (first row of the 8-row group + 4 h + (i16 >> 2)), 8-byte chunk i16 & 3
+    unsigned preG[KS][2], preX[KS][3][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 32 * ks + 8 * g + 4 * h + (i16 >> 2);
+            preG[ks][h] = (unsigned)(ws_rowbyte<RBG>(r) + 8 * (i16 & 3));
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh) preX[ks][sh][h] = (unsigned)(ws_rowbyte<RBX>(r + sh) + 8 * (i16 & 3));
+        }
+    const int dtk = d0.cv_toff[0][kt] - tmin;          // this wave's time tap: input frame i + dtk of the run
+
+    f32x4 acc[MTW][NTW], accb[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        accb[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v <= D; ++v) issue(v);
+    for (int i = 0; i < nout; ++i) {
+        ct_wait_vm<(D - 1) * 2>();                     // batch i + 1 (and every older one) has landed; no stores in this loop
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned gs = sm + G_OFF + (i & (R - 1)) * 4096;
+        const unsigned xs = sm + ((i + dtk) & (R - 1)) * SLOTX;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // every transposed read of the k step is requested, then one wait, then the MFMAs (two workgroups per CU fill the gap)
+            // A operands: dOut^T, row tile mt (16 channels = 32-byte unit MTW wmg + mt of the row)
+            ct_u2 al[MTW], ah[MTW], xl[NTW], xh[NTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const unsigned ux = (unsigned)((MTW * wmg + mt) * 32);
+                al[mt] = ws_tr_read(gs + (preG[ks][0] ^ ux));
+                ah[mt] = ws_tr_read(gs + (preG[ks][1] ^ ux));
+            }
+            // B operands: row tap kf = plane kf & 1, plane rows + (kf >> 1); column tile cs = unit cs of the row
+#pragma unroll
+            for (int kf = 0; kf < 5; ++kf)
+#pragma unroll
+                for (int cs = 0; cs < CSN; ++cs) {
+                    const unsigned pb = xs + (kf & 1) * PLANE;
+                    const unsigned ux = (unsigned)(cs * 32);
+                    xl[kf * CSN + cs] = ws_tr_read(pb + (preX[ks][kf >> 1][0] ^ ux));
+                    xh[kf * CSN + cs] = ws_tr_read(pb + (preX[ks][kf >> 1][1] ^ ux));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) { WS_TIE(al[mt]); WS_TIE(ah[mt]); }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) { WS_TIE(xl[nt]); WS_TIE(xh[nt]); }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 af[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                af[mt] = __builtin_bit_cast(bf16x8, ct_u4{al[mt].x, al[mt].y, ah[mt].x, ah[mt].y});
+                if (kt == 0) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], WS_ONES, accb[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, ct_u4{xl[nt].x, xl[nt].y, xh[nt].x, xh[nt].y});
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], xf, acc[mt][nt], 0, 0, 0);
+            }
+        }
+        issue(i + D + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after the workgroup has given its LDS back
+
+    // ---- this workgroup's row of the partial array: [CO][10 C] sums, then [CO] column sums of dOut
+    float* out = parts + (size_t)blockIdx.x * row_len;
+    constexpr int KV = 10 * C;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int co = 16 * (MTW * wmg + mt) + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int k = kt * 5 * C + nt * 16 + i16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[(size_t)(co + e) * KV + k] = acc[mt][nt][e];
+        }
+        if (kt == 0 && i16 == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[(size_t)CO * KV + co + e] = accb[mt][e];
+        }
+    }
+}
+
+// rows of the partial array ([nparts][co * kv + co]) -> dW ([co][K], K >= kv: the padded columns are left alone) and dbias
+__global__ __launch_bounds__(256) void ws_reduce_kernel(const float* __restrict__ parts, int nparts, int row_len, int co, int kv, int K,
+                                                        float* __restrict__ dW, float* __restrict__ dbias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_len) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < nparts; ++p) s += parts[(size_t)p * row_len + i];
+    if (i < co * kv) dW[(size_t)(i / kv) * K + (i % kv)] += s;
+    else if (dbias) dbias[i - co * kv] += s;
+}
+
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
+
+template <int C, int CO, int J>
+static int wgs_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)8 * 2 * (J + 2) * 2 * C + 8 * 4096 + 64;
+    static unsigned char state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrads_stream_kernel<C, CO, J>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    // workgroups per utterance: the launch runs on the weight-gradient stream beside the chain, and every workgroup stores (and the
+    // reduction re-reads) a whole dW: 8 x 16 utterances = 128 workgroups
+    static const int env_chunks = getenv("SEHIP_WGS_CHUNKS") ? atoi(getenv("SEHIP_WGS_CHUNKS")) : 0;
+    int chunks = env_chunks > 0 ? env_chunks : 8;
+    if (chunks > a.TT) chunks = a.TT;
+    const int fpw = (a.TT + chunks - 1) / chunks;
+    chunks = (a.TT + fpw - 1) / fpw;
+    const int grid = B * chunks, row_len = CO * 10 * C + CO;
+    float* parts = sehip_wgrad_scratch(st, (size_t)grid * row_len * sizeof(float));
+    if (!parts) return 0;                                // (inside a stream capture before the pool exists: the generic kernel)
+    sehip_note_kernel("wgrads_stream_kernel<%d, %d, %d>", C, CO, J);
+    wgrads_stream_kernel<C, CO, J><<<grid, 256, lds, st>>>(a, B, fpw, parts, row_len);
+    ws_reduce_kernel<<<(row_len + 255) / 256, 256, 0, st>>>(parts, grid, row_len, CO, 10 * C, a.K, a.dW, a.dbias);
+    return 1;
+}
+
+// returns 1 if the weight gradient was launched, 0 if the product does not qualify (the caller goes on to conv_small_wgrad_kernel)
+int sehip_try_wgrads_stream(const sehip_gemm_desc& a, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr || getenv("SEHIP_NO_WGRAD_STREAM") != nullptr;
+    if (disabled || sehip_deterministic()) return 0;     // (the deterministic schedule keeps its one kernel family: csrc/gemm.hip)
+    if (a.cv_nf != 5 || a.cv_fadd != -2 || a.fmul != 2 || a.tmul > 1 || a.N != a.Npad || a.bn_dz || a.cv2_nkt) return 0;
+    if (a.src[1].ptr || !a.src[0].ptr || a.dst[1].ptr || !a.dW) return 0;
+    const sehip_src& x = a.src[0];
+    const sehip_dst& gd = a.dst[0];
+    const int C = x.C, CO = a.N, J = a.J;
+    if (x.F != 2 * J || a.K != (2 * 5 * C + 63) / 64 * 64 || abs(a.cv_toff[0][0] - a.cv_toff[0][1]) != 1) return 0;
+    if (gd.is_f32 || gd.C != CO || gd.F != J || gd.fmul != 1 || gd.fadd != 0 || gd.tmul > 1) return 0;
+    if (a.M % (a.TT * a.J)) return 0;
+    const int B = a.M / (a.TT * a.J);
+    if ((long)B * x.T * x.F * x.C >= (1L << 30) - (1L << 20) || (long)B * gd.T * gd.F * gd.C >= (1L << 30) - (1L << 20)) return 0;
+    if (C == 16 && CO == 32 && J == 64) return wgs_launch<16, 32, 64>(a, B, st);
+    if (C == 32 && CO == 64 && J == 32) return wgs_launch<32, 64, 32>(a, B, st);
+    return 0;
+}

@@ -641,6 +641,7 @@ int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st);   // conv3
 void sehip_conv3_init(void);
 int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry);   // convt.hip
+int sehip_try_wgrads_stream(const sehip_gemm_desc& a, hipStream_t st);            // convt.hip
 void sehip_wgrad3_init(void);
 int sehip_try_dense_wgrad(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 
@@ -2579,7 +2580,12 @@ __device__ __forceinline__ void narrow_wgrad_add(const sehip_gemm_desc& d, int e
 // (dwords FMUL rows apart, the channel's half picked with v_perm) -- 12 MFMAs and ~80 LDS / VALU instructions per frame
 // instead of ~1 300 VALU instructions, so the launch is bound by reading dOut (the VALU kernel above: 68 us at the headline
 // shape, 5x its HBM time; it stays for frames that are not a multiple of 32 rows).
-template <int NF, int FMUL>
+// BN (sehip_gemm_desc.bn_dz ...): dOut is the ComplexBatchNorm + PReLU backward pass's output (cbn_bwd_apply_kernel's arithmetic, in
+// its order, rounded to bf16 as that kernel stores it) computed while the frame is staged: a lane fetches the same 16-byte pieces of
+// bn_dz and bn_y it would have fetched of dOut, trades them with the lane that holds the row's other part (real | imaginary: lane ^ 1)
+// and writes its half of the row's eight complex channels.  The 8 channels' forward records are wave-uniform, the five backward
+// coefficients of a lane's part live in 40 registers.
+template <int NF, int FMUL, bool BN>
 __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const sehip_gemm_desc d, int FRA, int fa, int frames_total,
                                                                            float* __restrict__ parts /* [workgroups][12][64] or NULL */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2595,8 +2601,25 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
 
     const int sT = d.src[0].T, sF = d.src[0].F;
     const bf16_raw* xsrc = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
-    const bf16_raw* gsrc = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr);
+    const bf16_raw* gsrc = reinterpret_cast<const bf16_raw*>(BN ? d.bn_dz : d.dst[0].ptr);
+    const bf16_raw* ysrc = reinterpret_cast<const bf16_raw*>(d.bn_y);
     const int gpieces = J * 2;              // 16-byte pieces of a dOut frame (8 channels each)
+    float4 bn_zc[BN ? 8 : 1], bn_mb[BN ? 8 : 1];   // forward records of the 8 complex channels (COEF_STRIDE = 16 floats per channel)
+    float bn_p[BN ? 8 : 1][5];                     // this lane's part of the backward records: out = p0 dr + p1 di + p2 cr + p3 ci + p4
+    float bn_a = 0.f;
+    if (BN) {
+        bn_a = d.bn_slope[0];
+        const bool im = lane & 1;                   // piece index = lane + 64 u: its part is the lane's parity
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            bn_zc[c] = reinterpret_cast<const float4*>(d.bn_coef)[4 * c];
+            bn_mb[c] = reinterpret_cast<const float4*>(d.bn_coef)[4 * c + 1];
+            const float4 A = reinterpret_cast<const float4*>(d.bn_bcoef)[4 * c], E = reinterpret_cast<const float4*>(d.bn_bcoef)[4 * c + 1];
+            const float ki = d.bn_bcoef[16 * c + 8];
+            bn_p[c][0] = im ? A.z : A.x; bn_p[c][1] = im ? A.w : A.y; bn_p[c][2] = im ? E.y : E.x; bn_p[c][3] = im ? E.z : E.y;
+            bn_p[c][4] = im ? ki : E.w;
+        }
+    }
     const int xpieces = FRA >> 2;           // 16-byte pieces (4 rows x 2 ch) of one input frame
     constexpr int GPL = 4, XPL = 2;         // pieces per lane: J <= 128, FRA <= 512
 
@@ -2605,7 +2628,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
 
     const int wave_id = blockIdx.x * NW_WAVES + w, nwaves = gridDim.x * NW_WAVES;
     uint4 grA[GPL], xrA[2][XPL], grB[GPL], xrB[2][XPL];     // two frames in flight per wave
-#define NWM_FETCH(fr_, gr, xr)                                                                                             \
+    uint4 yrA[BN ? GPL : 1], yrB[BN ? GPL : 1];
+#define NWM_FETCH(fr_, gr, xr, yr)                                                                                 \
     {                                                                                                              \
         const int b_ = (fr_) / d.TT, t_ = (fr_) - b_ * d.TT;                                                       \
         _Pragma("unroll") for (int u = 0; u < GPL; ++u) {                                                          \
@@ -2615,6 +2639,7 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
                 const int j = idx >> 1, h = idx & 1;                                                               \
                 const long off = (((long)b_ * d.dst[0].T + t_ + d.dst[0].toff) * d.dst[0].F + (long)j * d.dst[0].fmul + d.dst[0].fadd) * d.dst[0].C; \
                 gr[u] = *reinterpret_cast<const uint4*>(gsrc + off + 8 * h);                                       \
+                if (BN) yr[u] = *reinterpret_cast<const uint4*>(ysrc + off + 8 * h);                               \
             }                                                                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                            \
@@ -2636,12 +2661,41 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
         }                                                                                                          \
     }
 
-    auto stage = [&](const uint4 (&gr)[GPL], const uint4 (&xr)[2][XPL]) {
+    auto stage = [&](const uint4 (&gr)[GPL], const uint4 (&xr)[2][XPL], const uint4 (&yr)[BN ? GPL : 1]) {
         // registers -> this wave's LDS region (only this wave reads it: no barrier, the LDS pipe is in order per wave)
 #pragma unroll
         for (int u = 0; u < GPL; ++u) {
             const int idx = lane + 64 * u;
-            if (idx < gpieces) *reinterpret_cast<uint4*>(&sG[(idx >> 1) * 16 + 8 * (idx & 1)]) = gr[u];
+            uint4 go = gr[u];
+            if (BN) {
+                // (every lane takes part in the exchange: gpieces is even, so a lane and its partner are inside or outside together)
+                const unsigned gm[4] = {gr[u].x, gr[u].y, gr[u].z, gr[u].w}, ym[4] = {yr[u].x, yr[u].y, yr[u].z, yr[u].w};
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned gp = (unsigned)__shfl_xor((int)gm[e], 1, 64), yp = (unsigned)__shfl_xor((int)ym[e], 1, 64);
+                    const bool im = lane & 1;
+                    const unsigned g_re = im ? gp : gm[e], g_im = im ? gm[e] : gp, y_re = im ? yp : ym[e], y_im = im ? ym[e] : yp;
+                    float ov[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int c = 2 * e + hh;
+                        const float xr_ = hh ? __uint_as_float(y_re & 0xffff0000u) : __uint_as_float(y_re << 16);
+                        const float xi_ = hh ? __uint_as_float(y_im & 0xffff0000u) : __uint_as_float(y_im << 16);
+                        float dr = hh ? __uint_as_float(g_re & 0xffff0000u) : __uint_as_float(g_re << 16);
+                        float di = hh ? __uint_as_float(g_im & 0xffff0000u) : __uint_as_float(g_im << 16);
+                        const float cr = xr_ - bn_mb[c].x, ci = xi_ - bn_mb[c].y;
+                        const float vr = bn_zc[c].x * cr + bn_zc[c].y * ci + bn_mb[c].z;
+                        const float vi = bn_zc[c].z * cr + bn_zc[c].w * ci + bn_mb[c].w;
+                        if (!(vr > 0.f)) dr *= bn_a;
+                        if (!(vi > 0.f)) di *= bn_a;
+                        ov[hh] = bn_p[c][0] * dr + bn_p[c][1] * di + bn_p[c][2] * cr + bn_p[c][3] * ci + bn_p[c][4];
+                    }
+                    o[e] = pack_bf2(ov[0], ov[1]);
+                }
+                go = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            if (idx < gpieces) *reinterpret_cast<uint4*>(&sG[(idx >> 1) * 16 + 8 * (idx & 1)]) = go;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -2674,15 +2728,15 @@ __global__ __launch_bounds__(64 * NW_WAVES) void narrow_wgrad_mfma_kernel(const 
         asm volatile("" ::: "memory");
     };
     int fr = wave_id;
-    if (fr < frames_total) NWM_FETCH(fr, grA, xrA)
-    if (fr + nwaves < frames_total) NWM_FETCH(fr + nwaves, grB, xrB)
+    if (fr < frames_total) NWM_FETCH(fr, grA, xrA, yrA)
+    if (fr + nwaves < frames_total) NWM_FETCH(fr + nwaves, grB, xrB, yrB)
     for (; fr < frames_total; fr += 2 * nwaves) {
-        stage(grA, xrA);
-        if (fr + 2 * nwaves < frames_total) NWM_FETCH(fr + 2 * nwaves, grA, xrA)
+        stage(grA, xrA, yrA);
+        if (fr + 2 * nwaves < frames_total) NWM_FETCH(fr + 2 * nwaves, grA, xrA, yrA)
         multiply();
         if (fr + nwaves >= frames_total) break;
-        stage(grB, xrB);
-        if (fr + 3 * nwaves < frames_total) NWM_FETCH(fr + 3 * nwaves, grB, xrB)
+        stage(grB, xrB, yrB);
+        if (fr + 3 * nwaves < frames_total) NWM_FETCH(fr + 3 * nwaves, grB, xrB, yrB)
         multiply();
     }
 #undef NWM_FETCH
@@ -2738,6 +2792,8 @@ static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_NARROW") != nullptr;
     if (disabled || d.cv_nf <= 0 || d.src[0].C != 2 || d.src[1].ptr || d.dst[1].ptr) return 0;
     if (d.N != 16 || d.Npad != 16 || d.J > 128 || d.K < 32 || d.cv_nf > 8) return 0;
+    const bool bn = d.bn_dz != nullptr;
+    if (bn && (!d.bn_y || !d.bn_coef || !d.bn_bcoef || !d.bn_slope || d.dst[0].C != 16 || d.dst[0].tmul > 1)) return 0;
     if (d.dst[0].is_f32 || (d.dst[0].C & 7)) return 0;
     const int FR = (d.J - 1) * d.fmul + d.cv_nf;
     const int fa = (d.cv_fadd >= 0 ? d.cv_fadd / 4 : -((-d.cv_fadd + 3) / 4)) * 4;
@@ -2760,10 +2816,12 @@ static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
         sehip_note_kernel("narrow_wgrad_mfma_kernel<%d>", d.cv_nf);
         static const bool atomic_flush = getenv("SEHIP_NARROW_ATOMIC_FLUSH") != nullptr;
         float* parts = atomic_flush ? nullptr : sehip_wgrad_scratch(st, (size_t)grid * 768 * sizeof(float));
-        narrow_wgrad_mfma_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames, parts);
+        if (bn) narrow_wgrad_mfma_kernel<5, 2, true><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames, parts);
+        else narrow_wgrad_mfma_kernel<5, 2, false><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames, parts);
         if (parts) narrow_wgrad_reduce_kernel<5><<<48, 256, 0, st>>>(d, parts, grid);
         return 1;
     }
+    if (bn) return 0;                                   // (only the MFMA build computes dOut on the way in: sehip_wgrad reports it)
     sehip_note_kernel("narrow_wgrad_kernel<%d>", d.cv_nf);
     narrow_wgrad_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
     return 1;
@@ -2778,6 +2836,8 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
         SEHIP_CHECK_LAUNCH("wgrad(narrow)");
         return 0;
     }
+    SEHIP_REQUIRE(d->bn_dz == nullptr, "wgrad: dOut computed from bn_dz / bn_y (sehip.h) is built into narrow_wgrad_mfma_kernel only, and this "
+                                        "product does not qualify for it (2-channel source, 16 outputs, 5 row taps at stride 2, J a multiple of 32)");
     const bool det = sehip_deterministic() != 0;
     // (deterministic schedule: conv_wgrad_v3's bias sums and conv_wgrad2 / dense_wgrad flush with plain atomics: those products take
     //  the kernels below, which keep one array per m-split)
@@ -2792,6 +2852,10 @@ extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {
     }
     if (!det && try_conv_wgrad2(*d, st)) {
         SEHIP_CHECK_LAUNCH("wgrad(conv2)");
+        return 0;
+    }
+    if (sehip_try_wgrads_stream(*d, st)) {
+        SEHIP_CHECK_LAUNCH("wgrad(stream)");
         return 0;
     }
     if (int r = try_conv_small_wgrad(*d, st)) {

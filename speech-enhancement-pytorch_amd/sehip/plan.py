@@ -45,12 +45,20 @@ class CGemmDesc(C.Structure):
                 ("tmul", C.c_int32), ("cv_nf", C.c_int32), ("cv_fadd", C.c_int32), ("cv_toff", (C.c_int32 * 2) * 2),
                 ("res", C.c_void_p), ("stats", C.c_void_p), ("stats_cr", C.c_int32), ("cv2_nkt", C.c_int32), ("cv2_nf", C.c_int32),
                 ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32), ("wg_hint", C.c_int32), ("dense_rows", C.c_int32),
-                ("dw_split_stride", C.c_int64)]
+                ("dw_split_stride", C.c_int64),
+                ("bn_dz", C.c_void_p), ("bn_y", C.c_void_p), ("bn_coef", C.c_void_p), ("bn_bcoef", C.c_void_p),
+                ("bn_slope", C.c_void_p)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient
 # (descriptor field `res`), so the BatchNorm backward kernels read one gradient tensor instead of two.
 FUSE_SKIP_GRAD = not os.environ.get("SEHIP_NO_FUSE_SKIP")
+# SEHIP_FUSE_ENC0_BN=1: the first encoder layer's BatchNorm backward apply pass runs inside its weight gradient (sehip_gemm_desc.bn_dz,
+# csrc/gemm.hip narrow_wgrad_mfma_kernel): nobody else reads that layer's dOut, 84 MB less traffic.  Built, tested
+# (tests/test_gpu_enc0_bn_wgrad.py) and 15-20 us SLOWER in the step (3.61 against 3.59 ms, same box): the fused kernel carries ~600 vector
+# instructions per frame on the chain's last launches, where the two plain passes overlap with the tail of the weight-gradient
+# stream.  Opt-in.  Needs the skip gradient already added (FUSE_SKIP_GRAD).
+FUSE_ENC0_BN_WGRAD = FUSE_SKIP_GRAD and bool(os.environ.get("SEHIP_FUSE_ENC0_BN"))
 # Products that conv_gemm_v3 takes get their packed weights in its tile order (the switches that take the kernel away keep [Npad][K])
 # the apply pass of a layer with fused sums also finalizes them (sehip_cbn_finalize_apply_n)
 # (read when a workspace is built: DCCRNWorkspace.fuse_finalize / fuse_bwd_finalize / BWD_REPLICAS rows of backward sums)
@@ -843,6 +851,10 @@ class DCCRNWorkspace:
             self.l2_gran_f = torch.zeros(int(lib_.sehip_lstm2_gran_bytes(B, T, 0)) // 8, dtype=torch.int64, device=device)
             self.l2_gran_b = torch.zeros(int(lib_.sehip_lstm2_gran_bytes(B, T, 1)) // 8, dtype=torch.int64, device=device)
             self.l2_sync = torch.zeros(int(lib_.sehip_lstm2_sync_bytes()) // 4, dtype=torch.int32, device=device)
+        # (two-launch BatchNorm backward -- SEHIP_FUSE_BWD_FINALIZE -- leaves no record array to read)
+        # (the kernel that can: 16 outputs, output rows a multiple of 32 and at most 128 -- csrc/gemm.hip try_narrow_wgrad)
+        self.enc0_bn_in_wgrad = (FUSE_ENC0_BN_WGRAD and not self.fuse_bwd_finalize and int(st.cfg.kernel_num[1]) == 16
+                                 and (st.F0 >> 1) % 32 == 0 and (st.F0 >> 1) <= 128)
         self._bind()
 
     def close(self):
@@ -929,6 +941,11 @@ class DCCRNWorkspace:
                     gb = self.bufs[gname]
                     w.dst[0].ptr = gb.ptr
                     w.dst[0].is_f32 = 0
+                if name == "enc0.fwd" and self.enc0_bn_in_wgrad:
+                    zb, yb, gb = self.bufs["dz0"], self.bufs["y0"], self.bufs["dye0"]
+                    assert (zb.Tst, zb.F, zb.C) == (gb.Tst, gb.F, gb.C) == (yb.Tst, yb.F, yb.C) and zb.t.dtype == yb.t.dtype == BF16
+                    w.bn_dz, w.bn_y = zb.ptr, yb.ptr
+                    w.bn_coef, w.bn_bcoef = ptr(self.bn_coef["encoder.0."]), ptr(self.bn_bcoef)     # (bn_slope: set per call, from params)
                 self.desc[name + ".wg"] = w
         # 32-output layers: fused BatchNorm sums if the small-channel kernel takes the forward product(s) as the step launches them
         # (encoder: one product; decoder: the pair of output-row parities)
@@ -1087,7 +1104,7 @@ class DCCRNWorkspace:
              1 if training else 0, ptr(coef), stream())
         call("sehip_cbn_apply", y.ptr, ptr(coef), pp("2.weight"), rows, cr, z.ptr, stream())
 
-    def bn_backward(self, pre, cr, dz, dz2, y, dy, params, tfirst):
+    def bn_backward(self, pre, cr, dz, dz2, y, dy, params, tfirst, apply=True):
         rows = y.t.numel() // (2 * cr)
         L, st = self.st.layout, self.st
         pp = lambda k: params.data_ptr() + 4 * L.param_off[pre + k][0]
@@ -1113,6 +1130,8 @@ class DCCRNWorkspace:
              ptr(self.bn_acc), stream())
         call("sehip_cbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
              g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
+        if not apply:        # the consumer applies the records itself (enc0's weight gradient)
+            return
         call("sehip_cbn_bwd_apply", dz.ptr, dz2p, y.ptr, ptr(coef), ptr(self.bn_bcoef), pp("2.weight"), rows, cr, y.F,
              y.Tst, tfirst, dy.ptr, stream())
 
@@ -1295,7 +1314,12 @@ class DCCRNWorkspace:
         for i in range(5, -1, -1):
             dz = b["dz5l"] if i == 5 else b[f"dz{i}"]
             dz2 = b[f"dskip{i}"] if (i == 5 or not FUSE_SKIP_GRAD) else None   # enc{i+1}.dg0/dg1 already added it (res)
-            self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, dz2, b[f"y{i}"], b[f"dye{i}"], params, 0)
+            in_wgrad = i == 0 and self.enc0_bn_in_wgrad and dz2 is None
+            self.bn_backward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, dz, dz2, b[f"y{i}"], b[f"dye{i}"], params, 0, apply=not in_wgrad)
+            if i == 0:
+                wd = self.desc["enc0.fwd.wg"]
+                wd.bn_dz = dz.ptr if in_wgrad else None
+                wd.bn_slope = params.data_ptr() + 4 * self.st.layout.param_off["encoder.0.2.weight"][0] if in_wgrad else None
             self.wgrad(f"enc{i}.fwd")
             if i > 0:
                 self.gemm_pair(f"enc{i}.dg0", f"enc{i}.dg1")     # one streaming launch for the outer layers (csrc/convt.hip), else the two products
