@@ -276,6 +276,10 @@ int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* st
 int sehip_conv_small_takes(const sehip_gemm_desc* a, const sehip_gemm_desc* b /* or NULL */);
 /* weight gradient: dW[n][k] += sum_m dOut[m][n] * A[m][k]; dOut is addressed through dst/ntab (bf16 only) */
 int sehip_wgrad(const sehip_gemm_desc* desc, void* stream);
+/* The weight gradients of two products over the same sources and the same dOut tensor (the two output-row parities of a transposed
+ * convolution, src/model/dccrn.py:387-450; descriptors as sehip_gemm_pair's with dW / dbias set and dst[0] = dOut): one launch that
+ * reads every frame once where the streaming kernel takes the pair, otherwise the two sehip_wgrad calls. */
+int sehip_wgrad_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream);
 /* n (<= 16) plain weight-gradient products (no convolution description, Npad a multiple of 128: the LSTM input / recurrent
  * products of src/model/dccrn.py:264-302) in ONE launch.  prepare copies the descriptors and their block table into dev_buf
  * (sehip_wgrad_group_bytes(n) bytes of device memory; synchronous, once per binding) and returns the grid size; the launch

@@ -73,6 +73,7 @@ _PROTOS = {
     "sehip_gemm": [P, P],
     "sehip_gemm_pair": [P, P, P],
     "sehip_wgrad": [P, P],
+    "sehip_wgrad_pair": [P, P, P],
     "sehip_wgrad_group_bytes": [I],
     "sehip_wgrad_group_prepare": [P, I, P, P],
     "sehip_wgrad_group": [P, I, I, P],

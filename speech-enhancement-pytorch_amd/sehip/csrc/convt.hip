@@ -982,3 +982,280 @@ int sehip_try_wgrads_stream(const sehip_gemm_desc& a, hipStream_t st) {
     if (C == 32 && CO == 64 && J == 32) return wgs_launch<32, 64, 32>(a, B, st);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wgradt_stream_kernel: the weight gradients of BOTH output-row parities of an outer transposed convolution (decoder 3 / 4,
+// src/model/dccrn.py:387-450 backward) in one streaming launch:
+//   dW_p[co][(kt, d, s, ci)] = sum over (b, t, j) of dOut[b][t][2 j + p][co] * x_s[b][t + toff_s(kt)][j + d][ci],  d in {-1, 0, 1} (p = 0) | {0, 1} (p = 1)
+// Same construction as wgrads_stream_kernel with the roles of the planes swapped: the dOut frame ([2 J][CO], 4 KB) lands as two parity
+// planes, each source frame ([J][C], 4 KB) as one image with a zero row at both ends; wave (kt, s) owns time tap kt of source s for
+// both parities -- its three shifted B operands (rows j - 1, j, j + 1) serve five taps (three of parity 0, two of parity 1), every
+// fragment read once: 32 transposed reads for 40 MFMAs per k step at the 64-channel width.  Ring of 4 frames per tensor (two
+// workgroups per CU at 51 KB each), three DMA pieces per thread and frame.
+// (the 64-channel variant holds 160 accumulator registers: one workgroup per CU -- the launch has 128 workgroups)
+template <int C, int CO, int J>
+__global__ __launch_bounds__(256, (C * CO >= 2048 ? 1 : 2)) void wgradt_stream_kernel(const sehip_gemm_desc d0, const sehip_gemm_desc d1, int B, int fpw,
+                                                                float* __restrict__ parts, int row_len) {
+    static_assert(J * C == 2048 && 2 * J * CO == 2048 && (J == 32 || J == 64), "4 KB frames");
+    constexpr int RBX = 2 * C, RBG = 2 * CO;           // bytes per image row
+    constexpr int SLOTX = (J + 2) * RBX;
+    constexpr int R = 4, D = R - 2;
+    constexpr int KS = J / 32, MT = CO / 16, CSN = C / 16;
+    constexpr int G_OFF = 2 * R * SLOTX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt = wave >> 1, s_w = wave & 1;          // this wave: time tap kt of source s_w
+    const int g = lane >> 4, i16 = lane & 15;
+    const int TT = d0.TT;
+    const int chunks = (TT + fpw - 1) / fpw;
+    const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
+    const int t_lo = ck * fpw, t_hi = min(TT, t_lo + fpw);
+    const int nout = t_hi - t_lo;
+    if (b >= B) return;
+
+    // ---- zero rows of every source image (rows 0 and J + 1)
+    for (int i = tid; i < 2 * R * 2 * (RBX / 16); i += 256) {
+        const int sl = i / (2 * (RBX / 16)), rr = (i / (RBX / 16)) & 1, q = i % (RBX / 16);
+        *reinterpret_cast<uint4*>(smem + sl * SLOTX + (rr ? (J + 1) * RBX : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // ---- DMA pieces: LDS position -> (row, 16-byte piece) by the inverse of the images' layouts (ws_rowbyte)
+    unsigned x_off, g_off;
+    {
+        const int prow_s = 1 + tid / (RBX / 16), q_s = tid % (RBX / 16);           // image row slot (1 .. J), piece slot
+        const int fx = RBX == 64 ? ((prow_s >> 3) & 1) : (((prow_s >> 1) & 1) | (((prow_s >> 3) & 1) << 1));
+        x_off = 2u * (unsigned)((prow_s - 1) * C + (q_s ^ (fx << 1)) * 8);
+        const int pl = tid >> 7, pp = tid & 127;       // plane (2 KB each), position inside it
+        const int pr_s = pp / (RBG / 16), gq_s = pp % (RBG / 16);
+        int grow, gq;
+        if (RBG == 32) { grow = pr_s ^ (((pr_s >> 3) & 1) << 2); gq = gq_s; }
+        else { grow = pr_s; gq = gq_s ^ (((grow >> 3) & 1) << 1); }
+        g_off = 2u * (unsigned)((2 * grow + pl) * CO + gq * 8);
+    }
+    const sehip_dst& Gd = d0.dst[0];
+    int tmin[2];
+    unsigned xfbytes[2], xbase[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const sehip_src& S = s ? d0.src[1] : d0.src[0];
+        tmin[s] = min(d0.cv_toff[s][0], d0.cv_toff[s][1]);
+        xfbytes[s] = 2u * (unsigned)(S.F * S.C);
+        xbase[s] = (unsigned)(b * S.T) * xfbytes[s];
+    }
+    const unsigned gfbytes = 2u * (unsigned)(Gd.F * Gd.C);
+    const unsigned gbase = (unsigned)(b * Gd.T + Gd.toff) * gfbytes;
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[1].ptr)), 0, CT_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_RECORDS, 0x00020000);
+    // issue(v): frame v of the run of both sources (source frame t_lo + tmin_s + v) and dOut frame t_lo + v: three instructions
+    auto issue = [&](int v) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const sehip_src& S = s ? d0.src[1] : d0.src[0];
+            const int u = t_lo + tmin[s] + v;
+            const bool ok = u >= S.tlo && u < S.thi && v <= nout;
+            const unsigned vo = ok ? xbase[s] + (unsigned)u * xfbytes[s] + x_off : CT_OOB;
+            unsigned char* dst = smem + (s * R + (v & (R - 1))) * SLOTX + RBX + wave * 1024;
+            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+        }
+        const bool okg = v < nout;
+        const unsigned vg = okg ? gbase + (unsigned)(t_lo + v) * gfbytes + g_off : CT_OOB;
+        unsigned char* dg = smem + G_OFF + (v & (R - 1)) * 4096 + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, 0);
+    };
+
+    unsigned preG[KS][2], preX[KS][3][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 32 * ks + 8 * g + 4 * h + (i16 >> 2);
+            preG[ks][h] = (unsigned)(ws_rowbyte<RBG>(r) + 8 * (i16 & 3));
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh) preX[ks][sh][h] = (unsigned)(ws_rowbyte<RBX>(r + sh) + 8 * (i16 & 3));
+        }
+    const int dtk = (s_w ? d0.cv_toff[1][kt] - tmin[1] : d0.cv_toff[0][kt] - tmin[0]);
+
+    f32x4 acc0[MT][3 * CSN], acc1[MT][2 * CSN], accb[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        accb[0][mt] = accb[1][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 3 * CSN; ++nt) acc0[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 2 * CSN; ++nt) acc1[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v <= D; ++v) issue(v);
+    for (int i = 0; i < nout; ++i) {
+        ct_wait_vm<(D - 1) * 3>();                     // batch i + 1 (and every older one) has landed; no stores in this loop
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned gs = sm + G_OFF + (i & (R - 1)) * 4096;
+        const unsigned xs = sm + (s_w * R + ((i + dtk) & (R - 1))) * SLOTX;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ct_u2 al[2][MT], ah[2][MT], xl[3][CSN], xh[3][CSN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const unsigned ux = (unsigned)(mt * 32);
+                    al[p][mt] = ws_tr_read(gs + p * 2048 + (preG[ks][0] ^ ux));
+                    ah[p][mt] = ws_tr_read(gs + p * 2048 + (preG[ks][1] ^ ux));
+                }
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh)
+#pragma unroll
+                for (int cs = 0; cs < CSN; ++cs) {
+                    const unsigned ux = (unsigned)(cs * 32);
+                    xl[sh][cs] = ws_tr_read(xs + (preX[ks][sh][0] ^ ux));
+                    xh[sh][cs] = ws_tr_read(xs + (preX[ks][sh][1] ^ ux));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { WS_TIE(al[p][mt]); WS_TIE(ah[p][mt]); }
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh)
+#pragma unroll
+                for (int cs = 0; cs < CSN; ++cs) { WS_TIE(xl[sh][cs]); WS_TIE(xh[sh][cs]); }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 af[2][MT];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    af[p][mt] = __builtin_bit_cast(bf16x8, ct_u4{al[p][mt].x, al[p][mt].y, ah[p][mt].x, ah[p][mt].y});
+                    if (wave == 0) accb[p][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][mt], WS_ONES, accb[p][mt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh)
+#pragma unroll
+                for (int cs = 0; cs < CSN; ++cs) {
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, ct_u4{xl[sh][cs].x, xl[sh][cs].y, xh[sh][cs].x, xh[sh][cs].y});
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        // rows j + d = image rows j + sh: parity 0 tap q = sh (d = sh - 1), parity 1 tap q = sh - 1 (d = sh - 1 >= 0)
+                        acc0[mt][sh * CSN + cs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], xf, acc0[mt][sh * CSN + cs], 0, 0, 0);
+                        if (sh >= 1) acc1[mt][(sh - 1) * CSN + cs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mt], xf, acc1[mt][(sh - 1) * CSN + cs], 0, 0, 0);
+                    }
+                }
+        }
+        issue(i + D + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after the workgroup has given its LDS back
+
+    // ---- this workgroup's row of the partial array: [CO][12 C] (parity 0), [CO][8 C] (parity 1), [CO] + [CO] column sums of dOut
+    float* out = parts + (size_t)blockIdx.x * row_len;
+    constexpr int KA = 12 * C, KB = 8 * C;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = 16 * mt + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int cs = 0; cs < CSN; ++cs) {
+                const int k = ((kt * 3 + q) * 2 + s_w) * C + cs * 16 + i16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(size_t)(co + e) * KA + k] = acc0[mt][q * CSN + cs][e];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int cs = 0; cs < CSN; ++cs) {
+                const int k = ((kt * 2 + q) * 2 + s_w) * C + cs * 16 + i16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(size_t)CO * KA + (size_t)(co + e) * KB + k] = acc1[mt][q * CSN + cs][e];
+            }
+        if (wave == 0 && i16 == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                out[(size_t)CO * (KA + KB) + co + e] = accb[0][mt][e];
+                out[(size_t)CO * (KA + KB) + CO + co + e] = accb[1][mt][e];
+            }
+        }
+    }
+}
+
+// rows of the pair's partial array -> the two dW ([co][ka], [co][kb]: no padded columns at these widths) and dbias
+__global__ __launch_bounds__(256) void ws_reduce2_kernel(const float* __restrict__ parts, int nparts, int row_len, int co, int ka, int kb,
+                                                         float* __restrict__ dWa, float* __restrict__ dWb, float* __restrict__ dba,
+                                                         float* __restrict__ dbb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_len) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < nparts; ++p) s += parts[(size_t)p * row_len + i];
+    if (i < co * ka) dWa[i] += s;
+    else if (i < co * (ka + kb)) dWb[i - co * ka] += s;
+    else if (i < co * (ka + kb) + co) { if (dba) dba[i - co * (ka + kb)] += s; }
+    else if (dbb) dbb[i - co * (ka + kb) - co] += s;
+}
+
+template <int C, int CO, int J>
+static int wgt_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 4 * (J + 2) * 2 * C + 4 * 4096 + 64;
+    static unsigned char state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradt_stream_kernel<C, CO, J>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    static const int env_chunks = getenv("SEHIP_WGS_CHUNKS") ? atoi(getenv("SEHIP_WGS_CHUNKS")) : 0;
+    int chunks = env_chunks > 0 ? env_chunks : 8;
+    if (chunks > a.TT) chunks = a.TT;
+    const int fpw = (a.TT + chunks - 1) / chunks;
+    chunks = (a.TT + fpw - 1) / fpw;
+    const int grid = B * chunks, row_len = CO * 20 * C + 2 * CO;
+    float* parts = sehip_wgrad_scratch(st, (size_t)grid * row_len * sizeof(float));
+    if (!parts) return 0;
+    sehip_note_kernel("wgradt_stream_kernel<%d, %d, %d>", C, CO, J);
+    wgradt_stream_kernel<C, CO, J><<<grid, 256, lds, st>>>(a, b, B, fpw, parts, row_len);
+    ws_reduce2_kernel<<<(row_len + 255) / 256, 256, 0, st>>>(parts, grid, row_len, CO, 12 * C, 8 * C, a.dW, b.dW, a.dbias, b.dbias);
+    return 1;
+}
+
+// the weight gradients of the two parity products of a transposed convolution (descriptors as sehip_gemm_pair's, dst[0] = dOut):
+// 1 if launched, 0 if the pair does not qualify (the caller launches the two weight gradients one by one)
+int sehip_try_wgradt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, hipStream_t st) {
+    static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr || getenv("SEHIP_NO_WGRAD_STREAM") != nullptr;
+    if (disabled || sehip_deterministic()) return 0;
+    if (a.cv_nf != 3 || b.cv_nf != 2 || a.cv_fadd != -1 || b.cv_fadd != 0 || a.fmul != 1 || b.fmul != 1) return 0;
+    if (a.tmul > 1 || b.tmul > 1 || a.J != b.J || a.TT != b.TT || a.M != b.M || a.N != b.N || a.Npad != b.Npad || a.N != a.Npad) return 0;
+    if (!a.dW || !b.dW || a.bn_dz || b.bn_dz || a.cv2_nkt || b.cv2_nkt) return 0;
+    if (!a.src[1].ptr || !b.src[1].ptr || a.src[2].ptr) return 0;
+    for (int s = 0; s < 2; ++s) {
+        const sehip_src &x = a.src[s], &y = b.src[s];
+        if (x.ptr != y.ptr || x.T != y.T || x.F != y.F || x.C != y.C || x.tlo != y.tlo || x.thi != y.thi) return 0;
+        if (x.F != a.J || x.C != a.src[0].C) return 0;
+        for (int kt = 0; kt < 2; ++kt)
+            if (a.cv_toff[s][kt] != b.cv_toff[s][kt]) return 0;
+        if (abs(a.cv_toff[s][0] - a.cv_toff[s][1]) != 1) return 0;
+    }
+    const int C = a.src[0].C, CO = a.N, J = a.J;
+    if (a.K != 12 * C || b.K != 8 * C) return 0;
+    const sehip_dst &da = a.dst[0], &db = b.dst[0];
+    if (a.dst[1].ptr || b.dst[1].ptr || da.ptr != db.ptr || da.is_f32 || db.is_f32 || da.C != CO || da.F != 2 * J || da.T != db.T ||
+        da.toff != db.toff || da.fmul != 2 || db.fmul != 2 || da.fadd != 0 || db.fadd != 1 || da.tmul > 1 || db.tmul > 1) return 0;
+    if (a.M % (a.TT * a.J)) return 0;
+    const int B = a.M / (a.TT * a.J);
+    if ((long)B * da.T * da.F * da.C >= (1L << 30) - (1L << 20)) return 0;
+    for (int s = 0; s < 2; ++s)
+        if ((long)B * a.src[s].T * a.src[s].F * a.src[s].C >= (1L << 30) - (1L << 20)) return 0;
+    if (C == 64 && CO == 32 && J == 32) return wgt_launch<64, 32, 32>(a, b, B, st);
+    if (C == 32 && CO == 16 && J == 64) return wgt_launch<32, 16, 64>(a, b, B, st);
+    return 0;
+}

@@ -642,6 +642,7 @@ void sehip_conv3_init(void);
 int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry);   // convt.hip
 int sehip_try_wgrads_stream(const sehip_gemm_desc& a, hipStream_t st);            // convt.hip
+int sehip_try_wgradt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, hipStream_t st);   // convt.hip
 void sehip_wgrad3_init(void);
 int sehip_try_dense_wgrad(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 
@@ -2825,6 +2826,22 @@ static int try_narrow_wgrad(const sehip_gemm_desc& d, hipStream_t st) {
     sehip_note_kernel("narrow_wgrad_kernel<%d>", d.cv_nf);
     narrow_wgrad_kernel<5, 2><<<grid, 64 * NW_WAVES, lds, st>>>(d, FRA, fa, frames);
     return 1;
+}
+
+extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream);
+
+// The weight gradients of two products over the SAME sources and the same dOut tensor (the two output-row parities of a transposed
+// convolution, src/model/dccrn.py:387-450): one streaming launch where the library has one (csrc/convt.hip), otherwise the two calls.
+extern "C" int sehip_wgrad_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* stream) {
+    if (int e = check_desc("wgrad_pair", a)) return e;
+    if (int e = check_desc("wgrad_pair", b)) return e;
+    SEHIP_REQUIRE(a->dW != nullptr && b->dW != nullptr, "wgrad_pair: missing dW");
+    if (sehip_try_wgradt_stream(*a, *b, (hipStream_t)stream)) {
+        SEHIP_CHECK_LAUNCH("wgrad_pair(stream)");
+        return 0;
+    }
+    if (int e = sehip_wgrad(a, stream)) return e;
+    return sehip_wgrad(b, stream);
 }
 
 extern "C" int sehip_wgrad(const sehip_gemm_desc* d, void* stream) {

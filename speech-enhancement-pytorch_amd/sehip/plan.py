@@ -1041,6 +1041,18 @@ class DCCRNWorkspace:
             self._chain_dirty = False
         call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), self.side.cuda_stream)
 
+    def wgrad_pair(self, a, b):
+        """The weight gradients of the two output-row parities of a transposed convolution: one streaming launch for the outer layers
+        (sehip_wgrad_pair, csrc/convt.hip), else the two launches."""
+        main = torch.cuda.current_stream()
+        if self.side is None or a in self._wgrad_on_chain:
+            call("sehip_wgrad_pair", C.byref(self.desc[a + ".wg"]), C.byref(self.desc[b + ".wg"]), main.cuda_stream)
+            return
+        if self._chain_dirty:
+            call("sehip_stream_depend", self.side.cuda_stream, main.cuda_stream, self._event())
+            self._chain_dirty = False
+        call("sehip_wgrad_pair", C.byref(self.desc[a + ".wg"]), C.byref(self.desc[b + ".wg"]), self.side.cuda_stream)
+
     def _lstm_wgrad_names(self, layers):
         return [nm for layer in layers for nm in [f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)]]
 
@@ -1280,8 +1292,7 @@ class DCCRNWorkspace:
             if j < 5:
                 self.bn_backward(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"dzd{j}"], None, b[f"yd{j}"], b[f"dyd{j}"],
                                  params, 1)
-            self.wgrad(f"dec{j}.fwd0")
-            self.wgrad(f"dec{j}.fwd1")
+            self.wgrad_pair(f"dec{j}.fwd0", f"dec{j}.fwd1")
             self.gemm(f"dec{j}.dg")
         for tag in "ri":
             self.wgrad(f"proj_{tag}")
