@@ -61,6 +61,8 @@ __device__ __forceinline__ void ct_lds_write8(unsigned addr, ct_u2 v) {
 }
 __device__ __forceinline__ void ct_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // (macros, not functions: "+v" on an element of an array passed by reference is a "tied indirect register input" hipcc refuses)
+// (volatile asm statements keep their order: a register tied behind the wait is not consumed in front of it)
+#define WS_TIE(v) asm volatile("" : "+v"(v))
 #define CT_WAIT1(a) do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define CT_WAIT3(a, b, c) do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // all LDS operations but the youngest n_ have completed (they return in order)
@@ -594,6 +596,176 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
     }
 }
 
+// convn_stream_kernel: the same for the two products whose SOURCE has 2 channels -- encoder 0 forward (the spectrogram -> 16 channels,
+// bias, BatchNorm sums) and decoder 5's input gradient (d(mask) -> 16 + 16 channels, two destinations); src/model/dccrn.py:139-167,
+// 205-212.  A frame is 256 rows x 4 bytes = 1 KB: wave 0 alone issues its DMA (one piece per lane), as it lies in memory behind four
+// zero rows; K = 2 time taps x 5 row taps x 2 channels, stored as k = 16 kt + 2 tap + c and padded to 32, is ONE MFMA k step: a lane's
+// eight k are the 16 contiguous bytes of four consecutive rows (the taps beyond the fifth meet zero weights -- and zeroed rows behind
+// the frame, so that no NaN pattern of stale LDS is multiplied by them).  128 output rows = 8 row tiles, two per wave.
+template <int CO, int NDST, bool STATS>
+__global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_desc d0, int B, int fpw) {
+    static_assert(CO == 16 * NDST && (!STATS || NDST == 1), "16 channels per destination");
+    constexpr int J = 128, LEAD = 4, ROWS = LEAD + 2 * J + 8;     // image rows of 4 bytes: 4 zero rows, the frame, 8 zero rows
+    constexpr int SLOT = ROWS * 4;
+    constexpr int R = 8, D = R - 2;
+    constexpr int NT = CO / 16;
+    constexpr int OUT_OFF = (R * SLOT + 15) / 16 * 16, RED_OFF = OUT_OFF + 2 * NDST * 4096;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    const int TT = d0.TT;
+    const int chunks = (TT + fpw - 1) / fpw;
+    const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
+    const int t_lo = ck * fpw, t_hi = min(TT, t_lo + fpw);
+    const int nout = t_hi - t_lo;
+    if (nout <= 0 || b >= B) return;
+
+    // ---- the zero rows of every ring slot
+    for (int i = tid; i < R * (LEAD + 8); i += 256) {
+        const int sl = i / (LEAD + 8), rr = i % (LEAD + 8);
+        *reinterpret_cast<unsigned*>(smem + sl * SLOT + (rr < LEAD ? rr : 2 * J + rr) * 4) = 0u;
+    }
+    bf16x8 w[NT];
+    f32x4 bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        w[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(d0.W) + (size_t)(16 * nt + c16) * d0.K + 8 * g));
+        bias[nt] = d0.bias ? *reinterpret_cast<const f32x4*>(d0.bias + 16 * nt + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const sehip_src& S = d0.src[0];
+    const int tmin = min(d0.cv_toff[0][0], d0.cv_toff[0][1]);
+    const unsigned fbytes = 2u * (unsigned)(S.F * S.C);
+    const unsigned sbase = (unsigned)(b * S.T) * fbytes + 16u * (unsigned)lane;
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+    auto issue = [&](int v) {                          // (wave 0 only: one 1 KB instruction per frame)
+        if (wave != 0) return;
+        const int u = t_lo + tmin + v;
+        const bool ok = u >= S.tlo && u < S.thi && v <= nout;
+        const unsigned vo = ok ? sbase + (unsigned)u * fbytes : CT_OOB;
+        unsigned char* dst = smem + (v & (R - 1)) * SLOT + LEAD * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+    };
+    unsigned char* outp[NDST];
+    unsigned obytes[NDST];
+#pragma unroll
+    for (int q = 0; q < NDST; ++q) {
+        const sehip_dst& dd = q ? d0.dst[1] : d0.dst[0];
+        obytes[q] = 2u * (unsigned)(dd.F * dd.C);
+        outp[q] = reinterpret_cast<unsigned char*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)obytes[q] + 16 * tid;
+    }
+    // fragment address of row tile mt: input rows 2 j - 2 + 4 (g & 1) .. + 3 of time tap g >> 1
+    unsigned foff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) foff[mt] = (unsigned)((2 * (16 * (2 * wave + mt) + c16) - 2 + 4 * (g & 1) + LEAD) * 4);
+    const int dt0 = d0.cv_toff[0][0] - tmin, dt1 = d0.cv_toff[0][1] - tmin;
+
+    constexpr int OPR = 2;                             // pieces per output row of a destination: [8 real | 8 imaginary]
+    const bool im_thread = tid & 1;
+    float st[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) st[i] = 0.f;
+
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v <= D; ++v) issue(v);
+    for (int i = 0; i <= nout; ++i) {
+        // wave 0: the D - 1 younger DMA pieces and the NDST stores of each step since; the other waves have only their stores in flight
+        switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
+            case 0: ct_wait_vm<(D - 1) + 0 * NDST>(); break;
+            case 1: ct_wait_vm<(D - 1) + 1 * NDST>(); break;
+            case 2: ct_wait_vm<(D - 1) + 2 * NDST>(); break;
+            case 3: ct_wait_vm<(D - 1) + 3 * NDST>(); break;
+            case 4: ct_wait_vm<(D - 1) + 4 * NDST>(); break;
+            default: ct_wait_vm<(D - 1) + (D - 1) * NDST>(); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i > 0) {
+            const unsigned ot = sm + OUT_OFF + ((i - 1) & 1) * (NDST * 4096);
+            ct_u4 ld0 = ct_lds_read16(ot + 16 * tid);
+            ct_u4 ld1 = (STATS || NDST == 2) ? ct_lds_read16(STATS ? ot + 16 * (tid ^ (OPR / 2)) : ot + 4096 + 16 * tid) : ct_u4{0u, 0u, 0u, 0u};
+            CT_WAIT2N(0, ld0, ld1);
+            const uint4 v = __builtin_bit_cast(uint4, ld0);
+            *reinterpret_cast<uint4*>(outp[0] + (size_t)(t_lo + i - 1) * obytes[0]) = v;
+            if (NDST == 2) *reinterpret_cast<uint4*>(outp[NDST - 1] + (size_t)(t_lo + i - 1) * obytes[NDST - 1]) = __builtin_bit_cast(uint4, ld1);
+            if (STATS) {
+                const uint4 vp = __builtin_bit_cast(uint4, ld1);
+                const unsigned own[2] = {im_thread ? v.z : v.x, im_thread ? v.w : v.y}, oth[2] = {im_thread ? vp.z : vp.x, im_thread ? vp.w : vp.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned ar = im_thread ? oth[e] : own[e], ai = im_thread ? own[e] : oth[e];
+                    const float yr[2] = {__uint_as_float(ar << 16), __uint_as_float(ar & 0xffff0000u)};
+                    const float yi[2] = {__uint_as_float(ai << 16), __uint_as_float(ai & 0xffff0000u)};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = 2 * e + h;
+                        st[5 * c] += yr[h]; st[5 * c + 1] += yi[h];
+                        st[5 * c + 2] += yr[h] * yr[h]; st[5 * c + 3] += yr[h] * yi[h]; st[5 * c + 4] += yi[h] * yi[h];
+                    }
+                }
+            }
+        }
+        if (i == nout) break;
+        const unsigned ot = sm + OUT_OFF + (i & 1) * (NDST * 4096);
+        const unsigned sl = sm + ((i + ((g >> 1) ? dt1 : dt0)) & (R - 1)) * SLOT;
+        ct_u2 x0l = ct_lds_read8(sl + foff[0]), x0h = ct_lds_read8(sl + foff[0] + 8);
+        ct_u2 x1l = ct_lds_read8(sl + foff[1]), x1h = ct_lds_read8(sl + foff[1] + 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WS_TIE(x0l); WS_TIE(x0h); WS_TIE(x1l); WS_TIE(x1h);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 xf[2] = {__builtin_bit_cast(bf16x8, ct_u4{x0l.x, x0l.y, x0h.x, x0h.y}), __builtin_bit_cast(bf16x8, ct_u4{x1l.x, x1l.y, x1h.x, x1h.y})};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int j = 16 * (2 * wave + mt) + c16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], xf[mt], bias[nt], 0, 0, 0);
+                // D rows = output channels 16 nt + 4 g .. + 3 of output row j; destination nt
+                ct_lds_write8(ot + nt * 4096 + (j * 16 + 4 * g) * 2, ct_u2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])});
+            }
+        }
+        issue(i + D + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (STATS) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [4 waves][OPR][20]
+#pragma unroll
+        for (int i = 0; i < 20; ++i)
+#pragma unroll
+            for (int o = OPR; o < 64; o <<= 1) st[i] += __shfl_xor(st[i], o, 64);
+        if (lane < OPR) {
+#pragma unroll
+            for (int i = 0; i < 20; ++i) red[(wave * OPR + lane) * 20 + i] = st[i];
+        }
+        __syncthreads();
+        if (tid < OPR * 20) {
+            const int pi = tid / 20, i = tid - pi * 20, c = i / 5, k = i - 5 * c;
+            const float v = red[(0 * OPR + pi) * 20 + i] + red[(1 * OPR + pi) * 20 + i] + red[(2 * OPR + pi) * 20 + i] + red[(3 * OPR + pi) * 20 + i];
+            const int Cr = d0.stats_cr;
+            const int ch = (pi >= OPR / 2 ? 4 : 0) + c;
+            atomicAdd(d0.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + k * Cr + ch, v);
+        }
+    }
+}
+
+template <int CO, int NDST, bool STATS>
+static int cn_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)8 * (4 + 256 + 8) * 4 + 16 + 2 * NDST * 4096 + (STATS ? 4 * 2 * 20 * 4 : 0) + 64;
+    static const int env_chunks = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 0;
+    int chunks = env_chunks > 0 ? env_chunks : 32;
+    if (chunks > a.TT) chunks = a.TT;
+    const int fpw = (a.TT + chunks - 1) / chunks;
+    chunks = (a.TT + fpw - 1) / fpw;
+    sehip_note_kernel("convn_stream_kernel<%d, %d, %d>", CO, NDST, (int)STATS);
+    convn_stream_kernel<CO, NDST, STATS><<<B * chunks, 256, lds, st>>>(a, B, fpw);
+    return 1;
+}
+
 template <int C, int CO, int J, int NDST, bool STATS>
 static int cs_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
     constexpr size_t lds = (size_t)8 * 2 * (J + 2) * C * 2 + 2 * NDST * 4096 + (STATS ? 4 * (CO / 8) * 20 * 4 : 0) + 64;
@@ -625,7 +797,8 @@ int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) {
     if (a.src[1].ptr || !a.src[0].ptr) return 0;
     const sehip_src& x = a.src[0];
     const int C = x.C, CO = a.N, J = a.J;
-    if (x.F != 2 * J || a.K != (2 * 5 * C + 63) / 64 * 64 || abs(a.cv_toff[0][0] - a.cv_toff[0][1]) != 1) return 0;     // (K: padded to 64, zero weights)
+    if (x.F != 2 * J || abs(a.cv_toff[0][0] - a.cv_toff[0][1]) != 1) return 0;
+    if (C == 2 ? a.K < 32 : a.K != (2 * 5 * C + 63) / 64 * 64) return 0;     // (K: padded to 64, zero weights; 2 channels: k = 16 kt + 2 tap + c)
     if (a.M % (a.TT * a.J)) return 0;
     const int B = a.M / (a.TT * a.J);
     if ((long)B * x.T * x.F * x.C >= (1L << 30) - (1L << 20)) return 0;                     // byte offsets below CT_RECORDS
@@ -640,7 +813,9 @@ int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) {
     if (ndst == 1 && !stats) return 0;                    // (the uses built: forward with sums, two-destination input gradient)
     if (ndst == 2 && a.bias) return 0;
     if (((uintptr_t)a.W & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
-    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bits 32, 64: these two variants
+    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bits 32, 64, 128, 256: these variants
+    if (C == 2 && CO == 16 && J == 128 && ndst == 1) return (skip & 128) ? 0 : dry ? 1 : cn_launch<16, 1, true>(a, B, st);
+    if (C == 2 && CO == 32 && J == 128 && ndst == 2) return (skip & 256) ? 0 : dry ? 1 : cn_launch<32, 2, false>(a, B, st);
     if (C == 16 && CO == 32 && J == 64 && ndst == 1) return (skip & 32) ? 0 : dry ? 1 : cs_launch<16, 32, 64, 1, true>(a, B, st);
     if (C == 16 && CO == 64 && J == 64 && ndst == 2) return (skip & 64) ? 0 : dry ? 1 : cs_launch<16, 64, 64, 2, false>(a, B, st);
     return 0;
@@ -756,8 +931,6 @@ __device__ __forceinline__ ct_u2 ws_tr_read(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
-// (volatile asm statements keep their order: a register tied behind the wait is not consumed in front of it)
-#define WS_TIE(v) asm volatile("" : "+v"(v))
 #define WS_ONES __builtin_bit_cast(bf16x8, ct_u4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u})
 
 // C: input channels (16 | 32), CO: output channels (32 | 64), J: output rows per frame (64 | 32); 2 J C == J CO == 2048
