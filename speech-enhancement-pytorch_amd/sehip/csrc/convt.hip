@@ -397,34 +397,38 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// convs_stream_kernel: the same streaming construction for the stride-2 products with 16 input channels -- "two input rows per output
-// row": the forward pass of encoder 1 (ComplexConv2d 16 -> 32 channels, src/model/dccrn.py:316-384, with the ComplexBatchNorm sums)
-// and the input gradient of decoder 4 (ComplexConvTranspose2d, :387-450: 16 -> 32 + 32 channels, the second half to the skip
-// connection's gradient tensor).  One source, five row taps at input rows 2 j - 2 .. 2 j + 2, two time taps.
+// convs_stream_kernel: the same streaming construction for the stride-2 products with 16 or 32 input channels -- "two input rows per
+// output row": the forward pass of encoder 1 / 2 (ComplexConv2d 16 -> 32, 32 -> 64 channels, src/model/dccrn.py:316-384, with the
+// ComplexBatchNorm sums) and the input gradient of decoder 4 / 3 (ComplexConvTranspose2d, :387-450: 16 -> 32 + 32, 32 -> 64 + 64
+// channels, the second half to the skip connection's gradient tensor).  One source, five row taps at input rows 2 j - 2 .. 2 j + 2,
+// two time taps.
 //   * an input frame ([2 J rows][C] = 4 KB, one DMA piece per thread) lands as TWO PLANES -- even rows, odd rows, each [J + 2][C] with
 //     zero rows at both ends -- so that the 16 output rows of a fragment read touch 16 CONSECUTIVE plane rows (tap kf: plane kf & 1,
 //     plane row j + (kf >> 1)): conflict-free exactly as the frame image above (a stride-2 read of one image would be 4-way);
 //   * K is ordered (time tap, row tap, channel): with 16 channels an MFMA k step is two consecutive taps of that order -- lane groups
-//     0 / 1 read the first tap's two pieces, 2 / 3 the second's -- five k steps, no padding;
-//   * a wave owns one 16-row tile and ALL output channels (2 or 4 column tiles: 5 fragment reads feed 10 / 20 MFMAs; weights in
-//     40 / 80 registers); two destinations = the two channel halves, each a 4 KB frame = one 16-byte store per thread.
+//     0 / 1 read the first tap's two pieces, 2 / 3 the second's -- five k steps, no padding; with 32 channels a k step is one tap;
+//   * a wave owns one 16-row tile and its share of the output channels (64 rows: all 2 / 4 column tiles; 32 rows: half of the 4 / 8):
+//     5 or 10 fragment reads feed 10 - 40 MFMAs, weights in 40 - 160 registers; two destinations = the two channel halves, each a
+//     4 KB frame = one 16-byte store per thread.
 // NDST: destinations (1: forward, bias + sums; 2: input gradient).
 template <int C, int CO, int J, int NDST, bool STATS>
 __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_desc d0, int B, int fpw) {
-    static_assert(C == 16 && 2 * J * C == 2048 && J * CO * 2 == 4096 * NDST && J == 64, "4 KB frames in, 4 KB per destination out, four row tiles");
+    static_assert((C == 16 || C == 32) && 2 * J * C == 2048 && J * CO * 2 == 4096 * NDST, "4 KB frames in, 4 KB per destination out");
     static_assert(!STATS || NDST == 1, "sums: the forward product");
-    constexpr int PPR = C / 8;                         // 16-byte pieces per row (2)
+    constexpr int PPR = C / 8;                         // 16-byte pieces per row (2 | 4)
     constexpr int PLANE = (J + 2) * C * 2;             // bytes of one parity plane incl. its zero rows
     constexpr int SLOT = 2 * PLANE;
     constexpr int R = 8, D = R - 2;
-    constexpr int NFRAG = 2 * 5 * C / 32;              // MFMA k steps (5)
-    constexpr int NTW = CO / 16;                       // column tiles (all of them per wave)
+    constexpr int NFRAG = 2 * 5 * C / 32;              // MFMA k steps (5 | 10)
+    constexpr int WM = J / 16, WN = 4 / WM;            // waves: row tiles x column groups (4 x 1 | 2 x 2)
+    constexpr int NTW = CO / 16 / WN;                  // column tiles per wave
     constexpr int OUT_OFF = R * SLOT, RED_OFF = OUT_OFF + 2 * NDST * 4096;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c16 = lane & 15;
+    const int wm = wave % WM, wn = wave / WM;          // this wave: row tile wm, column tiles NTW wn ..
     const int TT = d0.TT;
     const int chunks = (TT + fpw - 1) / fpw;
     const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
@@ -437,17 +441,17 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
         const int pl = i / (2 * PPR), rr = (i / PPR) & 1, q = i % PPR;
         *reinterpret_cast<uint4*>(smem + pl * PLANE + (rr ? (J + 1) * C * 2 : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
-    // ---- weight fragments: rows n = 16 nt + c16, k chunk 32 f + 8 g
+    // ---- weight fragments: rows n = 16 (NTW wn + nt) + c16, k chunk 32 f + 8 g
     bf16x8 w[NTW][NFRAG];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const bf16_raw* W = reinterpret_cast<const bf16_raw*>(d0.W) + (size_t)(16 * nt + c16) * d0.K + 8 * g;
+        const bf16_raw* W = reinterpret_cast<const bf16_raw*>(d0.W) + (size_t)(16 * (NTW * wn + nt) + c16) * d0.K + 8 * g;
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) w[nt][f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W + 32 * f));
     }
     f32x4 bias[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) bias[nt] = d0.bias ? *reinterpret_cast<const f32x4*>(d0.bias + 16 * nt + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTW; ++nt) bias[nt] = d0.bias ? *reinterpret_cast<const f32x4*>(d0.bias + 16 * (NTW * wn + nt) + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- DMA: waves 0, 1 fill the even plane's J data rows, waves 2, 3 the odd plane's (1 KB per wave instruction)
     const int plane_w = wave >> 1;
@@ -476,15 +480,16 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
         outp[q] = reinterpret_cast<unsigned char*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)obytes[q] + 16 * tid;
     }
 
-    // ---- fragment addresses: k step f, lane group g: flattened tap tau = 2 f + (g >> 1) = 5 kt + kf, piece g & 1
-    const int j = 16 * wave + c16;
+    // ---- fragment addresses: k step f, lane group g: flattened tap tau = 5 kt + kf = 2 f + (g >> 1), piece g & 1 (16 channels);
+    // tau = f, piece g (32 channels)
+    const int j = 16 * wm + c16;
     int foff[NFRAG];                                   // offset inside a ring slot
     bool second[NFRAG];                                // time tap kt of this lane's half of the k step
 #pragma unroll
     for (int f = 0; f < NFRAG; ++f) {
-        const int tau = 2 * f + (g >> 1), kt = tau / 5, kf = tau - 5 * kt;
+        const int tau = C == 16 ? 2 * f + (g >> 1) : f, kt = tau / 5, kf = tau - 5 * kt;
         const int r = j + (kf >> 1);                   // plane row incl. the leading zero row
-        foff[f] = (kf & 1) * PLANE + (r * PPR + ((g & 1) ^ ct_swz<C>(r))) * 16;
+        foff[f] = (kf & 1) * PLANE + (r * PPR + ((C == 16 ? (g & 1) : g) ^ ct_swz<C>(r))) * 16;
         second[f] = kt != 0;
     }
     const int dt0 = d0.cv_toff[0][0] - tmin, dt1 = d0.cv_toff[0][1] - tmin;
@@ -541,33 +546,39 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
         // ---- compute phase: output frame i; all five fragments are requested at once (20 registers), each column tile's MFMAs follow
         const unsigned ot = sm + OUT_OFF + (i & 1) * (NDST * 4096);
         const unsigned sl0 = sm + ((i + dt0) & (R - 1)) * SLOT, sl1 = sm + ((i + dt1) & (R - 1)) * SLOT;
-        ct_u4 x0 = ct_lds_read16((second[0] ? sl1 : sl0) + foff[0]);
-        ct_u4 x1 = ct_lds_read16((second[1] ? sl1 : sl0) + foff[1]);
-        ct_u4 x2 = ct_lds_read16((second[2] ? sl1 : sl0) + foff[2]);
-        ct_u4 x3 = ct_lds_read16((second[3] ? sl1 : sl0) + foff[3]);
-        ct_u4 x4 = ct_lds_read16((second[4] ? sl1 : sl0) + foff[4]);
         f32x4 acc[NTW];
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[nt] = bias[nt];
-        CT_WAIT2N(3, x0, x1);
+        // five fragments at a time (all of them at 16 channels, one time tap's at 32): requested at once, consumed in order
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][0], __builtin_bit_cast(bf16x8, x0), acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][1], __builtin_bit_cast(bf16x8, x1), acc[nt], 0, 0, 0);
+        for (int h = 0; h < NFRAG / 5; ++h) {
+            ct_u4 x0 = ct_lds_read16((second[5 * h + 0] ? sl1 : sl0) + foff[5 * h + 0]);
+            ct_u4 x1 = ct_lds_read16((second[5 * h + 1] ? sl1 : sl0) + foff[5 * h + 1]);
+            ct_u4 x2 = ct_lds_read16((second[5 * h + 2] ? sl1 : sl0) + foff[5 * h + 2]);
+            ct_u4 x3 = ct_lds_read16((second[5 * h + 3] ? sl1 : sl0) + foff[5 * h + 3]);
+            ct_u4 x4 = ct_lds_read16((second[5 * h + 4] ? sl1 : sl0) + foff[5 * h + 4]);
+            CT_WAIT2N(3, x0, x1);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][5 * h + 0], __builtin_bit_cast(bf16x8, x0), acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][5 * h + 1], __builtin_bit_cast(bf16x8, x1), acc[nt], 0, 0, 0);
+            }
+            CT_WAIT2N(1, x2, x3);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][5 * h + 2], __builtin_bit_cast(bf16x8, x2), acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][5 * h + 3], __builtin_bit_cast(bf16x8, x3), acc[nt], 0, 0, 0);
+            }
+            CT_WAIT1(x4);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][5 * h + 4], __builtin_bit_cast(bf16x8, x4), acc[nt], 0, 0, 0);
         }
-        CT_WAIT2N(1, x2, x3);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][2], __builtin_bit_cast(bf16x8, x2), acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][3], __builtin_bit_cast(bf16x8, x3), acc[nt], 0, 0, 0);
-        }
-        CT_WAIT1(x4);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][4], __builtin_bit_cast(bf16x8, x4), acc[nt], 0, 0, 0);
-            // D rows = output channels 16 nt + 4 g .. + 3 of output row j; destination q holds channels q CO / NDST ..
+            // D rows = output channels 16 (NTW wn + nt) + 4 g .. + 3 of output row j; destination q holds channels q CO / NDST ..
             constexpr int CD = CO / NDST;              // channels per destination
-            const int ch = 16 * nt + 4 * g, q = ch / CD;
+            const int ch = 16 * (NTW * wn + nt) + 4 * g, q = ch / CD;
             ct_lds_write8(ot + q * 4096 + (j * CD + (ch - q * CD)) * 2, ct_u2{pack_bf2(acc[nt][0], acc[nt][1]), pack_bf2(acc[nt][2], acc[nt][3])});
         }
         issue(i + D + 1);
@@ -813,11 +824,13 @@ int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) {
     if (ndst == 1 && !stats) return 0;                    // (the uses built: forward with sums, two-destination input gradient)
     if (ndst == 2 && a.bias) return 0;
     if (((uintptr_t)a.W & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
-    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bits 32, 64, 128, 256: these variants
+    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bits 32 .. 1024: these variants
     if (C == 2 && CO == 16 && J == 128 && ndst == 1) return (skip & 128) ? 0 : dry ? 1 : cn_launch<16, 1, true>(a, B, st);
     if (C == 2 && CO == 32 && J == 128 && ndst == 2) return (skip & 256) ? 0 : dry ? 1 : cn_launch<32, 2, false>(a, B, st);
     if (C == 16 && CO == 32 && J == 64 && ndst == 1) return (skip & 32) ? 0 : dry ? 1 : cs_launch<16, 32, 64, 1, true>(a, B, st);
     if (C == 16 && CO == 64 && J == 64 && ndst == 2) return (skip & 64) ? 0 : dry ? 1 : cs_launch<16, 64, 64, 2, false>(a, B, st);
+    if (C == 32 && CO == 64 && J == 32 && ndst == 1) return (skip & 512) ? 0 : dry ? 1 : cs_launch<32, 64, 32, 1, true>(a, B, st);
+    if (C == 32 && CO == 128 && J == 32 && ndst == 2) return (skip & 1024) ? 0 : dry ? 1 : cs_launch<32, 128, 32, 2, false>(a, B, st);
     return 0;
 }
 

@@ -352,6 +352,23 @@ class GemmSpec:
                 return None
         return cs
 
+    def stream_takes(self):
+        """True when convs_stream_kernel (csrc/convt.hip, sehip_try_convs_stream) takes this product at any batch size: a 5-tap stride-2
+        convolution of ONE source with 32 input channels and 4 KB frames on both sides -- encoder 2's forward product (with the fused
+        BatchNorm sums) and decoder 3's input gradient (two destinations) at the headline widths.  Such a product keeps its weights in
+        [Npad][K] order (the kernel holds them in registers); the 16-channel layers never qualified for conv_gemm_v3's tile order."""
+        if os.environ.get("SEHIP_NO_CONVT_STREAM") or self.conv is None or self.kind == "wgrad_only" or self.res is not None:
+            return False
+        nf, fadd, _ = self.conv
+        if (nf, fadd, self.fmul) != (5, -2, 2) or len(self.srcs) != 1 or self.N != self.Npad:
+            return False
+        c_in = self.K // 10
+        if self.K != 10 * c_in or c_in != 32 or 2 * self.J * c_in != 2048 or self.N * self.J * 2 != 4096 * len(self.dsts):
+            return False
+        if len(self.dsts) == 1:
+            return self.kind == "fwd" and self.stats_of is not None
+        return len(self.dsts) == 2 and self.bias_pairs is None
+
     def tile_weights(self):
         """Moves the packed weights [Npad][K] (K ordered (tap, concatenated channel)) into the tile order conv_gemm_v3 streams:
         [n tile][16-channel chunk][tap pair][tap of the pair][128 (or 64) n][16 channels]; a pure permutation of the packing table."""
@@ -626,7 +643,7 @@ class DCCRNStatic:
             s.kt_off = kta.add(s.ktab)
             s.nt_off = nta.add(s.ntab)
             if s.kind != "wgrad_only":
-                if TILE_WEIGHTS and s.v3_channels() is not None:
+                if TILE_WEIGHTS and s.v3_channels() is not None and not s.stream_takes():
                     s.tile_weights()      # (widx / wneg themselves keep the [Npad][K] order: the weight-gradient un-packing uses them)
                     s.w_off = wa.add(enc_entry(s.widx_packed, s.wneg_packed).reshape(-1))
                 else:
