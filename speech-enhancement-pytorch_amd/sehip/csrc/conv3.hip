@@ -33,6 +33,9 @@ typedef __attribute__((address_space(1))) const void c3_gvoid;
 #define C3_RECORDS 0x7fff0000u
 
 #define C3_NSLOT 4
+#ifndef C3_PATCH_AUX
+#define C3_PATCH_AUX 0        // cache policy of the patch DMAs (2 = nt: measured)
+#endif
 
 // geometry of the patch image (tools/c3_census.py: conflict-free frame stride per (row stride, taps, rows per frame))
 template <int NF, int FM, int J, int TM, int NWN = 2>
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             unsigned char* dd = ((u * NWV + wave) * 64 < NPIECE) ? dst + u * (NWV * 1024) : dump;     // wave-uniform
             unsigned vo = second ? off1[u] : off0[u];
             if (ABL & 8) vo = (unsigned)(((blockIdx.x & 1023) * 16384 + ((u * NWV + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (c3_lds_void*)dd, 16, vo, soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (c3_lds_void*)dd, 16, vo, soff, 0, 0);
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (c3_lds_void*)dd, 16, vo, soff, 0, C3_PATCH_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (c3_lds_void*)dd, 16, vo, soff, 0, C3_PATCH_AUX);
         }
     };
     // ---- weight tile of step (ch, j): [tap 2j + u][128 n][16 channels]; instruction u of wave w: rows 32 w .. 32 w + 31.

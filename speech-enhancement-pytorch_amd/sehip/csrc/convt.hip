@@ -31,6 +31,9 @@ __device__ unsigned long long ct_phase[8];
 #else
 #define CT_T(k_) do { } while (0)
 #endif
+#ifndef CT_AUX
+#define CT_AUX 0              // cache policy of the frame DMAs (2 = nt: measured)
+#endif
 #define CT_OOB 0x7ffffff0u
 #define CT_RECORDS 0x7fff0000u
 
@@ -189,15 +192,15 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
             const bool ok = u >= S.tlo && u < S.thi && v <= nout && !(abl & 4);
             const unsigned vo = ok ? sbase[s] + (unsigned)u * fbytes[s] + piece_off : CT_OOB;
             unsigned char* dst = smem + (s * R + (v & (R - 1))) * SLOT + C * 2 + wave * 1024;
-            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
         }
         if (RES) {
             const int o = v - 2;
             const bool ok = o >= 0 && o < nout && !(abl & 4);
             const unsigned vo = ok ? rbase + (unsigned)(t_lo + o) * obytes : CT_OOB;
             unsigned char* dst = smem + RES_OFF + (o & (R - 1)) * 4096 + wave * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
         }
     };
 
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
         const bool ok = u >= S.tlo && u < S.thi && v <= nout;
         const unsigned vo = ok ? sbase + (unsigned)u * fbytes + piece_off : CT_OOB;
         unsigned char* dst = smem + (v & (R - 1)) * SLOT + plane_w * PLANE + C * 2 + (wave & 1) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
     };
     unsigned char* outp[NDST];
     unsigned obytes[NDST];
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
         const bool ok = u >= S.tlo && u < S.thi && v <= nout;
         const unsigned vo = ok ? sbase + (unsigned)u * fbytes : CT_OOB;
         unsigned char* dst = smem + (v & (R - 1)) * SLOT + LEAD * 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
     };
     unsigned char* outp[NDST];
     unsigned obytes[NDST];
@@ -1007,11 +1010,11 @@ __global__ __launch_bounds__(256, 2) void wgrads_stream_kernel(const sehip_gemm_
         const bool okx = u >= S.tlo && u < S.thi && v <= nout;
         const unsigned vx = okx ? xbase + (unsigned)u * xfbytes + x_off : CT_OOB;
         unsigned char* dx = smem + (v & (R - 1)) * SLOTX + plane_w * PLANE + RBX + (wave & 1) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (ct_lds_void*)dx, 16, vx, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (ct_lds_void*)dx, 16, vx, 0, 0, CT_AUX);
         const bool okg = v < nout;
         const unsigned vg = okg ? gbase + (unsigned)(t_lo + v) * gfbytes + g_off : CT_OOB;
         unsigned char* dg = smem + G_OFF + (v & (R - 1)) * 4096 + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, CT_AUX);
     };
 
     // ---- transposed-read addresses of this lane: row (first row of the 8-row group + 4 h + (i16 >> 2)), 8-byte chunk i16 & 3
@@ -1246,13 +1249,13 @@ __global__ __launch_bounds__(256, (C * CO >= 2048 ? 1 : 2)) void wgradt_stream_k
             const bool ok = u >= S.tlo && u < S.thi && v <= nout;
             const unsigned vo = ok ? xbase[s] + (unsigned)u * xfbytes[s] + x_off : CT_OOB;
             unsigned char* dst = smem + (s * R + (v & (R - 1))) * SLOTX + RBX + wave * 1024;
-            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, 0);
+            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
         }
         const bool okg = v < nout;
         const unsigned vg = okg ? gbase + (unsigned)(t_lo + v) * gfbytes + g_off : CT_OOB;
         unsigned char* dg = smem + G_OFF + (v & (R - 1)) * 4096 + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, CT_AUX);
     };
 
     unsigned preG[KS][2], preX[KS][3][2];

@@ -1,4 +1,4 @@
-// Standalone timing harness of convt_stream_kernel (csrc/convt.hip): synthetic DCCRN-shaped operands, hipEvent time per launch and the
+// Standalone timing harness of convt_stream_kernel's five variants (csrc/convt.hip; the other templates of the file are timed in the step: tools/_tl-style traces): synthetic DCCRN-shaped operands, hipEvent time per launch and the
 // core-clock cycles wave 0 of workgroup 0 spends in each phase of the frame loop.  Results are not checked here (tests/ do that).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/micro/convt_bench.hip -o tools/micro/_convt_bench
 //   SEHIP_CT_ABL=<bits> SEHIP_CT_CHUNKS=<n> tools/micro/_convt_bench [variant 0..4] [B] [T]
@@ -12,6 +12,12 @@
 #include "../../speech-enhancement-pytorch_amd/sehip/csrc/convt.hip"
 
 void sehip_note_kernel(const char*, ...) {}
+int sehip_deterministic(void) { return 0; }
+float* sehip_wgrad_scratch(hipStream_t, size_t bytes) {        // (the library's per-stream pool: one buffer is enough here)
+    static float* p = nullptr; static size_t have = 0;
+    if (bytes > have) { if (p) (void)hipFree(p); if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; have = bytes; }
+    return p;
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
