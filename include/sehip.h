@@ -253,9 +253,23 @@ typedef struct {
     const float* bn_coef;
     const float* bn_bcoef;
     const float* bn_slope;
+    /* Optional (sehip_gemm / sehip_gemm_pair, input-gradient products whose dst[0] is the gradient that arrives at a
+     * ComplexBatchNorm + PReLU layer's output): the launch ALSO computes that layer's backward reduce pass (sehip_cbn_bwd_reduce:
+     * six sums per complex channel + the PReLU slope's) from the values it stores and bnr_y (the layer's own convolution output,
+     * laid out like dst[0]), with the layer's forward records bnr_coef and slope bnr_slope, one row of 6 Cr + 1 sums per workgroup
+     * at bnr_part (Cr = dst[0].C / 2; sehip_cbn_bwd_finalize_n adds the rows) -- one read of two 42-MB tensors less per layer.
+     * Honoured by the streaming kernels only (csrc/convt.hip); ask sehip_bnr_rows first: 0 = this product does not qualify, run
+     * sehip_cbn_bwd_reduce as before (the fields are then ignored). */
+    const void* bnr_y;
+    const float* bnr_coef;
+    const float* bnr_slope;
+    float* bnr_part;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);
+/* rows of 6 Cr + 1 sums the product (pair: b != NULL) writes at bnr_part when launched with the bnr_* fields set, 0 if it does not
+ * compute the reduce pass (then run sehip_cbn_bwd_reduce).  Depends on the shapes only: ask once per workspace. */
+int sehip_bnr_rows(const sehip_gemm_desc* a, const sehip_gemm_desc* b /* or NULL */);
 /* Deterministic reductions, process-wide (the reference's switch is config.solver.cudnn_deterministic -> src/utils.py:108-111): with
  * on != 0 every floating-point sum whose order depends on scheduling takes a fixed-order form -- weight gradients through per-split
  * partial arrays added in split order (sehip_wgrad; grouped launches run one by one; the store-flush kernels already do), the
@@ -337,6 +351,11 @@ int sehip_cbn_bwd_reduce(const void* dz, const void* dz2 /*or NULL*/, const void
 int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri, const float* Wii,
                            long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope,
                            float* bcoef /*[Cr][16]*/, void* stream);
+/* the same over nblk rows of sums written by somebody else (a streaming input-gradient launch: sehip_gemm_desc.bnr_part,
+ * sehip_bnr_rows), nblk <= 1024 */
+int sehip_cbn_bwd_finalize_n(const float* part, int nblk, const float* coef, const float* Wrr, const float* Wri, const float* Wii,
+                             long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope,
+                             float* bcoef /*[Cr][16]*/, void* stream);
 /* the backward pass of the layer in two launches: sehip_cbn_bwd_reduce adding its block sums to `rep` ([nrep][6 Cr + 1] fp32, zero
  * on entry, nrep <= 64) with atomics, then an apply pass that finalizes them itself (parameter gradients written as by
  * sehip_cbn_bwd_finalize) and clears `rep_next` -- a second set of rows, to be passed as `rep` by the layer's next call (the two

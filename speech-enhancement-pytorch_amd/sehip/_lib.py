@@ -74,6 +74,8 @@ _PROTOS = {
     "sehip_gemm_pair": [P, P, P],
     "sehip_wgrad": [P, P],
     "sehip_wgrad_pair": [P, P, P],
+    "sehip_bnr_rows": [P, P],
+    "sehip_cbn_bwd_finalize_n": [P, I, P, P, P, P, L, I, P, P, P, P, P, P, P, P],
     "sehip_wgrad_group_bytes": [I],
     "sehip_wgrad_group_prepare": [P, I, P, P],
     "sehip_wgrad_group": [P, I, I, P],

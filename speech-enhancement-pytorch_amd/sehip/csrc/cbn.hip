@@ -81,12 +81,12 @@ __device__ __forceinline__ void block_partials(float (&s)[NS][CH], int nq, int C
 // ago, so every load is a round trip to memory: ALL of a lane's loads (8 blocks x NS values; nblk <= 512) are issued before
 // the first add -- a trip-by-trip loop took 8 serial round trips, 14 of this kernel's 19 us, on the dependent chain.
 #define CBN_MAX_BLOCKS 512
-template <int NS>
+template <int NS, int MAXB = CBN_MAX_BLOCKS>
 __device__ __forceinline__ void wave_reduce_partials(const float* __restrict__ part, int nblk, int stride, int idx0, int Cr,
                                                      double (&out)[NS]) {
-    float v[CBN_MAX_BLOCKS / 64][NS];
+    float v[MAXB / 64][NS];
 #pragma unroll
-    for (int t = 0; t < CBN_MAX_BLOCKS / 64; ++t) {
+    for (int t = 0; t < MAXB / 64; ++t) {
         const int b = (threadIdx.x & 63) + 64 * t;
         const float* p = part + (size_t)(b < nblk ? b : 0) * stride + idx0;
 #pragma unroll
@@ -96,7 +96,7 @@ __device__ __forceinline__ void wave_reduce_partials(const float* __restrict__ p
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
 #pragma unroll
-    for (int t = 0; t < CBN_MAX_BLOCKS / 64; ++t) {
+    for (int t = 0; t < MAXB / 64; ++t) {
         const bool live = (int)(threadIdx.x & 63) + 64 * t < nblk;
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k] += live ? (double)v[t][k] : 0.0;
@@ -494,6 +494,7 @@ __device__ __forceinline__ void cbn_bwd_record(float sdr, float sdi, float qrr, 
 }
 
 // one wave per channel: parameter gradients + coefficients of the apply pass
+template <int MAXB>
 __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ coef,
                                         const float* __restrict__ Wrr, const float* __restrict__ Wri,
                                         const float* __restrict__ Wii, long rows, int Cr, float* __restrict__ gWrr,
@@ -503,7 +504,7 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
     const int st = 6 * Cr + 1;
     if (c == Cr) {  // extra block: the PReLU slope gradient (its own block, so that channel 0 is not a straggler)
         double ds[1];
-        wave_reduce_partials<1>(part, nblk, st, 6 * Cr, Cr, ds);
+        wave_reduce_partials<1, MAXB>(part, nblk, st, 6 * Cr, Cr, ds);
         if (threadIdx.x == 0) gslope[0] = (float)ds[0];
         return;
     }
@@ -512,7 +513,7 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
     const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
     const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
     double a[6];
-    wave_reduce_partials<6>(part, nblk, st, c, Cr, a);
+    wave_reduce_partials<6, MAXB>(part, nblk, st, c, Cr, a);
     const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
     if (threadIdx.x != 0) return;
     float g5[5], rec[9];
@@ -854,9 +855,24 @@ extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, cons
                                       const float* Wii, long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr,
                                       float* gBi, float* gslope, float* bcoef, void* stream) {
     if (int e = check_cbn("cbn_bwd_finalize", rows, Cr)) return e;
-    cbn_bwd_finalize_kernel<<<Cr + 1, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), coef, Wrr, Wri, Wii, rows, Cr, gWrr,
-                                                                gWri, gWii, gBr, gBi, gslope, bcoef);
+    cbn_bwd_finalize_kernel<CBN_MAX_BLOCKS><<<Cr + 1, 64, 0, (hipStream_t)stream>>>(part, stat_blocks(rows, Cr), coef, Wrr, Wri, Wii, rows, Cr,
+                                                                                gWrr, gWri, gWii, gBr, gBi, gslope, bcoef);
     SEHIP_CHECK_LAUNCH("cbn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sehip_cbn_bwd_finalize_n(const float* part, int nblk, const float* coef, const float* Wrr, const float* Wri,
+                                        const float* Wii, long rows, int Cr, float* gWrr, float* gWri, float* gWii, float* gBr,
+                                        float* gBi, float* gslope, float* bcoef, void* stream) {
+    if (int e = check_cbn("cbn_bwd_finalize_n", rows, Cr)) return e;
+    SEHIP_REQUIRE(nblk >= 1 && nblk <= 1024, "cbn_bwd_finalize_n: %d rows of sums (1..1024)", nblk);
+    if (nblk <= CBN_MAX_BLOCKS)
+        cbn_bwd_finalize_kernel<CBN_MAX_BLOCKS><<<Cr + 1, 64, 0, (hipStream_t)stream>>>(part, nblk, coef, Wrr, Wri, Wii, rows, Cr, gWrr, gWri,
+                                                                                    gWii, gBr, gBi, gslope, bcoef);
+    else
+        cbn_bwd_finalize_kernel<1024><<<Cr + 1, 64, 0, (hipStream_t)stream>>>(part, nblk, coef, Wrr, Wri, Wii, rows, Cr, gWrr, gWri, gWii, gBr,
+                                                                          gBi, gslope, bcoef);
+    SEHIP_CHECK_LAUNCH("cbn_bwd_finalize_n");
     return 0;
 }
 

@@ -85,6 +85,75 @@ __device__ __forceinline__ constexpr int ct_swz(int r) { return C == 64 ? (r & 6
 // (C == 16, two pieces per 32-byte row: the 16 rows of a group are 8 at piece 0 and 8 at piece 1, rows r and r + 8 -- the same banks --
 //  always on different pieces: conflict-free as stored)
 
+// ---- the ComplexBatchNorm backward REDUCE pass inside a producer's store phase (sehip_gemm_desc.bnr_*; csrc/cbn.hip
+// cbn_bwd_reduce_kernel's arithmetic on the same bf16 values: the output frame as stored, the layer's own convolution output fetched
+// by one more DMA piece per thread and frame).  A row of the tensor is [Cr real | Cr imaginary] channels = OPR pieces of 8; the thread
+// of piece pi and the thread of its partner piece pi ^ (OPR / 2) share a row's eight complex channels as for the forward sums: 4
+// channels x 6 sums + the PReLU slope's sum per thread, one row of 6 Cr + 1 sums per workgroup at the end (plain stores).
+struct CtBnr { float s[24]; float da; };
+template <int OPR>
+__device__ __forceinline__ void ct_bnr_coef(const float* __restrict__ coef, int tid, float4 (&zc)[4], float4 (&mb)[4]) {
+    const int pcol = (tid % OPR) % (OPR / 2), half = (tid % OPR) >= OPR / 2 ? 4 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // records of 16 floats per channel: [0..3] the matrix, [4..7] mean / shift
+        zc[k] = reinterpret_cast<const float4*>(coef)[4 * (8 * pcol + half + k)];
+        mb[k] = reinterpret_cast<const float4*>(coef)[4 * (8 * pcol + half + k) + 1];
+    }
+}
+__device__ __forceinline__ void ct_bnr_add(CtBnr& A, const uint4& g_own, const uint4& g_par, const uint4& y_own, const uint4& y_par,
+                                           const float4 (&zc)[4], const float4 (&mb)[4], float a, bool im) {
+    // the words of this thread's four channels: the real piece's thread takes words x, y of both pieces, the imaginary piece's z, w
+    const unsigned gown[2] = {im ? g_own.z : g_own.x, im ? g_own.w : g_own.y}, gpar[2] = {im ? g_par.z : g_par.x, im ? g_par.w : g_par.y};
+    const unsigned yown[2] = {im ? y_own.z : y_own.x, im ? y_own.w : y_own.y}, ypar[2] = {im ? y_par.z : y_par.x, im ? y_par.w : y_par.y};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned grw = im ? gpar[e] : gown[e], giw = im ? gown[e] : gpar[e], yrw = im ? ypar[e] : yown[e], yiw = im ? yown[e] : ypar[e];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * e + h;
+            const float xr = h ? __uint_as_float(yrw & 0xffff0000u) : __uint_as_float(yrw << 16);
+            const float xi = h ? __uint_as_float(yiw & 0xffff0000u) : __uint_as_float(yiw << 16);
+            float dr = h ? __uint_as_float(grw & 0xffff0000u) : __uint_as_float(grw << 16);
+            float di = h ? __uint_as_float(giw & 0xffff0000u) : __uint_as_float(giw << 16);
+            const float cr = xr - mb[k].x, ci = xi - mb[k].y;
+            const float vr = zc[k].x * cr + zc[k].y * ci + mb[k].z;
+            const float vi = zc[k].z * cr + zc[k].w * ci + mb[k].w;
+            if (!(vr > 0.f)) { A.da += dr * vr; dr *= a; }
+            if (!(vi > 0.f)) { A.da += di * vi; di *= a; }
+            A.s[0 * 4 + k] += dr; A.s[1 * 4 + k] += di;
+            A.s[2 * 4 + k] += dr * cr; A.s[3 * 4 + k] += dr * ci; A.s[4 * 4 + k] += di * cr; A.s[5 * 4 + k] += di * ci;
+        }
+    }
+}
+// threads with equal tid % OPR hold the same 4 complex channels for different rows: shuffles over the lanes OPR apart, the four waves
+// through LDS (red: [4][OPR][25] floats), then sum a of channel c to out[a Cr + c], the slope's sum to out[6 Cr]
+template <int OPR>
+__device__ __forceinline__ void ct_bnr_flush(CtBnr& A, float* red, float* __restrict__ out, int Cr, int tid, int lane, int wave) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i)
+#pragma unroll
+        for (int o = OPR; o < 64; o <<= 1) A.s[i] += __shfl_xor(A.s[i], o, 64);
+#pragma unroll
+    for (int o = OPR; o < 64; o <<= 1) A.da += __shfl_xor(A.da, o, 64);
+    __syncthreads();
+    if (lane < OPR) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) red[(wave * OPR + lane) * 25 + i] = A.s[i];
+        red[(wave * OPR + lane) * 25 + 24] = A.da;
+    }
+    __syncthreads();
+    if (tid < OPR * 24) {
+        const int pi = tid / 24, i = tid - pi * 24, a = i >> 2, k = i & 3;
+        const float v = red[(0 * OPR + pi) * 25 + i] + red[(1 * OPR + pi) * 25 + i] + red[(2 * OPR + pi) * 25 + i] + red[(3 * OPR + pi) * 25 + i];
+        out[a * Cr + 8 * (pi % (OPR / 2)) + (pi >= OPR / 2 ? 4 : 0) + k] = v;
+    }
+    if (tid == 255) {
+        float v = 0.f;
+        for (int q = 0; q < 4 * OPR; ++q) v += red[q * 25 + 24];
+        out[6 * Cr] = v;
+    }
+}
+
 // C: channels per source (16 | 32 | 64), NS: sources (1 | 2), CO: output channels (2 | 16 | 32), J: input rows per frame, J * C == 2048.
 // CO == 2 (the network's last layer, src/model/dccrn.py:205-212: 16 + 16 channels -> the complex mask): W / bias padded to 16 rows, fp32
 // output [2 J rows][2], two 16-row tiles per wave.
@@ -414,18 +483,22 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
 //     5 or 10 fragment reads feed 10 - 40 MFMAs, weights in 40 - 160 registers; two destinations = the two channel halves, each a
 //     4 KB frame = one 16-byte store per thread.
 // NDST: destinations (1: forward, bias + sums; 2: input gradient).
-template <int C, int CO, int J, int NDST, bool STATS>
+// BNR: the launch also computes the backward reduce pass of the ComplexBatchNorm layer whose activation gradient destination 0 is
+// (sehip_gemm_desc.bnr_*, ct_bnr_add above): one more DMA piece per thread and frame (that layer's convolution output).
+template <int C, int CO, int J, int NDST, bool STATS, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_desc d0, int B, int fpw) {
     static_assert((C == 16 || C == 32) && 2 * J * C == 2048 && J * CO * 2 == 4096 * NDST, "4 KB frames in, 4 KB per destination out");
     static_assert(!STATS || NDST == 1, "sums: the forward product");
+    static_assert(!BNR || (NDST == 2 && !STATS), "the reduce pass rides on an input gradient");
     constexpr int PPR = C / 8;                         // 16-byte pieces per row (2 | 4)
     constexpr int PLANE = (J + 2) * C * 2;             // bytes of one parity plane incl. its zero rows
     constexpr int SLOT = 2 * PLANE;
-    constexpr int R = 8, D = R - 2;
+    constexpr int R = BNR ? 4 : 8, D = R - 2;          // (with the third tensor's ring: 4 frames each, 49 KB, three workgroups per CU)
     constexpr int NFRAG = 2 * 5 * C / 32;              // MFMA k steps (5 | 10)
     constexpr int WM = J / 16, WN = 4 / WM;            // waves: row tiles x column groups (4 x 1 | 2 x 2)
     constexpr int NTW = CO / 16 / WN;                  // column tiles per wave
-    constexpr int OUT_OFF = R * SLOT, RED_OFF = OUT_OFF + 2 * NDST * 4096;
+    constexpr int OUT_OFF = R * SLOT, Y_OFF = OUT_OFF + 2 * NDST * 4096, RED_OFF = Y_OFF + (BNR ? R * 4096 : 0);
+    constexpr int NSR = 1 + (BNR ? 1 : 0);             // DMA instructions per thread and step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -467,12 +540,24 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
     const unsigned sbase = (unsigned)(b * S.T) * fbytes;
     const __amdgpu_buffer_rsrc_t rs0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+    const sehip_dst& dy0 = d0.dst[0];
+    const unsigned ybytes = 2u * (unsigned)(dy0.F * dy0.C);
+    const unsigned ybase = (unsigned)(b * dy0.T + dy0.toff) * ybytes + 16u * (unsigned)tid;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(BNR ? d0.bnr_y : S.ptr)), 0, CT_RECORDS, 0x00020000);
     auto issue = [&](int v) {
         const int u = t_lo + tmin + v;
         const bool ok = u >= S.tlo && u < S.thi && v <= nout;
         const unsigned vo = ok ? sbase + (unsigned)u * fbytes + piece_off : CT_OOB;
         unsigned char* dst = smem + (v & (R - 1)) * SLOT + plane_w * PLANE + C * 2 + (wave & 1) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
+        if (BNR) {                                     // the BatchNorm layer's convolution output at output frame v - 2 (stored at step v - 1)
+            const int o = v - 2;
+            const bool oky = o >= 0 && o < nout;
+            const unsigned vy = oky ? ybase + (unsigned)(t_lo + o) * ybytes : CT_OOB;
+            unsigned char* dy = smem + Y_OFF + (o & (R - 1)) * 4096 + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (ct_lds_void*)dy, 16, vy, 0, 0, CT_AUX);
+        }
     };
     unsigned char* outp[NDST];
     unsigned obytes[NDST];
@@ -497,8 +582,15 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
     }
     const int dt0 = d0.cv_toff[0][0] - tmin, dt1 = d0.cv_toff[0][1] - tmin;
 
-    constexpr int OPR = CO / 8;
+    constexpr int OPR = CO / NDST / 8;                 // pieces per row of a destination
     const bool im_thread = (tid % OPR) >= OPR / 2;
+    CtBnr bnr;
+    float4 bzc[4], bmb[4];
+    float bslope = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) bnr.s[i] = 0.f;
+    bnr.da = 0.f;
+    if (BNR) { ct_bnr_coef<OPR>(d0.bnr_coef, tid, bzc, bmb); bslope = d0.bnr_slope[0]; }
     float st[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) st[i] = 0.f;
@@ -510,12 +602,12 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
     for (int i = 0; i <= nout; ++i) {
         // exact count: the D - 1 younger DMA pieces and the NDST stores of each step since (convt_stream_kernel)
         switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
-            case 0: ct_wait_vm<(D - 1) + 0 * NDST>(); break;
-            case 1: ct_wait_vm<(D - 1) + 1 * NDST>(); break;
-            case 2: ct_wait_vm<(D - 1) + 2 * NDST>(); break;
-            case 3: ct_wait_vm<(D - 1) + 3 * NDST>(); break;
-            case 4: ct_wait_vm<(D - 1) + 4 * NDST>(); break;
-            default: ct_wait_vm<(D - 1) + (D - 1) * NDST>(); break;
+            case 0: ct_wait_vm<(D - 1) * NSR + 0 * NDST>(); break;
+            case 1: ct_wait_vm<(D - 1) * NSR + 1 * NDST>(); break;
+            case 2: ct_wait_vm<(D - 1) * NSR + 2 * NDST>(); break;
+            case 3: ct_wait_vm<(D - 1) * NSR + 3 * NDST>(); break;
+            case 4: ct_wait_vm<(D - 1) * NSR + 4 * NDST>(); break;
+            default: ct_wait_vm<(D - 1) * NSR + (D - 1) * NDST>(); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -524,10 +616,18 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
             const unsigned ot = sm + OUT_OFF + ((i - 1) & 1) * (NDST * 4096);
             ct_u4 ld0 = ct_lds_read16(ot + 16 * tid);
             ct_u4 ld1 = (STATS || NDST == 2) ? ct_lds_read16(STATS ? ot + 16 * (tid ^ (OPR / 2)) : ot + 4096 + 16 * tid) : ct_u4{0u, 0u, 0u, 0u};
+            ct_u4 lb0 = ld0, lb1 = ld0, lb2 = ld0;
+            if (BNR) {                                 // the partner piece of destination 0, this thread's and the partner's piece of y
+                lb0 = ct_lds_read16(ot + 16 * (tid ^ (OPR / 2)));
+                lb1 = ct_lds_read16(sm + Y_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * tid);
+                lb2 = ct_lds_read16(sm + Y_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * (tid ^ (OPR / 2)));
+            }
             CT_WAIT2N(0, ld0, ld1);
+            if (BNR) { WS_TIE(lb0); WS_TIE(lb1); WS_TIE(lb2); }
             const uint4 v = __builtin_bit_cast(uint4, ld0);
             *reinterpret_cast<uint4*>(outp[0] + (size_t)(t_lo + i - 1) * obytes[0]) = v;
             if (NDST == 2) *reinterpret_cast<uint4*>(outp[NDST - 1] + (size_t)(t_lo + i - 1) * obytes[NDST - 1]) = __builtin_bit_cast(uint4, ld1);
+            if (BNR) ct_bnr_add(bnr, v, __builtin_bit_cast(uint4, lb0), __builtin_bit_cast(uint4, lb1), __builtin_bit_cast(uint4, lb2), bzc, bmb, bslope, im_thread);
             if (STATS) {
                 const uint4 vp = __builtin_bit_cast(uint4, ld1);
                 const unsigned own[2] = {im_thread ? v.z : v.x, im_thread ? v.w : v.y}, oth[2] = {im_thread ? vp.z : vp.x, im_thread ? vp.w : vp.y};
@@ -588,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after the workgroup has given its LDS back
 
+    if (BNR) ct_bnr_flush<OPR>(bnr, reinterpret_cast<float*>(smem + RED_OFF), d0.bnr_part + (size_t)blockIdx.x * (6 * (CO / NDST / 2) + 1), CO / NDST / 2, tid, lane, wave);
     if (STATS) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [4 waves][OPR][20]
@@ -616,14 +717,15 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
 // zero rows; K = 2 time taps x 5 row taps x 2 channels, stored as k = 16 kt + 2 tap + c and padded to 32, is ONE MFMA k step: a lane's
 // eight k are the 16 contiguous bytes of four consecutive rows (the taps beyond the fifth meet zero weights -- and zeroed rows behind
 // the frame, so that no NaN pattern of stale LDS is multiplied by them).  128 output rows = 8 row tiles, two per wave.
-template <int CO, int NDST, bool STATS>
+template <int CO, int NDST, bool STATS, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_desc d0, int B, int fpw) {
+    static_assert(!BNR || (NDST == 2 && !STATS), "the reduce pass rides on the input gradient");
     static_assert(CO == 16 * NDST && (!STATS || NDST == 1), "16 channels per destination");
     constexpr int J = 128, LEAD = 4, ROWS = LEAD + 2 * J + 8;     // image rows of 4 bytes: 4 zero rows, the frame, 8 zero rows
     constexpr int SLOT = ROWS * 4;
     constexpr int R = 8, D = R - 2;
     constexpr int NT = CO / 16;
-    constexpr int OUT_OFF = (R * SLOT + 15) / 16 * 16, RED_OFF = OUT_OFF + 2 * NDST * 4096;
+    constexpr int OUT_OFF = (R * SLOT + 15) / 16 * 16, Y_OFF = OUT_OFF + 2 * NDST * 4096, RED_OFF = Y_OFF + (BNR ? R * 4096 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -654,7 +756,19 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
     const unsigned sbase = (unsigned)(b * S.T) * fbytes + 16u * (unsigned)lane;
     const __amdgpu_buffer_rsrc_t rs0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
-    auto issue = [&](int v) {                          // (wave 0 only: one 1 KB instruction per frame)
+    const sehip_dst& dy0 = d0.dst[0];
+    const unsigned ybytes = 2u * (unsigned)(dy0.F * dy0.C);
+    const unsigned ybase = (unsigned)(b * dy0.T + dy0.toff) * ybytes + 16u * (unsigned)tid;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(BNR ? d0.bnr_y : S.ptr)), 0, CT_RECORDS, 0x00020000);
+    auto issue = [&](int v) {                          // (the input frame by wave 0 only: one 1 KB instruction per frame)
+        if (BNR) {                                     // the BatchNorm layer's convolution output at output frame v - 2: every wave, 4 KB
+            const int o = v - 2;
+            const bool oky = o >= 0 && o < nout;
+            const unsigned vy = oky ? ybase + (unsigned)(t_lo + o) * ybytes : CT_OOB;
+            unsigned char* dy = smem + Y_OFF + (o & (R - 1)) * 4096 + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (ct_lds_void*)dy, 16, vy, 0, 0, CT_AUX);
+        }
         if (wave != 0) return;
         const int u = t_lo + tmin + v;
         const bool ok = u >= S.tlo && u < S.thi && v <= nout;
@@ -678,6 +792,13 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
 
     constexpr int OPR = 2;                             // pieces per output row of a destination: [8 real | 8 imaginary]
     const bool im_thread = tid & 1;
+    CtBnr bnr;
+    float4 bzc[4], bmb[4];
+    float bslope = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) bnr.s[i] = 0.f;
+    bnr.da = 0.f;
+    if (BNR) { ct_bnr_coef<OPR>(d0.bnr_coef, tid, bzc, bmb); bslope = d0.bnr_slope[0]; }
     float st[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) st[i] = 0.f;
@@ -686,14 +807,27 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
 #pragma unroll
     for (int v = 0; v <= D; ++v) issue(v);
     for (int i = 0; i <= nout; ++i) {
-        // wave 0: the D - 1 younger DMA pieces and the NDST stores of each step since; the other waves have only their stores in flight
-        switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
-            case 0: ct_wait_vm<(D - 1) + 0 * NDST>(); break;
-            case 1: ct_wait_vm<(D - 1) + 1 * NDST>(); break;
-            case 2: ct_wait_vm<(D - 1) + 2 * NDST>(); break;
-            case 3: ct_wait_vm<(D - 1) + 3 * NDST>(); break;
-            case 4: ct_wait_vm<(D - 1) + 4 * NDST>(); break;
-            default: ct_wait_vm<(D - 1) + (D - 1) * NDST>(); break;
+        // wave 0: the D - 1 younger DMA batches (input piece + y piece) and the NDST stores of each step since; the other waves have
+        // only their y pieces and stores in flight -- exact per wave: the y piece of frame i - 1 arrived with batch i + 1
+        if (!BNR || wave == 0) {
+            constexpr int NSR = 1 + (BNR ? 1 : 0);
+            switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
+                case 0: ct_wait_vm<(D - 1) * NSR + 0 * NDST>(); break;
+                case 1: ct_wait_vm<(D - 1) * NSR + 1 * NDST>(); break;
+                case 2: ct_wait_vm<(D - 1) * NSR + 2 * NDST>(); break;
+                case 3: ct_wait_vm<(D - 1) * NSR + 3 * NDST>(); break;
+                case 4: ct_wait_vm<(D - 1) * NSR + 4 * NDST>(); break;
+                default: ct_wait_vm<(D - 1) * NSR + (D - 1) * NDST>(); break;
+            }
+        } else {
+            switch (i - 1 < D - 1 ? (i - 1 < 0 ? 0 : i - 1) : D - 1) {
+                case 0: ct_wait_vm<(D - 1) + 0 * NDST>(); break;
+                case 1: ct_wait_vm<(D - 1) + 1 * NDST>(); break;
+                case 2: ct_wait_vm<(D - 1) + 2 * NDST>(); break;
+                case 3: ct_wait_vm<(D - 1) + 3 * NDST>(); break;
+                case 4: ct_wait_vm<(D - 1) + 4 * NDST>(); break;
+                default: ct_wait_vm<(D - 1) + (D - 1) * NDST>(); break;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -701,10 +835,18 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
             const unsigned ot = sm + OUT_OFF + ((i - 1) & 1) * (NDST * 4096);
             ct_u4 ld0 = ct_lds_read16(ot + 16 * tid);
             ct_u4 ld1 = (STATS || NDST == 2) ? ct_lds_read16(STATS ? ot + 16 * (tid ^ (OPR / 2)) : ot + 4096 + 16 * tid) : ct_u4{0u, 0u, 0u, 0u};
+            ct_u4 lb0 = ld0, lb1 = ld0, lb2 = ld0;
+            if (BNR) {                                 // the partner piece of destination 0, this thread's and the partner's piece of y
+                lb0 = ct_lds_read16(ot + 16 * (tid ^ (OPR / 2)));
+                lb1 = ct_lds_read16(sm + Y_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * tid);
+                lb2 = ct_lds_read16(sm + Y_OFF + ((i - 1) & (R - 1)) * 4096 + 16 * (tid ^ (OPR / 2)));
+            }
             CT_WAIT2N(0, ld0, ld1);
+            if (BNR) { WS_TIE(lb0); WS_TIE(lb1); WS_TIE(lb2); }
             const uint4 v = __builtin_bit_cast(uint4, ld0);
             *reinterpret_cast<uint4*>(outp[0] + (size_t)(t_lo + i - 1) * obytes[0]) = v;
             if (NDST == 2) *reinterpret_cast<uint4*>(outp[NDST - 1] + (size_t)(t_lo + i - 1) * obytes[NDST - 1]) = __builtin_bit_cast(uint4, ld1);
+            if (BNR) ct_bnr_add(bnr, v, __builtin_bit_cast(uint4, lb0), __builtin_bit_cast(uint4, lb1), __builtin_bit_cast(uint4, lb2), bzc, bmb, bslope, im_thread);
             if (STATS) {
                 const uint4 vp = __builtin_bit_cast(uint4, ld1);
                 const unsigned own[2] = {im_thread ? v.z : v.x, im_thread ? v.w : v.y}, oth[2] = {im_thread ? vp.z : vp.x, im_thread ? vp.w : vp.y};
@@ -745,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    if (BNR) ct_bnr_flush<OPR>(bnr, reinterpret_cast<float*>(smem + RED_OFF), d0.bnr_part + (size_t)blockIdx.x * (6 * 8 + 1), 8, tid, lane, wave);
     if (STATS) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem + RED_OFF);               // [4 waves][OPR][20]
@@ -767,45 +910,63 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
     }
 }
 
-template <int CO, int NDST, bool STATS>
-static int cn_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
-    constexpr size_t lds = (size_t)8 * (4 + 256 + 8) * 4 + 16 + 2 * NDST * 4096 + (STATS ? 4 * 2 * 20 * 4 : 0) + 64;
+// workgroups per utterance of the forward / input-gradient streaming kernels (and with them the rows of a fused reduce pass)
+// (a launch that also writes a row of BatchNorm sums per workgroup: 16, so that 32 utterances leave the 512 rows the finalize kernel
+//  reads in one trip -- with 1024 rows it took 24-31 us instead of 8.5)
+static int ct_chunks_of(int TT, bool bnr = false) {
     static const int env_chunks = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 0;
-    int chunks = env_chunks > 0 ? env_chunks : 32;
-    if (chunks > a.TT) chunks = a.TT;
-    const int fpw = (a.TT + chunks - 1) / chunks;
-    chunks = (a.TT + fpw - 1) / fpw;
-    sehip_note_kernel("convn_stream_kernel<%d, %d, %d>", CO, NDST, (int)STATS);
-    convn_stream_kernel<CO, NDST, STATS><<<B * chunks, 256, lds, st>>>(a, B, fpw);
-    return 1;
+    static const int env_bnr = getenv("SEHIP_BNR_CHUNKS") ? atoi(getenv("SEHIP_BNR_CHUNKS")) : 0;
+    int chunks = bnr ? (env_bnr > 0 ? env_bnr : 16) : env_chunks > 0 ? env_chunks : 32;
+    if (chunks > TT) chunks = TT;
+    const int fpw = (TT + chunks - 1) / chunks;
+    return (TT + fpw - 1) / fpw;
 }
 
-template <int C, int CO, int J, int NDST, bool STATS>
-static int cs_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
-    constexpr size_t lds = (size_t)8 * 2 * (J + 2) * C * 2 + 2 * NDST * 4096 + (STATS ? 4 * (CO / 8) * 20 * 4 : 0) + 64;
+template <int CO, int NDST, bool STATS, bool BNR = false>
+static int cn_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)8 * (4 + 256 + 8) * 4 + 16 + 2 * NDST * 4096 + (BNR ? 8 * 4096 + 4 * 2 * 25 * 4 : 0) + (STATS ? 4 * 2 * 20 * 4 : 0) + 64;
     static unsigned char state[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
     if (state[dev] == 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convs_stream_kernel<C, CO, J, NDST, STATS>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convn_stream_kernel<CO, NDST, STATS, BNR>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) (void)hipGetLastError();
         state[dev] = e == hipSuccess ? 1 : 2;
     }
     if (state[dev] != 1) return 0;
-    static const int env_chunks = getenv("SEHIP_CT_CHUNKS") ? atoi(getenv("SEHIP_CT_CHUNKS")) : 0;
-    int chunks = env_chunks > 0 ? env_chunks : 32;
-    if (chunks > a.TT) chunks = a.TT;
+    const int chunks = ct_chunks_of(a.TT, BNR);
     const int fpw = (a.TT + chunks - 1) / chunks;
-    chunks = (a.TT + fpw - 1) / fpw;
-    sehip_note_kernel("convs_stream_kernel<%d, %d, %d, %d, %d>", C, CO, J, NDST, (int)STATS);
-    convs_stream_kernel<C, CO, J, NDST, STATS><<<B * chunks, 256, lds, st>>>(a, B, fpw);
+    sehip_note_kernel("convn_stream_kernel<%d, %d, %d, %d>", CO, NDST, (int)STATS, (int)BNR);
+    convn_stream_kernel<CO, NDST, STATS, BNR><<<B * chunks, 256, lds, st>>>(a, B, fpw);
     return 1;
 }
 
-// returns 1 if the product was launched (dry: would be), 0 if it does not qualify (the caller goes on to conv_small2 / the generic kernels)
-int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) {
+template <int C, int CO, int J, int NDST, bool STATS, bool BNR = false>
+static int cs_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)(BNR ? 4 : 8) * 2 * (J + 2) * C * 2 + 2 * NDST * 4096 + (BNR ? 4 * 4096 + 4 * 4 * 25 * 4 : 0) + (STATS ? 4 * (CO / 8) * 20 * 4 : 0) + 64;
+    static unsigned char state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convs_stream_kernel<C, CO, J, NDST, STATS, BNR>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    const int chunks = ct_chunks_of(a.TT, BNR);
+    const int fpw = (a.TT + chunks - 1) / chunks;
+    sehip_note_kernel("convs_stream_kernel<%d, %d, %d, %d, %d, %d>", C, CO, J, NDST, (int)STATS, (int)BNR);
+    convs_stream_kernel<C, CO, J, NDST, STATS, BNR><<<B * chunks, 256, lds, st>>>(a, B, fpw);
+    return 1;
+}
+
+// mode 0: launch; 1: dry run (1 if it would be launched); 2: the rows of sums a launch with the bnr_* fields would write (0: none)
+static int convs_dispatch(const sehip_gemm_desc& a, hipStream_t st, int mode) {
     static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr;
+    static const bool no_bnr = getenv("SEHIP_NO_BNR") != nullptr;
+    const bool dry = mode == 1;
     if (disabled || a.w_tiled) return 0;
     if (a.cv_nf != 5 || a.cv_fadd != -2 || a.fmul != 2 || a.tmul > 1 || a.N != a.Npad || a.res) return 0;
     if (a.src[1].ptr || !a.src[0].ptr) return 0;
@@ -828,14 +989,25 @@ int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) {
     if (ndst == 2 && a.bias) return 0;
     if (((uintptr_t)a.W & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
     static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bits 32 .. 1024: these variants
+    // the BatchNorm backward reduce pass of destination 0's layer inside the launch (bnr_*): the two 16-channel input gradients;
+    // rows = workgroups, at most what sehip_cbn_bwd_finalize_n adds
+    const int rows = B * ct_chunks_of(a.TT, true);
+    const bool can_bnr = !no_bnr && rows <= 1024 && ndst == 2 && ((C == 2 && CO == 32 && J == 128 && !(skip & 256)) || (C == 16 && CO == 64 && J == 64 && !(skip & 64)));
+    if (mode == 2) return can_bnr ? rows : 0;
+    const bool bnr = can_bnr && a.bnr_part && a.bnr_y && a.bnr_coef && a.bnr_slope;
     if (C == 2 && CO == 16 && J == 128 && ndst == 1) return (skip & 128) ? 0 : dry ? 1 : cn_launch<16, 1, true>(a, B, st);
-    if (C == 2 && CO == 32 && J == 128 && ndst == 2) return (skip & 256) ? 0 : dry ? 1 : cn_launch<32, 2, false>(a, B, st);
+    if (C == 2 && CO == 32 && J == 128 && ndst == 2)
+        return (skip & 256) ? 0 : dry ? 1 : bnr ? cn_launch<32, 2, false, true>(a, B, st) : cn_launch<32, 2, false>(a, B, st);
     if (C == 16 && CO == 32 && J == 64 && ndst == 1) return (skip & 32) ? 0 : dry ? 1 : cs_launch<16, 32, 64, 1, true>(a, B, st);
-    if (C == 16 && CO == 64 && J == 64 && ndst == 2) return (skip & 64) ? 0 : dry ? 1 : cs_launch<16, 64, 64, 2, false>(a, B, st);
+    if (C == 16 && CO == 64 && J == 64 && ndst == 2)
+        return (skip & 64) ? 0 : dry ? 1 : bnr ? cs_launch<16, 64, 64, 2, false, true>(a, B, st) : cs_launch<16, 64, 64, 2, false>(a, B, st);
     if (C == 32 && CO == 64 && J == 32 && ndst == 1) return (skip & 512) ? 0 : dry ? 1 : cs_launch<32, 64, 32, 1, true>(a, B, st);
     if (C == 32 && CO == 128 && J == 32 && ndst == 2) return (skip & 1024) ? 0 : dry ? 1 : cs_launch<32, 128, 32, 2, false>(a, B, st);
     return 0;
 }
+// returns 1 if the product was launched (dry: would be), 0 if it does not qualify (the caller goes on to conv_small2 / the generic kernels)
+int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry) { return convs_dispatch(a, st, dry ? 1 : 0); }
+int sehip_convs_bnr_rows(const sehip_gemm_desc& a) { return convs_dispatch(a, nullptr, 2); }
 
 template <int C, int NS, int CO, int J, bool STATS, bool RES>
 static int ct_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, hipStream_t st) {

@@ -1381,6 +1381,12 @@ static int check_desc(const char* who, const sehip_gemm_desc* d) {
 
 extern "C" int sehip_gemm_desc_size(void) { return (int)sizeof(sehip_gemm_desc); }
 
+int sehip_convs_bnr_rows(const sehip_gemm_desc& a);   // convt.hip
+extern "C" int sehip_bnr_rows(const sehip_gemm_desc* a, const sehip_gemm_desc* b) {
+    if (!a || b) return 0;                            // (pairs: not built)
+    return sehip_convs_bnr_rows(*a);
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv_narrow_kernel: forward / dgrad product whose SOURCE has 2 channels (the first encoder layer reads the
 // spectrogram, the last decoder layer's input gradient reads d(mask)): K = 2 frames x 5 taps x 2 channels in the

@@ -47,7 +47,8 @@ class CGemmDesc(C.Structure):
                 ("cv2_fadd", C.c_int32), ("cv2_t0", C.c_int32), ("w_tiled", C.c_int32), ("wg_hint", C.c_int32), ("dense_rows", C.c_int32),
                 ("dw_split_stride", C.c_int64),
                 ("bn_dz", C.c_void_p), ("bn_y", C.c_void_p), ("bn_coef", C.c_void_p), ("bn_bcoef", C.c_void_p),
-                ("bn_slope", C.c_void_p)]
+                ("bn_slope", C.c_void_p),
+                ("bnr_y", C.c_void_p), ("bnr_coef", C.c_void_p), ("bnr_slope", C.c_void_p), ("bnr_part", C.c_void_p)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient
@@ -979,6 +980,25 @@ class DCCRNWorkspace:
                 for d in ds:
                     d.stats = None
                     d.stats_cr = 0
+        # the BatchNorm backward REDUCE pass of a decoder layer inside the streaming launch that produces its activation gradient
+        # (sehip_gemm_desc.bnr_*, csrc/convt.hip): dec{j}.dg stores dzd{j-1} and leaves one row of sums per workgroup in bn_acc,
+        # sehip_cbn_bwd_finalize_n adds them.  The library says whether (and with how many rows) it does this for the product.
+        self.bnr_rows = {}
+        if not os.environ.get("SEHIP_NO_BNR"):
+            for j in range(1, 6):
+                pre, cr = f"decoder.{j - 1}.", int(st.cfg.kernel_num[6 - j]) // 2
+                d = self.desc[f"dec{j}.dg"]
+                rows = int(lib.sehip_bnr_rows(C.byref(d), None))
+                yb, zb = self.bufs[f"yd{j - 1}"], self.bufs[f"dzd{j - 1}"]
+                if rows <= 0 or d.dst[0].ptr != zb.ptr or (yb.Tst, yb.F, yb.C) != (zb.Tst, zb.F, zb.C) or yb.C != 2 * cr:
+                    continue
+                if rows * (6 * cr + 1) > self.bn_acc.numel():
+                    self.bn_acc = torch.zeros(rows * (6 * cr + 1), dtype=torch.float32, device=self.device)
+                self.bnr_rows[pre] = (rows, f"dec{j}.dg")
+            for pre, (rows, name) in self.bnr_rows.items():
+                d = self.desc[name]
+                d.bnr_y, d.bnr_coef, d.bnr_part = self.bufs["yd" + pre.split(".")[1]].ptr, ptr(self.bn_coef[pre]), ptr(self.bn_acc)
+                # (bnr_slope: set per call, from params)
         if not os.environ.get("SEHIP_NO_WGRAD_GROUP") and not st.deterministic:
             for layers in ((1,), (2,), (2, 1)):
                 self._wgrad_group_handle(self._lstm_wgrad_names(layers))
@@ -1141,6 +1161,14 @@ class DCCRNWorkspace:
         coef = self.bn_coef[pre]
         dz2p = dz2.ptr if dz2 is not None else None
         self._chain_dirty = True
+        if pre in self.bnr_rows and dz2 is None and not self.fuse_bwd_finalize:
+            # the launch that produced dz left the reduce pass's sums in bn_acc, one row per workgroup (bnr_rows)
+            call("sehip_cbn_bwd_finalize_n", ptr(self.bn_acc), self.bnr_rows[pre][0], ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
+                 g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
+            if apply:
+                call("sehip_cbn_bwd_apply", dz.ptr, dz2p, y.ptr, ptr(coef), ptr(self.bn_bcoef), pp("2.weight"), rows, cr, y.F,
+                     y.Tst, tfirst, dy.ptr, stream())
+            return
         if self.fuse_bwd_finalize:  # the reduce pass leaves its sums in a few rows, the apply pass finalizes them: two launches
             rep = self.bn_brep[pre]
             if torch.cuda.is_current_stream_capturing():
@@ -1310,6 +1338,8 @@ class DCCRNWorkspace:
                 self.bn_backward(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"dzd{j}"], None, b[f"yd{j}"], b[f"dyd{j}"],
                                  params, 1)
             self.wgrad_pair(f"dec{j}.fwd0", f"dec{j}.fwd1")
+            if j >= 1 and f"decoder.{j - 1}." in self.bnr_rows:
+                self.desc[f"dec{j}.dg"].bnr_slope = params.data_ptr() + 4 * st.layout.param_off[f"decoder.{j - 1}.2.weight"][0]
             self.gemm(f"dec{j}.dg")
         for tag in "ri":
             self.wgrad(f"proj_{tag}")
