@@ -1,23 +1,31 @@
-// convt_stream_kernel (round 4): the small-channel "two output rows per input row" products of DCCRN as ONE streaming launch per
-// layer -- the forward pass of the outer ComplexConvTranspose2d layers (src/model/dccrn.py:387-450; decoder 3 / 4 at the headline
-// widths: 64 + 64 -> 32 and 32 + 32 -> 16 channels, skip concat as second source) and the input gradient of the outer ComplexConv2d
-// layers (:316-384; encoder 2 / 1: 64 -> 32 and 32 -> 16 channels), both output-row parities in one pass.
+// Streaming LDS-DMA kernels for the OUTER layers of DCCRN (round 4; DESIGN.md section 4 "The outer layers as streaming LDS-DMA
+// kernels"): every tensor of encoder 0-2 / decoder 3-5 at the headline widths has frames of exactly 4 KB (rows x channels x 2 B),
+// which gives one construction for the forward, input-gradient and weight-gradient products of those layers.  In this file:
+//   convt_stream_kernel    "two output rows per input row": ComplexConvTranspose2d forward (src/model/dccrn.py:387-450; decoder 3 / 4
+//                          with bias + BatchNorm sums, decoder 5 = the fp32 mask) and ComplexConv2d input gradient (:316-384;
+//                          encoder 2 / 1, + the skip connection's gradient), both output-row parities in one pass
+//   convs_stream_kernel    "two input rows per output row", 16 or 32 input channels: encoder 1 / 2 forward, decoder 4 / 3 input gradient
+//   convn_stream_kernel    the same for a 2-channel source: encoder 0 forward, decoder 5 input gradient
+//   wgrads_stream_kernel   weight gradient of encoder 1 / 2;  wgradt_stream_kernel: of both parities of decoder 3 / 4 (sehip_wgrad_pair)
+//   ws_reduce(2)_kernel    partial rows of the weight-gradient launches -> dW / dbias
+//   ct_bnr_*               the ComplexBatchNorm backward reduce pass inside an input-gradient launch (sehip_gemm_desc.bnr_*)
+// Other widths / shapes do not qualify and run on the round-3 kernels (csrc/gemm.hip): every sehip_try_* below returns 0 for them.
 //
-// These layers are HBM-bound by a wide margin (27 GF over 126 MB for the largest), but conv_small2_kernel ran them at 1.3-1.6 TB/s:
-// its descriptor-generic staging spends 13-29 vector instructions per MFMA on addresses and packing.  Here
-// nothing in the frame loop computes an address:
-//   * a workgroup (4 waves, two per CU) owns a run of consecutive output frames of one utterance; every input frame of every source is
-//     exactly 4 KB = ONE 16-byte LDS-DMA piece per thread (buffer_load ... lds; per-lane source offset computed once, a scalar frame
-//     offset per step; frames outside the valid range are offsets beyond num_records: zeros), ring of four frames per source, counted
-//     vmcnt, ONE barrier per output frame;
-//   * the LDS image of a frame is [J + 2 rows][C channels] with the 16-byte pieces of a row XOR-permuted by the row index (the DMA
-//     reads per-lane sources, so the permutation is free): the 16 rows a ds_read_b128 lane group touches are 16 distinct bank slots
-//     for every tap; rows -1 and J are zeros (the frequency padding);
+// convt_stream_kernel.  These layers are HBM-bound by a wide margin (27 GF over 126 MB for the largest), but conv_small2_kernel ran them
+// at 1.3-1.6 TB/s: its descriptor-generic staging spends 13-29 vector instructions per MFMA on addresses and packing (VERDICT r3
+// weak #6).  Here nothing in the frame loop computes an address:
+//   * a workgroup (4 waves; 32 workgroups per utterance = two per CU at B = 16-32) owns a run of consecutive output frames of one
+//     utterance; every input frame of every source is exactly 4 KB = ONE 16-byte LDS-DMA piece per thread (buffer_load ... lds;
+//     per-lane source offset computed once, a scalar frame offset per step; frames outside the valid range are offsets beyond
+//     num_records: zeros), ring of eight frames per source (six in flight), counted vmcnt, ONE barrier per output frame;
+//   * the LDS image of a frame is [J + 2 rows][C channels] with the 16-byte pieces of a row XOR-permuted by a function of the row
+//     index (ct_swz; the DMA reads per-lane sources, so the permutation is free): the 16 rows a ds_read_b128 lane group touches are
+//     16 distinct bank slots for every tap; rows -1 and J are zeros (the frequency padding);
 //   * ALL weight fragments of both parities live in registers for the whole launch (10 x (input channels / 32) MFMA A operands per
-//     wave: 40 - 160 VGPRs); wave (wn, wm) owns 16 output channels x 16 input rows x both parities;
+//     wave: 40 - 160 VGPRs); wave (wn, wm) owns 16 output channels x 16 (or 32) input rows x both parities;
 //   * the output frame ([2 J rows][CO channels] = 4 KB) is staged in LDS and leaves as one coalesced 16-byte store per thread, with the
 //     skip gradient (`res`, also fetched by DMA) added on the way; the ComplexBatchNorm sums of the forward layers are taken from that
-//     staged tile (the values as stored), 40 sums per thread in registers for the whole launch, 80 atomics per workgroup at the end.
+//     staged tile (the values as stored), 20 sums per thread in registers for the whole launch, 80-160 atomics per workgroup at the end.
 // Operand conventions are sehip_gemm's: the two descriptors of a pair (parity 0: row taps -1, 0, +1; parity 1: 0, +1), K ordered
 // (time tap, row tap, source, channel), W bf16 [Npad][K], bias fp32, dst rows 2 j + parity.
 #include <stdlib.h>
