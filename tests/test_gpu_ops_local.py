@@ -137,7 +137,7 @@ def test_complex_batchnorm_prelu_forward_backward(run, name):
     if enc:
         from sehip.plan import FUSE_SKIP_GRAD
         dz = to_ref(b["dz5l"] if idx == "5" else b[f"dz{idx}"])
-        if idx == "5" or not FUSE_SKIP_GRAD:      # for encoder 0..4 the skip gradient is already inside dz
+        if not FUSE_SKIP_GRAD:                    # otherwise the skip gradient is already inside dz (descriptor field `res` of the producer)
             dz = dz + to_ref(b[f"dskip{idx}"])
         dyh = to_ref(b[f"dye{idx}"])
     else:
@@ -170,7 +170,11 @@ def test_complex_lstm_forward_backward(run):
     assert rel_err(to_ref(b["P"]), out.detach()) < 1e-2
     dP = to_ref(b["dP"])
     outs = torch.autograd.grad((out * dP).sum(), [r_in, i_in] + [leaves[k] for k in names])
-    dz5 = to_ref(b["dz5l"]).permute(3, 0, 1, 2)
+    from sehip.plan import FUSE_SKIP_GRAD
+    dz5 = to_ref(b["dz5l"])
+    if FUSE_SKIP_GRAD:        # the dx1 products store the LSTM's input gradient + the innermost skip connection's (descriptor field `res`)
+        dz5 = dz5 - to_ref(b["dskip5"])
+    dz5 = dz5.permute(3, 0, 1, 2)
     assert rel_err(dz5[:, :, : ch // 2].reshape(T, B, -1), outs[0]) < 3e-2
     assert rel_err(dz5[:, :, ch // 2:].reshape(T, B, -1), outs[1]) < 3e-2
     G = run["grads"]
