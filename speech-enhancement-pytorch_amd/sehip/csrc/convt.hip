@@ -70,7 +70,6 @@ __device__ __forceinline__ ct_u2 ct_lds_read8(unsigned addr) {
 __device__ __forceinline__ void ct_lds_write8(unsigned addr, ct_u2 v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-__device__ __forceinline__ void ct_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // (macros, not functions: "+v" on an element of an array passed by reference is a "tied indirect register input" hipcc refuses)
 // (volatile asm statements keep their order: a register tied behind the wait is not consumed in front of it)
 #define WS_TIE(v) asm volatile("" : "+v"(v))
