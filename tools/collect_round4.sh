@@ -6,7 +6,7 @@
 #   kernel_stats_{dcunet,convtasnet,demucs}.csv          the same for the other workloads (overlapped)
 #   traffic.json / traffic_{dcunet,convtasnet,demucs}.json   FETCH_SIZE / WRITE_SIZE PMC passes over the real step (tools/traffic_summary.py)
 #   mfma_util.json                                       MFMA busy / instruction counters per kernel class (tools/mfma_util_summary.py)
-#   gaps.txt                                             two-queue timeline of one overlapped step (tools/trace_gaps.py)
+#   gaps.txt / gaps_{dcunet,convtasnet,demucs}.txt       two-queue timeline of one overlapped step (tools/trace_gaps.py)
 set +e
 COMMIT=${1:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -36,6 +36,14 @@ done
 t=$(ls $OUT/prof/*/run_kernel_trace.csv $OUT/prof/run_kernel_trace.csv 2>/dev/null | head -1)
 cd $ROOT
 [ -n "$t" ] && SEHIP_TRACE_TIMELINE=1 python tools/trace_gaps.py $t > $OUT/gaps.txt 2>&1
+# the same two-queue timeline for the other workloads (their step starts at a different kernel)
+for ws in "convtasnet:void ctn_encoder_fwd" "dcunet:dcunet_pack_input_kernel" "demucs:dmx_prep_up_kernel"; do
+  w=${ws%%:*}; first=${ws#*:}
+  (cd /tmp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$w -o run -- python3 $ROOT/bench.py --workload $w --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-traffic > /dev/null 2>&1)
+  tt=$(ls $OUT/tl_$w/*/run_kernel_trace.csv $OUT/tl_$w/run_kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$tt" ] && SEHIP_TRACE_START="$first" SEHIP_TRACE_TIMELINE=1 python tools/trace_gaps.py $tt > $OUT/gaps_$w.txt 2>&1
+  rm -rf $OUT/tl_$w
+done
 python tools/traffic_summary.py $OUT/pm_dccrn 3 > $OUT/traffic.json 2>$OUT/traffic.err
 for w in dcunet convtasnet demucs; do python tools/traffic_summary.py $OUT/pm_$w 3 > $OUT/traffic_$w.json 2>>$OUT/traffic.err; done
 python tools/mfma_util_summary.py $OUT $COMMIT > $OUT/mfma_util.json 2>$OUT/mfma.err
