@@ -1554,6 +1554,155 @@ __global__ __launch_bounds__(256, (C * CO >= 2048 ? 1 : 2)) void wgradt_stream_k
     }
 }
 
+// wgradt2_stream_kernel: the same pair of weight gradients for the network's LAST layer (decoder 5, src/model/dccrn.py:205-212: 16 + 16
+// channels -> the 2-channel mask; dOut = d(mask), 256 rows x 2 channels x bf16 = 1 KB per frame, fetched by wave 0 alone as it lies in
+// memory).  M = the 2 output channels padded to one 16-row MFMA tile (rows 2 .. 15 of the accumulators are never stored, whatever their
+// A operand rows hold); the A operand of a k step -- dOut^T of 32 rows j for both parities -- comes from eight 8-byte reads per lane
+// (rows 2 j, 2 j + 1: both channels of both parities) and a v_perm per pair of rows; the B operands are wgradt_stream_kernel's three
+// shifted transposed reads of the source image ([130 rows][16 channels], 32-byte rows in the permuted order), four k steps per frame.
+__global__ __launch_bounds__(256, 2) void wgradt2_stream_kernel(const sehip_gemm_desc d0, const sehip_gemm_desc d1, int B, int fpw,
+                                                                float* __restrict__ parts, int row_len) {
+    constexpr int C = 16, J = 128, RBX = 32;
+    constexpr int SLOTX = (J + 2) * RBX;               // 4160
+    constexpr int R = 4, D = R - 2;
+    constexpr int KS = J / 32;
+    constexpr int G_OFF = 2 * R * SLOTX, GSLOT = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned sm = (unsigned)(__UINTPTR_TYPE__)(ct_lds_void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt = wave >> 1, s_w = wave & 1;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int TT = d0.TT;
+    const int chunks = (TT + fpw - 1) / fpw;
+    const int b = blockIdx.x / chunks, ck = blockIdx.x - b * chunks;
+    const int t_lo = ck * fpw, t_hi = min(TT, t_lo + fpw);
+    const int nout = t_hi - t_lo;
+    if (b >= B) return;
+
+    for (int i = tid; i < 2 * R * 2 * (RBX / 16); i += 256) {        // zero rows 0 and J + 1 of every source image
+        const int sl = i / (2 * (RBX / 16)), rr = (i / (RBX / 16)) & 1, q = i % (RBX / 16);
+        *reinterpret_cast<uint4*>(smem + sl * SLOTX + (rr ? (J + 1) * RBX : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    unsigned x_off;
+    {
+        const int prow_s = 1 + tid / 2, q_s = tid & 1;               // image row slot (1 .. J), piece slot
+        const int rho = prow_s ^ (((prow_s >> 3) & 1) << 2);         // the row stored there (ws_rowbyte<32>: an involution)
+        x_off = 2u * (unsigned)((rho - 1) * C + q_s * 8);
+    }
+    const sehip_dst& Gd = d0.dst[0];
+    int tmin[2];
+    unsigned xfbytes[2], xbase[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const sehip_src& S = s ? d0.src[1] : d0.src[0];
+        tmin[s] = min(d0.cv_toff[s][0], d0.cv_toff[s][1]);
+        xfbytes[s] = 2u * (unsigned)(S.F * S.C);
+        xbase[s] = (unsigned)(b * S.T) * xfbytes[s];
+    }
+    const unsigned gfbytes = 2u * (unsigned)(Gd.F * Gd.C);           // 1024
+    const unsigned gbase = (unsigned)(b * Gd.T + Gd.toff) * gfbytes + 16u * (unsigned)lane;
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[1].ptr)), 0, CT_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_RECORDS, 0x00020000);
+    auto issue = [&](int v) {                          // two source pieces per thread; the dOut frame by wave 0 (third instruction)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const sehip_src& S = s ? d0.src[1] : d0.src[0];
+            const int u = t_lo + tmin[s] + v;
+            const bool ok = u >= S.tlo && u < S.thi && v <= nout;
+            const unsigned vo = ok ? xbase[s] + (unsigned)u * xfbytes[s] + x_off : CT_OOB;
+            unsigned char* dst = smem + (s * R + (v & (R - 1))) * SLOTX + RBX + wave * 1024;
+            if (s == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ct_lds_void*)dst, 16, vo, 0, 0, CT_AUX);
+        }
+        if (wave == 0) {
+            const bool okg = v < nout;
+            const unsigned vg = okg ? gbase + (unsigned)(t_lo + v) * gfbytes : CT_OOB;
+            unsigned char* dg = smem + G_OFF + (v & (R - 1)) * GSLOT;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ct_lds_void*)dg, 16, vg, 0, 0, CT_AUX);
+        }
+    };
+    unsigned preX[KS][3][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh)
+                preX[ks][sh][h] = (unsigned)(ws_rowbyte<RBX>(32 * ks + 8 * g + 4 * h + (i16 >> 2) + sh) + 8 * (i16 & 3));
+    const int dtk = (s_w ? d0.cv_toff[1][kt] - tmin[1] : d0.cv_toff[0][kt] - tmin[0]);
+    const unsigned sel = (i16 & 1) ? 0x07060302u : 0x05040100u;      // the channel's half of two rows' dwords (rows 2 j + p of j, j + 1)
+
+    f32x4 acc0[3], acc1[2], accb[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc1[0] = acc1[1] = accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v <= D; ++v) issue(v);
+    for (int i = 0; i < nout; ++i) {
+        if (wave == 0) ct_wait_vm<(D - 1) * 3>(); else ct_wait_vm<(D - 1) * 2>();     // exact per wave
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned gs = sm + G_OFF + (i & (R - 1)) * GSLOT;
+        const unsigned xs = sm + (s_w * R + ((i + dtk) & (R - 1))) * SLOTX;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ct_u2 gw[8], xl[3], xh[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gw[e] = ct_lds_read8(gs + (unsigned)(32 * ks + 8 * g + e) * 8);      // rows 2 j, 2 j + 1: {c0 c1 | c0 c1}
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh) { xl[sh] = ws_tr_read(xs + preX[ks][sh][0]); xh[sh] = ws_tr_read(xs + preX[ks][sh][1]); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 8; ++e) WS_TIE(gw[e]);
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh) { WS_TIE(xl[sh]); WS_TIE(xh[sh]); }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 af[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                unsigned w4[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2)
+                    w4[e2] = __builtin_amdgcn_perm(p ? gw[2 * e2 + 1].y : gw[2 * e2 + 1].x, p ? gw[2 * e2].y : gw[2 * e2].x, sel);
+                af[p] = __builtin_bit_cast(bf16x8, ct_u4{w4[0], w4[1], w4[2], w4[3]});
+                if (wave == 0) accb[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p], WS_ONES, accb[p], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sh = 0; sh < 3; ++sh) {
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, ct_u4{xl[sh].x, xl[sh].y, xh[sh].x, xh[sh].y});
+                acc0[sh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], xf, acc0[sh], 0, 0, 0);
+                if (sh >= 1) acc1[sh - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], xf, acc1[sh - 1], 0, 0, 0);
+            }
+        }
+        issue(i + D + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // partial row: [2][12 C] (parity 0), [2][8 C] (parity 1), [2] + [2] column sums of dOut; D rows 0, 1 = lane group 0, elements 0, 1
+    float* out = parts + (size_t)blockIdx.x * row_len;
+    constexpr int KA = 12 * C, KB = 8 * C;
+    if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) out[(size_t)e * KA + ((kt * 3 + q) * 2 + s_w) * C + i16] = acc0[q][e];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) out[(size_t)2 * KA + (size_t)e * KB + ((kt * 2 + q) * 2 + s_w) * C + i16] = acc1[q][e];
+            if (wave == 0 && i16 == 0) {
+                out[(size_t)2 * (KA + KB) + e] = accb[0][e];
+                out[(size_t)2 * (KA + KB) + 2 + e] = accb[1][e];
+            }
+        }
+    }
+}
+
 // rows of the pair's partial array -> the two dW ([co][ka], [co][kb]: no padded columns at these widths) and dbias
 __global__ __launch_bounds__(256) void ws_reduce2_kernel(const float* __restrict__ parts, int nparts, int row_len, int co, int ka, int kb,
                                                          float* __restrict__ dWa, float* __restrict__ dWb, float* __restrict__ dba,
@@ -1602,7 +1751,9 @@ int sehip_try_wgradt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, 
     static const bool disabled = getenv("SEHIP_NO_CONVT_STREAM") != nullptr || getenv("SEHIP_NO_WGRAD_STREAM") != nullptr;
     if (disabled || sehip_deterministic()) return 0;
     if (a.cv_nf != 3 || b.cv_nf != 2 || a.cv_fadd != -1 || b.cv_fadd != 0 || a.fmul != 1 || b.fmul != 1) return 0;
-    if (a.tmul > 1 || b.tmul > 1 || a.J != b.J || a.TT != b.TT || a.M != b.M || a.N != b.N || a.Npad != b.Npad || a.N != a.Npad) return 0;
+    if (a.tmul > 1 || b.tmul > 1 || a.J != b.J || a.TT != b.TT || a.M != b.M || a.N != b.N || a.Npad != b.Npad) return 0;
+    const bool mask = a.N == 2 && a.Npad == 16;           // the last layer: 2 of 16 padded rows of dW
+    if (a.N != a.Npad && !mask) return 0;
     if (!a.dW || !b.dW || a.bn_dz || b.bn_dz || a.cv2_nkt || b.cv2_nkt) return 0;
     if (!a.src[1].ptr || !b.src[1].ptr || a.src[2].ptr) return 0;
     for (int s = 0; s < 2; ++s) {
@@ -1625,5 +1776,20 @@ int sehip_try_wgradt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, 
         if ((long)B * a.src[s].T * a.src[s].F * a.src[s].C >= (1L << 30) - (1L << 20)) return 0;
     if (C == 64 && CO == 32 && J == 32) return wgt_launch<64, 32, 32>(a, b, B, st);
     if (C == 32 && CO == 16 && J == 64) return wgt_launch<32, 16, 64>(a, b, B, st);
+    static const int skip = getenv("SEHIP_CT_SKIP") ? atoi(getenv("SEHIP_CT_SKIP")) : 0;      // bit 2048: the last layer's pair (A/B timing)
+    if (mask && C == 16 && J == 128 && !(skip & 2048)) {
+        static const int env_chunks = getenv("SEHIP_WGS_CHUNKS") ? atoi(getenv("SEHIP_WGS_CHUNKS")) : 0;
+        int chunks = env_chunks > 0 ? env_chunks : 8;
+        if (chunks > a.TT) chunks = a.TT;
+        const int fpw = (a.TT + chunks - 1) / chunks;
+        chunks = (a.TT + fpw - 1) / fpw;
+        const int grid = B * chunks, row_len = 2 * 20 * C + 4;
+        float* parts = sehip_wgrad_scratch(st, (size_t)grid * row_len * sizeof(float));
+        if (!parts) return 0;
+        sehip_note_kernel("wgradt2_stream_kernel");
+        wgradt2_stream_kernel<<<grid, 256, (size_t)2 * 4 * 130 * 32 + 4 * 1024 + 64, st>>>(a, b, B, fpw, parts, row_len);
+        ws_reduce2_kernel<<<(row_len + 255) / 256, 256, 0, st>>>(parts, grid, row_len, 2, 12 * C, 8 * C, a.dW, b.dW, a.dbias, b.dbias);
+        return 1;
+    }
     return 0;
 }
