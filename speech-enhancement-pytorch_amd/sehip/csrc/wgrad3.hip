@@ -557,9 +557,12 @@ int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st) {
     // and LSTM part of the chain, where conv_wgrad_kernel's half-CU workgroups share CUs with the chain's kernels: the step was
     // 4.30-4.31 ms with them against 4.25 (SEHIP_W3_CLASSES=7 to measure again)
     static const int classes = getenv("SEHIP_W3_CLASSES") ? atoi(getenv("SEHIP_W3_CLASSES")) : 1;
+    // SEHIP_W3_DEC_J=<sum of J>: the decoder products (3- / 2-tap) of the layers with these rows per frame only (16: decoder 2)
+    static const int dec_j = getenv("SEHIP_W3_DEC_J") ? atoi(getenv("SEHIP_W3_DEC_J")) : 0;
+    const bool dec_ok = dec_j == 0 || (dec_j & d.J);
     if (d.cv_nf == 5 && d.fmul == 2 && (classes & 1)) return w3_launch_j<5, 2>(d, st);
-    if (d.cv_nf == 3 && d.fmul == 1 && (classes & 2)) return w3_launch_j<3, 1>(d, st);
-    if (d.cv_nf == 2 && d.fmul == 1 && (classes & 4)) return w3_launch_j<2, 1>(d, st);
+    if (d.cv_nf == 3 && d.fmul == 1 && (classes & 2) && dec_ok) return w3_launch_j<3, 1>(d, st);
+    if (d.cv_nf == 2 && d.fmul == 1 && (classes & 4) && dec_ok) return w3_launch_j<2, 1>(d, st);
     return 0;
 }
 
