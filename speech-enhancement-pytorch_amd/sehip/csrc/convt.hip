@@ -1289,16 +1289,20 @@ __global__ __launch_bounds__(256, 2) void wgrads_stream_kernel(const sehip_gemm_
     }
 }
 
+#define WS_REDUCE_SLICES 8
 // rows of the partial array ([nparts][co * kv + co]) -> dW ([co][K], K >= kv: the padded columns are left alone) and dbias
 __global__ __launch_bounds__(256) void ws_reduce_kernel(const float* __restrict__ parts, int nparts, int row_len, int co, int kv, int K,
                                                         float* __restrict__ dW, float* __restrict__ dbias) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= row_len) return;
+    // gridDim.y slices of the rows (their sums meet with atomics: 8 per entry, no queue): one slice per entry was 40 workgroups of 256
+    // dependent loads each, 14-25 us per launch
+    const int per = (nparts + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
     float s = 0.f;
 #pragma unroll 8
-    for (int p = 0; p < nparts; ++p) s += parts[(size_t)p * row_len + i];
-    if (i < co * kv) dW[(size_t)(i / kv) * K + (i % kv)] += s;
-    else if (dbias) dbias[i - co * kv] += s;
+    for (int p = p0; p < p1; ++p) s += parts[(size_t)p * row_len + i];
+    if (i < co * kv) atomicAdd(&dW[(size_t)(i / kv) * K + (i % kv)], s);
+    else if (dbias) atomicAdd(&dbias[i - co * kv], s);
 }
 
 float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
@@ -1328,7 +1332,7 @@ static int wgs_launch(const sehip_gemm_desc& a, int B, hipStream_t st) {
     if (!parts) return 0;                                // (inside a stream capture before the pool exists: the generic kernel)
     sehip_note_kernel("wgrads_stream_kernel<%d, %d, %d>", C, CO, J);
     wgrads_stream_kernel<C, CO, J><<<grid, 256, lds, st>>>(a, B, fpw, parts, row_len);
-    ws_reduce_kernel<<<(row_len + 255) / 256, 256, 0, st>>>(parts, grid, row_len, CO, 10 * C, a.K, a.dW, a.dbias);
+    ws_reduce_kernel<<<dim3((row_len + 255) / 256, WS_REDUCE_SLICES), 256, 0, st>>>(parts, grid, row_len, CO, 10 * C, a.K, a.dW, a.dbias);
     return 1;
 }
 
@@ -1709,13 +1713,14 @@ __global__ __launch_bounds__(256) void ws_reduce2_kernel(const float* __restrict
                                                          float* __restrict__ dbb) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= row_len) return;
+    const int per = (nparts + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);      // (as ws_reduce_kernel)
     float s = 0.f;
 #pragma unroll 8
-    for (int p = 0; p < nparts; ++p) s += parts[(size_t)p * row_len + i];
-    if (i < co * ka) dWa[i] += s;
-    else if (i < co * (ka + kb)) dWb[i - co * ka] += s;
-    else if (i < co * (ka + kb) + co) { if (dba) dba[i - co * (ka + kb)] += s; }
-    else if (dbb) dbb[i - co * (ka + kb) - co] += s;
+    for (int p = p0; p < p1; ++p) s += parts[(size_t)p * row_len + i];
+    if (i < co * ka) atomicAdd(&dWa[i], s);
+    else if (i < co * (ka + kb)) atomicAdd(&dWb[i - co * ka], s);
+    else if (i < co * (ka + kb) + co) { if (dba) atomicAdd(&dba[i - co * (ka + kb)], s); }
+    else if (dbb) atomicAdd(&dbb[i - co * (ka + kb) - co], s);
 }
 
 template <int C, int CO, int J>
@@ -1741,7 +1746,7 @@ static int wgt_launch(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B,
     if (!parts) return 0;
     sehip_note_kernel("wgradt_stream_kernel<%d, %d, %d>", C, CO, J);
     wgradt_stream_kernel<C, CO, J><<<grid, 256, lds, st>>>(a, b, B, fpw, parts, row_len);
-    ws_reduce2_kernel<<<(row_len + 255) / 256, 256, 0, st>>>(parts, grid, row_len, CO, 12 * C, 8 * C, a.dW, b.dW, a.dbias, b.dbias);
+    ws_reduce2_kernel<<<dim3((row_len + 255) / 256, WS_REDUCE_SLICES), 256, 0, st>>>(parts, grid, row_len, CO, 12 * C, 8 * C, a.dW, b.dW, a.dbias, b.dbias);
     return 1;
 }
 
@@ -1788,7 +1793,7 @@ int sehip_try_wgradt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, 
         if (!parts) return 0;
         sehip_note_kernel("wgradt2_stream_kernel");
         wgradt2_stream_kernel<<<grid, 256, (size_t)2 * 4 * 130 * 32 + 4 * 1024 + 64, st>>>(a, b, B, fpw, parts, row_len);
-        ws_reduce2_kernel<<<(row_len + 255) / 256, 256, 0, st>>>(parts, grid, row_len, 2, 12 * C, 8 * C, a.dW, b.dW, a.dbias, b.dbias);
+        ws_reduce2_kernel<<<dim3((row_len + 255) / 256, WS_REDUCE_SLICES), 256, 0, st>>>(parts, grid, row_len, 2, 12 * C, 8 * C, a.dW, b.dW, a.dbias, b.dbias);
         return 1;
     }
     return 0;
