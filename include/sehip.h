@@ -143,6 +143,8 @@ int sehip_comm_unique_id(void* id128);
 int sehip_comm_init(const void* id128, int world, int rank, void** comm_out);
 int sehip_allreduce_f32(void* comm, float* buf, long n, void* stream);
 int sehip_allreduce_i32_max(void* comm, int* buf, long n, void* stream);
+/* the live communicator's own view: ncclCommCount, ncclCommUserRank, ncclCommCuDevice */
+int sehip_comm_info(void* comm, int* nranks, int* rank, int* device);
 int sehip_comm_destroy(void* comm);
 
 /* ---- implicit-GEMM engine (bf16 MFMA, fp32 accumulate) used for

@@ -46,6 +46,7 @@ _PROTOS = {
     "sehip_comm_init": [P, I, I, P],
     "sehip_allreduce_f32": [P, P, L, P],
     "sehip_allreduce_i32_max": [P, P, L, P],
+    "sehip_comm_info": [P, P, P, P],
     "sehip_comm_destroy": [P],
     "sehip_wav_row_stats": [P, P, I, P, P],
     "sehip_wav_collate": [P, P, P, P, P, P, I, F, I, I, P, P],

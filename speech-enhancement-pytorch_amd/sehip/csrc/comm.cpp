@@ -18,6 +18,7 @@ typedef int (*comm_init_rank_fn)(rccl_comm*, int, rccl_unique_id, int);
 typedef int (*all_reduce_fn)(const void*, void*, size_t, int /*dtype*/, int /*op*/, rccl_comm, hipStream_t);
 typedef int (*comm_destroy_fn)(rccl_comm);
 typedef const char* (*get_error_fn)(int);
+typedef int (*comm_query_fn)(const rccl_comm, int*);
 struct Rccl {
     void* h = nullptr;
     get_unique_id_fn get_unique_id = nullptr;
@@ -25,6 +26,7 @@ struct Rccl {
     all_reduce_fn all_reduce = nullptr;
     comm_destroy_fn comm_destroy = nullptr;
     get_error_fn get_error = nullptr;
+    comm_query_fn comm_count = nullptr, comm_user_rank = nullptr, comm_device = nullptr;
 };
 Rccl g_rccl;
 
@@ -42,6 +44,9 @@ int load_rccl(const char* who) {
     r.all_reduce = (all_reduce_fn)dlsym(h, "ncclAllReduce");
     r.comm_destroy = (comm_destroy_fn)dlsym(h, "ncclCommDestroy");
     r.get_error = (get_error_fn)dlsym(h, "ncclGetErrorString");
+    r.comm_count = (comm_query_fn)dlsym(h, "ncclCommCount");
+    r.comm_user_rank = (comm_query_fn)dlsym(h, "ncclCommUserRank");
+    r.comm_device = (comm_query_fn)dlsym(h, "ncclCommCuDevice");
     if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.comm_destroy)
         return sehip_set_error(-3, "%s: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy", who);
     g_rccl = r;
@@ -90,6 +95,21 @@ extern "C" int sehip_allreduce_i32_max(void* comm, int* buf, long n, void* strea
     if (n == 0) return 0;
     const int r = g_rccl.all_reduce(buf, buf, (size_t)n, 2 /*ncclInt32*/, 2 /*ncclMax*/, (rccl_comm)comm, (hipStream_t)stream);
     SEHIP_REQUIRE(r == 0, "allreduce_i32_max: ncclAllReduce(n=%ld): %s", n, err_text(r));
+    return 0;
+}
+
+// what the LIVE communicator says about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): bench.py's N > 1 line carries it,
+// so that the line proves N ranks on N devices instead of repeating what the launcher was asked for
+extern "C" int sehip_comm_info(void* comm, int* nranks, int* rank, int* device) {
+    SEHIP_REQUIRE(comm && nranks && rank && device, "comm_info: null argument");
+    if (int e = load_rccl("comm_info")) return e;
+    SEHIP_REQUIRE(g_rccl.comm_count && g_rccl.comm_user_rank && g_rccl.comm_device, "comm_info: librccl lacks ncclCommCount / ncclCommUserRank / ncclCommCuDevice");
+    int r = g_rccl.comm_count((rccl_comm)comm, nranks);
+    SEHIP_REQUIRE(r == 0, "comm_info: ncclCommCount: %s", err_text(r));
+    r = g_rccl.comm_user_rank((rccl_comm)comm, rank);
+    SEHIP_REQUIRE(r == 0, "comm_info: ncclCommUserRank: %s", err_text(r));
+    r = g_rccl.comm_device((rccl_comm)comm, device);
+    SEHIP_REQUIRE(r == 0, "comm_info: ncclCommCuDevice: %s", err_text(r));
     return 0;
 }
 

@@ -33,6 +33,11 @@ typedef __attribute__((address_space(1))) const void c3_gvoid;
 #define C3_RECORDS 0x7fff0000u
 
 #define C3_NSLOT 4
+#ifdef C3_STAMPS      // tools/build_variant.py ... -DC3_STAMPS: per-wave cycle stamps (tools/c3_stamps.py reads them); never in the product build
+__device__ unsigned* c3_stamp_ptr;
+extern "C" int sehip_c3_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(c3_stamp_ptr), &p, sizeof(p)); }
+#define C3_T() ((unsigned)__builtin_amdgcn_s_memtime())
+#endif
 #ifndef C3_PATCH_AUX
 #define C3_PATCH_AUX 0        // cache policy of the patch DMAs (2 = nt: measured)
 #endif
@@ -51,7 +56,8 @@ struct C3Geo {
     static constexpr int MAXP = (NPIECE + NTH - 1) / NTH;              // DMA instructions per thread and chunk
     static constexpr int PBYTES = ((TB + 1) * S * 32 + 1023) / 1024 * 1024;
     static constexpr int RING = C3_NSLOT * 1024 * 2 * NWN * 2;         // four weight tiles of 32 TN NWN rows x 64 B (TN = 4)
-    static constexpr int LDS_MAIN = RING + 2 * PBYTES + 1024 + 2 * (TB + 1) * 4;
+    static constexpr int TABLES = (2 * (TB + 1) + TB + 8) * 4;         // source frame table [2][TB + 1], destination frame table [TB], 8 wave flags
+    static constexpr int LDS_MAIN = RING + 2 * PBYTES + 1024 + TABLES;
     static_assert(S >= FR && (FM == 1 || P1 + FR / 2 <= S), "frame stride");
     static_assert(J == 4 || J == 8 || J == 16 || J == 32, "rows per frame");
     static_assert(TM == 8 || TM == 6 || TM == 4, "MFMA row tiles per wave (even: the frame order of J = 4 / 8 pairs them)");
@@ -120,11 +126,34 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* pbuf = smem + RING;
     unsigned char* dump = pbuf + 2 * PBYTES;
-    int* ftab = reinterpret_cast<int*>(dump + 1024);                           // [2][TB + 1]
+    // The frame tables live above BOTH the main-loop image and the epilogue's staging image (which reuses the memory from 0): the
+    // epilogue reads the destination table, so nothing in it divides or touches the descriptor again.
+    constexpr int EPI_BYTES = NWV * (16 * TM * (16 * TN + 8) * 2) + 64;
+    constexpr int TBL = RING + 2 * PBYTES + 1024 > EPI_BYTES ? RING + 2 * PBYTES + 1024 : EPI_BYTES;
+    int* ftab = reinterpret_cast<int*>(smem + TBL);                            // [2][TB + 1] source frame -> element offset, -1 = padding
+    int* otab = ftab + 2 * (TB + 1);                                           // [TB] tile frame -> (utterance << 16) | frame, -1 = outside
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
+#ifdef C3_STAMPS
+    const unsigned st_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime(), st_t0 = C3_T();
+    unsigned st_issue = 0, st_dma = 0, st_bar = 0, st_tail = 0, st_n = 0, st_prev = 0, st_imax = 0, st_bmax = 0;
+#endif
+    // The whole descriptor in ONE batch of scalar loads: left to itself the compiler fetches the kernel arguments where they are first
+    // used, i.e. in four to five dependent groups, each a round trip to memory (~600 cycles: the kernarg segment is in no cache when a
+    // launch starts) before the first DMA can be issued, and again in the epilogue.
+#define C3_KEEP(x) asm volatile("" ::"s"(x))
+    C3_KEEP(d.Npad); C3_KEEP(d.TT); C3_KEEP(d.K); C3_KEEP(d.cv_fadd); C3_KEEP(d.w_tiled); C3_KEEP(B); C3_KEEP(order);
+    C3_KEEP(d.cv_toff[0][0]); C3_KEEP(d.cv_toff[0][1]); C3_KEEP(d.cv_toff[1][0]); C3_KEEP(d.cv_toff[1][1]);
+    C3_KEEP(d.src[0].ptr); C3_KEEP(d.src[0].T); C3_KEEP(d.src[0].tlo); C3_KEEP(d.src[0].thi); C3_KEEP(d.src[0].F); C3_KEEP(d.src[0].C);
+    C3_KEEP(d.src[1].ptr); C3_KEEP(d.src[1].T); C3_KEEP(d.src[1].tlo); C3_KEEP(d.src[1].thi); C3_KEEP(d.src[1].F); C3_KEEP(d.src[1].C);
+    C3_KEEP(d.ntab); C3_KEEP(d.W); C3_KEEP(d.stats); C3_KEEP(d.bias); C3_KEEP(d.res); C3_KEEP(d.stats_cr);
+    C3_KEEP(d.dst[0].ptr); C3_KEEP(d.dst[0].T); C3_KEEP(d.dst[0].F); C3_KEEP(d.dst[0].C); C3_KEEP(d.dst[0].toff); C3_KEEP(d.dst[0].fmul);
+    C3_KEEP(d.dst[0].fadd); C3_KEEP(d.dst[0].is_f32);
+    C3_KEEP(d.dst[1].ptr); C3_KEEP(d.dst[1].T); C3_KEEP(d.dst[1].F); C3_KEEP(d.dst[1].C); C3_KEEP(d.dst[1].toff); C3_KEEP(d.dst[1].fmul);
+    C3_KEEP(d.dst[1].fadd); C3_KEEP(d.dst[1].is_f32);
+#undef C3_KEEP
     const int ntn = d.Npad / BN;
     const int TV = d.TT + 2;
     const int nwg = gridDim.x;
@@ -152,19 +181,36 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(s0p), 0, C3_RECORDS, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(C1 ? s1p : s0p), 0, C3_RECORDS, 0x00020000);
 
-    // ---- frame table: element offset of patch frame p in source s, -1 = padding
+    // ---- this wave's 64 output columns: one destination? (ntab entries fetched now, used behind the barrier below: the epilogue
+    // does not wait for anything but its own stores)
+    constexpr int WCOLS_ = 16 * TN;
+    const int nw0 = n0 + wn * WCOLS_;
+    const sehip_nchunk nc_first = d.ntab[nw0 >> 2];
+    const sehip_nchunk nc_mine = d.ntab[(nw0 >> 2) + (lane & 15) % (WCOLS_ / 4)];
+    // ---- frame tables.  Every descriptor field is selected from SCALAR loads of both candidates: indexing the by-value descriptor
+    // with a per-lane (or even wave-uniform runtime) index becomes per-lane global loads from the kernarg segment -- three dependent
+    // round trips in front of the first DMA, more in the epilogue (round 5: 3 000 of the prologue's 9 000 cycles).
     if (tid < 2 * (TB + 1)) {
-        const int s = tid / (TB + 1), p = tid - s * (TB + 1);
-        const sehip_src& Sr = s ? d.src[1] : d.src[0];
+        const bool s = tid >= TB + 1;
+        const int p = s ? tid - (TB + 1) : tid;
+        const int sT = s ? d.src[1].T : d.src[0].T, sF = s ? d.src[1].F : d.src[0].F, sC = s ? d.src[1].C : d.src[0].C;
+        const int slo = s ? d.src[1].tlo : d.src[0].tlo, shi = s ? d.src[1].thi : d.src[0].thi;
         const int sv = g0 + p + (s ? tmin1 : tmin0);
         int v = -1;
-        if (sv >= 0 && (s == 0 || C1)) {
+        if (sv >= 0 && (!s || C1)) {
             const int b = sv / TV, x = sv - b * TV;
-            if (b < B && x >= Sr.tlo && x < Sr.thi) v = (b * Sr.T + x) * Sr.F * Sr.C;
+            if (b < B && x >= slo && x < shi) v = (b * sT + x) * sF * sC;
         }
         ftab[tid] = v;
+    } else if (tid < 2 * (TB + 1) + TB) {
+        const int gv = g0 + (tid - 2 * (TB + 1));
+        const int b = gv / TV, t = gv - b * TV;
+        otab[tid - 2 * (TB + 1)] = (b < B && t < d.TT) ? ((b << 16) | t) : -1;
     }
     __syncthreads();
+#ifdef C3_STAMPS
+    const unsigned st_p1 = C3_T();
+#endif
     // ---- patch pieces of this thread: piece P = (4 u + wave) * 64 + lane of a buffer = physical row P >> 1, half P & 1
     unsigned off0[MAXP], off1[MAXP];                                             // byte offsets; C3_OOB = padding
 #pragma unroll
@@ -183,14 +229,14 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
         off0[u] = (fa >= 0 && (unsigned)f < (unsigned)d.src[0].F) ? 2u * (unsigned)(fa + f * C0 + half * 8) : C3_OOB;
         off1[u] = (fb >= 0 && (unsigned)f < (unsigned)d.src[1].F) ? 2u * (unsigned)(fb + f * C1 + half * 8) : C3_OOB;
     }
-    auto issue_p = [&](int ch, int buf) {
+    auto issue_p = [&](int ch, int buf, bool past = false) {      // past: the periodic stream's pieces beyond the last chunk: zeros, no read
         const int second = ch * 16 >= C0 ? 1 : 0;
         const int soff = 2 * (second ? ch * 16 - C0 : ch * 16);                 // bytes, scalar
         unsigned char* dst = pbuf + buf * PBYTES + wave * 1024;
 #pragma unroll
         for (int u = 0; u < MAXP; ++u) {
             unsigned char* dd = ((u * NWV + wave) * 64 < NPIECE) ? dst + u * (NWV * 1024) : dump;     // wave-uniform
-            unsigned vo = second ? off1[u] : off0[u];
+            unsigned vo = past ? C3_OOB : second ? off1[u] : off0[u];
             if (ABL & 8) vo = (unsigned)(((blockIdx.x & 1023) * 16384 + ((u * NWV + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (c3_lds_void*)dd, 16, vo, soff, 0, C3_PATCH_AUX);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (c3_lds_void*)dd, 16, vo, soff, 0, C3_PATCH_AUX);
@@ -214,11 +260,11 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
         return 2u * (tiled ? (unsigned)(i * 8) : (unsigned)(n * d.K + pl * Ctot + (i & 1) * 8));
     };
     const unsigned woff0 = woff_of(0), woff1 = woff_of(DW - 1);
-    auto issue_w = [&](int ch, int j, int slot) {
-        const int soff = 2 * (tiled ? (ch * H + j) * (2 * (NWN == 4 ? 128 : BN) * 16) : 2 * j * Ctot + ch * 16);
+    auto issue_w = [&](int ch, int j, int slot, bool past = false) {
+        const int soff = past ? 0 : 2 * (tiled ? (ch * H + j) * (2 * (NWN == 4 ? 128 : BN) * 16) : 2 * j * Ctot + ch * 16);
         unsigned char* dst = smem + slot * WSLOT + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)dst, 16, woff0, soff, 0, 0);
-        if (DW > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + NWV * 1024), 16, woff1, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)dst, 16, past ? C3_OOB : woff0, soff, 0, 0);
+        if (DW > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (c3_lds_void*)(dst + NWV * 1024), 16, past ? C3_OOB : woff1, soff, 0, 0);
     };
 
     // ---- fragment addresses
@@ -245,14 +291,53 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
 
     // prologue: patch of chunk 0, weight tiles 0..2 (the periodic stream from here on: step s issues tile s + 3, a chunk's first
     // step also the next chunk's patch), then the first step's wait + barrier
+#ifdef C3_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned st_p2 = C3_T();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     issue_p(0, 0);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int cc = s / H, jj = s % H;
-        issue_w(cc < nch ? cc : 0, jj, s);
+        issue_w(cc < nch ? cc : 0, jj, s, cc >= nch);
     }
+#ifdef C3_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned st_p3 = C3_T();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // ---- this wave's destination, from the ntab entries requested at the top (by now they have landed: no round trip is waited for
+    // here, and none in the epilogue).  The waves' `dense` flags meet over the loop's first barrier.
+    int fdst, fcoff;
+    bool dense;
+    {
+        const int qc = (lane & 15) % (WCOLS_ / 4);
+        fdst = __builtin_amdgcn_readfirstlane(nc_first.dst);
+        fcoff = __builtin_amdgcn_readfirstlane(nc_first.coff);
+        const bool ok = nc_mine.nvalid == 4 && nc_mine.dst == fdst && nc_mine.coff == fcoff + 4 * qc;
+        const int f32 = fdst ? d.dst[1].is_f32 : d.dst[0].is_f32, ddC_ = fdst ? d.dst[1].C : d.dst[0].C;
+        dense = __all(ok) && !f32 && ((fcoff & 7) == 0) && ((ddC_ & 7) == 0);
+    }
+    // destination geometry of this wave's columns (scalar selects now: the epilogue touches no kernel argument)
+    const int ddF = fdst ? d.dst[1].F : d.dst[0].F, ddC = fdst ? d.dst[1].C : d.dst[0].C, ddT = fdst ? d.dst[1].T : d.dst[0].T;
+    const int ddtoff = fdst ? d.dst[1].toff : d.dst[0].toff, ddfmul = fdst ? d.dst[1].fmul : d.dst[0].fmul;
+    const int ddfadd = fdst ? d.dst[1].fadd : d.dst[0].fadd;
+    void* const ddptr = fdst ? d.dst[1].ptr : d.dst[0].ptr;
+    if (d.stats && lane == 0) otab[TB + wave] = dense ? 1 : 0;
     c3_wait_step<H, MAXP, DW>(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    bool with_stats = false;
+    if (d.stats) {
+        with_stats = true;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) with_stats = with_stats && otab[TB + i] != 0;
+    }
+#ifdef C3_STAMPS
+    const unsigned st_t1 = C3_T();
+    st_prev = st_t1;
+#endif
     int slot = 0;
     for (int ch = 0; ch < nch; ++ch) {
         const bool second = ch * 16 >= C0;
@@ -274,6 +359,11 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             // Order: 12 fragment reads, the DMA of tile s + 3 (and the next chunk's patch) behind them, 28 MFMAs with the
             // compiler's counted lgkmcnt waits, then wait for step s + 1's operands + barrier, then the last 4 MFMAs.
             __builtin_amdgcn_sched_barrier(0);
+#ifdef C3_STAMPS
+            const unsigned st_a = C3_T();
+            st_tail += st_a - st_prev;
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const unsigned char* wslot = smem + slot * WSLOT + wrd;
             const unsigned char* ap = smem + aoff[j];
             bf16x8 wf[TN], af[TM];
@@ -292,8 +382,8 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             if (!(ABL & 1)) {   // tile s + 3 -> the slot tile s - 1 has left; past the end: re-load something harmless (constant counts)
                 const int jj = (j + 3) % H, dc = (j + 3) / H;
                 const int cc = ch + dc < nch ? ch + dc : 0;
-                issue_w(cc, jj, (slot + 3) & 3);
-                if (j == 0) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1);
+                issue_w(cc, jj, (slot + 3) & 3, ch + dc >= nch);
+                if (j == 0) issue_p(ch + 1 < nch ? ch + 1 : 0, (ch + 1) & 1, ch + 1 >= nch);
             }
             if (ABL & 2) {
 #pragma unroll
@@ -314,10 +404,25 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
                 __builtin_amdgcn_sched_group_barrier(0x008, TN * (TM - 1), 0);                 // MFMAs
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef C3_STAMPS
+            const unsigned st_b = C3_T();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else c3_wait_step<H, MAXP, DW>((j + 1) % H);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef C3_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned st_c = C3_T();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+#ifdef C3_STAMPS
+            const unsigned st_d = C3_T();
+            st_issue += st_b - st_a; st_dma += st_c - st_b; st_bar += st_d - st_c; st_prev = st_d; ++st_n;
+            st_imax = st_b - st_a > st_imax ? st_b - st_a : st_imax; st_bmax = st_d - st_c > st_bmax ? st_d - st_c : st_bmax;
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (!(ABL & 2)) {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
@@ -327,47 +432,71 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
         }
     }
 
-    // ---- epilogue: every DMA has landed and every wave has finished reading before the LDS is reused
+    // ---- epilogue.  Everything it needs was fetched or tabulated in the prologue (destination choice `fdst / fcoff / dense`, the frame
+    // table `otab`): no division, no descriptor-indexed load and no table look-up in global memory sits between the last MFMA and the
+    // stores (round 5: the old epilogue spent 5 000 cycles waiting for such loads and 3 300-8 800 in a store loop that divided per row).
+#ifdef C3_STAMPS
+    const unsigned st_t2 = C3_T();
+    unsigned st_e1 = st_t2;
+    auto st_flush = [&]() {
+        const unsigned e2 = C3_T();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the output stores have left
+        const unsigned t3 = C3_T(), rt1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && c3_stamp_ptr) {
+            unsigned* o = c3_stamp_ptr + ((size_t)blockIdx.x * NWV + wave) * 16;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[0] = blockIdx.x; o[1] = hw; o[2] = xcc; o[3] = st_rt0; o[4] = rt1; o[5] = st_t1 - st_t0; o[6] = st_t2 - st_t1; o[7] = t3 - st_t2;
+            o[8] = st_issue; o[9] = st_dma; o[10] = st_bar; o[11] = st_tail; o[12] = st_n; o[13] = st_imax; o[14] = st_bmax; o[15] = 0x5eed;
+            unsigned* o2 = o + (size_t)8192 * 8 * 16;      // second record: prologue / epilogue split
+            o2[0] = st_p1 - st_t0; o2[1] = st_p2 - st_p1; o2[2] = st_p3 - st_p2; o2[3] = st_t1 - st_p3;
+            o2[4] = st_e1 - st_t2; o2[5] = e2 - st_e1; o2[6] = t3 - e2;
+        }
+    };
+#endif
+    constexpr int WROWS = 16 * TM, WCOLS = 16 * TN, TP = WCOLS + 8, PPR = WCOLS / 8, RPI = 64 / PPR;   // 16-byte pieces per row, rows per store trip
+    // the bias of this lane's columns, requested BEFORE the drain below so that its latency hides behind it
+    float4 bv[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+        bv[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // dense path: where the product adds a residual tensor (the skip connection's gradient), the first pieces of it are requested
+    // before the drain; the store loop below keeps RD of them in flight (destination offsets come from the frame table: no division)
+    constexpr int NIT = WROWS / RPI, RD = NIT < 8 ? NIT : 8;
+    const bf16_raw* rptr = (d.res && fdst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + fcoff : nullptr;
+    const int tsz = ddF * ddC, bsz = ddT * ddF * ddC, jsz = ddfmul * ddC;
+    const int base0 = (ddtoff * ddF + ddfadd) * ddC + (lane % PPR) * 8;
+    auto row_off = [&](int itr) {
+        int tl, jl;
+        c3_row<J, TM>(wm, itr * RPI + lane / PPR, tl, jl);
+        const int bt = otab[tl];                               // (utterance << 16) | frame, -1 = outside the tensor
+        return bt >= 0 ? (bt >> 16) * bsz + (bt & 0xffff) * tsz + jl * jsz + base0 : -1;
+    };
+    uint4 r4[RD];
+    if (dense && rptr) {
+#pragma unroll
+        for (int itr = 0; itr < RD; ++itr) {
+            const int o = row_off(itr);
+            r4[itr] = o >= 0 ? *reinterpret_cast<const uint4*>(rptr + o) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    // every DMA has landed (the run-ahead ones past the end are out-of-range pieces: zeros, no memory read) and every wave has
+    // finished reading before the LDS is reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int WROWS = 16 * TM, WCOLS = 16 * TN, TP = WCOLS + 8, PPR = WCOLS / 8, RPI = 64 / PPR;   // 16-byte pieces per row, rows per store trip
-    const int nw0 = n0 + wn * WCOLS;
-    sehip_nchunk first = d.ntab[nw0 >> 2];
-    bool dense;
-    {
-        const int qc = (lane & 15) % (WCOLS / 4);
-        const sehip_nchunk mine = d.ntab[(nw0 >> 2) + qc];
-        const bool ok = mine.nvalid == 4 && mine.dst == first.dst && mine.coff == first.coff + 4 * qc;
-        dense = __all(ok) && !(first.dst ? d.dst[1].is_f32 : d.dst[0].is_f32) && ((first.coff & 7) == 0) &&
-                (((first.dst ? d.dst[1].C : d.dst[0].C) & 7) == 0);
-    }
-    bool with_stats = false;
-    if (d.stats) {
-        int* flag = reinterpret_cast<int*>(smem + NWV * (WROWS * TP * 2));
-        if (lane == 0) flag[wave] = dense ? 1 : 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        with_stats = true;
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) with_stats = with_stats && flag[i] != 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
     if (dense) {
         bf16_raw* tb_ = reinterpret_cast<bf16_raw*>(smem) + wave * (WROWS * TP);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4));
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 const f32x4 v = acc[ni][mi];
                 *reinterpret_cast<uint2*>(&tb_[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * (lane >> 4)]) =
-                    make_uint2(pack_bf2(v[0] + bv.x, v[1] + bv.y), pack_bf2(v[2] + bv.z, v[3] + bv.w));
+                    make_uint2(pack_bf2(v[0] + bv[ni].x, v[1] + bv[ni].y), pack_bf2(v[2] + bv[ni].z, v[3] + bv[ni].w));
             }
         }
-        const sehip_dst& dd = first.dst ? d.dst[1] : d.dst[0];
         if (with_stats) {
             // batch statistics of the ComplexBatchNorm that follows (see conv_gemm_v2): wave (wm, 0) holds the real halves and wave
             // (wm, 1) the imaginary halves of the tile's 64 complex channels for the same 128 rows; wave (wm, wn) takes channels
@@ -377,9 +506,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             for (int hh = 0; hh < 2; ++hh) {
                 int tl, jl;
                 c3_row<J, TM>(wm, hh * 64 + lane, tl, jl);
-                const int gv = g0 + tl;
-                const int b = gv / TV, t = gv - b * TV;
-                rmask[hh] = __ballot(hh * 64 + lane < WROWS && b < B && t < d.TT);
+                rmask[hh] = __ballot(hh * 64 + lane < WROWS && otab[tl < TB ? tl : 0] >= 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -422,33 +549,36 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
                 }
             }
         }
-        bf16_raw* dptr = reinterpret_cast<bf16_raw*>(dd.ptr) + first.coff;
-        const bf16_raw* rptr = (d.res && first.dst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + first.coff : nullptr;
-        const int tsz = dd.F * dd.C, bsz = dd.T * dd.F * dd.C, jsz = dd.fmul * dd.C;
-        const int base0 = (dd.toff * dd.F + dd.fadd) * dd.C + (lane % PPR) * 8;
+#ifdef C3_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        st_e1 = C3_T();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        bf16_raw* dptr = reinterpret_cast<bf16_raw*>(ddptr) + fcoff;
 #pragma unroll
-        for (int itr = 0; itr < WROWS / RPI; ++itr) {
+        for (int itr = 0; itr < NIT; ++itr) {
             const int row = itr * RPI + lane / PPR;
-            int tl, jl;
-            c3_row<J, TM>(wm, row, tl, jl);
-            const int gv = g0 + tl;
-            const int b = gv / TV, t = gv - b * TV;
             uint4 v = *reinterpret_cast<const uint4*>(&tb_[row * TP + (lane % PPR) * 8]);
-            if (b < B && t < d.TT) {
-                const int off = b * bsz + t * tsz + jl * jsz + base0;
-                if (rptr) {
-                    const uint4 r4 = *reinterpret_cast<const uint4*>(rptr + off);
-                    const unsigned av[4] = {v.x, v.y, v.z, v.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
-                    unsigned o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        o[i] = pack_bf2(__uint_as_float(av[i] << 16) + __uint_as_float(rv[i] << 16),
-                                        __uint_as_float(av[i] & 0xffff0000u) + __uint_as_float(rv[i] & 0xffff0000u));
-                    v = make_uint4(o[0], o[1], o[2], o[3]);
+            const int off = row_off(itr);
+            if (rptr) {
+                const uint4 rr = r4[itr % RD];
+                if (itr + RD < NIT) {                              // the piece RD rows ahead takes the register this one leaves
+                    const int o2 = row_off(itr + RD);
+                    r4[itr % RD] = o2 >= 0 ? *reinterpret_cast<const uint4*>(rptr + o2) : make_uint4(0u, 0u, 0u, 0u);
                 }
-                *reinterpret_cast<uint4*>(dptr + off) = v;
+                const unsigned av[4] = {v.x, v.y, v.z, v.w}, rv[4] = {rr.x, rr.y, rr.z, rr.w};
+                unsigned o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o[i] = pack_bf2(__uint_as_float(av[i] << 16) + __uint_as_float(rv[i] << 16),
+                                    __uint_as_float(av[i] & 0xffff0000u) + __uint_as_float(rv[i] & 0xffff0000u));
+                v = make_uint4(o[0], o[1], o[2], o[3]);
             }
+            if (off >= 0) *reinterpret_cast<uint4*>(dptr + off) = v;
         }
+#ifdef C3_STAMPS
+        st_flush();
+#endif
         return;
     }
     // direct scatter, 4 consecutive channels per lane (fp32 destinations, narrow or split column groups)
@@ -456,25 +586,19 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     for (int mi = 0; mi < TM; ++mi) {
         int tl, jl;
         c3_row<J, TM>(wm, mi * 16 + (lane & 15), tl, jl);
-        const int gv = g0 + tl;
-        const int b = gv / TV, t = gv - b * TV;
-        if (b >= B || t >= d.TT) continue;
+        const int bt = otab[tl];
+        if (bt < 0) continue;
+        const int b = bt >> 16, t = bt & 0xffff;
         size_t ro[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const sehip_dst& q = d.dst[s];
-            ro[s] = q.ptr ? (((size_t)b * q.T + t + q.toff) * q.F + (size_t)jl * q.fmul + q.fadd) * q.C : 0;
-        }
+        ro[0] = d.dst[0].ptr ? (((size_t)b * d.dst[0].T + t + d.dst[0].toff) * d.dst[0].F + (size_t)jl * d.dst[0].fmul + d.dst[0].fadd) * d.dst[0].C : 0;
+        ro[1] = d.dst[1].ptr ? (((size_t)b * d.dst[1].T + t + d.dst[1].toff) * d.dst[1].F + (size_t)jl * d.dst[1].fmul + d.dst[1].fadd) * d.dst[1].C : 0;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int n = nw0 + ni * 16 + 4 * (lane >> 4);
             const sehip_nchunk nc = d.ntab[n >> 2];
             if (nc.nvalid <= 0) continue;
             f32x4 v = acc[ni][mi];
-            if (d.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(d.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
+            v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
             const size_t off = (nc.dst ? ro[1] : ro[0]) + nc.coff;
             void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
             const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
@@ -496,6 +620,9 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             }
         }
     }
+#ifdef C3_STAMPS
+    st_flush();
+#endif
 }
 
 static int c3_order() {
@@ -505,8 +632,8 @@ static int c3_order() {
 template <int NF, int FM, int J, int TM, int TN, int NWN = 2>
 static size_t c3_lds_bytes() {
     using G = C3Geo<NF, FM, J, TM, NWN>;
-    const size_t epi = 2 * NWN * (16 * TM * (16 * TN + 8) * 2) + 64;
-    return (size_t)G::LDS_MAIN > epi ? (size_t)G::LDS_MAIN : epi;
+    const size_t epi = 2 * NWN * (16 * TM * (16 * TN + 8) * 2) + 64, main_ = (size_t)G::LDS_MAIN - G::TABLES;
+    return (main_ > epi ? main_ : epi) + G::TABLES;      // the tables sit above both images (kernel: TBL)
 }
 // The dynamic-LDS limit of a kernel is a PER-DEVICE attribute: set once per (instantiation, device), the result checked (a
 // process-wide flag set it on whichever device was current first, and a failure surfaced as an unexplained launch error).

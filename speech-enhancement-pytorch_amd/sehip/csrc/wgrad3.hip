@@ -279,29 +279,38 @@ static void w3_reduce_launch(const float* parts, int nparts, size_t n, float* dW
 
 // Scratch for the splits' partial arrays: one per stream that launches weight gradients (launches on one stream are ordered; two
 // streams must not share).  Allocated on first use, never inside a stream capture (the caller then takes the atomic flush).
-struct W3Scratch { hipStream_t st; float* p; size_t bytes; };
+struct W3Scratch { hipStream_t st; float* p; size_t bytes; bool pinned; };
 static W3Scratch w3_pool[16];
+// A slot handed out while its stream is capturing is baked into a hipGraph: it is PINNED from then on -- never freed, never grown
+// (a recycle or a grow would leave the replays writing partial sums into freed memory).  A request a pinned slot cannot
+// serve gets nullptr, i.e. the caller's atomic flush, as any request inside a capture that finds no array does.
 static float* w3_scratch_for(hipStream_t st, size_t bytes) {
     static const bool off = getenv("SEHIP_W3_ATOMIC_FLUSH") != nullptr;
     if (off) return nullptr;
     W3Scratch* e = nullptr;
     for (auto& q : w3_pool)
         if (q.p && q.st == st) { e = &q; break; }
-    if (e && e->bytes >= bytes) return e->p;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (e && e->bytes >= bytes) {
+        if (capturing) e->pinned = true;
+        return e->p;
+    }
+    if (capturing || (e && e->pinned)) return nullptr;
     if (!e)
         for (auto& q : w3_pool)
             if (!q.p) { e = &q; break; }
     if (!e) {
-        // every slot belongs to some stream (workspaces come and go, each with a weight-gradient stream of its own): give all of
-        // them back once the device is idle and start over -- rare, outside any capture
+        // every slot belongs to some stream (workspaces come and go, each with a weight-gradient stream of its own): give the
+        // unpinned ones back once the device is idle and start over -- rare, outside any capture
         if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         for (auto& q : w3_pool) {
+            if (q.pinned) continue;
             if (q.p) (void)hipFree(q.p);
             q.p = nullptr; q.bytes = 0; q.st = nullptr;
+            if (!e) e = &q;
         }
-        e = &w3_pool[0];
+        if (!e) return nullptr;         // sixteen captured streams: atomic flush from here on
     }
     if (e->p) {                       // grow: the old array may still be in use on the stream
         if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
@@ -310,7 +319,7 @@ static float* w3_scratch_for(hipStream_t st, size_t bytes) {
     }
     float* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    e->st = st; e->p = p; e->bytes = bytes;
+    e->st = st; e->p = p; e->bytes = bytes; e->pinned = false;
     return p;
 }
 

@@ -127,6 +127,14 @@ class DirectComm:
         st = stream if stream is not None else torch.cuda.current_stream()
         call("sehip_allreduce_i32_max", self.handle, words.data_ptr(), words.numel(), st.cuda_stream)
 
+    def info(self):
+        """(nranks, rank, device) as the live RCCL communicator reports them (sehip_comm_info)."""
+        import ctypes as C
+        from ._lib import call
+        n, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        call("sehip_comm_info", self.handle, C.byref(n), C.byref(r), C.byref(d))
+        return n.value, r.value, d.value
+
     def close(self):
         from ._lib import call
         if self.handle:
@@ -189,6 +197,19 @@ def allreduce_step_guard(guard):
     else:
         dist.all_reduce(guard, op=dist.ReduceOp.MAX)
     return guard
+
+
+def global_flag(flag, device=None):
+    """OR of a host-side boolean over the ranks (MAX all-reduce of one int; a no-op without a process group).  For decisions every
+    rank must take together although the evidence is rank-local: model.check_health()'s fall-back after a hand-off time-out seen in
+    an eval forward on one rank only -- a rank that alone changed its launch path would pair a different collective
+    sequence with the others'.  Collective: every rank must call it at the same point."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    on_gpu = device is not None and torch.device(device).type == "cuda" and dist.get_backend() != "gloo"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t[0]))
 
 
 def allreduce_step_guard_async(guard, stream=None):

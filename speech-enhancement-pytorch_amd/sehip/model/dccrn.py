@@ -135,13 +135,21 @@ class DCCRN(FlatModule):
         """Device word the fused optimizer checks (sehip_opt_begin_g / sehip_opt_step_g): the sticky hand-off time-out word of the fused
         two-layer LSTM kernels of the workspace the last forward ran in (None when that workspace runs the unfused launches)."""
         ws = getattr(self, "_last_ws", None)
-        return ws.l2_sync[0:1] if ws is not None and ws.lstm_fused else None
+        # (returned while the word EXISTS, not while the fused launches are the current path: graphs captured before a fall-back keep
+        #  it as their guard, and under data parallelism every rank must issue the same MAX all-reduce whatever its own path -- ADVICE r4)
+        return ws.l2_sync[0:1] if ws is not None and hasattr(ws, "l2_sync") else None
 
     def check_health(self):
         """Called by the Solver wherever it synchronises anyway: True if steps were lost to a hand-off time-out (the workspace has
-        returned to one launch per LSTM layer)."""
+        returned to one launch per LSTM layer; captured hipGraphs are invalidated through storage_epoch).  Collective under data
+        parallelism: the decision is the OR over the ranks."""
+        from ..distrib import global_flag
         ws = getattr(self, "_last_ws", None)
-        return bool(ws is not None and ws.check_lstm_handoffs(recover=True))
+        if ws is None:
+            return global_flag(False, self._flat.device if self._flat is not None else None)
+        lost = bool(ws.check_lstm_handoffs(recover=True, global_flag=global_flag))
+        self._note_graph_epoch(ws)       # graphs captured on that workspace hold the fused launches: Solver.train_step_graphed re-captures
+        return lost
 
     def _run_forward(self, wav):
         ws = self.workspace(wav.shape[0], wav.shape[-1])

@@ -122,14 +122,20 @@ class Demucs(FlatModule):
     def check_health(self):
         """Called by the Solver wherever it synchronises anyway (loss read-back, checkpoints, end of evaluate()): True if steps were
         lost to a hand-off time-out (the model has switched to the per-step LSTM launches)."""
+        from ..distrib import global_flag
         ws = getattr(self, "_last_ws", None)
-        return bool(ws is not None and self.static.lstms and ws.check_lstm_handoffs(recover=True))
+        if ws is None or not self.static.lstms:
+            return global_flag(False, self._flat.device if self._flat is not None else None)
+        lost = bool(ws.check_lstm_handoffs(recover=True, global_flag=global_flag))      # collective: the OR over the ranks decides
+        self._note_graph_epoch(ws)
+        return lost
 
     def _run_forward(self, mix, need_backward):
         ws = self.workspace(mix.shape[0], mix.shape[-1])
         self._last_ws = ws
         ws.generation += 1
         ws.forward(mix.contiguous().float(), self._flat, need_backward=need_backward)
+        self._note_graph_epoch(ws)       # (the workspace looks at its time-out word every 64th forward)
         return ws
 
     def _run_backward(self, ws, grad_out):

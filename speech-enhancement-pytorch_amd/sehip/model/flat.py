@@ -143,6 +143,14 @@ class FlatModule(nn.Module):
             self._ws.move_to_end(key)
         return ws
 
+    def _note_graph_epoch(self, ws):
+        """A workspace bumps `graph_epoch` when launches captured from it have gone stale although the flat buffers are unchanged (its
+        persistent LSTM kernels fell back after a hand-off time-out): captured hipGraphs are keyed on storage_epoch, so move that."""
+        ge = getattr(ws, "graph_epoch", 0)
+        if ws is not None and ge != getattr(ws, "_graph_epoch_seen", 0):
+            ws._graph_epoch_seen = ge
+            self.storage_epoch += 1
+
     def _backward_into_flat(self, run):
         """`run(dst)` writes the flat parameter gradients of one backward pass into dst; accumulates like autograd when the
         previous gradients are still live (no zero_grad in between)."""

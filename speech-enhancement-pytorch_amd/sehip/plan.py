@@ -64,6 +64,7 @@ FUSE_ENC0_BN_WGRAD = FUSE_SKIP_GRAD and bool(os.environ.get("SEHIP_FUSE_ENC0_BN"
 # the apply pass of a layer with fused sums also finalizes them (sehip_cbn_finalize_apply_n)
 # (read when a workspace is built: DCCRNWorkspace.fuse_finalize / fuse_bwd_finalize / BWD_REPLICAS rows of backward sums)
 BWD_REPLICAS = int(os.environ.get("SEHIP_BWD_REPLICAS", "8"))
+L2_GRAPH_EPOCH = 65535       # granule-tag epoch of the fused LSTM launches inside captured graphs; eager calls use 1 .. 65534
 TILE_WEIGHTS = not any(os.environ.get(k) for k in ("SEHIP_NO_CONV_V3", "SEHIP_NO_PATCH", "SEHIP_NO_TILE_WEIGHTS"))
 
 
@@ -867,6 +868,7 @@ class DCCRNWorkspace:
         # hand-off time-out (check_lstm_handoffs) return to the two launches per direction of round 3.
         self.lstm_fused = len(self.lstm_chunks) == 1 and not os.environ.get("SEHIP_NO_LSTM_FUSE") and T < 65535
         self.l2_epoch = 0
+        self.graph_epoch = 0         # bumped when captured launches of this workspace go stale (fall-back after a hand-off time-out)
         if self.lstm_fused:
             lib_ = _lib.lib()
             self.l2_gran_f = torch.zeros(int(lib_.sehip_lstm2_gran_bytes(B, T, 0)) // 8, dtype=torch.int64, device=device)
@@ -1209,16 +1211,25 @@ class DCCRNWorkspace:
         """Epoch of the granule tags of one forward (+ its backward).  Eager: a new value per call, the granule arrays are never cleared.
         Under stream capture the value is frozen into the graph, so the graph clears the arrays itself (memset nodes)."""
         if torch.cuda.is_current_stream_capturing():
+            # Epoch 65535 belongs to captured graphs (ADVICE r4): eager calls cycle through 1..65534, so the tags a replay leaves in the
+            # arrays can never equal an eager call's, whatever the order of replays and eager forwards on this workspace.
             self.l2_gran_f.zero_(); self.l2_gran_b.zero_()
-            return self.l2_epoch if self.l2_epoch else 1
-        self.l2_epoch = self.l2_epoch % 65535 + 1
+            return L2_GRAPH_EPOCH
+        self.l2_epoch = self.l2_epoch % (L2_GRAPH_EPOCH - 1) + 1
         return self.l2_epoch
 
-    def check_lstm_handoffs(self, recover=True):
+    def check_lstm_handoffs(self, recover=True, global_flag=None):
         """Reads the sticky time-out word of the fused recurrence (the read waits for the stream).  A time-out means the launches since
         then produced garbage; the fused optimizer did not apply it (the word is its device-side guard, model.step_guard()).
         recover=True: this workspace returns to one launch per layer and direction, the word is cleared, True is returned."""
-        if not self.lstm_fused or int(self.l2_sync[0]) == 0:
+        # (the word is read while it exists, fused or not: hipGraphs captured before a fall-back keep replaying the fused launches
+        #  with this word as their optimizer guard -- ADVICE r4 -- until the Solver re-captures them, see graph_epoch)
+        if not hasattr(self, "l2_sync"):
+            return False
+        tripped = int(self.l2_sync[0]) != 0
+        if global_flag is not None:      # data parallel: every rank takes the same fall-back at the same health check
+            tripped = global_flag(tripped, self.device)
+        if not tripped:
             return False
         if not recover:
             raise SehipError("DCCRN: a hand-off wait of the fused two-layer LSTM kernels timed out (results since then are invalid and "
@@ -1228,6 +1239,7 @@ class DCCRNWorkspace:
                       "skipped on the device; falling back to one launch per LSTM layer for this workspace")
         self.lstm_fused = False
         self.l2_sync.zero_()
+        self.graph_epoch += 1        # graphs captured on this workspace still hold the fused launches: the owner re-captures
         return True
 
     def _lstm_forward(self, B, T, h):

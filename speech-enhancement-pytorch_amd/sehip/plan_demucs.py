@@ -706,13 +706,16 @@ class DemucsWorkspace:
              self.bufs[dy].ptr, stream())
         self._chain_dirty = True
 
-    def check_lstm_handoffs(self, recover=False):
+    def check_lstm_handoffs(self, recover=False, global_flag=None):
         """Reads the sticky time-out word of the persistent LSTM kernels (the read waits for the stream).  A time-out means the
         launches since then produced garbage; the fused optimizer never applied it (the word is its device-side guard,
         sehip_opt_step_g).  recover=False raises; recover=True switches THIS model to one launch per time step
         (dmx_lstm_step_*: no inter-workgroup hand-offs), clears the word and returns True -- the caller lost the steps since the
         time-out and carries on from unchanged parameters."""
-        if int(self.lstm_sync[60]) == 0:
+        tripped = int(self.lstm_sync[60]) != 0
+        if global_flag is not None:      # data parallel: every rank switches its launch path at the same call (ADVICE r4)
+            tripped = global_flag(tripped, self.lstm_sync.device)
+        if not tripped:
             return False
         if not recover:
             raise SehipError("Demucs: a hand-off spin of the persistent LSTM kernels timed out (results since then are invalid and no "
@@ -722,6 +725,7 @@ class DemucsWorkspace:
                       "skipped on the device; falling back to one launch per LSTM time step for this model")
         self.st.lstm_per_step = True
         self.lstm_sync[60:62].zero_()
+        self.graph_epoch = getattr(self, "graph_epoch", 0) + 1      # launches captured from this workspace are stale
         return True
 
     def _sync_arg(self):
@@ -734,7 +738,8 @@ class DemucsWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
         if st.lstms and self.generation % 64 == 2 and not torch.cuda.is_current_stream_capturing():
-            self.check_lstm_handoffs(recover=True)       # (every 64th call: the read waits for the previous step; the Solver also
+            from .distrib import global_flag             # (collective: every rank makes the same calls in the same order)
+            self.check_lstm_handoffs(recover=True, global_flag=global_flag)       # (every 64th call: the read waits for the previous step; the Solver also
                                                          #  asks at each of its own synchronisation points, model.check_health())
         self.stats.zero_()
         # weight packing (134 M parameters in both operand orientations: 2.5 ms of table-driven gathers).  Only the shallow levels'

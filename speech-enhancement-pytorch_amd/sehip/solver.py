@@ -126,11 +126,21 @@ class Solver(object):
         # True).  Here it selects the fixed-order reductions of libsehip and of the model's plan: two runs of the same steps are
         # bit-identical.  Built for DCCRN; a model without set_deterministic() keeps its own atomics and says so once.
         self.deterministic = bool(_cfg(config.solver, "cudnn_deterministic", False)) and device == "gpu"
-        if self.deterministic:
+        if self.deterministic and _cfg(config.solver, "use_graph", False):
+            # (the deterministic schedule sizes its per-split partial arrays on demand, which cannot happen inside a stream capture: say so
+            #  before a capture is left half-open -- ADVICE r4)
+            raise SehipError("solver.cudnn_deterministic and solver.use_graph cannot be combined: the deterministic schedule allocates its "
+                             "partial-sum arrays on demand (not capturable); switch one of them off")
+        if device == "gpu":
+            # process-wide library switch: set BOTH ways, so that a Solver without the flag does not inherit the fixed-order (~1.6 x slower)
+            # reductions of an earlier Solver of the same process
             from .utils import set_deterministic
-            set_deterministic(True)
+            set_deterministic(self.deterministic)
             if hasattr(model, "set_deterministic"):
-                model.set_deterministic(True)
+                model.set_deterministic(self.deterministic)
+        if self.deterministic:
+            if hasattr(model, "set_deterministic"):
+                pass
             else:
                 import warnings
                 warnings.warn(f"solver.cudnn_deterministic: model '{config.model.name}' has no deterministic plan yet (its normalisation "
