@@ -25,6 +25,7 @@
 
 typedef __attribute__((address_space(3))) void c3_lds_void;
 typedef __attribute__((address_space(1))) const void c3_gvoid;
+typedef __attribute__((address_space(3))) s16x4 c3_lds_s16x4;
 
 // Both operands are fetched with buffer_load_dwordx4 ... lds through raw buffer descriptors: the per-lane byte offset is a
 // register computed once per workgroup, what changes per K step / channel chunk is the scalar offset (no vector arithmetic in
@@ -113,8 +114,10 @@ __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constan
 // 2 = no MFMA, 4 = no fragment reads
 // TN = 16-column MFMA tiles per wave: 4 -> 128 output channels per workgroup, 2 -> 64 (the layers with 64 outputs)
 // NWN = waves along n: 2 -> 256 threads, two workgroups per CU; 4 -> 512 threads, 256 output channels, one workgroup per CU
+// The kernel body: workgroup `bid` of `nwg` of the product d (a function, so that one launch can run the tiles of TWO products -- the
+// output-row parities of a transposed convolution -- as conv_gemm_v3_pair_kernel does below).
 template <int NF, int FM, int J, int TM, int TN, int NWN = 2, int ABL = 0>
-__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B, int order) {
+__device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, const int order, const int bid, const int nwg) {
     using G = C3Geo<NF, FM, J, TM, NWN>;
     constexpr int NWV = 2 * NWN, NTH = 64 * NWV;     // waves, threads
     constexpr int WSLOT = 16 * TN * NWN * 64, RING = G::RING;
@@ -156,8 +159,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
 #undef C3_KEEP
     const int ntn = d.Npad / BN;
     const int TV = d.TT + 2;
-    const int nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int xcd = bid & 7, within = bid >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     // tile order.  0 (default): n-tile fastest.  1: the n-tiles of one m-tile 32 logical places apart -- under round-robin dispatch
@@ -172,7 +174,9 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     const int g0 = mt * TB, n0 = nt * BN;
     const int f0 = d.cv_fadd;
 
-    const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
+    // (the 5-tap products -- encoder forward, decoder input gradient -- have ONE source: the launcher checks; no second offset set)
+    constexpr bool TWO = NF != 5;
+    const int C0 = d.src[0].C, C1 = (TWO && d.src[1].ptr) ? d.src[1].C : 0;
     const int Ctot = C0 + C1;
     const int nch = Ctot >> 4;
     const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     const int nw0 = n0 + wn * WCOLS_;
     const sehip_nchunk nc_first = d.ntab[nw0 >> 2];
     const sehip_nchunk nc_mine = d.ntab[(nw0 >> 2) + (lane & 15) % (WCOLS_ / 4)];
+
     // ---- frame tables.  Every descriptor field is selected from SCALAR loads of both candidates: indexing the by-value descriptor
     // with a per-lane (or even wave-uniform runtime) index becomes per-lane global loads from the kernarg segment -- three dependent
     // round trips in front of the first DMA, more in the epilogue (round 5: 3 000 of the prologue's 9 000 cycles).
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     const unsigned st_p1 = C3_T();
 #endif
     // ---- patch pieces of this thread: piece P = (4 u + wave) * 64 + lane of a buffer = physical row P >> 1, half P & 1
-    unsigned off0[MAXP], off1[MAXP];                                             // byte offsets; C3_OOB = padding
+    unsigned off0[MAXP], off1[TWO ? MAXP : 1];                                   // byte offsets; C3_OOB = padding
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
         const int P = (u * NWV + wave) * 64 + lane;
@@ -227,17 +232,17 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
         const int f = f0 + r;
         const int fa = ok ? ftab[p] : -1, fb = (ok && C1) ? ftab[(TB + 1) + p] : -1;
         off0[u] = (fa >= 0 && (unsigned)f < (unsigned)d.src[0].F) ? 2u * (unsigned)(fa + f * C0 + half * 8) : C3_OOB;
-        off1[u] = (fb >= 0 && (unsigned)f < (unsigned)d.src[1].F) ? 2u * (unsigned)(fb + f * C1 + half * 8) : C3_OOB;
+        if (TWO) off1[u] = (fb >= 0 && (unsigned)f < (unsigned)d.src[1].F) ? 2u * (unsigned)(fb + f * C1 + half * 8) : C3_OOB;
     }
     auto issue_p = [&](int ch, int buf, bool past = false) {      // past: the periodic stream's pieces beyond the last chunk: zeros, no read
-        const int second = ch * 16 >= C0 ? 1 : 0;
+        const int second = (TWO && ch * 16 >= C0) ? 1 : 0;
         const int soff = 2 * (second ? ch * 16 - C0 : ch * 16);                 // bytes, scalar
         unsigned char* dst = pbuf + buf * PBYTES + wave * 1024;
 #pragma unroll
         for (int u = 0; u < MAXP; ++u) {
             unsigned char* dd = ((u * NWV + wave) * 64 < NPIECE) ? dst + u * (NWV * 1024) : dump;     // wave-uniform
-            unsigned vo = past ? C3_OOB : second ? off1[u] : off0[u];
-            if (ABL & 8) vo = (unsigned)(((blockIdx.x & 1023) * 16384 + ((u * NWV + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
+            unsigned vo = past ? C3_OOB : (TWO && second) ? off1[TWO ? u : 0] : off0[u];
+            if (ABL & 8) vo = (unsigned)(((bid & 1023) * 16384 + ((u * NWV + wave) * 64 + lane) * 8 + (ch & 15) * 1024) * 2);   // contiguous (wrong) source
             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (c3_lds_void*)dd, 16, vo, soff, 0, C3_PATCH_AUX);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (c3_lds_void*)dd, 16, vo, soff, 0, C3_PATCH_AUX);
         }
@@ -283,14 +288,13 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     };
     auto tap_off = [](int tap) constexpr { return (FM == 2 ? ((tap & 1) * P1 + (tap >> 1)) : tap) * 32; };
 
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     // prologue: patch of chunk 0, weight tiles 0..2 (the periodic stream from here on: step s issues tile s + 3, a chunk's first
     // step also the next chunk's patch), then the first step's wait + barrier
+    // the bias of this lane's columns, requested in front of the first DMAs: the accumulators START from it (no bias in the epilogue)
+    float4 bv[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+        bv[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef C3_STAMPS
     __builtin_amdgcn_sched_barrier(0);
     const unsigned st_p2 = C3_T();
@@ -325,6 +329,15 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     const int ddfadd = fdst ? d.dst[1].fadd : d.dst[0].fadd;
     void* const ddptr = fdst ? d.dst[1].ptr : d.dst[0].ptr;
     if (d.stats && lane == 0) otab[TB + wave] = dense ? 1 : 0;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+#ifdef C3_TEST_ZEROINIT
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){bv[a].x, bv[a].y, bv[a].z, bv[a].w};
+#endif
     c3_wait_step<H, MAXP, DW>(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
 #endif
     int slot = 0;
     for (int ch = 0; ch < nch; ++ch) {
-        const bool second = ch * 16 >= C0;
+        const bool second = TWO && ch * 16 >= C0;
         const int dtA = second ? d.cv_toff[1][0] - tmin1 : d.cv_toff[0][0] - tmin0;
         const int dtB = second ? d.cv_toff[1][1] - tmin1 : d.cv_toff[0][1] - tmin0;
         const int bufoff = RING + (ch & 1) * PBYTES;
@@ -456,14 +469,9 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     };
 #endif
     constexpr int WROWS = 16 * TM, WCOLS = 16 * TN, TP = WCOLS + 8, PPR = WCOLS / 8, RPI = 64 / PPR;   // 16-byte pieces per row, rows per store trip
-    // the bias of this lane's columns, requested BEFORE the drain below so that its latency hides behind it
-    float4 bv[TN];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-        bv[ni] = d.bias ? *reinterpret_cast<const float4*>(d.bias + nw0 + ni * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
     // dense path: where the product adds a residual tensor (the skip connection's gradient), the first pieces of it are requested
     // before the drain; the store loop below keeps RD of them in flight (destination offsets come from the frame table: no division)
-    constexpr int NIT = WROWS / RPI, RD = NIT < 8 ? NIT : 8;
+    constexpr int NIT = WROWS / RPI, RD = NIT < 4 ? NIT : 4;
     const bf16_raw* rptr = (d.res && fdst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + fcoff : nullptr;
     const int tsz = ddF * ddC, bsz = ddT * ddF * ddC, jsz = ddfmul * ddC;
     const int base0 = (ddtoff * ddF + ddfadd) * ddC + (lane % PPR) * 8;
@@ -489,66 +497,67 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
     if (dense) {
         bf16_raw* tb_ = reinterpret_cast<bf16_raw*>(smem) + wave * (WROWS * TP);
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
+        for (int mi = 0; mi < TM; ++mi) {
+            bool live = true;                                      // (fused sums only: rows outside the tensor are staged as zeros)
+            if (with_stats) {
+                int tl, jl;
+                c3_row<J, TM>(wm, mi * 16 + (lane & 15), tl, jl);
+                live = otab[tl] >= 0;
+            }
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
+            for (int ni = 0; ni < TN; ++ni) {
                 const f32x4 v = acc[ni][mi];
                 *reinterpret_cast<uint2*>(&tb_[(mi * 16 + (lane & 15)) * TP + ni * 16 + 4 * (lane >> 4)]) =
-                    make_uint2(pack_bf2(v[0] + bv[ni].x, v[1] + bv[ni].y), pack_bf2(v[2] + bv[ni].z, v[3] + bv[ni].w));
+                    live ? make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])) : make_uint2(0u, 0u);
             }
         }
+#ifndef C3_TEST_NOSTATS
         if (with_stats) {
-            // batch statistics of the ComplexBatchNorm that follows (see conv_gemm_v2): wave (wm, 0) holds the real halves and wave
-            // (wm, 1) the imaginary halves of the tile's 64 complex channels for the same 128 rows; wave (wm, wn) takes channels
-            // 32 wn .. 32 wn + 31: lane = channel pair (lane & 15) x row group (lane >> 4, 32 rows each)
-            unsigned long long rmask[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                int tl, jl;
-                c3_row<J, TM>(wm, hh * 64 + lane, tl, jl);
-                rmask[hh] = __ballot(hh * 64 + lane < WROWS && otab[tl < TB ? tl : 0] >= 0);
-            }
+            // Batch statistics of the ComplexBatchNorm that follows, from the values as stored, ON THE MATRIX CORES (round 5; the VALU
+            // form was ~700 instructions per wave with all eight waves of the CU in it at once: 6 000 of the epilogue's cycles).
+            // Wave (wm, 0) holds the real halves and wave (wm, 1) the imaginary halves of the tile's complex channels for the same
+            // rows; wave (wm, wn) takes the channels WCOLS / 2 * wn .. of both images.  With Yr, Yi = [rows][16 channels] slabs read
+            // as transposed fragments (ds_read_b64_tr_b16: a lane gets 8 consecutive ROWS of one channel -- the A and the B operand
+            // layout alike), the sums over rows are the diagonals of Yr^T Yr, Yr^T Yi, Yi^T Yi and any row of 1^T Yr, 1^T Yi: five
+            // MFMAs per 32 rows and 16 channels.  Rows outside the tensor were staged as zeros (`live` above).
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const bf16_raw* imr = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * (wn & ~1)) * (WROWS * TP);
             const bf16_raw* imi = reinterpret_cast<const bf16_raw*>(smem) + (wm + 2 * (wn | 1)) * (WROWS * TP);
-            // TN = 4: the tile is [64 re | 64 im], a lane takes two channels; TN = 2 (64-output layers): [32 re | 32 im], one channel
-            constexpr int CPL = TN / 2;
-            const int cp = (16 * CPL) * (wn & 1) + CPL * (lane & 15), rg = lane >> 4;
-            float sr[2] = {0.f, 0.f}, si[2] = {0.f, 0.f}, srr[2] = {0.f, 0.f}, sri[2] = {0.f, 0.f}, sii[2] = {0.f, 0.f};
-            constexpr int RG = WROWS / 4;                          // rows per row group
-#pragma unroll 4
-            for (int it = 0; it < RG; ++it) {
-                const int r = RG * rg + it;
-                const unsigned ur = CPL == 2 ? *reinterpret_cast<const unsigned*>(&imr[r * TP + cp]) : (unsigned)imr[r * TP + cp];
-                const unsigned ui = CPL == 2 ? *reinterpret_cast<const unsigned*>(&imi[r * TP + cp]) : (unsigned)imi[r * TP + cp];
-                const float ok = ((r < 64 ? rmask[0] >> r : rmask[1] >> (r - 64)) & 1ull) ? 1.f : 0.f;
-                const float yr[2] = {__uint_as_float(ur << 16) * ok, __uint_as_float(ur & 0xffff0000u) * ok};
-                const float yi[2] = {__uint_as_float(ui << 16) * ok, __uint_as_float(ui & 0xffff0000u) * ok};
+            constexpr int NCG = WCOLS / 32;                        // 16-channel groups per wave: 2 (128-column tiles) or 1
+            const int i16 = lane & 15, gq = lane >> 4;
+            const int trow = 8 * gq + (i16 >> 2), tcol = (WCOLS / 2) * (wn & 1) + 4 * (i16 & 3);
+            const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+            const bool diag = gq == (i16 >> 2);                    // this lane holds D[c][c] of its column c = i16, in component i16 & 3
 #pragma unroll
-                for (int e = 0; e < CPL; ++e) {
-                    sr[e] += yr[e]; si[e] += yi[e];
-                    srr[e] += yr[e] * yr[e]; sri[e] += yr[e] * yi[e]; sii[e] += yi[e] * yi[e];
+            for (int cg = 0; cg < NCG; ++cg) {
+                f32x4 a_r = {0.f, 0.f, 0.f, 0.f}, a_i = a_r, a_rr = a_r, a_ri = a_r, a_ii = a_r;
+#pragma unroll
+                for (int ks = 0; ks < WROWS / 32; ++ks) {
+                    const int o = (ks * 32 + trow) * TP + tcol + cg * 16;
+                    const s16x4 rl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_s16x4*)&imr[o]);
+                    const s16x4 rh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_s16x4*)&imr[o + 4 * TP]);
+                    const s16x4 il = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_s16x4*)&imi[o]);
+                    const s16x4 ih = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_s16x4*)&imi[o + 4 * TP]);
+                    const bf16x8 yr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(rl, rh, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const bf16x8 yi = __builtin_bit_cast(bf16x8, __builtin_shufflevector(il, ih, 0, 1, 2, 3, 4, 5, 6, 7));
+                    a_r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yr, a_r, 0, 0, 0);
+                    a_i = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yi, a_i, 0, 0, 0);
+                    a_rr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yr, yr, a_rr, 0, 0, 0);
+                    a_ri = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yr, yi, a_ri, 0, 0, 0);
+                    a_ii = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yi, yi, a_ii, 0, 0, 0);
                 }
-            }
-#pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    sr[e] += __shfl_xor(sr[e], o, 64); si[e] += __shfl_xor(si[e], o, 64);
-                    srr[e] += __shfl_xor(srr[e], o, 64); sri[e] += __shfl_xor(sri[e], o, 64); sii[e] += __shfl_xor(sii[e], o, 64);
-                }
-            }
-            if (lane < 16) {
-                const int Cr = d.stats_cr;
-                float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + 64 * (wn >> 1) + cp;
-#pragma unroll
-                for (int e = 0; e < CPL; ++e) {
-                    atomicAdd(sp + e, sr[e]); atomicAdd(sp + Cr + e, si[e]);
-                    atomicAdd(sp + 2 * Cr + e, srr[e]); atomicAdd(sp + 3 * Cr + e, sri[e]); atomicAdd(sp + 4 * Cr + e, sii[e]);
+                if (diag) {
+                    const int e = i16 & 3;
+                    auto pick = [&](const f32x4& v) { return e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3]; };
+                    const int Cr = d.stats_cr;
+                    float* sp = d.stats + (size_t)(blockIdx.x & 7) * 5 * Cr + (n0 >> 1) + 64 * (wn >> 1) + (WCOLS / 2) * (wn & 1) + cg * 16 + i16;
+                    atomicAdd(sp, a_r[0]); atomicAdd(sp + Cr, a_i[0]);
+                    atomicAdd(sp + 2 * Cr, pick(a_rr)); atomicAdd(sp + 3 * Cr, pick(a_ri)); atomicAdd(sp + 4 * Cr, pick(a_ii));
                 }
             }
         }
+#endif
 #ifdef C3_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         st_e1 = C3_T();
@@ -598,7 +607,6 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
             const sehip_nchunk nc = d.ntab[n >> 2];
             if (nc.nvalid <= 0) continue;
             f32x4 v = acc[ni][mi];
-            v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
             const size_t off = (nc.dst ? ro[1] : ro[0]) + nc.coff;
             void* dptr = nc.dst ? d.dst[1].ptr : d.dst[0].ptr;
             const int is_f32 = nc.dst ? d.dst[1].is_f32 : d.dst[0].is_f32;
@@ -623,6 +631,19 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kern
 #ifdef C3_STAMPS
     st_flush();
 #endif
+}
+
+template <int NF, int FM, int J, int TM, int TN, int NWN = 2, int ABL = 0>
+__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B, int order) {
+    c3_body<NF, FM, J, TM, TN, NWN, ABL>(d, B, order, (int)blockIdx.x, (int)gridDim.x);
+}
+// Both output-row parities of a transposed convolution (3 and 2 row taps over the same sources: sehip_gemm_pair) in ONE launch: the
+// first `na` workgroups run product a's tiles, the rest product b's.  Two launches of ~1.3 rounds of tiles each leave their last
+// rounds half empty and pay two launch ramps; together the tiles of the second product fill the first one's tail.
+template <int J, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_v3_pair_kernel(const sehip_gemm_desc da, const sehip_gemm_desc db, int B, int order, int na) {
+    if ((int)blockIdx.x < na) c3_body<3, 1, J, TM, TN, 2, 0>(da, B, order, (int)blockIdx.x, na);
+    else c3_body<2, 1, J, TM, TN, 2, 0>(db, B, order, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 
 static int c3_order() {
@@ -711,33 +732,91 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
 #undef C3_CASE
 }
 
-// returns 1 if the kernel was launched, 0 if the descriptor does not qualify (the caller falls back to conv_gemm_v2 / v1)
-int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
+// does the product qualify for the kernel?  (B = utterances)
+static bool c3_qualifies(const sehip_gemm_desc& d, int* Bout) {
     static const bool disabled = getenv("SEHIP_NO_CONV_V3") != nullptr || getenv("SEHIP_NO_PATCH") != nullptr;
-    if (disabled || d.cv_nf <= 0 || d.tmul > 1) return 0;
-    if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return 0;
+    if (disabled || d.cv_nf <= 0 || d.tmul > 1) return false;
+    if (d.stats && (d.dst[1].ptr || d.dst[0].is_f32 || (d.dst[0].C & 7) || d.stats_cr * 2 != d.Npad)) return false;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
-    if ((C0 & 15) || (C1 & 15) || (d.Npad & 63)) return 0;
-    if (d.J != 4 && d.J != 8 && d.J != 16 && d.J != 32) return 0;
-    if (d.K != 2 * d.cv_nf * (C0 + C1)) return 0;
-    if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return 0;
-    if (d.M % (d.TT * d.J)) return 0;
+    if ((C0 & 15) || (C1 & 15) || (d.Npad & 63)) return false;
+    if (d.J != 4 && d.J != 8 && d.J != 16 && d.J != 32) return false;
+    if (d.K != 2 * d.cv_nf * (C0 + C1)) return false;
+    if (d.cv_nf == 5 && C1) return false;                                    // (the 5-tap instantiations carry one source's offsets)
+    if ((d.dst[0].tmul > 1) || (d.dst[1].ptr && d.dst[1].tmul > 1)) return false;
+    if (d.TT >= 65535 || d.M % (d.TT * d.J)) return false;                  // (the destination frame table packs (utterance << 16) | frame)
     const int B = d.M / (d.TT * d.J);
+    if (B >= 32768) return false;
     for (int s = 0; s < 2; ++s) {
         if (!d.src[s].ptr) continue;
         for (int kt = 0; kt < 2; ++kt)
-            if (d.cv_toff[s][kt] < -1 || d.cv_toff[s][kt] > 1) return 0;
-        if (abs(d.cv_toff[s][0] - d.cv_toff[s][1]) > 1) return 0;
-        if (d.src[s].thi > d.TT + 1) return 0;
-        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 30) - (1L << 20)) return 0;      // byte offsets below C3_RECORDS
+            if (d.cv_toff[s][kt] < -1 || d.cv_toff[s][kt] > 1) return false;
+        if (abs(d.cv_toff[s][0] - d.cv_toff[s][1]) > 1) return false;
+        if (d.src[s].thi > d.TT + 1) return false;
+        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 30) - (1L << 20)) return false;      // byte offsets below C3_RECORDS
     }
     for (int s = 0; s < 2; ++s)
-        if (d.dst[s].ptr && (long)B * d.dst[s].T * d.dst[s].F * d.dst[s].C >= (1L << 31)) return 0;
-    if ((long)d.Npad * d.K >= (1L << 30) - (1L << 20)) return 0;
+        if (d.dst[s].ptr && (long)B * d.dst[s].T * d.dst[s].F * d.dst[s].C >= (1L << 31)) return false;
+    if ((long)d.Npad * d.K >= (1L << 30) - (1L << 20)) return false;
+    if (!((d.cv_nf == 5 && d.fmul == 2) || (d.cv_nf == 3 && d.fmul == 1) || (d.cv_nf == 2 && d.fmul == 1))) return false;
+    *Bout = B;
+    return true;
+}
+
+// returns 1 if the kernel was launched, 0 if the descriptor does not qualify (the caller falls back to conv_gemm_v2 / v1)
+int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st) {
+    int B = 0;
+    if (!c3_qualifies(d, &B)) return 0;
     if (d.cv_nf == 5 && d.fmul == 2) return c3_launch_j<5, 2>(d, B, st);
     if (d.cv_nf == 3 && d.fmul == 1) return c3_launch_j<3, 1>(d, B, st);
     if (d.cv_nf == 2 && d.fmul == 1) return c3_launch_j<2, 1>(d, B, st);
     return 0;
+}
+
+// ---- the two output-row parities of a transposed convolution (or of a stride-2 convolution's input gradient) in one launch
+template <int J, int TM, int TN>
+static int c3_launch_pair(const sehip_gemm_desc& a, const sehip_gemm_desc& b, int B, int na, int nb, hipStream_t st) {
+    static unsigned char state[64] = {};      // per device: 0 = not tried, 1 = set, 2 = failed (as c3_set_attr)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_pair_kernel<J, TM, TN>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    const size_t la = c3_lds_bytes<3, 1, J, TM, TN>(), lb = c3_lds_bytes<2, 1, J, TM, TN>();
+    sehip_note_kernel("conv_gemm_v3_pair_kernel<%d, %d, %d>", J, TM, TN);
+    conv_gemm_v3_pair_kernel<J, TM, TN><<<na + nb, 256, la > lb ? la : lb, st>>>(a, b, B, c3_order(), na);
+    return 1;
+}
+// a: the 3-tap product, b: the 2-tap product over the same sources (any order is accepted).  1 = launched.
+int sehip_try_conv_gemm_v3_pair(const sehip_gemm_desc& a_, const sehip_gemm_desc& b_, hipStream_t st) {
+    static const bool off = getenv("SEHIP_NO_C3_PAIR") != nullptr;
+    if (off) return 0;
+    const sehip_gemm_desc& a = a_.cv_nf == 3 ? a_ : b_;
+    const sehip_gemm_desc& b = a_.cv_nf == 3 ? b_ : a_;
+    int Ba = 0, Bb = 0;
+    if (!c3_qualifies(a, &Ba) || !c3_qualifies(b, &Bb)) return 0;
+    if (a.cv_nf != 3 || b.cv_nf != 2 || a.fmul != 1 || b.fmul != 1) return 0;
+    if (Ba != Bb || a.J != b.J || a.TT != b.TT || a.Npad != b.Npad) return 0;
+    const long vframes = (long)Ba * (a.TT + 2);
+    const int BN = (a.Npad & 127) ? 64 : 128, ntn = a.Npad / BN;
+    // rows per tile: the candidate (256 or 192) with the smaller (rounds of 512 tiles) x (tile height) for BOTH products together
+    static const int force = getenv("SEHIP_C3_PAIR_TM") ? atoi(getenv("SEHIP_C3_PAIR_TM")) : 0;
+    auto tiles = [&](int tm) { const int TB = 32 * tm / a.J; return (int)((vframes + TB - 1) / TB) * ntn; };
+    int tm = ((2 * tiles(8) + 511) / 512) * 8 <= ((2 * tiles(6) + 511) / 512) * 6 ? 8 : 6;
+    if (force == 8 || force == 6) tm = force;
+    const int n1 = tiles(tm);
+#define C3P_CASE(J_)                                                                                                        \
+    case J_:                                                                                                                \
+        if (BN == 128) return tm == 8 ? c3_launch_pair<J_, 8, 4>(a, b, Ba, n1, n1, st) : c3_launch_pair<J_, 6, 4>(a, b, Ba, n1, n1, st); \
+        return tm == 8 ? c3_launch_pair<J_, 8, 2>(a, b, Ba, n1, n1, st) : c3_launch_pair<J_, 6, 2>(a, b, Ba, n1, n1, st);
+    switch (a.J) {
+        C3P_CASE(4) C3P_CASE(8) C3P_CASE(16) C3P_CASE(32)
+        default: return 0;
+    }
+#undef C3P_CASE
 }
 
 template <int NF, int FM, int J, int TM, int TN>

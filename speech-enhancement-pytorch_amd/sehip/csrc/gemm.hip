@@ -638,6 +638,7 @@ static int launch_conv(const sehip_gemm_desc& d, int TB, int JB, int FR, int gri
 int sehip_try_conv_gemm_v2(const sehip_gemm_desc& d, hipStream_t st);   // conv2.hip
 void sehip_conv2_init(void);
 int sehip_try_conv_gemm_v3(const sehip_gemm_desc& d, hipStream_t st);   // conv3.hip
+int sehip_try_conv_gemm_v3_pair(const sehip_gemm_desc& a, const sehip_gemm_desc& b, hipStream_t st);
 void sehip_conv3_init(void);
 int sehip_try_conv_wgrad_v3(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
 int sehip_try_convs_stream(const sehip_gemm_desc& a, hipStream_t st, bool dry);   // convt.hip
@@ -1636,6 +1637,10 @@ extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* 
     }
     if (try_conv_small(*a, b, (hipStream_t)stream)) {
         SEHIP_CHECK_LAUNCH("gemm_pair(conv-small)");
+        return 0;
+    }
+    if (sehip_try_conv_gemm_v3_pair(*a, *b, (hipStream_t)stream)) {       // both parities' tiles in one conv_gemm_v3 launch
+        SEHIP_CHECK_LAUNCH("gemm_pair(conv-v3-pair)");
         return 0;
     }
     // same-shape dense products that the generic 64-row kernels take: one launch

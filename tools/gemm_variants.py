@@ -18,14 +18,22 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     res = {}
     for name in names:
         fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
-        d = ws.desc[name]
-        for _ in range(3): call(fn, C.byref(d), stream())
+        if "+" in name:          # "dec0.fwd0+dec0.fwd1": the pair through sehip_gemm_pair (one launch where the library merges them)
+            na, nb = name.split("+")
+            da, db = ws.desc[na], ws.desc[nb]
+            run = lambda: call("sehip_gemm_pair", C.byref(da), C.byref(db), stream())
+            d = da
+        else:
+            d = ws.desc[name]
+            run = lambda: call(fn, C.byref(d), stream())
+        for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20): call(fn, C.byref(d), stream())
+        for _ in range(20): run()
         e1.record(); torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 20
+        if "+" in name: continue
         if os.environ.get("SEHIP_VARIANT_SUMS") and fn == "sehip_gemm":      # digest of what ONE call writes (outputs + fused sums)
             B = 32
             for q in (0, 1):
