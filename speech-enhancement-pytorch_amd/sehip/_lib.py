@@ -80,6 +80,9 @@ _PROTOS = {
     "sehip_wgrad_group_bytes": [I],
     "sehip_wgrad_group_prepare": [P, I, P, P],
     "sehip_wgrad_group": [P, I, I, P],
+    "sehip_wgrad_dense_group_bytes": [I],
+    "sehip_wgrad_dense_group_prepare": [P, I, P, L, P],
+    "sehip_wgrad_dense_group": [P, I, P, P, P],
     "sehip_gemm_desc_size": [],
     "sehip_conv_small_takes": [P, P],
     "sehip_pack_bf16": [P, P, L, P, P],
@@ -144,7 +147,7 @@ _PROTOS = {
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_lstm2_gran_bytes": C.c_long, "sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
+_RESTYPE = {"sehip_lstm2_gran_bytes": C.c_long, "sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_wgrad_dense_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
 
 
 def lib():

@@ -1004,7 +1004,7 @@ class DCCRNWorkspace:
                 d = self.desc[name]
                 d.bnr_y, d.bnr_coef, d.bnr_part = self.bufs["yd" + pre.split(".")[1]].ptr, ptr(self.bn_coef[pre]), ptr(self.bn_acc)
                 # (bnr_slope: set per call, from params)
-        if not os.environ.get("SEHIP_NO_WGRAD_GROUP") and not st.deterministic:
+        if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
             for layers in ((1,), (2,), (2, 1)):
                 self._wgrad_group_handle(self._lstm_wgrad_names(layers))
 
@@ -1112,25 +1112,49 @@ class DCCRNWorkspace:
             buf = torch.empty(int(_lib.lib().sehip_wgrad_group_bytes(n)), dtype=torch.uint8, device=self.bufs["enc_in"].t.device)
             total = C.c_int(0)
             call("sehip_wgrad_group_prepare", C.cast(arr, C.c_void_p), n, ptr(buf), C.cast(C.pointer(total), C.c_void_p))
-            g = self._wg_groups[key] = (buf, n, total.value)
+            # the same group on the streaming dense-row kernel (csrc/dtw.hip) where the library takes it: its tables and the scratch
+            # its partial tiles go through (caller-owned: nothing is allocated per step; shared by the groups of this workspace --
+            # they run on one stream, one after the other)
+            dense = None
+            if not os.environ.get("SEHIP_NO_DENSE_GROUP"):
+                lib_ = _lib.lib()
+                dbuf = torch.empty(int(lib_.sehip_wgrad_dense_group_bytes(n)), dtype=torch.uint8, device=buf.device)
+                info = (C.c_int * 8)()
+                call("sehip_wgrad_dense_group_prepare", C.cast(arr, C.c_void_p), n, ptr(dbuf), dbuf.numel(), C.cast(info, C.c_void_p))
+                if info[0] == 1:
+                    need = info[4] + (info[5] << 31)
+                    if getattr(self, "_dtw_scratch", None) is None or self._dtw_scratch.numel() < need:
+                        self._dtw_scratch = torch.empty(need, dtype=torch.float32, device=buf.device)
+                    dense = (dbuf, info)
+            g = self._wg_groups[key] = (buf, n, total.value, dense)
         return g
 
     def wgrad_group(self, names):
         """The weight gradients of several plain products as ONE launch on the side stream (sehip_wgrad_group): the LSTM
         products are small grids that took ~30 us each back to back."""
-        if os.environ.get("SEHIP_NO_WGRAD_GROUP") or self.st.deterministic:
+        if os.environ.get("SEHIP_NO_WGRAD_GROUP"):
             for nm in names:
                 self.wgrad(nm)
             return
-        buf, n, total = self._wgrad_group_handle(names)
+        buf, n, total, dense = self._wgrad_group_handle(names)
+        if self.st.deterministic and dense is None:      # (the streaming dense-row launch adds its splits in a fixed order; the
+            for nm in names:                             #  table-gathered grouped launch uses atomics: not in the deterministic schedule)
+                self.wgrad(nm)
+            return
         main = torch.cuda.current_stream()
+
+        def launch(st):
+            if dense is not None:
+                call("sehip_wgrad_dense_group", ptr(dense[0]), n, C.cast(dense[1], C.c_void_p), ptr(self._dtw_scratch), st)
+            else:
+                call("sehip_wgrad_group", ptr(buf), n, total, st)
         if self.side is None:
-            call("sehip_wgrad_group", ptr(buf), n, total, main.cuda_stream)
+            launch(main.cuda_stream)
             return
         if self._chain_dirty:
             call("sehip_stream_depend", self.side.cuda_stream, main.cuda_stream, self._event())
             self._chain_dirty = False
-        call("sehip_wgrad_group", ptr(buf), n, total, self.side.cuda_stream)
+        launch(self.side.cuda_stream)
 
     # ---- BatchNorm helpers ---------------------------------------------------------------------
     def _bn_ptrs(self, pre, params, buffers, nbt):

@@ -48,6 +48,11 @@ def test_self_launch_two_ranks_prints_one_line():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+    # the line carries what the LIVE communicator saw: two ranks took part in a device collective; here they
+    # share one device, and the block says so
+    rc = out["rccl"]
+    assert rc["nranks"] == 2 and rc["allreduce_of_ones"] == 2.0 and len(rc["ranks"]) == 2 and rc["distinct_devices"] == 1
+    assert rc["ms_per_step_min"] <= rc["ms_per_step_max"] and sorted(a["rank"] for a in rc["ranks"]) == [0, 1]
 
 
 @pytest.mark.gpu
