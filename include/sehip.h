@@ -117,6 +117,12 @@ int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, cons
 int sehip_opt_step_g(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm,
                      float lr, float beta1, float beta2, float eps, int step, const int* step_dev, float weight_decay, int mode,
                      float grad_scale, const unsigned* guard, void* stream);
+/* sehip_opt_step_g behind sehip_unpack_grad_sums: also writes metric[0..1] (what sehip_grad_metric computes, from tensor_sums and
+ * sumsq of the UNCLIPPED gradient, scaled like the update) and clears next_sumsq / next_tensor_sums for the following step */
+int sehip_opt_step_m(float* params, float* grads, float* m, float* v, long n, const double* sumsq, float max_norm, float lr,
+                     float beta1, float beta2, float eps, int step, const int* step_dev, float weight_decay, int mode,
+                     float grad_scale, const unsigned* guard, const float* tensor_sums, int ntensors, float* metric,
+                     double* next_sumsq, float* next_tensor_sums, void* stream);
 int sehip_opt_begin_g(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, const unsigned* guard, void* stream);
 int sehip_counter_add(int* counter, int value, void* stream);
 /* sets the dynamic-LDS attributes of every kernel up front (call once before capturing a hipGraph) */
@@ -326,6 +332,12 @@ int sehip_pack_f32(const float* params, const int* table2 /*[n][2]*/, long n, fl
 int sehip_pack_head(const float* params, const int* wtable, long nw, void* wout_bf16, const int* btable2, long nb, float* bout,
                     float* zero, long nz, void* stream);
 int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n, float* grads, void* stream);
+/* unpack_grad that also takes, from the values it writes, the sum of squares (added to *sumsq) and the per-tensor sums (added to
+ * tensor_sums[t], tensors bounded by offsets[0 .. ntensors]) that sehip_grad_sumsq / sehip_grad_metric would read the buffer again
+ * for, and advances the optimizer's device step counter (unless *guard != 0): the single-replica tail of a train step in one launch.
+ * The accumulators must be zero on entry (sehip_opt_step_m clears the next step's).  Atomics: not in the deterministic schedule. */
+int sehip_unpack_grad_sums(const float* packed, const int* table4, long n, float* grads, const long* offsets, int ntensors,
+                           double* sumsq, float* tensor_sums, int* counter, const unsigned* guard, void* stream);
 /* compact forms for large models (Demucs: 133.7 M parameters):
  *   unpack_grad1    : one entry per parameter (table1 [n]); unpack_grad_list: grads[list[i]] = sum of table4[i] for the few
  *                     parameters with several entries (run after unpack_grad1, which leaves their first entry there)

@@ -60,6 +60,7 @@ _PROTOS = {
     "sehip_grad_sumsq": [P, L, P, P],
     "sehip_opt_step": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P],
     "sehip_opt_step_g": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P, P],
+    "sehip_opt_step_m": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P, P, I, P, P, P, P],
     "sehip_opt_begin_g": [P, I, P, P, I, P, P],
     "sehip_counter_add": [P, I, P],
     "sehip_init": [],
@@ -89,6 +90,7 @@ _PROTOS = {
     "sehip_pack_f32": [P, P, L, P, P],
     "sehip_pack_head": [P, P, L, P, P, L, P, P, L, P],
     "sehip_unpack_grad": [P, P, L, P, P],
+    "sehip_unpack_grad_sums": [P, P, L, P, P, I, P, P, P, P, P],
     "sehip_unpack_grad1": [P, P, L, P, P],
     "sehip_unpack_grad_list": [P, P, P, L, P, P],
     "sehip_pack_bf16_runs": [P, P, P, L, P, P],

@@ -117,7 +117,10 @@ __device__ __forceinline__ void c3_wait_step(int j) {          // j is a constan
 // The kernel body: workgroup `bid` of `nwg` of the product d (a function, so that one launch can run the tiles of TWO products -- the
 // output-row parities of a transposed convolution -- as conv_gemm_v3_pair_kernel does below).
 template <int NF, int FM, int J, int TM, int TN, int NWN = 2, int ABL = 0>
-__device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, const int order, const int bid, const int nwg) {
+// `first_logical`, `halves`: the tail form (conv_gemm_v3_tail_kernel): this workgroup's position `bid` of `nwg` counts HALF tiles of
+// the tiles from `first_logical` on -- tile height TM is then half of the launch's full tiles, two consecutive positions share a tile.
+__device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, const int order, const int bid, const int nwg,
+                                        const int first_logical = 0, const bool halves = false) {
     using G = C3Geo<NF, FM, J, TM, NWN>;
     constexpr int NWV = 2 * NWN, NTH = 64 * NWV;     // waves, threads
     constexpr int WSLOT = 16 * TN * NWN * 64, RING = G::RING;
@@ -170,6 +173,10 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
         const int mtiles = nwg / ntn;
         const int m_ = grp * 32 + (r & 31);
         if (grp * span + span <= nwg && m_ < mtiles) { nt = r >> 5; mt = m_; }     // (the ragged tail keeps the default order)
+    }
+    if (halves) {                 // position -> (tile, half): the tile grid is the FULL tiles' (2 TB frames each)
+        const int L = first_logical + (logical >> 1);
+        nt = L % ntn; mt = 2 * (L / ntn) + (logical & 1);
     }
     const int g0 = mt * TB, n0 = nt * BN;
     const int f0 = d.cv_fadd;
@@ -637,6 +644,14 @@ template <int NF, int FM, int J, int TM, int TN, int NWN = 2, int ABL = 0>
 __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void conv_gemm_v3_kernel(const sehip_gemm_desc d, int B, int order) {
     c3_body<NF, FM, J, TM, TN, NWN, ABL>(d, B, order, (int)blockIdx.x, (int)gridDim.x);
 }
+// The last, partial round of a launch as HALF tiles: a launch of 650 tiles on 512 slots runs 138 tiles alone on their CUs for a whole
+// tile life while 118 CUs idle; as 276 tiles of half the height the same rows occupy every CU for about half as long.  Workgroups
+// [0, nfull) run full tiles (TM = 8), the rest half tiles (TM = 4) of the remaining tiles.
+template <int NF, int FM, int J, int TN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_v3_tail_kernel(const sehip_gemm_desc d, int B, int order, int nfull) {
+    if ((int)blockIdx.x < nfull) c3_body<NF, FM, J, 8, TN, 2, 0>(d, B, order, (int)blockIdx.x, nfull);
+    else c3_body<NF, FM, J, 4, TN, 2, 0>(d, B, order, (int)blockIdx.x - nfull, (int)gridDim.x - nfull, nfull, true);
+}
 // Both output-row parities of a transposed convolution (3 and 2 row taps over the same sources: sehip_gemm_pair) in ONE launch: the
 // first `na` workgroups run product a's tiles, the rest product b's.  Two launches of ~1.3 rounds of tiles each leave their last
 // rounds half empty and pay two launch ramps; together the tiles of the second product fill the first one's tail.
@@ -676,6 +691,23 @@ static int c3_launch(const sehip_gemm_desc& d, int B, int grid, hipStream_t st) 
     if (!c3_set_attr<NF, FM, J, TM, TN, NWN>()) return 0;      // sehip_gemm then reports that the tile-ordered weights found no kernel
     sehip_note_kernel("conv_gemm_v3_kernel<%d, %d, %d, %d, %d, %d, 0>", NF, FM, J, TM, TN, NWN);
     conv_gemm_v3_kernel<NF, FM, J, TM, TN, NWN><<<grid, 128 * NWN, c3_lds_bytes<NF, FM, J, TM, TN, NWN>(), st>>>(d, B, c3_order());
+    return 1;
+}
+template <int NF, int FM, int J, int TN>
+static int c3_launch_tail(const sehip_gemm_desc& d, int B, int nfull, int nhalf, hipStream_t st) {
+    static unsigned char state[64] = {};      // per device: 0 = not tried, 1 = set, 2 = failed (as c3_set_attr)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_v3_tail_kernel<NF, FM, J, TN>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : 2;
+    }
+    if (state[dev] != 1) return 0;
+    const size_t l8 = c3_lds_bytes<NF, FM, J, 8, TN>(), l4 = c3_lds_bytes<NF, FM, J, 4, TN>();
+    sehip_note_kernel("conv_gemm_v3_tail_kernel<%d, %d, %d, %d>", NF, FM, J, TN);
+    conv_gemm_v3_tail_kernel<NF, FM, J, TN><<<nfull + nhalf, 256, l8 > l4 ? l8 : l4, st>>>(d, B, c3_order(), nfull);
     return 1;
 }
 #ifdef SEHIP_TOOLS_BUILD
@@ -718,6 +750,21 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     }
 #endif
     const int tm = c3_pick_tm(vframes, d.J, ntn);
+    // tail form: full rounds of 512 tiles as they are, the partial last round (at most 300 tiles: they would run alone on their CUs)
+    // as half tiles
+    static const bool notail = getenv("SEHIP_NO_C3_TAIL") != nullptr;
+    if (!notail && tm == 8) {
+        const int TB8 = 256 / d.J, nt8 = (int)((vframes + TB8 - 1) / TB8) * ntn, nfull = nt8 / 512 * 512, rem = nt8 - nfull;
+        if (nfull > 0 && rem > 0 && rem <= 300) {
+#define C3T_CASE(J_)                                                                                                 \
+            case J_: return BN == 128 ? c3_launch_tail<NF, FM, J_, 4>(d, B, nfull, 2 * rem, st) : c3_launch_tail<NF, FM, J_, 2>(d, B, nfull, 2 * rem, st);
+            switch (d.J) {
+                C3T_CASE(4) C3T_CASE(8) C3T_CASE(16) C3T_CASE(32)
+                default: break;
+            }
+#undef C3T_CASE
+        }
+    }
 #define C3_CASE(J_)                                                                                       \
     case J_: {                                                                                            \
         const int TB = 32 * tm / J_, grid = (int)((vframes + TB - 1) / TB) * ntn;                         \

@@ -33,7 +33,26 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, fl
                                                        float max_norm, float lr, float b1, float b2, float eps, float bc1,
                                                        float sqrt_bc2, float wd, int mode, int first_step,
                                                        const int* __restrict__ step_dev, float gscale,
-                                                       const unsigned* __restrict__ guard) {
+                                                       const unsigned* __restrict__ guard,
+                                                       const float* __restrict__ tsums, int ntensors, float* __restrict__ metric,
+                                                       double* __restrict__ next_sumsq, float* __restrict__ next_tsums) {
+    // (the fused tail, sehip_opt_step_m: the accumulators of the NEXT step are cleared here -- the other one of two sets, which nobody
+    //  reads during this step -- and workgroup 0 derives the logged metrics from the per-tensor sums sehip_unpack_grad_sums left)
+    if (next_tsums && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < ntensors; i += 256) next_tsums[i] = 0.f;
+        if (threadIdx.x == 0 && next_sumsq) next_sumsq[0] = 0.0;
+    }
+    if (metric && blockIdx.x == 0 && threadIdx.x < 64) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < ntensors; i += 64) acc += tsums[i] * tsums[i];
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) {
+            float c = gscale;                                   // the sums are of the UNCLIPPED, unscaled gradient: scale them as the
+            if (max_norm > 0.f) c = gscale * fminf(1.f, max_norm / ((float)sqrt(sumsq[0]) * gscale + 1e-6f));   // update below does
+            metric[0] = sqrtf(acc) * c;
+            metric[1] = (float)sqrt(sumsq[0]);
+        }
+    }
     if (guard && guard[0] != 0u) return;   // the step's gradients were declared invalid on the device: nothing is applied
     if (step_dev) {  // step counter lives on the device (graph replay): bias corrections computed here
         const int step = step_dev[0];
@@ -208,8 +227,30 @@ extern "C" int sehip_opt_step_g(float* params, float* grads, float* m, float* v,
     if (grid > 2048) grid = 2048;
     opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
                                                            (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev,
-                                                           grad_scale, guard);
+                                                           grad_scale, guard, nullptr, 0, nullptr, nullptr, nullptr);
     SEHIP_CHECK_LAUNCH("opt_step");
+    return 0;
+}
+// sehip_opt_step_g for a step whose gradients came through sehip_unpack_grad_sums (sumsq and tensor_sums hold this step's sums): the
+// same update, plus metric[0] = the reference's sqrt(sum_t (sum g_t)^2) of the CLIPPED gradient and metric[1] = sqrt(sumsq)
+// (sehip_grad_metric's outputs), plus the clearing of next_sumsq / next_tensor_sums (the set the next step will add to; may be
+// NULL).  No sehip_opt_begin, sehip_grad_sumsq or sehip_grad_metric launch is needed around it.
+extern "C" int sehip_opt_step_m(float* params, float* grads, float* m, float* v, long n, const double* sumsq,
+                                float max_norm, float lr, float beta1, float beta2, float eps, int step, const int* step_dev,
+                                float weight_decay, int mode, float grad_scale, const unsigned* guard, const float* tensor_sums,
+                                int ntensors, float* metric, double* next_sumsq, float* next_tensor_sums, void* stream) {
+    SEHIP_REQUIRE(n > 0 && (step >= 1 || step_dev != nullptr), "opt_step_m: bad n/step (n=%ld step=%d)", n, step);
+    if (step < 1) step = 1;
+    SEHIP_REQUIRE(mode == 0 || mode == 1, "opt_step_m: mode must be 0 (adam) or 1 (sgd)");
+    SEHIP_REQUIRE(grad_scale > 0.f && sumsq && tensor_sums && metric && ntensors > 0, "opt_step_m: bad arguments");
+    const double bc1 = mode == 0 ? 1.0 - pow((double)beta1, step) : 1.0;
+    const double bc2 = mode == 0 ? 1.0 - pow((double)beta2, step) : 1.0;
+    int grid = cdiv(n, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
+                                                           (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev,
+                                                           grad_scale, guard, tensor_sums, ntensors, metric, next_sumsq, next_tensor_sums);
+    SEHIP_CHECK_LAUNCH("opt_step_m");
     return 0;
 }
 extern "C" int sehip_opt_step(float* params, float* grads, float* m, float* v, long n, const double* sumsq,

@@ -76,6 +76,54 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restric
     }
 }
 
+// unpack_grad + the optimizer's two reductions over the SAME values while they are in registers (single-replica steps: the sums
+// must be taken after the data-parallel all-reduce otherwise): the clipping norm's sum of squares and the per-tensor sums of the
+// reference's logged grad_norm (src/solver.py:487-498).  Workgroup b owns a contiguous range of parameters and flushes its running
+// sum at every tensor boundary inside it (as tensor_sums_flat_kernel); workgroup 0 also advances the optimizer's device step counter
+// (what sehip_opt_begin did in a launch of its own).  Three launches less on the tail of the step's chain.
+__global__ __launch_bounds__(256) void unpack_grad_sums_kernel(const float* __restrict__ packed, const int4* __restrict__ tab, long n,
+                                                               float* __restrict__ grads, const long* __restrict__ offsets, int ntensors,
+                                                               double* __restrict__ sumsq, float* __restrict__ tsums,
+                                                               int* __restrict__ counter, const unsigned* __restrict__ guard) {
+    __shared__ float red[4];
+    __shared__ int first;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counter && !(guard && guard[0] != 0u)) counter[0] += 1;
+    const long per = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    long lo = (long)blockIdx.x * per;
+    const long hi = min(n, lo + per);
+    if (lo >= hi) return;
+    if (threadIdx.x == 0) {          // the tensor that holds parameter lo: largest t with offsets[t] <= lo
+        int a = 0, b = ntensors - 1;
+        while (a < b) {
+            const int mid = (a + b + 1) >> 1;
+            if (offsets[mid] <= lo) a = mid; else b = mid - 1;
+        }
+        first = a;
+    }
+    __syncthreads();
+    int t = first;
+    float q = 0.f;
+    while (lo < hi) {
+        const long e = min(hi, offsets[t + 1]);
+        if (e > lo) {
+            float acc = 0.f;
+            for (long i = lo + threadIdx.x; i < e; i += 256) {
+                const int4 en = tab[i];
+                const float g = term(packed, en.x) + term(packed, en.y) + term(packed, en.z) + term(packed, en.w);
+                grads[i] = g;
+                acc += g;
+                q += g * g;
+            }
+            acc = block_sum<4>(acc, red);
+            if (threadIdx.x == 0) atomicAdd(&tsums[t], acc);
+            lo = e;
+        }
+        ++t;
+    }
+    q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) atomicAdd(sumsq, (double)q);
+}
+
 // The common case of the above -- ONE entry per parameter -- with a 4-byte table entry instead of 16 (133.7 M parameters of Demucs:
 // 0.54 GB of table instead of 2.1 GB per step); four parameters per thread.
 __global__ __launch_bounds__(256) void unpack_grad1_kernel(const float* __restrict__ packed, const int* __restrict__ tab, long n,
@@ -164,6 +212,18 @@ extern "C" int sehip_unpack_grad(const float* packed, const int* table4, long n,
     if (n == 0) return 0;
     unpack_grad_kernel<<<grid_of(n), 256, 0, (hipStream_t)stream>>>(packed, (const int4*)table4, n, grads);
     SEHIP_CHECK_LAUNCH("unpack_grad");
+    return 0;
+}
+
+extern "C" int sehip_unpack_grad_sums(const float* packed, const int* table4, long n, float* grads, const long* offsets, int ntensors,
+                                      double* sumsq, float* tensor_sums, int* counter, const unsigned* guard, void* stream) {
+    SEHIP_REQUIRE(n >= 0 && ntensors > 0 && offsets && sumsq && tensor_sums, "unpack_grad_sums: bad arguments");
+    SEHIP_REQUIRE(!sehip_deterministic(), "unpack_grad_sums: not part of the deterministic schedule (fp32 / double atomics): use "
+                                          "sehip_unpack_grad + sehip_grad_sumsq + sehip_grad_metric");
+    if (n == 0) return 0;
+    unpack_grad_sums_kernel<<<1024, 256, 0, (hipStream_t)stream>>>(packed, (const int4*)table4, n, grads, offsets, ntensors, sumsq,
+                                                                  tensor_sums, counter, guard);
+    SEHIP_CHECK_LAUNCH("unpack_grad_sums");
     return 0;
 }
 

@@ -163,8 +163,14 @@ class DCCRN(FlatModule):
         if not self.training:
             raise SehipError("DCCRN.backward in eval mode (running-statistics BatchNorm) is not built")
         g = grad_out.reshape(ws.B, ws.length).contiguous().float()
-        hook = self.grad_range_hook if not (self._grads_live and self._params[0][1].grad is not None) else None   # not when accumulating
-        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, range_ready=hook))
+        accumulating = self._grads_live and self._params[0][1].grad is not None
+        hook = self.grad_range_hook if not accumulating else None   # not when accumulating
+        tail = self._tail_sink if (hook is None and not accumulating) else None      # FlatOptimizer's accumulators (single replica)
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, range_ready=hook, tail=tail))
+        if tail is not None:
+            self._tail_done = self._tail_counted = self._tail_dirty = True
+        else:
+            self._tail_done = False          # (an accumulating or data-parallel pass: the optimizer takes its sums from the final buffer)
 
     def forward(self, inputs, lens=None):
         if inputs.dim() == 2:

@@ -41,6 +41,10 @@ class FlatModule(nn.Module):
         self.storage_epoch = 0        # bumped whenever the flat buffers are re-created (captured hipGraphs go stale)
         self._anchor = None
         self._grads_live = False
+        # single-replica tail of the train step (sehip_unpack_grad_sums / sehip_opt_step_m): FlatOptimizer.zero_grad() leaves the
+        # addresses of its accumulators here, a plan that supports it un-packs the gradients with the sums and sets _tail_done
+        self._tail_sink, self._tail_done = None, False
+        self._tail_counted = self._tail_dirty = False      # the un-pack already advanced the step counter / left sums in the current set
         for name in list_roots:
             setattr(self, name, nn.ModuleList())
         self._params, self._buffers_named, self._nbt_named = [], [], []

@@ -36,8 +36,13 @@ class FlatOptimizer(torch.optim.Optimizer):
             if old_m is not None and old_m.numel() == flat.numel():
                 self._m.copy_(old_m); self._v.copy_(old_v)
             self._step_dev = torch.full((1,), int(self._step), dtype=torch.int32, device=flat.device)
+            # (sumsq / tsums: two sets, used alternately by the fused single-replica tail -- a step's optimizer launch clears the
+            #  set the NEXT step adds to, so no clearing launch sits on the chain; the unfused path uses set 0)
+            self._set = 0
             self._scratch = dict(sumsq=torch.zeros(1, dtype=torch.float64, device=flat.device),
                                  tsums=torch.zeros(len(self.model._params), device=flat.device),
+                                 sumsq1=torch.zeros(1, dtype=torch.float64, device=flat.device),
+                                 tsums1=torch.zeros(len(self.model._params), device=flat.device),
                                  metric=torch.zeros(2, device=flat.device),
                                  offsets=torch.from_numpy(self.model.static.layout.tensor_offsets).to(flat.device))
             self._publish_state()
@@ -70,11 +75,33 @@ class FlatOptimizer(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1  # host mirror; the kernel reads the device counter (valid under hipGraph replay)
         s = self._scratch
+        if getattr(model, "_tail_done", False) and self.grad_scale == 1.0:
+            # the backward pass un-packed the gradients WITH the clipping norm's and the metric's sums and advanced the device step
+            # counter (sehip_unpack_grad_sums): one launch updates, derives the logged metrics and clears the other set of accumulators
+            model._tail_done, model._tail_sink, model._tail_counted, model._tail_dirty = False, None, False, False
+            cur, nxt = ("", "1") if self._set == 0 else ("1", "")
+            gfn = getattr(model, "step_guard", None)
+            guard = gfn() if gfn is not None else None
+            if self.kind == "adam":
+                (b1, b2), mode = g["betas"], 0
+            else:
+                b1, b2, mode = g["momentum"], 0.0, 1
+            call("sehip_opt_step_m", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq" + cur]),
+                 self.max_norm, g["lr"], b1, b2, g["eps"], self._step, ptr(self._step_dev), g["weight_decay"], mode, 1.0, ptr(guard),
+                 ptr(s["tsums" + cur]), s["tsums"].numel(), ptr(s["metric"]), ptr(s["sumsq" + nxt]), ptr(s["tsums" + nxt]), stream())
+            self._set ^= 1
+            self._metric_fresh = True
+            self.max_norm = 0.0
+            return
         # one launch: step counter, and the accumulators of the clipping norm and of the grad_norm metric cleared
         # guard: device word that, when non-zero, turns this step into a no-op (model.step_guard(): Demucs' hand-off time-out word)
         gfn = getattr(model, "step_guard", None)
         guard = gfn() if gfn is not None else None
-        call("sehip_opt_begin_g", ptr(self._step_dev), 1, ptr(s["sumsq"]), ptr(s["tsums"]), s["tsums"].numel(), ptr(guard), stream())
+        counted = getattr(model, "_tail_counted", False)      # a fused un-pack whose sums were invalidated afterwards (a second, accumulating
+        if counted:                                           # backward pass; a data-parallel scale set late) has already counted this step
+            model._tail_counted = model._tail_done = False
+        call("sehip_opt_begin_g", ptr(self._step_dev), 0 if counted else 1, ptr(s["sumsq"]), ptr(s["tsums"]), s["tsums"].numel(), ptr(guard),
+             stream())
         self._tsums_clear = True
         if self.max_norm > 0:
             call("sehip_grad_sumsq_acc", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
@@ -92,6 +119,9 @@ class FlatOptimizer(torch.optim.Optimizer):
         """Device tensor [2]: the reference's sqrt(sum_p (p.grad.sum())^2) (src/solver.py:494-498) and the L2 norm."""
         self._ensure_state()
         s = self._scratch
+        if getattr(self, "_metric_fresh", False):          # the fused optimizer launch has written it
+            self._metric_fresh = False
+            return s["metric"]
         grads = self.model.flat_grads
         offs = self.model.static.layout.tensor_offsets
         fn = "sehip_grad_metric_acc" if getattr(self, "_tsums_clear", False) else "sehip_grad_metric"     # step() has just cleared tsums
@@ -107,6 +137,37 @@ class FlatOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=True)
         self.model._grads_live = False
+        self._arm_fused_tail()
+
+    def _arm_fused_tail(self):
+        """Single replica, default (non-deterministic) schedule, not under stream capture: tell the model where the next backward
+        pass may add the clipping norm's sum of squares and the metric's per-tensor sums while it un-packs the gradients
+        (model._tail_sink; the DCCRN plan does: csrc/pack.hip unpack_grad_sums_kernel).  Any other situation keeps the separate
+        launches of step() / grad_metric()."""
+        model = self.model
+        if not hasattr(model, "_tail_sink"):
+            return
+        model._tail_sink = None
+        if getattr(model, "_tail_counted", False) or getattr(model, "_tail_dirty", False):
+            self._ensure_state()
+            s = self._scratch
+            cur = "" if self._set == 0 else "1"
+            if model._tail_counted:                        # a fused backward pass whose step() never came: un-count it
+                self._step_dev.sub_(1)
+                model._tail_counted = False
+            if model._tail_dirty:                          # ... and its sums (or those of a pass that was invalidated) are stale
+                s["sumsq" + cur].zero_(); s["tsums" + cur].zero_()
+                model._tail_dirty = False
+        model._tail_done = False
+        from ._lib import lib
+        import os
+        if (os.environ.get("SEHIP_NO_FUSED_TAIL") or self.grad_scale != 1.0 or getattr(model, "grad_range_hook", None) is not None
+                or not model.flat_params.is_cuda or torch.cuda.is_current_stream_capturing() or lib().sehip_get_deterministic()):
+            return
+        self._ensure_state()
+        s = self._scratch
+        cur = "" if self._set == 0 else "1"
+        model._tail_sink = (ptr(s["sumsq" + cur]), ptr(s["tsums" + cur]), ptr(s["offsets"]), s["tsums"].numel(), ptr(self._step_dev))
 
     # ---- checkpoint format of torch.optim ----------------------------------------------------------
     def sync_step(self):

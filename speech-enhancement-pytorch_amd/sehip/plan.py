@@ -1362,7 +1362,7 @@ class DCCRNWorkspace:
              cfg.win_inc, cfg.fft_len, self.length, self.mode, ptr(self.frames), ptr(self.wav), stream())
         return self.wav
 
-    def backward(self, dwav, params, grads, range_ready=None):
+    def backward(self, dwav, params, grads, range_ready=None, tail=None):
         """dwav [B,length] fp32 -> flat parameter gradients (overwritten).
 
         range_ready(lo, hi, stream) -- data-parallel hook: called as soon as grads[lo:hi] is final ON `stream` (a torch stream),
@@ -1425,7 +1425,14 @@ class DCCRNWorkspace:
                 self.gemm_pair(f"enc{i}.dg0", f"enc{i}.dg1")     # one streaming launch for the outer layers (csrc/convt.hip), else the two products
         if self.side is not None:
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), lo if range_ready is not None else n_params, ptr(grads), stream())
+        if tail is not None and range_ready is None:
+            # tail = (sumsq, tensor_sums, offsets, ntensors, step counter) of the fused optimizer: the un-pack also takes its sums and
+            # advances its device step counter (guarded by this workspace's hand-off word): see FlatOptimizer._arm_fused_tail
+            guard = ptr(self.l2_sync) if hasattr(self, "l2_sync") else None
+            call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
+                 guard, stream())
+        else:
+            call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), lo if range_ready is not None else n_params, ptr(grads), stream())
         if range_ready is not None:
             range_ready(0, lo, torch.cuda.current_stream())
             call("sehip_stream_depend", stream(), self.comm.cuda_stream, self._event())

@@ -332,6 +332,8 @@ class Solver(object):
             # one SUM all-reduce of the flat buffer, in two ranges where the model hands them over early (the decoder / LSTM
             # range starts its exchange under the encoder's backward pass); 1/world is folded into the optimizer launch
             self.optimizer.grad_scale = 1.0 / self.world_size
+            if hasattr(self.model, "_tail_sink"):
+                self.model._tail_sink = None      # the optimizer's sums must be taken AFTER the all-reduce: no fused single-replica tail
             works = []
             early_guard = bool(getattr(self.model, "step_guard_early", False)) and hasattr(self.model, "step_guard")
             if hasattr(self.model, "grad_range_hook"):

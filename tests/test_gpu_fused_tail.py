@@ -1,0 +1,122 @@
+"""The single-replica tail of the train step in two launches (sehip_unpack_grad_sums + sehip_opt_step_m: un-pack with the clipping
+norm's sum of squares and the metric's per-tensor sums, then update + logged metrics + clearing of the next step's accumulators)
+against the separate launches (sehip_unpack_grad, sehip_opt_begin, sehip_grad_sumsq, sehip_opt_step, sehip_grad_metric) on the SAME
+packed gradient buffer and the same optimizer state: the un-packed gradients must be bit-equal, everything else equal up to the
+order of the sums.  HIP vs HIP at the operator level (whole steps differ from run to run by the default schedule's atomics; the
+oracle comparison of the whole step -- tests/test_gpu_solver.py -- runs the fused tail by default)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("clip", [0.0, 5.0, 0.05])
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_fused_tail_matches_the_separate_launches(clip, kind):
+    from sehip.model import DCCRN
+    from sehip.optim import FlatOptimizer
+    from sehip._lib import call, ptr, stream
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    model = DCCRN(kernel_num=[16, 16, 32, 32, 64, 64], rnn_units=128, length=4000).to(dev).train()
+    x = (0.1 * torch.randn(2, 1, 4000)).to(dev)
+    model(x).sum().backward()                      # builds the workspace, its tables and the flat gradient buffer
+    torch.cuda.synchronize()
+    ws = model.workspace(2, 4000)
+    n = model.flat_params.numel()
+    gen = torch.Generator(device=dev).manual_seed(7)
+    ws.gpack.copy_(torch.randn(ws.gpack.shape, device=dev, generator=gen) * 3e-2)
+    p0 = model.flat_params.detach().clone()
+    res = []
+    for fused in (False, True):
+        model.flat_params.data.copy_(p0)
+        opt = FlatOptimizer(model, lr=3e-3, kind=kind, momentum=0.9 if kind == "sgd" else 0.0)
+        opt._ensure_state()
+        opt._m.normal_(generator=gen).mul_(1e-2); opt._v.uniform_(1e-6, 1e-4, generator=gen)
+        if fused and res:
+            opt._m.copy_(res[0]["m0"]); opt._v.copy_(res[0]["v0"])
+        m0, v0 = opt._m.clone(), opt._v.clone()
+        opt._step = 3; opt._step_dev.fill_(3)
+        grads = model.flat_grads
+        grads.zero_()
+        s = opt._scratch
+        if fused:
+            call("sehip_unpack_grad_sums", ptr(ws.gpack), ptr(ws.tb.utab), n, ptr(grads), ptr(s["offsets"]), s["tsums"].numel(),
+                 ptr(s["sumsq"]), ptr(s["tsums"]), ptr(opt._step_dev), None, stream())
+            model._tail_done = True
+        else:
+            call("sehip_unpack_grad", ptr(ws.gpack), ptr(ws.tb.utab), n, ptr(grads), stream())
+            model._tail_done = False
+        g_unpacked = grads.clone()
+        if clip:
+            opt.clip_grad_norm_(clip)
+        opt.step()
+        metric = opt.grad_metric().clone()
+        torch.cuda.synchronize()
+        assert opt.sync_step() == 4
+        if fused:     # the launch cleared the OTHER set for the next step and left this one's sums in place
+            assert float(s["sumsq1"][0]) == 0.0 and float(s["tsums1"].abs().max()) == 0.0 and opt._set == 1
+        res.append(dict(g=g_unpacked, p=model.flat_params.detach().clone(), m=opt._m.clone(), v=opt._v.clone(), metric=metric,
+                        gc=grads.clone(), m0=m0, v0=v0))
+    a, b = res
+    assert torch.equal(a["g"], b["g"])
+    for key, tol in (("p", 1e-6), ("m", 1e-6), ("v", 1e-6), ("gc", 1e-6)):
+        err = float((a[key] - b[key]).norm() / a[key].norm())
+        assert err < tol, (key, clip, kind, err)
+    # metric[0]: the reference's sqrt(sum_t (sum g_t)^2) of the clipped gradient; metric[1]: the pre-clip L2 norm (the separate launches
+    # only take it when clipping is on; the fused un-pack always has it)
+    assert abs(float(a["metric"][0]) - float(b["metric"][0])) < 1e-5 * float(a["metric"][0]) and float(b["metric"][0]) > 0
+    if clip:
+        assert abs(float(a["metric"][1]) - float(b["metric"][1])) < 1e-5 * float(a["metric"][1])
+    assert abs(float(b["metric"][1]) - float(a["g"].double().norm())) < 1e-5 * float(b["metric"][1])
+
+
+def test_accumulation_and_skipped_steps_keep_the_counter_and_the_sums_right():
+    """The fused un-pack advances the device step counter and fills the accumulators during backward(); a second, accumulating
+    backward pass invalidates its sums (step() then takes them from the final buffer and does not count twice), and a backward
+    pass whose step() never comes is un-counted by the next zero_grad()."""
+    import numpy as np
+    from sehip.model import DCCRN
+    from sehip.optim import FlatOptimizer
+    from sehip.loss import loss_sisdr
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    model = DCCRN(kernel_num=[16, 16, 32, 32, 64, 64], rnn_units=128, length=4000).to(dev).train()
+    opt = FlatOptimizer(model, lr=3e-4)
+    g = torch.Generator().manual_seed(4)
+    def batch():
+        c = (0.1 * torch.randn(2, 1, 4000, generator=g)).to(dev)
+        return c + (0.05 * torch.randn(2, 1, 4000, generator=g)).to(dev), c
+    offs = model.static.layout.tensor_offsets
+
+    def ref_metric():
+        gr = model.flat_grads.double().cpu().numpy()
+        return float(np.sqrt(sum(gr[offs[t]:offs[t + 1]].sum() ** 2 for t in range(len(offs) - 1))))
+    # two backward passes, one step
+    opt.zero_grad()
+    for _ in range(2):
+        n, c = batch()
+        loss_sisdr(model(n), c).backward()
+    assert model._tail_done is False
+    opt.clip_grad_norm_(5.0)
+    opt.step()
+    m = opt.grad_metric()
+    torch.cuda.synchronize()
+    assert opt.sync_step() == 1
+    assert abs(float(m[0]) - ref_metric()) < 1e-4 * ref_metric()
+    # a backward pass without a step, then a normal (fused) step
+    opt.zero_grad()
+    n, c = batch()
+    loss_sisdr(model(n), c).backward()
+    assert model._tail_done is True
+    opt.zero_grad()
+    n, c = batch()
+    loss_sisdr(model(n), c).backward()
+    opt.clip_grad_norm_(5.0)
+    opt.step()
+    m = opt.grad_metric()
+    torch.cuda.synchronize()
+    assert opt.sync_step() == 2
+    assert abs(float(m[0]) - ref_metric()) < 1e-4 * ref_metric()
