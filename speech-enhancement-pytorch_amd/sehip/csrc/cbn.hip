@@ -719,6 +719,14 @@ static int unroll_rows() {
     static const int u = env_int("SEHIP_CBN_U", 2);
     return u == 1 || u == 4 ? u : 2;
 }
+// The backward passes run beside the weight-gradient stream, whose workgroups (conv_wgrad_kernel: 171-204 registers x 8 waves) stay
+// resident for 100-200 us: a backward pass with two rows per trip needs 146 / 194 registers and finds no room on those CUs -- it waits
+// for them (round 5: one apply pass took 84 us beside conv_wgrad_kernel<2>, 12 us alone).  One row per trip: 92 / 118 registers, the
+// passes share the CUs (B = 32 step 3.236 -> 3.216 ms, same box; the forward passes, which run alone, keep two rows).
+static int unroll_rows_bwd() {
+    static const int u = env_int("SEHIP_CBN_BU", 1);
+    return u == 2 || u == 4 ? u : 1;
+}
 // streaming passes: rows-per-thread target -> grid (the coefficient preamble is paid per workgroup)
 // Cap: 768 since the forward apply pass also finalizes the sums (every workgroup pays ~1 us for the records of all channels): B = 32
 // step, ms, two runs each: 2048: 4.157 / 4.184, 1536: 4.167 / 4.178, 1024: 4.146 / 4.158, 768: 4.138 / 4.149, 512: 4.142 / 4.164,
@@ -833,7 +841,7 @@ static int cbn_bwd_reduce_launch(const void* dz, const void* dz2, const void* y,
 #define CBN_RED(U, CH, H2) cbn_bwd_reduce_kernel<U, CH, H2><<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>( \
         (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part, nrep)
 #define CBN_RED2(U, CH) do { if (dz2) CBN_RED(U, CH, true); else CBN_RED(U, CH, false); } while (0)
-    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+    switch (unroll_rows_bwd() * 16 + cbn_ch(Cr)) {
         case 1 * 16 + 8: CBN_RED2(1, 8); break;
         case 2 * 16 + 8: CBN_RED2(2, 8); break;
         case 4 * 16 + 8: CBN_RED2(4, 8); break;
@@ -883,7 +891,7 @@ extern "C" int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* 
 #define CBN_BAPP(U, CH, H2) cbn_bwd_apply_kernel<U, CH, H2><<<apply_blocks(rows, Cr, true), 256, 0, (hipStream_t)stream>>>( \
         (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, bcoef, slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy)
 #define CBN_BAPP2(U, CH) do { if (dz2) CBN_BAPP(U, CH, true); else CBN_BAPP(U, CH, false); } while (0)
-    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+    switch (unroll_rows_bwd() * 16 + cbn_ch(Cr)) {
         case 1 * 16 + 8: CBN_BAPP2(1, 8); break;
         case 2 * 16 + 8: CBN_BAPP2(2, 8); break;
         case 4 * 16 + 8: CBN_BAPP2(4, 8); break;
@@ -912,7 +920,7 @@ extern "C" int sehip_cbn_bwd_fused(const void* dz, const void* dz2, const void* 
         (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, rep, nrep, rep_next, Wrr, Wri, Wii, gWrr, gWri, gWii, gBr, gBi, gslope, \
         slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy)
 #define CBN_BFIN2(U, CH) do { if (dz2) CBN_BFIN(U, CH, true); else CBN_BFIN(U, CH, false); } while (0)
-    switch (unroll_rows() * 16 + cbn_ch(Cr)) {
+    switch (unroll_rows_bwd() * 16 + cbn_ch(Cr)) {
         case 1 * 16 + 8: CBN_BFIN2(1, 8); break;
         case 2 * 16 + 8: CBN_BFIN2(2, 8); break;
         case 4 * 16 + 8: CBN_BFIN2(4, 8); break;

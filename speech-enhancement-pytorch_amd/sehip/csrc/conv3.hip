@@ -83,6 +83,18 @@ __device__ __forceinline__ void c3_row(int wm, int rw, int& tl, int& jl) {
     }
 }
 
+// scheduling groups: ND DMA instructions, each behind G MFMAs, then the remaining MFMAs (NM in all)
+template <int ND, int NM, int G = 3>
+__device__ __forceinline__ void c3_interleave() {
+    if constexpr (ND == 0 || NM < G) {
+        if constexpr (ND > 0) __builtin_amdgcn_sched_group_barrier(0x020, ND, 0);
+        if constexpr (NM > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        c3_interleave<ND - 1, NM - G, G>();
+    }
+}
 template <int N>
 __device__ __forceinline__ void c3_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -419,9 +431,18 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
             }
             if (!(ABL & 6)) {
                 __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                       // DS reads
-                if (j == 0) __builtin_amdgcn_sched_group_barrier(0x020, DW + MAXP, 0);         // the DMAs
-                else __builtin_amdgcn_sched_group_barrier(0x020, DW, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TN * (TM - 1), 0);                 // MFMAs
+                // Round 5: in the 5-tap instantiations the DMAs are spread between the MFMAs (three MFMAs in front of each) instead of
+                // issued in one block in front of them: a DMA instruction holds the wave's issue for 60-180 cycles, and a wave that
+                // has no partner on its SIMD (the last round of a launch) then idles its matrix pipe per DMA, not for all of them
+                // (dec0.dg 113 -> 104 us, dec1.dg 112 -> 106, same box; the 3- / 2-tap pair launches measured the same or slower).
+                if constexpr (NF == 5) {
+                    if (j == 0) c3_interleave<DW + MAXP, TN * (TM - 1)>();
+                    else c3_interleave<DW, TN * (TM - 1)>();
+                } else {
+                    if (j == 0) __builtin_amdgcn_sched_group_barrier(0x020, DW + MAXP, 0);     // the DMAs
+                    else __builtin_amdgcn_sched_group_barrier(0x020, DW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TN * (TM - 1), 0);             // MFMAs
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #ifdef C3_STAMPS

@@ -1674,8 +1674,11 @@ extern "C" int sehip_gemm_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* 
 // (the generic wgrad_kernel re-reads dOut once per 64 k-columns and the inputs once per tap).  Wave w accumulates
 // dW[64 n][taps][16 channels (16w..)] in registers: 4 x 2NF MFMA tiles; both operands come from transposed LDS reads.
 // ------------------------------------------------------------------------------------------------
+#ifndef CW_MINW
+#define CW_MINW 2      // minimum waves per SIMD the register allocation must allow (4: two workgroups, or one + a chain workgroup, per CU)
+#endif
 template <int NF>
-__global__ __launch_bounds__(512) void conv_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg, int nsplit) {
+__global__ __launch_bounds__(512, CW_MINW) void conv_wgrad_kernel(const sehip_gemm_desc d, int TB, int JB, int FR, int tiles_per_wg, int nsplit) {
     constexpr int NIT = 2 * NF;
     constexpr int GP = 80;  // pitch of the dOut tile: 160 B, so 8 consecutive rows sit on 8 disjoint 32-byte bank slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
