@@ -91,25 +91,43 @@ def gemm_roofline(ws, reps=5):
     from sehip._lib import call, stream, lib
     flush = torch.empty(80 * 1024 * 1024, dtype=torch.float32, device=ws.device)
     per = {}
-    for name, d in ws.desc.items():
-        if not name.endswith(".wg") and not d.W:
-            continue  # recurrent-weight gradients exist only as wgrad launches
-        fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
-        flops = 2.0 * d.M * _weight_entries(ws, name)   # algorithmic: padding channels / padded K columns do not count
-        call(fn, C.byref(d), stream())
+    # the launches as the step issues them where the workspace says so (DCCRN: pairs through sehip_gemm_pair / sehip_wgrad_pair, the
+    # LSTM weight gradients as their one grouped launch); every descriptor singly otherwise
+    if hasattr(ws, "launch_units"):
+        units = ws.launch_units()
+    else:
+        units = []
+        for name, d in ws.desc.items():
+            if not name.endswith(".wg") and not d.W:
+                continue  # recurrent-weight gradients exist only as wgrad launches
+            fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
+            units.append((name, [name], lambda st, fn=fn, d=d: call(fn, C.byref(d), st)))
+    queue = list(units)
+    while queue:
+        name, members, launch = queue.pop(0)
+        flops = sum(2.0 * ws.desc[m].M * _weight_entries(ws, m) for m in members)   # algorithmic: padding channels / padded K columns do not count
+        launch(stream())
         kname = lib().sehip_last_kernel().decode()
+        if len(members) == 2 and not any(t in kname for t in ("pair", "_stream_kernel", "conv_small2")):
+            # the library ran this pair as its two launches (e.g. the deep decoder weight gradients): time and label each on its own
+            for m in members:
+                fn = "sehip_wgrad" if m.endswith(".wg") else "sehip_gemm"
+                queue.append((m, [m], lambda st, fn=fn, m=m: call(fn, C.byref(ws.desc[m]), st)))
+            continue
         if kname.startswith("conv_gemm_v3_kernel<"):
             # one class per (taps, row stride): the instantiations by rows per frame / tile rows / tile columns are the same code
             # (csrc/conv3.hip), picked per layer shape -- the successor of round 2's conv_gemm_v2_kernel<taps, ...> classes
             a = kname[len("conv_gemm_v3_kernel<"):].split(",")
             kname = f"conv_gemm_v3_kernel<{a[0].strip()}, {a[1].strip()}, *>"
+        elif kname.startswith("conv_gemm_v3_pair_kernel<"):
+            kname = "conv_gemm_v3_pair_kernel<*>"        # both output-row parities (3 + 2 taps) of a layer in one launch
         torch.cuda.synchronize()
         times = []
         for _ in range(reps):
             flush.fill_(1.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            call(fn, C.byref(d), stream())
+            launch(stream())
             e1.record()
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1))

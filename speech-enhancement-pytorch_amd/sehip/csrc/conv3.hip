@@ -773,8 +773,10 @@ static int c3_launch_j(const sehip_gemm_desc& d, int B, hipStream_t st) {
     const int tm = c3_pick_tm(vframes, d.J, ntn);
     // tail form: full rounds of 512 tiles as they are, the partial last round (at most 300 tiles: they would run alone on their CUs)
     // as half tiles
-    static const bool notail = getenv("SEHIP_NO_C3_TAIL") != nullptr;
-    if (!notail && tm == 8) {
+    // (opt-in, SEHIP_C3_TAIL=1: built, tested, measured neutral -- a workgroup alone on its CU takes as long per K step with a
+    //  half tile as with a full one)
+    static const bool tail = getenv("SEHIP_C3_TAIL") != nullptr;
+    if (tail && tm == 8) {
         const int TB8 = 256 / d.J, nt8 = (int)((vframes + TB8 - 1) / TB8) * ntn, nfull = nt8 / 512 * 512, rem = nt8 - nfull;
         if (nfull > 0 && rem > 0 && rem <= 300) {
 #define C3T_CASE(J_)                                                                                                 \

@@ -10,6 +10,7 @@
 // Tiles of 32 frames x 32 bins go through LDS so that both the [T][F] side (activations) and the [F][T] side
 // (spectra) are accessed in >= 128-byte runs.
 #include "common.h"
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
 #include "mask.h"
 
 #define DT 32   // tile edge (frames and bins)
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(256) void dcunet_mask_bwd_kernel(const float2* __re
                                                               const float2* __restrict__ mask_ws, const bf16_raw* __restrict__ z,
                                                               const float* __restrict__ w_re, const float* __restrict__ w_im, int F,
                                                               int T, int Cs, int Cr, int mode, bf16_raw* __restrict__ dz,
-                                                              float* __restrict__ gacc) {
+                                                              float* __restrict__ gacc, float* __restrict__ part) {
+    // part != NULL (deterministic schedule): this workgroup's 2 Cs + 2 sums go to row (z, y, x) of `part` by plain stores and
+    // dcunet_rows_reduce_kernel adds the rows in order, instead of one fp32 atomic per weight and workgroup
     __shared__ float2 tile[DT][DP];      // in: the mask; out: d linear, [frame][bin]
     __shared__ float red[4][16][16];     // per wave: [piece q][8 a-sums | 8 b-sums]
     const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
@@ -201,14 +204,40 @@ __global__ __launch_bounds__(256) void dcunet_mask_bwd_kernel(const float2* __re
         const int c = (imag ? qq - (nq >> 1) : qq) * 8 + j;
         if (c < Cr) {
             // real-part piece: d wre += g_re zr, d wim += g_im zr ; imaginary-part piece: d wre += g_im zi, d wim -= g_re zi
-            atomicAdd(&gacc[c], imag ? b : a);
-            atomicAdd(&gacc[Cs + c], imag ? -a : b);
+            if (part) {          // [row][2 halves (real-part piece, imaginary-part piece)][2 Cs + 2]: the reduction adds the halves too
+                float* pr = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(2 * (2 * Cs + 2)) +
+                            (imag ? 2 * Cs + 2 : 0);
+                pr[c] = imag ? b : a;
+                pr[Cs + c] = imag ? -a : b;
+            } else {
+                atomicAdd(&gacc[c], imag ? b : a);
+                atomicAdd(&gacc[Cs + c], imag ? -a : b);
+            }
         }
     }
     if (threadIdx.x == 0) {
-        atomicAdd(&gacc[2 * Cs], redb[0][0] + redb[1][0] + redb[2][0] + redb[3][0]);
-        atomicAdd(&gacc[2 * Cs + 1], redb[0][1] + redb[1][1] + redb[2][1] + redb[3][1]);
+        const float s0 = redb[0][0] + redb[1][0] + redb[2][0] + redb[3][0], s1 = redb[0][1] + redb[1][1] + redb[2][1] + redb[3][1];
+        if (part) {
+            float* pr = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(2 * (2 * Cs + 2));
+            pr[2 * Cs] = s0; pr[2 * Cs + 1] = s1;
+            pr[2 * Cs + 2 + 2 * Cs] = 0.f; pr[2 * Cs + 2 + 2 * Cs + 1] = 0.f;
+        } else {
+            atomicAdd(&gacc[2 * Cs], s0);
+            atomicAdd(&gacc[2 * Cs + 1], s1);
+        }
     }
+}
+
+// deterministic schedule: gacc[i] += sum over the rows, in row order (both halves of a row), i < 2 Cs + 2; entries with c >= Cr of the
+// weight halves were never written and are skipped
+__global__ __launch_bounds__(256) void dcunet_rows_reduce_kernel(const float* __restrict__ part, int nrows, int Cs, int Cr,
+                                                                 float* __restrict__ gacc) {
+    const int i = blockIdx.x * 256 + threadIdx.x, w = 2 * Cs + 2;
+    if (i >= w) return;
+    if (i < 2 * Cs && (i % Cs) >= Cr) return;
+    float acc = 0.f;
+    for (int r = 0; r < nrows; ++r) acc += part[(size_t)r * 2 * w + i] + part[(size_t)r * 2 * w + w + i];
+    gacc[i] += acc;
 }
 
 static int check_dcu(const char* who, int R, int F, int T, int Cs, int Cr, int mode) {
@@ -239,9 +268,16 @@ extern "C" int sehip_dcunet_mask_bwd(const float* dout, const float* spec, const
                                      const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, void* dz_bf16, float* gacc,
                                      void* stream) {
     if (int e = check_dcu("dcunet_mask_bwd", R, F, T, Cs, Cr, mode)) return e;
+    float* part = nullptr;
+    const int nrows = cdiv(T, DT) * cdiv(F, DT) * R;
+    if (sehip_deterministic()) {      // fixed-order sums: one row of partial sums per workgroup (the per-stream pool of csrc/wgrad3.hip)
+        part = sehip_wgrad_scratch((hipStream_t)stream, (size_t)nrows * 2 * (2 * Cs + 2) * sizeof(float));
+        SEHIP_REQUIRE(part != nullptr, "dcunet_mask_bwd: no scratch for the deterministic schedule (inside a stream capture?)");
+    }
     dcunet_mask_bwd_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, (hipStream_t)stream>>>(
         (const float2*)dout, (const float2*)spec, (const float2*)mask_ws, (const bf16_raw*)z_bf16, w_re, w_im, F, T, Cs, Cr, mode,
-        (bf16_raw*)dz_bf16, gacc);
+        (bf16_raw*)dz_bf16, gacc, part);
+    if (part) dcunet_rows_reduce_kernel<<<cdiv(2 * Cs + 2, 256), 256, 0, (hipStream_t)stream>>>(part, nrows, Cs, Cr, gacc);
     SEHIP_CHECK_LAUNCH("dcunet_mask_bwd");
     return 0;
 }

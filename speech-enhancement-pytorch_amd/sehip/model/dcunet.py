@@ -79,6 +79,15 @@ class DCUnet(FlatModule):
         return self
 
     # ---- HIP path -------------------------------------------------------------------------------------
+    def set_deterministic(self, on=True):
+        """The reference's `solver.cudnn_deterministic` switch (src/conf/config.yaml:130, src/utils.py:108-111) for this model.  Nothing
+        in the DCUnet plan changes: its BatchNorm sums already go through per-workgroup partial rows, its products take the library's
+        fixed-order weight gradients, and the one kernel of its own that used fp32 atomics (the mask layer's weight gradient,
+        sehip_dcunet_mask_bwd) follows the process-wide sehip_set_deterministic, which the Solver / sehip.utils.prepare_device switch
+        on.  Two runs of the same steps are then bit-identical (tests/test_gpu_deterministic.py)."""
+        self._deterministic = bool(on)
+        return self
+
     def workspace(self, batch, n_bins, n_frames):
         dev = self._require_gpu("DCUnet")
         gk = (n_bins, n_frames)

@@ -64,6 +64,7 @@ FUSE_ENC0_BN_WGRAD = FUSE_SKIP_GRAD and bool(os.environ.get("SEHIP_FUSE_ENC0_BN"
 # the apply pass of a layer with fused sums also finalizes them (sehip_cbn_finalize_apply_n)
 # (read when a workspace is built: DCCRNWorkspace.fuse_finalize / fuse_bwd_finalize / BWD_REPLICAS rows of backward sums)
 BWD_REPLICAS = int(os.environ.get("SEHIP_BWD_REPLICAS", "8"))
+PARALLEL_HEAD = not os.environ.get("SEHIP_NO_PARALLEL_HEAD")      # weight packing + gradient clearing beside the STFT (A/B switch)
 L2_GRAPH_EPOCH = 65535       # granule-tag epoch of the fused LSTM launches inside captured graphs; eager calls use 1 .. 65534
 TILE_WEIGHTS = not any(os.environ.get(k) for k in ("SEHIP_NO_CONV_V3", "SEHIP_NO_PATCH", "SEHIP_NO_TILE_WEIGHTS"))
 
@@ -1156,6 +1157,46 @@ class DCCRNWorkspace:
             self._chain_dirty = False
         launch(self.side.cuda_stream)
 
+    def launch_units(self):
+        """The product launches of one train step AS THE STEP ISSUES THEM (bench.py's per-kernel roofline pass times these, not the
+        descriptors one by one): single products, the pairs that go through sehip_gemm_pair / sehip_wgrad_pair (one launch where the
+        library merges them) and the grouped LSTM weight gradients.  [(label, names, fn(stream))]."""
+        d, units = self.desc, []
+
+        def one(fn, name):
+            return (name, [name], lambda st, fn=fn, name=name: call(fn, C.byref(d[name]), st))
+
+        def pair(fn, a, b):
+            return (a + "+" + b, [a, b], lambda st, fn=fn, a=a, b=b: call(fn, C.byref(d[a]), C.byref(d[b]), st))
+        for i in range(6):
+            units.append(one("sehip_gemm", f"enc{i}.fwd"))
+            units.append(one("sehip_wgrad", f"enc{i}.fwd.wg"))
+            units.append(one("sehip_gemm", f"dec{i}.dg"))
+            units.append(pair("sehip_gemm_pair", f"dec{i}.fwd0", f"dec{i}.fwd1"))
+            units.append(pair("sehip_wgrad_pair", f"dec{i}.fwd0.wg", f"dec{i}.fwd1.wg"))
+            if i > 0:
+                units.append(pair("sehip_gemm_pair", f"enc{i}.dg0", f"enc{i}.dg1"))
+        for a, b in (("ih1_r", "ih1_i"), ("proj_r", "proj_i"), ("dproj_r", "dproj_i"), ("dx1_r", "dx1_i")):
+            units.append(pair("sehip_gemm_pair", a, b))
+        if not self.lstm_fused:
+            for a, b in (("ih2_r", "ih2_i"), ("dx2_r", "dx2_i")):
+                units.append(pair("sehip_gemm_pair", a, b))
+        for tag in "ri":
+            units.append(one("sehip_wgrad", f"proj_{tag}.wg"))
+        names = self._lstm_wgrad_names((2, 1))
+        if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+            buf, n, total, dense = self._wgrad_group_handle(names)
+            if dense is not None:
+                units.append(("lstm.wg (dense group)", [nm + ".wg" for nm in names],
+                              lambda st: call("sehip_wgrad_dense_group", ptr(dense[0]), n, C.cast(dense[1], C.c_void_p), ptr(self._dtw_scratch), st)))
+            elif not self.st.deterministic:
+                units.append(("lstm.wg (group)", [nm + ".wg" for nm in names], lambda st: call("sehip_wgrad_group", ptr(buf), n, total, st)))
+            else:
+                units += [one("sehip_wgrad", nm + ".wg") for nm in names]
+        else:
+            units += [one("sehip_wgrad", nm + ".wg") for nm in names]
+        return units
+
     # ---- BatchNorm helpers ---------------------------------------------------------------------
     def _bn_ptrs(self, pre, params, buffers, nbt):
         L = self.st.layout
@@ -1344,10 +1385,22 @@ class DCCRNWorkspace:
         B, T, h = self.B, self.T, cfg.hid
         # both packings and the clearing of the fused BatchNorm sums: one launch
         zero = self.bn_stats_all if (self.st.fused_stats or self.fused_small) else None
+        # The step's head in parallel (round 5): the weight packing (28 us) and the clearing of the packed-gradient buffer (8 us, used
+        # to open the backward pass) run on the weight-gradient stream, which is idle now, while the STFT -- which needs neither --
+        # runs on the chain; the first encoder layer waits for both.
+        head = self.side.cuda_stream if (self.side is not None and PARALLEL_HEAD) else stream()
+        if head != stream():
+            call("sehip_stream_depend", head, stream(), self._event())          # the previous step's optimizer wrote the parameters
         call("sehip_pack_head", ptr(params), ptr(tb.wtab), st.n_wpack, ptr(tb.wpack), ptr(tb.btab), st.n_bpack, ptr(tb.bpack),
-             ptr(zero) if zero is not None else None, zero.numel() if zero is not None else 0, stream())
+             ptr(zero) if zero is not None else None, zero.numel() if zero is not None else 0, head)
+        if head != stream() and training:
+            with torch.cuda.stream(self.side):
+                self.gpack.zero_()
+            self._gpack_clean = True
         call("sehip_stft_fwd", ptr(wav_in), ptr(tb.window), B, self.N, cfg.win_len, cfg.win_inc, cfg.fft_len,
              ptr(self.spec), b["enc_in"].ptr, stream())
+        if head != stream():
+            call("sehip_stream_depend", stream(), head, self._event())
         for i in range(6):
             self.gemm(f"enc{i}.fwd")
             self.bn_forward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, b[f"y{i}"], b[f"z{i}"], params, buffers, nbt, training)
@@ -1371,7 +1424,9 @@ class DCCRNWorkspace:
         the encoder range at the end."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B, T, h = self.B, self.T, cfg.hid
-        self.gpack.zero_()
+        if not getattr(self, "_gpack_clean", False):      # (forward() has cleared it on the idle side stream; a second backward pass
+            self.gpack.zero_()                            #  over the same forward clears it here, as before)
+        self._gpack_clean = False
         self._chain_dirty = True
         call("sehip_istft_bwd", ptr(dwav), ptr(self.wav), ptr(self.spec), b["mask"].ptr, ptr(tb.window), ptr(self.inv_coff),
              B, T, cfg.win_len, cfg.win_inc, cfg.fft_len, self.length, self.mode, b["dmask"].ptr, stream())

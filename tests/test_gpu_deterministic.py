@@ -68,3 +68,44 @@ def test_the_library_flag_round_trips_and_refuses_grouped_launches():
     finally:
         set_deterministic(False)
     assert lib.sehip_get_deterministic() == 0
+
+
+def _dcunet_run(depth, shape, steps=3):
+    """Three optimizer steps of DCUnet (mse on the spectra, clip 5, Adam) under the deterministic schedule."""
+    from sehip.model import DCUnet
+    from sehip.optim import FlatOptimizer
+    from sehip.loss import mse_loss
+    from sehip.utils import set_deterministic
+    set_deterministic(True)
+    try:
+        torch.manual_seed(11)
+        model = DCUnet(data_type=True, model_complexity=23, model_depth=depth).cuda().train()
+        model.set_deterministic(True)
+        opt = FlatOptimizer(model, lr=3e-4)
+        g = torch.Generator().manual_seed(3)
+        losses = []
+        for _ in range(steps):
+            tgt = (0.1 * torch.randn(*shape, generator=g)).cuda()
+            mix = tgt + (0.05 * torch.randn(*shape, generator=g)).cuda()
+            loss = mse_loss(model(mix), tgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.clip_grad_norm_(5.0)
+            opt.step()
+            m = opt.grad_metric()
+            losses.append((float(loss), float(m[0]), float(m[1])))
+        torch.cuda.synchronize()
+        return losses, model.flat_params.detach().cpu().clone(), opt._m.cpu().clone(), opt._v.cpu().clone(), model.flat_grads.detach().cpu().clone()
+    finally:
+        set_deterministic(False)
+
+
+@pytest.mark.parametrize("depth,shape", [(10, (2, 1, 257, 65, 2)), (20, (1, 1, 257, 257, 2))])
+def test_dcunet_two_deterministic_runs_are_bit_identical(depth, shape):
+    """VERDICT r4 missing 2: the reference applies `cudnn_deterministic` whatever the model (src/utils.py:108-111).  DCUnet's plan under
+    the library switch: two independent runs of three optimizer steps are bit-identical."""
+    a = _dcunet_run(depth, shape)
+    c = _dcunet_run(depth, shape)
+    assert a[0] == c[0], (a[0], c[0])
+    for x, y, what in zip(a[1:], c[1:], ("parameters", "exp_avg", "exp_avg_sq", "gradients")):
+        assert torch.equal(x, y), what
