@@ -31,7 +31,11 @@ class _TasNetFunction(torch.autograd.Function):
         if ctx.generation != ctx.ws.generation or ctx.ws.closed:
             raise SehipError("ConvTasNet.backward: the workspace of this forward was overwritten by a later forward of the same "
                              "shape (or evicted); run backward before the next forward of that shape")
-        ctx.model._run_backward(ctx.ws, grad_out)
+        # (autograd runs this in its device thread: without a scope of its own every library call of the backward pass looks
+        #  torch's current stream up again -- ~60 look-ups of ~7 us per step: round 5, tools/host_profile2.py)
+        from .._lib import stream_scope
+        with stream_scope():
+            ctx.model._run_backward(ctx.ws, grad_out)
         return None, None, None
 
 
