@@ -129,3 +129,61 @@ def test_forced_handoff_timeout_sets_the_guard_and_falls_back(tmp_path):
     torch.cuda.synchronize()
     assert np.isfinite(float(loss)) and not torch.equal(model.flat_params.detach(), p0)
     assert int(solver.optimizer._step_dev.item()) == 1
+
+
+def test_eager_forward_after_a_graph_replay_does_not_accept_the_replays_granules():
+    """a hipGraph freezes the granule-tag epoch it was captured with and only the graph clears the granule arrays; an
+    eager forward on the same workspace afterwards used to draw the SAME epoch (the counter did not advance under capture), so
+    layer 2 accepted the replay's stale h1 granules at once and ran ahead of layer 1 -- silently wrong.  Captured launches now own
+    epoch 65535 and eager calls cycle through 1 .. 65534: the eager forward after a replay must equal the unfused launches."""
+    from sehip.model import DCCRN
+    from sehip import plan
+    dev = torch.device("cuda:0")
+    B, N = 3, 6000
+    g = torch.Generator().manual_seed(5)
+    x1 = (0.1 * torch.randn(B, 1, N, generator=g)).to(dev)
+    x2 = (0.1 * torch.randn(B, 1, N, generator=g)).to(dev)
+
+    def build(fuse):
+        old = os.environ.get("SEHIP_NO_LSTM_FUSE")
+        if fuse:
+            os.environ.pop("SEHIP_NO_LSTM_FUSE", None)
+        else:
+            os.environ["SEHIP_NO_LSTM_FUSE"] = "1"
+        try:
+            torch.manual_seed(3)
+            m = DCCRN(rnn_units=128, kernel_num=[16, 16, 32, 32, 64, 64], length=N).to(dev).eval()
+            ws = m.workspace(B, N)
+            assert ws.lstm_fused == bool(fuse)
+            return m, ws
+        finally:
+            if old is None:
+                os.environ.pop("SEHIP_NO_LSTM_FUSE", None)
+            else:
+                os.environ["SEHIP_NO_LSTM_FUSE"] = old
+    ref_model, _ = build(False)
+    with torch.no_grad():
+        ref1, ref2 = ref_model(x1).clone(), ref_model(x2).clone()
+    model, ws = build(True)
+    ws.pinned = True
+    static_x = x1.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad():
+        with torch.cuda.graph(graph):            # captured on the FRESH workspace: no eager call has advanced its epoch yet
+            y_static = model(static_x)
+    assert ws.l2_epoch == 0
+    graph.replay()
+    torch.cuda.synchronize()
+    assert rel_err(y_static, ref1) < 2e-2
+    with torch.no_grad():
+        y_eager = model(x2).clone()              # eager, same workspace, a DIFFERENT input: stale granules would show
+    torch.cuda.synchronize()
+    assert ws.l2_epoch == 1 and plan.L2_GRAPH_EPOCH == 65535 and int(ws.l2_sync[0]) == 0
+    assert rel_err(y_eager, ref2) < 2e-2, rel_err(y_eager, ref2)
+    graph.replay()                               # and the graph still works after the eager call
+    torch.cuda.synchronize()
+    assert rel_err(y_static, ref1) < 2e-2
+    # the eager epochs never reach the graphs' one
+    ws.l2_epoch = 65533
+    assert ws._l2_next_epoch() == 65534 and ws._l2_next_epoch() == 1
