@@ -31,7 +31,6 @@ typedef __attribute__((address_space(3))) s16x4 c3_lds_s16x4;
 // register computed once per workgroup, what changes per K step / channel chunk is the scalar offset (no vector arithmetic in
 // the loop), and padding pieces carry an offset beyond num_records -- the hardware range check returns zeros without a read.
 #define C3_OOB 0x7ffffff0u
-#define C3_RECORDS 0x7fff0000u
 
 #define C3_NSLOT 4
 #ifdef C3_STAMPS      // tools/build_variant.py ... -DC3_STAMPS: per-wave cycle stamps (tools/c3_stamps.py reads them); never in the product build
@@ -201,8 +200,12 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
     const int tmin0 = min(d.cv_toff[0][0], d.cv_toff[0][1]), tmin1 = min(d.cv_toff[1][0], d.cv_toff[1][1]);
     const bf16_raw* s0p = reinterpret_cast<const bf16_raw*>(d.src[0].ptr);
     const bf16_raw* s1p = reinterpret_cast<const bf16_raw*>(d.src[1].ptr);
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(s0p), 0, C3_RECORDS, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(C1 ? s1p : s0p), 0, C3_RECORDS, 0x00020000);
+    // num_records = the tensor's own size ([B][T][F][C] bf16, below 2^30 bytes: c3_qualifies): an offset that leaves the tensor
+    // reads zeros like the padding marker does, not a neighbour's bytes
+    const unsigned rec0 = 2u * (unsigned)B * (unsigned)d.src[0].T * (unsigned)d.src[0].F * (unsigned)C0;
+    const unsigned rec1 = C1 ? 2u * (unsigned)B * (unsigned)d.src[1].T * (unsigned)d.src[1].F * (unsigned)C1 : rec0;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(s0p), 0, rec0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(C1 ? s1p : s0p), 0, rec1, 0x00020000);
 
     // ---- this wave's 64 output columns: one destination? (ntab entries fetched now, used behind the barrier below: the epilogue
     // does not wait for anything but its own stores)
@@ -271,7 +274,7 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
     // (32-byte pieces of 5 KB rows: four times the L2 -> L1 line traffic)
     const bool tiled = d.w_tiled != 0;
     const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W) + (size_t)n0 * d.K;     // tile order: the n-tile's K * 128 elements
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(Wb), 0, C3_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(Wb), 0, 2u * (unsigned)(d.Npad - n0) * (unsigned)d.K, 0x00020000);
     // piece i = 256 u + 64 wave + lane of a tile: tap plane i / (2 BN), row (i / 2) % BN, half i & 1
     // (two named registers, not an array: hipcc's host pass silently dropped the whole kernel when a lambda passed an element of a
     //  captured array to the buffer-load builtin -- no diagnostic, undefined kernel symbol at load time)
@@ -822,7 +825,7 @@ static bool c3_qualifies(const sehip_gemm_desc& d, int* Bout) {
             if (d.cv_toff[s][kt] < -1 || d.cv_toff[s][kt] > 1) return false;
         if (abs(d.cv_toff[s][0] - d.cv_toff[s][1]) > 1) return false;
         if (d.src[s].thi > d.TT + 1) return false;
-        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 30) - (1L << 20)) return false;      // byte offsets below C3_RECORDS
+        if ((long)B * d.src[s].T * d.src[s].F * d.src[s].C >= (1L << 30) - (1L << 20)) return false;      // byte offsets (and num_records) below the padding marker
     }
     for (int s = 0; s < 2; ++s)
         if (d.dst[s].ptr && (long)B * d.dst[s].T * d.dst[s].F * d.dst[s].C >= (1L << 31)) return false;
