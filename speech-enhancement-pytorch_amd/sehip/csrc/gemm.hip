@@ -262,16 +262,27 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
     const bf16_raw* wrow[NRW];
 #pragma unroll
     for (int i = 0; i < NRW; ++i) wrow[i] = Wb + (size_t)(n0 + min(r0 + 32 * i, BN - 1)) * d.K + kc * 8;
+    // (two tiles of at most four pieces: returned by value as ONE six-piece tile, the weights of the 192-column instantiation went
+    //  through scratch memory inside the K loop and the kernel ran three times slower)
+    constexpr int NRW0 = NRW < 4 ? NRW : 4, NRW1 = NRW > 4 ? NRW - 4 : 0;
     auto fetch_w = [&](int kt) {
-        RegTile<NRW> t;
+        RegTile<NRW0> t;
 #pragma unroll
-        for (int i = 0; i < NRW; ++i) t.v[i] = *reinterpret_cast<const uint4*>(wrow[i] + kt * 64);   // rows >= BN: a duplicate, never stored
+        for (int i = 0; i < NRW0; ++i) t.v[i] = *reinterpret_cast<const uint4*>(wrow[i] + kt * 64);   // rows >= BN: a duplicate, never stored
+        return t;
+    };
+    auto fetch_w1 = [&](int kt) {
+        RegTile<(NRW1 > 0 ? NRW1 : 1)> t;
+#pragma unroll
+        for (int i = 0; i < NRW1; ++i) t.v[i] = *reinterpret_cast<const uint4*>(wrow[4 + i] + kt * 64);
         return t;
     };
 
     sehip_kchunk e1 = d.ktab[min(8 + kc, (d.K >> 3) - 1)];          // entry of K step 1
     RegTile<NRA> ra = gather(d.ktab[kc]);
-    RegTile<NRW> rw = fetch_w(0);
+    RegTile<NRW0> rw = fetch_w(0);
+    RegTile<(NRW1 > 0 ? NRW1 : 1)> rw1;
+    if (NRW1 > 0) rw1 = fetch_w1(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
@@ -279,14 +290,20 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
             sA[r * 8 + (kc ^ (r & 7))] = ra.v[i];
         }
 #pragma unroll
-        for (int i = 0; i < NRW; ++i) {
+        for (int i = 0; i < NRW0; ++i) {
             const int r = r0 + 32 * i;
             if (r < BN) sW[r * 8 + (kc ^ (r & 7))] = rw.v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NRW1; ++i) {
+            const int r = r0 + 32 * (4 + i);
+            if (r < BN) sW[r * 8 + (kc ^ (r & 7))] = rw1.v[i];
         }
         __syncthreads();
         if (kt + 1 < nk) {  // next K tile in flight behind this tile's MFMAs
             ra = gather(e1);
             rw = fetch_w(kt + 1);
+            if (NRW1 > 0) rw1 = fetch_w1(kt + 1);
             e1 = d.ktab[min((kt + 2) * 8 + kc, (d.K >> 3) - 1)];
         }
 #pragma unroll
@@ -1600,8 +1617,11 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         gemm_kernel<64, 64, 2, 2><<<cdiv(d->M, 64), 256, 0, st>>>(*d);
     } else if (d->Npad == 64) {
         gemm_kernel<64, 256, 1, 4><<<cdiv(d->M, 256), 256, 0, st>>>(*d);
+    } else if (d->Npad == 192) {   // 128 + 64 output columns (DCUnet's last decoder input gradient: decoder input | skip): one 192-wide tile
+        sehip_note_kernel("gemm_kernel<192, 128, 2, 2>");
+        gemm_kernel<192, 128, 2, 2><<<cdiv(d->M, 128), 256, 0, st>>>(*d);
     } else {
-        SEHIP_REQUIRE(d->Npad % 128 == 0, "gemm: Npad=%d must be 16, 32, 64 or a multiple of 128", d->Npad);
+        SEHIP_REQUIRE(d->Npad % 128 == 0, "gemm: Npad=%d must be 16, 32, 64, 192 or a multiple of 128", d->Npad);
         static const bool no64 = getenv("SEHIP_NO_BM64") != nullptr;
         if (!no64 && (long)cdiv(d->M, 128) * (d->Npad / 128) < 512) {  // under one round of 2 workgroups per CU: halve the tile
             sehip_note_kernel("gemm_kernel<128, 64, 2, 2>");

@@ -308,12 +308,12 @@ def bind_chunk_table(src_tab, out_tab, kt_off, nchunks, geometry):
 class GemmSpec:
     """Batch-independent description of one product (see sehip_gemm_desc)."""
 
-    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd", conv=None, res=None):
+    def __init__(self, name, rows, widx, wneg, n, bias_pairs, tt, j, fmul, srcs, dsts, ntab=None, kind="fwd", conv=None, res=None, npad=None):
         self.name = name
         self.conv = conv  # (nf, fadd, [[toff(s0,kt0), toff(s0,kt1)], [toff(s1,kt0), toff(s1,kt1)]]) or None
         self.ktab, self.K = pad_ktab(rows)
         self.N = n
-        self.Npad = npad_of(n)
+        self.Npad = npad if npad is not None else npad_of(n)      # (npad: a width the generic kernel has a tile for, e.g. 192)
         k0 = widx.shape[1]
         wi = np.full((self.Npad, self.K), -1, dtype=np.int64)
         wn = np.zeros((self.Npad, self.K), dtype=np.int64)

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import call, ptr, stream, SehipError
-from .plan import (Arena, CGemmDesc, GemmSpec, ParamLayout, bind_chunk_table, dense_ntab, enc_entry, round_up, BF16)
+from .plan import (Arena, CGemmDesc, GemmSpec, ParamLayout, bind_chunk_table, dense_ntab, enc_entry, npad_of, round_up, BF16)
 
 
 def stored_channels(c):
@@ -332,8 +332,10 @@ class DCUNetPlan:
             ntot = sum(2 * s[2] for s in srcs)
             nt = np.concatenate([dense_ntab(2 * s[2], 2 * s[2], q, 0) for q, s in enumerate(srcs)])
             dsts = [(f"dze{n - 1}", 0, 1, 0)] if j == 0 else [(f"dzd{j - 1}", 0, 1, 0), (f"dskip{n - 1 - j}", 0, 1, 0)]
+            # 128 + 64 columns (the last decoder of DCUnet-10: decoder input | skip): one 192-wide tile instead of two 128-wide ones
+            npad = 192 if ntot == 192 and "SEHIP_DCUNET_NO_N192" not in os.environ else npad_of(ntot)
             sp = GemmSpec(f"dec{j}.dg", rows, np.concatenate(cols_i, 1), np.concatenate(cols_n, 1), ntot, None, Tin, Fin, s_f,
-                          [(f"dyd{j}", "all")], dsts, ntab=self._pad_ntab(nt, ntot), kind="dgrad")
+                          [(f"dyd{j}", "all")], dsts, ntab=self._pad_ntab(nt, npad), kind="dgrad", npad=npad)
             sp.tmul, sp.dst_tmul = s_t, [1] * len(dsts)
             self.specs[sp.name] = sp
 
@@ -369,9 +371,7 @@ class DCUNetPlan:
         self.utab = self._build_unpack_table()
 
     @staticmethod
-    def _pad_ntab(nt, ntot):
-        from .plan import npad_of
-        npad = npad_of(ntot)
+    def _pad_ntab(nt, npad):
         if npad // 4 == nt.shape[0]:
             return nt
         out = np.zeros((npad // 4, 4), dtype=np.int32)
