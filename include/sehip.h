@@ -427,6 +427,21 @@ int sehip_dcunet_mask_fwd(const void* z_bf16, const float* w_re, const float* w_
                           const float* spec, int R, int F, int T, int Cs, int Cr, int mode, float* mask_ws, float* out, void* stream);
 int sehip_dcunet_mask_bwd(const float* dout, const float* spec, const float* mask_ws, const void* z_bf16, const float* w_re,
                           const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, void* dz_bf16, float* gacc, void* stream);
+/*      The fused tail (the last decoder's BatchNorm + LeakyReLU, src/model/dcunet.py:40-50 / :374-386, never stored: at B = 64 its
+ *      output and its gradient are 1.08 GB each):
+ *      mask_fwd_bn: mask_fwd from the last decoder's PRE-BatchNorm output y and that BatchNorm's coefficient records `coef`
+ *                  ([2*Cs][4] of sehip_rbn_finalize[_s]); BatchNorm + LeakyReLU are applied to the loaded values.
+ *      tail_bwd:   backward of mask + tanh + 1x1 conv + that BatchNorm + LeakyReLU: d out -> dy [R][T][F][2*Cs] bf16 (gradient of
+ *                  the pre-BatchNorm output), gw_* / gb_* [Cr] (BatchNorm weight / bias gradients, overwritten), bcoef [2*Cs][4]
+ *                  (work record as in sehip_rbn_bwd_finalize), gacc as in mask_bwd.  mask_ws: in tanh(linear), out d linear.
+ *                  scratch: sehip_dcunet_tail_scratch_floats floats.  All sums are formed in a fixed order. */
+int sehip_dcunet_mask_fwd_bn(const void* y_bf16, const float* coef, const float* w_re, const float* w_im, const float* b_re,
+                             const float* b_im, const float* spec, int R, int F, int T, int Cs, int Cr, int mode, float* mask_ws,
+                             float* out, void* stream);
+long sehip_dcunet_tail_scratch_floats(int R, int F, int T, int Cs);
+int sehip_dcunet_tail_bwd(const float* dout, const float* spec, float* mask_ws, const void* y_bf16, const float* coef, const float* w_re,
+                          const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, float* scratch, float* gw_re, float* gb_re,
+                          float* gw_im, float* gb_im, float* bcoef, void* dy_bf16, float* gacc, void* stream);
 
 /* ---- ConvTasNet, everything that is not a 1x1 convolution (those are sehip_gemm products): src/model/conv_tasnet.py:34-487 with
  *      the shipped options (skip=False, gLN, non-causal, relu mask).  Activations are channels-last bf16 [M][K][C] (M utterances,

@@ -115,6 +115,9 @@ _PROTOS = {
     "sehip_dcunet_pack_input": [P, I, I, I, P, P],
     "sehip_dcunet_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     "sehip_dcunet_mask_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
+    "sehip_dcunet_mask_fwd_bn": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
+    "sehip_dcunet_tail_scratch_floats": [I, I, I, I],
+    "sehip_dcunet_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "sehip_ctn_encoder_fwd": [P, P, P, P, I, I, I, I, I, P, P, P],
     "sehip_ctn_encoder_bwd": [P, P, P, P, P, I, I, I, I, I, P, P, P],
     "sehip_ctn_codec_bwd_scratch_floats": [I, I, I, I, I],
@@ -149,7 +152,7 @@ _PROTOS = {
     "sehip_lstm_fwd_chunk": [P, P, P, I, I, I, I, I, P, P, P, P],
     "sehip_lstm_bwd_chunk": [P, P, P, P, P, I, I, I, I, I, P, P, P, P],
 }
-_RESTYPE = {"sehip_lstm2_gran_bytes": C.c_long, "sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_wgrad_dense_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
+_RESTYPE = {"sehip_lstm2_gran_bytes": C.c_long, "sehip_dmx_attn_bwd_scratch_floats": C.c_long, "sehip_ctn_codec_bwd_scratch_floats": C.c_long, "sehip_ctn_gln_bwd_scratch_floats": C.c_long, "sehip_wgrad_group_bytes": C.c_long, "sehip_wgrad_dense_group_bytes": C.c_long, "sehip_cbn_scratch_floats": C.c_long, "sehip_rbn_scratch_floats": C.c_long, "sehip_dcunet_tail_scratch_floats": C.c_long, "sehip_event_create": C.c_void_p, "sehip_stream_create": C.c_void_p}
 
 
 def lib():

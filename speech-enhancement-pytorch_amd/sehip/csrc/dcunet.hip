@@ -12,6 +12,7 @@
 #include "common.h"
 float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
 #include "mask.h"
+#include "rbn.h"
 
 #define DT 32   // tile edge (frames and bins)
 #define DP 33   // LDS pitch of a tile row (float2 elements)
@@ -69,13 +70,22 @@ __global__ __launch_bounds__(256) void dcunet_mask_fwd_kernel(const bf16_raw* __
                                                               const float* __restrict__ w_im, const float* __restrict__ b_re,
                                                               const float* __restrict__ b_im, const float2* __restrict__ spec,
                                                               int F, int T, int Cs, int Cr, int mode, float2* __restrict__ mask_ws,
-                                                              float2* __restrict__ out) {
+                                                              float2* __restrict__ out, const float4* __restrict__ coef) {
+    // coef != NULL (fused tail): z is the last decoder's PRE-BatchNorm output and coef its per-channel (scale, shift, mean, rstd) of
+    // csrc/rbn.hip: BatchNorm + LeakyReLU are applied to the loaded piece, the activation tensor is never written
     __shared__ float2 tile[DT][DP];   // tanh(linear) per position, [frame][bin]
     const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
     const int C = 2 * Cs, nq = C >> 3, ppi = 64 / nq;   // positions per wave instruction
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane % nq, pl = lane / nq;
     const LinCoef lc = lin_coef(w_re, w_im, q, nq, Cs, Cr);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 k = coef ? coef[q * 8 + j] : make_float4(1.f, 0.f, 0.f, 0.f);
+        sc[j] = k.x; sh[j] = k.y;
+    }
+    const bool bn = coef != nullptr;
     const float bre = b_re[0] - b_im[0], bim = b_re[0] + b_im[0];   // each of the four real convs carries its own bias
     const bf16_raw* zb = z + (size_t)r * T * F * C;
     const int fw = min(DT, F - f0);            // valid bins of this tile
@@ -88,6 +98,10 @@ __global__ __launch_bounds__(256) void dcunet_mask_fwd_kernel(const bf16_raw* __
             tl = p / fw; fl = p - tl * fw;
             float v[8];
             unpack8f(*reinterpret_cast<const uint4*>(zb + ((size_t)(t0 + tl) * F + f0 + fl) * C + q * 8), v);
+            if (bn) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float o = sc[j] * v[j] + sh[j]; v[j] = o > 0.f ? o : RBN_SLOPE * o; }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sre += lc.wa[j] * v[j]; sim += lc.wb[j] * v[j]; }
         }
@@ -240,6 +254,186 @@ __global__ __launch_bounds__(256) void dcunet_rows_reduce_kernel(const float* __
     gacc[i] += acc;
 }
 
+// ---- the fused tail of the backward pass --------------------------------------------------------------------------------------
+// d(last decoder output) = the 1x1 convolution's transpose applied to d linear: TWO values per position spread over 2 Cs
+// channels.  The unfused path writes that 1.08 GB tensor (B = 64), BatchNorm's backward reads it twice with the pre-activation
+// and writes the gradient.  Here d linear stays the only thing stored per position ([R][T][F] float2, over the mask workspace),
+// and the two BatchNorm passes rebuild the row from it:
+//   dlin     tile kernel over the spectra: d enhanced -> d linear (through mask and tanh), [frame][bin] order; bias partials
+//   reduce   rows of y: per channel sum g, sum g xh (BatchNorm), sum g_re z, sum g_im z (the 1x1 conv's weights)
+//   finalize per channel: BatchNorm weight / bias gradients + its backward coefficients, the 1x1 conv's weight and bias gradients
+//   apply    rows of y: dy = w rstd (g - mean g - xh mean(g xh))
+// y is read twice, dy written once: 3.3 GB instead of 7.6 GB; nothing is accumulated with atomics in an order that varies (the
+// two addends per 1x1 weight commute), so the deterministic schedule runs the same kernels.
+__global__ __launch_bounds__(256) void dcunet_dlin_kernel(const float2* __restrict__ dout, const float2* __restrict__ spec,
+                                                          float2* __restrict__ mask_ws, int F, int T, int mode,
+                                                          float* __restrict__ bpart) {
+    __shared__ float2 tile[DT][DP];
+    __shared__ float redb[4][2];
+    const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float2* mw = mask_ws + (size_t)r * T * F;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + ty + 8 * k, f = f0 + tx;
+        if (t < T && f < F) tile[ty + 8 * k][tx] = mw[(size_t)t * F + f];
+    }
+    __syncthreads();
+    const float2* s = spec + (size_t)r * F * T;
+    const float2* go = dout + (size_t)r * F * T;
+    float2 gl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = f0 + ty + 8 * k, t = t0 + tx;
+        gl[k] = make_float2(0.f, 0.f);
+        if (t < T && f < F) {
+            const float2 x = s[(size_t)f * T + t], g = go[(size_t)f * T + t], m = tile[tx][ty + 8 * k];
+            float gmr, gmi;
+            mask_grad(mode, x.x, x.y, m.x, m.y, g.x, g.y, gmr, gmi);
+            gl[k] = make_float2(gmr * (1.f - m.x * m.x), gmi * (1.f - m.y * m.y));   // through the tanh
+        }
+    }
+    float sbr = 0.f, sbi = 0.f;   // bias gradients: d b_re = sum (g_re + g_im), d b_im = sum (-g_re + g_im)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sbr += gl[k].x + gl[k].y; sbi += gl[k].y - gl[k].x; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[tx][ty + 8 * k] = gl[k];
+    sbr = wave_sum(sbr); sbi = wave_sum(sbi);
+    if ((threadIdx.x & 63) == 0) { redb[threadIdx.x >> 6][0] = sbr; redb[threadIdx.x >> 6][1] = sbi; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + ty + 8 * k, f = f0 + tx;
+        if (t < T && f < F) mw[(size_t)t * F + f] = tile[ty + 8 * k][tx];
+    }
+    if (threadIdx.x == 0) {
+        float* pr = bpart + 2 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        pr[0] = redb[0][0] + redb[1][0] + redb[2][0] + redb[3][0];
+        pr[1] = redb[0][1] + redb[1][1] + redb[2][1] + redb[3][1];
+    }
+}
+
+__global__ __launch_bounds__(256) void dcunet_tail_reduce_kernel(const float2* __restrict__ dlin, const bf16_raw* __restrict__ y,
+                                                                 const float4* __restrict__ coef, const float* __restrict__ w_re,
+                                                                 const float* __restrict__ w_im, long rows, int Cs, int Cr,
+                                                                 float* __restrict__ part) {
+    __shared__ float lds[4 * 4 * 8 * 32];        // [4 waves][NS * 8][nq <= 32]
+    const int C = 2 * Cs, nq = C >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    const LinCoef lc = lin_coef(w_re, w_im, q, nq, Cs, Cr);
+    float4 k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = coef[q * 8 + j];
+    float s[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[a][j] = 0.f;
+    const long stride = (long)gridDim.x * rpb;
+    for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 4 * stride) {
+        uint4 uy[4];
+        float2 g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long r = r0 + t * stride;
+            uy[t] = make_uint4(0u, 0u, 0u, 0u); g[t] = make_float2(0.f, 0.f);
+            if (r < rows) { uy[t] = *reinterpret_cast<const uint4*>(y + r * C + q * 8); g[t] = dlin[r]; }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const RChunk8 a = r_unpack8(uy[t]);       // rows beyond the end: g == 0 contributes nothing
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float o = k[j].x * a.v[j] + k[j].y;
+                const bool pos = o > 0.f;
+                const float z = pos ? o : RBN_SLOPE * o;
+                const float dzv = g[t].x * lc.wa[j] + g[t].y * lc.wb[j];
+                const float gg = pos ? dzv : RBN_SLOPE * dzv;
+                s[0][j] += gg;
+                s[1][j] += gg * (a.v[j] - k[j].z) * k[j].w;
+                s[2][j] += g[t].x * z;
+                s[3][j] += g[t].y * z;
+            }
+        }
+    }
+    rbn_block_partials<4>(s, nq, C, part, lds);
+}
+
+__global__ void dcunet_tail_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ bpart, int nbp,
+                                            const float4* __restrict__ coef, long rows, int Cs, int Cr, float* __restrict__ gw_re,
+                                            float* __restrict__ gb_re, float* __restrict__ gw_im, float* __restrict__ gb_im,
+                                            float4* __restrict__ bcoef, float* __restrict__ gacc) {
+    const int c = blockIdx.x, C = 2 * Cs;
+    const int half = c / Cs, i = c - half * Cs;
+    if (c == 0) {        // the 1x1 conv's two bias gradients: the tile kernel's partials, in order
+        double b0 = 0.0, b1 = 0.0;
+        for (int r = threadIdx.x; r < nbp; r += 64) { b0 += (double)bpart[2 * r]; b1 += (double)bpart[2 * r + 1]; }
+        b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
+        if (threadIdx.x == 0) { gacc[2 * Cs] += (float)b0; gacc[2 * Cs + 1] += (float)b1; }
+    }
+    if (i >= Cr) {
+        if (threadIdx.x == 0) bcoef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 k = coef[c];
+    double a[4];
+    rbn_wave_reduce<4>(part, nblk, C, c, a);
+    if (threadIdx.x != 0) return;
+    (half ? gb_im : gb_re)[i] = (float)a[0];
+    (half ? gw_im : gw_re)[i] = (float)a[1];
+    const double n = (double)rows;
+    bcoef[c] = make_float4(k.x, (float)(a[0] / n), (float)(a[1] / n), 0.f);
+    // real-part channel: d wre += sum g_re zr, d wim += sum g_im zr; imaginary-part channel: d wre += sum g_im zi, d wim -= sum g_re zi
+    // (two addends per weight, onto the caller's zero: the order does not matter)
+    atomicAdd(&gacc[i], half ? (float)a[3] : (float)a[2]);
+    atomicAdd(&gacc[Cs + i], half ? -(float)a[2] : (float)a[3]);
+}
+
+__global__ __launch_bounds__(256) void dcunet_tail_apply_kernel(const float2* __restrict__ dlin, const bf16_raw* __restrict__ y,
+                                                                const float4* __restrict__ coef, const float4* __restrict__ bcoef,
+                                                                const float* __restrict__ w_re, const float* __restrict__ w_im,
+                                                                long rows, int Cs, int Cr, bf16_raw* __restrict__ dy) {
+    const int C = 2 * Cs, nq = C >> 3;
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
+    const LinCoef lc = lin_coef(w_re, w_im, q, nq, Cs, Cr);
+    float4 k[8];
+    float ka[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        k[j] = coef[q * 8 + j];
+        const float4 kb = bcoef[q * 8 + j];
+        ka[j] = kb.x; k1[j] = kb.y; k2[j] = kb.z;
+    }
+    const long stride = (long)gridDim.x * rpb;
+    for (long r0 = (long)blockIdx.x * rpb + rl; r0 < rows; r0 += 4 * stride) {
+        uint4 uy[4];
+        float2 g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long r = r0 + t * stride;
+            uy[t] = make_uint4(0u, 0u, 0u, 0u); g[t] = make_float2(0.f, 0.f);
+            if (r < rows) { uy[t] = *reinterpret_cast<const uint4*>(y + r * C + q * 8); g[t] = dlin[r]; }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long r = r0 + t * stride;
+            if (r >= rows) continue;
+            const RChunk8 a = r_unpack8(uy[t]);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = k[j].x * a.v[j] + k[j].y;
+                const float dzv = g[t].x * lc.wa[j] + g[t].y * lc.wb[j];
+                const float gg = v > 0.f ? dzv : RBN_SLOPE * dzv;
+                const float xh = (a.v[j] - k[j].z) * k[j].w;
+                o[j] = ka[j] * (gg - k1[j] - xh * k2[j]);
+            }
+            *reinterpret_cast<uint4*>(dy + r * C + q * 8) = r_pack8(o);
+        }
+    }
+}
+
 static int check_dcu(const char* who, int R, int F, int T, int Cs, int Cr, int mode) {
     SEHIP_REQUIRE(R > 0 && F > 0 && T > 0, "%s: empty input", who);
     SEHIP_REQUIRE(Cs >= 8 && Cs <= 64 && (Cs & (Cs - 1)) == 0 && Cr >= 1 && Cr <= Cs, "%s: bad channel counts Cs=%d Cr=%d", who, Cs, Cr);
@@ -259,8 +453,52 @@ extern "C" int sehip_dcunet_mask_fwd(const void* z_bf16, const float* w_re, cons
                                      void* stream) {
     if (int e = check_dcu("dcunet_mask_fwd", R, F, T, Cs, Cr, mode)) return e;
     dcunet_mask_fwd_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, (hipStream_t)stream>>>(
-        (const bf16_raw*)z_bf16, w_re, w_im, b_re, b_im, (const float2*)spec, F, T, Cs, Cr, mode, (float2*)mask_ws, (float2*)out);
+        (const bf16_raw*)z_bf16, w_re, w_im, b_re, b_im, (const float2*)spec, F, T, Cs, Cr, mode, (float2*)mask_ws, (float2*)out, nullptr);
     SEHIP_CHECK_LAUNCH("dcunet_mask_fwd");
+    return 0;
+}
+
+// the same from the last decoder's PRE-BatchNorm output y and that BatchNorm's coefficient records (sehip_rbn_finalize[_s]): the
+// BatchNorm + LeakyReLU output is never stored (src/model/dcunet.py:40-50 decoder tail + :93-95, :131-159)
+extern "C" int sehip_dcunet_mask_fwd_bn(const void* y_bf16, const float* coef, const float* w_re, const float* w_im, const float* b_re,
+                                        const float* b_im, const float* spec, int R, int F, int T, int Cs, int Cr, int mode,
+                                        float* mask_ws, float* out, void* stream) {
+    if (int e = check_dcu("dcunet_mask_fwd_bn", R, F, T, Cs, Cr, mode)) return e;
+    SEHIP_REQUIRE(coef != nullptr, "dcunet_mask_fwd_bn: missing BatchNorm coefficients");
+    dcunet_mask_fwd_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_raw*)y_bf16, w_re, w_im, b_re, b_im, (const float2*)spec, F, T, Cs, Cr, mode, (float2*)mask_ws, (float2*)out,
+        (const float4*)coef);
+    SEHIP_CHECK_LAUNCH("dcunet_mask_fwd_bn");
+    return 0;
+}
+
+// scratch of sehip_dcunet_tail_bwd (floats): [blocks][4][2 Cs] partial sums + [tiles][2] bias partials
+extern "C" long sehip_dcunet_tail_scratch_floats(int R, int F, int T, int Cs) {
+    const long rows = (long)R * T * F;
+    return (long)rbn_stat_blocks(rows, 2 * Cs) * 4L * 2 * Cs + 2L * cdiv(T, DT) * cdiv(F, DT) * R;
+}
+
+// backward of mask + tanh + 1x1 conv + the last decoder's BatchNorm + LeakyReLU in one entry (see the kernels): d enhanced ->
+// d(pre-BatchNorm output) dy, BatchNorm's weight / bias gradients (overwritten), the 1x1 conv's gradients gacc (accumulated: the
+// caller zeroes).  mask_ws: in tanh(linear) of the forward pass, out d linear.  No tensor-sized intermediate is written.
+extern "C" int sehip_dcunet_tail_bwd(const float* dout, const float* spec, float* mask_ws, const void* y_bf16, const float* coef,
+                                     const float* w_re, const float* w_im, int R, int F, int T, int Cs, int Cr, int mode, float* scratch,
+                                     float* gw_re, float* gb_re, float* gw_im, float* gb_im, float* bcoef, void* dy_bf16, float* gacc,
+                                     void* stream) {
+    if (int e = check_dcu("dcunet_tail_bwd", R, F, T, Cs, Cr, mode)) return e;
+    SEHIP_REQUIRE(scratch && coef && bcoef && gacc, "dcunet_tail_bwd: missing buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)R * T * F;
+    const int C = 2 * Cs, nblk = rbn_stat_blocks(rows, C), ntile = cdiv(T, DT) * cdiv(F, DT) * R;
+    float* part = scratch;
+    float* bpart = scratch + (size_t)nblk * 4 * C;
+    dcunet_dlin_kernel<<<dim3(cdiv(T, DT), cdiv(F, DT), R), 256, 0, st>>>((const float2*)dout, (const float2*)spec, (float2*)mask_ws, F, T, mode, bpart);
+    dcunet_tail_reduce_kernel<<<nblk, 256, 0, st>>>((const float2*)mask_ws, (const bf16_raw*)y_bf16, (const float4*)coef, w_re, w_im, rows, Cs, Cr, part);
+    dcunet_tail_finalize_kernel<<<C, 64, 0, st>>>(part, nblk, bpart, ntile, (const float4*)coef, rows, Cs, Cr, gw_re, gb_re, gw_im, gb_im,
+                                                   (float4*)bcoef, gacc);
+    dcunet_tail_apply_kernel<<<rbn_apply_blocks(rows, C), 256, 0, st>>>((const float2*)mask_ws, (const bf16_raw*)y_bf16, (const float4*)coef,
+                                                                         (const float4*)bcoef, w_re, w_im, rows, Cs, Cr, (bf16_raw*)dy_bf16);
+    SEHIP_CHECK_LAUNCH("dcunet_tail_bwd");
     return 0;
 }
 

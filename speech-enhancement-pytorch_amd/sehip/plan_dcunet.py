@@ -474,6 +474,13 @@ class DCUNetWorkspace:
         self.bn_coef = {pre: torch.zeros(2 * cs, 4, dtype=torch.float32, device=device) for pre, tag, cs, cr in pl.bn}
         self.bn_bcoef = torch.zeros(2 * max(cs for _, _, cs, _ in pl.bn), 4, dtype=torch.float32, device=device)     # sehip_rbn_bwd_finalize: [2 cs][4]
         self.mode = {"E": 0, "C": 1, "R": 2}[st.cfg.masking_mode]
+        # The fused tail (csrc/dcunet.hip): the last decoder's BatchNorm + LeakyReLU output zd{n-1} and its gradient dzd{n-1} -- 1.08 GB
+        # each at B = 64 -- are never written; the mask kernel applies the BatchNorm to the pre-activation it loads, the backward pass
+        # rebuilds d(output) from the two values per position the 1x1 convolution's transpose spreads over the channels.
+        # SEHIP_DCUNET_NO_TAIL=1: the separate kernels (the op-local tests compare those two tensors with the oracle).
+        self.fused_tail = "SEHIP_DCUNET_NO_TAIL" not in os.environ
+        self.tail_scratch = torch.zeros(int(lib.sehip_dcunet_tail_scratch_floats(B, F0, T0, st.dec_c[-1])), dtype=torch.float32,
+                                        device=device)
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self._bind()
@@ -573,7 +580,7 @@ class DCUNetWorkspace:
         nb = lambda k: nbt.data_ptr() + 8 * L.nbt_idx[pre + k + ".num_batches_tracked"]
         return pp, bp, nb
 
-    def bn_forward(self, pre, cs, cr, y, z, params, buffers, nbt, training):
+    def bn_forward(self, pre, cs, cr, y, z, params, buffers, nbt, training, apply=True):
         rows = y.t.numel() // (2 * cs)
         pp, bp, nb = self._bn_ptrs(pre, params, buffers, nbt)
         coef = self.bn_coef[pre]
@@ -585,7 +592,16 @@ class DCUNetWorkspace:
         call("sehip_rbn_finalize_s", ptr(self.bn_acc), pp("bn_re.weight"), pp("bn_re.bias"), pp("bn_im.weight"), pp("bn_im.bias"),
              bp("bn_re.running_mean"), bp("bn_re.running_var"), bp("bn_im.running_mean"), bp("bn_im.running_var"),
              nb("bn_re"), nb("bn_im"), rows, cs, cr, 1e-5, 0.1, 1 if training else 0, shift, ptr(coef), stream())
-        call("sehip_rbn_apply", y.ptr, ptr(coef), rows, cs, cr, z.ptr, stream())
+        if apply:
+            call("sehip_rbn_apply", y.ptr, ptr(coef), rows, cs, cr, z.ptr, stream())
+
+    def materialize_tail(self):
+        """Debug / tests: write the last decoder's BatchNorm + LeakyReLU output (zd{n-1}) the fused tail does not store."""
+        n, st = self.pl.st.n, self.pl.st
+        y, z = self.bufs[f"yd{n - 1}"], self.bufs[f"zd{n - 1}"]
+        cs, cr = st.dec_c[-1], st.dec_cr[-1]
+        call("sehip_rbn_apply", y.ptr, ptr(self.bn_coef[f"decoder{n - 1}.bn."]), y.t.numel() // (2 * cs), cs, cr, z.ptr, stream())
+        return z
 
     def bn_backward(self, pre, cs, cr, dz, y, dy):
         rows = y.t.numel() // (2 * cs)
@@ -616,10 +632,15 @@ class DCUNetWorkspace:
         for j in range(n):
             for name in pl.bias_group[f"dec{j}"]:
                 self.gemm(name)
-            self.bn_forward(f"decoder{j}.bn.", st.dec_c[j], st.dec_cr[j], b[f"yd{j}"], b[f"zd{j}"], params, buffers, nbt, training)
+            self.bn_forward(f"decoder{j}.bn.", st.dec_c[j], st.dec_cr[j], b[f"yd{j}"], b[f"zd{j}"], params, buffers, nbt, training,
+                            apply=not (self.fused_tail and j == n - 1))
         wre, wim, bre, bim = self._lin_ptrs(params)
-        call("sehip_dcunet_mask_fwd", b[f"zd{n - 1}"].ptr, wre, wim, bre, bim, ptr(spec), B, pl.F0, pl.T0, st.dec_c[-1], st.dec_cr[-1],
-             self.mode, ptr(self.mask_ws), ptr(self.out), stream())
+        if self.fused_tail:
+            call("sehip_dcunet_mask_fwd_bn", b[f"yd{n - 1}"].ptr, ptr(self.bn_coef[f"decoder{n - 1}.bn."]), wre, wim, bre, bim, ptr(spec), B,
+                 pl.F0, pl.T0, st.dec_c[-1], st.dec_cr[-1], self.mode, ptr(self.mask_ws), ptr(self.out), stream())
+        else:
+            call("sehip_dcunet_mask_fwd", b[f"zd{n - 1}"].ptr, wre, wim, bre, bim, ptr(spec), B, pl.F0, pl.T0, st.dec_c[-1], st.dec_cr[-1],
+                 self.mode, ptr(self.mask_ws), ptr(self.out), stream())
         return self.out
 
     def backward(self, dout, params, grads):
@@ -629,10 +650,18 @@ class DCUNetWorkspace:
         self.gpack.zero_()
         self._chain_dirty = True
         wre, wim, _, _ = self._lin_ptrs(params)
-        call("sehip_dcunet_mask_bwd", ptr(dout), ptr(self.spec), ptr(self.mask_ws), b[f"zd{n - 1}"].ptr, wre, wim, B, pl.F0, pl.T0,
-             st.dec_c[-1], st.dec_cr[-1], self.mode, b[f"dzd{n - 1}"].ptr, self.gpack.data_ptr() + 4 * pl.lin_g_off, stream())
+        if self.fused_tail:
+            pre = f"decoder{n - 1}.bn."
+            g = lambda k: self.gpack.data_ptr() + 4 * pl.bn_g_off[pre][k]
+            call("sehip_dcunet_tail_bwd", ptr(dout), ptr(self.spec), ptr(self.mask_ws), b[f"yd{n - 1}"].ptr, ptr(self.bn_coef[pre]), wre, wim,
+                 B, pl.F0, pl.T0, st.dec_c[-1], st.dec_cr[-1], self.mode, ptr(self.tail_scratch), g("w_re"), g("b_re"), g("w_im"), g("b_im"),
+                 ptr(self.bn_bcoef), b[f"dyd{n - 1}"].ptr, self.gpack.data_ptr() + 4 * pl.lin_g_off, stream())
+        else:
+            call("sehip_dcunet_mask_bwd", ptr(dout), ptr(self.spec), ptr(self.mask_ws), b[f"zd{n - 1}"].ptr, wre, wim, B, pl.F0, pl.T0,
+                 st.dec_c[-1], st.dec_cr[-1], self.mode, b[f"dzd{n - 1}"].ptr, self.gpack.data_ptr() + 4 * pl.lin_g_off, stream())
         for j in range(n - 1, -1, -1):
-            self.bn_backward(f"decoder{j}.bn.", st.dec_c[j], st.dec_cr[j], b[f"dzd{j}"], b[f"yd{j}"], b[f"dyd{j}"])
+            if not (self.fused_tail and j == n - 1):
+                self.bn_backward(f"decoder{j}.bn.", st.dec_c[j], st.dec_cr[j], b[f"dzd{j}"], b[f"yd{j}"], b[f"dyd{j}"])
             for name in pl.bias_group[f"dec{j}"]:
                 self.wgrad(name)
             self.gemm(f"dec{j}.dg")

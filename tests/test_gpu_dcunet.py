@@ -42,9 +42,11 @@ def padding_is_zero(buf, cr):
     return float(x[..., cr:cs].abs().max()) == 0.0 and float(x[..., cs + cr:].abs().max()) == 0.0 if cr < cs else True
 
 
-@pytest.fixture(scope="module")
-def tiny():
-    """The reference's tiny model (weights from the golden file), one forward/backward through libsehip."""
+def _run_tiny(fused):
+    """The reference's tiny model (weights from the golden file), one forward/backward through libsehip; `fused`: with the fused tail
+    of csrc/dcunet.hip (the default) or with the separate BatchNorm / mask kernels (SEHIP_DCUNET_NO_TAIL, read when the workspace is
+    built)."""
+    import os
     from sehip.model import DCUnet
     from sehip.loss import mse_loss
     g = load_golden("dcunet_tiny.npz")
@@ -53,17 +55,43 @@ def tiny():
     model.load_state_dict(ref_sd, strict=False)
     model = model.cuda().train()
     x, tgt = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
-    est = model(x.cuda())
+    old = os.environ.pop("SEHIP_DCUNET_NO_TAIL", None)
+    if not fused:
+        os.environ["SEHIP_DCUNET_NO_TAIL"] = "1"
+    try:
+        est = model(x.cuda())
+    finally:
+        os.environ.pop("SEHIP_DCUNET_NO_TAIL", None)
+        if old is not None:
+            os.environ["SEHIP_DCUNET_NO_TAIL"] = old
     loss = mse_loss(est, tgt.cuda())
     loss.backward()
     torch.cuda.synchronize()
     ws = model.workspace(2, 257, 33)
+    assert ws.fused_tail == fused
     grads = {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters()}
     return dict(g=g, model=model, ws=ws, est=est.detach().cpu(), loss=float(loss.detach()), grads=grads, p=ref_sd, x=x, tgt=tgt,
                 sz=D.dcunet_sizes(8, 10, 1))
 
 
-def test_whole_chain_vs_reference_vectors(tiny):
+@pytest.fixture(scope="module")
+def tiny():
+    """Separate kernels: every intermediate tensor exists for the op-local comparisons."""
+    return _run_tiny(False)
+
+
+@pytest.fixture(scope="module")
+def tiny_fused():
+    return _run_tiny(True)
+
+
+@pytest.fixture(params=["fused", "separate"])
+def tiny_both(request):
+    return request.getfixturevalue("tiny_fused" if request.param == "fused" else "tiny")
+
+
+def test_whole_chain_vs_reference_vectors(tiny_both):
+    tiny = tiny_both
     g = tiny["g"]
     assert rel_err(tiny["est"], g["train_out"]) < 3e-2
     assert abs(tiny["loss"] - float(g["loss"])) < 2e-3 * float(g["loss"])
@@ -226,6 +254,45 @@ def test_linear_tanh_mask_op_local(tiny):
         assert rel_err(tiny["grads"][k], gref) < 1e-4, k
 
 
+def test_fused_tail_op_local(tiny_fused, tiny):
+    """csrc/dcunet.hip, the fused tail: last BatchNorm + LeakyReLU + 1x1 complex conv + tanh + mask, forward and backward, against the
+    oracle's functions from the HIP path's stored pre-BatchNorm tensor; and against the separate kernels on the same model."""
+    t = tiny_fused
+    ws, p, sz = t["ws"], t["p"], t["sz"]
+    b = ws.bufs
+    cr = sz["dec_ch"][-1]
+    pre = "decoder4.bn."
+    y = to_ref(b["yd4"], cr).requires_grad_(True)
+    q = {k: v.clone() for k, v in p.items() if k.startswith((pre, "linear."))}
+    leaves = {k: q[k].requires_grad_(True) for k in q if k.endswith((".weight", ".bias"))}
+    z = F.leaky_relu(D.complex_batchnorm2d(y, q, pre, True), 0.01)
+    mask = torch.tanh(D.complex_conv2d(z, q, "linear.", 1, 0)).transpose(2, 3)
+    x = t["x"]
+    real, imag = x[..., 0], x[..., 1]
+    mr, mi = mask[..., 0], mask[..., 1]
+    x_mag, x_phase = torch.sqrt(real ** 2 + imag ** 2 + 1e-8), torch.atan2(imag, real)
+    mm = (mr ** 2 + mi ** 2) ** 0.5
+    ph = x_phase + torch.atan2(mi / (mm + 1e-8), mr / (mm + 1e-8))
+    est = torch.stack([torch.tanh(mm) * x_mag * torch.cos(ph), torch.tanh(mm) * x_mag * torch.sin(ph)], dim=-1)
+    assert rel_err(t["est"], est.detach()) < 1e-4
+    dout = 2.0 * (t["est"] - t["tgt"]) / t["tgt"].numel()
+    names = sorted(leaves)
+    outs = torch.autograd.grad((est * dout).sum(), [y] + [leaves[k] for k in names])
+    assert rel_err(to_ref(b["dyd4"], cr), outs[0]) < 6e-3                     # bf16 output
+    for k, gref in zip(names, outs[1:]):
+        assert rel_err(t["grads"][k], gref) < 2e-3, k
+    # the debug materialisation of the tensor the fused tail skips, and the two paths on the same weights and input
+    assert rel_err(to_ref(ws.materialize_tail(), cr), z.detach()) < 4e-3
+    assert rel_err(t["est"], tiny["est"]) < 5e-3
+    # (the biases of the convolutions in front of a BatchNorm have a zero gradient up to rounding: compared through the global norm)
+    num = sum(float(((t["grads"][k].double() - tiny["grads"][k].double()) ** 2).sum()) for k in t["grads"])
+    den = sum(float((tiny["grads"][k].double() ** 2).sum()) for k in t["grads"])
+    assert (num / den) ** 0.5 < 2e-2
+    for k in t["grads"]:
+        if k.startswith("linear.") or ".bn." in k:
+            assert rel_err(t["grads"][k], tiny["grads"][k]) < 3e-2, k
+
+
 def test_masking_modes_and_rejections():
     from sehip.model import DCUnet
     from sehip import SehipError
@@ -343,6 +410,8 @@ def test_c2_headline_shape_one_step(tmp_path):
     for k, v in model.named_parameters():
         assert float(v.grad.abs().max()) > 0 and bool(torch.isfinite(v.grad).all()), k
     ws = model.workspace(64, 257, 257)
+    if ws.fused_tail:
+        ws.materialize_tail()
     assert padding_is_zero(ws.bufs["zd4"], 62) and padding_is_zero(ws.bufs["ze0"], 31)
     # batch statistics of the B=64 training forward, checked through a property: BatchNorm output before the LeakyReLU has
     # zero mean / unit variance per channel -> reproduce from the stored pre-activation
@@ -395,6 +464,8 @@ def test_full_width_gradients_vs_oracle(depth, frames, batch):
     torch.cuda.synchronize()
     got = {k: v.grad.detach().cpu() for k, v in model.named_parameters() if not k.startswith(("encoders.", "decoders."))}
     ws = model.workspace(batch, 257, frames)
+    if ws.fused_tail:
+        ws.materialize_tail()
     masks = {}
     for i in range(depth // 2):
         masks[f"encoder{i}"] = to_ref(ws.bufs[f"ze{i}"], sz["enc_ch"][i + 1]) > 0
