@@ -26,18 +26,21 @@ typedef __attribute__((address_space(3))) s16x4 dtw_lds_s16x4;
 #define DTW_MAXP 16
 
 struct DtwProd {                 // one product (device copy)
-    const bf16_raw* g;           // dOut tensor, row m at g + m * gstride
-    const bf16_raw* x[2];        // source tensors, row m at x[s] + m * xstride[s]
+    const bf16_raw* g;           // dOut tensor, row (b, t) at g + ((b * Tg + t + gtoff) * gstride)
+    const bf16_raw* x[2];        // source tensors, row (b, t) at x[s] + ((b * Tx[s] + t) * xstride[s])
     float* dW;                   // [N][K] fp32
     float* dbias;                // [N] fp32 column sums of dOut, or NULL
     int gstride, gcol0, xstride[2];
-    int T, M, N, K;
+    int T, M, N, K;              // T: frames per utterance of the ROW space (M = B * T)
     int plane0;                  // first entry of this product in the plane table
+    int B, Tg, gtoff;            // utterances; frames per utterance stored in dOut, frame offset of row t in it
+    int Tx[2], tlo[2], thi[2];   // frames per utterance stored in the sources, their valid frame ranges
+    unsigned gbytes, xbytes[2];  // tensor sizes (num_records)
     int pad_[1];
 };
-struct DtwPlane { int src, delta, shift, pad_; };      // 16 columns of A: tensor, element offset inside the row, 1 = previous frame
-struct DtwTile { int prod, n0, k0, s_begin, s_end, out_off, cls, bias; };   // out_off: floats into scratch; bias: also the column sums of dOut
-struct DtwRed { int first, prod, n0, k0, N, K, parts_off, nparts, part_stride, bias, pad_[2]; };   // one (product, tile): blocks [first, ...); bias: one more block
+struct DtwPlane { int src, delta, shift, live; };      // 16 columns of A: tensor, element offset inside the row, source frame = t - shift; live 0: zero columns (K padding)
+struct DtwTile { int prod, n0, k0, s_begin, s_end, out_off, cls, bias; };   // out_off: floats into scratch, -1: the only split of its tile, adds to dW directly; bias: also the column sums of dOut
+struct DtwRed { int first, prod, n0, k0, N, K, parts_off, nparts, part_stride, bias, liveN, liveK; };   // one (product, tile): blocks [first, ...); bias: one more block; live*: the part of the tile inside [Npad][K]
 
 template <int N>
 __device__ __forceinline__ void dtw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -54,52 +57,59 @@ __device__ __forceinline__ void dtw_body(const DtwProd& P, const DtwPlane* __res
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv % WN, wk = wv / WN;
     const int ns = t.s_end - t.s_begin;
-    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(P.g), 0, (unsigned)((size_t)P.M * P.gstride * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(P.x[0]), 0, (unsigned)((size_t)P.M * P.xstride[0] * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(P.g), 0, P.gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(P.x[0]), 0, P.xbytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(P.x[1] ? P.x[1] : P.x[0]), 0,
-                                                                          (unsigned)((size_t)P.M * (P.x[1] ? P.xstride[1] : P.xstride[0]) * 2), 0x00020000);
+                                                                          P.x[1] ? P.xbytes[1] : P.xbytes[0], 0x00020000);
     // piece i = (8 u + wave) * 64 + lane of an image: plane i >> 7, row (i >> 1) & 63, half i & 1.  The row and the half depend on
     // (lane, wave parity) only; the plane is wave-uniform per instruction.
     const int row = (lane >> 1) + 32 * (wv & 1), half = lane & 1;
     const int r0 = t.s_begin * 64 + row;
-    unsigned goff[GI];
+    // per instruction: the column part of the offset (elements) and whether the plane exists (the tile may reach past Npad / K)
+    int gcol[GI];
+    bool glive[GI];
 #pragma unroll
     for (int u = 0; u < GI; ++u) {
         const int pl = (u * 8 + wv) >> 1;
-        goff[u] = 2u * (unsigned)(r0 * P.gstride + P.gcol0 + t.n0 + pl * 16 + half * 8);
+        glive[u] = t.n0 + pl * 16 < P.N;
+        gcol[u] = P.gcol0 + t.n0 + pl * 16 + half * 8;
     }
-    // A planes: per instruction the tensor (wave-uniform), the per-lane offset of stage s_begin, and whether the rows shift
-    unsigned xoff[XI];
-    int xsrc[XI], xshift[XI], xstr[XI];
+    // A planes: per instruction the tensor (wave-uniform), the column part, the frame shift
+    int xcol[XI], xsrc[XI], xshift[XI];
     bool xlive[XI];
 #pragma unroll
     for (int u = 0; u < XI; ++u) {
         const int pl = (u * 8 + wv) >> 1;
-        xlive[u] = pl < K / 16;                       // (K = 64: four planes, waves 0..7 cover them with one instruction)
-        const DtwPlane e = planes[P.plane0 + (t.k0 >> 4) + (xlive[u] ? pl : 0)];
+        const bool in = pl < K / 16 && t.k0 + pl * 16 < P.K;       // (K = 64: four planes, waves 0..7 cover them with one instruction)
+        const DtwPlane e = planes[P.plane0 + (in ? (t.k0 >> 4) + pl : 0)];
+        xlive[u] = in && __builtin_amdgcn_readfirstlane(e.live) != 0;
         xsrc[u] = __builtin_amdgcn_readfirstlane(e.src);
         xshift[u] = __builtin_amdgcn_readfirstlane(e.shift);
-        xstr[u] = xsrc[u] ? P.xstride[1] : P.xstride[0];
-        xoff[u] = 2u * (unsigned)((r0 - xshift[u]) * xstr[u] + e.delta + half * 8);
+        xcol[u] = e.delta + half * 8;
     }
-    int tm = r0 % P.T;                                 // frame of this thread's row (the recurrent products skip t = 0)
-    auto issue = [&](int stage_rel, int buf, bool past) {      // past the range: offsets beyond num_records, zeros (constant DMA count)
+    // this thread's row as (utterance, frame); every issue advances it by the 64 rows of a stage (no division in the loop)
+    int ub = r0 / P.T, tm = r0 - ub * P.T;
+    auto issue = [&](int buf, bool past) {             // stages are issued in order; past the range: offsets beyond num_records, zeros (constant DMA count)
         unsigned char* base = smem + buf * STAGE + wv * 1024;
-        const unsigned gs = (unsigned)stage_rel * (64u * (unsigned)P.gstride * 2u);
+        const bool rowlive = !past && ub < P.B;
+        const int grow = ((ub * P.Tg + tm + P.gtoff) * P.gstride);
 #pragma unroll
         for (int u = 0; u < GI; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (dtw_lds_void*)(base + u * 8192), 16, past ? DTW_OOB : goff[u] + gs, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (dtw_lds_void*)(base + u * 8192), 16,
+                                                     (rowlive && glive[u]) ? 2u * (unsigned)(grow + gcol[u]) : DTW_OOB, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < XI; ++u) {
-            const unsigned xs = (unsigned)stage_rel * (64u * (unsigned)xstr[u] * 2u);
-            const bool dead = past || !xlive[u] || (xshift[u] && tm == 0);
-            const unsigned vo = dead ? DTW_OOB : xoff[u] + xs;
+            const int sx = xsrc[u];
+            const int ts = tm - xshift[u];
+            const bool ok = rowlive && xlive[u] && ts >= (sx ? P.tlo[1] : P.tlo[0]) && ts < (sx ? P.thi[1] : P.thi[0]);
+            const int xrow = (ub * (sx ? P.Tx[1] : P.Tx[0]) + ts) * (sx ? P.xstride[1] : P.xstride[0]);
+            const unsigned vo = ok ? 2u * (unsigned)(xrow + xcol[u]) : DTW_OOB;
             unsigned char* dd = base + GB + u * 8192;
-            if (xsrc[u]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx1, (dtw_lds_void*)dd, 16, vo, 0, 0, 0);
+            if (sx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx1, (dtw_lds_void*)dd, 16, vo, 0, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx0, (dtw_lds_void*)dd, 16, vo, 0, 0, 0);
         }
-        tm += 64;                                      // the next stage's frame (T >= 64: one subtraction; the launcher checks)
-        if (tm >= P.T) tm -= P.T;
+        tm += 64;                                      // the next stage's row
+        while (tm >= P.T) { tm -= P.T; ++ub; }
     };
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
     const int ga = (wn * TN) * 2048 + (4 * g + q) * 32 + 8 * p4;              // + tn * 2048 + ks * 1024 + h * 512
@@ -114,13 +124,13 @@ __device__ __forceinline__ void dtw_body(const DtwProd& P, const DtwPlane* __res
     const bool do_bias = t.bias != 0 && wk == 0;      // the column sums of dOut (dbias): one more MFMA per row tile against ones
     const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
-    for (int s = 0; s < NB - 1; ++s) issue(s, s, s >= ns);
+    for (int s = 0; s < NB - 1; ++s) issue(s, s >= ns);
     int buf = 0;
     for (int s = 0; s < ns; ++s) {
         dtw_wait_vm<(NB - 2) * NI>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(s + NB - 1, buf == 0 ? NB - 1 : buf - 1, s + NB - 1 >= ns);
+        issue(buf == 0 ? NB - 1 : buf - 1, s + NB - 1 >= ns);
         const unsigned char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -150,6 +160,30 @@ __device__ __forceinline__ void dtw_body(const DtwProd& P, const DtwPlane* __res
         buf = buf == NB - 1 ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t.out_off < 0) {                              // the tile's only split: straight into dW (one writer per element)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < TK; ++tk) {
+                const int n = t.n0 + (wn * TN + tn) * 16 + 4 * (lane >> 4);
+                const int k = t.k0 + (wk * TK + tk) * 16 + (lane & 15);
+                if (k < P.K) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (n + u < P.N) P.dW[(size_t)(n + u) * P.K + k] += acc[tn][tk][u];
+                }
+            }
+        if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = t.n0 + (wn * TN + tn) * 16 + 4 * (lane >> 4) + u;
+                    if (n < P.N) P.dbias[n] += accb[tn][u];
+                }
+        }
+        return;
+    }
     float* out = scratch + t.out_off;                 // this split's partial tile [N][K]
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -191,7 +225,7 @@ __global__ __launch_bounds__(256) void dtw_reduce_kernel(const DtwProd* __restri
     const int bi = (int)blockIdx.x - r.first, nmain = (r.N * r.K + 1023) / 1024;
     if (bi >= nmain) {                                // the tile's column sums of dOut -> dbias
         const int n = (int)threadIdx.x;
-        if (!r.bias || n >= r.N) return;
+        if (!r.bias || n >= r.liveN) return;
         float s = 0.f;
         for (int i = 0; i < r.nparts; ++i) s += scratch[r.parts_off + (size_t)i * r.part_stride + r.N * r.K + n];
         prods[r.prod].dbias[r.n0 + n] += s;
@@ -206,6 +240,7 @@ __global__ __launch_bounds__(256) void dtw_reduce_kernel(const DtwProd* __restri
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const int n = idx / r.K, k = idx - n * r.K;
+    if (n >= r.liveN || k >= r.liveK) return;         // (the tile reaches past [Npad][K]: whole 16-column planes, so whole float4s)
     float* o = prods[r.prod].dW + (size_t)(r.n0 + n) * prods[r.prod].K + r.k0 + k;
     float4 c = *reinterpret_cast<float4*>(o);
     c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w;
@@ -213,15 +248,18 @@ __global__ __launch_bounds__(256) void dtw_reduce_kernel(const DtwProd* __restri
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
+#define DTW_MAXPLANES 1024       // 16-column planes of A over the whole group (K <= 16384 for a single product)
+#define DTW_MAXTILES 4096
+#define DTW_MAXRED 1024
 namespace {
 struct DtwLayout { size_t prods, planes, tiles, red, total; };
 DtwLayout dtw_layout(int n) {
     DtwLayout L;
     L.prods = 0;
     L.planes = L.prods + (size_t)DTW_MAXP * sizeof(DtwProd);
-    L.tiles = L.planes + (size_t)DTW_MAXP * 64 * sizeof(DtwPlane);          // K <= 1024 per product
-    L.red = L.tiles + (size_t)1024 * sizeof(DtwTile);
-    L.total = L.red + (size_t)DTW_MAXP * 16 * sizeof(DtwRed);
+    L.tiles = L.planes + (size_t)DTW_MAXPLANES * sizeof(DtwPlane);
+    L.red = L.tiles + (size_t)DTW_MAXTILES * sizeof(DtwTile);
+    L.total = L.red + (size_t)DTW_MAXRED * sizeof(DtwRed);
     (void)n;
     return L;
 }
@@ -232,6 +270,11 @@ extern "C" long sehip_wgrad_dense_group_bytes(int n) { return (long)dtw_layout(n
 // info[0] = 1: the group qualifies and dev_buf holds its tables (info[1] = workgroups, info[2] = reduction workgroups, info[3] =
 // (product, tile) entries of the reduction, info[4..5] = scratch floats (low / high 31 bits)); info[0] = 0: it does not (no error: the
 // caller keeps its other path).  Synchronous (reads the products' chunk tables back): once per binding, never inside a capture.
+// What qualifies: dense rows (J = 1, one row per frame), up to two bf16 sources whose 16-column planes are contiguous pieces of a
+// source row at ANY frame offset (zero outside the source's valid frame range: the taps of Demucs' 1-D convolutions on their
+// [B][T][C] / quad-view tensors, src/model/demucs.py:386-413, :191), sources and dOut with their own frames per utterance, one dense
+// run of destination columns.  The tile is 128 x 256 (256 x 128 / 256 x 64 for the shapes that divide so); a tile may reach past
+// [Npad][K] (planes that do not exist are not loaded).
 extern "C" int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int n, void* dev_buf, long dev_bytes, int* info) {
     SEHIP_REQUIRE(descs && dev_buf && info, "wgrad_dense_group_prepare: null argument");
     info[0] = 0;
@@ -243,20 +286,23 @@ extern "C" int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int
     std::vector<DtwPlane> planes;
     struct Shape { int cls, N, K; };
     std::vector<Shape> shp(n);
+    const long lim = (1L << 31) - (1L << 20);          // byte offsets stay below the out-of-range marker
     for (int p = 0; p < n; ++p) {
         const sehip_gemm_desc& d = descs[p];
-        if (!d.dW || d.cv_nf > 0 || d.cv2_nkt > 0 || d.J != 1 || d.tmul > 1 || d.N != d.Npad) return 0;
-        if (d.dst[1].ptr || d.dst[0].is_f32 || d.dst[0].F != 1 || d.dst[0].T != d.TT || d.dst[0].toff || d.dst[0].fadd || d.dst[0].tmul > 1) return 0;
-        if (d.TT < 64 || d.M % d.TT || (long)d.M * 2048 * 2 >= (1L << 31)) return 0;
+        if (!d.dW || d.cv_nf > 0 || d.cv2_nkt > 0 || d.J != 1 || d.tmul > 1 || (d.N & 3) || (d.Npad & 15) || (d.K & 15)) return 0;
+        if (d.dst[1].ptr || d.dst[0].is_f32 || d.dst[0].F != 1 || d.dst[0].fadd || d.dst[0].tmul > 1) return 0;
+        if (d.TT < 1 || d.M % d.TT) return 0;
+        const int B = d.M / d.TT;
+        if ((long)B * d.dst[0].T * d.dst[0].C * 2 >= lim) return 0;
+        if (d.dst[0].toff < 0 || d.dst[0].toff + d.TT > d.dst[0].T) return 0;
         int cls;
         if (d.Npad % 128 == 0 && d.K % 256 == 0) cls = 0;
         else if (d.Npad % 256 == 0 && d.K % 128 == 0) cls = 1;
         else if (d.Npad % 256 == 0 && d.K == 64) cls = 2;
-        else return 0;
-        if (d.K > 1024) return 0;
+        else cls = 0;                                  // 128 x 256 tiles that reach past the edges
         for (int s = 0; s < 2; ++s)
-            if (d.src[s].ptr && (d.src[s].T != d.TT || d.src[s].tlo != 0 || d.src[s].thi != d.TT)) return 0;
-        // destination columns: one dense run
+            if (d.src[s].ptr && (long)B * d.src[s].T * d.src[s].F * d.src[s].C * 2 >= lim) return 0;
+        // destination columns: one dense run (then padding)
         std::vector<sehip_nchunk> nt(d.Npad / 4);
         std::vector<sehip_kchunk> kt(d.K / 8);
         if (hipMemcpy(nt.data(), d.ntab, nt.size() * sizeof(sehip_nchunk), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -264,34 +310,48 @@ extern "C" int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int
             (void)hipGetLastError();
             return 0;
         }
-        for (size_t i = 0; i < nt.size(); ++i)
-            if (nt[i].dst != 0 || nt[i].nvalid != 4 || nt[i].coff != nt[0].coff + 4 * (int)i) return 0;
+        for (size_t i = 0; i < nt.size(); ++i) {
+            if ((int)i < d.N / 4) {
+                if (nt[i].dst != 0 || nt[i].nvalid != 4 || nt[i].coff != nt[0].coff + 4 * (int)i) return 0;
+            } else if (nt[i].nvalid != 0) return 0;
+        }
+        // (the planes are read 16 columns at a time: the padded width must exist in the row)
         if ((nt[0].coff & 7) || (d.dst[0].C & 7) || nt[0].coff + d.Npad > d.dst[0].C) return 0;
         DtwProd& P = prods[p];
         P = DtwProd{};
         P.g = reinterpret_cast<const bf16_raw*>(d.dst[0].ptr);
         P.gstride = d.dst[0].C; P.gcol0 = nt[0].coff;
+        P.B = B; P.Tg = d.dst[0].T; P.gtoff = d.dst[0].toff;
+        P.gbytes = (unsigned)((long)B * d.dst[0].T * d.dst[0].C * 2);
         for (int s = 0; s < 2; ++s) {
             P.x[s] = reinterpret_cast<const bf16_raw*>(d.src[s].ptr);
             P.xstride[s] = d.src[s].ptr ? d.src[s].F * d.src[s].C : 0;
+            P.Tx[s] = d.src[s].T; P.tlo[s] = d.src[s].tlo; P.thi[s] = d.src[s].thi;
+            P.xbytes[s] = d.src[s].ptr ? (unsigned)((long)B * d.src[s].T * d.src[s].F * d.src[s].C * 2) : 0u;
         }
         P.dW = d.dW; P.dbias = d.dbias; P.T = d.TT; P.M = d.M; P.N = d.Npad; P.K = d.K;
         P.plane0 = (int)planes.size();
         for (int pl = 0; pl < d.K / 16; ++pl) {
             const sehip_kchunk a = kt[2 * pl], b = kt[2 * pl + 1];
+            if (a.src < 0 && b.src < 0) {              // K padding: zero columns
+                planes.push_back(DtwPlane{0, 0, 0, 0});
+                continue;
+            }
             if (a.src < 0 || a.src > 1 || b.src != a.src || b.toff != a.toff || b.fadd != a.fadd + 8 || !d.src[a.src].ptr) return 0;
             const int foff = a.toff >> 16, roff = (int)(short)(a.toff & 0xffff);
-            if ((foff != 0 && foff != -1) || roff < 0 || roff >= d.src[a.src].F) return 0;
+            if (foff < -64 || foff > 64 || roff < 0 || roff >= d.src[a.src].F) return 0;
             const int stride = d.src[a.src].F * d.src[a.src].C;
             const int delta = a.fadd - foff * stride;                     // the column part of the element delta
             if (delta < 0 || delta + 16 > stride || (delta & 7)) return 0;
-            planes.push_back(DtwPlane{a.src, delta, -foff, 0});
+            planes.push_back(DtwPlane{a.src, delta, -foff, 1});
         }
         shp[p] = {cls, cls == 0 ? 128 : 256, cls == 0 ? 256 : cls == 1 ? 128 : 64};
     }
+    if (planes.size() > DTW_MAXPLANES) return 0;
     // tiles: every workgroup streams about the same number of rows
     long row_tiles = 0;
-    for (int p = 0; p < n; ++p) row_tiles += (long)(prods[p].N / shp[p].N) * (prods[p].K / shp[p].K) * ((prods[p].M + 63) / 64);
+    for (int p = 0; p < n; ++p)
+        row_tiles += (long)((prods[p].N + shp[p].N - 1) / shp[p].N) * ((prods[p].K + shp[p].K - 1) / shp[p].K) * ((prods[p].M + 63) / 64);
     static const int want = getenv("SEHIP_DTW_WGS") ? atoi(getenv("SEHIP_DTW_WGS")) : 248;
     long per = (row_tiles + want - 1) / want;                             // stages per workgroup
     if (per < 4) per = 4;
@@ -305,9 +365,15 @@ extern "C" int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int
         for (int n0 = 0; n0 < prods[p].N; n0 += tn)
             for (int k0 = 0; k0 < prods[p].K; k0 += tk) {
                 const int bias = (k0 == 0 && prods[p].dbias) ? 1 : 0;      // the first k-tile of every n-tile also sums dOut's columns
+                if (splits == 1) {                     // one workgroup streams all rows of this tile: it adds to dW itself
+                    tiles.push_back(DtwTile{p, n0, k0, 0, nst, -1, shp[p].cls, bias});
+                    continue;
+                }
                 DtwRed r{};
                 r.first = red_first; r.prod = p; r.n0 = n0; r.k0 = k0; r.N = tn; r.K = tk; r.parts_off = (int)out_off; r.part_stride = tn * tk + tn;
                 r.bias = bias;
+                r.liveN = prods[p].N - n0 < tn ? prods[p].N - n0 : tn;
+                r.liveK = prods[p].K - k0 < tk ? prods[p].K - k0 : tk;
                 int np = 0;
                 for (int s = 0; s < splits; ++s) {
                     const int sb = s * spw, se = sb + spw < nst ? sb + spw : nst;
@@ -321,13 +387,12 @@ extern "C" int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int
                 red_first += (tn * tk + 1023) / 1024 + bias;
             }
     }
-    if (tiles.size() > 1024 || red.size() > (size_t)DTW_MAXP * 16 || out_off >= (1L << 31)) return 0;
-    // longest ranges first is not needed (equal ranges); class 0 tiles first so that the big tiles start first
+    if (tiles.size() > DTW_MAXTILES || red.size() > DTW_MAXRED || out_off >= (1L << 31)) return 0;
     char* db = reinterpret_cast<char*>(dev_buf);
     hipError_t e = hipMemcpy(db + L.prods, prods.data(), prods.size() * sizeof(DtwProd), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db + L.planes, planes.data(), planes.size() * sizeof(DtwPlane), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db + L.tiles, tiles.data(), tiles.size() * sizeof(DtwTile), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db + L.red, red.data(), red.size() * sizeof(DtwRed), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !red.empty()) e = hipMemcpy(db + L.red, red.data(), red.size() * sizeof(DtwRed), hipMemcpyHostToDevice);
     if (e != hipSuccess) return sehip_set_error(-2, "wgrad_dense_group_prepare: %s", hipGetErrorString(e));
     info[0] = 1; info[1] = (int)tiles.size(); info[2] = red_first; info[3] = (int)red.size();
     info[4] = (int)(out_off & 0x7fffffff); info[5] = (int)(out_off >> 31);
@@ -335,7 +400,7 @@ extern "C" int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int
 }
 
 extern "C" int sehip_wgrad_dense_group(const void* dev_buf, int n, const int* info, float* scratch, void* stream) {
-    SEHIP_REQUIRE(dev_buf && info && info[0] == 1 && scratch, "wgrad_dense_group: not prepared (info[0] != 1) or no scratch");
+    SEHIP_REQUIRE(dev_buf && info && info[0] == 1 && (scratch || info[2] == 0), "wgrad_dense_group: not prepared (info[0] != 1) or no scratch");
     const DtwLayout L = dtw_layout(n);
     const char* db = reinterpret_cast<const char*>(dev_buf);
     hipStream_t st = (hipStream_t)stream;
@@ -348,7 +413,8 @@ extern "C" int sehip_wgrad_dense_group(const void* dev_buf, int n, const int* in
     sehip_note_kernel("dense_tile_wgrad_kernel");
     dense_tile_wgrad_kernel<<<info[1], 512, lds, st>>>(reinterpret_cast<const DtwProd*>(db + L.prods), reinterpret_cast<const DtwPlane*>(db + L.planes),
                                                        reinterpret_cast<const DtwTile*>(db + L.tiles), scratch);
-    dtw_reduce_kernel<<<info[2], 256, 0, st>>>(reinterpret_cast<const DtwProd*>(db + L.prods), reinterpret_cast<const DtwRed*>(db + L.red), info[3], scratch);
+    if (info[2] > 0)
+        dtw_reduce_kernel<<<info[2], 256, 0, st>>>(reinterpret_cast<const DtwProd*>(db + L.prods), reinterpret_cast<const DtwRed*>(db + L.red), info[3], scratch);
     SEHIP_CHECK_LAUNCH("wgrad_dense_group");
     return 0;
 }

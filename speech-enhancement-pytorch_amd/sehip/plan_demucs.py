@@ -645,6 +645,39 @@ class DemucsWorkspace:
                 w.dst[0].is_f32 = 0
                 w.res = None
                 self.desc[name + ".wg"] = w
+        self._bind_dense_wgrads()
+
+    def _bind_dense_wgrads(self):
+        """The weight gradients the streaming dense-row kernel takes (csrc/dtw.hip: every product here is dense rows of a [B][T][C] or
+        quad-view tensor at a few frame offsets): tables per product, built once per binding (sehip_wgrad_dense_group_prepare reads
+        the chunk table back), one scratch for the partial tiles of whichever launch is running (they share the second stream).
+        SEHIP_DMX_NO_DENSE_WGRAD=1: the table-gathered generic kernel for all of them (round 4)."""
+        self._dtw, self._dtw_scratch = {}, None
+        if os.environ.get("SEHIP_DMX_NO_DENSE_WGRAD") or os.environ.get("SEHIP_NO_DENSE_GROUP"):
+            return
+        lib = _lib.lib()
+        nbytes, need = int(lib.sehip_wgrad_dense_group_bytes(1)), 1
+        only = os.environ.get("SEHIP_DMX_DENSE_ONLY")          # tools: comma-separated product names
+        for name, w in self.desc.items():
+            if not name.endswith(".wg") or (only and name[:-3] not in only.split(",")):
+                continue
+            if w.K < 128 and not only:       # 64 columns of A in a 256- (64-) column tile: measured slower than the generic kernel
+                continue                     # (e0.rw 177 vs 156 us, e0.d*.c2 157 vs 142, e1.d*.c2 107 vs 81)
+            arr = (CGemmDesc * 1)(CGemmDesc.from_buffer_copy(w))
+            dbuf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            info = (C.c_int * 8)()
+            call("sehip_wgrad_dense_group_prepare", C.cast(arr, C.c_void_p), 1, ptr(dbuf), dbuf.numel(), C.cast(info, C.c_void_p))
+            if info[0] == 1:
+                self._dtw[name] = (dbuf, info)
+                need = max(need, info[4] + (info[5] << 31))
+        self._dtw_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+
+    def _launch_wgrad(self, name, st):
+        h = self._dtw.get(name + ".wg")
+        if h is not None:
+            call("sehip_wgrad_dense_group", ptr(h[0]), 1, C.cast(h[1], C.c_void_p), ptr(self._dtw_scratch), st)
+        else:
+            call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), st)
 
     # ---- launches -----------------------------------------------------------------------------------------------------
     def gemm(self, name):
@@ -673,12 +706,12 @@ class DemucsWorkspace:
     def wgrad(self, name):
         main = torch.cuda.current_stream()
         if self.side is None or torch.cuda.is_current_stream_capturing():
-            call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), main.cuda_stream)
+            self._launch_wgrad(name, main.cuda_stream)
             return
         if self._chain_dirty:
             call("sehip_stream_depend", self.side.cuda_stream, main.cuda_stream, self._event())
             self._chain_dirty = False
-        call("sehip_wgrad", C.byref(self.desc[name + ".wg"]), self.side.cuda_stream)
+        self._launch_wgrad(name, self.side.cuda_stream)
 
     def _pp(self, params, name):
         return params.data_ptr() + 4 * self.st.layout.param_off[name][0]

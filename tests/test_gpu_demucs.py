@@ -176,6 +176,50 @@ def test_full_width_default_network():
     check_chain(r, "full width (64 channels, depth 6)", fwd_tol=3e-2, est_tol=1.5e-2, glob_tol=6e-2, big_tol=0.15)
 
 
+@pytest.mark.parametrize("kw,B,T", [(dict(sources=["clean"], audio_channels=2), 2, 24000),
+                                     (dict(sources=["a", "b"], audio_channels=1, channels=32, depth=4), 3, 9000)])
+def test_streaming_weight_gradients_match_the_generic_kernel(kw, B, T):
+    """csrc/dtw.hip on Demucs' products (dense rows at frame offsets, quad views, chunked LSTM frames, padded K / N, short and long
+    row spaces): every weight gradient the streaming kernel takes, against the table-gathered generic kernel on the same operands."""
+    import ctypes as C
+    from sehip.model import Demucs
+    from sehip._lib import call, stream
+    torch.manual_seed(3)
+    model = Demucs(**kw).cuda().train()
+    x = 0.3 * torch.randn(B, kw["audio_channels"], T, device="cuda")
+    y = model(x)
+    y.backward(torch.randn_like(y) / y.numel() ** 0.5)
+    torch.cuda.synchronize()
+    ws = model.workspace(B, T)
+    assert len(ws._dtw) >= 0.4 * sum(1 for k in ws.desc if k.endswith(".wg")), (len(ws._dtw), "products on the streaming kernel")
+    worst = 0.0
+    for name in sorted(ws._dtw):
+        d = ws.desc[name]
+        p = ws.st.prods[name[:-3]]
+        n = p.Npad * p.K
+        lo = p.dw_off
+        view = ws.gpack[lo:lo + n]
+        bview = ws.gpack[p.db_off:p.db_off + p.Npad] if p.db_off is not None else None
+        res = []
+        for dense in (False, True):
+            view.zero_()
+            if bview is not None:
+                bview.zero_()
+            if dense:
+                ws._launch_wgrad(name[:-3], stream())
+            else:
+                call("sehip_wgrad", C.byref(d), stream())
+            torch.cuda.synchronize()
+            res.append((view.view(p.Npad, p.K)[:p.N].clone(), bview[:p.N].clone() if bview is not None else None))
+        (w0, b0), (w1, b1) = res
+        e = rel_err(w1.cpu(), w0.cpu()) if float(w0.abs().max()) > 0 else float(w1.abs().max())
+        worst = max(worst, e)
+        assert e < 2e-3, (name, e)
+        if b0 is not None and float(b0.abs().max()) > 0:
+            assert rel_err(b1.cpu(), b0.cpu()) < 2e-3, name
+    print(f"{len(ws._dtw)} streaming weight gradients, worst relative difference to the generic kernel {worst:.2e}")
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # op-local
 # ---------------------------------------------------------------------------------------------------------------------------
