@@ -1623,6 +1623,15 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     } else {
         SEHIP_REQUIRE(d->Npad % 128 == 0, "gemm: Npad=%d must be 16, 32, 64, 192 or a multiple of 128", d->Npad);
         static const bool no64 = getenv("SEHIP_NO_BM64") != nullptr;
+        // very short row spaces (Demucs' deepest levels: 736 rows x 2048-4096 columns x 6144-12288 k): even 64-row tiles leave
+        // under one workgroup per CU, each a chain of dependent K steps: 64 x 64 tiles double the workgroups in flight
+        static const int small64 = getenv("SEHIP_GEMM_SMALL64") ? atoi(getenv("SEHIP_GEMM_SMALL64")) : 384;
+        if (!no64 && (long)cdiv(d->M, 64) * (d->Npad / 128) < small64) {
+            sehip_note_kernel("gemm_kernel<64, 64, 2, 2>");
+            gemm_kernel<64, 64, 2, 2><<<cdiv(d->M, 64) * (d->Npad / 64), 256, 0, st>>>(*d);
+            SEHIP_CHECK_LAUNCH("gemm");
+            return 0;
+        }
         if (!no64 && (long)cdiv(d->M, 128) * (d->Npad / 128) < 512) {  // under one round of 2 workgroups per CU: halve the tile
             sehip_note_kernel("gemm_kernel<128, 64, 2, 2>");
             gemm_kernel<128, 64, 2, 2><<<cdiv(d->M, 64) * (d->Npad / 128), 256, 0, st>>>(*d);
