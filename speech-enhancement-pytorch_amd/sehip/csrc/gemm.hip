@@ -176,8 +176,10 @@ __device__ __forceinline__ RegTile<NRW> fetch_w_tile(const bf16_raw* Wb, int K, 
     return t;
 }
 
+// kt0 / kt1: the K steps (64 columns each) this workgroup sums, kt1 < 0 = all; part != NULL: the accumulators go to part[m][Npad]
+// (fp32, no bias / residual / scatter: gemm_splitk_finish_kernel adds the splits and stores) -- the split-K launches of sehip_gemm
 template <int BN, int BM, int WN, int WM>
-__device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
+__device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d, const int kt0 = 0, const int kt1_ = -1, float* __restrict__ part = nullptr) {
     constexpr int TN = BN / WN / 16, TM = BM / WM / 16;
     constexpr int NRA = BM / 32;
     constexpr int NRW = (BN + 31) / 32;
@@ -222,7 +224,7 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
         }
     }
 
-    const int nk = d.K >> 6;
+    const int nk = kt1_ < 0 ? (d.K >> 6) : kt1_;
     const bf16_raw* Wb = reinterpret_cast<const bf16_raw*>(d.W);
 
     f32x4 acc[TN][TM];
@@ -278,12 +280,12 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
         return t;
     };
 
-    sehip_kchunk e1 = d.ktab[min(8 + kc, (d.K >> 3) - 1)];          // entry of K step 1
-    RegTile<NRA> ra = gather(d.ktab[kc]);
-    RegTile<NRW0> rw = fetch_w(0);
+    sehip_kchunk e1 = d.ktab[min((kt0 + 1) * 8 + kc, (d.K >> 3) - 1)];          // entry of the second K step
+    RegTile<NRA> ra = gather(d.ktab[kt0 * 8 + kc]);
+    RegTile<NRW0> rw = fetch_w(kt0);
     RegTile<(NRW1 > 0 ? NRW1 : 1)> rw1;
-    if (NRW1 > 0) rw1 = fetch_w1(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    if (NRW1 > 0) rw1 = fetch_w1(kt0);
+    for (int kt = kt0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
             const int r = r0 + 32 * i;
@@ -330,6 +332,20 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
     }
 
     // epilogue: lane holds n = nb + 4*(lane>>4) + {0..3}, m = mb + (lane&15).
+    if (part) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * (BM / WM) + mi * 16 + (lane & 15);
+            if (m >= d.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * (lane >> 4);
+                const f32x4 v = acc[ni][mi];
+                *reinterpret_cast<float4*>(part + (size_t)m * d.Npad + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        return;
+    }
     // Dense case (the wave's WC columns are one contiguous run of a bf16 destination): the tile leaves through a wave-private
     // LDS image as 16-byte pieces, a row's WC columns in consecutive lanes, rows stepped with carries -- instead of 8-byte
     // pieces scattered over 16 rows per store instruction and two divisions per row.
@@ -411,6 +427,34 @@ __device__ __forceinline__ void gemm_body(const sehip_gemm_desc& d) {
 template <int BN, int BM, int WN, int WM>
 __global__ __launch_bounds__(256) void gemm_kernel(const sehip_gemm_desc d) {
     gemm_body<BN, BM, WN, WM>(d);
+}
+
+// split-K: blockIdx.y sums K steps [y * per, (y + 1) * per) into its own fp32 image of the output; the finish kernel adds the images in
+// order and stores through the ordinary epilogue (bias, residual, destination table).  For very short row spaces (Demucs' deepest
+// levels, src/model/demucs.py:386-413 at 736 rows: 2048-4096 x 6144-12288 weights streamed by under one workgroup per CU, each a
+// chain of 100-200 dependent K steps: 0.3 TB/s of weights).
+template <int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(const sehip_gemm_desc d, int per, float* __restrict__ part) {
+    const int nk = d.K >> 6;
+    const int k0 = (int)blockIdx.y * per, k1 = min(nk, k0 + per);
+    gemm_body<BN, BM, WN, WM>(d, k0, k1, part + (size_t)blockIdx.y * d.M * d.Npad);
+}
+__global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const sehip_gemm_desc d, const float* __restrict__ part, int nsplit) {
+    const int n4 = d.Npad >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d.M * n4) return;
+    const int m = (int)(idx / n4), n = 4 * (int)(idx - (long)m * n4);
+    const sehip_nchunk nc = d.ntab[n >> 2];
+    if (nc.nvalid <= 0) return;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(part + ((size_t)s * d.M + m) * d.Npad + n);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    }
+    const RowPos r = row_pos(m, d.M, d.TT, d.J, d.fmul);
+    const size_t ro0 = dst_row_offset(d.dst[0], r, d.fmul);
+    const size_t ro1 = d.dst[1].ptr ? dst_row_offset(d.dst[1], r, d.fmul) : 0;
+    store_out4(d, nc, v, ro0, ro1, n);
 }
 
 // two products of the same shape in one launch (blockIdx.y picks the descriptor): the real / imaginary halves of the LSTM
@@ -1575,6 +1619,8 @@ static int try_conv_narrow(const sehip_gemm_desc& d, hipStream_t st, bool dry = 
     return 1;
 }
 
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
+
 extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     if (int e = check_desc("gemm", d)) return e;
     SEHIP_REQUIRE(d->W != nullptr, "gemm: missing weights");
@@ -1625,6 +1671,19 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
         static const bool no64 = getenv("SEHIP_NO_BM64") != nullptr;
         // very short row spaces (Demucs' deepest levels: 736 rows x 2048-4096 columns x 6144-12288 k): even 64-row tiles leave
         // under one workgroup per CU, each a chain of dependent K steps: 64 x 64 tiles double the workgroups in flight
+        // ... and long K: split-K (4 splits of >= 8 steps; the partial images are S x M x Npad floats from the per-stream pool)
+        static const int splitk = getenv("SEHIP_GEMM_SPLITK") ? atoi(getenv("SEHIP_GEMM_SPLITK")) : 4;
+        if (splitk > 1 && !no64 && (long)cdiv(d->M, 64) * (d->Npad / 128) < 512 && (d->K >> 6) >= 8 * splitk) {
+            const int nk = d->K >> 6, per = cdiv(nk, splitk), S = cdiv(nk, per);
+            float* part = sehip_wgrad_scratch(st, (size_t)S * d->M * d->Npad * sizeof(float));
+            if (part) {
+                sehip_note_kernel("gemm_splitk_kernel<128, 64, 2, 2>");
+                gemm_splitk_kernel<128, 64, 2, 2><<<dim3(cdiv(d->M, 64) * (d->Npad / 128), S), 256, 0, st>>>(*d, per, part);
+                gemm_splitk_finish_kernel<<<cdiv((long)d->M * (d->Npad >> 2), 256), 256, 0, st>>>(*d, part, S);
+                SEHIP_CHECK_LAUNCH("gemm(split-K)");
+                return 0;
+            }
+        }
         static const int small64 = getenv("SEHIP_GEMM_SMALL64") ? atoi(getenv("SEHIP_GEMM_SMALL64")) : 384;
         if (!no64 && (long)cdiv(d->M, 64) * (d->Npad / 128) < small64) {
             sehip_note_kernel("gemm_kernel<64, 64, 2, 2>");
