@@ -309,13 +309,16 @@ int sehip_wgrad_pair(const sehip_gemm_desc* a, const sehip_gemm_desc* b, void* s
 long sehip_wgrad_group_bytes(int n);
 int sehip_wgrad_group_prepare(const sehip_gemm_desc* descs, int n, void* dev_buf, int* total_blocks);
 int sehip_wgrad_group(const void* dev_buf, int n, int total_blocks, void* stream);
-/* The same group as ONE launch of the streaming dense-row kernel (csrc/dtw.hip: each workgroup owns a 128 x 256 / 256 x 128 / 256 x 64
- * tile of one product's dW in registers and streams its share of the rows by LDS-DMA; partial tiles go to `scratch` by plain stores
- * and a second launch adds them in a fixed order -- no atomics, deterministic) for products whose rows are dense: J = 1, every
- * 16-column run of A contiguous in ONE source row (frame offset 0 or -1), dOut one dense run of a bf16 destination; (Npad, K)
- * multiples of (128, 256) or (256, 128), or K = 64 with Npad a multiple of 256.  prepare reads the products' tables back
- * (synchronous, once per binding, not inside a capture) and fills info[8]: info[0] = 1 if the group qualifies, else 0 (not an
- * error: use sehip_wgrad_group); info[4] + (info[5] << 31) = floats of scratch the launch needs (caller-owned, no need to clear). */
+/* The same group -- or ONE product (n = 1: the 1-D convolutions of Demucs, src/model/demucs.py:386-413, :191) -- as a launch of the
+ * streaming dense-row kernel (csrc/dtw.hip: each workgroup owns a 128 x 256 / 256 x 128 / 256 x 64 tile of one product's dW in
+ * registers and streams its share of the rows by LDS-DMA; partial tiles go to `scratch` by plain stores and a second launch adds
+ * them in a fixed order, a tile that one workgroup streams alone adds to dW itself -- no atomics, deterministic) for products whose
+ * rows are dense: J = 1, tmul <= 1, every 16-column run of A contiguous in ONE source row at any frame offset (zero outside the
+ * source's [tlo, thi)), sources and dOut with their own frames per utterance, dOut one dense run of a bf16 destination whose rows hold
+ * Npad columns from its first; tiles may reach past [Npad][K] (128 x 256 tiles unless (Npad, K) are multiples of (256, 128) or
+ * K = 64 with Npad a multiple of 256).  prepare reads the products' tables back (synchronous, once per binding, not inside a
+ * capture) and fills info[8]: info[0] = 1 if the group qualifies, else 0 (not an error: use sehip_wgrad_group / sehip_wgrad);
+ * info[4] + (info[5] << 31) = floats of scratch the launch needs (caller-owned, no need to clear; 0 when no tile is split). */
 long sehip_wgrad_dense_group_bytes(int n);
 int sehip_wgrad_dense_group_prepare(const sehip_gemm_desc* descs, int n, void* dev_buf, long dev_bytes, int* info);
 int sehip_wgrad_dense_group(const void* dev_buf, int n, const int* info, float* scratch, void* stream);
