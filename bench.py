@@ -101,7 +101,11 @@ def gemm_roofline(ws, reps=5):
             if not name.endswith(".wg") and not d.W:
                 continue  # recurrent-weight gradients exist only as wgrad launches
             fn = "sehip_wgrad" if name.endswith(".wg") else "sehip_gemm"
-            units.append((name, [name], lambda st, fn=fn, d=d: call(fn, C.byref(d), st)))
+            if name.endswith(".wg") and hasattr(ws, "_launch_wgrad"):
+                # (Demucs: the launch the step makes -- the streaming dense-row kernel where the workspace bound one)
+                units.append((name, [name], lambda st, nm=name[:-3]: ws._launch_wgrad(nm, st)))
+            else:
+                units.append((name, [name], lambda st, fn=fn, d=d: call(fn, C.byref(d), st)))
     queue = list(units)
     while queue:
         name, members, launch = queue.pop(0)

@@ -89,7 +89,9 @@ class ConvTasNet(FlatModule):
 
     def _run_backward(self, ws, grad_out):
         g = grad_out.contiguous().float()
-        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst))
+        tail = self._tail_for_backward()
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, tail=tail))
+        self._tail_mark(tail)
 
     def forward(self, mixture):
         if mixture.dim() != 3 or mixture.shape[1] != self.audio_channels:

@@ -113,7 +113,9 @@ class DCUnet(FlatModule):
         if not self.training:
             raise SehipError("DCUnet.backward in eval mode (running-statistics BatchNorm) is not built")
         g = grad_out.contiguous().float()
-        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst))
+        tail = self._tail_for_backward()
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, tail=tail))
+        self._tail_mark(tail)
 
     def forward(self, x):
         if x.dim() != 5 or x.shape[-1] != 2 or x.shape[1] != 1:

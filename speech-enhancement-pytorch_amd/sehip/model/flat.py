@@ -65,6 +65,20 @@ class FlatModule(nn.Module):
                 self._nbt_named.append((name, node, parts[-1]))
         self._register_state_dict_hook(_clone_state_hook)
 
+    def _tail_for_backward(self):
+        """FlatOptimizer's accumulators for this backward pass (sehip_unpack_grad_sums), or None: not when the pass accumulates into
+        live gradients or a data-parallel hook takes finished ranges (the sums must then follow the final buffer)."""
+        accumulating = self._grads_live and self._params[0][1].grad is not None
+        if accumulating or getattr(self, "grad_range_hook", None) is not None:
+            return None
+        return self._tail_sink
+
+    def _tail_mark(self, tail):
+        if tail is not None:
+            self._tail_done = self._tail_counted = self._tail_dirty = True
+        else:
+            self._tail_done = False
+
     def _descend(self, parts):
         node = self
         for key in parts:

@@ -643,8 +643,8 @@ class DCUNetWorkspace:
                  self.mode, ptr(self.mask_ws), ptr(self.out), stream())
         return self.out
 
-    def backward(self, dout, params, grads):
-        """dout [B, 1, F0, T0, 2] fp32 -> flat parameter gradients (overwritten)."""
+    def backward(self, dout, params, grads, tail=None):
+        """dout [B, 1, F0, T0, 2] fp32 -> flat parameter gradients (overwritten).  tail: FlatOptimizer's accumulators (plan.DCCRNWorkspace.backward)."""
         pl, tb, b, st = self.pl, self.tb, self.bufs, self.pl.st
         n, B = st.n, self.B
         self.gpack.zero_()
@@ -673,5 +673,9 @@ class DCUNetWorkspace:
                     self.gemm(name)
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
+        if tail is not None:
+            call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
+                 None, stream())
+        else:
+            call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
         return grads

@@ -301,7 +301,7 @@ class TasNetWorkspace:
              cfg.C, self.T, ptr(self.out), stream())
         return self.out
 
-    def backward(self, dout, params, grads):
+    def backward(self, dout, params, grads, tail=None):
         """dout [M, C, ac, T] fp32 -> flat parameter gradients (overwritten)."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         M, K, N, H = self.M, self.K, cfg.N, cfg.H
@@ -337,5 +337,9 @@ class TasNetWorkspace:
              cfg.audio_channels, self.T, N, cfg.L, gp(st.enc_g_off), ptr(self.codec_scratch), stream())
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
+        if tail is not None:         # FlatOptimizer's accumulators: the un-pack also takes the clipping norm / metric sums (plan.DCCRNWorkspace.backward)
+            call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
+                 None, stream())
+        else:
+            call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
         return grads

@@ -120,3 +120,50 @@ def test_accumulation_and_skipped_steps_keep_the_counter_and_the_sums_right():
     torch.cuda.synchronize()
     assert opt.sync_step() == 2
     assert abs(float(m[0]) - ref_metric()) < 1e-4 * ref_metric()
+
+
+@pytest.mark.parametrize("which", ["dcunet", "convtasnet"])
+def test_fused_tail_on_the_other_flat_models(which):
+    """DCUnet and ConvTasNet un-pack through sehip_unpack_grad_sums as well: the step counter, the clipping norm and the logged
+    per-tensor metric of a fused step against the same quantities recomputed from the un-packed gradient buffer; an accumulating
+    second pass falls back to the separate launches."""
+    import numpy as np
+    from sehip.optim import FlatOptimizer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    if which == "dcunet":
+        from sehip.model import DCUnet
+        model = DCUnet(data_type=True, model_complexity=8, model_depth=10).to(dev).train()
+        make = lambda: torch.randn(2, 1, 257, 33, 2, device=dev)
+    else:
+        from sehip.model import ConvTasNet
+        model = ConvTasNet(sources=["None", "None"], N=16, L=8, B=16, H=32, P=3, X=3, R=2, audio_channels=1).to(dev).train()
+        make = lambda: 0.3 * torch.randn(2, 1, 404, device=dev)
+    opt = FlatOptimizer(model, lr=3e-4)
+    offs = model.static.layout.tensor_offsets
+
+    def ref():
+        gr = model.flat_grads.double().cpu().numpy()
+        return (float(np.sqrt(sum(gr[offs[t]:offs[t + 1]].sum() ** 2 for t in range(len(offs) - 1)))), float(np.sqrt((gr ** 2).sum())))
+    opt.zero_grad()
+    model(make()).pow(2).mean().backward()
+    assert model._tail_done is True
+    opt.clip_grad_norm_(1e9)
+    opt.step()
+    m = opt.grad_metric()
+    torch.cuda.synchronize()
+    metric, total = ref()
+    assert opt.sync_step() == 1
+    assert abs(float(m[0]) - metric) < 1e-4 * metric + 1e-12
+    assert abs(float(m[1]) - total) < 1e-4 * total          # the pre-clip L2 norm the clipping used
+    opt.zero_grad()
+    for _ in range(2):
+        model(make()).pow(2).mean().backward()
+    assert model._tail_done is False
+    opt.clip_grad_norm_(1e9)
+    opt.step()
+    m = opt.grad_metric()
+    torch.cuda.synchronize()
+    metric, _ = ref()
+    assert opt.sync_step() == 2
+    assert abs(float(m[0]) - metric) < 1e-4 * metric + 1e-12
