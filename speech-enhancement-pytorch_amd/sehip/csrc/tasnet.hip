@@ -1194,7 +1194,8 @@ static int ctn_check(const char* who, int M, int K, int C) {
 // ~512 workgroups in all, each thread then walks 10+ rows
 static dim3 ctn_reduce_grid(int M, int K, int C) {
     const int rpb = 256 / (C >> 3) > 0 ? 256 / (C >> 3) : 1;
-    long g = (512 + M - 1) / M;
+    static const int total = getenv("SEHIP_CTN_RBLOCKS") ? atoi(getenv("SEHIP_CTN_RBLOCKS")) : 512;     // workgroups (= rows of partials) per launch
+    long g = (total + M - 1) / M;
     const long cap = ((long)K + rpb - 1) / rpb;
     if (g > cap) g = cap;
     if (g > 64) g = 64;
