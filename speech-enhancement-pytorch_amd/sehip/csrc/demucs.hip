@@ -10,6 +10,7 @@
 // count is a multiple of the number of pieces, so piece = global thread id % pieces), hence per-channel affine terms and the
 // per-channel gradient sums stay in registers.
 #include "common.h"
+float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
 #include <math.h>
 #include <stdlib.h>
 
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(256) void dmx_act_bwd_reduce_kernel(const bf16_raw*
                                                                  const double* __restrict__ stats, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int G, float eps,
                                                                  const float* __restrict__ scale, int T, int C, double* __restrict__ sums,
-                                                                 float* __restrict__ gch) {
+                                                                 float* __restrict__ gch, float* __restrict__ part) {
+    // part != NULL: the block's 2 C + Co per-channel sums go to ITS ROW of `part` by plain stores and the apply pass adds the rows
+    // into gch (dmx_colsum_share) -- flushing every block with fp32 atomics was up to 2 048 blocks x 320-10 240 addresses per launch:
+    // a ~26-us floor under each of the 32 launches of a step, whatever the tensor's size
     extern __shared__ float lds[];   // [2 C + Co] per-channel partials of the block, then [16] group partials
     const int b = blockIdx.y;
     const int Co = MODE ? C >> 1 : C, nq = Co >> 3;
@@ -470,9 +474,31 @@ __global__ __launch_bounds__(256) void dmx_act_bwd_reduce_kernel(const bf16_raw*
     atomicAdd(&lds[NV + 2 * grp_a + 1], s2a);
     if (MODE) { atomicAdd(&lds[NV + 2 * grp_g], s1g); atomicAdd(&lds[NV + 2 * grp_g + 1], s2g); }
     __syncthreads();
-    for (int i = threadIdx.x; i < NV; i += 256)
-        if (lds[i] != 0.f) atomicAdd(&gch[i], lds[i]);
+    if (part) {
+        float* row = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NV;
+        for (int i = threadIdx.x; i < NV; i += 256) row[i] = lds[i];
+    } else {
+        for (int i = threadIdx.x; i < NV; i += 256)
+            if (lds[i] != 0.f) atomicAdd(&gch[i], lds[i]);
+    }
     if (threadIdx.x < 2 * G) atomicAdd(&sums[(long)b * G * 2 + threadIdx.x], (double)lds[NV + threadIdx.x]);
+}
+
+// gch[c] += sum_r part[r][c], spread over the workgroups of the launch that hosts it as units of (256 columns, one of <= 64 row
+// groups): each unit adds its rows and flushes with one atomic per column (csrc/tasnet.hip ctn_gln_bwd_apply_kernel does the same)
+__device__ __forceinline__ void dmx_colsum_share(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ gch) {
+    const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ncb = (ncols + 255) >> 8;
+    int rg = nrows >> 3;
+    rg = rg > 64 ? 64 : (rg < 1 ? 1 : rg);
+    for (int u = bid; u < ncb * rg; u += nblk) {
+        const int c = (u % ncb) * 256 + threadIdx.x, r0 = u / ncb;
+        if (c < ncols) {
+            float acc = 0.f;
+            for (int r = r0; r < nrows; r += rg) acc += part[(size_t)r * ncols + c];
+            if (acc != 0.f) atomicAdd(&gch[c], acc);
+        }
+    }
 }
 
 // pass 2: dy[b][t][C]
@@ -480,7 +506,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void dmx_act_bwd_apply_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
                                                                 const double* __restrict__ stats, const double* __restrict__ sums,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int G, float eps,
-                                                                const float* __restrict__ scale, int T, int C, bf16_raw* __restrict__ dy) {
+                                                                const float* __restrict__ scale, int T, int C, bf16_raw* __restrict__ dy,
+                                                                const float* __restrict__ part, int nrows, float* __restrict__ gch) {
+    if (part) dmx_colsum_share(part, nrows, 2 * C + (MODE ? C >> 1 : C), gch);      // the reduce pass's partial rows -> gch (see there)
     const int b = blockIdx.y;
     const int Co = MODE ? C >> 1 : C, nq = Co >> 3;
     const Walk w = walk(nq);
@@ -1243,24 +1271,32 @@ extern "C" int sehip_dmx_act_bwd(const void* dz, const void* y, const double* st
     SEHIP_REQUIRE(!scale || stats, "dmx_act_bwd: LayerScale is only built behind a GroupNorm");
     const int nq = (mode ? C >> 1 : C) >> 3;
     const dim3 g = dmx_grid(B, T, nq);
+    float* part = nullptr;
+    int nrows = 0;
     if (stats) {
         SEHIP_REQUIRE(gamma && beta && sums && gch, "dmx_act_bwd: GroupNorm needs gamma, beta, sums and the gradient accumulator");
-        const size_t lds = ((size_t)2 * C + (mode ? C >> 1 : C) + 16) * sizeof(float);
+        const int NV = 2 * C + (mode ? C >> 1 : C);
+        const size_t lds = ((size_t)NV + 16) * sizeof(float);
         SEHIP_REQUIRE(lds <= 64 * 1024, "dmx_act_bwd: C=%d does not fit the LDS partials", C);
+        // one row of per-channel sums per workgroup (per-stream pool of csrc/wgrad3.hip; none available -- e.g. a capture that would
+        // have to grow it -- or SEHIP_DMX_ATOMIC_FLUSH: the workgroups flush with atomics as in rounds 2-4)
+        static const bool atomic_flush = getenv("SEHIP_DMX_ATOMIC_FLUSH") != nullptr;
+        nrows = (int)(g.x * g.y);
+        part = atomic_flush ? nullptr : sehip_wgrad_scratch((hipStream_t)stream, (size_t)nrows * NV * sizeof(float));
         if (mode)
             dmx_act_bwd_reduce_kernel<1><<<g, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, gamma, beta, G, eps, scale, T,
-                                                                                C, sums, gch);
+                                                                                C, sums, gch, part);
         else
             dmx_act_bwd_reduce_kernel<0><<<g, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, gamma, beta, G, eps, scale, T,
-                                                                                C, sums, gch);
+                                                                                C, sums, gch, part);
         SEHIP_CHECK_LAUNCH("dmx_act_bwd_reduce");
     }
     if (mode)
         dmx_act_bwd_apply_kernel<1><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, sums, gamma, beta, G, eps, scale, T, C,
-                                                                         (bf16_raw*)dy);
+                                                                         (bf16_raw*)dy, part, nrows, gch);
     else
         dmx_act_bwd_apply_kernel<0><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, sums, gamma, beta, G, eps, scale, T, C,
-                                                                         (bf16_raw*)dy);
+                                                                         (bf16_raw*)dy, part, nrows, gch);
     SEHIP_CHECK_LAUNCH("dmx_act_bwd_apply");
     return 0;
 }
