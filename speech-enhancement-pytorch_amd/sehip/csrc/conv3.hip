@@ -355,11 +355,7 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-#ifdef C3_TEST_ZEROINIT
-        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#else
-        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){bv[a].x, bv[a].y, bv[a].z, bv[a].w};
-#endif
+        for (int bb = 0; bb < TM; ++bb) acc[a][bb] = (f32x4){bv[a].x, bv[a].y, bv[a].z, bv[a].w};     // the bias is the accumulators' initial value
     c3_wait_step<H, MAXP, DW>(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -542,7 +538,6 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
                     live ? make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])) : make_uint2(0u, 0u);
             }
         }
-#ifndef C3_TEST_NOSTATS
         if (with_stats) {
             // Batch statistics of the ComplexBatchNorm that follows, from the values as stored, ON THE MATRIX CORES (round 5; the VALU
             // form was ~700 instructions per wave with all eight waves of the CU in it at once: 6 000 of the epilogue's cycles).
@@ -588,7 +583,6 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
                 }
             }
         }
-#endif
 #ifdef C3_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         st_e1 = C3_T();
