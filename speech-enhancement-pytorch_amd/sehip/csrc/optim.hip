@@ -70,22 +70,43 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, fl
         coef = gscale * fminf(1.f, max_norm / (total + 1e-6f));
     }
     const float step_size = lr / bc1;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-        float gi = g[i] * coef;
-        g[i] = gi;
-        float pi = p[i];
+    // 16 bytes per lane and array (the four-byte form moved Demucs' 134 M parameters at 4.1 TB/s: 0.92 ms at the end of the step with
+    // nothing beside it); the scaled gradient is written back only when the scale is not exactly 1 (unclipped single-replica steps:
+    // one of the eight streams less)
+    const bool wr_g = coef != 1.f;
+    const long n4 = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? (n >> 2) : 0;
+    auto upd = [&](float gi_in, float pi, float& mi, float& vi, float& gout) {
+        float gi = gi_in * coef;
+        gout = gi;
         if (wd != 0.f) gi += wd * pi;
         if (mode == 0) {
-            float mi = m[i] * b1 + (1.f - b1) * gi;
-            float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-            m[i] = mi; v[i] = vi;
+            mi = mi * b1 + (1.f - b1) * gi;
+            vi = vi * b2 + (1.f - b2) * gi * gi;
             const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-            p[i] = pi - step_size * (mi / denom);
-        } else {
-            float mi = first_step ? gi : (m[i] * b1 + gi);
-            m[i] = mi;
-            p[i] = pi - lr * (b1 != 0.f ? mi : gi);
+            return pi - step_size * (mi / denom);
         }
+        mi = first_step ? gi : (mi * b1 + gi);
+        return pi - lr * (b1 != 0.f ? mi : gi);
+    };
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        float4 g4 = reinterpret_cast<const float4*>(g)[i], p4 = reinterpret_cast<const float4*>(p)[i];
+        float4 m4 = reinterpret_cast<const float4*>(m)[i];
+        float4 v4 = mode == 0 ? reinterpret_cast<const float4*>(v)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 go;
+        p4.x = upd(g4.x, p4.x, m4.x, v4.x, go.x); p4.y = upd(g4.y, p4.y, m4.y, v4.y, go.y);
+        p4.z = upd(g4.z, p4.z, m4.z, v4.z, go.z); p4.w = upd(g4.w, p4.w, m4.w, v4.w, go.w);
+        if (wr_g) reinterpret_cast<float4*>(g)[i] = go;
+        reinterpret_cast<float4*>(m)[i] = m4;
+        if (mode == 0) reinterpret_cast<float4*>(v)[i] = v4;
+        reinterpret_cast<float4*>(p)[i] = p4;
+    }
+    for (long i = 4 * n4 + blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {      // the last n % 4 (or everything, unaligned)
+        float mi = m[i], vi = mode == 0 ? v[i] : 0.f, go;
+        const float pn = upd(g[i], p[i], mi, vi, go);
+        if (wr_g) g[i] = go;
+        m[i] = mi;
+        if (mode == 0) v[i] = vi;
+        p[i] = pn;
     }
 }
 
@@ -223,8 +244,9 @@ extern "C" int sehip_opt_step_g(float* params, float* grads, float* m, float* v,
     if (n == 0) return 0;
     const double bc1 = mode == 0 ? 1.0 - pow((double)beta1, step) : 1.0;
     const double bc2 = mode == 0 ? 1.0 - pow((double)beta2, step) : 1.0;
-    int grid = cdiv(n, 256 * 4);
+    int grid = cdiv(n, 256 * 16);
     if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
     opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
                                                            (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev,
                                                            grad_scale, guard, nullptr, 0, nullptr, nullptr, nullptr);
@@ -245,8 +267,9 @@ extern "C" int sehip_opt_step_m(float* params, float* grads, float* m, float* v,
     SEHIP_REQUIRE(grad_scale > 0.f && sumsq && tensor_sums && metric && ntensors > 0, "opt_step_m: bad arguments");
     const double bc1 = mode == 0 ? 1.0 - pow((double)beta1, step) : 1.0;
     const double bc2 = mode == 0 ? 1.0 - pow((double)beta2, step) : 1.0;
-    int grid = cdiv(n, 256 * 4);
+    int grid = cdiv(n, 256 * 16);
     if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
     opt_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps,
                                                            (float)bc1, (float)sqrt(bc2), weight_decay, mode, step == 1, step_dev,
                                                            grad_scale, guard, tensor_sums, ntensors, metric, next_sumsq, next_tensor_sums);
