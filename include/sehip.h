@@ -341,6 +341,12 @@ int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n,
  * The accumulators must be zero on entry (sehip_opt_step_m clears the next step's).  Atomics: not in the deterministic schedule. */
 int sehip_unpack_grad_sums(const float* packed, const int* table4, long n, float* grads, const long* offsets, int ntensors,
                            double* sumsq, float* tensor_sums, int* counter, const unsigned* guard, void* stream);
+/* The same for the one-entry-per-parameter tables (sehip_unpack_grad1 + sehip_unpack_grad_list over the WHOLE vector: Demucs): the
+ * main launch, then the launch for the parameters with several entries, which corrects the accumulators by what it adds. */
+int sehip_unpack_grad1_sums(const float* packed, const int* table1, long n, float* grads, const long* offsets, int ntensors, double* sumsq,
+                            float* tensor_sums, int* counter, const unsigned* guard, void* stream);
+int sehip_unpack_grad_list_sums(const float* packed, const int* list, const int* table4, long m, float* grads, const long* offsets,
+                                int ntensors, double* sumsq, float* tensor_sums, void* stream);
 /* compact forms for large models (Demucs: 133.7 M parameters):
  *   unpack_grad1    : one entry per parameter (table1 [n]); unpack_grad_list: grads[list[i]] = sum of table4[i] for the few
  *                     parameters with several entries (run after unpack_grad1, which leaves their first entry there)

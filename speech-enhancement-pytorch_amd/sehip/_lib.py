@@ -92,6 +92,8 @@ _PROTOS = {
     "sehip_unpack_grad": [P, P, L, P, P],
     "sehip_unpack_grad_sums": [P, P, L, P, P, I, P, P, P, P, P],
     "sehip_unpack_grad1": [P, P, L, P, P],
+    "sehip_unpack_grad1_sums": [P, P, L, P, P, I, P, P, P, P, P],
+    "sehip_unpack_grad_list_sums": [P, P, P, L, P, P, I, P, P, P],
     "sehip_unpack_grad_list": [P, P, P, L, P, P],
     "sehip_pack_bf16_runs": [P, P, P, L, P, P],
     "sehip_pack_bf16_runs_to": [P, P, P, P, L, P, P],

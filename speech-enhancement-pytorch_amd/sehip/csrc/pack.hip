@@ -176,6 +176,75 @@ __global__ __launch_bounds__(256) void pack_bf16_runs_kernel(const float* __rest
     }
 }
 
+// The one-entry-per-parameter un-pack (Demucs) WITH the sums of the fused optimizer tail, as unpack_grad_sums_kernel: every block
+// takes a contiguous range, walks the tensors inside it (16-byte table / gradient accesses where a tensor's part of the range allows,
+// single elements at its unaligned ends) and leaves the per-tensor sums and the sum of squares in the optimizer's accumulators.
+__global__ __launch_bounds__(256) void unpack_grad1_sums_kernel(const float* __restrict__ packed, const int* __restrict__ tab, long n,
+                                                                float* __restrict__ grads, const long* __restrict__ offsets, int ntensors,
+                                                                double* __restrict__ sumsq, float* __restrict__ tsums,
+                                                                int* __restrict__ counter, const unsigned* __restrict__ guard) {
+    __shared__ float red[4];
+    __shared__ int first;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counter && !(guard && guard[0] != 0u)) counter[0] += 1;
+    const long per = ((n + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;
+    long lo = (long)blockIdx.x * per;
+    const long hi = min(n, lo + per);
+    if (lo >= hi) return;
+    if (threadIdx.x == 0) {          // the tensor that holds parameter lo: largest t with offsets[t] <= lo
+        int a = 0, b = ntensors - 1;
+        while (a < b) {
+            const int mid = (a + b + 1) >> 1;
+            if (offsets[mid] <= lo) a = mid; else b = mid - 1;
+        }
+        first = a;
+    }
+    __syncthreads();
+    int t = first;
+    float q = 0.f;
+    while (lo < hi) {
+        const long e = min(hi, offsets[t + 1]);
+        if (e > lo) {
+            float acc = 0.f;
+            const long a4 = min(e, (lo + 3) & ~3L), b4 = max(a4, e & ~3L);       // [lo, a4) single, [a4, b4) by four, [b4, e) single
+            for (long i = lo + threadIdx.x; i < a4; i += 256) { const float g = term(packed, tab[i]); grads[i] = g; acc += g; q += g * g; }
+            for (long v = (a4 >> 2) + threadIdx.x; v < (b4 >> 2); v += 256) {
+                const int4 en = *reinterpret_cast<const int4*>(tab + 4 * v);
+                const float4 g = make_float4(term(packed, en.x), term(packed, en.y), term(packed, en.z), term(packed, en.w));
+                *reinterpret_cast<float4*>(grads + 4 * v) = g;
+                acc += (g.x + g.y) + (g.z + g.w);
+                q += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+            }
+            for (long i = b4 + threadIdx.x; i < e; i += 256) { const float g = term(packed, tab[i]); grads[i] = g; acc += g; q += g * g; }
+            acc = block_sum<4>(acc, red);
+            if (threadIdx.x == 0) atomicAdd(&tsums[t], acc);
+            lo = e;
+        }
+        ++t;
+    }
+    q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) atomicAdd(sumsq, (double)q);
+}
+// ... and the parameters with several entries: the launch above left the FIRST entry's value in grads and in the sums; this one
+// writes the whole sum and corrects the accumulators by the difference
+__global__ __launch_bounds__(256) void unpack_grad_list_sums_kernel(const float* __restrict__ packed, const int* __restrict__ list,
+                                                                    const int4* __restrict__ tab, long m, float* __restrict__ grads,
+                                                                    const long* __restrict__ offsets, int ntensors,
+                                                                    double* __restrict__ sumsq, float* __restrict__ tsums) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
+        const int4 e = tab[i];
+        const float old = term(packed, e.x), g = old + term(packed, e.y) + term(packed, e.z) + term(packed, e.w);
+        const long pi = list[i];
+        grads[pi] = g;
+        int a = 0, b = ntensors - 1;
+        while (a < b) {
+            const int mid = (a + b + 1) >> 1;
+            if (offsets[mid] <= pi) a = mid; else b = mid - 1;
+        }
+        atomicAdd(&tsums[a], g - old);
+        atomicAdd(sumsq, (double)g * g - (double)old * old);
+    }
+}
+
 static int grid_of(long n) { long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
 
 extern "C" int sehip_pack_bf16(const float* params, const int* table, long n, void* out_bf16, void* stream) {
@@ -241,6 +310,29 @@ extern "C" int sehip_unpack_grad_list(const float* packed, const int* list, cons
     if (m == 0) return 0;
     unpack_grad_list_kernel<<<grid_of(m), 256, 0, (hipStream_t)stream>>>(packed, list, (const int4*)table4, m, grads);
     SEHIP_CHECK_LAUNCH("unpack_grad_list");
+    return 0;
+}
+
+// sehip_unpack_grad1 / sehip_unpack_grad_list over the WHOLE parameter vector with the sums of the fused optimizer tail
+// (sehip_unpack_grad_sums for the one-entry tables of Demucs; same accumulators, same counter / guard semantics).  The list launch
+// must follow the main one on the same stream.
+extern "C" int sehip_unpack_grad1_sums(const float* packed, const int* table1, long n, float* grads, const long* offsets, int ntensors,
+                                       double* sumsq, float* tensor_sums, int* counter, const unsigned* guard, void* stream) {
+    SEHIP_REQUIRE(n >= 0 && ntensors > 0 && offsets && sumsq && tensor_sums, "unpack_grad1_sums: bad arguments");
+    SEHIP_REQUIRE(!sehip_deterministic(), "unpack_grad1_sums: not part of the deterministic schedule (fp32 / double atomics)");
+    SEHIP_REQUIRE(((((uintptr_t)table1) | ((uintptr_t)grads)) & 15) == 0, "unpack_grad1_sums: table / gradients must be 16-byte aligned");
+    if (n == 0) return 0;
+    unpack_grad1_sums_kernel<<<2048, 256, 0, (hipStream_t)stream>>>(packed, table1, n, grads, offsets, ntensors, sumsq, tensor_sums, counter, guard);
+    SEHIP_CHECK_LAUNCH("unpack_grad1_sums");
+    return 0;
+}
+extern "C" int sehip_unpack_grad_list_sums(const float* packed, const int* list, const int* table4, long m, float* grads, const long* offsets,
+                                           int ntensors, double* sumsq, float* tensor_sums, void* stream) {
+    SEHIP_REQUIRE(m >= 0 && ntensors > 0 && offsets && sumsq && tensor_sums, "unpack_grad_list_sums: bad arguments");
+    if (m == 0) return 0;
+    unpack_grad_list_sums_kernel<<<grid_of(m), 256, 0, (hipStream_t)stream>>>(packed, list, (const int4*)table4, m, grads, offsets, ntensors, sumsq,
+                                                                              tensor_sums);
+    SEHIP_CHECK_LAUNCH("unpack_grad_list_sums");
     return 0;
 }
 

@@ -145,7 +145,9 @@ class Demucs(FlatModule):
     def _run_backward(self, ws, grad_out):
         g = grad_out.contiguous().float()
         hook = self.grad_range_hook if not (self._grads_live and self._params[0][1].grad is not None) else None   # not when accumulating
-        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, range_ready=hook))
+        tail = self._tail_for_backward()              # FlatOptimizer's accumulators (single replica, not accumulating)
+        self._backward_into_flat(lambda dst: ws.backward(g, self._flat, dst, range_ready=hook, tail=tail))
+        self._tail_mark(tail)
 
     def forward(self, mix):
         if mix.dim() != 3 or mix.shape[1] != self.audio_channels:

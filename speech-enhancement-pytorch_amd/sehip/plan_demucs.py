@@ -867,9 +867,18 @@ class DemucsWorkspace:
         call("sehip_pack_bf16_runs_to", ptr(params), tb.runs.data_ptr() + lo, tb.pack_dst.data_ptr() + lo // 2, ptr(tb.side), hi - lo,
              tb.wpack.data_ptr(), on_stream)
 
-    def _unpack(self, lo, hi, grads, on_stream):
-        """flat parameter gradients [lo, hi) (multiples of 4) from the packed-gradient buffer"""
+    def _unpack(self, lo, hi, grads, on_stream, tail=None):
+        """flat parameter gradients [lo, hi) (multiples of 4) from the packed-gradient buffer.  tail (whole vector only): FlatOptimizer's
+        accumulators -- the un-pack also takes the clipping norm's and the metric's sums (plan.DCCRNWorkspace.backward)"""
         tb, st = self.tb, self.st
+        if tail is not None:
+            assert lo == 0 and hi == st.layout.n_params
+            call("sehip_unpack_grad1_sums", ptr(self.gpack), ptr(tb.utab1), hi, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
+                 (self.lstm_sync[60:61].data_ptr() if self.st.lstms else None), on_stream)      # guard: the sticky hand-off word
+            if st.ulist.size:
+                call("sehip_unpack_grad_list_sums", ptr(self.gpack), ptr(tb.ulist), ptr(tb.utab4), int(st.ulist.size), ptr(grads), tail[2],
+                     tail[3], tail[0], tail[1], on_stream)
+            return
         call("sehip_unpack_grad1", ptr(self.gpack), tb.utab1.data_ptr() + 4 * lo, hi - lo, grads.data_ptr() + 4 * lo, on_stream)
         a, b = np.searchsorted(st.ulist, [lo, hi])
         if b > a:
@@ -889,7 +898,7 @@ class DemucsWorkspace:
             ev.append(e)
         self._bwd_pack_events = ev
 
-    def backward(self, dout, params, grads, range_ready=None):
+    def backward(self, dout, params, grads, range_ready=None, tail=None):
         """dout [B, S, ac, T] fp32 -> flat parameter gradients (overwritten).
         range_ready(lo, hi, stream): called as soon as grads[lo:hi] is final ON `stream` (a torch stream); the ranges tile
         [0, n_params): the decoder's parameters after the decoder's backward pass, then the encoder layers that hold at least
@@ -993,7 +1002,7 @@ class DemucsWorkspace:
                 done_from = enc_off[i]
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
-        self._unpack(0, done_from, grads, stream())
+        self._unpack(0, done_from, grads, stream(), tail=tail if range_ready is None else None)
         if range_ready is not None:
             range_ready(0, done_from, torch.cuda.current_stream())
             call("sehip_stream_depend", stream(), self.comm.cuda_stream, self._event())

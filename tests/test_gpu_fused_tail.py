@@ -122,9 +122,9 @@ def test_accumulation_and_skipped_steps_keep_the_counter_and_the_sums_right():
     assert abs(float(m[0]) - ref_metric()) < 1e-4 * ref_metric()
 
 
-@pytest.mark.parametrize("which", ["dcunet", "convtasnet"])
+@pytest.mark.parametrize("which", ["dcunet", "convtasnet", "demucs"])
 def test_fused_tail_on_the_other_flat_models(which):
-    """DCUnet and ConvTasNet un-pack through sehip_unpack_grad_sums as well: the step counter, the clipping norm and the logged
+    """DCUnet and ConvTasNet un-pack through sehip_unpack_grad_sums as well, Demucs through sehip_unpack_grad1_sums: the step counter, the clipping norm and the logged
     per-tensor metric of a fused step against the same quantities recomputed from the un-packed gradient buffer; an accumulating
     second pass falls back to the separate launches."""
     import numpy as np
@@ -135,6 +135,10 @@ def test_fused_tail_on_the_other_flat_models(which):
         from sehip.model import DCUnet
         model = DCUnet(data_type=True, model_complexity=8, model_depth=10).to(dev).train()
         make = lambda: torch.randn(2, 1, 257, 33, 2, device=dev)
+    elif which == "demucs":       # one-entry un-pack tables + the list of multi-entry parameters (sehip_unpack_grad1_sums / _list_sums)
+        from sehip.model import Demucs
+        model = Demucs(sources=["a", "b"], audio_channels=1, channels=32, depth=4).to(dev).train()
+        make = lambda: 0.3 * torch.randn(2, 1, 9000, device=dev)
     else:
         from sehip.model import ConvTasNet
         model = ConvTasNet(sources=["None", "None"], N=16, L=8, B=16, H=32, P=3, X=3, R=2, audio_channels=1).to(dev).train()
