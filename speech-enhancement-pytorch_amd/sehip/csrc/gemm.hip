@@ -2073,6 +2073,10 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const sehip_gemm_desc 
     const int tlo = second ? d.src[1].tlo : d.src[0].tlo, thi = second ? d.src[1].thi : d.src[0].thi;
     const bf16_raw* sbase = reinterpret_cast<const bf16_raw*>(second ? d.src[1].ptr : d.src[0].ptr) + (cc * 64 - (second ? C0 : 0));
     const int tfirst = d.cv2_t0, f0 = d.cv2_fadd;
+    // lattice steps of the source (1, or 2 for the tap-parity classes of DCUnet's strided encoder convolutions, src/model/dcunet.py:
+    // 165-212): row (t, j) and tap (a', b') read source frame TS (t + a') + cv2_t0, source row FS (j + b') + cv2_fadd -- the patch is
+    // the same (TB + NKT - 1) x (J + NF - 1) positions, taken every TS-th frame / FS-th row
+    const int TS = d.tmul > 1 ? d.tmul : 1, FS = d.fmul > 1 ? d.fmul : 1;
     const int NPF = TB + NKT - 1;
     const int NP = NPF * FR * 8;
 
@@ -2104,9 +2108,9 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const sehip_gemm_desc 
         p_goff[i] = INT_MIN; p_lds[i] = -1;
         if (idx < NP) {
             const int pp = idx / (FR * 8), rem = idx - pp * (FR * 8);
-            const int f = f0 + (rem >> 3);
+            const int f = f0 + FS * (rem >> 3);
             p_lds[i] = ((pp * FR + (rem >> 3)) * PPW + (rem & 7) * 8) | (pp << 16);
-            if (f >= 0 && f < sF) p_goff[i] = (pp * sF + f) * sC + (rem & 7) * 8;
+            if (f >= 0 && f < sF) p_goff[i] = (pp * TS * sF + f) * sC + (rem & 7) * 8;
         }
     }
     const bf16_raw* g_ptr[GPT];
@@ -2138,10 +2142,10 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const sehip_gemm_desc 
 #define CW2_FETCH(mt_)                                                                                             \
     {                                                                                                              \
         const int b_ = (mt_) / tblocks, t0_ = ((mt_) - b_ * tblocks) * TB;                                         \
-        const bf16_raw* tb_ = sbase + ((long)b_ * sT + t0_ + tfirst) * sF * sC;                                    \
+        const bf16_raw* tb_ = sbase + ((long)b_ * sT + t0_ * TS + tfirst) * sF * sC;                               \
         _Pragma("unroll") for (int i = 0; i < CW2_NPS; ++i) {                                                      \
             pr[i] = make_uint4(0u, 0u, 0u, 0u);                                                                    \
-            const int ts_ = t0_ + tfirst + (p_lds[i] >> 16);                                                       \
+            const int ts_ = t0_ * TS + tfirst + TS * (p_lds[i] >> 16);                                             \
             if (p_goff[i] != INT_MIN && ts_ >= tlo && ts_ < thi) pr[i] = *reinterpret_cast<const uint4*>(tb_ + p_goff[i]); \
         }                                                                                                          \
         _Pragma("unroll") for (int u = 0; u < GPT; ++u) {                                                          \
@@ -2212,7 +2216,8 @@ static int try_conv_wgrad2(const sehip_gemm_desc& d, hipStream_t st) {
     static const bool disabled = getenv("SEHIP_NO_PATCH") != nullptr || getenv("SEHIP_NO_WGRAD2") != nullptr;
     if (disabled || d.cv2_nkt <= 0) return 0;
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
-    if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.fmul != 1 || d.tmul > 1) return 0;
+    if ((C0 & 63) || (C1 & 63) || (d.Npad & 63) || d.fmul < 1 || d.fmul > 2 || d.tmul > 2) return 0;
+    const int TSh = d.tmul > 1 ? d.tmul : 1;
     if (d.K != d.cv2_nkt * d.cv2_nf * (C0 + C1)) return 0;
     if (d.src[1].ptr && (d.src[1].T != d.src[0].T || d.src[1].F != d.src[0].F)) return 0;      // one grid for both sources
     const int J = d.J;
@@ -2227,7 +2232,7 @@ static int try_conv_wgrad2(const sehip_gemm_desc& d, hipStream_t st) {
     const int NPF = TB + d.cv2_nkt - 1;
     if (NPF * FR * 8 > CW2_NPS * 512 || NPF * FR * 80 > 65535) return 0;
     for (int s = 0; s < 2; ++s)
-        if (d.src[s].ptr && (long)d.src[s].T * d.src[s].F * d.src[s].C * (NPF + 1) >= (1L << 31)) return 0;   // 32-bit piece offsets
+        if (d.src[s].ptr && (long)d.src[s].T * d.src[s].F * d.src[s].C * (NPF * TSh + 1) >= (1L << 31)) return 0;   // 32-bit piece offsets
     const size_t lds = (size_t)NKS * 32 * 80 * 2 + (size_t)NPF * FR * 80 * 2;
     if (lds > 160 * 1024) return 0;
     const int B = d.M / (d.TT * d.J);
@@ -2252,7 +2257,7 @@ static int try_conv_wgrad2(const sehip_gemm_desc& d, hipStream_t st) {
     }
     CW2_CASE(4, 3, 5) CW2_CASE(3, 3, 5) CW2_CASE(4, 3, 4) CW2_CASE(3, 3, 4)
     CW2_CASE(4, 2, 4) CW2_CASE(3, 2, 4) CW2_CASE(4, 2, 5) CW2_CASE(3, 2, 5)
-    CW2_CASE(2, 2, 4) CW2_CASE(2, 3, 4)
+    CW2_CASE(2, 2, 4) CW2_CASE(2, 3, 4) CW2_CASE(3, 1, 4) CW2_CASE(2, 1, 4)
 #undef CW2_CASE
     return 0;
 }

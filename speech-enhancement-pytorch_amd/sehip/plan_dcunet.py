@@ -213,6 +213,7 @@ class DCUNetPlan:
             return [(src, toff, fadd, 8 * q) for q in range(c // 8)]
 
         # ---------------- encoders ----------------
+        self.enc_wg = {}       # encoder -> the products whose weight-gradient twins make up its weight gradient
         for i in range(n):
             (kt, kf), (s_t, s_f), (p_t, p_f) = t["enc_k"][i], t["enc_s"][i], t["enc_p"][i]
             cin_r, cout_r = t["enc_ch"][i], t["enc_ch"][i + 1]
@@ -249,6 +250,43 @@ class DCUNetPlan:
                           Tout, Fout, s_f, [(src, "all")], [(f"ye{i}", 0, 1, 0)])
             sp.tmul, sp.dst_tmul = s_t, [1]
             self.specs[sp.name] = sp
+            self.enc_wg[i] = [sp.name]
+            # Weight gradient by the parity class of the TAP: the taps a = pa (mod s_t), b = pb (mod s_f) read the sub-lattice
+            # (s_t t + pa - p_t + s_t a', s_f j + pb - p_f + s_f b') of the input, on which they are a stride-1 convolution of
+            # ceil-half the taps -- the shape the patch-based weight gradient stages once per tile (csrc/gemm.hip conv_wgrad2_kernel:
+            # cv2_* with the descriptor's tmul / fmul as the lattice step).  As ONE table-gathered product the encoders' weight
+            # gradients ran at 0.085 of the MFMA peak (enc1: 660 us for 141 GF).  Weight-gradient-only products (kind "wg").
+            # (only where the row space is long enough: four launches of the deeper layers' 16 k / 8 k rows measured slower than their one
+            #  generic product -- enc3 103 vs 75 us, enc4 81 vs 45 us)
+            if (i >= 1 and (2 * cin_s) % 64 == 0 and Tout * Fout >= int(os.environ.get("SEHIP_DCUNET_ENC_WG_MIN", "1024"))
+                    and not os.environ.get("SEHIP_DCUNET_NO_ENC_WG_CLASSES")):
+                cls = []
+                for pa in range(s_t):
+                    for pb in range(s_f):
+                        at = [a for a in range(kt) if a % s_t == pa]
+                        bf_ = [b for b in range(kf) if b % s_f == pb]
+                        if at and bf_:
+                            cls.append((pa, pb, at, bf_))
+                supported = {(4, 3), (3, 3), (4, 2), (3, 2), (2, 2), (2, 3), (3, 1), (2, 1)}
+                if all((len(at), len(bf_)) in supported for _, _, at, bf_ in cls):
+                    names = []
+                    for pa, pb, at, bf_ in cls:
+                        rows = []
+                        for a in at:
+                            for b in bf_:
+                                rows += wide(0, a - p_t, b - p_f, 2 * cin_s)
+                        wi_ = np.concatenate([full[:, :, a, b] for a in at for b in bf_], 1)      # [2co, taps x 2ci]: k order (a', b', channel)
+                        wn_ = np.concatenate([neg[:, :, a, b] for a in at for b in bf_], 1)
+                        name = f"enc{i}.wg{pa}{pb}"
+                        c = GemmSpec(name, rows, wi_, wn_, 2 * cout_s,
+                                     eff_bias(pre + "conv_re", pre + "conv_im", cout_s, cout_r) if not names else None,
+                                     Tout, Fout, s_f, [(src, "all")], [(f"ye{i}", 0, 1, 0)], kind="wg")
+                        c.tmul, c.dst_tmul = s_t, [1]
+                        c.conv2 = (len(at), len(bf_), bf_[0] - p_f, at[0] - p_t)      # (nkt, nf, fadd, t0); tap step = (tmul, fmul)
+                        self.specs[name] = c
+                        names.append(name)
+                    self.enc_wg[i] = names
+                    sp.no_wgrad = True
             self.bn.append((f"encoder{i}.bn.", f"e{i}", cout_s, cout_r))
             if i >= 1:
                 # dgrad by the parity class of the input position
@@ -346,10 +384,11 @@ class DCUNetPlan:
         for name, s in self.specs.items():
             s.kt_off = kta.add(s.ktab)
             s.nt_off = nta.add(s.ntab)
-            s.w_off = wa.add(enc_entry(s.widx, s.wneg).reshape(-1))
-            if s.bias_pairs is not None:
-                s.b_off = ba.add(s.bias_pairs)
-            if s.kind == "fwd":
+            if s.kind != "wg":         # (weight-gradient-only products read no packed weights / bias)
+                s.w_off = wa.add(enc_entry(s.widx, s.wneg).reshape(-1))
+                if s.bias_pairs is not None:
+                    s.b_off = ba.add(s.bias_pairs)
+            if (s.kind == "fwd" and not getattr(s, "no_wgrad", False)) or s.kind == "wg":
                 s.dw_off = ga.reserve(s.Npad * s.K)
                 if s.bias_pairs is not None:
                     # the parity classes of one transposed convolution cover disjoint output positions: their bias sums
@@ -524,7 +563,7 @@ class DCUNetWorkspace:
                 d.dst[q].tmul = s.dst_tmul[q]
             d.ktab = self.ktab_dev.data_ptr() + 16 * s.kt_off
             d.ntab = tb.ntab.data_ptr() + 16 * s.nt_off
-            d.W = tb.wpack.data_ptr() + 2 * s.w_off
+            d.W = tb.wpack.data_ptr() + 2 * s.w_off if s.w_off is not None else None
             # Every convolution here feeds a BatchNorm, which cancels its bias exactly (src/model/dcunet.py:323-338 adds it, :374-386
             # removes it): the products store their output WITHOUT the bias (d.bias stays NULL) and the BatchNorm finalize takes
             # the bias as `shift` (sehip_rbn_finalize_s) for the running mean / the inference mean.  With small-amplitude spectra the
@@ -536,7 +575,8 @@ class DCUNetWorkspace:
                 rb, db_ = self.bufs[s.res], self.bufs[s.dsts[0][0]]
                 assert (rb.Tst, rb.F, rb.C) == (db_.Tst, db_.F, db_.C)
                 d.res = rb.ptr
-            self.desc[name] = d
+            if s.kind != "wg":         # (weight-gradient-only products have no forward launch)
+                self.desc[name] = d
             if s.dw_off is not None:   # weight-gradient twin: dOut replaces the destination
                 w = CGemmDesc.from_buffer_copy(d)
                 w.dW = self.gpack.data_ptr() + 4 * s.dw_off
@@ -667,7 +707,8 @@ class DCUNetWorkspace:
             self.gemm(f"dec{j}.dg")
         for i in range(n - 1, -1, -1):
             self.bn_backward(f"encoder{i}.bn.", st.enc_c[i], st.enc_cr[i], b[f"dze{i}"], b[f"ye{i}"], b[f"dye{i}"])
-            self.wgrad(f"enc{i}.fwd")
+            for name in pl.enc_wg[i]:
+                self.wgrad(name)
             if i > 0:
                 for name in [k for k in pl.specs if k.startswith(f"enc{i}.dg")]:
                     self.gemm(name)
