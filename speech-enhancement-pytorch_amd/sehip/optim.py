@@ -89,6 +89,8 @@ class FlatOptimizer(torch.optim.Optimizer):
             call("sehip_opt_step_m", ptr(params), ptr(grads), ptr(self._m), ptr(self._v), params.numel(), ptr(s["sumsq" + cur]),
                  self.max_norm, g["lr"], b1, b2, g["eps"], self._step, ptr(self._step_dev), g["weight_decay"], mode, 1.0, ptr(guard),
                  ptr(s["tsums" + cur]), s["tsums"].numel(), ptr(s["metric"]), ptr(s["sumsq" + nxt]), ptr(s["tsums" + nxt]), stream())
+            if self._set == 1:                             # this launch has just cleared set 0 (its `next` set)
+                self._set0_stale = False
             self._set ^= 1
             self._metric_fresh = True
             self.max_norm = 0.0
@@ -103,6 +105,9 @@ class FlatOptimizer(torch.optim.Optimizer):
         call("sehip_opt_begin_g", ptr(self._step_dev), 0 if counted else 1, ptr(s["sumsq"]), ptr(s["tsums"]), s["tsums"].numel(), ptr(guard),
              stream())
         self._tsums_clear = True
+        # (this path -- and grad_metric() behind it -- leaves THIS step's sums in set 0: sehip_opt_begin_g clears at the START of a
+        #  step only.  A fused tail armed on set 0 afterwards would add to them: _arm_fused_tail clears the set first -- ADVICE r5)
+        self._set0_stale = True
         if self.max_norm > 0:
             call("sehip_grad_sumsq_acc", ptr(grads), grads.numel(), ptr(s["sumsq"]), stream())
         if self.kind == "adam":
@@ -126,6 +131,7 @@ class FlatOptimizer(torch.optim.Optimizer):
         offs = self.model.static.layout.tensor_offsets
         fn = "sehip_grad_metric_acc" if getattr(self, "_tsums_clear", False) else "sehip_grad_metric"     # step() has just cleared tsums
         self._tsums_clear = False
+        self._set0_stale = True                            # (the per-tensor sums of set 0 now hold this step's values)
         call(fn, ptr(grads), ptr(s["offsets"]), s["tsums"].numel(), int((offs[1:] - offs[:-1]).max()),
              ptr(s["sumsq"]), ptr(s["tsums"]), ptr(s["metric"]), stream())
         if self.grad_scale != 1.0:
@@ -148,21 +154,39 @@ class FlatOptimizer(torch.optim.Optimizer):
         if not hasattr(model, "_tail_sink"):
             return
         model._tail_sink = None
-        if getattr(model, "_tail_counted", False) or getattr(model, "_tail_dirty", False):
+        from ._lib import lib
+        import os
+        capturing = model.flat_params.is_cuda and torch.cuda.is_current_stream_capturing()
+        stale0 = getattr(self, "_set0_stale", False) and getattr(self, "_set", 0) == 0 and self._scratch is not None
+        if capturing:
+            # The repairs below are eager one-off corrections: recorded into a hipGraph they would be replayed with every step (ADVICE
+            # r5).  Stale sums can wait for the next eager zero_grad() (a capture never arms the fused tail); a counted step cannot --
+            # the captured step() would record "do not count" for every replay.
+            if getattr(model, "_tail_counted", False):
+                raise SehipError("FlatOptimizer.zero_grad() inside a stream capture after a fused backward pass whose step() never came: "
+                                 "call zero_grad() once outside the capture first")
+        elif getattr(model, "_tail_counted", False) or getattr(model, "_tail_dirty", False) or stale0:
             self._ensure_state()
             s = self._scratch
             cur = "" if self._set == 0 else "1"
-            if model._tail_counted:                        # a fused backward pass whose step() never came: un-count it
-                self._step_dev.sub_(1)
+            if getattr(model, "_tail_counted", False):     # a fused backward pass whose step() never came: un-count it
+                # (the un-pack kernel does NOT count when the guard word is set -- a hand-off time-out: only a counted step is
+                #  un-counted, or the counter could reach 0, where Adam's bias correction divides by 1 - b1^0 = 0)
+                gfn = getattr(model, "step_guard", None)
+                guard = gfn() if gfn is not None else None
+                if guard is None:
+                    self._step_dev.sub_(1)
+                else:
+                    self._step_dev.sub_((guard.reshape(-1)[:1] == 0).to(self._step_dev.dtype))
                 model._tail_counted = False
-            if model._tail_dirty:                          # ... and its sums (or those of a pass that was invalidated) are stale
+            if getattr(model, "_tail_dirty", False) or stale0:   # ... and its sums (or an unfused step's, left in set 0) are stale
                 s["sumsq" + cur].zero_(); s["tsums" + cur].zero_()
                 model._tail_dirty = False
+                if self._set == 0:
+                    self._set0_stale = False
         model._tail_done = False
-        from ._lib import lib
-        import os
         if (os.environ.get("SEHIP_NO_FUSED_TAIL") or self.grad_scale != 1.0 or getattr(model, "grad_range_hook", None) is not None
-                or not model.flat_params.is_cuda or torch.cuda.is_current_stream_capturing() or lib().sehip_get_deterministic()):
+                or not model.flat_params.is_cuda or capturing or lib().sehip_get_deterministic()):
             return
         self._ensure_state()
         s = self._scratch

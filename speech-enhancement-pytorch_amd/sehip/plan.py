@@ -1289,13 +1289,16 @@ class DCCRNWorkspace:
         recover=True: this workspace returns to one launch per layer and direction, the word is cleared, True is returned."""
         # (the word is read while it exists, fused or not: hipGraphs captured before a fall-back keep replaying the fused launches
         #  with this word as their optimizer guard -- ADVICE r4 -- until the Solver re-captures them, see graph_epoch)
-        if not hasattr(self, "l2_sync"):
-            return False
-        tripped = int(self.l2_sync[0]) != 0
+        # (a workspace without the fused recurrence -- a chunked LSTM, T >= 65535 -- has no word: it still takes part in the
+        #  collective with tripped = False, BEFORE any early return: the other ranks may hold fused workspaces -- ADVICE r5)
+        has_word = hasattr(self, "l2_sync")
+        tripped = has_word and int(self.l2_sync[0]) != 0
         if global_flag is not None:      # data parallel: every rank takes the same fall-back at the same health check
             tripped = global_flag(tripped, self.device)
         if not tripped:
             return False
+        if not has_word:                 # another rank lost steps (they were skipped here too, through the global step guard)
+            return True
         if not recover:
             raise SehipError("DCCRN: a hand-off wait of the fused two-layer LSTM kernels timed out (results since then are invalid and "
                              "no optimizer step was applied); set SEHIP_NO_LSTM_FUSE=1 to use one launch per layer")

@@ -691,6 +691,12 @@ class DCUNetWorkspace:
         self._chain_dirty = True
         wre, wim, _, _ = self._lin_ptrs(params)
         if self.fused_tail:
+            # sehip_dcunet_tail_bwd overwrites mask_ws in place (tanh(linear) -> d linear): a second backward pass over the SAME forward
+            # (retain_graph=True) would read d linear as the tanh output and return wrong gradients silently
+            if getattr(self, "_tail_consumed", -1) == self.generation:
+                raise SehipError("DCUnet.backward: a second backward pass over the same forward (retain_graph=True) is not possible with the "
+                                 "fused tail (it consumes the forward's mask record); set SEHIP_DCUNET_NO_TAIL=1 for the separate kernels")
+            self._tail_consumed = self.generation
             pre = f"decoder{n - 1}.bn."
             g = lambda k: self.gpack.data_ptr() + 4 * pl.bn_g_off[pre][k]
             call("sehip_dcunet_tail_bwd", ptr(dout), ptr(self.spec), ptr(self.mask_ws), b[f"yd{n - 1}"].ptr, ptr(self.bn_coef[pre]), wre, wim,

@@ -771,9 +771,15 @@ class DemucsWorkspace:
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
         if st.lstms and self.generation % 64 == 2 and not torch.cuda.is_current_stream_capturing():
-            from .distrib import global_flag             # (collective: every rank makes the same calls in the same order)
-            self.check_lstm_handoffs(recover=True, global_flag=global_flag)       # (every 64th call: the read waits for the previous step; the Solver also
-                                                         #  asks at each of its own synchronisation points, model.check_health())
+            # Every 64th call of THIS workspace (the read waits for the previous step).  The counter is per workspace, so under data
+            # parallelism the ranks reach this line at different forwards (validation clips of different lengths, a partial last
+            # batch, an LRU-evicted workspace restarting at 0): nothing collective may happen here.  A single process
+            # recovers at once; with several ranks the word just stays set -- the step guard (made global before every optimizer
+            # launch) keeps skipping the steps on every rank -- until the Solver's own synchronisation points, which every rank
+            # reaches together, take the decision (model.check_health(): the OR over the ranks).
+            import torch.distributed as _dist
+            if not (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1):
+                self.check_lstm_handoffs(recover=True)
         self.stats.zero_()
         # weight packing (134 M parameters in both operand orientations: 2.5 ms of table-driven gathers).  Only the shallow levels'
         # forward operands are packed on the chain's stream; the two deepest levels' (94 % of the weights, reached after most of

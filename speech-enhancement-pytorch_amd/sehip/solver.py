@@ -138,10 +138,8 @@ class Solver(object):
             set_deterministic(self.deterministic)
             if hasattr(model, "set_deterministic"):
                 model.set_deterministic(self.deterministic)
-        if self.deterministic:
-            if hasattr(model, "set_deterministic"):
-                pass
-            else:
+        if self.deterministic and not hasattr(model, "set_deterministic"):
+            if True:
                 import warnings
                 warnings.warn(f"solver.cudnn_deterministic: model '{config.model.name}' has no deterministic plan yet (its normalisation "
                               f"sums use fp32 atomics); the library-level reductions are deterministic, run-to-run bit equality is not guaranteed")

@@ -527,3 +527,20 @@ def test_full_width_gradients_vs_oracle(depth, frames, batch):
     for k, v in stats.items():
         if k.endswith(("running_mean", "running_var")):
             assert rel_err(sd[k].cpu().float(), v.float()) < 2e-2, k
+
+
+def test_second_backward_over_the_fused_tail_raises():
+    """sehip_dcunet_tail_bwd consumes the forward's mask record in place: a retain_graph second backward must fail loudly instead of
+    returning gradients formed from d linear in place of tanh(linear)."""
+    from sehip.model import DCUnet
+    from sehip._lib import SehipError
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model = DCUnet(data_type=True, model_complexity=8, model_depth=10).to(dev).train()
+    ws_probe = model(torch.randn(2, 1, 257, 33, 2, device=dev))
+    loss = ws_probe.pow(2).mean()
+    loss.backward(retain_graph=True)
+    if not model.workspace(2, 257, 33).fused_tail:
+        pytest.skip("fused tail off (SEHIP_DCUNET_NO_TAIL)")
+    with pytest.raises(SehipError, match="second backward"):
+        loss.backward()

@@ -171,3 +171,47 @@ def test_fused_tail_on_the_other_flat_models(which):
     metric, _ = ref()
     assert opt.sync_step() == 2
     assert abs(float(m[0]) - metric) < 1e-4 * metric + 1e-12
+
+
+def test_step_then_zero_grad_order_does_not_add_to_the_previous_steps_sums():
+    """The common loop order `backward(); step(); zero_grad()`: step 1 is unfused (nothing armed the tail yet) and leaves
+    its sums in set 0; the zero_grad() behind it arms the fused tail on set 0, which must start from zero -- otherwise step 2 clips
+    with sqrt(|g1|^2 + |g2|^2) and logs a wrong metric.  Also an unfused step in the middle of fused ones (the eager step after graph
+    replays), with the set index at 0 and at 1."""
+    import numpy as np
+    from sehip.model import DCCRN
+    from sehip.optim import FlatOptimizer
+    from sehip.loss import loss_sisdr
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = DCCRN(kernel_num=[16, 16, 32, 32, 64, 64], rnn_units=128, length=4000).to(dev).train()
+    opt = FlatOptimizer(model, lr=3e-4)
+    g = torch.Generator().manual_seed(11)
+    offs = model.static.layout.tensor_offsets
+
+    def batch():
+        c = (0.1 * torch.randn(2, 1, 4000, generator=g)).to(dev)
+        return c + (0.05 * torch.randn(2, 1, 4000, generator=g)).to(dev), c
+
+    def ref():
+        gr = model.flat_grads.double().cpu().numpy()
+        return (float(np.sqrt(sum(gr[offs[t]:offs[t + 1]].sum() ** 2 for t in range(len(offs) - 1)))), float(np.sqrt((gr ** 2).sum())))
+    fused_seen = []
+    for it in range(6):
+        n, c = batch()
+        loss_sisdr(model(n), c).backward()
+        if it == 3:                       # an unfused step between fused ones: drop the armed tail's result
+            model._tail_done = False
+            model._tail_counted = True    # (the un-pack has counted the step; step() must not count again)
+        fused_seen.append(bool(model._tail_done))
+        torch.cuda.synchronize()
+        metric, total = ref()             # the un-packed, unclipped gradient of THIS step
+        opt.clip_grad_norm_(1e9)          # (a clip that never bites: the buffer stays comparable; metric[1] is the norm the clip used)
+        opt.step()
+        m = opt.grad_metric()
+        torch.cuda.synchronize()
+        assert abs(float(m[1]) - total) < 1e-4 * total, (it, float(m[1]), total)
+        assert abs(float(m[0]) - metric) < 1e-4 * metric + 1e-9, (it, float(m[0]), metric)
+        assert opt.sync_step() == it + 1
+        opt.zero_grad()                   # AFTER the step: arms the next backward pass
+    assert fused_seen == [False, True, True, False, True, True]
