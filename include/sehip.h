@@ -125,6 +125,9 @@ int sehip_opt_step_m(float* params, float* grads, float* m, float* v, long n, co
                      double* next_sumsq, float* next_tensor_sums, void* stream);
 int sehip_opt_begin_g(int* counter, int value, double* sumsq, float* tensor_sums, int ntensors, const unsigned* guard, void* stream);
 int sehip_counter_add(int* counter, int value, void* stream);
+/* clears up to four device buffers (p_k, b_k bytes: 16-byte aligned, multiples of 4; NULL / 0 = none) in ONE launch: the accumulators a
+ * train step adds to (packed gradients, normalisation sums, the overlap-add output of src/model/conv_tasnet.py:11-31) */
+int sehip_zero_regions(void* p0, long b0, void* p1, long b1, void* p2, long b2, void* p3, long b3, void* stream);
 /* sets the dynamic-LDS attributes of every kernel up front (call once before capturing a hipGraph) */
 int sehip_init(void);
 int sehip_grad_metric(const float* grads, const long* offsets /*[ntensors+1]*/, int ntensors, long max_tensor_numel,
@@ -341,6 +344,12 @@ int sehip_unpack_grad(const float* packed, const int* table4 /*[n][4]*/, long n,
  * The accumulators must be zero on entry (sehip_opt_step_m clears the next step's).  Atomics: not in the deterministic schedule. */
 int sehip_unpack_grad_sums(const float* packed, const int* table4, long n, float* grads, const long* offsets, int ntensors,
                            double* sumsq, float* tensor_sums, int* counter, const unsigned* guard, void* stream);
+/* The same with the rows of a tensor's range in any order: row i of table4 un-packs parameter perm[i], which must lie in the SAME
+ * tensor [offsets[t], offsets[t + 1]) as position i (the per-tensor sums are taken by position).  With a tensor's rows sorted by the
+ * address of their first packed entry the gathers of a wave are neighbours in `packed` (a convolution weight [co][ci][kf][kt] of
+ * src/model/dccrn.py:316-450 against its dW[n][(kt, kf, ci)]) and the scattered side is the 4-byte store. */
+int sehip_unpack_grad_sums_perm(const float* packed, const int* table4, const int* perm, long n, float* grads, const long* offsets,
+                                int ntensors, double* sumsq, float* tensor_sums, int* counter, const unsigned* guard, void* stream);
 /* The same for the one-entry-per-parameter tables (sehip_unpack_grad1 + sehip_unpack_grad_list over the WHOLE vector: Demucs): the
  * main launch, then the launch for the parameters with several entries, which corrects the accumulators by what it adds. */
 int sehip_unpack_grad1_sums(const float* packed, const int* table1, long n, float* grads, const long* offsets, int ntensors, double* sumsq,

@@ -63,6 +63,7 @@ _PROTOS = {
     "sehip_opt_step_m": [P, P, P, P, L, P, F, F, F, F, F, I, P, F, I, F, P, P, I, P, P, P, P],
     "sehip_opt_begin_g": [P, I, P, P, I, P, P],
     "sehip_counter_add": [P, I, P],
+    "sehip_zero_regions": [P, L, P, L, P, L, P, L, P],
     "sehip_init": [],
     "sehip_grad_metric": [P, P, I, L, P, P, P, P],
     "sehip_opt_begin": [P, I, P, P, I, P],
@@ -91,6 +92,7 @@ _PROTOS = {
     "sehip_pack_head": [P, P, L, P, P, L, P, P, L, P],
     "sehip_unpack_grad": [P, P, L, P, P],
     "sehip_unpack_grad_sums": [P, P, L, P, P, I, P, P, P, P, P],
+    "sehip_unpack_grad_sums_perm": [P, P, P, L, P, P, I, P, P, P, P, P],
     "sehip_unpack_grad1": [P, P, L, P, P],
     "sehip_unpack_grad1_sums": [P, P, L, P, P, I, P, P, P, P, P],
     "sehip_unpack_grad_list_sums": [P, P, P, L, P, P, I, P, P, P],

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_apply_fin_kernel(const bf16_ra
                                                                float* __restrict__ gWri, float* __restrict__ gWii, float* __restrict__ gBr,
                                                                float* __restrict__ gBi, float* __restrict__ gslope,
                                                                const float* __restrict__ slope, long rows, int Cr, int F, int Tst,
-                                                               int tfirst, bf16_raw* __restrict__ dy) {
+                                                               int tfirst, bf16_raw* __restrict__ dy, int dbg_mode) {
     __shared__ float4 cl[5 * 256];
     const int nq = Cr / CH;
     const int C = 2 * Cr;
@@ -620,7 +620,10 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_apply_fin_kernel(const bf16_ra
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) v[r][kk] = rep[(size_t)(r0 + r < nrep ? r0 + r : 0) * (6 * Cr + 1) + kk * Cr + c];
+                for (int kk = 0; kk < 6; ++kk) {
+                    const float* pr = &rep[(size_t)(r0 + r < nrep ? r0 + r : 0) * (6 * Cr + 1) + kk * Cr + c];
+                    v[r][kk] = (dbg_mode & 1) ? __hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *pr;
+                }
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -916,9 +919,10 @@ extern "C" int sehip_cbn_bwd_fused(const void* dz, const void* dz2, const void* 
     SEHIP_REQUIRE(nrep >= 1 && nrep <= 64 && rep != nullptr && rep_next != nullptr && rep_next != rep,
                   "cbn_bwd_fused: %d rows of sums (1..64), two distinct sets", nrep);
     if (int e = cbn_bwd_reduce_launch(dz, dz2, y, coef, slope, rows, Cr, F, Tst, tfirst, rep, nrep, stream)) return e;
+    static const int dbg_mode = env_int("SEHIP_BWD_FIN_DBG", 0);
 #define CBN_BFIN(U, CH, H2) cbn_bwd_apply_fin_kernel<U, CH, H2><<<apply_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>(              \
         (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, rep, nrep, rep_next, Wrr, Wri, Wii, gWrr, gWri, gWii, gBr, gBi, gslope, \
-        slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy)
+        slope, rows, Cr, F, Tst, tfirst, (bf16_raw*)dy, dbg_mode)
 #define CBN_BFIN2(U, CH) do { if (dz2) CBN_BFIN(U, CH, true); else CBN_BFIN(U, CH, false); } while (0)
     switch (unroll_rows_bwd() * 16 + cbn_ch(Cr)) {
         case 1 * 16 + 8: CBN_BFIN2(1, 8); break;

@@ -226,6 +226,42 @@ extern "C" int sehip_opt_begin(int* counter, int value, double* sumsq, float* te
     return sehip_opt_begin_g(counter, value, sumsq, tensor_sums, ntensors, nullptr, stream);
 }
 
+// Up to four buffers cleared by ONE launch (a train step's accumulators -- packed gradients, normalisation sums, an overlap-add
+// output -- were four runtime fill kernels with their host gaps on ConvTasNet's chain: round 6).  Sizes in bytes, multiples of 4;
+// 16-byte aligned pointers (whole allocations).
+struct ZeroRegions { float* p[4]; long n[4]; };
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroRegions r) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float* p = r.p[k];
+        const long n = r.n[k], n4 = n >> 2;
+        if (!p) continue;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+            reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.x == 0 && (long)threadIdx.x < n - (n4 << 2)) p[(n4 << 2) + threadIdx.x] = 0.f;
+    }
+}
+extern "C" int sehip_zero_regions(void* p0, long b0, void* p1, long b1, void* p2, long b2, void* p3, long b3, void* stream) {
+    ZeroRegions r;
+    void* ps[4] = {p0, p1, p2, p3};
+    const long bs[4] = {b0, b1, b2, b3};
+    long most = 0;
+    for (int k = 0; k < 4; ++k) {
+        SEHIP_REQUIRE(bs[k] >= 0 && (bs[k] & 3) == 0 && (reinterpret_cast<size_t>(ps[k]) & 15) == 0,
+                      "zero_regions: region %d needs a 16-byte aligned pointer and a multiple of 4 bytes (%ld)", k, bs[k]);
+        r.p[k] = bs[k] > 0 ? reinterpret_cast<float*>(ps[k]) : nullptr;
+        r.n[k] = bs[k] >> 2;
+        if (r.p[k] && r.n[k] > most) most = r.n[k];
+    }
+    if (most == 0) return 0;
+    long g = (most / 4 + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    zero_regions_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(r);
+    SEHIP_CHECK_LAUNCH("zero_regions");
+    return 0;
+}
+
 extern "C" int sehip_counter_add(int* counter, int value, void* stream) {
     SEHIP_REQUIRE(counter != nullptr, "counter_add: null counter");
     counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter, value);

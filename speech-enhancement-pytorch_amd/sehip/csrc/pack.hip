@@ -81,10 +81,16 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restric
 // reference's logged grad_norm (src/solver.py:487-498).  Workgroup b owns a contiguous range of parameters and flushes its running
 // sum at every tensor boundary inside it (as tensor_sums_flat_kernel); workgroup 0 also advances the optimizer's device step counter
 // (what sehip_opt_begin did in a launch of its own).  Three launches less on the tail of the step's chain.
+// perm (round 6, optional): position i of a tensor's range un-packs parameter perm[i] OF THE SAME TENSOR, the table is in position
+// order.  With the positions of a tensor sorted by the address of their first packed entry, the lanes of a wave gather neighbouring
+// floats of gpack (a convolution weight [co][ci][kf][kt] reads dW[n][(kt, kf, ci)]: in parameter order consecutive lanes are 5 C
+// floats apart and every 4-byte read pulls its own 64-byte sector -- 281 MB of traffic to re-lay 8.3 MB of gradients at the DCCRN
+// headline shape) and the scattered side becomes the 4-byte store, which L2 merges.  The per-tensor sums do not notice.
 __global__ __launch_bounds__(256) void unpack_grad_sums_kernel(const float* __restrict__ packed, const int4* __restrict__ tab, long n,
                                                                float* __restrict__ grads, const long* __restrict__ offsets, int ntensors,
                                                                double* __restrict__ sumsq, float* __restrict__ tsums,
-                                                               int* __restrict__ counter, const unsigned* __restrict__ guard) {
+                                                               int* __restrict__ counter, const unsigned* __restrict__ guard,
+                                                               const int* __restrict__ perm) {
     __shared__ float red[4];
     __shared__ int first;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter && !(guard && guard[0] != 0u)) counter[0] += 1;
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void unpack_grad_sums_kernel(const float* __re
             for (long i = lo + threadIdx.x; i < e; i += 256) {
                 const int4 en = tab[i];
                 const float g = term(packed, en.x) + term(packed, en.y) + term(packed, en.z) + term(packed, en.w);
-                grads[i] = g;
+                grads[perm ? (long)perm[i] : i] = g;
                 acc += g;
                 q += g * g;
             }
@@ -291,8 +297,22 @@ extern "C" int sehip_unpack_grad_sums(const float* packed, const int* table4, lo
                                           "sehip_unpack_grad + sehip_grad_sumsq + sehip_grad_metric");
     if (n == 0) return 0;
     unpack_grad_sums_kernel<<<1024, 256, 0, (hipStream_t)stream>>>(packed, (const int4*)table4, n, grads, offsets, ntensors, sumsq,
-                                                                  tensor_sums, counter, guard);
+                                                                  tensor_sums, counter, guard, nullptr);
     SEHIP_CHECK_LAUNCH("unpack_grad_sums");
+    return 0;
+}
+
+extern "C" int sehip_unpack_grad_sums_perm(const float* packed, const int* table4, const int* perm, long n, float* grads,
+                                           const long* offsets, int ntensors, double* sumsq, float* tensor_sums, int* counter,
+                                           const unsigned* guard, void* stream) {
+    SEHIP_REQUIRE(n >= 0 && ntensors > 0 && offsets && sumsq && tensor_sums && perm, "unpack_grad_sums_perm: bad arguments");
+    SEHIP_REQUIRE(!sehip_deterministic(), "unpack_grad_sums_perm: not part of the deterministic schedule (fp32 / double atomics): use "
+                                          "sehip_unpack_grad + sehip_grad_sumsq + sehip_grad_metric");
+    if (n == 0) return 0;
+    sehip_note_kernel("unpack_grad_sums_kernel<perm>");
+    unpack_grad_sums_kernel<<<1024, 256, 0, (hipStream_t)stream>>>(packed, (const int4*)table4, n, grads, offsets, ntensors, sumsq,
+                                                                  tensor_sums, counter, guard, perm);
+    SEHIP_CHECK_LAUNCH("unpack_grad_sums_perm");
     return 0;
 }
 

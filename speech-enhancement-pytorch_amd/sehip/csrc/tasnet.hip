@@ -681,29 +681,30 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
             if (!DW) {
                 dy = ld8(gb + (long)t * C);
             } else {
-                // rows t - d, t, t + d of dh2 (dy and the centre tap's dWd) and of h (the three taps' dWd): 7 loads in flight
-                C8 gq[P], xq[P];
+                // rows t - d, t, t + d of dh2 serve BOTH sums (round 6; it was 3 more rows of h and the normalisation three times per
+                // element): dy[t] = sum_p' Wd[p'] dh2[t - (p' - P/2) d], and dWd[p'] = sum_t dh2[t - (p' - P/2) d] n[t] -- the same
+                // pairs (t - (p' - P/2) d, t) as sum_t dh2[t] n[t + (p' - P/2) d], indexed by the row that holds n.  4 loads in flight.
+                C8 gq[P];
                 bool ok[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int tt = t + (p - P / 2) * dil;
                     ok[p] = tt >= 0 && tt < K;
                     gq[p] = ld8(gb + (long)(ok[p] ? tt : t) * C);
-                    xq[p] = p == P / 2 ? x : ld8(hb + (long)(ok[p] ? tt : t) * C);
                 }
+                float nt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nt[j] = gm[j] * ((prelu(x.v[j], a) - mu) * rs) + bt[j];
                 dy = zero8();
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    // dy[t] += Wd[p'] dh2[t - (p' - P/2) d]: the row t + (p - P/2) d is tap p' = P - 1 - p
+                    // the row t + (p - P/2) d is t - (p' - P/2) d for tap p' = P - 1 - p
                     if (ok[p]) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) dy.v[j] += wd[P - 1 - p][j] * gq[p].v[j];
-                    }
-                    // dWd[p] += dh2[t] n[t + (p - P/2) d]
-                    if (ok[p]) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            dw[p][j] += gq[P / 2].v[j] * (gm[j] * ((prelu(xq[p].v[j], a) - mu) * rs) + bt[j]);
+                        for (int j = 0; j < 8; ++j) {
+                            dy.v[j] += wd[P - 1 - p][j] * gq[p].v[j];
+                            dw[P - 1 - p][j] += gq[p].v[j] * nt[j];
+                        }
                     }
                 }
             }

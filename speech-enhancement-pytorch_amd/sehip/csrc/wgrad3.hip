@@ -27,18 +27,20 @@ typedef __attribute__((ext_vector_type(8))) short w3_s16x8;
 #define W3_RECORDS 0x7fff0000u
 #define W3_ONES __builtin_bit_cast(bf16x8, (w3_s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
 
-template <int NF, int FM, int J>
+template <int NF, int FM, int J, int NPL = 4>
 struct W3Geo {
+    static constexpr int NWV = 2 * NPL, NTH = 64 * NWV;                // waves = 2 (64-column halves of the 128 n) x NPL (16-channel planes)
+    static constexpr int GI = 1024 / NTH;                              // dOut DMA instructions per thread and stage
     static constexpr int FR = (J - 1) * FM + NF;                       // patch rows per frame
     static constexpr int S = J == 4 ? 12 : FR;                         // frame stride in rows
     static constexpr int P1 = FM == 2 ? (FR + 1) / 2 : 0;              // first physical row of the odd-row plane
     static constexpr int TB = 64 / J;                                  // frames per stage
     static constexpr int NPP = (TB + 1) * S * 2;                       // 16-byte pieces per 16-channel plane
     static constexpr int PLB = NPP * 16;
-    static constexpr int NPIECE = 4 * NPP;
-    static constexpr int MAXP = (NPIECE + 511) / 512;                  // patch DMA instructions per thread and stage
-    static constexpr int NI = 2 + MAXP;                                // DMA instructions per thread and stage
-    static constexpr int STAGE = (16384 + 4 * PLB + 1023) / 1024 * 1024;
+    static constexpr int NPIECE = NPL * NPP;
+    static constexpr int MAXP = (NPIECE + NTH - 1) / NTH;              // patch DMA instructions per thread and stage
+    static constexpr int NI = GI + MAXP;                               // DMA instructions per thread and stage
+    static constexpr int STAGE = (16384 + NPL * PLB + 1023) / 1024 * 1024;
     static_assert(S >= FR && (FM == 1 || P1 + FR / 2 <= S), "frame stride");
     static_assert(J == 4 || J == 8 || J == 16 || J == 32 || J == 64, "rows per frame");
 };
@@ -49,23 +51,28 @@ __device__ __forceinline__ void w3_wait_vm() {
 }
 
 // ABL: timing ablations for tools/ (SEHIP_W3_ABL, wrong results): 1 = no DMA inside the loop, 2 = no MFMA, 4 = no fragment reads
-template <int NF, int FM, int J, int NB, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_desc d, int tiles_per_wg, int nsplit, float* scratch) {
-    using G = W3Geo<NF, FM, J>;
+// NPL: 16-channel planes of the patch per workgroup.  4 (round 3): 512 threads, dW[128 n][taps][64 channels], one workgroup takes a
+// CU's whole register file (8 waves x 234 VGPRs for the 5-tap layers).  2 (round 6, the "half-CU" form the round-5 verdict asked
+// for): 256 threads = ONE wave per SIMD with the same wave tile, dW[128 n][taps][32 channels], <= 240 of a SIMD's 512 VGPRs and
+// 59 KB of LDS -- a conv_gemm_v3 workgroup (4 waves x 256 VGPRs) or a BatchNorm pass fits beside it on the same CU, which is what
+// the weight-gradient queue needs next to the step's dependent chain (finding 1).
+template <int NF, int FM, int J, int NB, int NPL = 4, int ABL = 0>
+__global__ __launch_bounds__(128 * NPL, 2) void conv_wgrad_v3_kernel(const sehip_gemm_desc d, int tiles_per_wg, int nsplit, float* scratch) {
+    using G = W3Geo<NF, FM, J, NPL>;
     constexpr int NIT = 2 * NF, S = G::S, P1 = G::P1, FR = G::FR, TB = G::TB, NPP = G::NPP, PLB = G::PLB, NPIECE = G::NPIECE;
-    constexpr int MAXP = G::MAXP, NI = G::NI, STAGE = G::STAGE;
+    constexpr int MAXP = G::MAXP, NI = G::NI, STAGE = G::STAGE, NWV = G::NWV, GI = G::GI, CW = 16 * NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* dump = smem + NB * STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv & 3, nh = wv >> 2;              // wave -> 16-channel plane w of the patch, 64-wide half nh of the 128 output columns
+    const int w = wv % NPL, nh = wv / NPL;           // wave -> 16-channel plane w of the patch, 64-wide half nh of the 128 output columns
     // All (n-tile, channel-chunk) workgroups of one m-split read the same dOut rows and patches at the same time: one XCD per
     // group of splits (blocks are dealt round-robin over the 8 XCDs), so the re-reads hit its L2
     const int C0 = d.src[0].C, C1 = d.src[1].ptr ? d.src[1].C : 0;
     const int Ctot = C0 + C1;
     const int ntn = d.Npad >> 7;
-    const int gx = ntn * (Ctot >> 6);
+    const int gx = ntn * (Ctot / CW);
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     const int xi = rr % gx, split = (rr / gx) * 8 + xcd;       // nsplit is a multiple of 8
     (void)nsplit;
@@ -78,10 +85,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
     const int ns = mt_end - mt_begin;
     if (ns <= 0) return;
 
-    const bool second = cc * 64 >= C0;
+    const bool second = cc * CW >= C0;
     const sehip_src& Sr = second ? d.src[1] : d.src[0];
     const int sT = Sr.T, sF = Sr.F, sC = Sr.C, tlo = Sr.tlo, thi = Sr.thi;
-    const int cbase = cc * 64 - (second ? C0 : 0);
+    const int cbase = cc * CW - (second ? C0 : 0);
     const int tmin = second ? min(d.cv_toff[1][0], d.cv_toff[1][1]) : min(d.cv_toff[0][0], d.cv_toff[0][1]);
     const int dt0 = (second ? d.cv_toff[1][0] : d.cv_toff[0][0]) - tmin, dt1 = (second ? d.cv_toff[1][1] : d.cv_toff[0][1]) - tmin;
     const int f0 = d.cv_fadd;
@@ -92,13 +99,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(dd.ptr)), 0, W3_RECORDS, 0x00020000);
     const unsigned sframe = 2u * (unsigned)(sF * sC), gframe = 2u * (unsigned)(dd.F * dd.C);     // bytes per time frame
 
-    // ---- DMA pieces of this thread.  dOut image: 8 planes (16 columns) x 64 rows x 32 B; piece Q = (8 u + wave) * 64 + lane =
-    // plane Q >> 7, row (Q & 127) >> 1, half Q & 1.  Patch image: 4 planes (16 channels) x (TB + 1) frames x S rows x 32 B.
-    unsigned gconst[2], pconst[MAXP];                 // byte offset for stage frame 0 of batch item 0 (W3_OOB: always zero)
-    int gtl[2], pfr[MAXP];                            // frame inside the stage
+    // ---- DMA pieces of this thread.  dOut image: 8 planes (16 columns) x 64 rows x 32 B; piece Q = (NWV u + wave) * 64 + lane =
+    // plane Q >> 7, row (Q & 127) >> 1, half Q & 1.  Patch image: NPL planes (16 channels) x (TB + 1) frames x S rows x 32 B.
+    unsigned gconst[GI], pconst[MAXP];                // byte offset for stage frame 0 of batch item 0 (W3_OOB: always zero)
+    int gtl[GI], pfr[MAXP];                           // frame inside the stage
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int Q = (u * 8 + wv) * 64 + lane;
+    for (int u = 0; u < GI; ++u) {
+        const int Q = (u * NWV + wv) * 64 + lane;
         const int plane = Q >> 7, m = (Q & 127) >> 1, half = Q & 1;
         const int tl = m / J, jl = m - tl * J;
         const int n = n0 + plane * 16 + half * 8;
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
     }
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
-        const int P = (u * 8 + wv) * 64 + lane;
+        const int P = (u * NWV + wv) * 64 + lane;
         const int pl = P / NPP, rem = P - pl * NPP;
         const int prow = rem >> 1, half = rem & 1;
         const int p = prow / S, rs_ = prow - p * S;
@@ -126,10 +133,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
         unsigned char* base = smem + buf * STAGE + wv * 1024;
         const unsigned gb = (unsigned)(b_ * dd.T + t0_) * gframe;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < GI; ++u) {
             const unsigned gc = gconst[u];
             const unsigned vo = (live && gc != W3_OOB && t0_ + gtl[u] < d.TT) ? gc + gb : W3_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (w3_lds_void*)(base + u * 8192), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (w3_lds_void*)(base + u * (NWV * 1024)), 16, vo, 0, 0, 0);
         }
         const int ts0 = t0_ + tmin;
         const unsigned pb = (unsigned)(b_ * sT + ts0) * sframe;      // (may wrap for ts0 = -1: added to a piece of frame >= 1 only)
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
             const unsigned pc = pconst[u];
             const int ts = ts0 + pfr[u];
             const unsigned vo = (live && pc != W3_OOB && ts >= tlo && ts < thi) ? pc + pb : W3_OOB;
-            unsigned char* dst = ((u * 8 + wv) * 64 < NPIECE) ? base + 16384 + u * 8192 : dump;      // wave-uniform
+            unsigned char* dst = ((u * NWV + wv) * 64 < NPIECE) ? base + 16384 + u * (NWV * 1024) : dump;      // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (w3_lds_void*)dst, 16, vo, 0, 0, 0);
         }
     };
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v3_kernel(const sehip_gemm_
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int n = n0 + 64 * nh + ni * 16 + 4 * (lane >> 4);
-            const int k = it * Ctot + cc * 64 + 16 * w + (lane & 15);
+            const int k = it * Ctot + cc * CW + 16 * w + (lane & 15);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (scratch) out[(size_t)(n + u) * d.K + k] = acc[ni][it][u];
@@ -326,28 +333,38 @@ static float* w3_scratch_for(hipStream_t st, size_t bytes) {
 // (the same pool for the other weight-gradient kernels that keep partial arrays: csrc/gemm.hip's narrow_wgrad_mfma_kernel)
 float* sehip_wgrad_scratch(hipStream_t st, size_t bytes) { return w3_scratch_for(st, bytes); }
 
-template <int NF, int FM, int J, int NB>
+template <int NF, int FM, int J, int NB, int NPL = 4>
 static size_t w3_lds_bytes() {
-    return (size_t)NB * W3Geo<NF, FM, J>::STAGE + 1024;
+    return (size_t)NB * W3Geo<NF, FM, J, NPL>::STAGE + 1024;
 }
-template <int NF, int FM, int J, int NB>
+template <int NF, int FM, int J, int NB, int NPL = 4>
 static void w3_set_attr() {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_v3_kernel<NF, FM, J, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_v3_kernel<NF, FM, J, NB, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
 }
 template <int NF, int FM, int J>
-static void w3_launch(const sehip_gemm_desc& d, int grid, int tiles_per_wg, int splits, int nb, float* scratch, hipStream_t st) {
-    sehip_note_kernel("conv_wgrad_v3_kernel<%d, %d, %d, %d>", NF, FM, J, nb);
+static void w3_launch(const sehip_gemm_desc& d, int grid, int tiles_per_wg, int splits, int nb, int npl, float* scratch, hipStream_t st) {
+    sehip_note_kernel("conv_wgrad_v3_kernel<%d, %d, %d, %d, %d>", NF, FM, J, nb, npl);
+    if (npl == 2) {                                    // the half-CU form: one wave per SIMD
+        if (nb == 2) {
+            w3_set_attr<NF, FM, J, 2, 2>();
+            conv_wgrad_v3_kernel<NF, FM, J, 2, 2><<<grid, 256, w3_lds_bytes<NF, FM, J, 2, 2>(), st>>>(d, tiles_per_wg, splits, scratch);
+        } else {
+            w3_set_attr<NF, FM, J, 3, 2>();
+            conv_wgrad_v3_kernel<NF, FM, J, 3, 2><<<grid, 256, w3_lds_bytes<NF, FM, J, 3, 2>(), st>>>(d, tiles_per_wg, splits, scratch);
+        }
+        return;
+    }
 #ifdef SEHIP_TOOLS_BUILD      // timing ablations (wrong results): tools builds only
     static const int abl = getenv("SEHIP_W3_ABL") ? atoi(getenv("SEHIP_W3_ABL")) : 0;
     if (abl && NF == 5 && J <= 8) {
         const size_t lds = w3_lds_bytes<NF, FM, J, 3>();
-#define W3_ABL(A_) case A_: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_v3_kernel<NF, FM, J, 3, A_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                            conv_wgrad_v3_kernel<NF, FM, J, 3, A_><<<grid, 512, lds, st>>>(d, tiles_per_wg, splits, scratch); return;
+#define W3_ABL(A_) case A_: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_v3_kernel<NF, FM, J, 3, 4, A_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                            conv_wgrad_v3_kernel<NF, FM, J, 3, 4, A_><<<grid, 512, lds, st>>>(d, tiles_per_wg, splits, scratch); return;
         switch (abl) { W3_ABL(1) W3_ABL(2) W3_ABL(3) W3_ABL(4) W3_ABL(5) W3_ABL(6) W3_ABL(7) default: break; }
 #undef W3_ABL
     }
@@ -516,13 +533,15 @@ static int w3_launch_j(const sehip_gemm_desc& d, hipStream_t st) {
     const int TB = 64 / d.J;
     const int B = d.M / (d.TT * d.J);
     const int MT = B * ((d.TT + TB - 1) / TB);
-    const int gx = (d.Npad >> 7) * ((C0 + C1) >> 6);
+    // SEHIP_W3_NPL: 16-channel planes per workgroup (4: 512 threads, a whole CU's registers; 2: 256 threads, half of them)
+    static const int npl = getenv("SEHIP_W3_NPL") ? (atoi(getenv("SEHIP_W3_NPL")) == 2 ? 2 : 4) : 4;
+    const int gx = (d.Npad >> 7) * ((C0 + C1) / (16 * npl));
     // m-splits: groups of 8 (one split of each group per XCD), at least four stages each.  A workgroup takes a whole CU (all its
     // VGPRs), and inside the train step the launch runs on the weight-gradient stream beside the dependent chain: alone on the GPU
     // 256 workgroups are fastest (enc4 / enc5: 83 / 80 us against 157 / 161 for conv_wgrad_kernel), in the step about 96 are
     // (B = 32 step, ms: 64: 4.30, 80: 4.23, 96: 4.22-4.25, 112: 4.24-4.27, 128: 4.24, 192: 4.29-4.33, conv_wgrad_kernel: 4.25-4.27)
     // -- more of them take the CUs from the chain's kernels, whose tiles then run in more rounds.  Two stage buffers or three: the same.
-    static const int want = getenv("SEHIP_W3_WGS") ? atoi(getenv("SEHIP_W3_WGS")) : 96;
+    static const int want = getenv("SEHIP_W3_WGS") ? atoi(getenv("SEHIP_W3_WGS")) : (npl == 2 ? 256 : 96);
     static const int nb = getenv("SEHIP_W3_NB") ? atoi(getenv("SEHIP_W3_NB")) : 2;
     int splits = (want / gx + 7) / 8 * 8;
     if (splits < 8) splits = 8;
@@ -533,9 +552,9 @@ static int w3_launch_j(const sehip_gemm_desc& d, hipStream_t st) {
     const size_t n = (size_t)d.Npad * d.K;
     float* scratch = w3_scratch_for(st, (size_t)used * n * sizeof(float));
     switch (d.J) {
-        case 4: w3_launch<NF, FM, 4>(d, grid, tiles_per_wg, splits, nb, scratch, st); break;
-        case 8: w3_launch<NF, FM, 8>(d, grid, tiles_per_wg, splits, nb, scratch, st); break;
-        case 16: w3_launch<NF, FM, 16>(d, grid, tiles_per_wg, splits, nb, scratch, st); break;
+        case 4: w3_launch<NF, FM, 4>(d, grid, tiles_per_wg, splits, nb, npl, scratch, st); break;
+        case 8: w3_launch<NF, FM, 8>(d, grid, tiles_per_wg, splits, nb, npl, scratch, st); break;
+        case 16: w3_launch<NF, FM, 16>(d, grid, tiles_per_wg, splits, nb, npl, scratch, st); break;
         default: return 0;
     }
     if (scratch) w3_reduce_launch(scratch, used, n, d.dW, st);
@@ -579,6 +598,8 @@ template <int NF, int FM>
 static void w3_init_nf() {
     w3_set_attr<NF, FM, 4, 2>(); w3_set_attr<NF, FM, 8, 2>(); w3_set_attr<NF, FM, 16, 2>();
     w3_set_attr<NF, FM, 4, 3>(); w3_set_attr<NF, FM, 8, 3>(); w3_set_attr<NF, FM, 16, 3>();
+    w3_set_attr<NF, FM, 4, 2, 2>(); w3_set_attr<NF, FM, 8, 2, 2>(); w3_set_attr<NF, FM, 16, 2, 2>();
+    w3_set_attr<NF, FM, 4, 3, 2>(); w3_set_attr<NF, FM, 8, 3, 2>(); w3_set_attr<NF, FM, 16, 3, 2>();
 }
 void sehip_wgrad3_init(void) {
     w3_init_nf<5, 2>(); w3_init_nf<3, 1>(); w3_init_nf<2, 1>();

@@ -46,9 +46,10 @@ class ConvTasNet(FlatModule):
         from .. import plan_tasnet
         self.cfg = cfg = plan_tasnet.TasNetConfig(sources, N=N, L=L, B=B, H=H, P=P, X=X, R=R, audio_channels=audio_channels,
                                                   norm_type=norm_type, causal=causal, mask_nonlinear=mask_nonlinear, skip=skip)
-        if cfg.key() not in _STATIC_CACHE:
-            _STATIC_CACHE[cfg.key()] = plan_tasnet.TasNetStatic(cfg)
-        self.static = _STATIC_CACHE[cfg.key()]
+        skey = (cfg.key(), bool(os.environ.get("SEHIP_CTN_KEEP_GRADS")))      # (the test switch changes the buffer names of the plan)
+        if skey not in _STATIC_CACHE:
+            _STATIC_CACHE[skey] = plan_tasnet.TasNetStatic(cfg)
+        self.static = _STATIC_CACHE[skey]
         self.sources, self.C = sources, cfg.C
         self.N, self.L, self.B, self.H, self.P, self.X, self.R = N, L, B, H, P, X, R
         self.audio_channels, self.sample_rate, self.segment_length = audio_channels, sample_rate, segment_length

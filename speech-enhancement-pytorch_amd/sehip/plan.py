@@ -716,6 +716,22 @@ class DCCRNStatic:
         return tab
 
 
+def gather_ordered_unpack_table(tab, tensor_offsets):
+    """The un-pack table [n_params][4] with the rows of every tensor sorted by the address of their first packed entry, and the
+    parameter each row un-packs (int32 [n_params]): the form sehip_unpack_grad_sums_perm takes.  A convolution weight
+    [co][ci][kf][kt] reads dW[n][(kt, kf, ci)]: in parameter order neighbouring lanes gather floats 5 C apart (one 64-byte sector per
+    4-byte read), in gather order they read a run of `ci`.  Rows never leave their tensor: the per-tensor sums are taken by position."""
+    tab = np.asarray(tab)
+    n = tab.shape[0]
+    first = tab[:, 0].astype(np.int64) >> 1
+    first[tab[:, 0] < 0] = np.iinfo(np.int64).max >> 2          # parameters without a packed entry stay where they are, at the end
+    offs = np.asarray(tensor_offsets, dtype=np.int64)
+    tensor_of = np.searchsorted(offs, np.arange(n, dtype=np.int64), side="right") - 1
+    perm = np.lexsort((np.arange(n), first, tensor_of)).astype(np.int32)     # by tensor, then by gather address, stable
+    assert np.array_equal(tensor_of[perm], tensor_of)
+    return np.ascontiguousarray(tab[perm]), perm
+
+
 # --------------------------------------------------------------------------------------------------
 # dynamic part: buffers for one (batch, length), bound descriptors, launch sequences
 # --------------------------------------------------------------------------------------------------
@@ -736,6 +752,10 @@ class DeviceTables:
         self.wtab, self.btab, self.utab = f(st.wtab), f(st.btab), f(st.utab)
         self.ktab, self.ntab = f(st.ktab), f(st.ntab)
         self.tensor_offsets = f(st.layout.tensor_offsets)
+        self.utab_g = self.uperm = None                 # the fused tail's un-pack in gather order (SEHIP_NO_UNPACK_PERM: parameter order)
+        if not os.environ.get("SEHIP_NO_UNPACK_PERM"):
+            tg, pm = gather_ordered_unpack_table(st.utab, st.layout.tensor_offsets)
+            self.utab_g, self.uperm = f(tg), f(pm)
         cfg = st.cfg
         self.window = f(ops.hann_periodic(cfg.win_len))
         self.wpack = torch.zeros(st.n_wpack, dtype=BF16, device=device)
@@ -820,9 +840,15 @@ class DCCRNWorkspace:
         # two sets of [BWD_REPLICAS][6 Cr + 1] sums of the backward reduce pass per layer (sehip_cbn_bwd_fused: a call adds to one set
         # and clears the other for the next call)
         self.fuse_finalize = not os.environ.get("SEHIP_NO_FUSE_FINALIZE")
-        # (the same for the backward pass -- sehip_cbn_bwd_fused -- measured no gain: B = 32 step 4.129 ms with 8 rows of sums, 4.159
-        #  with 16, against 4.131 without it; opt-in)
-        self.fuse_bwd_finalize = bool(os.environ.get("SEHIP_FUSE_BWD_FINALIZE")) and self.fuse_finalize
+        # (the same for the backward pass -- sehip_cbn_bwd_fused: the reduce pass adds its block sums to BWD_REPLICAS rows with atomics,
+        #  the apply pass finalizes them itself.  Round 3 measured no gain (B = 32 step 4.129 ms with 8 rows of sums, 4.159 with 16,
+        #  against 4.131 without it) and left it opt-in; in round 6, with the chain 1 ms shorter and the eleven cbn_bwd_finalize
+        #  launches 0.10 ms of it, the same code is 3.142 against 3.213 / 3.204 ms (same box, twice): default.  Not in the
+        #  deterministic schedule (atomics in a varying order).  SEHIP_NO_FUSE_BWD_FINALIZE=1: the three launches.)
+        self.fuse_bwd_finalize = (self.fuse_finalize and not st.deterministic and bool(os.environ.get("SEHIP_FUSE_BWD_FINALIZE")))
+        # the two decoder layers whose reduce pass rides in the launch that produces their dz (bnr_rows) keep finalize_n + apply unless
+        # SEHIP_FUSE_BWD_ALL=1 (then their rows are written and ignored)
+        self.fuse_bwd_all = bool(os.environ.get("SEHIP_FUSE_BWD_ALL"))
         self.bn_brep = {pre: torch.zeros(2, BWD_REPLICAS * (6 * cr + 1), dtype=torch.float32, device=device) for pre, cr in st.bn}
         self._brep_turn = {pre: 0 for pre, _ in st.bn}
         self.bn_stats = {pre: self.bn_stats_all[o:o + 8 * 5 * cr] for (pre, cr) in st.bn if pre in offs for o in [offs[pre]]}
@@ -1234,7 +1260,7 @@ class DCCRNWorkspace:
         coef = self.bn_coef[pre]
         dz2p = dz2.ptr if dz2 is not None else None
         self._chain_dirty = True
-        if pre in self.bnr_rows and dz2 is None and not self.fuse_bwd_finalize:
+        if pre in self.bnr_rows and dz2 is None and not (self.fuse_bwd_finalize and self.fuse_bwd_all):
             # the launch that produced dz left the reduce pass's sums in bn_acc, one row per workgroup (bnr_rows)
             call("sehip_cbn_bwd_finalize_n", ptr(self.bn_acc), self.bnr_rows[pre][0], ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
                  g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
@@ -1487,8 +1513,12 @@ class DCCRNWorkspace:
             # tail = (sumsq, tensor_sums, offsets, ntensors, step counter) of the fused optimizer: the un-pack also takes its sums and
             # advances its device step counter (guarded by this workspace's hand-off word): see FlatOptimizer._arm_fused_tail
             guard = ptr(self.l2_sync) if hasattr(self, "l2_sync") else None
-            call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
-                 guard, stream())
+            if tb.uperm is not None:
+                call("sehip_unpack_grad_sums_perm", ptr(self.gpack), ptr(tb.utab_g), ptr(tb.uperm), n_params, ptr(grads), tail[2], tail[3],
+                     tail[0], tail[1], tail[4], guard, stream())
+            else:
+                call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
+                     guard, stream())
         else:
             call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), lo if range_ready is not None else n_params, ptr(grads), stream())
         if range_ready is not None:

@@ -472,6 +472,11 @@ class DCUNetDeviceTables:
         f = lambda a: torch.from_numpy(a).to(device)
         self.wtab, self.btab, self.utab, self.ntab = f(pl.wtab), f(pl.btab), f(pl.utab), f(pl.ntab)
         self.tensor_offsets = f(pl.st.layout.tensor_offsets)
+        self.utab_g = self.uperm = None                 # the fused tail's un-pack in gather order (plan.gather_ordered_unpack_table)
+        if not os.environ.get("SEHIP_NO_UNPACK_PERM"):
+            from .plan import gather_ordered_unpack_table
+            tg, pm = gather_ordered_unpack_table(pl.utab, pl.st.layout.tensor_offsets)
+            self.utab_g, self.uperm = f(tg), f(pm)
         self.wpack = torch.zeros(pl.n_wpack, dtype=BF16, device=device)
         self.bpack = torch.zeros(max(pl.n_bpack, 4), dtype=torch.float32, device=device)
 
@@ -721,8 +726,12 @@ class DCUNetWorkspace:
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
         if tail is not None:
-            call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
-                 None, stream())
+            if tb.uperm is not None:
+                call("sehip_unpack_grad_sums_perm", ptr(self.gpack), ptr(tb.utab_g), ptr(tb.uperm), st.layout.n_params, ptr(grads), tail[2],
+                     tail[3], tail[0], tail[1], tail[4], None, stream())
+            else:
+                call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), tail[2], tail[3], tail[0],
+                     tail[1], tail[4], None, stream())
         else:
             call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
         return grads

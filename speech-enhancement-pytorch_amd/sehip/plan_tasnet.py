@@ -84,6 +84,12 @@ class TasNetStatic:
             sp = GemmSpec(name, rows, widx, np.zeros_like(widx), cout, None, "K", 1, 1, [(src, "all")], [(dst, 0, 1, 0)], kind=kind, res=res)
             self.specs[name] = sp
 
+        # SEHIP_CTN_KEEP_GRADS=1 (tests): every block keeps its own du / dh2 instead of sharing one pair, so that EVERY product and
+        # normalisation kernel of the backward pass can be checked op-locally afterwards (tests/test_gpu_convtasnet_fullwidth.py);
+        # same kernels, same launches, 2 x 14 more activation-sized buffers.
+        self.keep_grads = bool(os.environ.get("SEHIP_CTN_KEEP_GRADS"))
+        self.du_name = (lambda b: f"du{b}") if self.keep_grads else (lambda b: "du")
+        self.dh2_name = (lambda b: f"dh2_{b}") if self.keep_grads else (lambda b: "dh2")
         net = "separator.network."
         dense("bott.fwd", net + "1.weight", N, B, "cln", "x0", "fwd")
         dense("bott.dg", net + "1.weight", B, N, "dx0", "dcln", "dgrad", transposed=True)
@@ -93,7 +99,7 @@ class TasNetStatic:
             dense(f"b{b}.in.fwd", q + "0.weight", B, H, f"x{b}", f"h1_{b}", "fwd")
             dense(f"b{b}.in.dg", q + "0.weight", H, B, f"dh1_{b}", f"dx{b}", "dgrad", res=f"dx{b + 1}", transposed=True)
             dense(f"b{b}.pw.fwd", q + "3.pointwise_conv.weight", H, B, f"u{b}", f"x{b + 1}", "fwd", res=f"x{b}")
-            dense(f"b{b}.pw.dg", q + "3.pointwise_conv.weight", B, H, f"dx{b + 1}", "du", "dgrad", transposed=True)
+            dense(f"b{b}.pw.dg", q + "3.pointwise_conv.weight", B, H, f"dx{b + 1}", self.du_name(b), "dgrad", transposed=True)
         nb = len(self.blocks)
         dense("mask.fwd", net + "3.weight", B, cfg.C * N, f"x{nb}", "mlin", "fwd")
         dense("mask.dg", net + "3.weight", cfg.C * N, B, "dmlin", f"dx{nb}", "dgrad", transposed=True)
@@ -161,6 +167,11 @@ class TasNetDeviceTables:
         f = lambda a: torch.from_numpy(a).to(device)
         self.wtab, self.utab, self.ntab = f(st.wtab), f(st.utab), f(st.ntab)
         self.tensor_offsets = f(st.layout.tensor_offsets)
+        self.utab_g = self.uperm = None                 # the fused tail's un-pack in gather order (plan.gather_ordered_unpack_table)
+        if not os.environ.get("SEHIP_NO_UNPACK_PERM"):
+            from .plan import gather_ordered_unpack_table
+            tg, pm = gather_ordered_unpack_table(st.utab, st.layout.tensor_offsets)
+            self.utab_g, self.uperm = f(tg), f(pm)
         self.wpack = torch.zeros(st.n_wpack, dtype=BF16, device=device)
 
 
@@ -184,7 +195,8 @@ class TasNetWorkspace:
             add(f"x{b}", B); add(f"dx{b}", B)
         for b in range(nb):
             add(f"h1_{b}", H); add(f"h2_{b}", H); add(f"u{b}", H); add(f"dh1_{b}", H)
-        add("du", H); add("dh2", H)
+        for name in sorted({st.du_name(b) for b in range(nb)} | {st.dh2_name(b) for b in range(nb)}):
+            add(name, H)
         add("mlin", cfg.C * N); add("dmlin", cfg.C * N)
         self.w = torch.empty(M, K, N, dtype=torch.float32, device=device)
         self.dw_dec = torch.empty(M, K, N, dtype=torch.float32, device=device)
@@ -196,6 +208,7 @@ class TasNetWorkspace:
         self.codec_scratch = torch.empty(int(_lib.lib().sehip_ctn_codec_bwd_scratch_floats(M, K, N, cfg.L, cfg.audio_channels)),
                                          dtype=torch.float32, device=device)
         self.wav = None
+        self._one_clear, self._bwd_clean = not os.environ.get("SEHIP_CTN_TORCH_ZEROS"), False
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self._bind()
@@ -279,7 +292,15 @@ class TasNetWorkspace:
         M, K, N, H = self.M, self.K, cfg.N, cfg.H
         pp = lambda n: self._pp(params, n)
         self.wav = wav
-        self.stats.zero_()
+        # every accumulator of the step cleared by ONE launch (round 6: they were four runtime fill kernels -- stats, out, gpack, bsums --
+        # with 30-55 us of host gap in front of each on the chain; SEHIP_CTN_TORCH_ZEROS=1 for those)
+        nbytes = lambda t: t.numel() * t.element_size()
+        if self._one_clear:
+            call("sehip_zero_regions", ptr(self.stats), nbytes(self.stats), ptr(self.out), nbytes(self.out), ptr(self.gpack), nbytes(self.gpack),
+                 ptr(self.bsums), nbytes(self.bsums), stream())
+            self._bwd_clean = True
+        else:
+            self.stats.zero_()
         call("sehip_pack_bf16", ptr(params), ptr(tb.wtab), st.n_wpack, ptr(tb.wpack), stream())
         net = "separator.network."
         call("sehip_ctn_encoder_fwd", ptr(wav), pp("encoder.conv1d_U.weight"), pp(net + "0.gamma"), pp(net + "0.beta"), M,
@@ -296,7 +317,8 @@ class TasNetWorkspace:
                  M, K, H, b[f"u{i}"].ptr, stream())
             self.gemm(f"b{i}.pw.fwd")
         self.gemm("mask.fwd")
-        self.out.zero_()
+        if not self._one_clear:
+            self.out.zero_()
         call("sehip_ctn_decoder_fwd", ptr(self.w), b["mlin"].ptr, pp("decoder.basis_signals.weight"), M, K, N, cfg.L, cfg.audio_channels,
              cfg.C, self.T, ptr(self.out), stream())
         return self.out
@@ -309,8 +331,10 @@ class TasNetWorkspace:
         gp = lambda off: self.gpack.data_ptr() + 4 * off
         nb = len(st.blocks)
         net = "separator.network."
-        self.gpack.zero_()
-        self.bsums.zero_()
+        if not getattr(self, "_bwd_clean", False):      # (a second backward pass over the same forward, or the torch-fill switch)
+            self.gpack.zero_()
+            self.bsums.zero_()
+        self._bwd_clean = False
         self._chain_dirty = True
         call("sehip_ctn_decoder_bwd", ptr(dout), ptr(self.w), b["mlin"].ptr, pp("decoder.basis_signals.weight"), M, K, N, cfg.L,
              cfg.audio_channels, cfg.C, self.T, b["dmlin"].ptr, ptr(self.dw_dec), gp(st.dec_g_off), ptr(self.codec_scratch), stream())
@@ -322,10 +346,11 @@ class TasNetWorkspace:
             o = st.blk_g_off[i]
             self.wgrad(f"b{i}.pw.fwd")
             self.gemm(f"b{i}.pw.dg")
-            call("sehip_ctn_gln_bwd", b["du"].ptr, b[f"h2_{i}"].ptr, pp(q + "3.net.1.weight"), self.stats[i, 1].data_ptr(),
+            du, dh2 = b[st.du_name(i)], b[st.dh2_name(i)]
+            call("sehip_ctn_gln_bwd", du.ptr, b[f"h2_{i}"].ptr, pp(q + "3.net.1.weight"), self.stats[i, 1].data_ptr(),
                  pp(q + "3.net.2.gamma"), pp(q + "3.net.2.beta"), pp(q + "3.net.0.weight"), cfg.P, 2 ** x, 0, M, K, H,
-                 self.bsums[i, 1].data_ptr(), gp(o["gch2"]), b["dh2"].ptr, gp(o["a2"]), ptr(self.gln_scratch), stream())
-            call("sehip_ctn_gln_bwd", b["dh2"].ptr, b[f"h1_{i}"].ptr, pp(q + "1.weight"), self.stats[i, 0].data_ptr(),
+                 self.bsums[i, 1].data_ptr(), gp(o["gch2"]), dh2.ptr, gp(o["a2"]), ptr(self.gln_scratch), stream())
+            call("sehip_ctn_gln_bwd", dh2.ptr, b[f"h1_{i}"].ptr, pp(q + "1.weight"), self.stats[i, 0].data_ptr(),
                  pp(q + "2.gamma"), pp(q + "2.beta"), pp(q + "3.net.0.weight"), cfg.P, 2 ** x, 1, M, K, H,
                  self.bsums[i, 0].data_ptr(), gp(o["gch1"]), b[f"dh1_{i}"].ptr, gp(o["a1"]), ptr(self.gln_scratch), stream())
             self._chain_dirty = True
@@ -338,8 +363,12 @@ class TasNetWorkspace:
         if self.side is not None and not torch.cuda.is_current_stream_capturing():
             call("sehip_stream_depend", stream(), self.side.cuda_stream, self._event())
         if tail is not None:         # FlatOptimizer's accumulators: the un-pack also takes the clipping norm / metric sums (plan.DCCRNWorkspace.backward)
-            call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), tail[2], tail[3], tail[0], tail[1], tail[4],
-                 None, stream())
+            if tb.uperm is not None:
+                call("sehip_unpack_grad_sums_perm", ptr(self.gpack), ptr(tb.utab_g), ptr(tb.uperm), st.layout.n_params, ptr(grads), tail[2],
+                     tail[3], tail[0], tail[1], tail[4], None, stream())
+            else:
+                call("sehip_unpack_grad_sums", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), tail[2], tail[3], tail[0],
+                     tail[1], tail[4], None, stream())
         else:
             call("sehip_unpack_grad", ptr(self.gpack), ptr(tb.utab), st.layout.n_params, ptr(grads), stream())
         return grads

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("clip", [0.0, 5.0, 0.05])
-@pytest.mark.parametrize("kind", ["adam", "sgd"])
-def test_fused_tail_matches_the_separate_launches(clip, kind):
+@pytest.mark.parametrize("kind,perm", [("adam", False), ("sgd", False), ("adam", True)])
+def test_fused_tail_matches_the_separate_launches(clip, kind, perm):
     from sehip.model import DCCRN
     from sehip.optim import FlatOptimizer
     from sehip._lib import call, ptr, stream
@@ -42,7 +42,12 @@ def test_fused_tail_matches_the_separate_launches(clip, kind):
         grads = model.flat_grads
         grads.zero_()
         s = opt._scratch
-        if fused:
+        if fused and perm:         # rows of every tensor in gather order (sehip_unpack_grad_sums_perm, round 6: what the plans launch)
+            assert ws.tb.uperm is not None
+            call("sehip_unpack_grad_sums_perm", ptr(ws.gpack), ptr(ws.tb.utab_g), ptr(ws.tb.uperm), n, ptr(grads), ptr(s["offsets"]),
+                 s["tsums"].numel(), ptr(s["sumsq"]), ptr(s["tsums"]), ptr(opt._step_dev), None, stream())
+            model._tail_done = True
+        elif fused:
             call("sehip_unpack_grad_sums", ptr(ws.gpack), ptr(ws.tb.utab), n, ptr(grads), ptr(s["offsets"]), s["tsums"].numel(),
                  ptr(s["sumsq"]), ptr(s["tsums"]), ptr(opt._step_dev), None, stream())
             model._tail_done = True
