@@ -612,8 +612,9 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_apply_fin_kernel(const bf16_ra
     // derives the channel's record straight into the slots the streaming loop reads; workgroup 0 stores the parameter gradients
     for (int c = threadIdx.x; c < Cr; c += 256) {
         const float* k = coef + (size_t)c * COEF_STRIDE;
-        const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
-        const float wrr = Wrr[c], wri = Wri[c], wii = Wii[c];
+        auto ldg = [&](const float* p_) { return (dbg_mode & 2) ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_; };
+        const float urr = ldg(k + 8), uri = ldg(k + 9), uii = ldg(k + 10), vrr = ldg(k + 11), vri = ldg(k + 12), vii = ldg(k + 13);
+        const float wrr = ldg(Wrr + c), wri = ldg(Wri + c), wii = ldg(Wii + c);
         double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int r0 = 0; r0 < nrep; r0 += 8) {                   // 48 independent loads per trip
             float v[8][6];

@@ -501,6 +501,32 @@ __device__ __forceinline__ void c3_body(const sehip_gemm_desc& d, const int B, c
     constexpr int NIT = WROWS / RPI, RD = NIT < 4 ? NIT : 4;
     const bf16_raw* rptr = (d.res && fdst == 0) ? reinterpret_cast<const bf16_raw*>(d.res) + fcoff : nullptr;
     const int tsz = ddF * ddC, bsz = ddT * ddF * ddC, jsz = ddfmul * ddC;
+    if (dense && rptr && with_stats) {
+        // A product that carries the layer's fused BatchNorm sums AND a residual (round 6: the main-source half of a decoder's forward
+        // product, whose skip-connection half ran earlier, under the LSTM, into `res`): the sums are of product + residual, so the
+        // residual joins the accumulators BEFORE the tile is staged -- 8-byte loads in the accumulator layout (row 16 mi + lane % 16,
+        // columns 16 ni + 4 (lane / 16) ...), all requested before the first use; the store loop then adds nothing.
+        const int basea = (ddtoff * ddF + ddfadd) * ddC + 4 * (lane >> 4);
+        uint2 rv[TM][TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            int tl, jl;
+            c3_row<J, TM>(wm, mi * 16 + (lane & 15), tl, jl);
+            const int bt = otab[tl];
+            const int ro = bt >= 0 ? (bt >> 16) * bsz + (bt & 0xffff) * tsz + jl * jsz + basea : -1;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                rv[mi][ni] = ro >= 0 ? *reinterpret_cast<const uint2*>(rptr + ro + ni * 16) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                acc[ni][mi][0] += __uint_as_float(rv[mi][ni].x << 16); acc[ni][mi][1] += __uint_as_float(rv[mi][ni].x & 0xffff0000u);
+                acc[ni][mi][2] += __uint_as_float(rv[mi][ni].y << 16); acc[ni][mi][3] += __uint_as_float(rv[mi][ni].y & 0xffff0000u);
+            }
+        rptr = nullptr;
+    }
     const int base0 = (ddtoff * ddF + ddfadd) * ddC + (lane % PPR) * 8;
     auto row_off = [&](int itr) {
         int tl, jl;

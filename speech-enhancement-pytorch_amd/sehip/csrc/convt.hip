@@ -43,7 +43,9 @@ __device__ unsigned long long ct_phase[8];
 #define CT_AUX 0              // cache policy of the frame DMAs (2 = nt: measured)
 #endif
 #define CT_OOB 0x7ffffff0u
-#define CT_RECORDS 0x7fff0000u
+// num_records = the tensor's own size (round 6; it was a fixed 0x7fff0000): an offset that leaves the tensor reads zeros like the padding
+// marker, not a neighbour's bytes.  bf16 tensors of geometry [B][T][F][C]; below 2^30 bytes (the launchers check).
+#define CT_BYTES(G_) (2u * (unsigned)B * (unsigned)(G_).T * (unsigned)(G_).F * (unsigned)(G_).C)
 
 template <int N>
 __device__ __forceinline__ void ct_wait_vm() {
@@ -247,14 +249,14 @@ __global__ __launch_bounds__(256, 2) void convt_stream_kernel(const sehip_gemm_d
     // (two named descriptors, not an array: hipcc's host pass silently drops every kernel of the file when a lambda hands an element of
     //  a captured array to the buffer-load builtin -- csrc/conv3.hip)
     const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_BYTES(d0.src[0]), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(NS == 2 ? d0.src[1].ptr : d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(NS == 2 ? d0.src[1].ptr : d0.src[0].ptr)), 0, NS == 2 ? CT_BYTES(d0.src[1]) : CT_BYTES(d0.src[0]), 0x00020000);
     const sehip_dst& dd = d0.dst[0];
     const unsigned obytes = (F32OUT ? 4u : 2u) * (unsigned)(dd.F * dd.C);      // bytes per output frame (= OUT_BYTES: dense rows, checked by the launcher)
     unsigned char* outp = reinterpret_cast<unsigned char*>(dd.ptr) + ((size_t)b * dd.T + dd.toff) * (size_t)obytes;
     const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(RES ? d0.res : dd.ptr)), 0, CT_RECORDS, 0x00020000);
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(RES ? d0.res : dd.ptr)), 0, CT_BYTES(dd), 0x00020000);
     const unsigned rbase = (unsigned)(b * dd.T + dd.toff) * obytes + 16u * (unsigned)tid;
 
     // issue(v): input frame v of the run (source frame t_lo + tmin_s + v) into ring slot v % R of every source, and the `res` tile of
@@ -546,12 +548,12 @@ __global__ __launch_bounds__(256, 2) void convs_stream_kernel(const sehip_gemm_d
     const unsigned fbytes = 2u * (unsigned)(S.F * S.C);
     const unsigned sbase = (unsigned)(b * S.T) * fbytes;
     const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_BYTES(S), 0x00020000);
     const sehip_dst& dy0 = d0.dst[0];
     const unsigned ybytes = 2u * (unsigned)(dy0.F * dy0.C);
     const unsigned ybase = (unsigned)(b * dy0.T + dy0.toff) * ybytes + 16u * (unsigned)tid;
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(BNR ? d0.bnr_y : S.ptr)), 0, CT_RECORDS, 0x00020000);
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(BNR ? d0.bnr_y : S.ptr)), 0, BNR ? CT_BYTES(dy0) : CT_BYTES(S), 0x00020000);
     auto issue = [&](int v) {
         const int u = t_lo + tmin + v;
         const bool ok = u >= S.tlo && u < S.thi && v <= nout;
@@ -762,12 +764,12 @@ __global__ __launch_bounds__(256, 2) void convn_stream_kernel(const sehip_gemm_d
     const unsigned fbytes = 2u * (unsigned)(S.F * S.C);
     const unsigned sbase = (unsigned)(b * S.T) * fbytes + 16u * (unsigned)lane;
     const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_BYTES(S), 0x00020000);
     const sehip_dst& dy0 = d0.dst[0];
     const unsigned ybytes = 2u * (unsigned)(dy0.F * dy0.C);
     const unsigned ybase = (unsigned)(b * dy0.T + dy0.toff) * ybytes + 16u * (unsigned)tid;
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(BNR ? d0.bnr_y : S.ptr)), 0, CT_RECORDS, 0x00020000);
+        const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(BNR ? d0.bnr_y : S.ptr)), 0, BNR ? CT_BYTES(dy0) : CT_BYTES(S), 0x00020000);
     auto issue = [&](int v) {                          // (the input frame by wave 0 only: one 1 KB instruction per frame)
         if (BNR) {                                     // the BatchNorm layer's convolution output at output frame v - 2: every wave, 4 KB
             const int o = v - 2;
@@ -1180,9 +1182,9 @@ __global__ __launch_bounds__(256, 2) void wgrads_stream_kernel(const sehip_gemm_
     const unsigned xfbytes = 2u * (unsigned)(S.F * S.C), gfbytes = 2u * (unsigned)(Gd.F * Gd.C);
     const unsigned xbase = (unsigned)(b * S.T) * xfbytes, gbase = (unsigned)(b * Gd.T + Gd.toff) * gfbytes;
     const __amdgpu_buffer_rsrc_t rsx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(S.ptr)), 0, CT_BYTES(S), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_BYTES(Gd), 0x00020000);
     // issue(v): input frame v of the run (source frame t_lo + tmin + v) and dOut frame v (t_lo + v); two instructions per call
     auto issue = [&](int v) {
         const int u = t_lo + tmin + v;
@@ -1418,11 +1420,11 @@ __global__ __launch_bounds__(256, (C * CO >= 2048 ? 1 : 2)) void wgradt_stream_k
     const unsigned gfbytes = 2u * (unsigned)(Gd.F * Gd.C);
     const unsigned gbase = (unsigned)(b * Gd.T + Gd.toff) * gfbytes;
     const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_BYTES(d0.src[0]), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[1].ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[1].ptr)), 0, CT_BYTES(d0.src[1]), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_BYTES(Gd), 0x00020000);
     // issue(v): frame v of the run of both sources (source frame t_lo + tmin_s + v) and dOut frame t_lo + v: three instructions
     auto issue = [&](int v) {
 #pragma unroll
@@ -1607,11 +1609,11 @@ __global__ __launch_bounds__(256, 2) void wgradt2_stream_kernel(const sehip_gemm
     const unsigned gfbytes = 2u * (unsigned)(Gd.F * Gd.C);           // 1024
     const unsigned gbase = (unsigned)(b * Gd.T + Gd.toff) * gfbytes + 16u * (unsigned)lane;
     const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[0].ptr)), 0, CT_BYTES(d0.src[0]), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[1].ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(d0.src[1].ptr)), 0, CT_BYTES(d0.src[1]), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Gd.ptr)), 0, CT_BYTES(Gd), 0x00020000);
     auto issue = [&](int v) {                          // two source pieces per thread; the dOut frame by wave 0 (third instruction)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {

@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void lstm2_fwd_kernel(const float* __restrict_
                                                         unsigned long long* gran, unsigned* sync, unsigned epoch) {
     __shared__ __attribute__((aligned(16))) bf16_raw hbuf[2][NBT * HP];
     __shared__ __attribute__((aligned(16))) bf16_raw xbuf[2][NBT * HP];
+    // (round 6: s_setprio 3 here -- the waves of this latency-bound chain winning their SIMDs' issue arbitration over co-resident
+    //  throughput work -- measured no effect, forward beside the decoders' skip halves 213 vs 216 us, backward 204 vs 203: what the
+    //  recurrence loses beside other kernels is hand-off latency through L2, not issue slots)
     const int ntiles = gridDim.x >> 3;
     const int cl = blockIdx.x / ntiles, tile = blockIdx.x - cl * ntiles;
     const int layer = cl >> 2, combo = cl & 3;

@@ -24,7 +24,6 @@ typedef __attribute__((address_space(3))) s16x4 w3_lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short w3_s16x8;
 
 #define W3_OOB 0x7ffffff0u
-#define W3_RECORDS 0x7fff0000u
 #define W3_ONES __builtin_bit_cast(bf16x8, (w3_s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
 
 template <int NF, int FM, int J, int NPL = 4>
@@ -93,10 +92,14 @@ __global__ __launch_bounds__(128 * NPL, 2) void conv_wgrad_v3_kernel(const sehip
     const int dt0 = (second ? d.cv_toff[1][0] : d.cv_toff[0][0]) - tmin, dt1 = (second ? d.cv_toff[1][1] : d.cv_toff[0][1]) - tmin;
     const int f0 = d.cv_fadd;
     const sehip_dst& dd = d.dst[0];
+    // num_records = the tensor's own size (round 6; it was a fixed 0x7fff0000): an offset that leaves the tensor reads zeros like the
+    // padding marker does, not a neighbour's bytes.  (Below 2^30 bytes: sehip_try_conv_wgrad_v3 checks.)
+    const unsigned recx = 2u * (unsigned)B * (unsigned)sT * (unsigned)sF * (unsigned)sC;
+    const unsigned recg = 2u * (unsigned)B * (unsigned)dd.T * (unsigned)dd.F * (unsigned)dd.C;
     const __amdgpu_buffer_rsrc_t rsx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Sr.ptr)), 0, W3_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(Sr.ptr)), 0, recx, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(dd.ptr)), 0, W3_RECORDS, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(reinterpret_cast<const bf16_raw*>(dd.ptr)), 0, recg, 0x00020000);
     const unsigned sframe = 2u * (unsigned)(sF * sC), gframe = 2u * (unsigned)(dd.F * dd.C);     // bytes per time frame
 
     // ---- DMA pieces of this thread.  dOut image: 8 planes (16 columns) x 64 rows x 32 B; piece Q = (NWV u + wave) * 64 + lane =

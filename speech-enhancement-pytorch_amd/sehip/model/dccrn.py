@@ -21,7 +21,7 @@ _STATIC_CACHE = {}
 
 def _static_for(cfg, deterministic=False):
     # (the experiment switches that DCCRNStatic reads when it is built are part of the key)
-    switches = tuple(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_STATS64", "SEHIP_NO_FUSE_STATS32"))
+    switches = tuple(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_STATS64", "SEHIP_NO_FUSE_STATS32", "SEHIP_DEC_SPLIT"))
     key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, switches,
            bool(deterministic))
     if key not in _STATIC_CACHE:

@@ -403,6 +403,50 @@ class GemmSpec:
 
 
 class DCCRNStatic:
+    def _maybe_split_decoder(self, j, pre, full, neg, cat1, cat2, c1, c2, co, f_in, s1, s1_mode, s2, bias_pairs):
+        """Round 6: a deep decoder layer's forward product as TWO products over its two sources (ComplexConvTranspose2d of
+        complex_cat([main, skip]), src/model/dccrn.py:186-197, :387-450, is linear in the concatenated channels): the skip-connection
+        half `dec{j}.fs{p}` (source: the encoder activation, ready since the encoder ran) runs on the weight-gradient stream, idle in the
+        forward pass, UNDER the two-layer LSTM (150 us on 64 of 256 CUs) and leaves a bf16 partial tensor `pd{j}`; the main half
+        `dec{j}.fm{p}` behind the LSTM has half the K steps, starts from nothing but adds the partial tile before it takes the fused
+        BatchNorm sums and stores (conv_gemm_v3's residual, csrc/conv3.hip).  Forward-only products: the weight gradients keep the
+        two-source descriptors `dec{j}.fwd{p}`.  Only where conv_gemm_v3 takes both halves."""
+        # MEASURED AND NOT THE DEFAULT (SEHIP_DEC_SPLIT=1 to enable): B = 32, same box, ms per step 3.166 / 3.161 with the split against
+        # 3.144 / 3.136 without (and 3.211 / 3.210 / 3.202 against 3.184 / 3.193 / 3.186 on another box).  The main halves do shrink
+        # (dec0 99 -> 72 us, dec1 105 -> 76, dec2 75 -> 69: prologue + epilogue + the partial tile's read do not halve with K), but the
+        # LSTM launch beside the three skip halves takes 216 us instead of 147 (its per-step hand-offs go through the same L2 the
+        # convolutions' DMA streams load; wave priority does not help, csrc/lstm2.hip) and its input product 54 instead of 39.
+        if not os.environ.get("SEHIP_DEC_SPLIT") or not TILE_WEIGHTS or co % 64 or c1 % 16 or c2 % 16:
+            return
+        names = []
+        for p in (0, 1):
+            ds = (-1, 0, 1) if p == 0 else (0, 1)
+            off1 = 0 if j == 0 else 1
+            rows_m, rows_s, cm_i, cm_n, cs_i, cs_n = [], [], [], [], [], []
+            for kt in (0, 1):
+                for d in ds:
+                    kf = p + 2 - 2 * d
+                    rows_m += wide_chunks(0, -kt + off1, d, 0, c1)
+                    rows_s += wide_chunks(0, -kt, d, 0, c2)
+                    cm_i.append(full[cat1, :, kf, kt].T); cm_n.append(neg[cat1, :, kf, kt].T)
+                    cs_i.append(full[cat2, :, kf, kt].T); cs_n.append(neg[cat2, :, kf, kt].T)
+            fs = GemmSpec(f"dec{j}.fs{p}", rows_s, np.concatenate(cs_i, 1), np.concatenate(cs_n, 1), co, None, "T+1", f_in, 1,
+                          [(s2, "all")], [(f"pd{j}", 0, 2, p)], kind="fwd_only", conv=(len(ds), ds[0], [[0, -1], [0, 0]]))
+            fm = GemmSpec(f"dec{j}.fm{p}", rows_m, np.concatenate(cm_i, 1), np.concatenate(cm_n, 1), co, bias_pairs, "T+1", f_in, 1,
+                          [(s1, s1_mode)], [(f"yd{j}", 0, 2, p)], kind="fwd_only", conv=(len(ds), ds[0], [[off1, off1 - 1], [0, 0]]),
+                          res=f"pd{j}")
+            if fs.v3_channels() is None or fm.v3_channels() is None:
+                return
+            names.append((fs, fm))
+        ref = self.specs[f"dec{j}.fwd0"]
+        for fs, fm in names:
+            if ref.stats_of is not None:
+                if co > 128:
+                    fs.tile_complex_columns(); fm.tile_complex_columns()
+                fm.stats_of = ref.stats_of
+            self.specs[fs.name] = fs; self.specs[fm.name] = fm
+        self.dec_split.append(j)
+
     def _maybe_fuse_stats(self, pre, names, co, cins, J):
         """Forward products that conv_gemm_v2 takes (64-multiple source channels, 128-multiple outputs, J | 128, J <= 64) also
         accumulate the batch statistics of the ComplexBatchNorm behind them: no cbn_stats pass for these layers."""
@@ -435,6 +479,7 @@ class DCCRNStatic:
         kn = cfg.kernel_num
         self.specs = {}
         self.bn = []  # (prefix, Cr)
+        self.dec_split = []    # decoder layers whose forward product runs as skip half (under the LSTM) + main half: _maybe_split_decoder
         ia = L.index_array
         self.F0 = cfg.fft_len // 2  # 256 bins after dropping DC
 
@@ -539,6 +584,7 @@ class DCCRNStatic:
             if not last:
                 self.bn.append((pre, co // 2))
                 self._maybe_fuse_stats(pre, [f"dec{j}.fwd0", f"dec{j}.fwd1"], co, [c1, c2], f_in)
+                self._maybe_split_decoder(j, pre, full, neg, cat1, cat2, c1, c2, co, f_in, s1, s1_mode, s2, eff_bias(pre, co // 2))
             # dgrad: dIn[b,t,fi,(s,c)] = sum dOut'[b,t+kt,2fi-2+kf,co] * full[cin,co,kf,kt]
             gsrc = "dmask" if last else f"dyd{j}"
             if co >= 8:
@@ -815,6 +861,8 @@ class DCCRNWorkspace:
             f, c = (F0 >> idx) * 2, kn[idx - 1]
             add(f"yd{j}", T + 1, f, c, 1); add(f"zd{j}", T + 1, f, c, 1)
             add(f"dyd{j}", T + 1, f, c, 1); add(f"dzd{j}", T + 1, f, c, 1)
+            if j in st.dec_split:
+                add(f"pd{j}", T + 1, f, c, 1)      # the skip-connection half of the layer's forward product (bf16 partial sums)
         add("mask", T, F0, 2, dtype=torch.float32)
         add("dmask", T, F0, 2)
         self.spec = torch.empty(B, T, 257, 2, dtype=torch.float32, device=device)
@@ -867,6 +915,7 @@ class DCCRNWorkspace:
             else:
                 self.side = torch.cuda.Stream(device=device)
         self._events, self._event_i, self._chain_dirty = [], 0, True
+        self._fs_events = []
         self.comm = None     # third stream: early un-pack + all-reduce of the decoder / LSTM gradients (data-parallel runs only)
         # The two stacked complex LSTM layers are pipelined over chunks of time steps: layer 2 (and the input product that
         # feeds it) runs chunk c on a second high-priority stream while layer 1 runs chunk c+1 (backward: the other way
@@ -913,9 +962,9 @@ class DCCRNWorkspace:
             return
         self.closed = True
         lib = _lib.lib()
-        for e in self._events:
+        for e in self._events + getattr(self, "_fs_events", []):
             lib.sehip_event_destroy(e)
-        self._events = []
+        self._events, self._fs_events = [], []
         if self._side_handle:
             lib.sehip_stream_destroy(self._side_handle)
             self._side_handle = None
@@ -1198,7 +1247,11 @@ class DCCRNWorkspace:
             units.append(one("sehip_gemm", f"enc{i}.fwd"))
             units.append(one("sehip_wgrad", f"enc{i}.fwd.wg"))
             units.append(one("sehip_gemm", f"dec{i}.dg"))
-            units.append(pair("sehip_gemm_pair", f"dec{i}.fwd0", f"dec{i}.fwd1"))
+            if i in self.st.dec_split and self.side is not None:      # (forward: the skip half under the LSTM + the main half)
+                units.append(pair("sehip_gemm_pair", f"dec{i}.fs0", f"dec{i}.fs1"))
+                units.append(pair("sehip_gemm_pair", f"dec{i}.fm0", f"dec{i}.fm1"))
+            else:
+                units.append(pair("sehip_gemm_pair", f"dec{i}.fwd0", f"dec{i}.fwd1"))
             units.append(pair("sehip_wgrad_pair", f"dec{i}.fwd0.wg", f"dec{i}.fwd1.wg"))
             if i > 0:
                 units.append(pair("sehip_gemm_pair", f"enc{i}.dg0", f"enc{i}.dg1"))
@@ -1433,10 +1486,29 @@ class DCCRNWorkspace:
         for i in range(6):
             self.gemm(f"enc{i}.fwd")
             self.bn_forward(f"encoder.{i}.", cfg.kernel_num[i + 1] // 2, b[f"y{i}"], b[f"z{i}"], params, buffers, nbt, training)
+        # the skip-connection halves of the deep decoders' forward products: on the weight-gradient stream (idle in the forward pass),
+        # behind the encoder, beside the LSTM's 64 workgroups (DCCRNStatic._maybe_split_decoder); one event per layer
+        split = st.dec_split if self.side is not None else []       # (also inside a stream capture: a fork / join of the graph, as the head)
+        if split:
+            sd = self.side.cuda_stream
+            call("sehip_stream_depend", sd, stream(), self._event())
+            if not self._fs_events:
+                for _ in range(6):
+                    e = _lib.lib().sehip_event_create()
+                    if not e:
+                        raise SehipError("sehip_event_create: " + _lib.lib().sehip_last_error().decode())
+                    self._fs_events.append(e)
+            for j in split:
+                call("sehip_gemm_pair", C.byref(self.desc[f"dec{j}.fs0"]), C.byref(self.desc[f"dec{j}.fs1"]), sd)
+                call("sehip_event_record", self._fs_events[j], sd)
         self._lstm_forward(B, T, h)
         self.gemm_pair("proj_r", "proj_i")
         for j in range(6):
-            self.gemm_pair(f"dec{j}.fwd0", f"dec{j}.fwd1")
+            if j in split:
+                call("sehip_stream_wait_event", stream(), self._fs_events[j])
+                self.gemm_pair(f"dec{j}.fm0", f"dec{j}.fm1")
+            else:
+                self.gemm_pair(f"dec{j}.fwd0", f"dec{j}.fwd1")
             if j < 5:
                 self.bn_forward(f"decoder.{j}.", cfg.kernel_num[5 - j] // 2, b[f"yd{j}"], b[f"zd{j}"], params, buffers, nbt,
                                 training)

@@ -156,7 +156,9 @@ def test_full_width_model_vs_oracle():
     print(f"ConvTasNet full width: bf16-storage oracle vs fp32 oracle gradients {sim_dev:.3e}")
     # the binding gate on the plain comparison: what bf16 storage alone does to the oracle (measured here: 5.1e-2; HIP vs fp32 oracle
     # 5.2e-2, HIP vs bf16-storage oracle 4.5e-2)
-    assert glob < 1.3 * sim_dev and glob_s < 1.1 * sim_dev, (glob, glob_s, sim_dev)
+    # (round 6: 1.0 x instead of 1.1 x; the tight gates are op-local, tests/test_gpu_convtasnet_fullwidth.py: all 14 blocks' products and
+    #  streams against float64 on their own operands, one bf16 ulp / 2e-5 / 2e-4)
+    assert glob < 1.3 * sim_dev and glob_s < 1.0 * sim_dev, (glob, glob_s, sim_dev)
     # the same comparison through the SAME branches (oracle/convtasnet_oracle.py:_prelu, act_masks from the HIP path's stored
     # pre-activations): what is left is the backward arithmetic itself
     ws = model.workspace(2, 8000)

@@ -514,7 +514,10 @@ def test_full_width_gradients_vs_oracle(depth, frames, batch):
     # bf16-storage oracle than that oracle is to the fp32 one (the two bf16 evaluations share most of their flipped branches; what
     # is left differs by summation order only).  Measured: plain 1.35e-1 vs storage-alone 1.33e-1, HIP vs bf16-storage oracle 8.7e-2
     # (depth 20: 2.77e-1 / 2.80e-1 / 1.86e-1).
-    assert glob_plain < 1.3 * sim_dev and glob_sim < sim_dev, (glob_plain, glob_sim, sim_dev)
+    # (round 6: 0.8 x instead of 1 x -- measured 0.65 / 0.66 of the storage-alone figure at depth 10 / 20; the gates that a few-percent
+    #  regression of ONE kernel cannot pass are the op-local ones of tests/test_gpu_dcunet_fullwidth.py: every product and
+    #  normalisation kernel at this width against float64 on its own operands, one bf16 ulp / 2e-5)
+    assert glob_plain < 1.3 * sim_dev and glob_sim < 0.8 * sim_dev, (glob_plain, glob_sim, sim_dev)
     assert out_sim < 0.8 * out_err + 1e-3                   # the output is closer to the bf16-storage oracle too (5.9e-3 vs 9.9e-3)
     glob, big = compare(grads2, "kink-aligned oracle")
     # twenty bf16 layers instead of ten, and the last encoders normalise over 16 ... 64 positions: about twice the noise

@@ -166,6 +166,60 @@ def test_decoder_tables_with_skip_concat_and_frame_drop(ctx, j):
     assert np.abs(got2 - cl(dskip)).max() < 1e-5
 
 
+def test_split_decoder_products_add_up_to_the_two_source_product():
+    """Round 6 (DCCRNStatic._maybe_split_decoder): the skip-connection half `dec{j}.fs{p}` and the main half `dec{j}.fm{p}` of a deep
+    decoder's forward product, interpreted from their tables, add up to the two-source product `dec{j}.fwd{p}` -- i.e. to the
+    reference's ComplexConvTranspose2d of complex_cat([main, skip]) (src/model/dccrn.py:186-197, :387-450); the bias rides in the
+    main half only; both are forward-only (no weight-gradient twin, no rows in the un-packing table)."""
+    import os
+    from sehip import plan
+    kw = dict(kernel_num=[16, 16, 32, 32, 64, 64], rnn_units=128, length=1200)      # (the shared fixture's widths have no 64-output decoder)
+    old_env = os.environ.get("SEHIP_DEC_SPLIT")
+    os.environ["SEHIP_DEC_SPLIT"] = "1"                 # (opt-in: measured slower in the step, see DCCRNStatic._maybe_split_decoder)
+    try:
+        st = plan.DCCRNStatic(plan.DCCRNConfig(**kw))
+    finally:
+        if old_env is None:
+            os.environ.pop("SEHIP_DEC_SPLIT", None)
+        else:
+            os.environ["SEHIP_DEC_SPLIT"] = old_env
+    p = O.init_params(O.DCCRNConfig(**kw), seed=3)
+    g = torch.Generator().manual_seed(4)
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = 0.1 * torch.randn(p[k].shape, generator=g)
+    flat = np.zeros(st.layout.n_params, dtype=np.float64)
+    for name in st.layout.param_names:
+        off, shape = st.layout.param_off[name]
+        flat[off:off + p[name].numel()] = p[name].reshape(-1).double().numpy()
+    assert st.dec_split, "no decoder layer of this configuration is split"
+    B, T = 2, 6
+    kn = st.cfg.kernel_num
+    for j in st.dec_split:
+        idx = 6 - j
+        c1, co, f_in = kn[idx], kn[idx - 1], 256 >> idx
+        a = torch.randn(B, c1, f_in, T, generator=g)
+        skip = torch.randn(B, c1, f_in, T, generator=g)
+        pre = f"decoder.{j}."
+        full = O.complex_deconv2d(O.complex_cat(a, skip), p[pre + "0.real_conv.weight"], p[pre + "0.real_conv.bias"],
+                                  p[pre + "0.imag_conv.weight"], p[pre + "0.imag_conv.bias"])
+        s1 = "P" if j == 0 else f"zd{j - 1}"
+        a_cl = cl(a)
+        if j > 0:
+            a_cl = np.concatenate([np.full((B, 1, f_in, c1), 7.0), a_cl], 1)
+        bufs = {s1: a_cl, f"z{5 - j}": cl(skip)}
+        shape = (B, T + 1, 2 * f_in, co)
+        part, got = np.zeros(shape), np.zeros(shape)
+        for par in (0, 1):
+            fs, fm = st.specs[f"dec{j}.fs{par}"], st.specs[f"dec{j}.fm{par}"]
+            assert fs.kind == fm.kind == "fwd_only" and fs.dw_off is None and fm.dw_off is None and fs.bias_pairs is None
+            assert fm.res == f"pd{j}" and fm.stats_of == st.specs[f"dec{j}.fwd{par}"].stats_of
+            part += scatter(run_spec(st, flat, fs, bufs, T, B), f"pd{j}", shape)
+            got += scatter(run_spec(st, flat, fm, bufs, T, B), f"yd{j}", shape)
+        assert np.abs(part + got - cl(full)).max() < 1e-5, j
+        assert np.abs(part).max() > 0.1 and np.abs(got).max() > 0.1
+
+
 def test_unpack_table_folds_block_gradients(ctx):
     """d(packed W) -> d(Wr), d(Wi): feed the packed-gradient buffer with the analytic block gradient of a linear probe."""
     st, flat = ctx["st"], ctx["flat"]

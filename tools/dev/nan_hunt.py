@@ -72,3 +72,28 @@ for i in range(5, -1, -1):
          ptr(rep[0]), ptr(rep[1]), 8, *[ptr(t) for t in gs], ptr(out), stream())
     torch.cuda.synchronize()
     print(f"     fused again: dy finite {fin(out)} grads finite {all(fin(t) for t in gs)}  (params finite {fin(params)})")
+# ---- pattern of the damage in encoder.5's dy against the separate launches on the same inputs
+i = 5
+pre = f"encoder.{i}."; cr = cfg.kernel_num[i + 1] // 2
+dz, y, dy = b["dz5l"], b[f"y{i}"], b[f"dye{i}"]
+rows = y.t.numel() // (2 * cr)
+coef = ws.bn_coef[pre]
+pp = lambda kk: params.data_ptr() + 4 * Lh.param_off[pre + kk][0]
+acc = torch.zeros(512 * (6 * cr + 1), device=params.device)
+bco = torch.zeros(cr, 16, device=params.device)
+gs = [torch.zeros(cr, device=params.device) for _ in range(5)] + [torch.zeros(1, device=params.device)]
+ref = torch.empty_like(dy.t)
+if bool(torch.isfinite(params).all()) or True:
+    # (the parameters may be NaN after a bad optimizer step: use finite stand-ins for Wrr / Wri / Wii / slope, the comparison is of structure)
+    W = [torch.full((cr,), v, device=params.device) for v in (0.7071, 0.0, 0.7071)]
+    sl = torch.full((1,), 0.25, device=params.device)
+    call("sehip_cbn_bwd_reduce", dz.ptr, None, y.ptr, ptr(coef), ptr(sl), rows, cr, y.F, y.Tst, 0, ptr(acc), stream())
+    call("sehip_cbn_bwd_finalize", ptr(acc), ptr(coef), ptr(W[0]), ptr(W[1]), ptr(W[2]), rows, cr, *[ptr(t) for t in gs], ptr(bco), stream())
+    call("sehip_cbn_bwd_apply", dz.ptr, None, y.ptr, ptr(coef), ptr(bco), ptr(sl), rows, cr, y.F, y.Tst, 0, ptr(ref), stream())
+    torch.cuda.synchronize()
+d = dy.t.float().reshape(rows, 2 * cr)
+nanmask = ~torch.isfinite(d)
+print("enc5 dy: non-finite elements", int(nanmask.sum()), "of", d.numel(), "| rows with any", int(nanmask.any(1).sum()), "| channels with any", int(nanmask.any(0).sum()))
+rws = nanmask.any(1).nonzero().flatten()
+print("   first bad rows", rws[:12].tolist(), "row mod 8 hist", torch.bincount(rws % 8, minlength=8).tolist())
+print("   bad channels", nanmask.any(0).nonzero().flatten().tolist()[:40])
