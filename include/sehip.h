@@ -246,7 +246,8 @@ typedef struct {
     /* 1: the caller vouches that the product is a plain dense one -- ONE source whose row m is the K contiguous elements at m K
      * (J = 1, F = 1, C = K, every frame valid, trivial chunk table) and ONE bf16 destination / dOut whose row m is the N = Npad
      * contiguous elements at m N: the 1x1 convolutions of ConvTasNet (src/model/conv_tasnet.py:307-402).  sehip_wgrad may then take
-     * dense_wgrad_kernel (N, K in {128, 256}); whatever it does not take runs as before. */
+     * dense_wgrad_kernel and sehip_gemm dense_rows_gemm_kernel (no bias; `res` honoured) for N, K in {128, 256}; whatever they do
+     * not take runs as before. */
     int32_t dense_rows;
     /* Deterministic schedule (sehip_set_deterministic): the launcher points dW / dbias at ONE PRIVATE ARRAY PER M-SPLIT of the launch
      * (floats between two splits' arrays; 0 = all splits add to the same dW with fp32 atomics, the default) and adds the arrays in
@@ -275,12 +276,21 @@ typedef struct {
     const float* bnr_coef;
     const float* bnr_slope;
     float* bnr_part;
+    /* Optional (sehip_gemm, dense-row forward products whose output feeds PReLU + gLN: the first 1x1 convolution of a ConvTasNet
+     * temporal block, src/model/conv_tasnet.py:366-379, :465-487): the launch also adds, per utterance (TT rows each), the sum and
+     * the sum of squares of PReLU(out; *gln_slope) of the bf16 values it stores to gln_stats[2 m .. 2 m + 1] (double atomics; the caller
+     * zeroes them) -- what sehip_ctn_gln_stats would read the tensor back for.  Honoured by dense_rows_gemm_kernel only: ask
+     * sehip_gemm_takes_gln_stats first; 0 = run sehip_ctn_gln_stats as before (the fields are then ignored). */
+    double* gln_stats;
+    const float* gln_slope;
 } sehip_gemm_desc;
 
 int sehip_gemm_desc_size(void);
 /* rows of 6 Cr + 1 sums the product (pair: b != NULL) writes at bnr_part when launched with the bnr_* fields set, 0 if it does not
  * compute the reduce pass (then run sehip_cbn_bwd_reduce).  Depends on the shapes only: ask once per workspace. */
 int sehip_bnr_rows(const sehip_gemm_desc* a, const sehip_gemm_desc* b /* or NULL */);
+/* 1 when sehip_gemm(desc) will honour desc->gln_stats (the dense-row kernel takes the product), else 0.  Shapes only: ask once. */
+int sehip_gemm_takes_gln_stats(const sehip_gemm_desc* desc);
 /* Deterministic reductions, process-wide (the reference's switch is config.solver.cudnn_deterministic -> src/utils.py:108-111): with
  * on != 0 every floating-point sum whose order depends on scheduling takes a fixed-order form -- weight gradients through per-split
  * partial arrays added in split order (sehip_wgrad; grouped launches run one by one; the store-flush kernels already do), the

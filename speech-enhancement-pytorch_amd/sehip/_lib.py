@@ -64,6 +64,7 @@ _PROTOS = {
     "sehip_opt_begin_g": [P, I, P, P, I, P, P],
     "sehip_counter_add": [P, I, P],
     "sehip_zero_regions": [P, L, P, L, P, L, P, L, P],
+    "sehip_gemm_takes_gln_stats": [P],
     "sehip_init": [],
     "sehip_grad_metric": [P, P, I, L, P, P, P, P],
     "sehip_opt_begin": [P, I, P, P, I, P],

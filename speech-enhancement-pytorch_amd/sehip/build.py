@@ -25,7 +25,9 @@ def _stale(src, obj):
     if not os.path.exists(obj):
         return True
     m = os.path.getmtime(obj)
+    # (the public header too: sehip_gemm_desc is passed to kernels by value, a stale object would read another layout)
     deps = [src] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "sehip.h"))
     return any(os.path.getmtime(d) > m for d in deps)
 
 

@@ -707,6 +707,7 @@ int sehip_try_wgrads_stream(const sehip_gemm_desc& a, hipStream_t st);          
 int sehip_try_wgradt_stream(const sehip_gemm_desc& a, const sehip_gemm_desc& b, hipStream_t st);   // convt.hip
 void sehip_wgrad3_init(void);
 int sehip_try_dense_wgrad(const sehip_gemm_desc& d, hipStream_t st);   // wgrad3.hip
+int sehip_try_dense_rows_gemm(const sehip_gemm_desc& d, hipStream_t st);   // dgemm.hip
 
 // returns 1 if the LDS-patch kernel was launched, 0 if the descriptor does not qualify
 static int try_conv_gemm(const sehip_gemm_desc& d, hipStream_t st) {
@@ -1650,6 +1651,10 @@ extern "C" int sehip_gemm(const sehip_gemm_desc* d, void* stream) {
     }
     if (try_conv_narrow(*d, st)) {
         SEHIP_CHECK_LAUNCH("gemm(conv-narrow)");
+        return 0;
+    }
+    if (sehip_try_dense_rows_gemm(*d, st)) {      // plain dense rows, the whole reduction in one pass (ConvTasNet's 1x1 convolutions)
+        SEHIP_CHECK_LAUNCH("gemm(dense-rows)");
         return 0;
     }
     sehip_note_kernel("gemm_kernel<%d, %d, %d, %d>", d->Npad <= 64 ? d->Npad : 128, d->Npad <= 64 ? 256 : 128,

@@ -10,9 +10,9 @@
 #include <stdlib.h>
 
 __device__ __forceinline__ float term(const float* __restrict__ src, int e) {
-    if (e < 0) return 0.f;
-    const float v = src[e >> 1];
-    return (e & 1) ? -v : v;
+    // (unconditional load -- entry 0 stands in for an absent one: a predicated load is waited for at once and serialises its neighbours)
+    const float v = src[(e < 0 ? 0 : e) >> 1];
+    return e < 0 ? 0.f : ((e & 1) ? -v : v);
 }
 
 // eight outputs per thread: two 16-byte table loads, eight gathers in flight, one 16-byte store (one element per thread
@@ -98,14 +98,10 @@ __global__ __launch_bounds__(256) void unpack_grad_sums_kernel(const float* __re
     long lo = (long)blockIdx.x * per;
     const long hi = min(n, lo + per);
     if (lo >= hi) return;
-    if (threadIdx.x == 0) {          // the tensor that holds parameter lo: largest t with offsets[t] <= lo
-        int a = 0, b = ntensors - 1;
-        while (a < b) {
-            const int mid = (a + b + 1) >> 1;
-            if (offsets[mid] <= lo) a = mid; else b = mid - 1;
-        }
-        first = a;
-    }
+    // the tensor that holds parameter lo (round 6: every thread tests its share of the boundaries -- ONE round trip; the binary search
+    // by one thread was eight dependent ones before the block's first useful load)
+    for (int i = threadIdx.x; i < ntensors; i += 256)
+        if (offsets[i] <= lo && lo < offsets[i + 1]) first = i;
     __syncthreads();
     int t = first;
     float q = 0.f;
@@ -113,15 +109,34 @@ __global__ __launch_bounds__(256) void unpack_grad_sums_kernel(const float* __re
         const long e = min(hi, offsets[t + 1]);
         if (e > lo) {
             float acc = 0.f;
-            for (long i = lo + threadIdx.x; i < e; i += 256) {
+            long i = lo + threadIdx.x;
+            // (round 6: four table rows, then their up to sixteen gathers, requested before the first use -- the walk was two dependent
+            //  round trips per parameter, eight parameters per thread: 54 us whatever the traffic, 281 MB or 122 MB)
+            for (; i + 3 * 256 < e; i += 4 * 256) {
+                int4 en[4];
+                long dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { en[u] = tab[i + u * 256]; dst[u] = perm ? (long)perm[i + u * 256] : i + u * 256; }
+                float g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = term(packed, en[u].x) + term(packed, en[u].y) + term(packed, en[u].z) + term(packed, en[u].w);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { grads[dst[u]] = g[u]; acc += g[u]; q += g[u] * g[u]; }
+            }
+            for (; i < e; i += 256) {
                 const int4 en = tab[i];
                 const float g = term(packed, en.x) + term(packed, en.y) + term(packed, en.z) + term(packed, en.w);
                 grads[perm ? (long)perm[i] : i] = g;
                 acc += g;
                 q += g * g;
             }
-            acc = block_sum<4>(acc, red);
-            if (threadIdx.x == 0) atomicAdd(&tsums[t], acc);
+            if (e - lo > 256) {        // (one atomic per block and tensor: per-wave atomics on a large tensor's ONE address cost more -- 61 vs 49 us)
+                acc = block_sum<4>(acc, red);
+                if (threadIdx.x == 0) atomicAdd(&tsums[t], acc);
+            } else {                   // a run of small tensors (biases, BatchNorm / PReLU parameters): per wave, no block barriers
+                acc = wave_sum(acc);
+                if ((threadIdx.x & 63) == 0 && lo + (threadIdx.x & ~63) < e) atomicAdd(&tsums[t], acc);
+            }
             lo = e;
         }
         ++t;

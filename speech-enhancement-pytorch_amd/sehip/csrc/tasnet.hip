@@ -32,6 +32,15 @@ __device__ __forceinline__ C8 ld8(const bf16_raw* p) {
 __device__ __forceinline__ void st8(bf16_raw* p, const float* v) {
     *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
+__device__ __forceinline__ uint4 ld8raw(const bf16_raw* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ C8 unpack8(const uint4 u) {
+    C8 c;
+    c.v[0] = bf2f((bf16_raw)(u.x & 0xffff)); c.v[1] = bf2f((bf16_raw)(u.x >> 16));
+    c.v[2] = bf2f((bf16_raw)(u.y & 0xffff)); c.v[3] = bf2f((bf16_raw)(u.y >> 16));
+    c.v[4] = bf2f((bf16_raw)(u.z & 0xffff)); c.v[5] = bf2f((bf16_raw)(u.z >> 16));
+    c.v[6] = bf2f((bf16_raw)(u.w & 0xffff)); c.v[7] = bf2f((bf16_raw)(u.w >> 16));
+    return c;
+}
 __device__ __forceinline__ C8 zero8() { C8 c; for (int j = 0; j < 8; ++j) c.v[j] = 0.f; return c; }
 __device__ __forceinline__ float prelu(float h, float a) { return h > 0.f ? h : a * h; }
 
@@ -531,6 +540,7 @@ __global__ __launch_bounds__(256) void ctn_gln_stats_kernel(const bf16_raw* __re
     const long pieces = (long)K * nq;
     const bf16_raw* base = h + (long)m * K * C;
     float s = 0.f, q = 0.f;
+    // (three pieces in flight per thread measured the same 11.2 us per launch: 26 MB at the launch floor)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
         const C8 x = ld8(base + i * 8);
 #pragma unroll
@@ -583,6 +593,7 @@ __global__ __launch_bounds__(256) void ctn_dwconv_fwd_kernel(const bf16_raw* __r
 #pragma unroll
             for (int p = 0; p < P; ++p) wd[p][j] = Wd[(pm.c0 + j) * P + p];
         }
+        // (two output rows -- six loads -- in flight per thread measured 22.8 us per launch against 21.6: one row)
         for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
             C8 x[P];
             bool ok[P];
@@ -675,35 +686,47 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
 #pragma unroll
             for (int p = 0; p < (DW ? P : 1); ++p) wd[p][j] = DW ? Wd[(pm.c0 + j) * P + p] : 0.f;
         }
-        for (int t = blockIdx.x * pm.rpb + pm.rsub; t < K; t += gridDim.x * pm.rpb) {
-            const C8 x = ld8(hb + (long)t * C);
-            C8 dy;
+        // Rows in flight (round 6): a workgroup walks ~12 trips of one row per thread, each a dependent round trip to memory with 2-4
+        // loads behind it -- 3.0 TB/s for the DW = false pass.  U rows are requested before the first is used (more workgroups instead
+        // cost the apply pass, which adds their partial rows: SEHIP_CTN_RBLOCKS).
+        constexpr int U = DW ? 1 : 4;      // (measured: DW = false 24.3 -> 19.0 us per launch; DW = true 30.2 -> 30.1 with two rows: one)
+        struct Row { uint4 x; uint4 gq[DW ? P : 1]; };        // (raw 16-byte pieces: un-packed when the row is used)
+        auto load_row = [&](int t) {
+            Row r;
+            r.x = ld8raw(hb + (long)t * C);
             if (!DW) {
-                dy = ld8(gb + (long)t * C);
+                r.gq[0] = ld8raw(gb + (long)t * C);
             } else {
-                // rows t - d, t, t + d of dh2 serve BOTH sums (round 6; it was 3 more rows of h and the normalisation three times per
-                // element): dy[t] = sum_p' Wd[p'] dh2[t - (p' - P/2) d], and dWd[p'] = sum_t dh2[t - (p' - P/2) d] n[t] -- the same
-                // pairs (t - (p' - P/2) d, t) as sum_t dh2[t] n[t + (p' - P/2) d], indexed by the row that holds n.  4 loads in flight.
-                C8 gq[P];
-                bool ok[P];
+                // rows t - d, t, t + d of dh2 serve BOTH sums (it was 3 more rows of h and the normalisation three times per element):
+                // dy[t] = sum_p' Wd[p'] dh2[t - (p' - P/2) d], and dWd[p'] = sum_t dh2[t - (p' - P/2) d] n[t] -- the same pairs
+                // (t - (p' - P/2) d, t) as sum_t dh2[t] n[t + (p' - P/2) d], indexed by the row that holds n
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int tt = t + (p - P / 2) * dil;
-                    ok[p] = tt >= 0 && tt < K;
-                    gq[p] = ld8(gb + (long)(ok[p] ? tt : t) * C);
+                    r.gq[p] = ld8raw(gb + (long)((tt >= 0 && tt < K) ? tt : t) * C);
                 }
+            }
+            return r;
+        };
+        auto do_row = [&](const Row& r, int t) {
+            const C8 x = unpack8(r.x);
+            C8 dy;
+            if (!DW) {
+                dy = unpack8(r.gq[0]);
+            } else {
                 float nt[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) nt[j] = gm[j] * ((prelu(x.v[j], a) - mu) * rs) + bt[j];
                 dy = zero8();
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    // the row t + (p - P/2) d is t - (p' - P/2) d for tap p' = P - 1 - p
-                    if (ok[p]) {
+                    const int tt = t + (p - P / 2) * dil;      // the row t + (p - P/2) d is t - (p' - P/2) d for tap p' = P - 1 - p
+                    if (tt >= 0 && tt < K) {
+                        const C8 gp = unpack8(r.gq[p]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            dy.v[j] += wd[P - 1 - p][j] * gq[p].v[j];
-                            dw[P - 1 - p][j] += gq[p].v[j] * nt[j];
+                            dy.v[j] += wd[P - 1 - p][j] * gp.v[j];
+                            dw[P - 1 - p][j] += gp.v[j] * nt[j];
                         }
                     }
                 }
@@ -716,7 +739,17 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
                 dg[j] += dy.v[j] * xh; db[j] += dy.v[j];
                 if (!(x.v[j] > 0.f)) { qa += gd * x.v[j]; qb += x.v[j]; qc += xh * x.v[j]; }
             }
+        };
+        const int stride = gridDim.x * pm.rpb;
+        int t = blockIdx.x * pm.rpb + pm.rsub;
+        for (; t + (U - 1) * stride < K; t += U * stride) {
+            Row r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = load_row(t + u * stride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) do_row(r[u], t + u * stride);
         }
+        for (; t < K; t += stride) do_row(load_row(t), t);
     }
     // per-channel partials of the block.  nq a power of two <= 64: the lanes of a wave that hold the same channels (nq apart) meet by
     // xor-shuffles, then the four waves add their words one after the other with plain read-add-write (ds_add_f32 from all lanes

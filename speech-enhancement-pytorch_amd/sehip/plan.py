@@ -48,7 +48,8 @@ class CGemmDesc(C.Structure):
                 ("dw_split_stride", C.c_int64),
                 ("bn_dz", C.c_void_p), ("bn_y", C.c_void_p), ("bn_coef", C.c_void_p), ("bn_bcoef", C.c_void_p),
                 ("bn_slope", C.c_void_p),
-                ("bnr_y", C.c_void_p), ("bnr_coef", C.c_void_p), ("bnr_slope", C.c_void_p), ("bnr_part", C.c_void_p)]
+                ("bnr_y", C.c_void_p), ("bnr_coef", C.c_void_p), ("bnr_slope", C.c_void_p), ("bnr_part", C.c_void_p),
+                ("gln_stats", C.c_void_p), ("gln_slope", C.c_void_p)]
 
 
 # The gradient that arrives over the skip connection is added by the dgrad product that writes the encoder output's gradient

@@ -249,6 +249,9 @@ class TasNetWorkspace:
             d.TT, d.J, d.fmul, d.tmul = K, 1, 1, 1
             if s.res is not None:
                 d.res = self.bufs[s.res].ptr
+            # (every product here is a 1x1 convolution over dense rows: the library may take the streaming dense-row kernels --
+            #  csrc/dgemm.hip forward / input gradient, csrc/wgrad3.hip weight gradient -- where the widths are ones they are built for)
+            d.dense_rows = 1 if (b.C == s.K and o.C == s.Npad == s.N) else 0
             self.desc[name] = d
             if s.dw_off is not None:
                 w = CGemmDesc.from_buffer_copy(d)
@@ -258,6 +261,11 @@ class TasNetWorkspace:
                 w.dense_rows = 1 if (b.C == s.K and o.C == s.Npad == s.N) else 0     # every product here is a 1x1 convolution over dense rows
                 w.wg_hint = 160          # measured at the C4 shape (ms per step): 96: 4.28, 128: 3.68, 160: 3.59, 192: 3.79, 256: 3.75
                 self.desc[name + ".wg"] = w
+        # round 6: the gLN statistics of every block's first 1x1 output inside the product's launch, where the dense-row kernel takes it
+        # (sehip_gemm_desc.gln_stats; SEHIP_CTN_NO_FUSED_GLN=1: the separate sehip_ctn_gln_stats pass)
+        lib_ = _lib.lib()
+        self.fused_gln = (not os.environ.get("SEHIP_CTN_NO_FUSED_GLN") and len(st.blocks) > 0 and
+                          all(int(lib_.sehip_gemm_takes_gln_stats(C.byref(self.desc[f"b{i}.in.fwd"]))) == 1 for i in range(len(st.blocks))))
 
     def gemm(self, name):
         self._chain_dirty = True
@@ -309,8 +317,13 @@ class TasNetWorkspace:
         for i, (r, x) in enumerate(st.blocks):
             q = f"{net}2.{r}.{x}.net."
             s1 = self.stats[i, 0].data_ptr(); s2 = self.stats[i, 1].data_ptr()
-            self.gemm(f"b{i}.in.fwd")
-            call("sehip_ctn_gln_stats", b[f"h1_{i}"].ptr, pp(q + "1.weight"), M, K, H, s1, stream())
+            if self.fused_gln:      # the product's launch also takes the gLN statistics of what it stores (csrc/dgemm.hip)
+                d = self.desc[f"b{i}.in.fwd"]
+                d.gln_stats, d.gln_slope = s1, pp(q + "1.weight")
+                self.gemm(f"b{i}.in.fwd")
+            else:
+                self.gemm(f"b{i}.in.fwd")
+                call("sehip_ctn_gln_stats", b[f"h1_{i}"].ptr, pp(q + "1.weight"), M, K, H, s1, stream())
             call("sehip_ctn_dwconv_fwd", b[f"h1_{i}"].ptr, pp(q + "1.weight"), s1, pp(q + "2.gamma"), pp(q + "2.beta"),
                  pp(q + "3.net.0.weight"), cfg.P, 2 ** x, pp(q + "3.net.1.weight"), M, K, H, b[f"h2_{i}"].ptr, s2, stream())
             call("sehip_ctn_gln_apply", b[f"h2_{i}"].ptr, pp(q + "3.net.1.weight"), s2, pp(q + "3.net.2.gamma"), pp(q + "3.net.2.beta"),

@@ -53,7 +53,7 @@ def test_split_decoder_products_match_the_two_source_products(kw, B):
         ya, yb = a["ws"].bufs[f"yd{j}"].t.float().cpu(), b["ws"].bufs[f"yd{j}"].t.float().cpu()
         e = rel_err(yb, ya)
         print(f"decoder {j}: split vs two-source pre-BatchNorm tensor rel {e:.2e}")
-        assert e < 4e-3, (j, e)
+        assert e < 7e-3, (j, e)          # (two independent roundings of the stored tensor, 1.66e-3 each, + the partial tile's)
     e_est, e_grad = rel_err(b["est"], a["est"]), rel_err(b["grads"], a["grads"])
     print(f"split vs default: waveform rel {e_est:.2e}, |loss a - loss b| {abs(a['loss'] - b['loss']):.4f} dB, gradient rel {e_grad:.2e}")
     assert e_est < 8e-3 and abs(a["loss"] - b["loss"]) < 0.05 and e_grad < 3e-2
