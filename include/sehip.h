@@ -416,6 +416,14 @@ int sehip_cbn_bwd_fused(const void* dz, const void* dz2 /*or NULL*/, const void*
                         const float* Wii, const float* slope, long rows, int Cr, int F, int Tst, int tfirst, float* rep, float* rep_next,
                         int nrep,
                         float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi, float* gslope, void* dy, void* stream);
+/* sehip_cbn_bwd_reduce + sehip_cbn_bwd_finalize in ONE launch: every workgroup adds its block sums to `rep` ([nrep][6 Cr + 1] fp32,
+ * nrep <= 64, zero on entry) with atomics, the last one to finish (device counter `ticket`, zero on entry) derives the parameter
+ * gradients and the apply pass's records `bcoef` from the rows and leaves rows and counter zero again for the next call; follow with
+ * sehip_cbn_bwd_apply.  Not in the deterministic schedule. */
+int sehip_cbn_bwd_reduce_fin(const void* dz, const void* dz2 /*or NULL*/, const void* y, const float* coef, const float* Wrr,
+                             const float* Wri, const float* Wii, const float* slope, long rows, int Cr, int F, int Tst, int tfirst,
+                             float* rep, int nrep, unsigned* ticket, float* gWrr, float* gWri, float* gWii, float* gBr, float* gBi,
+                             float* gslope, float* bcoef /*[Cr][16]*/, void* stream);
 int sehip_cbn_bwd_apply(const void* dz, const void* dz2, const void* y, const float* coef, const float* bcoef,
                         const float* slope, long rows, int Cr, int F, int Tst, int tfirst, void* dy, void* stream);
 
@@ -439,6 +447,11 @@ int sehip_rbn_finalize_s(const float* part, const float* w_re, const float* b_re
                          float momentum, int training, const float* shift, float* coef, void* stream);
 int sehip_rbn_apply(const void* y, const float* coef, long rows, int Cs, int Cr, void* z, void* stream);
 int sehip_rbn_bwd_reduce(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part, void* stream);
+/* sehip_rbn_bwd_reduce + sehip_rbn_bwd_finalize in ONE launch: the last workgroup of the reduce pass to finish (device counter
+ * `ticket`: zero on entry, left zero) adds the partial rows in row order and writes the gradients and `bcoef`; no launch of its own
+ * that would wait for a CU beside long-lived weight-gradient workgroups.  Deterministic (fixed order, no atomics on data). */
+int sehip_rbn_bwd_reduce_fin(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part, unsigned* ticket,
+                             float* gw_re, float* gb_re, float* gw_im, float* gb_im, float* bcoef, void* stream);
 int sehip_rbn_bwd_finalize(const float* part, const float* coef, long rows, int Cs, int Cr, float* gw_re, float* gb_re, float* gw_im,
                            float* gb_im, float* bcoef, void* stream);
 int sehip_rbn_bwd_apply(const void* dz, const void* y, const float* coef, const float* bcoef, long rows, int Cs, int Cr, void* dy,

@@ -109,12 +109,14 @@ _PROTOS = {
     "sehip_cbn_bwd_finalize": [P, P, P, P, P, L, I, P, P, P, P, P, P, P, P],
     "sehip_cbn_bwd_apply": [P, P, P, P, P, P, L, I, I, I, I, P, P],
     "sehip_cbn_bwd_fused": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, I, P, P, P, P, P, P, P, P],
+    "sehip_cbn_bwd_reduce_fin": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, I, P, P, P, P, P, P, P, P, P],
     "sehip_rbn_scratch_floats": [L, I],
     "sehip_rbn_stats": [P, L, I, I, P, P],
     "sehip_rbn_finalize": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, F, I, P, P],
     "sehip_rbn_finalize_s": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, F, F, I, P, P, P],
     "sehip_rbn_apply": [P, P, L, I, I, P, P],
     "sehip_rbn_bwd_reduce": [P, P, P, L, I, I, P, P],
+    "sehip_rbn_bwd_reduce_fin": [P, P, P, L, I, I, P, P, P, P, P, P, P, P],
     "sehip_rbn_bwd_finalize": [P, P, L, I, I, P, P, P, P, P, P],
     "sehip_rbn_bwd_apply": [P, P, P, P, L, I, I, P, P],
     "sehip_dcunet_pack_input": [P, I, I, I, P, P],

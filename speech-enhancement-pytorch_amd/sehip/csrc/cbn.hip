@@ -385,11 +385,27 @@ __device__ __forceinline__ RowIn<CH, HAS2> load_row(const bf16_raw* __restrict__
     return v;
 }
 
+// The finalize step inside the reduce launch (round 6, sehip_cbn_bwd_reduce_fin): with nrep > 0 (block sums added to nrep replica
+// rows) and fin.ticket != NULL, the LAST workgroup to finish -- a ticket counter behind a device-scope release of its adds -- derives
+// every channel's parameter gradients and apply-pass record from the rows (what cbn_bwd_finalize_kernel does in a launch of its
+// own: 11 launches, 0.10 ms of the DCCRN chain for microseconds of work), writes them where the plain apply pass reads them, and
+// leaves the rows and the counter zero for the next call.  ONE workgroup finalizes and the coefficients travel through global
+// memory as in the three-launch form: the per-workgroup finalize of cbn_bwd_apply_fin_kernel is what produced non-finite rows beside
+// the weight-gradient stream.
+struct CbnFin {
+    const float *Wrr, *Wri, *Wii;
+    float *gWrr, *gWri, *gWii, *gBr, *gBi, *gslope, *bcoef;
+    unsigned* ticket;
+};
+__device__ __forceinline__ void cbn_bwd_record(float sdr, float sdi, float qrr, float qri, float qir, float qii, float urr, float uri,
+                                               float uii, float vrr, float vri, float vii, float wrr, float wri, float wii, float n,
+                                               float (&g5)[5], float (&o)[9]);
+
 template <int U, int CH, bool HAS2>
 __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
                                                                 const bf16_raw* __restrict__ y, const float* __restrict__ coef,
                                                                 const float* __restrict__ slope, long rows, int Cr, int F,
-                                                                int Tst, int tfirst, float* __restrict__ part, int nrep) {
+                                                                int Tst, int tfirst, float* __restrict__ part, int nrep, const CbnFin fin) {
     __shared__ float lds[4 * 6 * 8 * 32];
     const int nq = Cr / CH;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
@@ -453,6 +469,61 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* 
         if (nrep > 0) atomicAdd(&part[(size_t)(blockIdx.x % nrep) * (6 * Cr + 1) + 6 * Cr], t);
         else part[(size_t)blockIdx.x * (6 * Cr + 1) + 6 * Cr] = t;
     }
+    if (nrep <= 0 || fin.ticket == nullptr) return;
+    // ---- last workgroup: finalize.  Release (every thread's adds are performed device-wide before the ticket is drawn), ticket,
+    // acquire; the rows are read with device-scope loads (they were written by atomics of every XCD)
+    // (cdna_hip_programming.md, slab-reducer recipe: every wave drains its own memory operations, ONE lane per workgroup releases and
+    //  draws the ticket -- a device-scope fence per thread is an L2 write-back per wave: +0.58 ms per step when every thread did it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned is_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        is_last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int st = 6 * Cr + 1;
+    for (int c = threadIdx.x; c < Cr; c += 256) {
+        const float* k = coef + (size_t)c * COEF_STRIDE;
+        const float urr = k[8], uri = k[9], uii = k[10], vrr = k[11], vri = k[12], vii = k[13];
+        const float wrr = fin.Wrr[c], wri = fin.Wri[c], wii = fin.Wii[c];
+        double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // (plain loads behind the acquire fence, 48 in flight per trip: one device-scope atomic load per value was 48 dependent round
+        //  trips in the one workgroup everybody waits for -- 3.80 ms per step instead of 3.22)
+        for (int r0 = 0; r0 < nrep; r0 += 8) {
+            float v[8][6];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) v[r][kk] = part[(size_t)(r0 + r < nrep ? r0 + r : 0) * st + kk * Cr + c];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) a6[kk] += r0 + r < nrep ? (double)v[r][kk] : 0.0;
+        }
+        float g5[5], rec[9];
+        cbn_bwd_record((float)a6[0], (float)a6[1], (float)a6[2], (float)a6[3], (float)a6[4], (float)a6[5], urr, uri, uii, vrr, vri, vii,
+                       wrr, wri, wii, (float)rows, g5, rec);
+        fin.gWrr[c] = g5[0]; fin.gWri[c] = g5[1]; fin.gWii[c] = g5[2]; fin.gBr[c] = g5[3]; fin.gBi[c] = g5[4];
+        float* o = fin.bcoef + (size_t)c * COEF_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o[i] = rec[i];
+    }
+    if (threadIdx.x == 255) {
+        double ds = 0.0;
+        for (int r = 0; r < nrep; ++r) ds += (double)part[(size_t)r * st + 6 * Cr];
+        fin.gslope[0] = (float)ds;
+    }
+    __syncthreads();                 // every row has been read: clear them and the counter for the layer's next call
+    for (int i = threadIdx.x; i < nrep * st; i += 256) part[i] = 0.f;
+    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // parameter gradients (g5: dWrr dWri dWii dBr dBi) and the apply pass's record of one channel from its six sums
@@ -839,11 +910,12 @@ extern "C" int sehip_cbn_finalize_apply_n(const void* y, const float* part, int 
 }
 
 static int cbn_bwd_reduce_launch(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
-                                 long rows, int Cr, int F, int Tst, int tfirst, float* part, int nrep, void* stream) {
+                                 long rows, int Cr, int F, int Tst, int tfirst, float* part, int nrep, void* stream,
+                                 const CbnFin fin = CbnFin{}) {
     if (int e = check_cbn("cbn_bwd_reduce", rows, Cr)) return e;
     SEHIP_REQUIRE(rows < (1L << 31), "cbn_bwd_reduce: %ld rows exceed the 32-bit frame arithmetic", rows);
 #define CBN_RED(U, CH, H2) cbn_bwd_reduce_kernel<U, CH, H2><<<stat_blocks(rows, Cr), 256, 0, (hipStream_t)stream>>>( \
-        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part, nrep)
+        (const bf16_raw*)dz, (const bf16_raw*)dz2, (const bf16_raw*)y, coef, slope, rows, Cr, F, Tst, tfirst, part, nrep, fin)
 #define CBN_RED2(U, CH) do { if (dz2) CBN_RED(U, CH, true); else CBN_RED(U, CH, false); } while (0)
     switch (unroll_rows_bwd() * 16 + cbn_ch(Cr)) {
         case 1 * 16 + 8: CBN_RED2(1, 8); break;
@@ -861,6 +933,17 @@ static int cbn_bwd_reduce_launch(const void* dz, const void* dz2, const void* y,
 extern "C" int sehip_cbn_bwd_reduce(const void* dz, const void* dz2, const void* y, const float* coef, const float* slope,
                                     long rows, int Cr, int F, int Tst, int tfirst, float* part, void* stream) {
     return cbn_bwd_reduce_launch(dz, dz2, y, coef, slope, rows, Cr, F, Tst, tfirst, part, 0, stream);
+}
+
+extern "C" int sehip_cbn_bwd_reduce_fin(const void* dz, const void* dz2, const void* y, const float* coef, const float* Wrr,
+                                        const float* Wri, const float* Wii, const float* slope, long rows, int Cr, int F, int Tst,
+                                        int tfirst, float* rep, int nrep, unsigned* ticket, float* gWrr, float* gWri, float* gWii,
+                                        float* gBr, float* gBi, float* gslope, float* bcoef, void* stream) {
+    SEHIP_REQUIRE(nrep >= 1 && nrep <= 64 && rep && ticket && bcoef, "cbn_bwd_reduce_fin: %d rows of sums (1..64), rows / ticket / bcoef", nrep);
+    SEHIP_REQUIRE(!sehip_deterministic(), "cbn_bwd_reduce_fin: not part of the deterministic schedule (fp32 atomics): use "
+                                          "sehip_cbn_bwd_reduce + sehip_cbn_bwd_finalize");
+    CbnFin fin{Wrr, Wri, Wii, gWrr, gWri, gWii, gBr, gBi, gslope, bcoef, ticket};
+    return cbn_bwd_reduce_launch(dz, dz2, y, coef, slope, rows, Cr, F, Tst, tfirst, rep, nrep, stream, fin);
 }
 
 extern "C" int sehip_cbn_bwd_finalize(const float* part, const float* coef, const float* Wrr, const float* Wri,

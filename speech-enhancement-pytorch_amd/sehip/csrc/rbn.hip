@@ -116,10 +116,24 @@ __global__ __launch_bounds__(256) void rbn_apply_kernel(const bf16_raw* __restri
     }
 }
 
+// The finalize step inside the reduce launch (round 6, sehip_rbn_bwd_reduce_fin).  In the DCUnet step the weight gradients of the last
+// decoder hold every CU's whole register file for 1-3 ms per workgroup; a NEW launch -- rbn_bwd_finalize_kernel's 2 Cs one-wave
+// workgroups, microseconds of work -- waits for one of them to retire: 9 launches x ~105 us on the chain (profiles/r6_gaps_dcunet.txt).
+// The reduce pass's workgroups are resident already: the LAST one to finish (ticket counter behind a device-scope release of its
+// row of partials: cdna_hip_programming.md, slab-reducer recipe) adds the rows IN ROW ORDER -- deterministic whoever is last --
+// and writes the parameter gradients and the apply pass's records.
+struct RbnFin {
+    unsigned* ticket;
+    float *gw_re, *gb_re, *gw_im, *gb_im;
+    float4* bcoef;
+    int Cs, Cr;
+};
+
 // backward pass 1: per-channel sum g, sum g xh
+template <bool FIN>
 __global__ __launch_bounds__(256) void rbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ y,
                                                              const float4* __restrict__ coef, long rows, int C,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, const RbnFin fin) {
     __shared__ float lds[4 * 2 * 8 * 32];        // [4 waves][NS * 8][nq <= 32]
     const int nq = C >> 3;
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, rpb = 256 / nq;
@@ -154,6 +168,45 @@ __global__ __launch_bounds__(256) void rbn_bwd_reduce_kernel(const bf16_raw* __r
         }
     }
     rbn_block_partials<2>(s, nq, C, part, lds);
+    if (!FIN) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the row has left
+    __syncthreads();
+    __shared__ unsigned is_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        is_last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the layer's next call
+    }
+    __syncthreads();
+    const int nblk = gridDim.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int half = c / fin.Cs, i = c - half * fin.Cs;
+        if (i >= fin.Cr) { fin.bcoef[c] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        double a0 = 0.0, a1 = 0.0;
+        for (int b0 = 0; b0 < nblk; b0 += 32) {            // 64 loads in flight per trip, rows added in row order
+            float v0[32], v1[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const float* p = part + (size_t)(b0 + t < nblk ? b0 + t : 0) * 2 * C + c;
+                v0[t] = p[0]; v1[t] = p[C];
+            }
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+                if (b0 + t < nblk) { a0 += (double)v0[t]; a1 += (double)v1[t]; }
+        }
+        const float4 k = coef[c];
+        (half ? fin.gb_im : fin.gb_re)[i] = (float)a0;
+        (half ? fin.gw_im : fin.gw_re)[i] = (float)a1;
+        const double n = (double)rows;
+        fin.bcoef[c] = make_float4(k.x, (float)(a0 / n), (float)(a1 / n), 0.f);
+    }
 }
 
 // bcoef record per stored channel: a = w rstd, k1 = mean(g), k2 = mean(g xh)
@@ -259,9 +312,21 @@ extern "C" int sehip_rbn_apply(const void* y, const float* coef, long rows, int 
 extern "C" int sehip_rbn_bwd_reduce(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part,
                                     void* stream) {
     if (int e = check_rbn("rbn_bwd_reduce", rows, Cs, Cr)) return e;
-    rbn_bwd_reduce_kernel<<<rbn_stat_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y,
-                                                                                       (const float4*)coef, rows, 2 * Cs, part);
+    rbn_bwd_reduce_kernel<false><<<rbn_stat_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y,
+                                                                                              (const float4*)coef, rows, 2 * Cs, part, RbnFin{});
     SEHIP_CHECK_LAUNCH("rbn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int sehip_rbn_bwd_reduce_fin(const void* dz, const void* y, const float* coef, long rows, int Cs, int Cr, float* part,
+                                        unsigned* ticket, float* gw_re, float* gb_re, float* gw_im, float* gb_im, float* bcoef,
+                                        void* stream) {
+    if (int e = check_rbn("rbn_bwd_reduce_fin", rows, Cs, Cr)) return e;
+    SEHIP_REQUIRE(ticket && bcoef && part, "rbn_bwd_reduce_fin: null ticket / bcoef / part");
+    const RbnFin fin{ticket, gw_re, gb_re, gw_im, gb_im, (float4*)bcoef, Cs, Cr};
+    rbn_bwd_reduce_kernel<true><<<rbn_stat_blocks(rows, 2 * Cs), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y,
+                                                                                             (const float4*)coef, rows, 2 * Cs, part, fin);
+    SEHIP_CHECK_LAUNCH("rbn_bwd_reduce_fin");
     return 0;
 }
 

@@ -895,6 +895,15 @@ class DCCRNWorkspace:
         #  launches 0.10 ms of it, the same code is 3.142 against 3.213 / 3.204 ms (same box, twice): default.  Not in the
         #  deterministic schedule (atomics in a varying order).  SEHIP_NO_FUSE_BWD_FINALIZE=1: the three launches.)
         self.fuse_bwd_finalize = (self.fuse_finalize and not st.deterministic and bool(os.environ.get("SEHIP_FUSE_BWD_FINALIZE")))
+        # round 6, second form: the finalize step inside the reduce launch's LAST workgroup (sehip_cbn_bwd_reduce_fin) + the plain apply
+        # pass -- two launches like the fused form, but ONE workgroup finalizes and the records travel through global memory as in the
+        # three-launch form.  Correct on every box (finite, 46 oracle tests green) and SLOWER: 3.238 / 3.219 against 3.156 / 3.160 ms (the
+        # release fence + ticket of 512 workgroups and one workgroup's serial finalize cost more than eleven 9-us launches that overlap
+        # with the weight-gradient queue anyway).  SEHIP_BN_REDUCE_FIN=1
+        self.bn_reduce_fin = (self.fuse_finalize and not st.deterministic and not self.fuse_bwd_finalize
+                              and bool(os.environ.get("SEHIP_BN_REDUCE_FIN")))
+        self.bn_ticket = torch.zeros(len(st.bn) + 1, dtype=torch.int32, device=device)
+        self._bn_index = {pre: i for i, (pre, _) in enumerate(st.bn)}
         # the two decoder layers whose reduce pass rides in the launch that produces their dz (bnr_rows) keep finalize_n + apply unless
         # SEHIP_FUSE_BWD_ALL=1 (then their rows are written and ignored)
         self.fuse_bwd_all = bool(os.environ.get("SEHIP_FUSE_BWD_ALL"))
@@ -1336,10 +1345,16 @@ class DCCRNWorkspace:
                  y.F, y.Tst, tfirst, ptr(rep[turn]), ptr(rep[turn ^ 1]), BWD_REPLICAS, g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"),
                  g("slope"), dy.ptr, stream())
             return
-        call("sehip_cbn_bwd_reduce", dz.ptr, dz2p, y.ptr, ptr(coef), pp("2.weight"), rows, cr, y.F, y.Tst, tfirst,
-             ptr(self.bn_acc), stream())
-        call("sehip_cbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
-             g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
+        if self.bn_reduce_fin:
+            rep = self.bn_brep[pre]
+            call("sehip_cbn_bwd_reduce_fin", dz.ptr, dz2p, y.ptr, ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("2.weight"), rows, cr,
+                 y.F, y.Tst, tfirst, ptr(rep[0]), BWD_REPLICAS, self.bn_ticket.data_ptr() + 4 * self._bn_index[pre], g("Wrr"), g("Wri"),
+                 g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
+        else:
+            call("sehip_cbn_bwd_reduce", dz.ptr, dz2p, y.ptr, ptr(coef), pp("2.weight"), rows, cr, y.F, y.Tst, tfirst,
+                 ptr(self.bn_acc), stream())
+            call("sehip_cbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), rows, cr,
+                 g("Wrr"), g("Wri"), g("Wii"), g("Br"), g("Bi"), g("slope"), ptr(self.bn_bcoef), stream())
         if not apply:        # the consumer applies the records itself (enc0's weight gradient)
             return
         call("sehip_cbn_bwd_apply", dz.ptr, dz2p, y.ptr, ptr(coef), ptr(self.bn_bcoef), pp("2.weight"), rows, cr, y.F,

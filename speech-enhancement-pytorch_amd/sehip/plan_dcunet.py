@@ -523,6 +523,13 @@ class DCUNetWorkspace:
         # rebuilds d(output) from the two values per position the 1x1 convolution's transpose spreads over the channels.
         # SEHIP_DCUNET_NO_TAIL=1: the separate kernels (the op-local tests compare those two tensors with the oracle).
         self.fused_tail = "SEHIP_DCUNET_NO_TAIL" not in os.environ
+        # (round 6: the BatchNorm backward finalize step inside the reduce launch's last workgroup -- sehip_rbn_bwd_reduce_fin, built because
+        #  the 9 rbn_bwd_finalize launches of the C2 step take ~105 us each waiting for a CU beside the last decoder's whole-CU
+        #  weight-gradient workgroups.  Correct, deterministic, and NO gain: 13.69 / 13.86 against 13.67 / 13.82 ms -- the wait moves to
+        #  the next launch of the chain; what bounds the step is the work on the machine, not the launch that happens to be waiting.
+        #  SEHIP_DCUNET_REDUCE_FIN=1)
+        self.reduce_fin = "SEHIP_DCUNET_REDUCE_FIN" in os.environ
+        self.bn_ticket = torch.zeros(4, dtype=torch.int32, device=device)
         self.tail_scratch = torch.zeros(int(lib.sehip_dcunet_tail_scratch_floats(B, F0, T0, st.dec_c[-1])), dtype=torch.float32,
                                         device=device)
         self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
@@ -653,9 +660,13 @@ class DCUNetWorkspace:
         g = lambda k: self.gpack.data_ptr() + 4 * self.pl.bn_g_off[pre][k]
         coef = self.bn_coef[pre]
         self._chain_dirty = True
-        call("sehip_rbn_bwd_reduce", dz.ptr, y.ptr, ptr(coef), rows, cs, cr, ptr(self.bn_acc), stream())
-        call("sehip_rbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), rows, cs, cr, g("w_re"), g("b_re"), g("w_im"), g("b_im"),
-             ptr(self.bn_bcoef), stream())
+        if self.reduce_fin:      # the finalize step inside the reduce launch's last workgroup (csrc/rbn.hip: no launch that waits for a CU)
+            call("sehip_rbn_bwd_reduce_fin", dz.ptr, y.ptr, ptr(coef), rows, cs, cr, ptr(self.bn_acc), ptr(self.bn_ticket), g("w_re"),
+                 g("b_re"), g("w_im"), g("b_im"), ptr(self.bn_bcoef), stream())
+        else:
+            call("sehip_rbn_bwd_reduce", dz.ptr, y.ptr, ptr(coef), rows, cs, cr, ptr(self.bn_acc), stream())
+            call("sehip_rbn_bwd_finalize", ptr(self.bn_acc), ptr(coef), rows, cs, cr, g("w_re"), g("b_re"), g("w_im"), g("b_im"),
+                 ptr(self.bn_bcoef), stream())
         call("sehip_rbn_bwd_apply", dz.ptr, y.ptr, ptr(coef), ptr(self.bn_bcoef), rows, cs, cr, dy.ptr, stream())
 
     def _lin_ptrs(self, params):
