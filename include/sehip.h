@@ -289,7 +289,8 @@ int sehip_gemm_desc_size(void);
 /* rows of 6 Cr + 1 sums the product (pair: b != NULL) writes at bnr_part when launched with the bnr_* fields set, 0 if it does not
  * compute the reduce pass (then run sehip_cbn_bwd_reduce).  Depends on the shapes only: ask once per workspace. */
 int sehip_bnr_rows(const sehip_gemm_desc* a, const sehip_gemm_desc* b /* or NULL */);
-/* 1 when sehip_gemm(desc) will honour desc->gln_stats (the dense-row kernel takes the product), else 0.  Shapes only: ask once. */
+/* 1 when sehip_gemm(desc) will honour desc->gln_stats (the dense-row kernel takes the product), else 0.  Depends on the shapes and on
+ * sehip_set_deterministic (the deterministic schedule answers 0: the separate pass adds in a fixed order): ask again after a switch. */
 int sehip_gemm_takes_gln_stats(const sehip_gemm_desc* desc);
 /* Deterministic reductions, process-wide (the reference's switch is config.solver.cudnn_deterministic -> src/utils.py:108-111): with
  * on != 0 every floating-point sum whose order depends on scheduling takes a fixed-order form -- weight gradients through per-split

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "common.h"
+#include "det.h"
 
 static thread_local char g_err[512] = "";
 
@@ -28,6 +29,53 @@ static int g_deterministic = 0;
 int sehip_deterministic(void) { return g_deterministic; }
 extern "C" int sehip_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return 0; }
 extern "C" int sehip_get_deterministic(void) { return g_deterministic; }
+
+// ---- the deterministic schedule's per-stream partial arrays (csrc/det.h).  Launches of one stream are ordered, so one array per
+// stream serves them all; an array that has to grow waits for its stream first.  Not inside a stream capture (Solver refuses
+// cudnn_deterministic + use_graph for the same reason).
+namespace {
+struct DetSlot { hipStream_t st; double* p; size_t doubles; };
+DetSlot det_pool[32];
+}  // namespace
+
+DetCtx sehip_det_ctx(hipStream_t st, size_t ndoubles, bool* ok) {
+    *ok = true;
+    if (!g_deterministic) return DetCtx{nullptr};
+    *ok = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        sehip_set_error(-2, "deterministic schedule: its partial arrays cannot be set up inside a stream capture");
+        return DetCtx{nullptr};
+    }
+    DetSlot* e = nullptr;
+    for (auto& q : det_pool)
+        if (q.p && q.st == st) { e = &q; break; }
+    if (!e)
+        for (auto& q : det_pool)
+            if (!q.p) { e = &q; break; }
+    if (!e) {       // every slot belongs to some stream: give them all back once the device is idle
+        if (hipDeviceSynchronize() != hipSuccess) { sehip_set_error(-2, "deterministic schedule: device synchronize failed"); return DetCtx{nullptr}; }
+        for (auto& q : det_pool) { (void)hipFree(q.p); q.p = nullptr; q.doubles = 0; q.st = nullptr; }
+        e = &det_pool[0];
+    }
+    if (!e->p || e->doubles < ndoubles) {
+        if (e->p) {
+            if (hipStreamSynchronize(st) != hipSuccess) { sehip_set_error(-2, "deterministic schedule: stream synchronize failed"); return DetCtx{nullptr}; }
+            (void)hipFree(e->p);
+            e->p = nullptr;
+        }
+        const size_t want = ndoubles < (1u << 16) ? (1u << 16) : ndoubles * 2;
+        double* p = nullptr;
+        if (hipMalloc(&p, want * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            sehip_set_error(-2, "deterministic schedule: could not allocate %zu partial sums", want);
+            return DetCtx{nullptr};
+        }
+        e->st = st; e->p = p; e->doubles = want;
+    }
+    *ok = true;
+    return DetCtx{e->p};
+}
 
 extern "C" const char* sehip_last_error(void) { return g_err; }
 extern "C" const char* sehip_last_kernel(void) { return g_kernel; }

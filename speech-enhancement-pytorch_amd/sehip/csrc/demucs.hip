@@ -13,6 +13,7 @@
 #define DMX_FU 2      // frames per trip of the activation passes (loads of all of them in flight)
 #endif
 #include "common.h"
+#include "det.h"
 float* sehip_wgrad_scratch(hipStream_t st, size_t bytes);   // csrc/wgrad3.hip: per-stream pool of partial arrays
 #include <math.h>
 #include <stdlib.h>
@@ -71,7 +72,7 @@ __device__ __forceinline__ void moments(const double* __restrict__ stats, int b,
 // prep / post
 // ---------------------------------------------------------------------------------------------------------------------------
 // acc[b] += (sum, sum of squares) of the mono mix over this workgroup's share of the clip (double atomics; the caller zeroes acc)
-__global__ __launch_bounds__(256) void dmx_moments_kernel(const float* __restrict__ mix, int ac, int T, double* __restrict__ acc) {
+__global__ __launch_bounds__(256) void dmx_moments_kernel(const float* __restrict__ mix, int ac, int T, double* __restrict__ acc, const DetCtx dc) {
     const int b = blockIdx.y;
     __shared__ double red[2][4];
     double s = 0, q = 0;
@@ -84,10 +85,13 @@ __global__ __launch_bounds__(256) void dmx_moments_kernel(const float* __restric
     s = wave_sum_d(s); q = wave_sum_d(q);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
     __syncthreads();
+    __shared__ double pair[2];
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[2 * b], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(&acc[2 * b + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        pair[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        pair[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
+    __syncthreads();
+    det_group_add(pair, 2, acc + 2 * b, dc, b, blockIdx.x, gridDim.x);      // (deterministic schedule: slots added in slot order, csrc/det.h)
 }
 // ms[b] = (mean, unbiased std) of the mono mix (src/model/demucs.py:457-461); normalize == 0: (0, 1)
 __global__ void dmx_moments_finish_kernel(const double* __restrict__ acc, int B, int T, int normalize, float* __restrict__ ms) {
@@ -310,7 +314,8 @@ __global__ __launch_bounds__(256) void dmx_post_bwd_down_kernel(const float* __r
 // GroupNorm + activation family.  mode 0: z = gelu(n(y)) over C channels; mode 1: z = n(y)[:C/2] * sigmoid(n(y)[C/2:]) (GLU).
 // Optional LayerScale + residual: z <- resid + scale[c] * z; optional addend: z <- z + add.  n = GroupNorm(G) or identity.
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dmx_gn_stats_kernel(const bf16_raw* __restrict__ y, int T, int C, int G, double* __restrict__ stats) {
+__global__ __launch_bounds__(256) void dmx_gn_stats_kernel(const bf16_raw* __restrict__ y, int T, int C, int G, double* __restrict__ stats,
+                                                           const DetCtx dc) {
     const int b = blockIdx.y, nq = C >> 3;
     const Walk w = walk(nq);
     const int g = (w.q * 8) / (C / G);
@@ -324,10 +329,17 @@ __global__ __launch_bounds__(256) void dmx_gn_stats_kernel(const bf16_raw* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s += x.v[j]; q += x.v[j] * x.v[j]; }
     }
-    atomicAdd(&acc[2 * g], s);
-    atomicAdd(&acc[2 * g + 1], q);
-    __syncthreads();
-    if (threadIdx.x < 2 * G) atomicAdd(&stats[(long)b * G * 2 + threadIdx.x], (double)acc[threadIdx.x]);
+    if (dc.part == nullptr) {
+        atomicAdd(&acc[2 * g], s);
+        atomicAdd(&acc[2 * g + 1], q);
+        __syncthreads();
+    } else {         // deterministic schedule: one thread per group adds the threads' sums in thread order, the workgroups in slot order
+        __shared__ float tmpv[256];
+        __shared__ int tmps[256];
+        det_slot_sum(s, 2 * g, 2 * G, acc, tmpv, tmps, false);
+        det_slot_sum(q, 2 * g + 1, 2 * G, acc, tmpv, tmps, true);
+    }
+    det_group_add(acc, 2 * G, stats + (long)b * G * 2, dc, b, blockIdx.x, gridDim.x);
 }
 
 template <int MODE>
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(256) void dmx_act_bwd_reduce_kernel(const bf16_raw*
                                                                  const double* __restrict__ stats, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int G, float eps,
                                                                  const float* __restrict__ scale, int T, int C, double* __restrict__ sums,
-                                                                 float* __restrict__ gch, float* __restrict__ part) {
+                                                                 float* __restrict__ gch, float* __restrict__ part, const DetCtx dc) {
     // part != NULL: the block's 2 C + Co per-channel sums go to ITS ROW of `part` by plain stores and the apply pass adds the rows
     // into gch (dmx_colsum_share) -- flushing every block with fp32 atomics was up to 2 048 blocks x 320-10 240 addresses per launch:
     // a ~26-us floor under each of the 32 launches of a step, whatever the tensor's size
@@ -493,18 +505,37 @@ __global__ __launch_bounds__(256) void dmx_act_bwd_reduce_kernel(const bf16_raw*
             __syncthreads();
         }
     } else {
+        // any other piece count: runs of nq consecutive threads hold distinct channels (piece index = global thread index mod nq); the
+        // runs add one after the other -- a fixed order (it was LDS atomics: the hardware's order, different from run to run)
+        const int run = threadIdx.x / nq, nruns = (256 + nq - 1) / nq;
+        for (int turn = 0; turn < nruns; ++turn) {
+            if (run == turn) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(&lds[c0 + j], dga[j]);
-            atomicAdd(&lds[C + c0 + j], dba[j]);
-            if (MODE) { atomicAdd(&lds[c1 + j], dgg[j]); atomicAdd(&lds[C + c1 + j], dbg[j]); }
-            if (scale) atomicAdd(&lds[2 * C + c0 + j], dsc[j]);
+                for (int j = 0; j < 8; ++j) {
+                    lds[c0 + j] += dga[j];
+                    lds[C + c0 + j] += dba[j];
+                    if (MODE) { lds[c1 + j] += dgg[j]; lds[C + c1 + j] += dbg[j]; }
+                    if (scale) lds[2 * C + c0 + j] += dsc[j];
+                }
+            }
+            __syncthreads();
         }
     }
-    atomicAdd(&lds[NV + 2 * grp_a], s1a);
-    atomicAdd(&lds[NV + 2 * grp_a + 1], s2a);
-    if (MODE) { atomicAdd(&lds[NV + 2 * grp_g], s1g); atomicAdd(&lds[NV + 2 * grp_g + 1], s2g); }
-    __syncthreads();
+    if (dc.part == nullptr) {
+        atomicAdd(&lds[NV + 2 * grp_a], s1a);
+        atomicAdd(&lds[NV + 2 * grp_a + 1], s2a);
+        if (MODE) { atomicAdd(&lds[NV + 2 * grp_g], s1g); atomicAdd(&lds[NV + 2 * grp_g + 1], s2g); }
+        __syncthreads();
+    } else {         // deterministic schedule: the threads' group sums in thread order (csrc/det.h)
+        __shared__ float tmpv[256];
+        __shared__ int tmps[256];
+        det_slot_sum(s1a, 2 * grp_a, 2 * G, lds + NV, tmpv, tmps, true);
+        det_slot_sum(s2a, 2 * grp_a + 1, 2 * G, lds + NV, tmpv, tmps, true);
+        if (MODE) {
+            det_slot_sum(s1g, 2 * grp_g, 2 * G, lds + NV, tmpv, tmps, true);
+            det_slot_sum(s2g, 2 * grp_g + 1, 2 * G, lds + NV, tmpv, tmps, true);
+        }
+    }
     if (part) {
         float* row = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NV;
         for (int i = threadIdx.x; i < NV; i += 256) row[i] = lds[i];
@@ -512,16 +543,17 @@ __global__ __launch_bounds__(256) void dmx_act_bwd_reduce_kernel(const bf16_raw*
         for (int i = threadIdx.x; i < NV; i += 256)
             if (lds[i] != 0.f) atomicAdd(&gch[i], lds[i]);
     }
-    if (threadIdx.x < 2 * G) atomicAdd(&sums[(long)b * G * 2 + threadIdx.x], (double)lds[NV + threadIdx.x]);
+    det_group_add(lds + NV, 2 * G, sums + (long)b * G * 2, dc, b, blockIdx.x, gridDim.x);
 }
 
 // gch[c] += sum_r part[r][c], spread over the workgroups of the launch that hosts it as units of (256 columns, one of <= 64 row
 // groups): each unit adds its rows and flushes with one atomic per column (csrc/tasnet.hip ctn_gln_bwd_apply_kernel does the same)
-__device__ __forceinline__ void dmx_colsum_share(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ gch) {
+__device__ __forceinline__ void dmx_colsum_share(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ gch, int det) {
     const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int ncb = (ncols + 255) >> 8;
     int rg = nrows >> 3;
     rg = rg > 64 ? 64 : (rg < 1 ? 1 : rg);
+    if (det) rg = 1;           // deterministic schedule: one unit per 256 columns adds ALL rows in row order, one add per column
     for (int u = bid; u < ncb * rg; u += nblk) {
         const int c = (u % ncb) * 256 + threadIdx.x, r0 = u / ncb;
         if (c < ncols) {
@@ -538,8 +570,8 @@ __global__ __launch_bounds__(256) void dmx_act_bwd_apply_kernel(const bf16_raw* 
                                                                 const double* __restrict__ stats, const double* __restrict__ sums,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int G, float eps,
                                                                 const float* __restrict__ scale, int T, int C, bf16_raw* __restrict__ dy,
-                                                                const float* __restrict__ part, int nrows, float* __restrict__ gch) {
-    if (part) dmx_colsum_share(part, nrows, 2 * C + (MODE ? C >> 1 : C), gch);      // the reduce pass's partial rows -> gch (see there)
+                                                                const float* __restrict__ part, int nrows, float* __restrict__ gch, int det) {
+    if (part) dmx_colsum_share(part, nrows, 2 * C + (MODE ? C >> 1 : C), gch, det);      // the reduce pass's partial rows -> gch (see there)
     const int b = blockIdx.y;
     const int Co = MODE ? C >> 1 : C, nq = Co >> 3;
     const Walk w = walk(nq);
@@ -1242,7 +1274,11 @@ extern "C" int sehip_dmx_prep(const float* mix, int B, int ac, int acp, int T, i
         SEHIP_REQUIRE(hipMemsetAsync(acc, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream) == hipSuccess, "dmx_prep: clearing the accumulators failed");
         int gx = (T + 256 * 16 - 1) / (256 * 16);
         if (gx > 64) gx = 64;
-        dmx_moments_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(mix, ac, T, acc);
+        bool ok;
+        const DetCtx dc = sehip_det_ctx((hipStream_t)stream, (size_t)gx * B * 2, &ok);
+        if (!ok) return -2;
+        dmx_moments_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(mix, ac, T, acc, dc);
+        if (int e = sehip_det_finish((hipStream_t)stream, dc, B, gx, 2, acc, 2)) return e;
     }
     dmx_moments_finish_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(acc, B, T, normalize, ms);
     const long T0 = up ? 2L * Tv : Tv;
@@ -1287,7 +1323,12 @@ extern "C" int sehip_dmx_post_bwd(const float* dout, const float* ms, int B, int
 
 extern "C" int sehip_dmx_gn_stats(const void* y, int B, int T, int C, int G, double* stats, void* stream) {
     if (int e = dmx_check("dmx_gn_stats", B, T, C, 0, G)) return e;
-    dmx_gn_stats_kernel<<<dmx_grid(B, T, C >> 3), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, T, C, G, stats);
+    const dim3 grid = dmx_grid(B, T, C >> 3);
+    bool ok;
+    const DetCtx dc = sehip_det_ctx((hipStream_t)stream, (size_t)grid.x * B * 2 * G, &ok);
+    if (!ok) return -2;
+    dmx_gn_stats_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)y, T, C, G, stats, dc);
+    if (int e = sehip_det_finish((hipStream_t)stream, dc, B, (int)grid.x, 2 * G, stats, 2L * G)) return e;
     SEHIP_CHECK_LAUNCH("dmx_gn_stats");
     return 0;
 }
@@ -1326,21 +1367,27 @@ extern "C" int sehip_dmx_act_bwd(const void* dz, const void* y, const double* st
         // have to grow it -- or SEHIP_DMX_ATOMIC_FLUSH: the workgroups flush with atomics as in rounds 2-4)
         static const bool atomic_flush = getenv("SEHIP_DMX_ATOMIC_FLUSH") != nullptr;
         nrows = (int)(g.x * g.y);
-        part = atomic_flush ? nullptr : sehip_wgrad_scratch((hipStream_t)stream, (size_t)nrows * NV * sizeof(float));
+        part = atomic_flush && !sehip_deterministic() ? nullptr : sehip_wgrad_scratch((hipStream_t)stream, (size_t)nrows * NV * sizeof(float));
+        SEHIP_REQUIRE(part || !sehip_deterministic(), "dmx_act_bwd: the deterministic schedule could not get its partial rows (allocation failed, "
+                                                      "or inside a stream capture)");
+        bool ok;
+        const DetCtx dc = sehip_det_ctx((hipStream_t)stream, (size_t)nrows * 2 * G, &ok);
+        if (!ok) return -2;
         if (mode)
             dmx_act_bwd_reduce_kernel<1><<<g, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, gamma, beta, G, eps, scale, T,
-                                                                                C, sums, gch, part);
+                                                                                C, sums, gch, part, dc);
         else
             dmx_act_bwd_reduce_kernel<0><<<g, 256, lds, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, gamma, beta, G, eps, scale, T,
-                                                                                C, sums, gch, part);
+                                                                                C, sums, gch, part, dc);
         SEHIP_CHECK_LAUNCH("dmx_act_bwd_reduce");
+        if (int e = sehip_det_finish((hipStream_t)stream, dc, B, (int)g.x, 2 * G, sums, 2L * G)) return e;
     }
     if (mode)
         dmx_act_bwd_apply_kernel<1><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, sums, gamma, beta, G, eps, scale, T, C,
-                                                                         (bf16_raw*)dy, part, nrows, gch);
+                                                                         (bf16_raw*)dy, part, nrows, gch, sehip_deterministic());
     else
         dmx_act_bwd_apply_kernel<0><<<g, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dz, (const bf16_raw*)y, stats, sums, gamma, beta, G, eps, scale, T, C,
-                                                                         (bf16_raw*)dy, part, nrows, gch);
+                                                                         (bf16_raw*)dy, part, nrows, gch, sehip_deterministic());
     SEHIP_CHECK_LAUNCH("dmx_act_bwd_apply");
     return 0;
 }

@@ -170,7 +170,9 @@ static int dg_launch(const sehip_gemm_desc& d, hipStream_t st) {
     static const int spw = getenv("SEHIP_DG_STAGES") ? atoi(getenv("SEHIP_DG_STAGES")) : 2;
     const int nstages = (d.M + 63) / 64;
     int per = spw < 1 ? 1 : spw;
-    const bool gl = !RES && d.gln_stats != nullptr && d.gln_slope != nullptr;
+    // (deterministic schedule: the statistics' double atomics are not part of it -- sehip_gemm_takes_gln_stats answers 0 and the
+    //  caller runs sehip_ctn_gln_stats, whose workgroups add in a fixed order)
+    const bool gl = !RES && d.gln_stats != nullptr && d.gln_slope != nullptr && !sehip_deterministic();
     while (gl && per > 1 && per * 64 >= d.TT) --per;       // (a workgroup's rows may touch two utterances, not three)
     sehip_note_kernel("dense_rows_gemm_kernel<%d, %d, %d>", N, K, RES ? 1 : 0);
     dense_rows_gemm_kernel<N, K, RES><<<(nstages + per - 1) / per, 256, lds, st>>>(
@@ -184,7 +186,7 @@ static int dg_launch(const sehip_gemm_desc& d, hipStream_t st) {
 // whose row m is the N contiguous elements at m N, every frame valid, trivial tables); the geometry is checked here all the same.
 static bool dg_qualifies(const sehip_gemm_desc& d);
 extern "C" int sehip_gemm_takes_gln_stats(const sehip_gemm_desc* d) {
-    return d && !d->res && d->TT > 64 && dg_qualifies(*d) ? 1 : 0;
+    return d && !d->res && d->TT > 64 && !sehip_deterministic() && dg_qualifies(*d) ? 1 : 0;
 }
 int sehip_try_dense_rows_gemm(const sehip_gemm_desc& d, hipStream_t st) {
     if (!dg_qualifies(d)) return 0;

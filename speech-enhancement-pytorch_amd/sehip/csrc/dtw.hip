@@ -406,10 +406,14 @@ extern "C" int sehip_wgrad_dense_group(const void* dev_buf, int n, const int* in
     hipStream_t st = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
+
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tile_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    constexpr size_t lds = (size_t)DTW_NB * (128 + 256) * 64 * 2;
+    // SEHIP_DTW_LDS_ALL=1 (tools/dev/det_diff.py): the CU's whole LDS, i.e. no LDS-using workgroup of another kernel beside this one --
+    // the setting under which the Demucs step's deterministic schedule was bit-stable WITH the second stream
+    static const bool lds_all = getenv("SEHIP_DTW_LDS_ALL") != nullptr;
+    const size_t lds = lds_all ? (size_t)160 * 1024 : (size_t)DTW_NB * (128 + 256) * 64 * 2;
     sehip_note_kernel("dense_tile_wgrad_kernel");
     dense_tile_wgrad_kernel<<<info[1], 512, lds, st>>>(reinterpret_cast<const DtwProd*>(db + L.prods), reinterpret_cast<const DtwPlane*>(db + L.planes),
                                                        reinterpret_cast<const DtwTile*>(db + L.tiles), scratch);

@@ -344,3 +344,22 @@ extern "C" int sehip_grad_metric_acc(const float* grads, const long* offsets, in
                                      float* tensor_sums, float* metric, void* stream) {
     return grad_metric_impl(grads, offsets, ntensors, max_tensor, sumsq, tensor_sums, metric, false, stream);
 }
+
+// ---- the deterministic schedule's second launch (csrc/det.h): one wave per (group, value); lane l adds the slots l, l + 64, ... in
+// increasing order, the lane sums meet in a fixed xor tree
+#include "det.h"
+__global__ __launch_bounds__(64) void det_sum_slots_kernel(const double* __restrict__ part, int nb, int nvals, double* __restrict__ dst,
+                                                          long dst_stride) {
+    const int g = blockIdx.x, i = blockIdx.y, lane = threadIdx.x;
+    const double* base = part + (size_t)g * nb * nvals + i;
+    double s = 0.0;
+    for (int b = lane; b < nb; b += 64) s += base[(size_t)b * nvals];
+    s = wave_sum_d(s);
+    if (lane == 0) dst[(size_t)g * dst_stride + i] += s;
+}
+int sehip_det_finish(hipStream_t st, DetCtx dc, int ngroups, int nb, int nvals, double* dst, long dst_stride) {
+    if (dc.part == nullptr) return 0;
+    det_sum_slots_kernel<<<dim3((unsigned)ngroups, (unsigned)nvals), 64, 0, st>>>(dc.part, nb, nvals, dst, dst_stride);
+    SEHIP_CHECK_LAUNCH("det_finish");
+    return 0;
+}

@@ -16,6 +16,7 @@
 //   gLN:  y = gamma (v - mu) / sqrt(var + 1e-8) + beta,  mu / var over (channels, frames) of ONE utterance;  v = PReLU(h; a)
 //         dv = (gamma dy - mean(gamma dy) - xh mean(gamma dy xh)) / sigma;  dh = dv (h > 0 ? 1 : a);  da = sum dv h [h <= 0]
 #include "common.h"
+#include "det.h"
 
 #define CTN_EPS 1e-8f
 
@@ -281,12 +282,16 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
     float* sgb = sdU + (size_t)4 * AL * N;             // [2][N] behind the four waves' dU images
     for (int i = threadIdx.x; i < 2 * N; i += 256) sgb[i] = 0.f;
     __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {          // the four waves one after the other: a fixed order (LDS atomics have the hardware's)
+        if (wave == turn) {
 #pragma unroll
-    for (int i = 0; i < ENC_MAXC; ++i) {
-        const int n = lane + 64 * i;
-        if (n < N) { atomicAdd(&sgb[n], dg[i]); atomicAdd(&sgb[N + n], db[i]); }
+            for (int i = 0; i < ENC_MAXC; ++i) {
+                const int n = lane + 64 * i;
+                if (n < N) { sgb[n] += dg[i]; sgb[N + n] += db[i]; }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* row = part + (size_t)blockIdx.x * (AL * N + 2 * N);
     for (int i = threadIdx.x; i < AL * N; i += 256) {
         const int l = i / N, n = i - l * N;
@@ -359,17 +364,21 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_reg_kernel(const float* _
     const int ncols = N * AL + 2 * N;
     for (int i = threadIdx.x; i < ncols; i += 256) srow[i] = 0.f;
     __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {          // the four waves one after the other: a fixed order (LDS atomics have the hardware's)
+        if (wave == turn) {
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int n = lane + 64 * i;
-        if (n < N) {
+            for (int i = 0; i < NC; ++i) {
+                const int n = lane + 64 * i;
+                if (n < N) {
 #pragma unroll
-            for (int l = 0; l < AL; ++l) atomicAdd(&srow[n * AL + l], acc[i][l]);
-            atomicAdd(&srow[N * AL + n], dg[i]);
-            atomicAdd(&srow[N * AL + N + n], db[i]);
+                    for (int l = 0; l < AL; ++l) srow[n * AL + l] += acc[i][l];
+                    srow[N * AL + n] += dg[i];
+                    srow[N * AL + N + n] += db[i];
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float* row = part + (size_t)blockIdx.x * ncols;
     for (int i = threadIdx.x; i < ncols; i += 256) row[i] = srow[i];
 }
@@ -522,19 +531,25 @@ __global__ __launch_bounds__(256, 2) void ctn_encoder_bwd_mfma_kernel(const floa
 // ------------------------------------------------------------------------------------------------------------------
 // global LayerNorm pieces.  Rows of utterance m: [m*K, (m+1)*K).  grid = (blocks per utterance, M).
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_add2_double(float s, float q, double* dst) {
+// dst[0..1] += the workgroup's (s, q).  Default schedule: two double atomics per workgroup; deterministic schedule (dc.part != NULL):
+// the workgroups of utterance blockIdx.y leave their pairs in slots and the wrapper's sehip_det_finish adds them in a fixed order
+// (csrc/det.h).
+__device__ __forceinline__ void block_add2_double(float s, float q, double* dst, const DetCtx dc) {
     __shared__ float red[2][4];
+    __shared__ double pair[2];
     s = wave_sum(s); q = wave_sum(q);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&dst[0], (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(&dst[1], (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        pair[0] = (double)red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        pair[1] = (double)red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
+    __syncthreads();
+    det_group_add(pair, 2, dst, dc, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void ctn_gln_stats_kernel(const bf16_raw* __restrict__ h, const float* __restrict__ slope, int K, int C,
-                                                            double* __restrict__ stats) {
+                                                            double* __restrict__ stats, const DetCtx dc) {
     const int m = blockIdx.y, nq = C >> 3;
     const float a = slope[0];
     const long pieces = (long)K * nq;
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(256) void ctn_gln_stats_kernel(const bf16_raw* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float v = prelu(x.v[j], a); s += v; q += v * v; }
     }
-    block_add2_double(s, q, stats + 2 * m);
+    block_add2_double(s, q, stats + 2 * m, dc);
 }
 
 // Thread layout of the frame-streaming kernels below: a thread owns ONE piece of 8 channels (q = tid % nq) for all its
@@ -574,7 +589,7 @@ __global__ __launch_bounds__(256) void ctn_dwconv_fwd_kernel(const bf16_raw* __r
                                                              const double* __restrict__ stats1, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ Wd /*[C][P]*/,
                                                              int dil, const float* __restrict__ slope2, int K, int C,
-                                                             bf16_raw* __restrict__ h2, double* __restrict__ stats2) {
+                                                             bf16_raw* __restrict__ h2, double* __restrict__ stats2, const DetCtx dc) {
     const int m = blockIdx.y, nq = C >> 3;
     const PieceMap pm = piece_map(nq);
     const float a1 = slope1[0], a2 = slope2[0];
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(256) void ctn_dwconv_fwd_kernel(const bf16_raw* __r
             for (int j = 0; j < 8; ++j) { const float v = prelu(bf2f(f2bf(o[j])), a2); s += v; q += v * v; }   // statistics of what is stored
         }
     }
-    block_add2_double(s, q, stats2 + 2 * m);
+    block_add2_double(s, q, stats2 + 2 * m, dc);
 }
 
 __global__ __launch_bounds__(256) void ctn_gln_apply_kernel(const bf16_raw* __restrict__ h, const float* __restrict__ slope,
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
                                                                  const float* __restrict__ slope, const double* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ Wd, int dil, int K, int C,
-                                                                 double* __restrict__ sums, float* __restrict__ part) {
+                                                                 double* __restrict__ sums, float* __restrict__ part, const DetCtx dc) {
     extern __shared__ float lds[];       // per-channel partials of the block in gch layout: [(2 + (DW ? P : 0)) * C]
     const int m = blockIdx.y, nq = C >> 3;
     const PieceMap pm = piece_map(nq);
@@ -781,18 +796,25 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_reduce_kernel(const bf16_raw*
             }
             __syncthreads();
         }
-    } else if (pm.active) {
+    } else {
+        // any other piece count: the rpb row groups of the workgroup (nq threads with distinct channels each) add one after the other
+        // -- a fixed order (it was LDS atomics: the order of the hardware, different from run to run)
+        for (int turn = 0; turn < pm.rpb; ++turn) {
+            if (pm.active && pm.rsub == turn) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(&lds[pm.c0 + j], dg[j]);
-            atomicAdd(&lds[C + pm.c0 + j], db[j]);
-            if (DW) {
+                for (int j = 0; j < 8; ++j) {
+                    lds[pm.c0 + j] += dg[j];
+                    lds[C + pm.c0 + j] += db[j];
+                    if (DW) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) atomicAdd(&lds[2 * C + (pm.c0 + j) * P + p], dw[p][j]);
+                        for (int p = 0; p < P; ++p) lds[2 * C + (pm.c0 + j) * P + p] += dw[p][j];
+                    }
+                }
             }
+            __syncthreads();
         }
     }
-    block_add2_double(s1, s2, sums + 2 * m);      // (contains a __syncthreads: the LDS partials are complete after it)
+    block_add2_double(s1, s2, sums + 2 * m, dc);  // (contains a __syncthreads: the LDS partials are complete after it)
     float* row = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NV * C);
     for (int i = threadIdx.x; i < NV * C; i += 256) row[i] = lds[i];
     // The PReLU slope's gradient is sum over h <= 0 of dv h with dv = (gamma dy - S1/n - xh S2/n) / sigma, i.e. LINEAR in the three
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
                                                                 const float* __restrict__ gamma, const float* __restrict__ Wd, int dil,
                                                                 const double* __restrict__ sums, int K, int C, bf16_raw* __restrict__ dh,
                                                                 float* __restrict__ dslope, const float* __restrict__ part, int nrows,
-                                                                int ncols, float* __restrict__ gch) {
+                                                                int ncols, float* __restrict__ gch, int det) {
     // first: the column sums of the reduce kernel's partial rows (gch += sum_r part[r][c]; it was a launch of its own, 28 per step, on
     // the dependent chain), spread over this launch's workgroups as units of (256 columns, one of <= 64 row groups)
     {
@@ -832,6 +854,7 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
         const int ncb = (ncols + 255) >> 8;
         int rg = nrows >> 3;
         rg = rg > 64 ? 64 : (rg < 1 ? 1 : rg);
+        if (det) rg = 1;             // deterministic schedule: one unit per 256 columns adds ALL rows in row order, one add per column
         for (int u = bid; u < ncb * rg; u += nblk) {
             const int c = (u % ncb) * 256 + threadIdx.x, r0 = u / ncb;
             if (c < ncols) {
@@ -1239,7 +1262,7 @@ static dim3 ctn_reduce_grid(int M, int K, int C) {
 static dim3 ctn_colsum_grid(int nrows, int ncols) {
     int rs = nrows / 8;                      // >= 8 rows per thread, up to 64 row groups
     if (rs > 64) rs = 64;
-    if (rs < 1) rs = 1;
+    if (rs < 1 || sehip_deterministic()) rs = 1;       // deterministic schedule: one add per column, rows in row order
     return dim3((unsigned)((ncols + 255) / 256), (unsigned)rs);
 }
 static dim3 ctn_grid(int M, int K, int C) {
@@ -1337,7 +1360,12 @@ extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const voi
 
 extern "C" int sehip_ctn_gln_stats(const void* h, const float* slope, int M, int K, int C, double* stats /*[M][2], caller zeroes*/, void* stream) {
     if (int e = ctn_check("ctn_gln_stats", M, K, C)) return e;
-    ctn_gln_stats_kernel<<<ctn_grid(M, K, C), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h, slope, K, C, stats);
+    const dim3 grid = ctn_grid(M, K, C);
+    bool ok;
+    const DetCtx dc = sehip_det_ctx((hipStream_t)stream, (size_t)grid.x * grid.y * 2, &ok);
+    if (!ok) return -2;
+    ctn_gln_stats_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h, slope, K, C, stats, dc);
+    if (int e = sehip_det_finish((hipStream_t)stream, dc, (int)grid.y, (int)grid.x, 2, stats, 2)) return e;
     SEHIP_CHECK_LAUNCH("ctn_gln_stats");
     return 0;
 }
@@ -1347,8 +1375,13 @@ extern "C" int sehip_ctn_dwconv_fwd(const void* h1, const float* slope1, const d
                                     void* stream) {
     if (int e = ctn_check("ctn_dwconv_fwd", M, K, C)) return e;
     SEHIP_REQUIRE(P == 3, "ctn_dwconv_fwd: only kernel size P=3 is built (got %d)", P);
-    ctn_dwconv_fwd_kernel<3><<<ctn_grid(M, K, C), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h1, slope1, stats1, gamma, beta, Wd, dilation,
-                                                                                slope2, K, C, (bf16_raw*)h2, stats2);
+    const dim3 grid = ctn_grid(M, K, C);
+    bool ok;
+    const DetCtx dc = sehip_det_ctx((hipStream_t)stream, (size_t)grid.x * grid.y * 2, &ok);
+    if (!ok) return -2;
+    ctn_dwconv_fwd_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h1, slope1, stats1, gamma, beta, Wd, dilation,
+                                                                   slope2, K, C, (bf16_raw*)h2, stats2, dc);
+    if (int e = sehip_det_finish((hipStream_t)stream, dc, (int)grid.y, (int)grid.x, 2, stats2, 2)) return e;
     SEHIP_CHECK_LAUNCH("ctn_dwconv_fwd");
     return 0;
 }
@@ -1380,14 +1413,20 @@ extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slop
     const dim3 grid = ctn_grid(M, K, C), rgrid = ctn_reduce_grid(M, K, C);
     const int ncols = (2 + (dw ? 3 : 0)) * C, nrows = (int)(rgrid.x * rgrid.y);
     const size_t lds = (size_t)ncols * sizeof(float);
+    bool ok;
+    const DetCtx dc = sehip_det_ctx(st, (size_t)rgrid.x * rgrid.y * 2, &ok);
+    if (!ok) return -2;
+    const int det = sehip_deterministic();
     if (dw) {
-        ctn_gln_bwd_reduce_kernel<3, true><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
+        ctn_gln_bwd_reduce_kernel<3, true><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch, dc);
+        if (int e = sehip_det_finish(st, dc, (int)rgrid.y, (int)rgrid.x, 2, sums, 2)) return e;
         ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope,
-                                                                scratch, nrows, ncols, gch);
+                                                                scratch, nrows, ncols, gch, det);
     } else {
-        ctn_gln_bwd_reduce_kernel<3, false><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch);
+        ctn_gln_bwd_reduce_kernel<3, false><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch, dc);
+        if (int e = sehip_det_finish(st, dc, (int)rgrid.y, (int)rgrid.x, 2, sums, 2)) return e;
         ctn_gln_bwd_apply_kernel<3, false><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope,
-                                                                 scratch, nrows, ncols, gch);
+                                                                 scratch, nrows, ncols, gch, det);
     }
     SEHIP_CHECK_LAUNCH("ctn_gln_bwd");
     return 0;

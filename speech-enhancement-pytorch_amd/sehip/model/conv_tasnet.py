@@ -76,6 +76,17 @@ class ConvTasNet(FlatModule):
     def valid_length(self, length):
         return length
 
+    def set_deterministic(self, on=True):
+        """The reference's `solver.cudnn_deterministic` switch (src/conf/config.yaml:130, src/utils.py:108-111) for this model.  The work
+        is done by the process-wide sehip_set_deterministic (the Solver / sehip.utils.prepare_device switch it on): the gLN statistics
+        leave the 1x1 products' launches for sehip_ctn_gln_stats, every per-utterance sum of csrc/tasnet.hip goes through per-workgroup
+        slots added in a fixed order by a second small launch (csrc/det.h), the column sums add their rows in row order, the weight
+        gradients take the library's fixed-order kernels, the optimizer the unfused tail, and the whole step runs on ONE queue
+        (plan_tasnet.TasNetWorkspace.forward says why).  Two runs of the same steps are then bit-identical
+        (tests/test_gpu_deterministic.py)."""
+        self._deterministic = bool(on)
+        return self
+
     def workspace(self, batch, nsample):
         dev = self._require_gpu("ConvTasNet")
         if self._tables is None:

@@ -101,6 +101,17 @@ class Demucs(FlatModule):
     def valid_length(self, length):
         return self.cfg.valid_length(length)
 
+    def set_deterministic(self, on=True):
+        """The reference's `solver.cudnn_deterministic` switch (src/conf/config.yaml:130, src/utils.py:108-111) for this model.  The work
+        is done by the process-wide sehip_set_deterministic (the Solver / sehip.utils.prepare_device switch it on): the GroupNorm
+        statistics and backward sums of csrc/demucs.hip add their threads in thread order and their workgroups through slots that a second
+        small launch adds in a fixed order (csrc/det.h), the per-channel partial rows are added in row order, the weight gradients take
+        the library's fixed-order kernels, the optimizer the unfused tail, and the whole step runs on ONE queue
+        (plan_demucs.DemucsWorkspace._select_streams says why).  Two runs of the same steps are then bit-identical
+        (tests/test_gpu_deterministic.py)."""
+        self._deterministic = bool(on)
+        return self
+
     def load_state_dict(self, state, strict=True, **kw):
         state = dict(state)
         for idx in range(self.depth):    # the reference's own key migration (src/model/demucs.py:492-501)

@@ -571,7 +571,8 @@ class DemucsWorkspace:
         self.attn_slabs = torch.empty(max([int(_lib.lib().sehip_dmx_attn_bwd_scratch_floats(B, lens[a["level"]], a["hid"])) for a in st.attns] + [1]),
                                       dtype=torch.float32, device=device)      # key / content gradients per query tile (LocalState backward)
         self.lstm_sync = torch.zeros(int(_lib.lib().sehip_dmx_lstm_sync_bytes()) // 4, dtype=torch.int32, device=device)   # arrival counters + time-out word
-        self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        self._side_stream = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        self.side = self._side_stream      # (None while the deterministic schedule is on: _select_streams)
         self.comm = None     # third stream: early un-pack + all-reduce of finished gradient ranges (data-parallel runs only)
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self._held_events = []
@@ -672,8 +673,21 @@ class DemucsWorkspace:
                 need = max(need, info[4] + (info[5] << 31))
         self._dtw_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
 
+    def _select_streams(self):
+        """The deterministic schedule (solver.cudnn_deterministic / sehip.utils.set_deterministic) runs the step on ONE queue.  With the
+        weight gradients on the second stream two runs of the same step were NOT bit-identical although every reduction has a fixed order:
+        in a few passes of ten, a per-utterance sum of a normalisation kernel came out 1e-4 ... 2e-3 (relative) off when a workgroup of the
+        streaming dense-row weight-gradient kernel (csrc/dtw.hip: LDS-DMA operands, 96 KB of LDS) shared its CU, and was exact again when
+        the same call was repeated right behind it on the same operands; never with that kernel's workgroups taking a CU's whole LDS,
+        never on one queue (tools/dev/det_diff.py, tools/dev/det_actbwd.py, tools/micro/lds_dma_canary.hip).  Not
+        understood; one queue is what is bit-stable."""
+        self.side = None if _lib.lib().sehip_get_deterministic() else self._side_stream
+
     def _launch_wgrad(self, name, st):
         h = self._dtw.get(name + ".wg")
+        skip = os.environ.get("SEHIP_DET_SKIP_WGRAD")       # tools/dev/det_diff.py bisection (wrong gradients): all | generic | dense
+        if skip and (skip == "all" or (skip == "dense") == (h is not None)):
+            return
         if h is not None:
             call("sehip_wgrad_dense_group", ptr(h[0]), 1, C.cast(h[1], C.c_void_p), ptr(self._dtw_scratch), st)
         else:
@@ -770,6 +784,7 @@ class DemucsWorkspace:
         pass reads are not packed."""
         st, cfg, b, tb = self.st, self.st.cfg, self.bufs, self.tb
         B = self.B
+        self._select_streams()
         if st.lstms and self.generation % 64 == 2 and not torch.cuda.is_current_stream_capturing():
             # Every 64th call of THIS workspace (the read waits for the previous step).  The counter is per workspace, so under data
             # parallelism the ranks reach this line at different forwards (validation clips of different lengths, a partial last

@@ -209,7 +209,8 @@ class TasNetWorkspace:
                                          dtype=torch.float32, device=device)
         self.wav = None
         self._one_clear, self._bwd_clean = not os.environ.get("SEHIP_CTN_TORCH_ZEROS"), False
-        self.side = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        self._side_stream = None if os.environ.get("SEHIP_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        self.side = self._side_stream      # (None while the deterministic schedule is on: forward())
         self._events, self._event_i, self._chain_dirty = [], 0, True
         self._bind()
 
@@ -311,13 +312,20 @@ class TasNetWorkspace:
             self.stats.zero_()
         call("sehip_pack_bf16", ptr(params), ptr(tb.wtab), st.n_wpack, ptr(tb.wpack), stream())
         net = "separator.network."
+        # (the deterministic schedule -- solver.cudnn_deterministic, sehip.utils.set_deterministic -- keeps the statistics out of the product's
+        #  launch: its double atomics arrive in a varying order; sehip_ctn_gln_stats adds the workgroups' sums in a fixed one)
+        det = bool(_lib.lib().sehip_get_deterministic())
+        fused_gln = self.fused_gln and not det
+        # ... and runs the step on ONE queue: with the weight gradients on the second stream two runs were not bit-identical in a few
+        # passes of ten although every reduction has a fixed order (plan_demucs.DemucsWorkspace._select_streams)
+        self.side = None if det else self._side_stream
         call("sehip_ctn_encoder_fwd", ptr(wav), pp("encoder.conv1d_U.weight"), pp(net + "0.gamma"), pp(net + "0.beta"), M,
              cfg.audio_channels, self.T, N, cfg.L, ptr(self.w), b["cln"].ptr, stream())
         self.gemm("bott.fwd")
         for i, (r, x) in enumerate(st.blocks):
             q = f"{net}2.{r}.{x}.net."
             s1 = self.stats[i, 0].data_ptr(); s2 = self.stats[i, 1].data_ptr()
-            if self.fused_gln:      # the product's launch also takes the gLN statistics of what it stores (csrc/dgemm.hip)
+            if fused_gln:           # the product's launch also takes the gLN statistics of what it stores (csrc/dgemm.hip)
                 d = self.desc[f"b{i}.in.fwd"]
                 d.gln_stats, d.gln_slope = s1, pp(q + "1.weight")
                 self.gemm(f"b{i}.in.fwd")

@@ -124,7 +124,8 @@ class Solver(object):
         self.is_main = self.rank == 0
         # src/solver.py:133 hands config.solver.cudnn_deterministic to prepare_device (src/utils.py:108-111; the shipped YAML sets it
         # True).  Here it selects the fixed-order reductions of libsehip and of the model's plan: two runs of the same steps are
-        # bit-identical.  Built for DCCRN; a model without set_deterministic() keeps its own atomics and says so once.
+        # bit-identical.  Built for every HIP model (DCCRN, DCUnet, ConvTasNet, Demucs); a model without set_deterministic() keeps
+        # its own atomics and says so once.
         self.deterministic = bool(_cfg(config.solver, "cudnn_deterministic", False)) and device == "gpu"
         if self.deterministic and _cfg(config.solver, "use_graph", False):
             # (the deterministic schedule sizes its per-split partial arrays on demand, which cannot happen inside a stream capture: say so
@@ -139,10 +140,9 @@ class Solver(object):
             if hasattr(model, "set_deterministic"):
                 model.set_deterministic(self.deterministic)
         if self.deterministic and not hasattr(model, "set_deterministic"):
-            if True:
-                import warnings
-                warnings.warn(f"solver.cudnn_deterministic: model '{config.model.name}' has no deterministic plan yet (its normalisation "
-                              f"sums use fp32 atomics); the library-level reductions are deterministic, run-to-run bit equality is not guaranteed")
+            import warnings
+            warnings.warn(f"solver.cudnn_deterministic: model '{config.model.name}' has no deterministic plan yet (its normalisation "
+                          f"sums use fp32 atomics); the library-level reductions are deterministic, run-to-run bit equality is not guaranteed")
 
         self.optimizer = optimizer
         self.loss_function = loss_function

@@ -56,7 +56,13 @@ def test_split_decoder_products_match_the_two_source_products(kw, B):
         assert e < 7e-3, (j, e)          # (two independent roundings of the stored tensor, 1.66e-3 each, + the partial tile's)
     e_est, e_grad = rel_err(b["est"], a["est"]), rel_err(b["grads"], a["grads"])
     print(f"split vs default: waveform rel {e_est:.2e}, |loss a - loss b| {abs(a['loss'] - b['loss']):.4f} dB, gradient rel {e_grad:.2e}")
-    assert e_est < 8e-3 and abs(a["loss"] - b["loss"]) < 0.05 and e_grad < 3e-2
+    # The loss bound.  A random-initialised network's estimate is almost orthogonal to the target: SI-SDR = -45 dB here, i.e. the
+    # target component is 5.6e-3 of the estimate, and a 3.5e-3 relative change of the waveform moves the loss by tenths of a dB.  The
+    # DEFAULT path alone does so from run to run (its BatchNorm sums are fp32 atomics: 44.70 / 44.75 / 44.82 dB for the same seed over
+    # three processes, gpurun_out trail of round 6), so 0.05 dB -- this test's first bound -- failed in 3 of 8 runs with |delta| 0.12-0.17 dB
+    # and gradient rel 2.5e-2 ... 3.3e-2.  Bounds now: 4 x that jitter; the tight statements are the stored tensors above and the
+    # op-local tests of the kernel path (tests/test_gpu_ops_local.py).
+    assert e_est < 8e-3 and abs(a["loss"] - b["loss"]) < 0.5 and e_grad < 8e-2
     for k in a["sd"]:                                        # running statistics of the decoders' BatchNorm layers (the fused sums)
         if k.startswith("decoder.") and k.endswith(("RMr", "RMi", "RVrr", "RVii")):
             assert rel_err(b["sd"][k].float(), a["sd"][k].float()) < 5e-3, k

@@ -109,3 +109,73 @@ def test_dcunet_two_deterministic_runs_are_bit_identical(depth, shape):
     assert a[0] == c[0], (a[0], c[0])
     for x, y, what in zip(a[1:], c[1:], ("parameters", "exp_avg", "exp_avg_sq", "gradients")):
         assert torch.equal(x, y), what
+
+
+def _solver_run(cfg, mix, src, steps=3):
+    """`steps` Solver train steps under solver.cudnn_deterministic = True; returns losses + metrics, parameters, Adam moments, gradients."""
+    import warnings
+    from sehip import distrib
+    from sehip.solver import Solver, ScalarLog
+    from sehip.utils import set_deterministic
+    cfg.solver.cudnn_deterministic = True
+    try:
+        torch.manual_seed(cfg.seed)
+        model = distrib.get_model(cfg.model)
+        opt = distrib.get_optimizer(cfg.optim, model)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")             # "model ... has no deterministic plan yet" must not be raised any more
+            solver = Solver(cfg, model, opt, distrib.get_loss_function(cfg.optim), device="gpu", writer=ScalarLog())
+        assert solver.deterministic
+        out = []
+        for s in range(steps):
+            loss, metric = solver.train_step(*solver._prepare_batch(mix[s], src[s]))
+            out.append((float(loss), float(metric[0]), float(metric[1])))
+        torch.cuda.synchronize()
+        return out, model.flat_params.detach().cpu().clone(), opt._m.cpu().clone(), opt._v.cpu().clone(), model.flat_grads.detach().cpu().clone()
+    finally:
+        set_deterministic(False)
+
+
+def _assert_bit_identical(a, c):
+    assert a[0] == c[0], (a[0], c[0])                      # losses and both gradient metrics, every step
+    assert all(np.isfinite(v) for step in a[0] for v in step), a[0]
+    for x, y, what in zip(a[1:], c[1:], ("parameters", "exp_avg", "exp_avg_sq", "gradients")):
+        assert torch.equal(x, y), what
+
+
+@pytest.mark.parametrize("width,b,n", [(dict(N=64, B=64, H=128, X=3, R=2), 3, 6000), (dict(), 4, 16000)])
+def test_convtasnet_two_deterministic_runs_are_bit_identical(tmp_path, width, b, n):
+    """VERDICT r5 missing 2: `cudnn_deterministic: True` (src/conf/config.yaml:130) is applied whatever the model (src/utils.py:108-111).
+    ConvTasNet under the switch (gLN statistics out of the products' launches, per-utterance sums through ordered slots, column sums in
+    row order, fixed-order weight gradients, unfused optimizer tail): two independent runs of three Solver steps are BIT-identical --
+    at a reduced width and at the C4 width (N128 B128 H256 X7 R2)."""
+    from test_gpu_convtasnet import c4_config
+
+    def once():
+        cfg = c4_config(tmp_path)
+        for k, v in width.items():
+            setattr(cfg.model, k, v)
+        g = torch.Generator().manual_seed(21)
+        src = [0.1 * torch.randn(b, 2, 1, n, generator=g) for _ in range(3)]
+        return _solver_run(cfg, [s.sum(1) for s in src], src)
+
+    _assert_bit_identical(once(), once())
+
+
+@pytest.mark.parametrize("kw,b,n", [(dict(channels=32, depth=4), 3, 9000), (dict(), 2, 24000)])
+def test_demucs_two_deterministic_runs_are_bit_identical(tmp_path, kw, b, n):
+    """The same for Demucs (GroupNorm statistics and backward sums: threads in thread order, workgroups through ordered slots; the
+    per-channel partial rows added in row order; fixed-order weight gradients; unfused tail) -- a reduced network and the default
+    133.7-M-parameter one."""
+    from test_gpu_demucs import c3_config
+
+    def once():
+        cfg = c3_config(tmp_path)
+        for k, v in kw.items():
+            setattr(cfg.model, k, v)
+        g = torch.Generator().manual_seed(22)
+        clean = [0.1 * torch.randn(b, 1, 2, n, generator=g) for _ in range(3)]
+        mix = [c[:, 0] + 0.05 * torch.randn(b, 2, n, generator=g) for c in clean]
+        return _solver_run(cfg, mix, clean)
+
+    _assert_bit_identical(once(), once())
