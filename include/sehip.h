@@ -58,7 +58,8 @@ int sehip_istft_bwd(const float* dwav, const float* wav, const float* spec, cons
 /* ---- stft_custom / istft_custom: src/evaluate.py:101-128 and :130-162 (torch.stft / torch.istft with a periodic hann
  *      window of win_length centred in n_fft, center -> reflect padding, one-sided, and the reference's own / and * by
  *      win_length).  wav [rows][n_samples] fp32, spec [rows][n_fft/2+1][n_frames][2] fp32 (time innermost, as the
- *      reference returns it), frames_ws [rows][n_frames][n_fft] fp32 scratch.  n_fft must be 512. */
+ *      reference returns it), frames_ws [rows][n_frames][n_fft] fp32 scratch.  n_fft = 512 (the shipped configurations) runs on
+ *      the wave64 FFT, any other n_fft in [2, 4096] -- even or odd -- on a direct DFT per frame. */
 int sehip_stft_custom_frames(int n_samples, int n_fft, int hop, int center);
 int sehip_stft_custom_fwd(const float* wav, int rows, int n_samples, int n_fft, int hop, int win_length, int center,
                           float* spec, void* stream);

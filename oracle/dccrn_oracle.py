@@ -43,7 +43,8 @@ class DCCRNConfig:
 
     def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512,
                  length=16384, masking_mode="E", kernel_size=5,
-                 kernel_num=DEFAULT_KERNEL_NUM, **_ignored):
+                 kernel_num=DEFAULT_KERNEL_NUM, win_type="hann", **_ignored):
+        self.win_type = win_type
         self.rnn_layers = rnn_layers
         self.rnn_units = rnn_units
         self.win_len = win_len
@@ -104,7 +105,21 @@ def hann_periodic(n: int) -> np.ndarray:
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
 
 
-def stft_bases(win_len: int, fft_len: int):
+def window_of(win_type, n: int) -> np.ndarray:
+    """init_kernels' window (src/model/dccrn.py:650-653): ones for None / 'None', else scipy.signal.get_window(win_type, n, fftbins=True)
+    (the `**0.5` there is commented out).  'hann' and 'hamming' in closed form (the periodic cosine windows), anything else through scipy."""
+    if win_type is None or win_type == "None":
+        return np.ones(n, dtype=np.float64)
+    k = np.arange(n, dtype=np.float64)
+    if win_type == "hann":
+        return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+    if win_type == "hamming":
+        return 0.54 - 0.46 * np.cos(2.0 * np.pi * k / n)
+    from scipy.signal import get_window
+    return np.asarray(get_window(win_type, n, fftbins=True), dtype=np.float64)
+
+
+def stft_bases(win_len: int, fft_len: int, win_type="hann"):
     """Returns (analysis[2*(fft/2+1), win], synthesis[2*(fft/2+1), win], window[win]) as fp32.
 
     analysis rows = [cos rows ; -sin rows] * window; synthesis = pinv(unwindowed).T * window.
@@ -113,7 +128,7 @@ def stft_bases(win_len: int, fft_len: int):
     k = np.arange(fft_len // 2 + 1, dtype=np.float64)[:, None]
     ang = 2.0 * np.pi * k * n / fft_len
     basis = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0)  # [2F, win]
-    win = hann_periodic(win_len)
+    win = window_of(win_type, win_len)
     analysis = basis * win[None, :]
     synthesis = np.linalg.pinv(basis).T * win[None, :]
     return (torch.from_numpy(analysis.astype(np.float32)),
@@ -272,7 +287,7 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
     ``capture`` (dict) receives named intermediates; ``stats_out`` the updated BN buffers.
     """
     if bases is None:
-        bases = stft_bases(cfg.win_len, cfg.fft_len)
+        bases = stft_bases(cfg.win_len, cfg.fft_len, getattr(cfg, "win_type", "hann"))
     analysis, synthesis, window = bases
     nbin = cfg.fft_len // 2 + 1
     cap = capture if capture is not None else {}

@@ -4,7 +4,8 @@
 Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_stft.py
 Needs /root/reference (read-only).  The fixture holds inputs and the reference's numeric outputs of
 src/evaluate.py stft_custom / istft_custom for the two shipped STFT configurations (src/conf/config.yaml:38-41:
-512/128/512, test/conf/config.yaml:38-41: 512/256/512), a shorter window, a 4-D (speaker) input and an odd length.
+512/128/512, test/conf/config.yaml:38-41: 512/256/512), a shorter window, a 4-D (speaker) input, an odd length, and (round 6) four
+configurations with n_fft other than 512: 256, 1024 with an 800-sample window, 400 (not a power of two), 255 (odd).
 """
 import os
 import sys
@@ -25,6 +26,12 @@ CASES = [
     ("win_400", (1, 2, 1777), 512, 100, 400, 1777),
     ("spk_4d", (2, 2, 1, 1500), 512, 128, 512, 1500),
     ("longer_length", (1, 1, 1024), 512, 128, 512, 1100),
+    # round 6: n_fft other than 512 (src/evaluate.py:101-162 passes config.n_fft to torch.stft as it is); appended, so the cases above
+    # keep their random draws
+    ("nfft_256", (2, 1, 3000), 256, 64, 256, 3000),
+    ("nfft_1024_win_800", (1, 2, 5000), 1024, 256, 800, 5000),
+    ("nfft_400", (2, 1, 2500), 400, 100, 400, 2500),
+    ("nfft_255_odd", (1, 1, 1500), 255, 60, 255, 1500),
 ]
 
 

@@ -22,7 +22,7 @@ _STATIC_CACHE = {}
 def _static_for(cfg, deterministic=False):
     # (the experiment switches that DCCRNStatic reads when it is built are part of the key)
     switches = tuple(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_STATS64", "SEHIP_NO_FUSE_STATS32", "SEHIP_DEC_SPLIT"))
-    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, switches,
+    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, str(cfg.win_type), switches,
            bool(deterministic))
     if key not in _STATIC_CACHE:
         _STATIC_CACHE[key] = plan.DCCRNStatic(cfg, deterministic=deterministic)
@@ -69,7 +69,7 @@ class DCCRN(FlatModule):
         self.grad_range_hook = None   # data-parallel: called with (lo, hi, stream) when flat_grads[lo:hi] is final (see plan.backward)
 
         # persistent STFT buffers (checkpoint compatibility; the FFT kernels do not read them)
-        an, sy, win = _stft_bases(win_len, fft_len)
+        an, sy, win = _stft_bases(win_len, fft_len, win_type)
         self.stft = _Node()
         self.stft.register_buffer("weight", torch.from_numpy(an[:, None, :]))
         self.istft = _Node()
@@ -196,11 +196,11 @@ class DCCRN(FlatModule):
         return [{"params": weights, "weight_decay": weight_decay}, {"params": biases, "weight_decay": 0.0}]
 
 
-def _stft_bases(win_len, fft_len):
-    """init_kernels (src/model/dccrn.py:649-666): analysis = [cos; -sin] * hann, synthesis = pinv(basis).T * hann."""
+def _stft_bases(win_len, fft_len, win_type="hann"):
+    """init_kernels (src/model/dccrn.py:649-666): analysis = [cos; -sin] * window, synthesis = pinv(basis).T * window."""
     n = np.arange(win_len, dtype=np.float64)[None, :]
     k = np.arange(fft_len // 2 + 1, dtype=np.float64)[:, None]
     ang = 2.0 * np.pi * k * n / fft_len
     basis = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0)
-    win = ops.hann_periodic(win_len).astype(np.float64)
+    win = ops.window_of(win_type, win_len).astype(np.float64)
     return ((basis * win).astype(np.float32), (np.linalg.pinv(basis).T * win).astype(np.float32), win.astype(np.float32))

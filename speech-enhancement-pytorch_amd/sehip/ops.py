@@ -17,9 +17,26 @@ def hann_periodic(n):
     return (0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)).astype(np.float32)
 
 
-def inv_window_energy(win, hop, frames, length):
+def window_of(win_type, n):
+    """The window of init_kernels (src/model/dccrn.py:650-653): ones for None / 'None', else
+    scipy.signal.get_window(win_type, n, fftbins=True).  'hann' / 'hamming' in closed form, anything else through scipy."""
+    if win_type is None or win_type == "None":
+        return np.ones(n, dtype=np.float32)
+    if win_type == "hann":
+        return hann_periodic(n)
+    k = np.arange(n, dtype=np.float64)
+    if win_type == "hamming":
+        return (0.54 - 0.46 * np.cos(2.0 * np.pi * k / n)).astype(np.float32)
+    try:
+        from scipy.signal import get_window
+        return np.asarray(get_window(win_type, n, fftbins=True), dtype=np.float64).astype(np.float32)
+    except Exception as e:      # an unknown name, or scipy absent
+        raise _lib.SehipError(f"sehip DCCRN: win_type={win_type!r}: {e}")
+
+
+def inv_window_energy(win, hop, frames, length, win_type="hann"):
     """1 / (overlap-added window^2 + 1e-8), trimmed like src/model/dccrn.py:733-745."""
-    w2 = hann_periodic(win).astype(np.float64) ** 2
+    w2 = window_of(win_type, win).astype(np.float64) ** 2
     total = (frames - 1) * hop + win
     e = np.zeros(total, dtype=np.float64)
     for t in range(frames):

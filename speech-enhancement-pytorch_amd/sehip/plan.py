@@ -95,8 +95,10 @@ class DCCRNConfig:
                  kernel_num=(16, 32, 64, 128, 256, 256), **_ignored):
         if not use_clstm or not use_cbn:
             raise SehipError("sehip DCCRN implements the reference defaults use_clstm=True, use_cbn=True only")
-        if win_type != "hann":
-            raise SehipError("sehip DCCRN: only win_type='hann' is built")
+        # (the window is data for the FFT front end: ones for None / 'None', any scipy.signal.get_window name otherwise --
+        #  src/model/dccrn.py:650-653; checked here so that a bad name fails at construction)
+        ops.window_of(win_type, win_len)
+        self.win_type = win_type
         if kernel_size != 5:
             raise SehipError("sehip DCCRN: only kernel_size=5 is built")
         if rnn_layers != 2:
@@ -804,7 +806,7 @@ class DeviceTables:
             tg, pm = gather_ordered_unpack_table(st.utab, st.layout.tensor_offsets)
             self.utab_g, self.uperm = f(tg), f(pm)
         cfg = st.cfg
-        self.window = f(ops.hann_periodic(cfg.win_len))
+        self.window = f(ops.window_of(cfg.win_type, cfg.win_len))
         self.wpack = torch.zeros(st.n_wpack, dtype=BF16, device=device)
         self.bpack = torch.zeros(max(st.n_bpack, 4), dtype=torch.float32, device=device)
 
@@ -869,7 +871,7 @@ class DCCRNWorkspace:
         self.spec = torch.empty(B, T, 257, 2, dtype=torch.float32, device=device)
         self.frames = torch.empty(B, T, cfg.win_len, dtype=torch.float32, device=device)
         self.wav = torch.empty(B, self.length, dtype=torch.float32, device=device)
-        self.inv_coff = torch.from_numpy(ops.inv_window_energy(cfg.win_len, cfg.win_inc, T, self.length)).to(device)
+        self.inv_coff = torch.from_numpy(ops.inv_window_energy(cfg.win_len, cfg.win_inc, T, self.length, cfg.win_type)).to(device)
         self.gpack = torch.zeros(st.n_gpack, dtype=torch.float32, device=device)
         maxcr = max(cr for _, cr in st.bn)
         lib = _lib.lib()

@@ -178,3 +178,26 @@ def test_hip_vs_reference_full_size_checksum():
     big = [k for k in norms if norms[k] > 0.02 * gn_ref]
     for k in big:                            # per-tensor gradient norms of everything that matters
         assert abs(float(grads[k].double().norm()) - norms[k]) < 0.2 * norms[k], (k, float(grads[k].norm()), norms[k])
+
+
+@pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("none", dict(win_type=None)),
+                                        ("blackman", dict(win_type="blackman"))])
+def test_hip_window_types_against_reference_vectors(case, extra):
+    """win_type of the reference constructor (src/model/dccrn.py:20; init_kernels :650-653: ones for None, else
+    scipy.signal.get_window) on the HIP path -- the window is data for the FFT front end -- against what the imported reference
+    produced (tests/golden/dccrn_variants.npz, oracle/gen_golden_dccrn_variants.py): waveform, loss, gradients, eval-mode waveform,
+    and the istft.window buffer of the state_dict."""
+    g = {k[len(case) + 1:]: v for k, v in load_golden("dccrn_variants.npz").items() if k.startswith(case + "/")}
+    model = _hip_model_from_seed(dict(LEGAL, **extra), 31, 32)
+    assert np.allclose(model.state_dict()["istft.window"][0, :, 0].cpu().numpy(), g["window"], atol=1e-7)
+    noisy, clean = make_batch(33, 2, 4000)
+    est, loss, grads = _fwd_bwd(model, noisy, clean)
+    full, norms = golden_grads(g)
+    num = sum(float(((grads[k].double() - full[k].double()) ** 2).sum()) for k in full)
+    den = sum(n * n for n in norms.values())
+    print(f"{case}: waveform rel {rel_err(est, g['est']):.3e} dloss {abs(loss - float(g['loss'])):.4f} global grad rel {(num / den) ** 0.5:.3e}")
+    assert rel_err(est, g["est"]) < 3e-2 and abs(loss - float(g["loss"])) < 0.1
+    assert (num / den) ** 0.5 < 5e-2
+    model.eval()
+    with torch.no_grad():
+        assert rel_err(model(noisy.cuda()).cpu(), g["est_eval"]) < 3e-2

@@ -26,7 +26,8 @@ def test_against_reference_golden():
         c = cfg(n_fft, hop, win)
         s = stft_custom(torch.from_numpy(g[name + ".x"]).to(dev), c)
         assert tuple(s.shape) == g[name + ".stft"].shape
-        assert np.abs(s.cpu().numpy() - g[name + ".stft"]).max() < 2e-7, name            # |X| <= ~0.1 here: ~1e-6 relative
+        # |X| <= ~0.1 here: ~1e-6 relative; the direct DFT of the other n_fft adds up to 1024 fp32 terms per bin
+        assert np.abs(s.cpu().numpy() - g[name + ".stft"]).max() < (2e-7 if n_fft == 512 else 6e-7), name
         y = istft_custom(torch.from_numpy(g[name + ".z"]).to(dev), length, c)
         ref = g[name + ".istft"]
         assert tuple(y.shape) == ref.shape
@@ -41,6 +42,10 @@ def test_against_reference_golden():
     ((1, 1, 257), 512, 64, 512, True),        # shortest input reflect padding allows (n_fft/2 < N)
     ((2, 1, 4096), 512, 256, 320, True),      # window shorter than n_fft, 512/256
     ((2, 2, 1, 3000), 512, 128, 512, False),  # no centring, speaker axis
+    ((2, 1, 4000), 1024, 256, 1024, True),    # round 6: n_fft other than 512 (direct DFT per frame)
+    ((1, 2, 3000), 320, 160, 256, False),     # not a power of two, window shorter than n_fft, no centring
+    ((1, 1, 1500), 2048, 512, 2048, True),    # a clip shorter than one frame (reflect padding on both sides: n_fft/2 < N < n_fft)
+    ((2, 1, 2000), 129, 32, 129, True),       # odd n_fft
 ])
 def test_stft_against_oracle(shape, n_fft, hop, win, center):
     from sehip.evaluate import stft_custom
@@ -75,7 +80,7 @@ def test_errors():
     with pytest.raises(SehipError):
         stft_custom(torch.zeros(1, 1, 1000), cfg(512, 128, 512))                 # CPU tensor
     with pytest.raises(SehipError):
-        stft_custom(torch.zeros(1, 1, 1000).cuda(), cfg(320, 160, 320))         # n_fft not built
+        stft_custom(torch.zeros(1, 1, 10000).cuda(), cfg(8192, 2048, 8192))     # n_fft beyond the direct transform's limit (4096)
     with pytest.raises(SehipError):
         stft_custom(torch.zeros(1, 1, 200).cuda(), cfg(512, 128, 512))          # reflect padding impossible
     with pytest.raises(SehipError):

@@ -175,7 +175,7 @@ def test_stft_custom_oracle_matches_reference():
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stft_custom.npz"))
     names = sorted({k.split(".")[0] for k in g.files})
-    assert len(names) == 5
+    assert len(names) == 9             # five with n_fft 512, four with other n_fft (256, 1024, 400, 255: round 6)
     for name in names:
         n_fft, hop, win, length = [int(v) for v in g[name + ".cfg"]]
         s = S.stft_custom(g[name + ".x"], n_fft, hop, win)
@@ -323,3 +323,28 @@ def test_demucs_resampler_properties():
     assert back.shape == s.shape and float((back - s)[..., 100:-100].abs().max()) < 2e-3
     k, width, _, _ = DM.resample_kernels(1, 2)
     assert width == 26 and tuple(k.shape) == (2, 53) and float((k.sum(1) - 1).abs().max()) < 1e-6
+
+
+# ---- constructor options beyond the shipped YAML (round 6): tests/golden/dccrn_variants.npz (oracle/gen_golden_dccrn_variants.py)
+@pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("none", dict(win_type=None)),
+                                        ("blackman", dict(win_type="blackman"))])
+def test_window_types_against_reference(case, extra):
+    """win_type of the reference constructor (src/model/dccrn.py:20, init_kernels :650-653): the oracle with that window against the
+    imported reference's waveform, loss, gradients and eval-mode waveform."""
+    g = {k[len(case) + 1:]: v for k, v in load_golden("dccrn_variants.npz").items() if k.startswith(case + "/")}
+    kw = dict(LEGAL, **extra)
+    assert np.allclose(O.window_of(extra["win_type"], 400), g["window"], atol=1e-7)
+    cfg, p, noisy, est, loss, grads, stats = _oracle_fwd_bwd(kw, 31, 32, 33, 2, 4000)
+    assert rel_err(est, g["est"]) < 5e-5 and abs(loss - float(g["loss"])) < 2e-4
+    full, norms = golden_grads(g)
+    assert set(full) == set(grads)
+    for k, gr in grads.items():
+        tol = 5e-3 * norms[k] + 6e-4 * float(full[k].abs().max()) * gr.numel() ** 0.5 + 2e-6 * gr.numel() ** 0.5
+        if k.endswith("conv.bias") and not k.startswith("decoder.5."):
+            # a convolution bias in front of a BatchNorm: the true gradient is zero, both sides hold fp32 round-off (|g| ~ 1e-6 per
+            # entry, uncorrelated): bounded, not compared
+            assert float(gr.norm()) < 1e-4 and norms[k] < 1e-4, (k, float(gr.norm()), norms[k])
+            continue
+        assert float((gr - full[k]).norm()) < tol, (k, float((gr - full[k]).norm()), norms[k])
+    q = dict(p); q.update({k: v for k, v in stats.items()})
+    assert rel_err(O.dccrn_forward(q, noisy, cfg, training=False), g["est_eval"]) < 5e-5
