@@ -55,9 +55,10 @@ def test_errors_are_reported_not_thrown():
     assert b"step range" in lib.sehip_last_error()
     assert lib.sehip_lstm_bwd_chunk(None, None, None, None, None, 2, 10, 64, 0, 5, None, None, None, None) != 0
     assert b"state buffer" in lib.sehip_last_error()
-    # stft_custom: only n_fft 512 is built; frame count helper follows torch.stft
-    assert lib.sehip_stft_custom_fwd(None, 1, 1000, 320, 160, 320, 1, None, None) != 0
-    assert b"n_fft 512" in lib.sehip_last_error()
+    # stft_custom: n_fft in [2, 4096] (512 on the FFT path, anything else a direct DFT: round 6); frame count helper follows torch.stft
+    assert lib.sehip_stft_custom_fwd(None, 1, 100000, 8192, 2048, 8192, 1, None, None) != 0
+    assert b"n_fft 8192 outside" in lib.sehip_last_error()
     assert lib.sehip_stft_custom_frames(32768, 512, 128, 1) == 257
     assert lib.sehip_stft_custom_frames(2048, 512, 256, 0) == 7
+    assert lib.sehip_stft_custom_frames(1500, 255, 60, 1) == 25        # odd n_fft: the centre padding is n_fft - 1 samples in all
     assert lib.sehip_stream_depend(None, None, None) != 0
