@@ -681,7 +681,9 @@ class DemucsWorkspace:
         the same call was repeated right behind it on the same operands; never with that kernel's workgroups taking a CU's whole LDS,
         never on one queue (tools/dev/det_diff.py, tools/dev/det_actbwd.py, tools/micro/lds_dma_canary.hip).  Not
         understood; one queue is what is bit-stable."""
-        self.side = None if _lib.lib().sehip_get_deterministic() else self._side_stream
+        # (SEHIP_DET_FORCE_SIDE=1, tools/dev/det_diff.py: keep the second stream under the deterministic schedule -- to reproduce the above)
+        one_queue = _lib.lib().sehip_get_deterministic() and not os.environ.get("SEHIP_DET_FORCE_SIDE")
+        self.side = None if one_queue else self._side_stream
 
     def _launch_wgrad(self, name, st):
         h = self._dtw.get(name + ".wg")
