@@ -1361,7 +1361,8 @@ extern "C" int sehip_dmx_act_bwd(const void* dz, const void* y, const double* st
     if (stats) {
         SEHIP_REQUIRE(gamma && beta && sums && gch, "dmx_act_bwd: GroupNorm needs gamma, beta, sums and the gradient accumulator");
         const int NV = 2 * C + (mode ? C >> 1 : C);
-        const size_t lds = ((size_t)NV + 16) * sizeof(float);
+        static const int lds_pad = getenv("SEHIP_DMX_LDS_PAD") ? atoi(getenv("SEHIP_DMX_LDS_PAD")) : 0;       // tools/dev: unused bytes behind the partials
+        const size_t lds = ((size_t)NV + 16) * sizeof(float) + (size_t)lds_pad;
         SEHIP_REQUIRE(lds <= 64 * 1024, "dmx_act_bwd: C=%d does not fit the LDS partials", C);
         // one row of per-channel sums per workgroup (per-stream pool of csrc/wgrad3.hip; none available -- e.g. a capture that would
         // have to grow it -- or SEHIP_DMX_ATOMIC_FLUSH: the workgroups flush with atomics as in rounds 2-4)

@@ -34,6 +34,35 @@ __global__ __launch_bounds__(512, 1) void dma_kernel(const unsigned* __restrict_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// Second victim: WRITES, atomics and barriers.  Every iteration each thread stores a fresh word, adds 1.0f to one of four LDS counters
+// (ds_add_f32, 64 lanes per counter) and, behind a barrier, checks ANOTHER thread's word and the counters -- a lost store, a lost
+// atomic or a barrier that lets a read pass a write would all show.
+__global__ __launch_bounds__(256) void rw_canary_kernel(int iters, unsigned* __restrict__ bad_count, unsigned* __restrict__ bad_log) {
+    __shared__ unsigned word[256];
+    __shared__ float cnt[4];
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0.f;
+    __syncthreads();
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        word[threadIdx.x] = (unsigned)it * 2654435761u + threadIdx.x;
+        atomicAdd(&cnt[threadIdx.x & 3], 1.0f);
+        __syncthreads();
+        const unsigned j = (threadIdx.x * 37u + 11u) & 255u;
+        const unsigned got = word[j], want = (unsigned)it * 2654435761u + j;
+        const float c = cnt[threadIdx.x & 3], cw = 64.0f * (float)(it + 1);
+        if (got != want || c != cw) {
+            ++bad;
+            const unsigned slot = atomicAdd(bad_count + 1, 1u);
+            if (slot < 64) { bad_log[slot * 4] = got != want ? j : 1000u + (threadIdx.x & 3); bad_log[slot * 4 + 1] = got != want ? got : __float_as_uint(c);
+                             bad_log[slot * 4 + 2] = (unsigned)it; bad_log[slot * 4 + 3] = blockIdx.x; }
+        }
+        __syncthreads();
+        if (c != cw && threadIdx.x < 4) cnt[threadIdx.x] = cw;      // repair, count every event once
+        __syncthreads();
+    }
+    if (bad) atomicAdd(bad_count, bad);
+}
+
 __global__ __launch_bounds__(256) void canary_kernel(int iters, unsigned* __restrict__ bad_count, unsigned* __restrict__ bad_log) {
     __shared__ unsigned pat[2048];                 // 8 KB
     for (int i = threadIdx.x; i < 2048; i += 256) pat[i] = 0xA5000000u | (unsigned)(i * 2654435761u >> 8);
@@ -72,16 +101,19 @@ int main(int argc, char** argv) {
     // order: "dma first" (the DMA workgroups take the low LDS addresses of every CU) or "canary first" (argv[3] = workgroups of the
     // canary kernel resident per CU before the DMA kernel arrives: its 96 KB then start ABOVE their 8 KB each)
     const int first = argc > 3 ? atoi(argv[3]) : 0;
+    const int rw = argc > 4 ? atoi(argv[4]) : 0;           // 1: the write / atomic / barrier victim instead of the read-only one
     for (int rep = 0; rep < 20; ++rep) {
         if (first > 0) {
-            canary_kernel<<<256 * first, 256, 0, s1>>>(3000, cnt, log_);
+            if (rw) rw_canary_kernel<<<256 * first, 256, 0, s1>>>(20000, cnt, log_);
+            else canary_kernel<<<256 * first, 256, 0, s1>>>(3000, cnt, log_);
             hipStreamQuery(s1);
             usleep(300);
             dma_kernel<<<256, 512, (size_t)lds_kb * 1024, s2>>>(src, nbytes, stages, 400, oob_pct, sink);
             hipDeviceSynchronize();
         } else {
             dma_kernel<<<256, 512, (size_t)lds_kb * 1024, s2>>>(src, nbytes, stages, 400, oob_pct, sink);
-            canary_kernel<<<2048, 256, 0, s1>>>(300, cnt, log_);
+            if (rw) rw_canary_kernel<<<2048, 256, 0, s1>>>(3000, cnt, log_);
+            else canary_kernel<<<2048, 256, 0, s1>>>(300, cnt, log_);
         }
     }
     hipError_t e = hipDeviceSynchronize();
@@ -89,7 +121,8 @@ int main(int argc, char** argv) {
     std::vector<unsigned> hl(64 * 4);
     hipMemcpy(h, cnt, 8, hipMemcpyDeviceToHost);
     hipMemcpy(hl.data(), log_, 64 * 16, hipMemcpyDeviceToHost);
-    printf("dma lds %d KB (%d stages), oob %d %%: %s; mismatching words seen by the canary workgroups: %u (events %u)\n", lds_kb, stages, oob_pct,
+    printf("%s victim, %s: dma lds %d KB (%d stages), oob %d %%: %s; mismatching words seen by the canary workgroups: %u (events %u)\n", rw ? "write/atomic/barrier" : "read-only",
+           first ? "canary first" : "dma first", lds_kb, stages, oob_pct,
            hipGetErrorString(e), h[0], h[1]);
     for (unsigned i = 0; i < (h[1] < 16 ? h[1] : 16); ++i)
         printf("   word %u got 0x%08x (iteration %u, block %u)\n", hl[i * 4], hl[i * 4 + 1], hl[i * 4 + 2], hl[i * 4 + 3]);
