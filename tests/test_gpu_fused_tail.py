@@ -220,3 +220,36 @@ def test_step_then_zero_grad_order_does_not_add_to_the_previous_steps_sums():
         assert opt.sync_step() == it + 1
         opt.zero_grad()                   # AFTER the step: arms the next backward pass
     assert fused_seen == [False, True, True, False, True, True]
+
+
+def test_a_loop_that_never_arms_the_fused_tail_is_told_so_once():
+    """the fused tail is armed by zero_grad(); a loop that never calls it between steps silently took the separate
+    launches.  It still does (same results) -- and says so once, at the third such step in a row; the Solver's order never hears it."""
+    import warnings
+    from sehip.model import DCCRN
+    from sehip.optim import FlatOptimizer
+    from sehip.loss import loss_sisdr
+    dev = torch.device("cuda:0")
+
+    def loop(call_zero_grad, steps=5):
+        torch.manual_seed(4)
+        model = DCCRN(kernel_num=[16, 16, 32, 32, 64, 64], rnn_units=128, length=4000).to(dev).train()
+        opt = FlatOptimizer(model, lr=3e-4)
+        g = torch.Generator().manual_seed(12)
+        c = (0.1 * torch.randn(2, 1, 4000, generator=g)).to(dev)
+        n = c + (0.05 * torch.randn(2, 1, 4000, generator=g)).to(dev)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(steps):
+                if call_zero_grad:
+                    opt.zero_grad()
+                else:
+                    model.flat_grads.zero_()          # (a caller that clears the gradients some other way)
+                loss_sisdr(model(n), c).backward()
+                opt.clip_grad_norm_(5.0)
+                opt.step()
+            torch.cuda.synchronize()
+        return [x for x in w if "fused tail" in str(x.message)]
+
+    assert len(loop(False)) == 1
+    assert len(loop(True)) == 0
