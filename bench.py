@@ -37,12 +37,16 @@ def make_batch(b, n, seed, device):
     return noisy.to(device), clean.to(device)
 
 
+HEADLINE_KERNEL_NUM = [16, 32, 64, 128, 256, 256]
+KERNEL_NUM = list(HEADLINE_KERNEL_NUM)      # --kernel-num replaces it (a side measurement: other widths of the same network)
+
+
 def bench_config(length):
     from sehip.utils import dict2obj
     return dict2obj({
         "seed": 10, "root": None, "ha": None,
         "model": {"name": "dccrn", "audio_channels": 1, "num_spk": 1, "length": length,
-                  "kernel_num": [16, 32, 64, 128, 256, 256], "rnn_units": 128, "masking_mode": "E"},
+                  "kernel_num": list(KERNEL_NUM), "rnn_units": 128, "masking_mode": "E"},
         "optim": {"optim": "adam", "lr": 3e-4, "beta1": 0.9, "beta2": 0.999, "loss": "si-sdr", "clip_grad": 5, "pit": False,
                   "load": False},
         "dset": {"name": "synthetic"},
@@ -602,6 +606,10 @@ def main():
                     help="dccrn = BASELINE configs[1], the headline metric; dcunet = configs[2] (DCUnet-10, STFT-domain mse, B=64); "
                          "convtasnet = configs[4] (2-speaker separation, 8 kHz 4-s clips, B=32 per GPU); demucs = configs[3] (48 kHz stereo "
                          "2-s clips, B=16 per GPU)")
+    ap.add_argument("--kernel-num", default="", help="DCCRN only: six comma-separated channel counts instead of the headline's "
+                    "16,32,64,128,256,256 (e.g. the reference YAML's commented 'paper' widths 32,64,128,256,256,256, "
+                    "src/conf/config.yaml:86-88).  A side measurement: implies --no-roofline --no-cpu-baseline --no-traffic, and the "
+                    "line's config.workload names the widths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as two captured hipGraphs instead of launching "
@@ -618,6 +626,13 @@ def main():
                          "box torch's CPU ops with 256 threads did not finish ONE B=32 step in 15 minutes, 32 threads take ~5 s)")
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("STATE", "OUT"))
     args = ap.parse_args()
+    if args.kernel_num:
+        widths = [int(v) for v in args.kernel_num.split(",")]
+        if args.workload != "dccrn" or len(widths) != 6:
+            sys.exit("--kernel-num: six channel counts, DCCRN only")
+        KERNEL_NUM[:] = widths
+        if widths != HEADLINE_KERNEL_NUM:
+            args.no_roofline = args.no_cpu_baseline = args.no_traffic = True
     dcu = args.workload == "dcunet"
     ctn = args.workload == "convtasnet"
     dmx = args.workload == "demucs"
@@ -756,7 +771,7 @@ def main():
                                 "SI-SNR, Adam 3e-4, clip 5" if ctn else
                                 "Demucs (channels 64, depth 6, DConv with BLSTM + LocalState from layer 4, x2 resampling; 133.7 M parameters) "
                                 "denoising train step, 48 kHz stereo 2-s clips, SI-SNR, Adam 3e-4, clip 5" if dmx else
-                                "DCCRN (kernel_num 16-32-64-128-256-256, complex LSTM 128, mask E) train step, 16 kHz 2-s "
+                                f"DCCRN (kernel_num {'-'.join(str(v) for v in KERNEL_NUM)}, complex LSTM 128, mask E) train step, 16 kHz 2-s "
                                 "clips, SI-SNR, Adam 3e-4, clip 5"), "per_gpu_batch": args.batch,
                    "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
                    "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step, overlapped with the previous step" if args.h2d_overlap else
