@@ -383,7 +383,13 @@ int sehip_pack_bf16_runs_to(const float* params, const int* runs2 /*[n/8][2]*/, 
 
 /* ---- ComplexBatchNorm + PReLU: src/model/dccrn.py:457-634 (training branch :549-611, whitening :593-602,
  *      running statistics :555-556,577-579) fused with nn.PReLU() (:79,122).  Activations are [rows][2*Cr] bf16.
- *      `part` is scratch of sehip_cbn_scratch_floats() floats shared by stats / bwd_reduce and their finalize. */
+ *      `part` is scratch of sehip_cbn_scratch_floats() floats shared by stats / bwd_reduce and their finalize.
+ *      eps < 0 (every entry point that takes eps) selects the REAL nn.BatchNorm2d of DCCRN(use_cbn=False) (src/model/dccrn.py:110-113,
+ *      :130-133) with |eps|: the real and the imaginary half of a complex channel are normalised independently -- the same record with
+ *      the cross covariance taken as zero; pass the layer's weight halves as (Wrr, Wii), a row of Cr zeros as Wri, its bias halves as
+ *      (Br, Bi), its running_mean / running_var halves as (RMr, RMi) / (RVrr, RVii) (running_var receives the UNBIASED batch
+ *      variance, as nn.BatchNorm2d keeps it) and any Cr floats as RVri.  The forward record tells the backward entry points which
+ *      kind the layer is: they need no flag (gWri receives zeros). */
 long sehip_cbn_scratch_floats(long rows, int Cr);
 int sehip_cbn_stats(const void* y, long rows, int Cr, float* part, void* stream);
 int sehip_cbn_finalize(const float* part, const float* Wrr, const float* Wri, const float* Wii, const float* Br,

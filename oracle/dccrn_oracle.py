@@ -43,8 +43,9 @@ class DCCRNConfig:
 
     def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512,
                  length=16384, masking_mode="E", kernel_size=5,
-                 kernel_num=DEFAULT_KERNEL_NUM, win_type="hann", **_ignored):
+                 kernel_num=DEFAULT_KERNEL_NUM, win_type="hann", use_cbn=True, **_ignored):
         self.win_type = win_type
+        self.use_cbn = bool(use_cbn)
         self.rnn_layers = rnn_layers
         self.rnn_units = rnn_units
         self.win_len = win_len
@@ -237,6 +238,28 @@ def complex_batchnorm(x, p, prefix, training, eps=1e-5, momentum=0.1, stats_out=
     return torch.cat([yr, yi], 1)
 
 
+def real_batchnorm(x, p, prefix, training, eps=1e-5, momentum=0.1, stats_out=None):
+    """use_cbn=False (src/model/dccrn.py:110-113, :130-133): nn.BatchNorm2d over the [real half | imaginary half] channels.  Training mode
+    normalises with the BIASED batch variance and reports (when ``stats_out`` is a dict) the running statistics nn.BatchNorm2d would
+    hold afterwards -- mean by lerp, variance by lerp towards the UNBIASED batch variance -- without mutating ``p``."""
+    dims = [0, 2, 3]
+    shape = [1, -1, 1, 1]
+    if training:
+        m = x.mean(dims)
+        c = x - m.view(shape)
+        v = (c * c).mean(dims)
+        if stats_out is not None:
+            n = x.numel() // x.shape[1]
+            old_m, old_v = p[prefix + "running_mean"], p[prefix + "running_var"]
+            stats_out[prefix + "running_mean"] = old_m + momentum * (m.detach() - old_m)
+            stats_out[prefix + "running_var"] = old_v + momentum * (v.detach() * (n / max(n - 1, 1)) - old_v)
+            stats_out[prefix + "num_batches_tracked"] = p[prefix + "num_batches_tracked"] + 1
+    else:
+        m, v = p[prefix + "running_mean"], p[prefix + "running_var"]
+        c = x - m.view(shape)
+    return c * (p[prefix + "weight"] / (v + eps).sqrt()).view(shape) + p[prefix + "bias"].view(shape)
+
+
 def lstm_single(x, w_ih, w_hh, b_ih, b_hh, sim=NoSim):
     """One-layer unidirectional nn.LSTM with zero initial state; x [T,B,I] -> [T,B,H].
 
@@ -306,7 +329,7 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
                              sim.weight(p[pre + "0.imag_conv.weight"]), p[pre + "0.imag_conv.bias"])
         out = sim.act(out)
         cap[f"enc{i}.conv"] = out
-        out = complex_batchnorm(out, p, pre + "1.", training, stats_out=stats_out)
+        out = (complex_batchnorm if cfg.use_cbn else real_batchnorm)(out, p, pre + "1.", training, stats_out=stats_out)
         out = sim.act(F.prelu(out, p[pre + "2.weight"]))
         cap[f"enc{i}"] = out
         skips.append(out)
@@ -334,7 +357,7 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
         if i != cfg.n_layers - 1:
             out = sim.act(out)
             cap[f"dec{i}.conv"] = out[..., 1:]
-            out = complex_batchnorm(out, p, pre + "1.", training, stats_out=stats_out)
+            out = (complex_batchnorm if cfg.use_cbn else real_batchnorm)(out, p, pre + "1.", training, stats_out=stats_out)
             out = sim.act(F.prelu(out, p[pre + "2.weight"]))
         out = out[..., 1:]  # drop the first frame (src/model/dccrn.py:196)
         cap[f"dec{i}"] = out
@@ -396,6 +419,14 @@ def init_params(cfg: DCCRNConfig, seed=0) -> "OrderedDict[str, torch.Tensor]":
             p[f"{pre}0.{part}.bias"] = torch.zeros(nb)
 
     def bn_block(pre, n):
+        if not cfg.use_cbn:          # nn.BatchNorm2d(2 n): weight 1, bias 0, running (0, 1)
+            p[pre + "1.weight"] = torch.ones(2 * n)
+            p[pre + "1.bias"] = torch.zeros(2 * n)
+            p[pre + "1.running_mean"] = torch.zeros(2 * n)
+            p[pre + "1.running_var"] = torch.ones(2 * n)
+            p[pre + "1.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+            p[pre + "2.weight"] = torch.full((1,), 0.25)
+            return
         p[pre + "1.Wrr"] = torch.ones(n)
         p[pre + "1.Wri"] = torch.rand(n, generator=g) * 1.8 - 0.9
         p[pre + "1.Wii"] = torch.ones(n)
@@ -443,14 +474,14 @@ def perturb_params(p, seed=5):
     for k in p:
         if k.endswith(".bias") or k.endswith((".Br", ".Bi")):
             p[k] = 0.1 * torch.randn(p[k].shape, generator=g)
-        if k.endswith((".Wrr", ".Wii")):
+        if k.endswith((".Wrr", ".Wii")) or (k.endswith(".1.weight") and k.startswith(("encoder.", "decoder."))):
             p[k] = 1.0 + 0.2 * torch.randn(p[k].shape, generator=g)
         if k.endswith("2.weight"):
             p[k] = 0.25 + 0.1 * torch.randn(p[k].shape, generator=g)
     return p
 
 
-BUFFER_SUFFIXES = ("RMr", "RMi", "RVrr", "RVri", "RVii", "num_batches_tracked")
+BUFFER_SUFFIXES = ("RMr", "RMi", "RVrr", "RVri", "RVii", "num_batches_tracked", "running_mean", "running_var")
 
 
 def is_trainable(name: str) -> bool:

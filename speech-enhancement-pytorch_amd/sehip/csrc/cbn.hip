@@ -146,9 +146,15 @@ __global__ __launch_bounds__(256) void cbn_stats_kernel(const bf16_raw* __restri
     block_partials<5, CH>(s, nq, Cr, part, 5 * Cr, lds);
 }
 
-// the forward coefficient record of one channel from its moments (covariance WITHOUT eps) and affine parameters
+// the forward coefficient record of one channel from its moments (covariance WITHOUT eps) and affine parameters.
+// eps < 0 selects the REAL BatchNorm2d of DCCRN(use_cbn=False) (src/model/dccrn.py:110-113, :130-133: nn.BatchNorm2d over the
+// [real half | imaginary half] channels) with |eps|: the two halves of a complex channel are normalised independently -- exactly this
+// record with the cross covariance taken as zero (then U = diag(Vrr + eps, Vii + eps)^(-1/2)), weights (Wrr, 0, Wii) = the layer's
+// weight halves and biases (Br, Bi) = its bias halves.  Field 14 tells the backward pass (cbn_bwd_record) which kind it is.
 __device__ __forceinline__ void cbn_fwd_record(float mr, float mi, float vrr, float vri, float vii, float eps, float wrr, float wri,
-                                               float wii, float br_, float bi_, float (&o)[14]) {
+                                               float wii, float br_, float bi_, float (&o)[15]) {
+    const bool real = eps < 0.f;
+    if (real) { eps = -eps; vri = 0.f; wri = 0.f; }
     vrr += eps; vii += eps;
     const float tau = vrr + vii;
     const float delta = vrr * vii - vri * vri;
@@ -162,7 +168,10 @@ __device__ __forceinline__ void cbn_fwd_record(float mr, float mi, float vrr, fl
     o[3] = wri * uri + wii * uii;
     o[4] = mr; o[5] = mi; o[6] = br_; o[7] = bi_;
     o[8] = urr; o[9] = uri; o[10] = uii; o[11] = vrr; o[12] = vri; o[13] = vii;
+    o[14] = real ? 1.f : 0.f;
 }
+// running-variance factor: nn.BatchNorm2d keeps the UNBIASED batch variance (n / (n - 1)), the reference's ComplexBatchNorm the biased one
+__device__ __forceinline__ float cbn_unbias(float eps, long rows) { return eps < 0.f && rows > 1 ? (float)((double)rows / (double)(rows - 1)) : 1.f; }
 
 // one wave per complex channel
 __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ Wrr, const float* __restrict__ Wri,
@@ -188,19 +197,20 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ part, int nblk, co
         vii = (float)(a4 / n - dmi * dmi);
         RMr[c] = rmr + momentum * (mr - rmr);
         RMi[c] = rmi + momentum * (mi - rmi);
-        RVrr[c] = rvrr + momentum * (vrr - rvrr);
+        const float unb = cbn_unbias(eps, rows);
+        RVrr[c] = rvrr + momentum * (vrr * unb - rvrr);
         RVri[c] = rvri + momentum * (vri - rvri);
-        RVii[c] = rvii + momentum * (vii - rvii);
+        RVii[c] = rvii + momentum * (vii * unb - rvii);
         if (c == 0 && nbt) nbt[0] += 1;
     } else {
         if (threadIdx.x != 0) return;
         mr = rmr; mi = rmi; vrr = rvrr; vri = rvri; vii = rvii;
     }
-    float rec[14];
+    float rec[15];
     cbn_fwd_record(mr, mi, vrr, vri, vii, eps, wrr, wri, wii, br_, bi_, rec);
     float* o = coef + (size_t)c * COEF_STRIDE;
 #pragma unroll
-    for (int i = 0; i < 14; ++i) o[i] = rec[i];
+    for (int i = 0; i < 15; ++i) o[i] = rec[i];
 }
 
 // The per-channel coefficient records reach the threads through LDS: every thread needs the records of its CH complex
@@ -306,15 +316,16 @@ __global__ __launch_bounds__(256, 2) void cbn_apply_fin_kernel(const bf16_raw* _
             vri = (float)(a[3] / n - dmr * dmi);
             vii = (float)(a[4] / n - dmi * dmi);
             if (blockIdx.x == 0) {
+                const float unb = cbn_unbias(eps, rows);
                 RMr[c] = rmr + momentum * (mr - rmr);
                 RMi[c] = rmi + momentum * (mi - rmi);
-                RVrr[c] = rvrr + momentum * (vrr - rvrr);
+                RVrr[c] = rvrr + momentum * (vrr * unb - rvrr);
                 RVri[c] = rvri + momentum * (vri - rvri);
-                RVii[c] = rvii + momentum * (vii - rvii);
+                RVii[c] = rvii + momentum * (vii * unb - rvii);
                 if (c == 0 && nbt) nbt[0] += 1;
             }
         }
-        float rec[14];
+        float rec[15];
         cbn_fwd_record(mr, mi, vrr, vri, vii, eps, wrr, wri, wii, br_, bi_, rec);
         const int slot = (c % CH) * nq + (c / CH);               // the layout stage_coef gives the streaming loop
         cl[slot] = make_float4(rec[0], rec[1], rec[2], rec[3]);
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void cbn_apply_fin_kernel(const bf16_raw* _
         if (blockIdx.x == 0) {
             float* o = coef + (size_t)c * COEF_STRIDE;
 #pragma unroll
-            for (int i = 0; i < 14; ++i) o[i] = rec[i];
+            for (int i = 0; i < 15; ++i) o[i] = rec[i];
         }
     }
     __syncthreads();
@@ -399,7 +410,7 @@ struct CbnFin {
 };
 __device__ __forceinline__ void cbn_bwd_record(float sdr, float sdi, float qrr, float qri, float qir, float qii, float urr, float uri,
                                                float uii, float vrr, float vri, float vii, float wrr, float wri, float wii, float n,
-                                               float (&g5)[5], float (&o)[9]);
+                                               float (&g5)[5], float (&o)[9], float real = 0.f);
 
 template <int U, int CH, bool HAS2>
 __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* __restrict__ dz, const bf16_raw* __restrict__ dz2,
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* 
         }
         float g5[5], rec[9];
         cbn_bwd_record((float)a6[0], (float)a6[1], (float)a6[2], (float)a6[3], (float)a6[4], (float)a6[5], urr, uri, uii, vrr, vri, vii,
-                       wrr, wri, wii, (float)rows, g5, rec);
+                       wrr, wri, wii, (float)rows, g5, rec, k[14]);
         fin.gWrr[c] = g5[0]; fin.gWri[c] = g5[1]; fin.gWii[c] = g5[2]; fin.gBr[c] = g5[3]; fin.gBi[c] = g5[4];
         float* o = fin.bcoef + (size_t)c * COEF_STRIDE;
 #pragma unroll
@@ -527,9 +538,12 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_reduce_kernel(const bf16_raw* 
 }
 
 // parameter gradients (g5: dWrr dWri dWii dBr dBi) and the apply pass's record of one channel from its six sums
+// real != 0 (field 14 of the forward record): the REAL BatchNorm2d of DCCRN(use_cbn=False) -- the cross covariance is not part of the
+// computation (no gradient flows through it: o[5] = 0), the cross weight does not exist (its gradient slot receives 0)
 __device__ __forceinline__ void cbn_bwd_record(float sdr, float sdi, float qrr, float qri, float qir, float qii, float urr, float uri,
                                                float uii, float vrr, float vri, float vii, float wrr, float wri, float wii, float n,
-                                               float (&g5)[5], float (&o)[9]) {
+                                               float (&g5)[5], float (&o)[9], float real) {
+    if (real != 0.f) wri = 0.f;
     // P = Q U  (sum d xh^T)
     const float prr = qrr * urr + qri * uri, pri = qrr * uri + qri * uii;
     const float pir = qir * urr + qii * uri, pii = qir * uri + qii * uii;
@@ -562,6 +576,7 @@ __device__ __forceinline__ void cbn_bwd_record(float sdr, float sdi, float qrr, 
     o[4] = 2.f * d_vrr / n; o[5] = d_vri / n; o[6] = 2.f * d_vii / n;
     o[7] = -(arr * sdr + ari * sdi) / n;
     o[8] = -(air * sdr + aii * sdi) / n;
+    if (real != 0.f) { o[5] = 0.f; g5[1] = 0.f; }
 }
 
 // one wave per channel: parameter gradients + coefficients of the apply pass
@@ -588,7 +603,7 @@ __global__ void cbn_bwd_finalize_kernel(const float* __restrict__ part, int nblk
     const float sdr = (float)a[0], sdi = (float)a[1], qrr = (float)a[2], qri = (float)a[3], qir = (float)a[4], qii = (float)a[5];
     if (threadIdx.x != 0) return;
     float g5[5], rec[9];
-    cbn_bwd_record(sdr, sdi, qrr, qri, qir, qii, urr, uri, uii, vrr, vri, vii, wrr, wri, wii, (float)rows, g5, rec);
+    cbn_bwd_record(sdr, sdi, qrr, qri, qir, qii, urr, uri, uii, vrr, vri, vii, wrr, wri, wii, (float)rows, g5, rec, k[14]);
     gWrr[c] = g5[0]; gWri[c] = g5[1]; gWii[c] = g5[2]; gBr[c] = g5[3]; gBi[c] = g5[4];
     float* o = bcoef + (size_t)c * COEF_STRIDE;
 #pragma unroll
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void cbn_bwd_apply_fin_kernel(const bf16_ra
         }
         float g5[5], rec[9];
         cbn_bwd_record((float)a6[0], (float)a6[1], (float)a6[2], (float)a6[3], (float)a6[4], (float)a6[5], urr, uri, uii, vrr, vri, vii,
-                       wrr, wri, wii, (float)rows, g5, rec);
+                       wrr, wri, wii, (float)rows, g5, rec, k[14]);
         const int slot = (c % CH) * nq + (c / CH);
         cl[2 * Cr + slot] = make_float4(rec[0], rec[1], rec[2], rec[3]);
         cl[3 * Cr + slot] = make_float4(rec[4], rec[5], rec[6], rec[7]);

@@ -22,7 +22,7 @@ _STATIC_CACHE = {}
 def _static_for(cfg, deterministic=False):
     # (the experiment switches that DCCRNStatic reads when it is built are part of the key)
     switches = tuple(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_STATS64", "SEHIP_NO_FUSE_STATS32", "SEHIP_DEC_SPLIT"))
-    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, str(cfg.win_type), switches,
+    key = (tuple(cfg.kernel_num), cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, str(cfg.win_type), bool(cfg.use_cbn), switches,
            bool(deterministic))
     if key not in _STATIC_CACHE:
         _STATIC_CACHE[key] = plan.DCCRNStatic(cfg, deterministic=deterministic)
@@ -90,9 +90,9 @@ class DCCRN(FlatModule):
                 leaf = name.split(".")[-1]
                 if "conv.weight" in name:
                     p.normal_(0.0, 0.05)
-                elif "conv.bias" in name or leaf in ("Br", "Bi"):
+                elif "conv.bias" in name or leaf in ("Br", "Bi") or name.endswith(".1.bias"):
                     p.zero_()
-                elif leaf in ("Wrr", "Wii"):
+                elif leaf in ("Wrr", "Wii") or name.endswith(".1.weight"):        # (".1.weight": nn.BatchNorm2d of use_cbn=False)
                     p.fill_(1.0)
                 elif leaf == "Wri":
                     p.uniform_(-0.9, 0.9)
@@ -105,7 +105,7 @@ class DCCRN(FlatModule):
                 else:
                     raise KeyError(name)
             for name, node, leaf in self._buffers_named:
-                getattr(node, leaf).fill_(1.0 if leaf in ("RVrr", "RVii") else 0.0)
+                getattr(node, leaf).fill_(1.0 if leaf in ("RVrr", "RVii", "running_var") else 0.0)
             self._nbt.zero_()
 
     # ---- HIP path -------------------------------------------------------------------------------------

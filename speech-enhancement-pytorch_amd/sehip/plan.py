@@ -93,8 +93,11 @@ class DCCRNConfig:
     def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512, length=16384,
                  win_type="hann", masking_mode="E", use_clstm=True, use_cbn=True, kernel_size=5,
                  kernel_num=(16, 32, 64, 128, 256, 256), **_ignored):
-        if not use_clstm or not use_cbn:
-            raise SehipError("sehip DCCRN implements the reference defaults use_clstm=True, use_cbn=True only")
+        if not use_clstm:
+            raise SehipError("sehip DCCRN implements the reference default use_clstm=True only")
+        # use_cbn=False (round 6): nn.BatchNorm2d over the [real half | imaginary half] channels (src/model/dccrn.py:110-113, :130-133) on
+        # the ComplexBatchNorm kernels with the cross covariance taken as zero (csrc/cbn.hip cbn_fwd_record: eps < 0 selects it)
+        self.use_cbn = bool(use_cbn)
         # (the window is data for the FFT front end: ones for None / 'None', any scipy.signal.get_window name otherwise --
         #  src/model/dccrn.py:650-653; checked here so that a bad name fails at construction)
         ops.window_of(win_type, win_len)
@@ -133,6 +136,14 @@ class DCCRNConfig:
                 out.append((f"{pre}0.{part}.bias", (nb,), "param"))
 
         def bn(pre, n):
+            if not self.use_cbn:      # nn.BatchNorm2d(2 n): weight, bias | running_mean, running_var, num_batches_tracked
+                out.append((f"{pre}1.weight", (2 * n,), "param"))
+                out.append((f"{pre}1.bias", (2 * n,), "param"))
+                out.append((f"{pre}1.running_mean", (2 * n,), "buffer"))
+                out.append((f"{pre}1.running_var", (2 * n,), "buffer"))
+                out.append((f"{pre}1.num_batches_tracked", (), "nbt"))
+                out.append((f"{pre}2.weight", (1,), "param"))
+                return
             for k in ("Wrr", "Wri", "Wii", "Br", "Bi"):
                 out.append((f"{pre}1.{k}", (n,), "param"))
             for k in ("RMr", "RMi", "RVrr", "RVri", "RVii"):
@@ -190,6 +201,19 @@ class ParamLayout:
         # tensor boundaries for the reference's per-tensor grad_norm metric (src/solver.py:494-498)
         offs = [self.param_off[n][0] for n in self.param_names] + [po]
         self.tensor_offsets = np.asarray(offs, dtype=np.int64)
+
+    # ComplexBatchNorm field -> (tensor, element offset inside it); None = the field does not exist (real BatchNorm2d: no cross terms)
+    _REAL_BN = {"1.Wrr": ("1.weight", 0), "1.Wii": ("1.weight", 1), "1.Br": ("1.bias", 0), "1.Bi": ("1.bias", 1), "1.Wri": None,
+                "1.RMr": ("1.running_mean", 0), "1.RMi": ("1.running_mean", 1), "1.RVrr": ("1.running_var", 0),
+                "1.RVii": ("1.running_var", 1), "1.RVri": None}
+
+    def bn_field(self, pre, k, cr):
+        """(name, element offset) of ComplexBatchNorm field k ("1.Wrr", "1.RMr", ...) of layer `pre`, or None.  With use_cbn=False the
+        layer is an nn.BatchNorm2d over 2 cr channels: its weight / bias / running statistics are the real and imaginary halves."""
+        if getattr(self.cfg, "use_cbn", True) or k not in self._REAL_BN:
+            return pre + k, 0
+        m = self._REAL_BN[k]
+        return None if m is None else (pre + m[0], m[1] * cr)
 
     def index_array(self, name):
         off, shape = self.param_off[name]
@@ -748,7 +772,10 @@ class DCCRNStatic:
                     gs.append(s.db_off + np.flatnonzero(mm))
         for pre, cr in self.bn:
             for k in ("Wrr", "Wri", "Wii", "Br", "Bi"):
-                ps.append(L.index_array(pre + "1." + k)); ns.append(np.zeros(cr, np.int64))
+                f = L.bn_field(pre, "1." + k, cr)
+                if f is None:         # (real BatchNorm2d: the cross weight does not exist; its slot of the packed gradients stays unread)
+                    continue
+                ps.append(L.index_array(f[0]).reshape(-1)[f[1]:f[1] + cr]); ns.append(np.zeros(cr, np.int64))
                 gs.append(self.bn_g_off[pre][k] + np.arange(cr))
             ps.append(L.index_array(pre + "2.weight")); ns.append(np.zeros(1, np.int64))
             gs.append(np.asarray([self.bn_g_off[pre]["slope"]]))
@@ -913,6 +940,11 @@ class DCCRNWorkspace:
         self._brep_turn = {pre: 0 for pre, _ in st.bn}
         self.bn_stats = {pre: self.bn_stats_all[o:o + 8 * 5 * cr] for (pre, cr) in st.bn if pre in offs for o in [offs[pre]]}
         self.bn_bcoef = torch.zeros(maxcr, 16, dtype=torch.float32, device=device)
+        # use_cbn=False: the kernels' eps < 0 convention (csrc/cbn.hip), a zero row for the cross weight, a sink for the cross variance
+        self.bn_eps = 1e-5 if cfg.use_cbn else -1e-5
+        self.bn_zero = torch.zeros(maxcr, dtype=torch.float32, device=device)
+        self.bn_dummy = torch.zeros(maxcr, dtype=torch.float32, device=device)
+        self._bn_cr = {pre: cr for pre, cr in st.bn}
         self.mode = {"E": 0, "C": 1, "R": 2}[cfg.masking_mode]
         # the weight-gradient stream.  SEHIP_SIDE_PRIORITY=1: created through the C ABI with the device's lowest priority
         self.side, self._side_handle = None, None
@@ -1291,8 +1323,15 @@ class DCCRNWorkspace:
     # ---- BatchNorm helpers ---------------------------------------------------------------------
     def _bn_ptrs(self, pre, params, buffers, nbt):
         L = self.st.layout
-        pp = lambda k: params.data_ptr() + 4 * L.param_off[pre + k][0]
-        bp = lambda k: buffers.data_ptr() + 4 * L.buffer_off[pre + k][0]
+        cr = self._bn_cr[pre]
+
+        def pp(k):
+            f = L.bn_field(pre, k, cr)
+            return ptr(self.bn_zero) if f is None else params.data_ptr() + 4 * (L.param_off[f[0]][0] + f[1])
+
+        def bp(k):
+            f = L.bn_field(pre, k, cr)
+            return ptr(self.bn_dummy) if f is None else buffers.data_ptr() + 4 * (L.buffer_off[f[0]][0] + f[1])
         return pp, bp, nbt.data_ptr() + 8 * L.nbt_idx[pre + "1.num_batches_tracked"]
 
     def bn_forward(self, pre, cr, y, z, params, buffers, nbt, training):
@@ -1302,25 +1341,28 @@ class DCCRNWorkspace:
         if pre in self.st.fused_stats or pre in self.fused_small:     # the producing convolution accumulated the sums (8 replicas)
             if self.fuse_finalize:          # ... and the apply pass derives the coefficients itself: one launch
                 call("sehip_cbn_finalize_apply_n", y.ptr, ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"),
-                     pp("1.Bi"), bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
+                     pp("1.Bi"), bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, self.bn_eps, 0.1,
                      1 if training else 0, ptr(coef), pp("2.weight"), z.ptr, stream())
                 return
             call("sehip_cbn_finalize_n", ptr(self.bn_stats[pre]), 8, pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
-                 bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
+                 bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, self.bn_eps, 0.1,
                  1 if training else 0, ptr(coef), stream())
             call("sehip_cbn_apply", y.ptr, ptr(coef), pp("2.weight"), rows, cr, z.ptr, stream())
             return
         if training:
             call("sehip_cbn_stats", y.ptr, rows, cr, ptr(self.bn_acc), stream())
         call("sehip_cbn_finalize", ptr(self.bn_acc), pp("1.Wrr"), pp("1.Wri"), pp("1.Wii"), pp("1.Br"), pp("1.Bi"),
-             bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, 1e-5, 0.1,
+             bp("1.RMr"), bp("1.RMi"), bp("1.RVrr"), bp("1.RVri"), bp("1.RVii"), nb, rows, cr, self.bn_eps, 0.1,
              1 if training else 0, ptr(coef), stream())
         call("sehip_cbn_apply", y.ptr, ptr(coef), pp("2.weight"), rows, cr, z.ptr, stream())
 
     def bn_backward(self, pre, cr, dz, dz2, y, dy, params, tfirst, apply=True):
         rows = y.t.numel() // (2 * cr)
         L, st = self.st.layout, self.st
-        pp = lambda k: params.data_ptr() + 4 * L.param_off[pre + k][0]
+
+        def pp(k):
+            f = L.bn_field(pre, k, cr)
+            return ptr(self.bn_zero) if f is None else params.data_ptr() + 4 * (L.param_off[f[0]][0] + f[1])
         g = lambda k: self.gpack.data_ptr() + 4 * st.bn_g_off[pre][k]
         coef = self.bn_coef[pre]
         dz2p = dz2.ptr if dz2 is not None else None

@@ -181,7 +181,7 @@ def test_hip_vs_reference_full_size_checksum():
 
 
 @pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("none", dict(win_type=None)),
-                                        ("blackman", dict(win_type="blackman"))])
+                                        ("blackman", dict(win_type="blackman")), ("realbn", dict(use_cbn=False))])
 def test_hip_window_types_against_reference_vectors(case, extra):
     """win_type of the reference constructor (src/model/dccrn.py:20; init_kernels :650-653: ones for None, else
     scipy.signal.get_window) on the HIP path -- the window is data for the FFT front end -- against what the imported reference
@@ -198,6 +198,14 @@ def test_hip_window_types_against_reference_vectors(case, extra):
     print(f"{case}: waveform rel {rel_err(est, g['est']):.3e} dloss {abs(loss - float(g['loss'])):.4f} global grad rel {(num / den) ** 0.5:.3e}")
     assert rel_err(est, g["est"]) < 3e-2 and abs(loss - float(g["loss"])) < 0.1
     assert (num / den) ** 0.5 < 5e-2
+    # (realbn = use_cbn=False, src/model/dccrn.py:110-113: nn.BatchNorm2d on the ComplexBatchNorm kernels with the cross covariance taken
+    #  as zero; its running statistics -- running_var is the lerp towards the UNBIASED batch variance -- against the reference's)
+    sd = model.state_dict()
+    for k, v in sub(g, "state_after").items():
+        if k.endswith(("running_mean", "running_var", "RVrr", "RVii")):
+            assert rel_err(sd[k].cpu().float(), v.float()) < 2e-2, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v), k
     model.eval()
     with torch.no_grad():
         assert rel_err(model(noisy.cuda()).cpu(), g["est_eval"]) < 3e-2

@@ -327,13 +327,14 @@ def test_demucs_resampler_properties():
 
 # ---- constructor options beyond the shipped YAML (round 6): tests/golden/dccrn_variants.npz (oracle/gen_golden_dccrn_variants.py)
 @pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("none", dict(win_type=None)),
-                                        ("blackman", dict(win_type="blackman"))])
+                                        ("blackman", dict(win_type="blackman")), ("realbn", dict(use_cbn=False))])
 def test_window_types_against_reference(case, extra):
-    """win_type of the reference constructor (src/model/dccrn.py:20, init_kernels :650-653): the oracle with that window against the
-    imported reference's waveform, loss, gradients and eval-mode waveform."""
+    """Constructor options of the reference beyond the shipped YAML (src/model/dccrn.py:12-27): win_type (init_kernels :650-653) and
+    use_cbn=False (nn.BatchNorm2d instead of ComplexBatchNorm, :110-113): the oracle against the imported reference's waveform, loss,
+    gradients, eval-mode waveform and running statistics."""
     g = {k[len(case) + 1:]: v for k, v in load_golden("dccrn_variants.npz").items() if k.startswith(case + "/")}
     kw = dict(LEGAL, **extra)
-    assert np.allclose(O.window_of(extra["win_type"], 400), g["window"], atol=1e-7)
+    assert np.allclose(O.window_of(extra.get("win_type", "hann"), 400), g["window"], atol=1e-7)
     cfg, p, noisy, est, loss, grads, stats = _oracle_fwd_bwd(kw, 31, 32, 33, 2, 4000)
     assert rel_err(est, g["est"]) < 5e-5 and abs(loss - float(g["loss"])) < 2e-4
     full, norms = golden_grads(g)
@@ -346,5 +347,7 @@ def test_window_types_against_reference(case, extra):
             assert float(gr.norm()) < 1e-4 and norms[k] < 1e-4, (k, float(gr.norm()), norms[k])
             continue
         assert float((gr - full[k]).norm()) < tol, (k, float((gr - full[k]).norm()), norms[k])
+    for k, v in sub(g, "state_after").items():           # running statistics after the step (running_var: unbiased for nn.BatchNorm2d)
+        assert rel_err(stats[k].float(), v.float()) < 1e-5, k
     q = dict(p); q.update({k: v for k, v in stats.items()})
     assert rel_err(O.dccrn_forward(q, noisy, cfg, training=False), g["est_eval"]) < 5e-5
