@@ -42,19 +42,39 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__
         re[r] = v; im[r] = 0.f;
     }
     fft512_wave<-1>(re, im, tw, lane);
+    // Round 6: the frame leaves through a wave-private LDS row.  The FFT leaves lane l with bins 8 brev6(l) .. + 7: stored from there,
+    // every store instruction touched 33 different 64-byte segments with 8 (4) bytes each -- 16 instructions per frame, 34 us for the
+    // 32 MB of a headline batch (0.9 TB/s).  From the row, lane i stores bin i + 64 j (512 contiguous bytes per instruction) and the
+    // i-th 16-byte piece of the encoder input (1 KB per instruction): 6 instructions.  (Row index k + (k >> 3): the lanes' 64-byte
+    // strides would otherwise meet in four banks.)
+    __shared__ float2 srow[4][264 + 33];
+    __shared__ unsigned senc[4][256];
+    const int w = threadIdx.x >> 6;
     const int k0 = 8 * brev6(lane);
-    if (k0 > 256) return;
     constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    if (k0 <= 256) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + brev3[j];
+            if (k <= 256) {
+                srow[w][k + (k >> 3)] = make_float2(re[j], im[j]);
+                if (k >= 1) senc[w][k - 1] = pack_bf2(re[j], im[j]);
+            }
+        }
+    }
+    // (the row belongs to this wave alone and a wave's LDS operations complete in order: a compiler-level barrier is enough)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float2* so = spec + (size_t)frame * NBIN;
     unsigned* eo = enc_in + (size_t)frame * 256;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + brev3[j];
-        if (k <= 256) {
-            so[k] = make_float2(re[j], im[j]);
-            if (k >= 1) eo[k - 1] = pack_bf2(re[j], im[j]);
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        so[k] = srow[w][k + (k >> 3)];
     }
+    if (lane == 0) so[256] = srow[w][256 + 32];
+    *reinterpret_cast<uint4*>(eo + 4 * lane) = *reinterpret_cast<const uint4*>(&senc[w][4 * lane]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -100,6 +120,18 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float2* __restr
     s2 = wave_sum(s2);
     const float c = 1.0f / (float)(FFT_N + win);
     float* fo = frames + (size_t)frame * win;
+    if (n0 + 8 <= win && (win & 3) == 0) {             // the lane's eight samples as two 16-byte stores (they were eight 4-byte ones)
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = n0 + q;
+            const float corr = c * (s1 + ((n & 1) ? -s2 : s2));
+            o[q] = window[n] * (1.0f / 256.0f) * (u[q] - corr);
+        }
+        *reinterpret_cast<float4*>(fo + n0) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(fo + n0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int n = n0 + q;
@@ -167,24 +199,49 @@ __global__ __launch_bounds__(256) void istft_bwd_kernel(const float* __restrict_
         const int n = lane + 64 * r;
         if (n < win) re[r] -= c * (s1 + ((n & 1) ? -s2 : s2));
     }
-    fft512_wave<-1>(re, im, tw, lane);
-    const int k0 = 8 * brev6(lane);
-    if (k0 > 256) return;
-    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    // Round 6 (as stft_fwd_kernel): the spectrum and mask rows of the frame are fetched LINEARLY (lane i takes bins i + 64 j: 512
+    // contiguous bytes per instruction, requested before the transform and parked in a wave-private LDS row behind it) and the mask
+    // gradient leaves as one 16-byte piece per lane; from the transform's own layout (lane l holds bins 8 brev6(l) .. + 7) these were
+    // 24 instructions per frame of 33 scattered 8- / 4-byte accesses each (41 us per headline batch).
     const float2* sp = spec + (size_t)frame * NBIN;
     const float2* mk = mask + (size_t)frame * 256;
-    unsigned* dm = dmask_bf16 + (size_t)frame * 256;
+    float2 spv[4], mkv[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + brev3[j];
-        if (k < 1 || k > 256) continue;
-        const float dr = re[j], di = im[j];  // d loss / d est_real[k], d est_imag[k]
-        const float2 z = sp[k];
-        const float2 m = mk[k - 1];
-        float gmr, gmi;
-        mask_grad(mode, z.x, z.y, m.x, m.y, dr, di, gmr, gmi);
-        dm[k - 1] = pack_bf2(gmr, gmi);
+    for (int j = 0; j < 4; ++j) { spv[j] = sp[1 + lane + 64 * j]; mkv[j] = mk[lane + 64 * j]; }      // bins 1 .. 256 (DC carries no mask)
+    fft512_wave<-1>(re, im, tw, lane);
+    __shared__ float2 ssp[4][256 + 32], smk[4][256 + 32];
+    __shared__ unsigned sdm[4][256];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;                   // index k - 1
+        ssp[w][i + (i >> 3)] = spv[j];
+        smk[w][i + (i >> 3)] = mkv[j];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int k0 = 8 * brev6(lane);
+    constexpr int brev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    if (k0 <= 256) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + brev3[j];
+            if (k < 1 || k > 256) continue;
+            const float dr = re[j], di = im[j];  // d loss / d est_real[k], d est_imag[k]
+            const int i = k - 1;
+            const float2 z = ssp[w][i + (i >> 3)];
+            const float2 m = smk[w][i + (i >> 3)];
+            float gmr, gmi;
+            mask_grad(mode, z.x, z.y, m.x, m.y, dr, di, gmr, gmi);
+            sdm[w][i] = pack_bf2(gmr, gmi);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned* dm = dmask_bf16 + (size_t)frame * 256;
+    *reinterpret_cast<uint4*>(dm + 4 * lane) = *reinterpret_cast<const uint4*>(&sdm[w][4 * lane]);
 }
 
 // ------------------------------------------------------------------------------------------------
