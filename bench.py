@@ -39,6 +39,7 @@ def make_batch(b, n, seed, device):
 
 HEADLINE_KERNEL_NUM = [16, 32, 64, 128, 256, 256]
 KERNEL_NUM = list(HEADLINE_KERNEL_NUM)      # --kernel-num replaces it (a side measurement: other widths of the same network)
+RNN_UNITS = [128]                           # --rnn-units replaces it (a side measurement too: 256 = the DCCRN paper's complex LSTM)
 
 
 def bench_config(length):
@@ -46,7 +47,7 @@ def bench_config(length):
     return dict2obj({
         "seed": 10, "root": None, "ha": None,
         "model": {"name": "dccrn", "audio_channels": 1, "num_spk": 1, "length": length,
-                  "kernel_num": list(KERNEL_NUM), "rnn_units": 128, "masking_mode": "E"},
+                  "kernel_num": list(KERNEL_NUM), "rnn_units": RNN_UNITS[0], "masking_mode": "E"},
         "optim": {"optim": "adam", "lr": 3e-4, "beta1": 0.9, "beta2": 0.999, "loss": "si-sdr", "clip_grad": 5, "pit": False,
                   "load": False},
         "dset": {"name": "synthetic"},
@@ -610,6 +611,8 @@ def main():
                     "16,32,64,128,256,256 (e.g. the reference YAML's commented 'paper' widths 32,64,128,256,256,256, "
                     "src/conf/config.yaml:86-88).  A side measurement: implies --no-roofline --no-cpu-baseline --no-traffic, and the "
                     "line's config.workload names the widths")
+    ap.add_argument("--rnn-units", type=int, default=128, help="DCCRN only: 256 = the complex LSTM of the DCCRN paper (hidden 128 per "
+                    "nn.LSTM; one launch per layer and direction).  A side measurement like --kernel-num")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as two captured hipGraphs instead of launching "
@@ -633,6 +636,11 @@ def main():
         KERNEL_NUM[:] = widths
         if widths != HEADLINE_KERNEL_NUM:
             args.no_roofline = args.no_cpu_baseline = args.no_traffic = True
+    if args.rnn_units != 128:
+        if args.workload != "dccrn":
+            sys.exit("--rnn-units: DCCRN only")
+        RNN_UNITS[0] = args.rnn_units
+        args.no_roofline = args.no_cpu_baseline = args.no_traffic = True
     dcu = args.workload == "dcunet"
     ctn = args.workload == "convtasnet"
     dmx = args.workload == "demucs"
@@ -771,7 +779,7 @@ def main():
                                 "SI-SNR, Adam 3e-4, clip 5" if ctn else
                                 "Demucs (channels 64, depth 6, DConv with BLSTM + LocalState from layer 4, x2 resampling; 133.7 M parameters) "
                                 "denoising train step, 48 kHz stereo 2-s clips, SI-SNR, Adam 3e-4, clip 5" if dmx else
-                                f"DCCRN (kernel_num {'-'.join(str(v) for v in KERNEL_NUM)}, complex LSTM 128, mask E) train step, 16 kHz 2-s "
+                                f"DCCRN (kernel_num {'-'.join(str(v) for v in KERNEL_NUM)}, complex LSTM {RNN_UNITS[0]}, mask E) train step, 16 kHz 2-s "
                                 "clips, SI-SNR, Adam 3e-4, clip 5"), "per_gpu_batch": args.batch,
                    "global_batch": args.batch * world, "samples_per_clip": n, "parallelism": f"dp{world}",
                    "launch": "eager" if args.eager else "hipGraph", "inputs": "pinned host -> HBM every step, overlapped with the previous step" if args.h2d_overlap else

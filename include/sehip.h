@@ -530,16 +530,16 @@ int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf
                           int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, float* scratch, void* stream);
 
 /* ---- recurrent part of NavieComplexLSTM: src/model/dccrn.py:264-302 (four nn.LSTM passes of one complex layer in one
- *      persistent launch; hidden size 64).  pre*: [B][T][2 lstm * 256] gates from the input GEMMs (fp32);
- *      h: [4 combos][B][T][64]; combo = part*2 + lstm.  gates / c are records private to the backward kernel, sized
- *      [4][ceil(B/16)*16][T][256] bf16 and [4][ceil(B/16)*16][T][64] fp32. */
+ *      persistent launch; hidden size H = 64 or 128, i.e. rnn_units 128 / 256; the shapes below are written for 64).
+ *      pre*: [B][T][2 lstm * 4 H] gates from the input GEMMs (fp32); h: [4 combos][B][T][H]; combo = part*2 + lstm.  gates / c are
+ *      records private to the backward kernel, sized [4][ceil(B/4)*4][T][4 H] bf16 and [4][ceil(B/4)*4][T][H] fp32. */
 int sehip_lstm_fwd(const float* pre_r, const float* pre_i, const void* whh_bf16 /*[2][256][64]*/, int B, int T, int hidden,
                    void* h_bf16, void* gates_bf16, float* c, void* stream);
 int sehip_lstm_bwd(const void* dh_a_bf16, const void* dh_b_bf16, const void* whhT_bf16 /*[2][64][256]*/,
                    const void* gates_bf16, const float* c, int B, int T, int hidden, void* dpre_r_bf16, void* dpre_i_bf16,
                    void* stream);
 /* the same recurrences over the step range [t0, t1) only: a forward chunk resumes from the h / c records of the steps before
- * t0, a backward chunk from `state` (ceil(B/4) * 2048 floats, written by the chunk that ran [t1, ...)).  sehip/plan.py
+ * t0, a backward chunk from `state` (ceil(B/4) * 32 H floats, written by the chunk that ran [t1, ...)).  sehip/plan.py
  * pipelines the two stacked layers chunk by chunk on two streams. */
 int sehip_lstm_fwd_chunk(const float* pre_r, const float* pre_i, const void* whh_bf16, int B, int T, int hidden, int t0, int t1,
                          void* h_bf16, void* gates_bf16, float* c, void* stream);

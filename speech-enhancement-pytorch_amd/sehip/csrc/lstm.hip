@@ -13,10 +13,9 @@
 // h[t] goes back through a double-buffered LDS tile: one barrier per step.  Latency-bound by construction (hidden 64).
 #include "common.h"
 
-#define H 64
-#define G4 256
-#define HP 72    // LDS pitch of the h tile (bf16 elements)
-#define DGP 264  // LDS pitch of the dgate tile
+// The kernels are written for a hidden size H that is a multiple of 32 (H / 16 waves of 64 lanes, 4 H threads: one (unit, batch row)
+// pair per lane); instantiated for 64 (rnn_units = 128, the reference default, src/model/dccrn.py:13) and 128 (rnn_units = 256, the
+// DCCRN paper's complex LSTM).
 #define NBT 4    // batch rows per workgroup
 #define PD 8     // prefetch distance of the per-step inputs in time steps (2: 4.74 ms per step, 4: 4.68, 8: 4.63, 16: 4.65)
 
@@ -39,10 +38,12 @@ __device__ __forceinline__ float quad_pick(const f32x4& a, int rs) {
 
 // Steps [t0, t1) of the sequence.  A chunk that does not start at 0 resumes from the h / c records the previous chunk wrote
 // (the two stacked layers are pipelined chunk by chunk on two streams, sehip/plan.py).
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ pre0, const float* __restrict__ pre1,
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(const float* __restrict__ pre0, const float* __restrict__ pre1,
                                                        const bf16_raw* __restrict__ whh, int B, int T, int t0, int t1,
                                                        bf16_raw* __restrict__ hout, bf16_raw* __restrict__ gates,
                                                        float* __restrict__ cout) {
+    constexpr int G4 = 4 * H, NT = 4 * H, HP = H + 8, KS = H / 32;     // gates per LSTM, threads, LDS pitch of the h tile, k-steps
     __shared__ __attribute__((aligned(16))) bf16_raw hbuf[2][NBT * HP];
     const int combo = blockIdx.x & 3, tile = blockIdx.x >> 2;
     const int part = combo >> 1, lstm = combo & 1;
@@ -58,16 +59,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     const int ntiles = gridDim.x >> 2;
     const size_t rbase = (size_t)(combo * ntiles + tile) * T;  // records private to the backward kernel: [combo][tile][t][thread]
 
-    // W_hh fragments: gate g, k-step s: rows g*64 + 16w + (lane&15), cols 32 s + 8 (lane>>4) ..
-    bf16x8 wf[4][2];
+    // W_hh fragments: gate g, k-step s: rows g*H + 16w + (lane&15), cols 32 s + 8 (lane>>4) ..
+    bf16x8 wf[4][KS];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
             wf[g][s] = __builtin_bit_cast(
                 bf16x8, *reinterpret_cast<const uint4*>(whh + ((size_t)lstm * G4 + g * H + 16 * w + m) * H + 32 * s + 8 * ug));
 
-    for (int i = threadIdx.x; i < NBT * HP; i += 256) hbuf[0][i] = 0;
+    for (int i = threadIdx.x; i < NBT * HP; i += NT) hbuf[0][i] = 0;
     float c = 0.f;
     // The pre-gates of step t + PD are requested while step t runs (PD rotating register sets, the loop is unrolled by PD so
     // that they stay in registers): one step of dependent work (0.4 us) does not cover a memory round trip, and beside the
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     __syncthreads();
     if (t0 > 0) {  // resume: h(t0-1) from the output, c(t0-1) from the cell-state record
         hbuf[0][bl * HP + unit] = hout[(obase + t0 - 1) * H + unit];
-        c = cout[(rbase + t0 - 1) * 256 + threadIdx.x];
+        c = cout[(rbase + t0 - 1) * NT + threadIdx.x];
         __syncthreads();
     }
     int cur = 0;
@@ -92,15 +93,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int g = 0; g < 4; ++g) pq[g] = pre[(size_t)(t + PD) * (2 * G4) + g * H];
         }
-        bf16x8 hf[2];
+        bf16x8 hf[KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
             hf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&hbuf[cur][bl * HP + 32 * s + 8 * ug]));
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][0], hf[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][1], hf[1], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][s], hf[s], acc[g], 0, 0, 0);
         }
         const float gi = sigmoidf_(quad_pick(acc[0], rs) + p0);
         const float gf = sigmoidf_(quad_pick(acc[1], rs) + p1);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         const bf16_raw hb = f2bf(go * tanhf_(c));
         hbuf[cur ^ 1][bl * HP + unit] = hb;
         if (bvalid) hout[(obase + t) * H + unit] = hb;
-        const size_t rec = (rbase + t) * 256 + threadIdx.x;   // one contiguous 1 KB / 2 KB run per workgroup and step
+        const size_t rec = (rbase + t) * NT + threadIdx.x;    // one contiguous 1 KB / 2 KB run per workgroup and step (H = 64)
         cout[rec] = c;
         *reinterpret_cast<uint2*>(gates + rec * 4) = make_uint2(pack_bf2(gi, gf), pack_bf2(gg, go));
         lds_barrier();
@@ -126,11 +128,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 // Backward through time.  dh_a / dh_b are the gradients w.r.t. the layer's two outputs
 //   out_r = h[r,real] - h[i,imag]   (dh_a),    out_i = h[i,real] + h[r,imag]   (dh_b)
 // combo 0 (r,real): +dh_a   combo 1 (r,imag): +dh_b   combo 2 (i,real): +dh_b   combo 3 (i,imag): -dh_a
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restrict__ dh_a, const bf16_raw* __restrict__ dh_b,
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restrict__ dh_a, const bf16_raw* __restrict__ dh_b,
                                                        const bf16_raw* __restrict__ whhT, const bf16_raw* __restrict__ gates,
                                                        const float* __restrict__ cst, int B, int T, int t0, int t1,
                                                        float* __restrict__ state,
                                                        bf16_raw* __restrict__ dpre0, bf16_raw* __restrict__ dpre1) {
+    constexpr int G4 = 4 * H, NT = 4 * H, DGP = 4 * H + 8, KS = G4 / 32;   // LDS pitch of the dgate tile; k-steps over the 4 H gate gradients
     __shared__ __attribute__((aligned(16))) bf16_raw dgbuf[2][NBT * DGP];
     const int combo = blockIdx.x & 3, tile = blockIdx.x >> 2;
     const int part = combo >> 1, lstm = combo & 1;
@@ -143,20 +147,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
     const bf16_raw* dh = (combo == 0 || combo == 3) ? dh_a : dh_b;
     const float sign = combo == 3 ? -1.f : 1.f;
     const bf16_raw* dhp = dh + ((size_t)bc * T) * H + unit;
-    // the step's gate gradients leave through LDS: wave w stores batch row w of the tile as one 512-byte run
-    const int srow = tile * NBT + w;
-    bf16_raw* dpre = (part ? dpre1 : dpre0) + ((size_t)(srow < B ? srow : 0) * T) * (2 * G4) + lstm * G4 + lane * 4;
+    // the step's gate gradients leave through LDS: H threads (wave w for H = 64) store one batch row of the tile as one 8 H-byte run
+    const int sr = threadIdx.x / H, sc = (threadIdx.x % H) * 4;
+    const int srow = tile * NBT + sr;
+    bf16_raw* dpre = (part ? dpre1 : dpre0) + ((size_t)(srow < B ? srow : 0) * T) * (2 * G4) + lstm * G4 + sc;
     const bool svalid = srow < B;
 
     // W_hh^T fragments: rows k = 16w + (lane&15), reduction index n = 32 s + 8 (lane>>4) ..
-    bf16x8 wf[8];
+    bf16x8 wf[KS];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < KS; ++s)
         wf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(whhT + ((size_t)lstm * H + 16 * w + m) * G4 + 32 * s + 8 * ug));
 
     // steps t1-1 ... t0; a chunk that does not end at T resumes from the (dc, recurrent dh) the later chunk left in `state`
     float dc = 0.f, dhrec = 0.f;
-    float* stp = state ? state + ((size_t)blockIdx.x * 256 + threadIdx.x) * 2 : nullptr;
+    float* stp = state ? state + ((size_t)blockIdx.x * NT + threadIdx.x) * 2 : nullptr;
     if (t1 < T) {
         const float2 a = *reinterpret_cast<const float2*>(stp);
         dc = a.x; dhrec = a.y;
@@ -166,13 +171,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
     struct StepIn { uint2 g; bf16_raw dh; float c, cp; };
     const int ntiles = gridDim.x >> 2;
     const size_t rbase = (size_t)(combo * ntiles + tile) * T;  // records written by lstm_fwd_kernel
-    const float* cbase = cst + rbase * 256 + threadIdx.x;
+    const float* cbase = cst + rbase * NT + threadIdx.x;
     auto load_step = [&](int t) {
         StepIn v;
-        v.g = *reinterpret_cast<const uint2*>(gates + ((rbase + t) * 256 + threadIdx.x) * 4);
+        v.g = *reinterpret_cast<const uint2*>(gates + ((rbase + t) * NT + threadIdx.x) * 4);
         v.dh = dhp[(size_t)t * H];
-        v.c = cbase[(size_t)t * 256];
-        v.cp = t > 0 ? cbase[(size_t)(t - 1) * 256] : 0.f;
+        v.c = cbase[(size_t)t * NT];
+        v.cp = t > 0 ? cbase[(size_t)(t - 1) * NT] : 0.f;
         return v;
     };
     StepIn ring[PD];
@@ -198,14 +203,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
         lds_barrier();
         f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;   // two accumulation chains of four
 #pragma unroll
-        for (int s = 0; s < 8; s += 2) {
+        for (int s = 0; s < KS; s += 2) {
             const bf16x8 g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&dgbuf[cur][bl * DGP + 32 * s + 8 * ug]));
             const bf16x8 g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&dgbuf[cur][bl * DGP + 32 * s + 32 + 8 * ug]));
             r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], g0, r0, 0, 0, 0);
             r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], g1, r1, 0, 0, 0);
         }
         {
-            const uint2 row = *reinterpret_cast<const uint2*>(&dgbuf[cur][w * DGP + lane * 4]);
+            const uint2 row = *reinterpret_cast<const uint2*>(&dgbuf[cur][sr * DGP + sc]);
             if (svalid) *reinterpret_cast<uint2*>(dpre + (size_t)t * (2 * G4)) = row;
         }
         dhrec = quad_pick(r0, rs) + quad_pick(r1, rs);
@@ -221,11 +226,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const bf16_raw* __restric
 
 extern "C" int sehip_lstm_fwd_chunk(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, int t0,
                                     int t1, void* h, void* gates, float* c, void* stream) {
-    SEHIP_REQUIRE(hidden == H, "lstm_fwd: only hidden size 64 (rnn_units=128) is built, got %d", hidden);
+    SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_fwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
     SEHIP_REQUIRE(B > 0 && T > 0, "lstm_fwd: empty input");
     SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_fwd: bad step range [%d, %d) of %d", t0, t1, T);
-    lstm_fwd_kernel<<<4 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1,
-                                                                     (bf16_raw*)h, (bf16_raw*)gates, c);
+    if (hidden == 64)
+        lstm_fwd_kernel<64><<<4 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1,
+                                                                             (bf16_raw*)h, (bf16_raw*)gates, c);
+    else
+        lstm_fwd_kernel<128><<<4 * cdiv(B, NBT), 512, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1,
+                                                                              (bf16_raw*)h, (bf16_raw*)gates, c);
     SEHIP_CHECK_LAUNCH("lstm_fwd");
     return 0;
 }
@@ -235,16 +244,21 @@ extern "C" int sehip_lstm_fwd(const float* pre0, const float* pre1, const void* 
     return sehip_lstm_fwd_chunk(pre0, pre1, whh, B, T, hidden, 0, T, h, gates, c, stream);
 }
 
-// state: 4 * ceil(B/4) * 256 * 2 floats carried between chunks (needed unless the chunk is the whole sequence)
+// state: 4 * ceil(B/4) * 4 * hidden * 2 floats carried between chunks (needed unless the chunk is the whole sequence)
 extern "C" int sehip_lstm_bwd_chunk(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B,
                                     int T, int hidden, int t0, int t1, float* state, void* dpre0, void* dpre1, void* stream) {
-    SEHIP_REQUIRE(hidden == H, "lstm_bwd: only hidden size 64 (rnn_units=128) is built, got %d", hidden);
+    SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_bwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
     SEHIP_REQUIRE(B > 0 && T > 0, "lstm_bwd: empty input");
     SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_bwd: bad step range [%d, %d) of %d", t0, t1, T);
     SEHIP_REQUIRE(state != nullptr || (t0 == 0 && t1 == T), "lstm_bwd: a partial step range needs the state buffer");
-    lstm_bwd_kernel<<<4 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
-                                                                     (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T, t0,
-                                                                     t1, state, (bf16_raw*)dpre0, (bf16_raw*)dpre1);
+    if (hidden == 64)
+        lstm_bwd_kernel<64><<<4 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
+                                                                             (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T, t0,
+                                                                             t1, state, (bf16_raw*)dpre0, (bf16_raw*)dpre1);
+    else
+        lstm_bwd_kernel<128><<<4 * cdiv(B, NBT), 512, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
+                                                                              (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T, t0,
+                                                                              t1, state, (bf16_raw*)dpre0, (bf16_raw*)dpre1);
     SEHIP_CHECK_LAUNCH("lstm_bwd");
     return 0;
 }

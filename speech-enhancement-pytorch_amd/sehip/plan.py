@@ -104,10 +104,10 @@ class DCCRNConfig:
         self.win_type = win_type
         if kernel_size != 5:
             raise SehipError("sehip DCCRN: only kernel_size=5 is built")
-        if rnn_layers != 2:
-            raise SehipError("sehip DCCRN: only rnn_layers=2 is built")
-        if rnn_units != 128:
-            raise SehipError("sehip DCCRN: only rnn_units=128 (LSTM hidden 64) is built")
+        if not 1 <= int(rnn_layers) <= 8:
+            raise SehipError("sehip DCCRN: rnn_layers must be 1 .. 8")
+        if rnn_units not in (128, 256):
+            raise SehipError("sehip DCCRN: rnn_units must be 128 or 256 (LSTM hidden 64 / 128: the sizes csrc/lstm.hip is built for)")
         if masking_mode not in ("E", "C", "R"):
             raise SehipError(f"unknown masking_mode {masking_mode}")
         self.rnn_layers, self.rnn_units = rnn_layers, rnn_units
@@ -676,18 +676,23 @@ class DCCRNStatic:
             #  gradient tensor like every other layer's: its apply pass 91 -> 60 us)
         # layer 2 input products and the projection: x2_r = h1[r,real] - h1[i,imag]; x2_i = h1[i,real] + h1[r,imag]
         combos = {"r": (0, 3, 1), "i": (2, 1, 0)}  # (first combo, second combo, negate second)
-        w2 = np.concatenate([ih(1, l) for l in (0, 1)])  # [512, 64]
+        # (the reference stacks rnn_layers of them, src/model/dccrn.py:86-96; every layer behind the first reads the one before it this way)
+        L = cfg.rnn_layers
         for tag, (ca, cb, ng) in combos.items():
             rows = wide_chunks(0, 0, 0, 0, h) + wide_chunks(1, 0, 0, 0, h)
-            wi = np.concatenate([w2, w2], 1)
-            wn = np.concatenate([zero(w2), zero(w2) + ng], 1)
-            self.specs[f"ih2_{tag}"] = GemmSpec(f"ih2_{tag}", rows, wi, wn, 8 * h, bias_pairs_lstm(1), "T", 1, 1,
-                                                [(f"h1_{ca}", "all"), (f"h1_{cb}", "all")], [(f"pre2_{tag}", 0, 1, 0)])
-            self.specs[f"dx2_{tag}"] = GemmSpec(f"dx2_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w2.T.copy(), zero(w2.T), h, None,
-                                                "T", 1, 1, [(f"dpre2_{tag}", "all")], [(f"dx2_{tag}", 0, 1, 0)], kind="dgrad")
+            for layer in range(2, L + 1):
+                w2 = np.concatenate([ih(layer - 1, l) for l in (0, 1)])  # [512, 64]
+                wi = np.concatenate([w2, w2], 1)
+                wn = np.concatenate([zero(w2), zero(w2) + ng], 1)
+                self.specs[f"ih{layer}_{tag}"] = GemmSpec(f"ih{layer}_{tag}", rows, wi, wn, 8 * h, bias_pairs_lstm(layer - 1), "T", 1, 1,
+                                                          [(f"h{layer - 1}_{ca}", "all"), (f"h{layer - 1}_{cb}", "all")],
+                                                          [(f"pre{layer}_{tag}", 0, 1, 0)])
+                self.specs[f"dx{layer}_{tag}"] = GemmSpec(f"dx{layer}_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w2.T.copy(), zero(w2.T), h,
+                                                          None, "T", 1, 1, [(f"dpre{layer}_{tag}", "all")],
+                                                          [(f"dx{layer}_{tag}", 0, 1, 0)], kind="dgrad")
             q = 0 if tag == "r" else 1
-            tr = ia(f"enhance.1.{tag}_trans.weight")        # [cp*4, h], row c*4+d
-            trb = ia(f"enhance.1.{tag}_trans.bias")
+            tr = ia(f"enhance.{L - 1}.{tag}_trans.weight")        # [cp*4, h], row c*4+d
+            trb = ia(f"enhance.{L - 1}.{tag}_trans.bias")
             wt = tr.reshape(cp, 4, h).transpose(1, 0, 2).reshape(4 * cp, h)   # row n' = d*cp + c
             bt = trb.reshape(cp, 4).T.reshape(-1)
             bp = np.full((4 * cp, 2), -1, dtype=np.int32)
@@ -698,14 +703,14 @@ class DCCRNStatic:
                 nt[n4] = (0, d * c5 + q * cp + c, 4, 0)
             self.specs[f"proj_{tag}"] = GemmSpec(f"proj_{tag}", rows, np.concatenate([wt, wt], 1),
                                                  np.concatenate([zero(wt), zero(wt) + ng], 1), 4 * cp, bp, "T", 1, 1,
-                                                 [(f"h2_{ca}", "all"), (f"h2_{cb}", "all")], [("P", 0, 1, 0)], ntab=nt)
+                                                 [(f"h{L}_{ca}", "all"), (f"h{L}_{cb}", "all")], [("P", 0, 1, 0)], ntab=nt)
             rows = []
             for d in range(4):
                 rows += wide_chunks(0, 0, d, q * cp, cp)
             self.specs[f"dproj_{tag}"] = GemmSpec(f"dproj_{tag}", rows, wt.T.copy(), zero(wt.T), h, None, "T", 1, 1,
                                                   [("dP", "all")], [(f"dxo_{tag}", 0, 1, 0)], kind="dgrad")
         # recurrent weight gradients: dW_hh[n,k] = sum dpre[b,t,n] h[b,t-1,k]
-        for layer in (1, 2):
+        for layer in range(1, L + 1):
             for combo in range(4):
                 part, l = combo >> 1, combo & 1
                 hh = ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0")
@@ -735,14 +740,15 @@ class DCCRNStatic:
                     s.db_off = ga.reserve(s.Npad)
         # recurrent weights for the LSTM kernels: whh [layer][lstm][256][64], whhT [layer][lstm][64][256]
         self.whh_off, self.whhT_off = {}, {}
-        for layer in (1, 2):
+        for layer in range(1, L + 1):
             hh = np.stack([ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0") for l in (0, 1)])
             self.whh_off[layer] = wa.add(enc_entry(hh, 0).reshape(-1))
             self.whhT_off[layer] = wa.add(enc_entry(hh.transpose(0, 2, 1), 0).reshape(-1))
         # layer 2's input weights for the fused two-layer recurrence (csrc/lstm2.hip): wih2 [lstm][256][64], wihT2 [lstm][64][256]
-        ih2 = np.stack([ia(f"enhance.1.{lstm[l]}.weight_ih_l0") for l in (0, 1)])
-        self.wih2_off = wa.add(enc_entry(ih2, 0).reshape(-1))
-        self.wihT2_off = wa.add(enc_entry(ih2.transpose(0, 2, 1), 0).reshape(-1))
+        if L == 2 and h == 64:
+            ih2 = np.stack([ia(f"enhance.1.{lstm[l]}.weight_ih_l0") for l in (0, 1)])
+            self.wih2_off = wa.add(enc_entry(ih2, 0).reshape(-1))
+            self.wihT2_off = wa.add(enc_entry(ih2.transpose(0, 2, 1), 0).reshape(-1))
         # BatchNorm / PReLU gradients land in the packed-gradient buffer too
         self.bn_g_off = {}
         for pre, cr in self.bn:
@@ -877,7 +883,8 @@ class DCCRNWorkspace:
                 add(f"dz{i}", T, f, c)
         c5, h = kn[6], cfg.hid
         add("dz5l", T, 4, c5); add("P", T, 4, c5); add("dP", T, 4, c5)
-        for layer in (1, 2):
+        L = cfg.rnn_layers
+        for layer in range(1, L + 1):
             for tag in "ri":
                 add(f"pre{layer}_{tag}", T, 1, 8 * h, dtype=torch.float32)
                 add(f"dpre{layer}_{tag}", T, 1, 8 * h)
@@ -885,7 +892,9 @@ class DCCRNWorkspace:
             add(f"gates{layer}", T, 1, 4 * h, lead=4, batch=Bp)
             add(f"c{layer}", T, 1, h, dtype=torch.float32, lead=4, batch=Bp)
         for tag in "ri":
-            add(f"dx2_{tag}", T, 1, h); add(f"dxo_{tag}", T, 1, h)
+            add(f"dxo_{tag}", T, 1, h)
+            for layer in range(2, L + 1):
+                add(f"dx{layer}_{tag}", T, 1, h)
         for j in range(5):
             idx = 6 - j
             f, c = (F0 >> idx) * 2, kn[idx - 1]
@@ -982,11 +991,14 @@ class DCCRNWorkspace:
             self.lstm_stream = torch.cuda.Stream(device=device, priority=hi)
             # the small products between the layers get their own stream: chunk c's product overlaps layer 2's chunk c-1
             self.lstm_gemm_stream = torch.cuda.Stream(device=device, priority=hi)
-        self.lstm_state = {layer: torch.zeros(4 * ((B + 15) // 16) * 2048, dtype=torch.float32, device=device) for layer in (1, 2)}
+        self.lstm_state = {layer: torch.zeros(4 * ((B + 3) // 4) * 4 * st.cfg.hid * 2, dtype=torch.float32, device=device)
+                           for layer in range(1, st.cfg.rnn_layers + 1)}
         # fused two-layer recurrence (csrc/lstm2.hip, round 4): both layers in ONE persistent launch per direction, layer 2 a dozen steps
         # behind layer 1, hand-off by data-tagged granules.  Default when the whole sequence runs as one chunk; SEHIP_NO_LSTM_FUSE or a
         # hand-off time-out (check_lstm_handoffs) return to the two launches per direction of round 3.
-        self.lstm_fused = len(self.lstm_chunks) == 1 and not os.environ.get("SEHIP_NO_LSTM_FUSE") and T < 65535
+        # (rnn_layers != 2 or rnn_units != 128: one launch per layer and direction, the products between them on the chain)
+        self.lstm_fused = (len(self.lstm_chunks) == 1 and not os.environ.get("SEHIP_NO_LSTM_FUSE") and T < 65535
+                           and st.cfg.rnn_layers == 2 and st.cfg.hid == 64)
         self.l2_epoch = 0
         self.graph_epoch = 0         # bumped when captured launches of this workspace go stale (fall-back after a hand-off time-out)
         if self.lstm_fused:
@@ -1125,7 +1137,9 @@ class DCCRNWorkspace:
                 d.bnr_y, d.bnr_coef, d.bnr_part = self.bufs["yd" + pre.split(".")[1]].ptr, ptr(self.bn_coef[pre]), ptr(self.bn_acc)
                 # (bnr_slope: set per call, from params)
         if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
-            for layers in ((1,), (2,), (2, 1)):
+            nl = self.st.cfg.rnn_layers
+            # (a group holds at most 16 products, six per layer: the whole stack in one launch for two layers only)
+            for layers in [(layer,) for layer in range(1, nl + 1)] + ([(2, 1)] if nl == 2 else []):
                 self._wgrad_group_handle(self._lstm_wgrad_names(layers))
 
     def _chunk_desc(self, name, t0, t1):
@@ -1301,13 +1315,15 @@ class DCCRNWorkspace:
                 units.append(pair("sehip_gemm_pair", f"enc{i}.dg0", f"enc{i}.dg1"))
         for a, b in (("ih1_r", "ih1_i"), ("proj_r", "proj_i"), ("dproj_r", "dproj_i"), ("dx1_r", "dx1_i")):
             units.append(pair("sehip_gemm_pair", a, b))
+        nl = self.st.cfg.rnn_layers
         if not self.lstm_fused:
-            for a, b in (("ih2_r", "ih2_i"), ("dx2_r", "dx2_i")):
-                units.append(pair("sehip_gemm_pair", a, b))
+            for layer in range(2, nl + 1):
+                for a, b in ((f"ih{layer}_r", f"ih{layer}_i"), (f"dx{layer}_r", f"dx{layer}_i")):
+                    units.append(pair("sehip_gemm_pair", a, b))
         for tag in "ri":
             units.append(one("sehip_wgrad", f"proj_{tag}.wg"))
-        names = self._lstm_wgrad_names((2, 1))
-        if not os.environ.get("SEHIP_NO_WGRAD_GROUP"):
+        names = self._lstm_wgrad_names(tuple(range(nl, 0, -1)))
+        if not os.environ.get("SEHIP_NO_WGRAD_GROUP") and nl <= 2:
             buf, n, total, dense = self._wgrad_group_handle(names)
             if dense is not None:
                 units.append(("lstm.wg (dense group)", [nm + ".wg" for nm in names],
@@ -1461,10 +1477,12 @@ class DCCRNWorkspace:
                  wp + 2 * st.wih2_off, self.desc["ih2_r"].bias, B, T, h, b["h1"].ptr, b["gates1"].ptr, b["c1"].ptr, b["h2"].ptr,
                  b["gates2"].ptr, b["c2"].ptr, ptr(self.l2_gran_f), ptr(self.l2_sync), self._l2_cur_epoch, main)
             return
-        if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():  # graph replay serialises the streams
+        nl = self.st.cfg.rnn_layers
+        if self.lstm_stream is None or nl != 2 or torch.cuda.is_current_stream_capturing():  # graph replay serialises the streams
             self._lstm_fwd_call(1, 0, T, main)
-            self.gemm_pair("ih2_r", "ih2_i")
-            self._lstm_fwd_call(2, 0, T, main)
+            for layer in range(2, nl + 1):
+                self.gemm_pair(f"ih{layer}_r", f"ih{layer}_i")
+                self._lstm_fwd_call(layer, 0, T, main)
             return
         s2, s3 = self.lstm_stream.cuda_stream, self.lstm_gemm_stream.cuda_stream
         for (t0, t1) in self.lstm_chunks:
@@ -1477,7 +1495,8 @@ class DCCRNWorkspace:
 
     def _lstm_bwd_call(self, layer, t0, t1, st_):
         b, cfg = self.bufs, self.st.cfg
-        dha, dhb = (b["dxo_r"], b["dxo_i"]) if layer == 2 else (b["dx2_r"], b["dx2_i"])
+        # a layer's output gradient: the projection's input gradient for the last one, the next layer's input gradient otherwise
+        dha, dhb = (b["dxo_r"], b["dxo_i"]) if layer == cfg.rnn_layers else (b[f"dx{layer + 1}_r"], b[f"dx{layer + 1}_i"])
         whhT = self.tb.wpack.data_ptr() + 2 * self.st.whhT_off[layer]
         call("sehip_lstm_bwd_chunk", dha.ptr, dhb.ptr, whhT, b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, self.B, self.T, cfg.hid,
              t0, t1, ptr(self.lstm_state[layer]), b[f"dpre{layer}_r"].ptr, b[f"dpre{layer}_i"].ptr, st_)
@@ -1496,8 +1515,9 @@ class DCCRNWorkspace:
             self.wgrad_group(self._lstm_wgrad_names((2, 1)))
             self.gemm_pair("dx1_r", "dx1_i")
             return
-        if self.lstm_stream is None or torch.cuda.is_current_stream_capturing():
-            for layer in (2, 1):
+        nl = self.st.cfg.rnn_layers
+        if self.lstm_stream is None or nl != 2 or torch.cuda.is_current_stream_capturing():
+            for layer in range(nl, 0, -1):
                 self._lstm_bwd_call(layer, 0, T, main)
                 self.wgrad_group(self._lstm_wgrad_names((layer,)))
                 self.gemm_pair(f"dx{layer}_r", f"dx{layer}_i")

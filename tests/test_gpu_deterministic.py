@@ -11,13 +11,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def run(tmp_path, deterministic, kernel_num, n, b, steps=3):
+def run(tmp_path, deterministic, kernel_num, n, b, steps=3, extra=None):
     from sehip import distrib
     from sehip.solver import Solver, ScalarLog
     from sehip.utils import set_deterministic
     from test_gpu_solver import solver_config, make_batch
     cfg = solver_config(tmp_path)
     cfg.model.kernel_num, cfg.model.length = list(kernel_num), n
+    for k, v in (extra or {}).items():
+        setattr(cfg.model, k, v)
     cfg.solver.cudnn_deterministic = deterministic
     try:
         torch.manual_seed(cfg.seed)
@@ -53,6 +55,20 @@ def test_two_deterministic_runs_are_bit_identical(tmp_path, kernel_num, n, b):
     print(f"deterministic vs default schedule, one step: loss {d1[0][0][0]:.4f} vs {d0[0][0][0]:.4f} dB, gradient rel {rel:.2e}")
     assert abs(d1[0][0][0] - d0[0][0][0]) < 3e-2
     assert rel < 3e-2
+
+
+def test_a_deeper_wider_recurrent_stack_is_bit_identical_too(tmp_path):
+    """rnn_layers=3, rnn_units=256 (round 6: one launch per layer and direction, csrc/lstm.hip at hidden 128; the recurrent weight
+    gradients one by one under the deterministic schedule): two runs of three steps, bit for bit."""
+    extra = dict(rnn_layers=3, rnn_units=256)
+    a = run(tmp_path, True, (16, 16, 32, 32, 64, 64), 4000, 3, extra=extra)
+    c = run(tmp_path, True, (16, 16, 32, 32, 64, 64), 4000, 3, extra=extra)
+    assert a[0] == c[0], (a[0], c[0])
+    for x, y, what in zip(a[1:], c[1:], ("parameters", "exp_avg", "exp_avg_sq", "gradients")):
+        assert torch.equal(x, y), what
+    d0 = run(tmp_path, False, (16, 16, 32, 32, 64, 64), 4000, 3, steps=1, extra=extra)
+    d1 = run(tmp_path, True, (16, 16, 32, 32, 64, 64), 4000, 3, steps=1, extra=extra)
+    assert abs(d1[0][0][0] - d0[0][0][0]) < 3e-2 and float((d1[4] - d0[4]).norm() / d0[4].norm()) < 3e-2
 
 
 def test_the_library_flag_round_trips_and_refuses_grouped_launches():

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def run_once(chunk, B, N):
+def run_once(chunk, B, N, units=128):
     from sehip.model import DCCRN
     old = os.environ.get("SEHIP_LSTM_CHUNK")
     os.environ["SEHIP_LSTM_CHUNK"] = str(chunk)
@@ -21,7 +21,7 @@ def run_once(chunk, B, N):
     try:
         dev = torch.device("cuda:0")
         torch.manual_seed(3)
-        model = DCCRN(rnn_units=128, kernel_num=[16, 16, 32, 32, 64, 64], length=N).to(dev).train()
+        model = DCCRN(rnn_units=units, kernel_num=[16, 16, 32, 32, 64, 64], length=N).to(dev).train()
         g = torch.Generator().manual_seed(11)
         x = (0.1 * torch.randn(B, 1, N, generator=g)).to(dev)
         out = model(x)
@@ -42,10 +42,11 @@ def run_once(chunk, B, N):
             os.environ["SEHIP_LSTM_CHUNK"] = old
 
 
-@pytest.mark.parametrize("B,N,chunk", [(3, 6000, 16), (17, 3000, 7), (2, 6000, 40)])
-def test_chunked_equals_whole_sequence(B, N, chunk):
-    whole, gw, n1 = run_once(0, B, N)
-    parts, gp, n2 = run_once(chunk, B, N)
+@pytest.mark.parametrize("B,N,chunk,units", [(3, 6000, 16, 128), (17, 3000, 7, 128), (2, 6000, 40, 128), (5, 6000, 16, 256)])
+def test_chunked_equals_whole_sequence(B, N, chunk, units):
+    """(units = 256: the hidden-128 instance of the same kernels -- 512 threads, the carried state 4 H floats per thread pair)"""
+    whole, gw, n1 = run_once(0, B, N, units)
+    parts, gp, n2 = run_once(chunk, B, N, units)
     assert n1 == 1 and n2 > 1
     for k in whole:
         assert torch.equal(whole[k], parts[k]), k

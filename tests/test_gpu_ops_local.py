@@ -155,6 +155,17 @@ def test_complex_batchnorm_prelu_forward_backward(run, name):
 def test_complex_lstm_forward_backward(run):
     """Both layers: recurrent kernels + the input / projection products, against the oracle's explicit recurrence with the
     same bf16 rounding points, from the HIP path's z5 and dP."""
+    _check_complex_lstm(run)
+
+
+@pytest.mark.parametrize("layers,units", [(1, 128), (3, 128), (2, 256), (3, 256)])
+def test_complex_lstm_other_depths_and_widths(layers, units):
+    """rnn_layers / rnn_units of the reference constructor (src/model/dccrn.py:12-13, the stack :84-96): the same op-local gate for the
+    per-layer launches (csrc/lstm.hip at hidden 64 / 128) and the products between the layers."""
+    _check_complex_lstm(build_run(dict(SMALL, rnn_layers=layers, rnn_units=units), 3, 4000))
+
+
+def _check_complex_lstm(run):
     ws, p, cfg = run["ws"], run["p"], run["cfg"]
     b, B, T = ws.bufs, run["B"], run["T"]
     z5 = to_ref(b["z5"])                                  # [B,C,4,T]
@@ -164,19 +175,25 @@ def test_complex_lstm_forward_backward(run):
     i_in = seq[:, :, ch // 2:].reshape(T, B, -1).requires_grad_(True)
     names = [k for k in p if k.startswith("enhance.")]
     leaves = {k: p[k].clone().requires_grad_(True) for k in names}
-    r1, i1 = O.complex_lstm(r_in, i_in, leaves, "enhance.0.", False, sim=O.Bf16Sim)
-    r2, i2 = O.complex_lstm(r1, i1, leaves, "enhance.1.", True, sim=O.Bf16Sim)
+    r2, i2 = r_in, i_in
+    for layer in range(cfg.rnn_layers):
+        r2, i2 = O.complex_lstm(r2, i2, leaves, f"enhance.{layer}.", layer == cfg.rnn_layers - 1, sim=O.Bf16Sim)
     out = torch.cat([r2.reshape(T, B, ch // 2, 4), i2.reshape(T, B, ch // 2, 4)], 2).permute(1, 2, 3, 0)  # [B,C,4,T]
     assert rel_err(to_ref(b["P"]), out.detach()) < 1e-2
     dP = to_ref(b["dP"])
     outs = torch.autograd.grad((out * dP).sum(), [r_in, i_in] + [leaves[k] for k in names])
     from sehip.plan import FUSE_SKIP_GRAD
     dz5 = to_ref(b["dz5l"])
+    floor = 0.0
     if FUSE_SKIP_GRAD:        # the dx1 products store the LSTM's input gradient + the innermost skip connection's (descriptor field `res`)
+        # (both tensors are bf16: the difference carries their rounding, 2^-9 of each at most -- what is left of a small input gradient
+        #  under a large skip gradient; a deeper stack at initialisation has exactly that)
+        floor = 2.0 ** -9 * float(dz5.norm() + to_ref(b["dskip5"]).norm()) / 2 ** 0.5
         dz5 = dz5 - to_ref(b["dskip5"])
     dz5 = dz5.permute(3, 0, 1, 2)
-    assert rel_err(dz5[:, :, : ch // 2].reshape(T, B, -1), outs[0]) < 3e-2
-    assert rel_err(dz5[:, :, ch // 2:].reshape(T, B, -1), outs[1]) < 3e-2
+    for part, ref in ((dz5[:, :, : ch // 2], outs[0]), (dz5[:, :, ch // 2:], outs[1])):
+        e = float((part.reshape(T, B, -1) - ref).norm())
+        assert e < 3e-2 * float(ref.norm()) + floor, (e, float(ref.norm()), floor)
     G = run["grads"]
     for k, gref in zip(names, outs[2:]):
         assert rel_err(G[k], gref) < 3e-2, k
