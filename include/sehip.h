@@ -546,6 +546,14 @@ int sehip_lstm_fwd_chunk(const float* pre_r, const float* pre_i, const void* whh
 int sehip_lstm_bwd_chunk(const void* dh_a_bf16, const void* dh_b_bf16, const void* whhT_bf16, const void* gates_bf16,
                          const float* c, int B, int T, int hidden, int t0, int t1, float* state, void* dpre_r_bf16,
                          void* dpre_i_bf16, void* stream);
+/* One plain nn.LSTM layer (unidirectional, zero initial state): the recurrent part of DCCRN(use_clstm=False), src/model/dccrn.py:98-106
+ * (`self.enhance = nn.LSTM(..., num_layers=2)`) as called at :184-189 -- the same kernels as above with ONE recurrence per launch.
+ *   pre : fp32 [B][T][4 H] = x @ W_ih^T + b_ih + b_hh;  whh : bf16 [4 H][H];  h : bf16 [B][T][H];  hidden H = 64 or 128
+ *   gates / c : records for the backward call, [ceil(B/4)*4][T][4 H] bf16 / [ceil(B/4)*4][T][H] fp32
+ *   backward: dh bf16 [B][T][H] (gradient of h), whhT bf16 [H][4 H] -> dpre bf16 [B][T][4 H] */
+int sehip_rlstm_fwd(const float* pre, const void* whh_bf16, int B, int T, int hidden, void* h_bf16, void* gates_bf16, float* c, void* stream);
+int sehip_rlstm_bwd(const void* dh_bf16, const void* whhT_bf16, const void* gates_bf16, const float* c, int B, int T, int hidden,
+                    void* dpre_bf16, void* stream);
 /* BOTH stacked complex LSTM layers (src/model/dccrn.py:264-302 wired as in :170-191: layer 2's input is the complex combination
  * x2_r = h1[r,real] - h1[i,imag], x2_i = h1[i,real] + h1[r,imag] of layer 1's outputs) as ONE persistent launch per direction
  * (csrc/lstm2.hip): 8 workgroups per tile of 4 batch rows, layer 2 runs a dozen steps behind layer 1; layer 2's input product

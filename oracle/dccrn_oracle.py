@@ -43,9 +43,10 @@ class DCCRNConfig:
 
     def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512,
                  length=16384, masking_mode="E", kernel_size=5,
-                 kernel_num=DEFAULT_KERNEL_NUM, win_type="hann", use_cbn=True, **_ignored):
+                 kernel_num=DEFAULT_KERNEL_NUM, win_type="hann", use_cbn=True, use_clstm=True, **_ignored):
         self.win_type = win_type
         self.use_cbn = bool(use_cbn)
+        self.use_clstm = bool(use_clstm)
         self.rnn_layers = rnn_layers
         self.rnn_units = rnn_units
         self.win_len = win_len
@@ -338,16 +339,26 @@ def dccrn_forward(p, wav, cfg: DCCRNConfig, training=True, capture=None, stats_o
     seq = out.permute(3, 0, 1, 2)  # [T,B,C,D]
     r_in = seq[:, :, : ch // 2].reshape(t, b, ch // 2 * d)
     i_in = seq[:, :, ch // 2:].reshape(t, b, ch // 2 * d)
-    for layer in range(cfg.rnn_layers):
-        r_in, i_in = complex_lstm(r_in, i_in, p, f"enhance.{layer}.",
-                                  has_projection=(layer == cfg.rnn_layers - 1), sim=sim)
-        if layer == cfg.rnn_layers - 1:
-            r_in, i_in = sim.act(r_in), sim.act(i_in)
-        cap[f"lstm{layer}.r"] = r_in
-        cap[f"lstm{layer}.i"] = i_in
-    r_in = r_in.reshape(t, b, ch // 2, d)
-    i_in = i_in.reshape(t, b, ch // 2, d)
-    out = torch.cat([r_in, i_in], 2).permute(1, 2, 3, 0)
+    if not getattr(cfg, "use_clstm", True):
+        # src/model/dccrn.py:184-189: ONE real nn.LSTM over all channels (two layers whatever rnn_layers says, :98-106) and a Linear
+        x = seq.reshape(t, b, ch * d)
+        for layer in range(2):
+            x = lstm_single(x, p[f"enhance.weight_ih_l{layer}"], p[f"enhance.weight_hh_l{layer}"],
+                            p[f"enhance.bias_ih_l{layer}"], p[f"enhance.bias_hh_l{layer}"], sim)
+            cap[f"lstm{layer}"] = x
+        x = sim.act(F.linear(x, sim.weight(p["tranform.weight"]), p["tranform.bias"]))
+        out = x.reshape(t, b, ch, d).permute(1, 2, 3, 0)
+    else:
+        for layer in range(cfg.rnn_layers):
+            r_in, i_in = complex_lstm(r_in, i_in, p, f"enhance.{layer}.",
+                                      has_projection=(layer == cfg.rnn_layers - 1), sim=sim)
+            if layer == cfg.rnn_layers - 1:
+                r_in, i_in = sim.act(r_in), sim.act(i_in)
+            cap[f"lstm{layer}.r"] = r_in
+            cap[f"lstm{layer}.i"] = i_in
+        r_in = r_in.reshape(t, b, ch // 2, d)
+        i_in = i_in.reshape(t, b, ch // 2, d)
+        out = torch.cat([r_in, i_in], 2).permute(1, 2, 3, 0)
 
     for i in range(cfg.n_layers):
         pre = f"decoder.{i}."
@@ -446,7 +457,17 @@ def init_params(cfg: DCCRNConfig, seed=0) -> "OrderedDict[str, torch.Tensor]":
         bn_block(f"encoder.{i}.", cout)
     hid = cfg.rnn_units // 2
     width = cfg.hidden_dim * kn[-1] // 2
-    for layer in range(cfg.rnn_layers):
+    if not getattr(cfg, "use_clstm", True):       # nn.LSTM(hidden_dim * kernel_num[-1], rnn_units, num_layers=2) + nn.Linear
+        hr, k = cfg.rnn_units, 1.0 / math.sqrt(cfg.rnn_units)
+        for layer in range(2):
+            nin = 2 * width if layer == 0 else hr
+            p[f"enhance.weight_ih_l{layer}"] = (torch.rand(4 * hr, nin, generator=g) * 2 - 1) * k
+            p[f"enhance.weight_hh_l{layer}"] = (torch.rand(4 * hr, hr, generator=g) * 2 - 1) * k
+            p[f"enhance.bias_ih_l{layer}"] = (torch.rand(4 * hr, generator=g) * 2 - 1) * k
+            p[f"enhance.bias_hh_l{layer}"] = (torch.rand(4 * hr, generator=g) * 2 - 1) * k
+        p["tranform.weight"] = (torch.rand(2 * width, hr, generator=g) * 2 - 1) * k
+        p["tranform.bias"] = (torch.rand(2 * width, generator=g) * 2 - 1) * k
+    for layer in range(cfg.rnn_layers if getattr(cfg, "use_clstm", True) else 0):
         nin = width if layer == 0 else hid
         k = 1.0 / math.sqrt(hid)
         for part in ("real_lstm", "imag_lstm"):

@@ -152,6 +152,8 @@ _PROTOS = {
     "sehip_dmx_attn_bwd": [P, P, I, I, I, I, I, I, P, P, P],
     "sehip_lstm_fwd": [P, P, P, I, I, I, P, P, P, P],
     "sehip_lstm_bwd": [P, P, P, P, P, I, I, I, P, P, P],
+    "sehip_rlstm_fwd": [P, P, I, I, I, P, P, P, P],
+    "sehip_rlstm_bwd": [P, P, P, P, I, I, I, P, P],
     "sehip_lstm2_gran_bytes": [I, I, I],
     "sehip_lstm2_sync_bytes": [],
     "sehip_lstm2_fwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, U, P],

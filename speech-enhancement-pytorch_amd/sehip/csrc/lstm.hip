@@ -42,10 +42,12 @@ template <int H>
 __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(const float* __restrict__ pre0, const float* __restrict__ pre1,
                                                        const bf16_raw* __restrict__ whh, int B, int T, int t0, int t1,
                                                        bf16_raw* __restrict__ hout, bf16_raw* __restrict__ gates,
-                                                       float* __restrict__ cout) {
+                                                       float* __restrict__ cout, int real) {
     constexpr int G4 = 4 * H, NT = 4 * H, HP = H + 8, KS = H / 32;     // gates per LSTM, threads, LDS pitch of the h tile, k-steps
     __shared__ __attribute__((aligned(16))) bf16_raw hbuf[2][NBT * HP];
-    const int combo = blockIdx.x & 3, tile = blockIdx.x >> 2;
+    // real != 0: ONE plain nn.LSTM (DCCRN(use_clstm=False), src/model/dccrn.py:98-106): a single "combo", pre rows of 4 H gates
+    const int combo = real ? 0 : (blockIdx.x & 3), tile = real ? blockIdx.x : (blockIdx.x >> 2);
+    const int PS = real ? G4 : 2 * G4;          // row pitch of the pre-gates
     const int part = combo >> 1, lstm = combo & 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, ug = lane >> 4;
@@ -54,9 +56,9 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(const float* __restrict
     const int b = tile * NBT + bl;
     const bool bvalid = b < B;
     const int bc = bvalid ? b : B - 1;
-    const float* pre = (part ? pre1 : pre0) + ((size_t)bc * T) * (2 * G4) + lstm * G4 + unit;
+    const float* pre = (part ? pre1 : pre0) + ((size_t)bc * T) * PS + lstm * G4 + unit;
     const size_t obase = ((size_t)combo * B + bc) * T;
-    const int ntiles = gridDim.x >> 2;
+    const int ntiles = real ? gridDim.x : (gridDim.x >> 2);
     const size_t rbase = (size_t)(combo * ntiles + tile) * T;  // records private to the backward kernel: [combo][tile][t][thread]
 
     // W_hh fragments: gate g, k-step s: rows g*H + 16w + (lane&15), cols 32 s + 8 (lane>>4) ..
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(const float* __restrict
     for (int k = 0; k < PD; ++k)
         if (t0 + k < t1) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pf[k][g] = pre[(size_t)(t0 + k) * (2 * G4) + g * H];
+            for (int g = 0; g < 4; ++g) pf[k][g] = pre[(size_t)(t0 + k) * PS + g * H];
         }
     __syncthreads();
     if (t0 > 0) {  // resume: h(t0-1) from the output, c(t0-1) from the cell-state record
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(const float* __restrict
         const float p0 = pq[0], p1 = pq[1], p2 = pq[2], p3 = pq[3];
         if (t + PD < t1) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pq[g] = pre[(size_t)(t + PD) * (2 * G4) + g * H];
+            for (int g = 0; g < 4; ++g) pq[g] = pre[(size_t)(t + PD) * PS + g * H];
         }
         bf16x8 hf[KS];
 #pragma unroll
@@ -133,10 +135,11 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restr
                                                        const bf16_raw* __restrict__ whhT, const bf16_raw* __restrict__ gates,
                                                        const float* __restrict__ cst, int B, int T, int t0, int t1,
                                                        float* __restrict__ state,
-                                                       bf16_raw* __restrict__ dpre0, bf16_raw* __restrict__ dpre1) {
+                                                       bf16_raw* __restrict__ dpre0, bf16_raw* __restrict__ dpre1, int real) {
     constexpr int G4 = 4 * H, NT = 4 * H, DGP = 4 * H + 8, KS = G4 / 32;   // LDS pitch of the dgate tile; k-steps over the 4 H gate gradients
     __shared__ __attribute__((aligned(16))) bf16_raw dgbuf[2][NBT * DGP];
-    const int combo = blockIdx.x & 3, tile = blockIdx.x >> 2;
+    const int combo = real ? 0 : (blockIdx.x & 3), tile = real ? blockIdx.x : (blockIdx.x >> 2);     // (real: see lstm_fwd_kernel)
+    const int PS = real ? G4 : 2 * G4;
     const int part = combo >> 1, lstm = combo & 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, ug = lane >> 4;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restr
     // the step's gate gradients leave through LDS: H threads (wave w for H = 64) store one batch row of the tile as one 8 H-byte run
     const int sr = threadIdx.x / H, sc = (threadIdx.x % H) * 4;
     const int srow = tile * NBT + sr;
-    bf16_raw* dpre = (part ? dpre1 : dpre0) + ((size_t)(srow < B ? srow : 0) * T) * (2 * G4) + lstm * G4 + sc;
+    bf16_raw* dpre = (part ? dpre1 : dpre0) + ((size_t)(srow < B ? srow : 0) * T) * PS + lstm * G4 + sc;
     const bool svalid = srow < B;
 
     // W_hh^T fragments: rows k = 16w + (lane&15), reduction index n = 32 s + 8 (lane>>4) ..
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restr
     // software pipeline: the inputs of step t - PD (gates, dh, c[t], c[t-1]) are requested while step t runs; PD register
     // sets, the loop is unrolled by PD (see lstm_fwd_kernel)
     struct StepIn { uint2 g; bf16_raw dh; float c, cp; };
-    const int ntiles = gridDim.x >> 2;
+    const int ntiles = real ? gridDim.x : (gridDim.x >> 2);
     const size_t rbase = (size_t)(combo * ntiles + tile) * T;  // records written by lstm_fwd_kernel
     const float* cbase = cst + rbase * NT + threadIdx.x;
     auto load_step = [&](int t) {
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restr
         }
         {
             const uint2 row = *reinterpret_cast<const uint2*>(&dgbuf[cur][sr * DGP + sc]);
-            if (svalid) *reinterpret_cast<uint2*>(dpre + (size_t)t * (2 * G4)) = row;
+            if (svalid) *reinterpret_cast<uint2*>(dpre + (size_t)t * PS) = row;
         }
         dhrec = quad_pick(r0, rs) + quad_pick(r1, rs);
         cur ^= 1;
@@ -224,46 +227,70 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restr
     if (t0 > 0 && stp) *reinterpret_cast<float2*>(stp) = make_float2(dc, dhrec);
 }
 
-extern "C" int sehip_lstm_fwd_chunk(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, int t0,
-                                    int t1, void* h, void* gates, float* c, void* stream) {
+static int lstm_fwd_launch(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, int t0, int t1, void* h,
+                           void* gates, float* c, int real, void* stream) {
     SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_fwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
     SEHIP_REQUIRE(B > 0 && T > 0, "lstm_fwd: empty input");
     SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_fwd: bad step range [%d, %d) of %d", t0, t1, T);
+    const int grid = (real ? 1 : 4) * cdiv(B, NBT);
     if (hidden == 64)
-        lstm_fwd_kernel<64><<<4 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1,
-                                                                             (bf16_raw*)h, (bf16_raw*)gates, c);
+        lstm_fwd_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1, (bf16_raw*)h,
+                                                                 (bf16_raw*)gates, c, real);
     else
-        lstm_fwd_kernel<128><<<4 * cdiv(B, NBT), 512, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1,
-                                                                              (bf16_raw*)h, (bf16_raw*)gates, c);
+        lstm_fwd_kernel<128><<<grid, 512, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1, (bf16_raw*)h,
+                                                                  (bf16_raw*)gates, c, real);
     SEHIP_CHECK_LAUNCH("lstm_fwd");
     return 0;
 }
 
+static int lstm_bwd_launch(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B, int T,
+                           int hidden, int t0, int t1, float* state, void* dpre0, void* dpre1, int real, void* stream) {
+    SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_bwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
+    SEHIP_REQUIRE(B > 0 && T > 0, "lstm_bwd: empty input");
+    SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_bwd: bad step range [%d, %d) of %d", t0, t1, T);
+    SEHIP_REQUIRE(state != nullptr || (t0 == 0 && t1 == T), "lstm_bwd: a partial step range needs the state buffer");
+    const int grid = (real ? 1 : 4) * cdiv(B, NBT);
+    if (hidden == 64)
+        lstm_bwd_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT,
+                                                                 (const bf16_raw*)gates, c, B, T, t0, t1, state, (bf16_raw*)dpre0,
+                                                                 (bf16_raw*)dpre1, real);
+    else
+        lstm_bwd_kernel<128><<<grid, 512, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT,
+                                                                  (const bf16_raw*)gates, c, B, T, t0, t1, state, (bf16_raw*)dpre0,
+                                                                  (bf16_raw*)dpre1, real);
+    SEHIP_CHECK_LAUNCH("lstm_bwd");
+    return 0;
+}
+
+extern "C" int sehip_lstm_fwd_chunk(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, int t0,
+                                    int t1, void* h, void* gates, float* c, void* stream) {
+    return lstm_fwd_launch(pre0, pre1, whh, B, T, hidden, t0, t1, h, gates, c, 0, stream);
+}
+
 extern "C" int sehip_lstm_fwd(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, void* h,
                               void* gates, float* c, void* stream) {
-    return sehip_lstm_fwd_chunk(pre0, pre1, whh, B, T, hidden, 0, T, h, gates, c, stream);
+    return lstm_fwd_launch(pre0, pre1, whh, B, T, hidden, 0, T, h, gates, c, 0, stream);
 }
 
 // state: 4 * ceil(B/4) * 4 * hidden * 2 floats carried between chunks (needed unless the chunk is the whole sequence)
 extern "C" int sehip_lstm_bwd_chunk(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B,
                                     int T, int hidden, int t0, int t1, float* state, void* dpre0, void* dpre1, void* stream) {
-    SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_bwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
-    SEHIP_REQUIRE(B > 0 && T > 0, "lstm_bwd: empty input");
-    SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_bwd: bad step range [%d, %d) of %d", t0, t1, T);
-    SEHIP_REQUIRE(state != nullptr || (t0 == 0 && t1 == T), "lstm_bwd: a partial step range needs the state buffer");
-    if (hidden == 64)
-        lstm_bwd_kernel<64><<<4 * cdiv(B, NBT), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
-                                                                             (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T, t0,
-                                                                             t1, state, (bf16_raw*)dpre0, (bf16_raw*)dpre1);
-    else
-        lstm_bwd_kernel<128><<<4 * cdiv(B, NBT), 512, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b,
-                                                                              (const bf16_raw*)whhT, (const bf16_raw*)gates, c, B, T, t0,
-                                                                              t1, state, (bf16_raw*)dpre0, (bf16_raw*)dpre1);
-    SEHIP_CHECK_LAUNCH("lstm_bwd");
-    return 0;
+    return lstm_bwd_launch(dh_a, dh_b, whhT, gates, c, B, T, hidden, t0, t1, state, dpre0, dpre1, 0, stream);
 }
 
 extern "C" int sehip_lstm_bwd(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B,
                               int T, int hidden, void* dpre0, void* dpre1, void* stream) {
-    return sehip_lstm_bwd_chunk(dh_a, dh_b, whhT, gates, c, B, T, hidden, 0, T, nullptr, dpre0, dpre1, stream);
+    return lstm_bwd_launch(dh_a, dh_b, whhT, gates, c, B, T, hidden, 0, T, nullptr, dpre0, dpre1, 0, stream);
+}
+
+// One plain nn.LSTM layer (unidirectional, zero initial state): DCCRN(use_clstm=False), src/model/dccrn.py:98-106 / :184-189.
+//   pre [B][T][4 H] fp32 = x @ W_ih^T + b_ih + b_hh;  whh bf16 [4 H][H];  h bf16 [B][T][H];  gates / c: records for sehip_rlstm_bwd,
+//   [ceil(B/4)*4][T][4 H] bf16 / [ceil(B/4)*4][T][H] fp32.  Backward: dh bf16 [B][T][H] -> dpre bf16 [B][T][4 H]; whhT bf16 [H][4 H].
+extern "C" int sehip_rlstm_fwd(const float* pre, const void* whh, int B, int T, int hidden, void* h, void* gates, float* c, void* stream) {
+    return lstm_fwd_launch(pre, pre, whh, B, T, hidden, 0, T, h, gates, c, 1, stream);
+}
+
+extern "C" int sehip_rlstm_bwd(const void* dh, const void* whhT, const void* gates, const float* c, int B, int T, int hidden, void* dpre,
+                               void* stream) {
+    return lstm_bwd_launch(dh, dh, whhT, gates, c, B, T, hidden, 0, T, nullptr, dpre, dpre, 1, stream);
 }

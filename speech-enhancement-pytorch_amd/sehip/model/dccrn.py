@@ -1,7 +1,7 @@
 """Drop-in DCCRN module on libsehip (reference: src/model/dccrn.py:10-246).
 
 Same constructor arguments, same `forward(x[B,1,N]) -> [B,1,length]`, same state_dict keys/shapes (204 entries incl.
-the persistent stft/istft buffers at the defaults; rnn_layers 1 .. 8, rnn_units 128 / 256, any win_type, use_cbn either way), so checkpoints of the reference load here and vice versa.  Differences by design:
+the persistent stft/istft buffers at the defaults; rnn_layers 1 .. 8, rnn_units 128 / 256, any win_type, use_cbn / use_clstm either way), so checkpoints of the reference load here and vice versa.  Differences by design:
   * all parameters are views into ONE flat fp32 buffer (`flat_params`), gradients into one flat buffer
     (`flat_grads`) -- one RCCL all-reduce, one fused clip+Adam launch;
   * forward/backward run the hand-written HIP kernels through the C ABI; there is no PyTorch/CPU fallback:
@@ -22,7 +22,7 @@ _STATIC_CACHE = {}
 def _static_for(cfg, deterministic=False):
     # (the experiment switches that DCCRNStatic reads when it is built are part of the key)
     switches = tuple(os.environ.get(k) for k in ("SEHIP_NO_FUSE_STATS", "SEHIP_NO_FUSE_STATS64", "SEHIP_NO_FUSE_STATS32", "SEHIP_DEC_SPLIT"))
-    key = (tuple(cfg.kernel_num), cfg.rnn_layers, cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, str(cfg.win_type), bool(cfg.use_cbn), switches,
+    key = (tuple(cfg.kernel_num), cfg.rnn_layers, cfg.rnn_units, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.length, cfg.masking_mode, str(cfg.win_type), bool(cfg.use_cbn), bool(cfg.use_clstm), switches,
            bool(deterministic))
     if key not in _STATIC_CACHE:
         _STATIC_CACHE[key] = plan.DCCRNStatic(cfg, deterministic=deterministic)
@@ -98,9 +98,9 @@ class DCCRN(FlatModule):
                     p.uniform_(-0.9, 0.9)
                 elif name.endswith("2.weight"):
                     p.fill_(0.25)
-                elif "lstm" in name:
+                elif "lstm" in name or name.startswith("enhance."):     # (use_clstm=False: `enhance` is the nn.LSTM itself)
                     p.uniform_(-1.0 / h ** 0.5, 1.0 / h ** 0.5)
-                elif "trans" in name:
+                elif "trans" in name or name.startswith("tranform."):   # (sic: the reference's attribute name, src/model/dccrn.py:106)
                     p.uniform_(-1.0 / h ** 0.5, 1.0 / h ** 0.5)
                 else:
                     raise KeyError(name)

@@ -93,8 +93,9 @@ class DCCRNConfig:
     def __init__(self, rnn_layers=2, rnn_units=128, win_len=400, win_inc=100, fft_len=512, length=16384,
                  win_type="hann", masking_mode="E", use_clstm=True, use_cbn=True, kernel_size=5,
                  kernel_num=(16, 32, 64, 128, 256, 256), **_ignored):
-        if not use_clstm:
-            raise SehipError("sehip DCCRN implements the reference default use_clstm=True only")
+        # use_clstm=False (round 6): one real nn.LSTM over all channels, hidden rnn_units, ALWAYS two layers (src/model/dccrn.py:98-106
+        # passes num_layers=2 whatever rnn_layers says), and the `tranform` Linear; csrc/lstm.hip with one recurrence per launch
+        self.use_clstm = bool(use_clstm)
         # use_cbn=False (round 6): nn.BatchNorm2d over the [real half | imaginary half] channels (src/model/dccrn.py:110-113, :130-133) on
         # the ComplexBatchNorm kernels with the cross covariance taken as zero (csrc/cbn.hip cbn_fwd_record: eps < 0 selects it)
         self.use_cbn = bool(use_cbn)
@@ -106,11 +107,13 @@ class DCCRNConfig:
             raise SehipError("sehip DCCRN: only kernel_size=5 is built")
         if not 1 <= int(rnn_layers) <= 8:
             raise SehipError("sehip DCCRN: rnn_layers must be 1 .. 8")
-        if rnn_units not in (128, 256):
+        if self.use_clstm and rnn_units not in (128, 256):
             raise SehipError("sehip DCCRN: rnn_units must be 128 or 256 (LSTM hidden 64 / 128: the sizes csrc/lstm.hip is built for)")
+        if not self.use_clstm and rnn_units not in (64, 128):
+            raise SehipError("sehip DCCRN(use_clstm=False): rnn_units must be 64 or 128 (the hidden sizes csrc/lstm.hip is built for)")
         if masking_mode not in ("E", "C", "R"):
             raise SehipError(f"unknown masking_mode {masking_mode}")
-        self.rnn_layers, self.rnn_units = rnn_layers, rnn_units
+        self.rnn_layers, self.rnn_units = (rnn_layers if self.use_clstm else 2), rnn_units
         self.win_len, self.win_inc, self.fft_len, self.length = win_len, win_inc, fft_len, length
         self.masking_mode = masking_mode
         self.kernel_size = kernel_size
@@ -122,7 +125,7 @@ class DCCRNConfig:
         for c in self.kernel_num[1:]:
             if c % 16 or (c & (c - 1)):
                 raise SehipError(f"sehip DCCRN: channel counts must be powers of two >= 16, got {kernel_num}")
-        self.hid = rnn_units // 2
+        self.hid = rnn_units // 2 if self.use_clstm else rnn_units
         self.lstm_in = self.hidden_dim * self.kernel_num[-1] // 2  # per real/imag part
 
     def param_specs(self):
@@ -161,6 +164,15 @@ class DCCRNConfig:
             if idx != 1:
                 bn(f"decoder.{j}.", cout)
         h = self.hid
+        if not self.use_clstm:
+            for layer in range(2):
+                out.append((f"enhance.weight_ih_l{layer}", (4 * h, 2 * self.lstm_in if layer == 0 else h), "param"))
+                out.append((f"enhance.weight_hh_l{layer}", (4 * h, h), "param"))
+                out.append((f"enhance.bias_ih_l{layer}", (4 * h,), "param"))
+                out.append((f"enhance.bias_hh_l{layer}", (4 * h,), "param"))
+            out.append(("tranform.weight", (2 * self.lstm_in, h), "param"))
+            out.append(("tranform.bias", (2 * self.lstm_in,), "param"))
+            return out
         for layer in range(self.rnn_layers):
             nin = self.lstm_in if layer == 0 else h
             for part in ("real_lstm", "imag_lstm"):
@@ -644,80 +656,120 @@ class DCCRNStatic:
         h = cfg.hid
         lstm = ("real_lstm", "imag_lstm")
 
-        def ih(layer, l):
-            return ia(f"enhance.{layer}.{lstm[l]}.weight_ih_l0")
+        if not cfg.use_clstm:
+            # ---- use_clstm=False (src/model/dccrn.py:98-106, :184-189): ONE real nn.LSTM over all c5 channels, two layers, hidden
+            #      rnn_units, and the `tranform` Linear back to 4 * c5 features.  Feature index of the reference: c * 4 + f.
+            def bias_pairs_real(layer):
+                bp = np.empty((4 * h, 2), dtype=np.int32)
+                bp[:, 0] = enc_entry(ia(f"enhance.bias_ih_l{layer}"), 0)
+                bp[:, 1] = enc_entry(ia(f"enhance.bias_hh_l{layer}"), 0)
+                return bp
 
-        def bias_pairs_lstm(layer):
-            bp = np.empty((2 * 4 * h, 2), dtype=np.int32)
-            for l in (0, 1):
-                bp[l * 4 * h:(l + 1) * 4 * h, 0] = enc_entry(ia(f"enhance.{layer}.{lstm[l]}.bias_ih_l0"), 0)
-                bp[l * 4 * h:(l + 1) * 4 * h, 1] = enc_entry(ia(f"enhance.{layer}.{lstm[l]}.bias_hh_l0"), 0)
-            return bp
-
-        zero = lambda a: np.zeros_like(a)
-        # layer 1 input products: x[(f,c)] with reference feature index c*4+f  (src/model/dccrn.py:170-176)
-        w1 = np.concatenate([ih(0, l).reshape(4 * h, cp, 4).transpose(0, 2, 1).reshape(4 * h, -1) for l in (0, 1)])  # [512,(f,c)]
-        for q, tag in enumerate("ri"):
+            zero = lambda a: np.zeros_like(a)
+            w1 = ia("enhance.weight_ih_l0").reshape(4 * h, c5, 4).transpose(0, 2, 1).reshape(4 * h, -1)      # [4h, (f, c)]
             rows = []
             for f in range(4):
-                rows += wide_chunks(0, 0, f, q * cp, cp)
-            self.specs[f"ih1_{tag}"] = GemmSpec(f"ih1_{tag}", rows, w1, zero(w1), 8 * h, bias_pairs_lstm(0), "T", 1, 1,
-                                                [("z5", "all")], [(f"pre1_{tag}", 0, 1, 0)])
-            # dx1: d z5[b,t,f,q*cp+c] = dpre1_q @ W
-            nt = np.zeros((4 * cp // 4, 4), dtype=np.int32)
-            for n4 in range(4 * cp // 4):
-                f, c = divmod(4 * n4, cp)
-                nt[n4] = (0, f * c5 + q * cp + c, 4, 0)
-            self.specs[f"dx1_{tag}"] = GemmSpec(f"dx1_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w1.T.copy(), zero(w1.T), 4 * cp,
-                                                None, "T", 1, 1, [(f"dpre1_{tag}", "all")], [("dz5l", 0, 1, 0)], ntab=nt,
-                                                kind="dgrad", res="dskip5" if FUSE_SKIP_GRAD else None)
-            # (res: the gradient that arrived over the innermost skip connection is added where the LSTM's input gradient is stored
-            #  -- each of the two products adds it to its own half of the columns -- so that encoder 5's BatchNorm backward reads one
-            #  gradient tensor like every other layer's: its apply pass 91 -> 60 us)
-        # layer 2 input products and the projection: x2_r = h1[r,real] - h1[i,imag]; x2_i = h1[i,real] + h1[r,imag]
-        combos = {"r": (0, 3, 1), "i": (2, 1, 0)}  # (first combo, second combo, negate second)
-        # (the reference stacks rnn_layers of them, src/model/dccrn.py:86-96; every layer behind the first reads the one before it this way)
-        L = cfg.rnn_layers
-        for tag, (ca, cb, ng) in combos.items():
-            rows = wide_chunks(0, 0, 0, 0, h) + wide_chunks(1, 0, 0, 0, h)
-            for layer in range(2, L + 1):
-                w2 = np.concatenate([ih(layer - 1, l) for l in (0, 1)])  # [512, 64]
-                wi = np.concatenate([w2, w2], 1)
-                wn = np.concatenate([zero(w2), zero(w2) + ng], 1)
-                self.specs[f"ih{layer}_{tag}"] = GemmSpec(f"ih{layer}_{tag}", rows, wi, wn, 8 * h, bias_pairs_lstm(layer - 1), "T", 1, 1,
-                                                          [(f"h{layer - 1}_{ca}", "all"), (f"h{layer - 1}_{cb}", "all")],
-                                                          [(f"pre{layer}_{tag}", 0, 1, 0)])
-                self.specs[f"dx{layer}_{tag}"] = GemmSpec(f"dx{layer}_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w2.T.copy(), zero(w2.T), h,
-                                                          None, "T", 1, 1, [(f"dpre{layer}_{tag}", "all")],
-                                                          [(f"dx{layer}_{tag}", 0, 1, 0)], kind="dgrad")
-            q = 0 if tag == "r" else 1
-            tr = ia(f"enhance.{L - 1}.{tag}_trans.weight")        # [cp*4, h], row c*4+d
-            trb = ia(f"enhance.{L - 1}.{tag}_trans.bias")
-            wt = tr.reshape(cp, 4, h).transpose(1, 0, 2).reshape(4 * cp, h)   # row n' = d*cp + c
-            bt = trb.reshape(cp, 4).T.reshape(-1)
-            bp = np.full((4 * cp, 2), -1, dtype=np.int32)
-            bp[:, 0] = enc_entry(bt, 0)
-            nt = np.zeros((4 * cp // 4, 4), dtype=np.int32)
-            for n4 in range(4 * cp // 4):
-                d, c = divmod(4 * n4, cp)
-                nt[n4] = (0, d * c5 + q * cp + c, 4, 0)
-            self.specs[f"proj_{tag}"] = GemmSpec(f"proj_{tag}", rows, np.concatenate([wt, wt], 1),
-                                                 np.concatenate([zero(wt), zero(wt) + ng], 1), 4 * cp, bp, "T", 1, 1,
-                                                 [(f"h{L}_{ca}", "all"), (f"h{L}_{cb}", "all")], [("P", 0, 1, 0)], ntab=nt)
+                rows += wide_chunks(0, 0, f, 0, c5)
+            self.specs["ih1"] = GemmSpec("ih1", rows, w1, zero(w1), 4 * h, bias_pairs_real(0), "T", 1, 1, [("z5", "all")],
+                                         [("pre1", 0, 1, 0)])
+            self.specs["dx1"] = GemmSpec("dx1", wide_chunks(0, 0, 0, 0, 4 * h), w1.T.copy(), zero(w1.T), 4 * c5, None, "T", 1, 1,
+                                         [("dpre1", "all")], [("dz5l", 0, 1, 0)], kind="dgrad", res="dskip5" if FUSE_SKIP_GRAD else None)
+            w2 = ia("enhance.weight_ih_l1")
+            self.specs["ih2"] = GemmSpec("ih2", wide_chunks(0, 0, 0, 0, h), w2, zero(w2), 4 * h, bias_pairs_real(1), "T", 1, 1,
+                                         [("h1_0", "all")], [("pre2", 0, 1, 0)])
+            self.specs["dx2"] = GemmSpec("dx2", wide_chunks(0, 0, 0, 0, 4 * h), w2.T.copy(), zero(w2.T), h, None, "T", 1, 1,
+                                         [("dpre2", "all")], [("dx2", 0, 1, 0)], kind="dgrad")
+            tr = ia("tranform.weight")                       # [c5 * 4, h], row c * 4 + d
+            wt = tr.reshape(c5, 4, h).transpose(1, 0, 2).reshape(4 * c5, h)          # row n' = d * c5 + c = the column of P
+            bp = np.full((4 * c5, 2), -1, dtype=np.int32)
+            bp[:, 0] = enc_entry(ia("tranform.bias").reshape(c5, 4).T.reshape(-1), 0)
+            self.specs["proj"] = GemmSpec("proj", wide_chunks(0, 0, 0, 0, h), wt, zero(wt), 4 * c5, bp, "T", 1, 1, [("h2_0", "all")],
+                                          [("P", 0, 1, 0)])
             rows = []
             for d in range(4):
-                rows += wide_chunks(0, 0, d, q * cp, cp)
-            self.specs[f"dproj_{tag}"] = GemmSpec(f"dproj_{tag}", rows, wt.T.copy(), zero(wt.T), h, None, "T", 1, 1,
-                                                  [("dP", "all")], [(f"dxo_{tag}", 0, 1, 0)], kind="dgrad")
-        # recurrent weight gradients: dW_hh[n,k] = sum dpre[b,t,n] h[b,t-1,k]
-        for layer in range(1, L + 1):
-            for combo in range(4):
-                part, l = combo >> 1, combo & 1
-                hh = ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0")
-                nt = dense_ntab(4 * h, 4 * h, 0, l * 4 * h)
-                self.specs[f"hh{layer}_{combo}"] = GemmSpec(f"hh{layer}_{combo}", wide_chunks(0, -1, 0, 0, h), hh, zero(hh),
-                                                            4 * h, None, "T", 1, 1, [(f"h{layer}_{combo}", "all")],
-                                                            [(f"dpre{layer}_{'ri'[part]}", 0, 1, 0)], ntab=nt, kind="wgrad_only")
+                rows += wide_chunks(0, 0, d, 0, c5)
+            self.specs["dproj"] = GemmSpec("dproj", rows, wt.T.copy(), zero(wt.T), h, None, "T", 1, 1, [("dP", "all")],
+                                           [("dxo", 0, 1, 0)], kind="dgrad")
+            for layer in (1, 2):
+                hh = ia(f"enhance.weight_hh_l{layer - 1}")
+                self.specs[f"hh{layer}"] = GemmSpec(f"hh{layer}", wide_chunks(0, -1, 0, 0, h), hh, zero(hh), 4 * h, None, "T", 1, 1,
+                                                    [(f"h{layer}_0", "all")], [(f"dpre{layer}", 0, 1, 0)],
+                                                    ntab=dense_ntab(4 * h, 4 * h, 0, 0), kind="wgrad_only")
+        else:
+            def ih(layer, l):
+                return ia(f"enhance.{layer}.{lstm[l]}.weight_ih_l0")
+
+            def bias_pairs_lstm(layer):
+                bp = np.empty((2 * 4 * h, 2), dtype=np.int32)
+                for l in (0, 1):
+                    bp[l * 4 * h:(l + 1) * 4 * h, 0] = enc_entry(ia(f"enhance.{layer}.{lstm[l]}.bias_ih_l0"), 0)
+                    bp[l * 4 * h:(l + 1) * 4 * h, 1] = enc_entry(ia(f"enhance.{layer}.{lstm[l]}.bias_hh_l0"), 0)
+                return bp
+
+            zero = lambda a: np.zeros_like(a)
+            # layer 1 input products: x[(f,c)] with reference feature index c*4+f  (src/model/dccrn.py:170-176)
+            w1 = np.concatenate([ih(0, l).reshape(4 * h, cp, 4).transpose(0, 2, 1).reshape(4 * h, -1) for l in (0, 1)])  # [512,(f,c)]
+            for q, tag in enumerate("ri"):
+                rows = []
+                for f in range(4):
+                    rows += wide_chunks(0, 0, f, q * cp, cp)
+                self.specs[f"ih1_{tag}"] = GemmSpec(f"ih1_{tag}", rows, w1, zero(w1), 8 * h, bias_pairs_lstm(0), "T", 1, 1,
+                                                    [("z5", "all")], [(f"pre1_{tag}", 0, 1, 0)])
+                # dx1: d z5[b,t,f,q*cp+c] = dpre1_q @ W
+                nt = np.zeros((4 * cp // 4, 4), dtype=np.int32)
+                for n4 in range(4 * cp // 4):
+                    f, c = divmod(4 * n4, cp)
+                    nt[n4] = (0, f * c5 + q * cp + c, 4, 0)
+                self.specs[f"dx1_{tag}"] = GemmSpec(f"dx1_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w1.T.copy(), zero(w1.T), 4 * cp,
+                                                    None, "T", 1, 1, [(f"dpre1_{tag}", "all")], [("dz5l", 0, 1, 0)], ntab=nt,
+                                                    kind="dgrad", res="dskip5" if FUSE_SKIP_GRAD else None)
+                # (res: the gradient that arrived over the innermost skip connection is added where the LSTM's input gradient is stored
+                #  -- each of the two products adds it to its own half of the columns -- so that encoder 5's BatchNorm backward reads one
+                #  gradient tensor like every other layer's: its apply pass 91 -> 60 us)
+            # layer 2 input products and the projection: x2_r = h1[r,real] - h1[i,imag]; x2_i = h1[i,real] + h1[r,imag]
+            combos = {"r": (0, 3, 1), "i": (2, 1, 0)}  # (first combo, second combo, negate second)
+            # (the reference stacks rnn_layers of them, src/model/dccrn.py:86-96; every layer behind the first reads the one before it this way)
+            L = cfg.rnn_layers
+            for tag, (ca, cb, ng) in combos.items():
+                rows = wide_chunks(0, 0, 0, 0, h) + wide_chunks(1, 0, 0, 0, h)
+                for layer in range(2, L + 1):
+                    w2 = np.concatenate([ih(layer - 1, l) for l in (0, 1)])  # [512, 64]
+                    wi = np.concatenate([w2, w2], 1)
+                    wn = np.concatenate([zero(w2), zero(w2) + ng], 1)
+                    self.specs[f"ih{layer}_{tag}"] = GemmSpec(f"ih{layer}_{tag}", rows, wi, wn, 8 * h, bias_pairs_lstm(layer - 1), "T", 1, 1,
+                                                              [(f"h{layer - 1}_{ca}", "all"), (f"h{layer - 1}_{cb}", "all")],
+                                                              [(f"pre{layer}_{tag}", 0, 1, 0)])
+                    self.specs[f"dx{layer}_{tag}"] = GemmSpec(f"dx{layer}_{tag}", wide_chunks(0, 0, 0, 0, 8 * h), w2.T.copy(), zero(w2.T), h,
+                                                              None, "T", 1, 1, [(f"dpre{layer}_{tag}", "all")],
+                                                              [(f"dx{layer}_{tag}", 0, 1, 0)], kind="dgrad")
+                q = 0 if tag == "r" else 1
+                tr = ia(f"enhance.{L - 1}.{tag}_trans.weight")        # [cp*4, h], row c*4+d
+                trb = ia(f"enhance.{L - 1}.{tag}_trans.bias")
+                wt = tr.reshape(cp, 4, h).transpose(1, 0, 2).reshape(4 * cp, h)   # row n' = d*cp + c
+                bt = trb.reshape(cp, 4).T.reshape(-1)
+                bp = np.full((4 * cp, 2), -1, dtype=np.int32)
+                bp[:, 0] = enc_entry(bt, 0)
+                nt = np.zeros((4 * cp // 4, 4), dtype=np.int32)
+                for n4 in range(4 * cp // 4):
+                    d, c = divmod(4 * n4, cp)
+                    nt[n4] = (0, d * c5 + q * cp + c, 4, 0)
+                self.specs[f"proj_{tag}"] = GemmSpec(f"proj_{tag}", rows, np.concatenate([wt, wt], 1),
+                                                     np.concatenate([zero(wt), zero(wt) + ng], 1), 4 * cp, bp, "T", 1, 1,
+                                                     [(f"h{L}_{ca}", "all"), (f"h{L}_{cb}", "all")], [("P", 0, 1, 0)], ntab=nt)
+                rows = []
+                for d in range(4):
+                    rows += wide_chunks(0, 0, d, q * cp, cp)
+                self.specs[f"dproj_{tag}"] = GemmSpec(f"dproj_{tag}", rows, wt.T.copy(), zero(wt.T), h, None, "T", 1, 1,
+                                                      [("dP", "all")], [(f"dxo_{tag}", 0, 1, 0)], kind="dgrad")
+            # recurrent weight gradients: dW_hh[n,k] = sum dpre[b,t,n] h[b,t-1,k]
+            for layer in range(1, L + 1):
+                for combo in range(4):
+                    part, l = combo >> 1, combo & 1
+                    hh = ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0")
+                    nt = dense_ntab(4 * h, 4 * h, 0, l * 4 * h)
+                    self.specs[f"hh{layer}_{combo}"] = GemmSpec(f"hh{layer}_{combo}", wide_chunks(0, -1, 0, 0, h), hh, zero(hh),
+                                                                4 * h, None, "T", 1, 1, [(f"h{layer}_{combo}", "all")],
+                                                                [(f"dpre{layer}_{'ri'[part]}", 0, 1, 0)], ntab=nt, kind="wgrad_only")
 
         # ---------------- arenas: packed weights / biases / gradient regions / tables ----------------
         wa, ba, ga = Arena(64), Arena(16), Arena(16)
@@ -740,12 +792,15 @@ class DCCRNStatic:
                     s.db_off = ga.reserve(s.Npad)
         # recurrent weights for the LSTM kernels: whh [layer][lstm][256][64], whhT [layer][lstm][64][256]
         self.whh_off, self.whhT_off = {}, {}
-        for layer in range(1, L + 1):
-            hh = np.stack([ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0") for l in (0, 1)])
+        for layer in range(1, cfg.rnn_layers + 1):
+            if cfg.use_clstm:
+                hh = np.stack([ia(f"enhance.{layer - 1}.{lstm[l]}.weight_hh_l0") for l in (0, 1)])
+            else:
+                hh = ia(f"enhance.weight_hh_l{layer - 1}")
             self.whh_off[layer] = wa.add(enc_entry(hh, 0).reshape(-1))
-            self.whhT_off[layer] = wa.add(enc_entry(hh.transpose(0, 2, 1), 0).reshape(-1))
+            self.whhT_off[layer] = wa.add(enc_entry(np.swapaxes(hh, -1, -2), 0).reshape(-1))
         # layer 2's input weights for the fused two-layer recurrence (csrc/lstm2.hip): wih2 [lstm][256][64], wihT2 [lstm][64][256]
-        if L == 2 and h == 64:
+        if cfg.use_clstm and cfg.rnn_layers == 2 and h == 64:
             ih2 = np.stack([ia(f"enhance.1.{lstm[l]}.weight_ih_l0") for l in (0, 1)])
             self.wih2_off = wa.add(enc_entry(ih2, 0).reshape(-1))
             self.wihT2_off = wa.add(enc_entry(ih2.transpose(0, 2, 1), 0).reshape(-1))
@@ -884,14 +939,22 @@ class DCCRNWorkspace:
         c5, h = kn[6], cfg.hid
         add("dz5l", T, 4, c5); add("P", T, 4, c5); add("dP", T, 4, c5)
         L = cfg.rnn_layers
-        for layer in range(1, L + 1):
+        if not cfg.use_clstm:        # one real recurrence per layer (sehip_rlstm_fwd / _bwd): no (real, imaginary) x (real_lstm, imag_lstm) combos
+            for layer in (1, 2):
+                add(f"pre{layer}", T, 1, 4 * h, dtype=torch.float32)
+                add(f"dpre{layer}", T, 1, 4 * h)
+                add(f"h{layer}", T, 1, h, lead=1)
+                add(f"gates{layer}", T, 1, 4 * h, lead=1, batch=Bp)
+                add(f"c{layer}", T, 1, h, dtype=torch.float32, lead=1, batch=Bp)
+            add("dxo", T, 1, h); add("dx2", T, 1, h)
+        for layer in range(1, L + 1 if cfg.use_clstm else 0):
             for tag in "ri":
                 add(f"pre{layer}_{tag}", T, 1, 8 * h, dtype=torch.float32)
                 add(f"dpre{layer}_{tag}", T, 1, 8 * h)
             add(f"h{layer}", T, 1, h, lead=4)
             add(f"gates{layer}", T, 1, 4 * h, lead=4, batch=Bp)
             add(f"c{layer}", T, 1, h, dtype=torch.float32, lead=4, batch=Bp)
-        for tag in "ri":
+        for tag in ("ri" if cfg.use_clstm else ""):
             add(f"dxo_{tag}", T, 1, h)
             for layer in range(2, L + 1):
                 add(f"dx{layer}_{tag}", T, 1, h)
@@ -998,7 +1061,7 @@ class DCCRNWorkspace:
         # hand-off time-out (check_lstm_handoffs) return to the two launches per direction of round 3.
         # (rnn_layers != 2 or rnn_units != 128: one launch per layer and direction, the products between them on the chain)
         self.lstm_fused = (len(self.lstm_chunks) == 1 and not os.environ.get("SEHIP_NO_LSTM_FUSE") and T < 65535
-                           and st.cfg.rnn_layers == 2 and st.cfg.hid == 64)
+                           and st.cfg.rnn_layers == 2 and st.cfg.hid == 64 and st.cfg.use_clstm)
         self.l2_epoch = 0
         self.graph_epoch = 0         # bumped when captured launches of this workspace go stale (fall-back after a hand-off time-out)
         if self.lstm_fused:
@@ -1233,6 +1296,8 @@ class DCCRNWorkspace:
         call("sehip_wgrad_pair", C.byref(self.desc[a + ".wg"]), C.byref(self.desc[b + ".wg"]), self.side.cuda_stream)
 
     def _lstm_wgrad_names(self, layers):
+        if not self.st.cfg.use_clstm:
+            return [nm for layer in layers for nm in (f"ih{layer}", f"hh{layer}")]
         return [nm for layer in layers for nm in [f"ih{layer}_{tag}" for tag in "ri"] + [f"hh{layer}_{combo}" for combo in range(4)]]
 
     def _wgrad_group_handle(self, names):
@@ -1313,6 +1378,11 @@ class DCCRNWorkspace:
             units.append(pair("sehip_wgrad_pair", f"dec{i}.fwd0.wg", f"dec{i}.fwd1.wg"))
             if i > 0:
                 units.append(pair("sehip_gemm_pair", f"enc{i}.dg0", f"enc{i}.dg1"))
+        if not self.st.cfg.use_clstm:         # one real nn.LSTM: single products, per-layer weight-gradient groups
+            for nm in ("ih1", "ih2", "proj", "dproj", "dx2", "dx1"):
+                units.append(one("sehip_gemm", nm))
+            units += [one("sehip_wgrad", nm + ".wg") for nm in ["proj"] + self._lstm_wgrad_names((2, 1))]
+            return units
         for a, b in (("ih1_r", "ih1_i"), ("proj_r", "proj_i"), ("dproj_r", "dproj_i"), ("dx1_r", "dx1_i")):
             units.append(pair("sehip_gemm_pair", a, b))
         nl = self.st.cfg.rnn_layers
@@ -1468,6 +1538,13 @@ class DCCRNWorkspace:
     def _lstm_forward(self, B, T, h):
         self._chain_dirty = True
         main = stream()
+        if not self.st.cfg.use_clstm:
+            b, wp = self.bufs, self.tb.wpack.data_ptr()
+            for layer in (1, 2):
+                self.gemm(f"ih{layer}")
+                call("sehip_rlstm_fwd", b[f"pre{layer}"].ptr, wp + 2 * self.st.whh_off[layer], B, T, h, b[f"h{layer}"].ptr,
+                     b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, main)
+            return
         self.gemm_pair("ih1_r", "ih1_i")
         if self.lstm_fused:
             b, st, tb = self.bufs, self.st, self.tb
@@ -1504,6 +1581,16 @@ class DCCRNWorkspace:
     def _lstm_backward(self, B, T, h):
         self._chain_dirty = True
         main = stream()
+        if not self.st.cfg.use_clstm:
+            b, wp = self.bufs, self.tb.wpack.data_ptr()
+            for layer in (2, 1):
+                dh = b["dxo"] if layer == 2 else b["dx2"]
+                call("sehip_rlstm_bwd", dh.ptr, wp + 2 * self.st.whhT_off[layer], b[f"gates{layer}"].ptr, b[f"c{layer}"].ptr, B, T, h,
+                     b[f"dpre{layer}"].ptr, main)
+                self._chain_dirty = True
+                self.wgrad_group(self._lstm_wgrad_names((layer,)))
+                self.gemm(f"dx{layer}")
+            return
         if self.lstm_fused:
             b, st, tb = self.bufs, self.st, self.tb
             wp = tb.wpack.data_ptr()
@@ -1582,7 +1669,10 @@ class DCCRNWorkspace:
                 call("sehip_gemm_pair", C.byref(self.desc[f"dec{j}.fs0"]), C.byref(self.desc[f"dec{j}.fs1"]), sd)
                 call("sehip_event_record", self._fs_events[j], sd)
         self._lstm_forward(B, T, h)
-        self.gemm_pair("proj_r", "proj_i")
+        if cfg.use_clstm:
+            self.gemm_pair("proj_r", "proj_i")
+        else:
+            self.gemm("proj")
         for j in range(6):
             if j in split:
                 call("sehip_stream_wait_event", stream(), self._fs_events[j])
@@ -1619,9 +1709,13 @@ class DCCRNWorkspace:
             if j >= 1 and f"decoder.{j - 1}." in self.bnr_rows:
                 self.desc[f"dec{j}.dg"].bnr_slope = params.data_ptr() + 4 * st.layout.param_off[f"decoder.{j - 1}.2.weight"][0]
             self.gemm(f"dec{j}.dg")
-        for tag in "ri":
-            self.wgrad(f"proj_{tag}")
-        self.gemm_pair("dproj_r", "dproj_i")
+        if cfg.use_clstm:
+            for tag in "ri":
+                self.wgrad(f"proj_{tag}")
+            self.gemm_pair("dproj_r", "dproj_i")
+        else:
+            self.wgrad("proj")
+            self.gemm("dproj")
         self._lstm_backward(B, T, h)
         n_params = st.layout.n_params
         lo = st.layout.param_off["decoder.0.0.real_conv.weight"][0] if range_ready is not None else 0

@@ -182,7 +182,8 @@ def test_hip_vs_reference_full_size_checksum():
 
 @pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("none", dict(win_type=None)),
                                         ("blackman", dict(win_type="blackman")), ("realbn", dict(use_cbn=False)),
-                                        ("rnn1", dict(rnn_layers=1)), ("rnn3", dict(rnn_layers=3)), ("ru256", dict(rnn_units=256))])
+                                        ("rnn1", dict(rnn_layers=1)), ("rnn3", dict(rnn_layers=3)), ("ru256", dict(rnn_units=256)),
+                                        ("reallstm", dict(use_clstm=False))])
 def test_hip_window_types_against_reference_vectors(case, extra):
     """win_type of the reference constructor (src/model/dccrn.py:20; init_kernels :650-653: ones for None, else
     scipy.signal.get_window) on the HIP path -- the window is data for the FFT front end -- against what the imported reference

@@ -57,10 +57,11 @@ def test_two_deterministic_runs_are_bit_identical(tmp_path, kernel_num, n, b):
     assert rel < 3e-2
 
 
-def test_a_deeper_wider_recurrent_stack_is_bit_identical_too(tmp_path):
+@pytest.mark.parametrize("extra", [dict(rnn_layers=3, rnn_units=256), dict(use_clstm=False)])
+def test_other_recurrent_stacks_are_bit_identical_too(tmp_path, extra):
     """rnn_layers=3, rnn_units=256 (round 6: one launch per layer and direction, csrc/lstm.hip at hidden 128; the recurrent weight
-    gradients one by one under the deterministic schedule): two runs of three steps, bit for bit."""
-    extra = dict(rnn_layers=3, rnn_units=256)
+    gradients one by one under the deterministic schedule) and use_clstm=False (one real two-layer nn.LSTM, sehip_rlstm_fwd / _bwd):
+    two runs of three steps, bit for bit."""
     a = run(tmp_path, True, (16, 16, 32, 32, 64, 64), 4000, 3, extra=extra)
     c = run(tmp_path, True, (16, 16, 32, 32, 64, 64), 4000, 3, extra=extra)
     assert a[0] == c[0], (a[0], c[0])

@@ -165,6 +165,42 @@ def test_complex_lstm_other_depths_and_widths(layers, units):
     _check_complex_lstm(build_run(dict(SMALL, rnn_layers=layers, rnn_units=units), 3, 4000))
 
 
+@pytest.mark.parametrize("units", [128, 64])
+def test_real_lstm_forward_backward(units):
+    """DCCRN(use_clstm=False) (src/model/dccrn.py:98-106, :184-189): one real two-layer nn.LSTM over all channels + the `tranform`
+    Linear -- sehip_rlstm_fwd / _bwd and the products around them against the oracle's explicit recurrence with the same bf16 rounding
+    points, from the HIP path's z5 and dP."""
+    import torch.nn.functional as F
+    run = build_run(dict(SMALL, use_clstm=False, rnn_units=units), 3, 4000)
+    ws, p = run["ws"], run["p"]
+    b, B, T = ws.bufs, run["B"], run["T"]
+    z5 = to_ref(b["z5"])                                  # [B,C,4,T]
+    ch = z5.shape[1]
+    x = z5.permute(3, 0, 1, 2).reshape(T, B, -1).requires_grad_(True)
+    names = [k for k in p if k.startswith(("enhance.", "tranform."))]
+    assert len(names) == 10
+    leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+    y = x
+    for layer in range(2):
+        y = O.lstm_single(y, leaves[f"enhance.weight_ih_l{layer}"], leaves[f"enhance.weight_hh_l{layer}"],
+                          leaves[f"enhance.bias_ih_l{layer}"], leaves[f"enhance.bias_hh_l{layer}"], O.Bf16Sim)
+    y = F.linear(y, O.Bf16Sim.weight(leaves["tranform.weight"]), leaves["tranform.bias"])
+    out = y.reshape(T, B, ch, 4).permute(1, 2, 3, 0)      # [B,C,4,T]
+    assert rel_err(to_ref(b["P"]), out.detach()) < 1e-2
+    dP = to_ref(b["dP"])
+    outs = torch.autograd.grad((out * dP).sum(), [x] + [leaves[k] for k in names])
+    from sehip.plan import FUSE_SKIP_GRAD
+    dz5, floor = to_ref(b["dz5l"]), 0.0
+    if FUSE_SKIP_GRAD:
+        floor = 2.0 ** -9 * float(dz5.norm() + to_ref(b["dskip5"]).norm()) / 2 ** 0.5
+        dz5 = dz5 - to_ref(b["dskip5"])
+    e = float((dz5.permute(3, 0, 1, 2).reshape(T, B, -1) - outs[0]).norm())
+    assert e < 3e-2 * float(outs[0].norm()) + floor, (e, float(outs[0].norm()), floor)
+    G = run["grads"]
+    for k, gref in zip(names, outs[1:]):
+        assert rel_err(G[k], gref) < 3e-2, k
+
+
 def _check_complex_lstm(run):
     ws, p, cfg = run["ws"], run["p"], run["cfg"]
     b, B, T = ws.bufs, run["B"], run["T"]

@@ -328,7 +328,8 @@ def test_demucs_resampler_properties():
 # ---- constructor options beyond the shipped YAML (round 6): tests/golden/dccrn_variants.npz (oracle/gen_golden_dccrn_variants.py)
 @pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("none", dict(win_type=None)),
                                         ("blackman", dict(win_type="blackman")), ("realbn", dict(use_cbn=False)),
-                                        ("rnn1", dict(rnn_layers=1)), ("rnn3", dict(rnn_layers=3)), ("ru256", dict(rnn_units=256))])
+                                        ("rnn1", dict(rnn_layers=1)), ("rnn3", dict(rnn_layers=3)), ("ru256", dict(rnn_units=256)),
+                                        ("reallstm", dict(use_clstm=False))])
 def test_window_types_against_reference(case, extra):
     """Constructor options of the reference beyond the shipped YAML (src/model/dccrn.py:12-27): win_type (init_kernels :650-653),
     use_cbn=False (nn.BatchNorm2d instead of ComplexBatchNorm, :110-113) and rnn_layers (:84-96): the oracle against the imported reference's waveform, loss,
