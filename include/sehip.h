@@ -530,7 +530,7 @@ int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf
                           int Cs, int T, void* dmlin_bf16, float* dw_dec, float* gacc, float* scratch, void* stream);
 
 /* ---- recurrent part of NavieComplexLSTM: src/model/dccrn.py:264-302 (four nn.LSTM passes of one complex layer in one
- *      persistent launch; hidden size H = 64 or 128, i.e. rnn_units 128 / 256; the shapes below are written for 64).
+ *      persistent launch; hidden size H = 32, 64, 96 or 128, i.e. rnn_units 64 ... 256; the shapes below are written for 64).
  *      pre*: [B][T][2 lstm * 4 H] gates from the input GEMMs (fp32); h: [4 combos][B][T][H]; combo = part*2 + lstm.  gates / c are
  *      records private to the backward kernel, sized [4][ceil(B/4)*4][T][4 H] bf16 and [4][ceil(B/4)*4][T][H] fp32. */
 int sehip_lstm_fwd(const float* pre_r, const float* pre_i, const void* whh_bf16 /*[2][256][64]*/, int B, int T, int hidden,
@@ -548,7 +548,7 @@ int sehip_lstm_bwd_chunk(const void* dh_a_bf16, const void* dh_b_bf16, const voi
                          void* dpre_i_bf16, void* stream);
 /* One plain nn.LSTM layer (unidirectional, zero initial state): the recurrent part of DCCRN(use_clstm=False), src/model/dccrn.py:98-106
  * (`self.enhance = nn.LSTM(..., num_layers=2)`) as called at :184-189 -- the same kernels as above with ONE recurrence per launch.
- *   pre : fp32 [B][T][4 H] = x @ W_ih^T + b_ih + b_hh;  whh : bf16 [4 H][H];  h : bf16 [B][T][H];  hidden H = 64 or 128
+ *   pre : fp32 [B][T][4 H] = x @ W_ih^T + b_ih + b_hh;  whh : bf16 [4 H][H];  h : bf16 [B][T][H];  hidden H = 32, 64, 96 or 128
  *   gates / c : records for the backward call, [ceil(B/4)*4][T][4 H] bf16 / [ceil(B/4)*4][T][H] fp32
  *   backward: dh bf16 [B][T][H] (gradient of h), whhT bf16 [H][4 H] -> dpre bf16 [B][T][4 H] */
 int sehip_rlstm_fwd(const float* pre, const void* whh_bf16, int B, int T, int hidden, void* h_bf16, void* gates_bf16, float* c, void* stream);

@@ -14,8 +14,8 @@
 #include "common.h"
 
 // The kernels are written for a hidden size H that is a multiple of 32 (H / 16 waves of 64 lanes, 4 H threads: one (unit, batch row)
-// pair per lane); instantiated for 64 (rnn_units = 128, the reference default, src/model/dccrn.py:13) and 128 (rnn_units = 256, the
-// DCCRN paper's complex LSTM).
+// pair per lane); instantiated for 32, 64 (rnn_units = 128, the reference default, src/model/dccrn.py:13), 96 and 128 (rnn_units = 256,
+// the DCCRN paper's complex LSTM).
 #define NBT 4    // batch rows per workgroup
 #define PD 8     // prefetch distance of the per-step inputs in time steps (2: 4.74 ms per step, 4: 4.68, 8: 4.63, 16: 4.65)
 
@@ -229,35 +229,38 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const bf16_raw* __restr
 
 static int lstm_fwd_launch(const float* pre0, const float* pre1, const void* whh, int B, int T, int hidden, int t0, int t1, void* h,
                            void* gates, float* c, int real, void* stream) {
-    SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_fwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
+    SEHIP_REQUIRE(hidden == 32 || hidden == 64 || hidden == 96 || hidden == 128, "lstm_fwd: hidden size 32, 64, 96 or 128, got %d", hidden);
     SEHIP_REQUIRE(B > 0 && T > 0, "lstm_fwd: empty input");
     SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_fwd: bad step range [%d, %d) of %d", t0, t1, T);
     const int grid = (real ? 1 : 4) * cdiv(B, NBT);
-    if (hidden == 64)
-        lstm_fwd_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1, (bf16_raw*)h,
-                                                                 (bf16_raw*)gates, c, real);
-    else
-        lstm_fwd_kernel<128><<<grid, 512, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1, (bf16_raw*)h,
-                                                                  (bf16_raw*)gates, c, real);
+#define LSTM_FWD(HH)                                                                                                              \
+    lstm_fwd_kernel<HH><<<grid, 4 * HH, 0, (hipStream_t)stream>>>(pre0, pre1, (const bf16_raw*)whh, B, T, t0, t1, (bf16_raw*)h, \
+                                                                 (bf16_raw*)gates, c, real)
+    if (hidden == 32) LSTM_FWD(32);
+    else if (hidden == 64) LSTM_FWD(64);
+    else if (hidden == 96) LSTM_FWD(96);
+    else LSTM_FWD(128);
+#undef LSTM_FWD
     SEHIP_CHECK_LAUNCH("lstm_fwd");
     return 0;
 }
 
 static int lstm_bwd_launch(const void* dh_a, const void* dh_b, const void* whhT, const void* gates, const float* c, int B, int T,
                            int hidden, int t0, int t1, float* state, void* dpre0, void* dpre1, int real, void* stream) {
-    SEHIP_REQUIRE(hidden == 64 || hidden == 128, "lstm_bwd: hidden size 64 or 128 (rnn_units 128 / 256), got %d", hidden);
+    SEHIP_REQUIRE(hidden == 32 || hidden == 64 || hidden == 96 || hidden == 128, "lstm_bwd: hidden size 32, 64, 96 or 128, got %d", hidden);
     SEHIP_REQUIRE(B > 0 && T > 0, "lstm_bwd: empty input");
     SEHIP_REQUIRE(0 <= t0 && t0 < t1 && t1 <= T, "lstm_bwd: bad step range [%d, %d) of %d", t0, t1, T);
     SEHIP_REQUIRE(state != nullptr || (t0 == 0 && t1 == T), "lstm_bwd: a partial step range needs the state buffer");
     const int grid = (real ? 1 : 4) * cdiv(B, NBT);
-    if (hidden == 64)
-        lstm_bwd_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT,
-                                                                 (const bf16_raw*)gates, c, B, T, t0, t1, state, (bf16_raw*)dpre0,
-                                                                 (bf16_raw*)dpre1, real);
-    else
-        lstm_bwd_kernel<128><<<grid, 512, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT,
-                                                                  (const bf16_raw*)gates, c, B, T, t0, t1, state, (bf16_raw*)dpre0,
-                                                                  (bf16_raw*)dpre1, real);
+#define LSTM_BWD(HH)                                                                                                                    \
+    lstm_bwd_kernel<HH><<<grid, 4 * HH, 0, (hipStream_t)stream>>>((const bf16_raw*)dh_a, (const bf16_raw*)dh_b, (const bf16_raw*)whhT, \
+                                                                 (const bf16_raw*)gates, c, B, T, t0, t1, state, (bf16_raw*)dpre0,    \
+                                                                 (bf16_raw*)dpre1, real)
+    if (hidden == 32) LSTM_BWD(32);
+    else if (hidden == 64) LSTM_BWD(64);
+    else if (hidden == 96) LSTM_BWD(96);
+    else LSTM_BWD(128);
+#undef LSTM_BWD
     SEHIP_CHECK_LAUNCH("lstm_bwd");
     return 0;
 }

@@ -1,7 +1,7 @@
 """Drop-in DCCRN module on libsehip (reference: src/model/dccrn.py:10-246).
 
 Same constructor arguments, same `forward(x[B,1,N]) -> [B,1,length]`, same state_dict keys/shapes (204 entries incl.
-the persistent stft/istft buffers at the defaults; rnn_layers 1 .. 8, rnn_units 128 / 256, any win_type, use_cbn / use_clstm either way), so checkpoints of the reference load here and vice versa.  Differences by design:
+the persistent stft/istft buffers at the defaults; rnn_layers 1 .. 8, rnn_units 64 ... 256, any win_type, use_cbn / use_clstm either way), so checkpoints of the reference load here and vice versa.  Differences by design:
   * all parameters are views into ONE flat fp32 buffer (`flat_params`), gradients into one flat buffer
     (`flat_grads`) -- one RCCL all-reduce, one fused clip+Adam launch;
   * forward/backward run the hand-written HIP kernels through the C ABI; there is no PyTorch/CPU fallback:

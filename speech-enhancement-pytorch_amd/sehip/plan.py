@@ -107,10 +107,11 @@ class DCCRNConfig:
             raise SehipError("sehip DCCRN: only kernel_size=5 is built")
         if not 1 <= int(rnn_layers) <= 8:
             raise SehipError("sehip DCCRN: rnn_layers must be 1 .. 8")
-        if self.use_clstm and rnn_units not in (128, 256):
-            raise SehipError("sehip DCCRN: rnn_units must be 128 or 256 (LSTM hidden 64 / 128: the sizes csrc/lstm.hip is built for)")
-        if not self.use_clstm and rnn_units not in (64, 128):
-            raise SehipError("sehip DCCRN(use_clstm=False): rnn_units must be 64 or 128 (the hidden sizes csrc/lstm.hip is built for)")
+        if self.use_clstm and rnn_units not in (64, 128, 192, 256):
+            raise SehipError("sehip DCCRN: rnn_units must be 64, 128, 192 or 256 (LSTM hidden 32 / 64 / 96 / 128: the sizes csrc/lstm.hip "
+                             "is built for)")
+        if not self.use_clstm and rnn_units not in (32, 64, 96, 128):
+            raise SehipError("sehip DCCRN(use_clstm=False): rnn_units must be 32, 64, 96 or 128 (the hidden sizes csrc/lstm.hip is built for)")
         if masking_mode not in ("E", "C", "R"):
             raise SehipError(f"unknown masking_mode {masking_mode}")
         self.rnn_layers, self.rnn_units = (rnn_layers if self.use_clstm else 2), rnn_units

@@ -158,14 +158,14 @@ def test_complex_lstm_forward_backward(run):
     _check_complex_lstm(run)
 
 
-@pytest.mark.parametrize("layers,units", [(1, 128), (3, 128), (2, 256), (3, 256)])
+@pytest.mark.parametrize("layers,units", [(1, 128), (3, 128), (2, 256), (3, 256), (2, 64), (2, 192)])
 def test_complex_lstm_other_depths_and_widths(layers, units):
     """rnn_layers / rnn_units of the reference constructor (src/model/dccrn.py:12-13, the stack :84-96): the same op-local gate for the
     per-layer launches (csrc/lstm.hip at hidden 64 / 128) and the products between the layers."""
     _check_complex_lstm(build_run(dict(SMALL, rnn_layers=layers, rnn_units=units), 3, 4000))
 
 
-@pytest.mark.parametrize("units", [128, 64])
+@pytest.mark.parametrize("units", [128, 64, 32, 96])
 def test_real_lstm_forward_backward(units):
     """DCCRN(use_clstm=False) (src/model/dccrn.py:98-106, :184-189): one real two-layer nn.LSTM over all channels + the `tranform`
     Linear -- sehip_rlstm_fwd / _bwd and the products around them against the oracle's explicit recurrence with the same bf16 rounding

@@ -66,7 +66,7 @@ def test_forward_loss_backward_vs_oracle(b, n, kw):
 def test_rejects_what_is_not_built():
     from sehip.model import DCCRN
     from sehip import SehipError
-    for bad in (dict(rnn_units=64), dict(kernel_num=[8, 16, 32, 64, 128, 128]), dict(kernel_size=3), dict(use_clstm=False, rnn_units=256),
+    for bad in (dict(rnn_units=80), dict(kernel_num=[8, 16, 32, 64, 128, 128]), dict(kernel_size=3), dict(use_clstm=False, rnn_units=256),
                 dict(win_type="no-such-window")):       # (any scipy.signal.get_window name / None is built since round 6)
         with pytest.raises(SehipError):
             DCCRN(**bad)
