@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void dcunet_mask_bwd_kernel(const float2* __re
     // part != NULL (deterministic schedule): this workgroup's 2 Cs + 2 sums go to row (z, y, x) of `part` by plain stores and
     // dcunet_rows_reduce_kernel adds the rows in order, instead of one fp32 atomic per weight and workgroup
     __shared__ float2 tile[DT][DP];      // in: the mask; out: d linear, [frame][bin]
-    __shared__ float red[4][16][16];     // per wave: [piece q][8 a-sums | 8 b-sums]
+    __shared__ float red[4][32][16];     // per wave: [piece q < nq <= 32][8 a-sums | 8 b-sums]
     const int r = blockIdx.z, t0 = blockIdx.x * DT, f0 = blockIdx.y * DT;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float2* mw = mask_ws + (size_t)r * T * F;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void dcunet_tail_apply_kernel(const float2* __
 
 static int check_dcu(const char* who, int R, int F, int T, int Cs, int Cr, int mode) {
     SEHIP_REQUIRE(R > 0 && F > 0 && T > 0, "%s: empty input", who);
-    SEHIP_REQUIRE(Cs >= 8 && Cs <= 64 && (Cs & (Cs - 1)) == 0 && Cr >= 1 && Cr <= Cs, "%s: bad channel counts Cs=%d Cr=%d", who, Cs, Cr);
+    SEHIP_REQUIRE(Cs >= 8 && Cs <= 128 && (Cs & (Cs - 1)) == 0 && Cr >= 1 && Cr <= Cs, "%s: bad channel counts Cs=%d Cr=%d", who, Cs, Cr);
     SEHIP_REQUIRE(mode >= 0 && mode <= 2, "%s: masking mode must be 0(E) 1(C) 2(R)", who);
     return 0;
 }

@@ -5,8 +5,8 @@ produces with stft_custom (src/solver.py:454-458), same state_dict keys -- inclu
 every block (``encoder{i}.*`` through add_module AND ``encoders.{i}.*`` through the ModuleList, src/model/dcunet.py:74-76,
 99-100), so its checkpoints load here and vice versa.  Parameters are views into one flat fp32 buffer (one RCCL all-reduce,
 one fused clip + Adam launch); forward / backward run the HIP kernels through the C ABI; a CPU tensor raises SehipError.
-Built: the complex network (data_type=True), model_depth 10, zero padding, masking modes E / C / R, up to 64 complex channels
-(model_complexity <= 45).
+Built: the complex network (data_type=True), model_depth 10 and 20, zero padding, masking modes E / C / R, up to 128 stored complex
+channels (model_complexity <= 90: 63 / 126 channels, the paper's "Large" network).
 """
 import math
 import os

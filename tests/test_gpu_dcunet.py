@@ -314,6 +314,41 @@ def test_masking_modes_and_rejections():
         DCUnet(data_type=False)
 
 
+def test_large_dcunet_complexity_90():
+    """model_complexity=90 (63 / 126 complex channels, stored as 64 / 128: the widest the plan accepts -- the "Large" DCUnet of the
+    paper; src/model/dcunet.py:64-65, :165-213): train-mode forward against the fp32 oracle on the same weights, and the separate mask /
+    BatchNorm kernels (SEHIP_DCUNET_NO_TAIL: dcunet_mask_bwd at 32 pieces per row) against the fused tail.  The op-local float64 gates
+    at this width: tests/test_gpu_dcunet_fullwidth.py[complexity90]."""
+    import os
+    from sehip.model import DCUnet
+    from sehip.loss import mse_loss
+    g = torch.Generator().manual_seed(5)
+    x = 0.5 * torch.randn(2, 1, 257, 33, 2, generator=g)
+    tgt = 0.5 * torch.randn(2, 1, 257, 33, 2, generator=g)
+    runs = {}
+    for fused in (True, False):
+        old = os.environ.pop("SEHIP_DCUNET_NO_TAIL", None)
+        if not fused:
+            os.environ["SEHIP_DCUNET_NO_TAIL"] = "1"
+        try:
+            torch.manual_seed(6)
+            model = DCUnet(data_type=True, model_complexity=90, model_depth=10)
+            sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            model = model.cuda().train()
+            est = model(x.cuda())
+        finally:
+            os.environ.pop("SEHIP_DCUNET_NO_TAIL", None)
+            if old is not None:
+                os.environ["SEHIP_DCUNET_NO_TAIL"] = old
+        mse_loss(est, tgt.cuda()).backward()
+        torch.cuda.synchronize()
+        assert model.workspace(2, 257, 33).fused_tail == fused
+        runs[fused] = (est.detach().cpu(), torch.cat([p.grad.detach().reshape(-1).cpu() for p in model.parameters()]), sd)
+    ref = D.dcunet_forward(runs[True][2], x, model_complexity=90, model_depth=10, training=True)
+    assert rel_err(runs[True][0], ref) < 3e-2 and rel_err(runs[False][0], ref) < 3e-2
+    assert rel_err(runs[False][1], runs[True][1]) < 2e-2       # (the two tails round the last decoder's gradient at different points)
+
+
 def c2_config(tmp, complexity=45):
     from sehip.utils import dict2obj
     return dict2obj({

@@ -42,9 +42,10 @@ def out_err(got, want):
     return rel_err(got, want), float(((got - want).abs() / (want.abs() + floor)).max())
 
 
-@pytest.fixture(scope="module")
-def full():
-    """One forward / backward of the full-width DCUnet-10 through libsehip with the DEFAULT plan (fused tail, the 192-column tile of
+@pytest.fixture(scope="module", params=[45, 90], ids=["complexity45", "complexity90"])
+def full(request):
+    """(complexity 90 = the "Large" DCUnet of the paper: 63 / 126 complex channels stored as 64 / 128 -- the widest the plan accepts;
+    the same gates.)  One forward / backward of the full-width DCUnet-10 through libsehip with the DEFAULT plan (fused tail, the 192-column tile of
     the last decoder's input gradient, the encoders' weight gradients by tap-parity class -- here from 256 rows per utterance so
     that encoder 1 AND 2 take them at 65 frames)."""
     from sehip.model import DCUnet
@@ -53,7 +54,7 @@ def full():
     os.environ["SEHIP_DCUNET_ENC_WG_MIN"] = "256"
     try:
         torch.manual_seed(21)
-        model = DCUnet(data_type=True, model_complexity=CPLX, model_depth=10)
+        model = DCUnet(data_type=True, model_complexity=request.param, model_depth=10)
         p = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith(("encoders.", "decoders."))}
         model = model.cuda().train()
         g = torch.Generator().manual_seed(22)
@@ -72,12 +73,14 @@ def full():
     assert ws.fused_tail, "this file checks the default plan (run it without SEHIP_DCUNET_NO_TAIL)"
     kinds = {name: ws.last_kernel.get(name, "") for name in getattr(ws, "last_kernel", {})} if hasattr(ws, "last_kernel") else {}
     grads = {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters()}
-    return dict(model=model, ws=ws, est=est.detach().cpu(), grads=grads, p=p, x=x, tgt=tgt, sz=D.dcunet_sizes(CPLX, 10, 1), kinds=kinds)
+    return dict(model=model, ws=ws, est=est.detach().cpu(), grads=grads, p=p, x=x, tgt=tgt, sz=D.dcunet_sizes(request.param, 10, 1), kinds=kinds, cplx=request.param)
 
 
 def test_the_default_plan_is_the_one_under_test(full):
     """The products this file is about are really in the plan: the 192-column input gradient of the last decoder and the tap-parity
     weight-gradient classes of encoder 1 and 2."""
+    if full["cplx"] != 45:
+        pytest.skip("the 192-column tile and the class counts below are the complexity-45 shapes")
     pl = full["ws"].pl
     assert any(n.startswith("enc1.wg") for n in pl.enc_wg[1]) and len(pl.enc_wg[1]) == 4, pl.enc_wg[1]
     assert any(n.startswith("enc2.wg") for n in pl.enc_wg[2]) and len(pl.enc_wg[2]) == 4, pl.enc_wg[2]
