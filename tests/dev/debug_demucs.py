@@ -1,10 +1,10 @@
-"""Debug aid: Demucs HIP path vs the CPU oracle, layer by layer (run on the GPU box: python tools/debug_demucs.py)."""
+"""Debug aid: Demucs HIP path vs the CPU oracle, layer by layer (run on the GPU box: python tests/dev/debug_demucs.py)."""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "speech-enhancement-pytorch_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import demucs_oracle as DM  # noqa: E402
 from oracle import dccrn_oracle as O  # noqa: E402

@@ -2,7 +2,7 @@
 """Where does the ConvTasNet full-width gradient error come from?  Per residual block: relative error of the residual-stream
 gradient dx_b (HIP bf16 buffer vs the oracle's autograd through its taps) and of the block's parameter gradients."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "speech-enhancement-pytorch_amd")); sys.path.insert(0, ROOT)
 import torch
 from oracle import convtasnet_oracle as CT

@@ -2,7 +2,7 @@
 """stft_custom / istft_custom at the DCUNet configuration (BASELINE configs[2]: 64 x 32768 samples, 512/128/512):
 HIP-event time per call, achieved HBM rate against the algorithmic bytes, and the numpy oracle on the host beside it."""
 import json, os, sys, time, types
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "speech-enhancement-pytorch_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from sehip.evaluate import stft_custom, istft_custom

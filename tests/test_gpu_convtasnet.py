@@ -139,7 +139,7 @@ def test_full_width_model_vs_oracle():
     got = {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters()}
     glob, worst = compare(got, torch.autograd.grad((ref * G).sum(), [leaves[k] for k in names], retain_graph=True), "fixed upstream gradient")
     # measured 5.1e-2 / 0.17 -- and already 6 % for the mask convolution's weight, the FIRST weight gradient of the backward pass
-    # (tools/debug_tasnet_grads.py): the difference is not rounding accumulated over the 14 blocks but the branches of the mask
+    # (tests/dev/debug_tasnet_grads.py): the difference is not rounding accumulated over the 14 blocks but the branches of the mask
     # ReLU and of the 28 PReLUs: ~1 % of the near-zero pre-activations have the other sign in the bf16 forward, and under a random G
     # the reference gradient is an incoherent sum that such flips perturb by sqrt(fraction flipped)
     assert glob < 8e-2 and worst < 0.25
