@@ -608,7 +608,7 @@ def main():
                          "convtasnet = configs[4] (2-speaker separation, 8 kHz 4-s clips, B=32 per GPU); demucs = configs[3] (48 kHz stereo "
                          "2-s clips, B=16 per GPU)")
     ap.add_argument("--kernel-num", default="", help="DCCRN only: six comma-separated channel counts instead of the headline's "
-                    "16,32,64,128,256,256 (e.g. the reference YAML's commented 'paper' widths 32,64,128,256,256,256, "
+                    "16,32,64,128,256,256 (e.g. the reference YAML's commented 'paper' widths 32,64,128,128,256,256, "
                     "src/conf/config.yaml:86-88).  A side measurement: implies --no-roofline --no-cpu-baseline --no-traffic, and the "
                     "line's config.workload names the widths")
     ap.add_argument("--rnn-units", type=int, default=128, help="DCCRN only: 256 = the complex LSTM of the DCCRN paper (hidden 128 per "
