@@ -524,6 +524,12 @@ long sehip_ctn_gln_bwd_scratch_floats(int M, int K, int C);
 int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
                       const float* Wd, int P, int dilation, int dw, int M, int K, int C, double* sums, float* gch, void* dh, float* dslope,
                       float* scratch, void* stream);
+/* mask_nonlinear='softmax' (src/model/conv_tasnet.py:298-299: F.softmax(score, dim=1) over the Cs <= 8 sources): score / out bf16
+ * [rows = M * K][Cs][N].  The decoder entry points below take `out` as their mask logits (their relu is the identity on it); what
+ * sehip_ctn_decoder_bwd writes for it is the gradient of the mask, which sehip_ctn_mask_softmax_bwd turns into the gradient of the
+ * scores IN PLACE: g_c <- s_c (g_c - sum_c' s_c' g_c'). */
+int sehip_ctn_mask_softmax_fwd(const void* score_bf16, long rows, int Cs, int N, void* out_bf16, void* stream);
+int sehip_ctn_mask_softmax_bwd(const void* soft_bf16, void* g_bf16, long rows, int Cs, int N, void* stream);
 int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac, int Cs, int T,
                           float* out, void* stream);
 int sehip_ctn_decoder_bwd(const float* dout, const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac,

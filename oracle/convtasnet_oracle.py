@@ -69,7 +69,7 @@ def temporal_block(x, p, pre, dilation, P, masks=None, sim=NoSim):
 
 
 def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2, audio_channels=1, taps=None, act_masks=None,
-                       sim=NoSim):
+                       sim=NoSim, mask_nonlinear="relu"):
     """mixture [M, ac, T] -> separated sources [M, C, ac, T] (src/model/conv_tasnet.py:136-154).
     act_masks (tests only): {"block{r}.{i}": (mask1, mask2), "mask": mask} -- given branches of the PReLUs / the mask ReLU.
     sim=Bf16Sim (tests only): bf16 storage at the HIP path's layer boundaries (cLN output, bottleneck, the five tensors of every
@@ -87,7 +87,10 @@ def convtasnet_forward(p, mixture, C=2, N=128, L=40, B=128, H=256, P=3, X=7, R=2
                 taps[f"block{r}.{i}"] = x
     m, n, k = w.shape
     score = sim.act(F.conv1d(x, sim.weight(p[net + "3.weight"]))).view(m, C, n, k)
-    mask = F.relu(score) if act_masks is None else score * act_masks["mask"].to(score.dtype)
+    if mask_nonlinear == "softmax":         # src/model/conv_tasnet.py:298-299: over the sources (the HIP path stores it in bf16)
+        mask = sim.act(F.softmax(score, dim=1))
+    else:
+        mask = F.relu(score) if act_masks is None else score * act_masks["mask"].to(score.dtype)
     src_w = (w.unsqueeze(1) * mask).transpose(2, 3)                                        # [M, C, K, N]
     est = F.linear(src_w, p["decoder.basis_signals.weight"])                               # [M, C, K, ac*L]
     est = est.view(m, C, k, audio_channels, L).transpose(2, 3)

@@ -133,6 +133,8 @@ _PROTOS = {
     "sehip_ctn_gln_apply": [P, P, P, P, P, I, I, I, P, P],
     "sehip_ctn_gln_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P],
     "sehip_ctn_gln_bwd_scratch_floats": [I, I, I],
+    "sehip_ctn_mask_softmax_fwd": [P, L, I, I, P, P],
+    "sehip_ctn_mask_softmax_bwd": [P, P, L, I, I, P],
     "sehip_ctn_decoder_fwd": [P, P, P, I, I, I, I, I, I, I, P, P],
     "sehip_ctn_decoder_bwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P],
     "sehip_dmx_prep": [P, I, I, I, I, I, I, I, I, P, I, I, P, P, P, P],

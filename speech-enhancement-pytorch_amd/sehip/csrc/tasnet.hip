@@ -1432,6 +1432,97 @@ extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slop
     return 0;
 }
 
+// mask_nonlinear='softmax' (src/model/conv_tasnet.py:298-299: est_mask = F.softmax(score, dim=1), over the Cs sources): a pass of its own
+// between the mask product and the decoder.  The decoder kernels take the result as their "mask logits": their relu is the identity
+// on a softmax output, and what sehip_ctn_decoder_bwd returns for it is the gradient of the MASK, which ctn_mask_softmax_bwd turns
+// into the gradient of the scores in place:  d score_c = s_c (g_c - sum_c' s_c' g_c').
+// rows = M * K frames of [Cs][N] values; one thread per (frame, 8 neighbouring n), the Cs sources in registers.
+#define CTN_SOFTMAX_MAX_C 8
+__global__ __launch_bounds__(256) void ctn_mask_softmax_fwd_kernel(const bf16_raw* __restrict__ score, long rows, int Cs, int N,
+                                                                   bf16_raw* __restrict__ out) {
+    const int n8 = N >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * n8; i += (long)gridDim.x * 256) {
+        const long r = i / n8;
+        const int q = (int)(i - r * n8);
+        const bf16_raw* sp = score + r * ((long)Cs * N) + 8 * q;
+        C8 x[CTN_SOFTMAX_MAX_C];
+        float mx[8], sum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mx[j] = -3.0e38f; sum[j] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < CTN_SOFTMAX_MAX_C; ++c)
+            if (c < Cs) {
+                x[c] = unpack8(ld8raw(sp + (long)c * N));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], x[c].v[j]);
+            }
+#pragma unroll
+        for (int c = 0; c < CTN_SOFTMAX_MAX_C; ++c)
+            if (c < Cs) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { x[c].v[j] = __expf(x[c].v[j] - mx[j]); sum[j] += x[c].v[j]; }
+            }
+#pragma unroll
+        for (int c = 0; c < CTN_SOFTMAX_MAX_C; ++c)
+            if (c < Cs) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = x[c].v[j] / sum[j];
+                st8(out + r * ((long)Cs * N) + (long)c * N + 8 * q, o);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void ctn_mask_softmax_bwd_kernel(const bf16_raw* __restrict__ soft, bf16_raw* __restrict__ g, long rows, int Cs,
+                                                                   int N) {
+    const int n8 = N >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * n8; i += (long)gridDim.x * 256) {
+        const long r = i / n8;
+        const int q = (int)(i - r * n8);
+        const long base = r * ((long)Cs * N) + 8 * q;
+        C8 s[CTN_SOFTMAX_MAX_C], d[CTN_SOFTMAX_MAX_C];
+        float dot[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CTN_SOFTMAX_MAX_C; ++c)
+            if (c < Cs) {
+                s[c] = unpack8(ld8raw(soft + base + (long)c * N));
+                d[c] = unpack8(ld8raw(g + base + (long)c * N));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot[j] += s[c].v[j] * d[c].v[j];
+            }
+#pragma unroll
+        for (int c = 0; c < CTN_SOFTMAX_MAX_C; ++c)
+            if (c < Cs) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = s[c].v[j] * (d[c].v[j] - dot[j]);
+                st8(g + base + (long)c * N, o);
+            }
+    }
+}
+
+static int ctn_softmax_grid(long items) { long gsz = (items + 255) / 256; return (int)(gsz > 4096 ? 4096 : gsz < 1 ? 1 : gsz); }
+
+extern "C" int sehip_ctn_mask_softmax_fwd(const void* score_bf16, long rows, int Cs, int N, void* out_bf16, void* stream) {
+    SEHIP_REQUIRE(rows > 0 && Cs >= 1 && Cs <= CTN_SOFTMAX_MAX_C && N > 0 && N % 8 == 0, "ctn_mask_softmax_fwd: rows=%ld Cs=%d (1..8) N=%d (multiple of 8)",
+                  rows, Cs, N);
+    ctn_mask_softmax_fwd_kernel<<<ctn_softmax_grid(rows * (N >> 3)), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)score_bf16, rows, Cs, N,
+                                                                                                  (bf16_raw*)out_bf16);
+    SEHIP_CHECK_LAUNCH("ctn_mask_softmax_fwd");
+    return 0;
+}
+
+extern "C" int sehip_ctn_mask_softmax_bwd(const void* soft_bf16, void* g_bf16, long rows, int Cs, int N, void* stream) {
+    SEHIP_REQUIRE(rows > 0 && Cs >= 1 && Cs <= CTN_SOFTMAX_MAX_C && N > 0 && N % 8 == 0, "ctn_mask_softmax_bwd: rows=%ld Cs=%d (1..8) N=%d (multiple of 8)",
+                  rows, Cs, N);
+    ctn_mask_softmax_bwd_kernel<<<ctn_softmax_grid(rows * (N >> 3)), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)soft_bf16, (bf16_raw*)g_bf16, rows,
+                                                                                                  Cs, N);
+    SEHIP_CHECK_LAUNCH("ctn_mask_softmax_bwd");
+    return 0;
+}
+
 extern "C" int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, const float* V, int M, int K, int N, int L, int ac, int Cs, int T,
                                      float* out /*zeroed by the caller*/, void* stream) {
     SEHIP_REQUIRE(M > 0 && K > 0 && Cs > 0 && ac > 0, "ctn_decoder_fwd: empty input");

@@ -25,9 +25,12 @@ class TasNetConfig:
 
     def __init__(self, sources, N=128, L=40, B=128, H=256, P=3, X=7, R=2, audio_channels=2, norm_type="gLN", causal=False,
                  mask_nonlinear="relu", sample_rate=44100, segment_length=44100 * 2 * 4, skip=False, **_ignored):
-        if skip or norm_type != "gLN" or causal or mask_nonlinear != "relu":
-            raise SehipError("sehip ConvTasNet: the shipped options (skip=False, norm_type='gLN', causal=False, "
-                             "mask_nonlinear='relu') are built")
+        if skip or norm_type != "gLN" or causal or mask_nonlinear not in ("relu", "softmax"):
+            raise SehipError("sehip ConvTasNet: the shipped options (skip=False, norm_type='gLN', causal=False) with "
+                             "mask_nonlinear='relu' or 'softmax' are built")
+        if mask_nonlinear == "softmax" and len(sources) > 8:
+            raise SehipError("sehip ConvTasNet: mask_nonlinear='softmax' is built for at most 8 sources")
+        self.mask_nonlinear = mask_nonlinear
         if P != 3:
             raise SehipError("sehip ConvTasNet: only kernel size P=3 is built")
         for name, v in (("N", N), ("B", B), ("H", H)):
@@ -43,7 +46,7 @@ class TasNetConfig:
         self.audio_channels = audio_channels
 
     def key(self):
-        return (self.C, self.N, self.L, self.B, self.H, self.P, self.X, self.R, self.audio_channels)
+        return (self.C, self.N, self.L, self.B, self.H, self.P, self.X, self.R, self.audio_channels, self.mask_nonlinear)
 
     def blocks(self):
         return [(r, x) for r in range(self.R) for x in range(self.X)]
@@ -198,6 +201,8 @@ class TasNetWorkspace:
         for name in sorted({st.du_name(b) for b in range(nb)} | {st.dh2_name(b) for b in range(nb)}):
             add(name, H)
         add("mlin", cfg.C * N); add("dmlin", cfg.C * N)
+        if cfg.mask_nonlinear == "softmax":      # the mask itself, between the mask product's scores and the decoder (sehip_ctn_mask_softmax_fwd)
+            add("msoft", cfg.C * N)
         self.w = torch.empty(M, K, N, dtype=torch.float32, device=device)
         self.dw_dec = torch.empty(M, K, N, dtype=torch.float32, device=device)
         self.out = torch.zeros(M, cfg.C, cfg.audio_channels, T, dtype=torch.float32, device=device)
@@ -340,7 +345,11 @@ class TasNetWorkspace:
         self.gemm("mask.fwd")
         if not self._one_clear:
             self.out.zero_()
-        call("sehip_ctn_decoder_fwd", ptr(self.w), b["mlin"].ptr, pp("decoder.basis_signals.weight"), M, K, N, cfg.L, cfg.audio_channels,
+        mk = b["mlin"]
+        if cfg.mask_nonlinear == "softmax":
+            call("sehip_ctn_mask_softmax_fwd", b["mlin"].ptr, M * K, cfg.C, N, b["msoft"].ptr, stream())
+            mk = b["msoft"]
+        call("sehip_ctn_decoder_fwd", ptr(self.w), mk.ptr, pp("decoder.basis_signals.weight"), M, K, N, cfg.L, cfg.audio_channels,
              cfg.C, self.T, ptr(self.out), stream())
         return self.out
 
@@ -357,8 +366,11 @@ class TasNetWorkspace:
             self.bsums.zero_()
         self._bwd_clean = False
         self._chain_dirty = True
-        call("sehip_ctn_decoder_bwd", ptr(dout), ptr(self.w), b["mlin"].ptr, pp("decoder.basis_signals.weight"), M, K, N, cfg.L,
-             cfg.audio_channels, cfg.C, self.T, b["dmlin"].ptr, ptr(self.dw_dec), gp(st.dec_g_off), ptr(self.codec_scratch), stream())
+        soft = cfg.mask_nonlinear == "softmax"
+        call("sehip_ctn_decoder_bwd", ptr(dout), ptr(self.w), (b["msoft"] if soft else b["mlin"]).ptr, pp("decoder.basis_signals.weight"), M, K, N,
+             cfg.L, cfg.audio_channels, cfg.C, self.T, b["dmlin"].ptr, ptr(self.dw_dec), gp(st.dec_g_off), ptr(self.codec_scratch), stream())
+        if soft:        # what came back is the gradient of the mask: through the softmax, in place
+            call("sehip_ctn_mask_softmax_bwd", b["msoft"].ptr, b["dmlin"].ptr, M * K, cfg.C, N, stream())
         self.wgrad("mask.fwd")
         self.gemm("mask.dg")
         for i in range(nb - 1, -1, -1):

@@ -20,12 +20,14 @@ def cl(x):
     return x.detach().transpose(1, 2)
 
 
-@pytest.fixture(scope="module")
-def tiny():
+@pytest.fixture(scope="module", params=["relu", "softmax"])
+def tiny(request):
+    """(softmax: mask_nonlinear='softmax', src/model/conv_tasnet.py:298-299, against its own vectors of the imported reference,
+    tests/golden/convtasnet_tiny_softmax.npz)"""
     from sehip.model import ConvTasNet
     from sehip.loss import loss_sisdr
-    g = load_golden("convtasnet_tiny.npz")
-    model = ConvTasNet(sources=["None", "None"], **TINY)
+    g = load_golden("convtasnet_tiny.npz" if request.param == "relu" else "convtasnet_tiny_softmax.npz")
+    model = ConvTasNet(sources=["None", "None"], mask_nonlinear=request.param, **TINY)
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
     model.load_state_dict(sd)
     model = model.cuda().train()
@@ -65,6 +67,27 @@ def test_whole_chain_vs_reference_vectors(tiny):
     for e, n, k in rows:
         if n > 0.05 * gn:
             assert e < 0.25 * n, (k, e, n)
+
+
+@pytest.mark.parametrize("rows,Cs,N", [(37, 2, 16), (101, 3, 24), (64, 8, 128)])
+def test_softmax_mask_kernels_op_local(rows, Cs, N):
+    """sehip_ctn_mask_softmax_fwd / _bwd (F.softmax over the sources, src/model/conv_tasnet.py:298-299) against float64 on the same
+    bf16 operands: the stored mask within one bf16 rounding, the in-place gradient g_c <- s_c (g_c - sum s g) likewise."""
+    from sehip import _lib
+    gen = torch.Generator().manual_seed(rows)
+    score = (3.0 * torch.randn(rows, Cs, N, generator=gen)).to(torch.bfloat16).cuda()
+    out = torch.empty_like(score)
+    _lib.call("sehip_ctn_mask_softmax_fwd", score.data_ptr(), rows, Cs, N, out.data_ptr(), _lib.stream())
+    want = torch.softmax(score.double(), dim=1)
+    torch.cuda.synchronize()
+    assert float(((out.double() - want).abs() / want).max()) < 2.0 ** -8 * 1.05
+    g = torch.randn(rows, Cs, N, generator=gen).to(torch.bfloat16).cuda()
+    gd, sd = g.double(), out.double()
+    wantg = sd * (gd - (sd * gd).sum(1, keepdim=True))
+    _lib.call("sehip_ctn_mask_softmax_bwd", out.data_ptr(), g.data_ptr(), rows, Cs, N, _lib.stream())
+    torch.cuda.synchronize()
+    err = (g.double() - wantg).abs()
+    assert float((err / (wantg.abs() + 1e-3 * float(wantg.abs().mean()))).max()) < 2.0 ** -8 * 1.05 + 1e-4
 
 
 def test_encoder_cln_op_local(tiny):

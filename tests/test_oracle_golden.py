@@ -250,10 +250,12 @@ def test_dcunet20_oracle_matches_reference():
 
 
 # ---- ConvTasNet: oracle/convtasnet_oracle.py vs the reference's activations / gradients
-def test_convtasnet_oracle_matches_reference():
+@pytest.mark.parametrize("fixture,extra", [("convtasnet_tiny.npz", {}), ("convtasnet_tiny_softmax.npz", dict(mask_nonlinear="softmax"))])
+def test_convtasnet_oracle_matches_reference(fixture, extra):
+    """(softmax: mask_nonlinear='softmax', src/model/conv_tasnet.py:298-299 -- F.softmax over the sources)"""
     from oracle import convtasnet_oracle as CT
-    g = load_golden("convtasnet_tiny.npz")
-    kw = dict(C=2, N=16, L=8, B=16, H=32, P=3, X=3, R=2, audio_channels=1)
+    g = load_golden(fixture)
+    kw = dict(C=2, N=16, L=8, B=16, H=32, P=3, X=3, R=2, audio_channels=1, **extra)
     p = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     taps = {}
