@@ -58,7 +58,8 @@ __device__ __forceinline__ void gln_moments(const double* __restrict__ st, int m
 // ------------------------------------------------------------------------------------------------------------------
 // encoder + cLN.  One wave per frame; lane owns channels lane, lane + 64, ... (N <= 256); U^T in LDS.
 // ------------------------------------------------------------------------------------------------------------------
-#define ENC_MAXC 4
+#define ENC_MAXC 8        // the widest instantiation of the wave-per-frame kernels below
+template <int MC>        // channels per lane: N <= 64 MC (4: N <= 256, 8: N <= 512)
 __global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __restrict__ wav, const float* __restrict__ U /*[N][ac*L]*/,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int M,
                                                               int ac, int T, int K, int N, int L, float* __restrict__ w,
@@ -72,15 +73,15 @@ __global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __res
     const long frames = (long)M * K;
     for (long fr = (long)blockIdx.x * 4 + wave; fr < frames; fr += (long)gridDim.x * 4) {
         const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
-        float acc[ENC_MAXC];
+        float acc[MC];
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) acc[i] = 0.f;
+        for (int i = 0; i < MC; ++i) acc[i] = 0.f;
         for (int a = 0; a < ac; ++a) {
             const float* x = wav + ((long)m * ac + a) * T + (long)k * step;
             for (int l = 0; l < L; ++l) {
                 const float xv = x[l];
 #pragma unroll
-                for (int i = 0; i < ENC_MAXC; ++i) {
+                for (int i = 0; i < MC; ++i) {
                     const int n = lane + 64 * i;
                     if (n < N) acc[i] += xv * sU[(a * L + l) * N + n];
                 }
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __res
         }
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) {
+        for (int i = 0; i < MC; ++i) {
             acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
             if (lane + 64 * i < N) { s += acc[i]; q += acc[i] * acc[i]; }
         }
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void ctn_encoder_fwd_kernel(const float* __res
         var = var > 0.f ? var : 0.f;
         const float rs = 1.f / sqrtf(var + CTN_EPS);
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const int n = lane + 64 * i;
             if (n < N) {
                 w[fr * N + n] = acc[i];
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void ctn_encoder_fwd_mfma_kernel(const float* 
 
 // backward of cLN + ReLU + encoder conv:  dw = dw_dec + cLN'(dcln);  dpre = dw [w > 0];  dU[n][l] += dpre x[l]
 // gacc: dU [N][ac*L] | dgamma [N] | dbeta [N]   (fp32, atomics; caller zeroes)
+template <int MC>        // channels per lane: N <= 64 MC (4: N <= 256, 8: N <= 512)
 __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                                               const bf16_raw* __restrict__ dcln, const float* __restrict__ dw_dec,
                                                               const float* __restrict__ gamma, int M, int ac, int T, int K, int N, int L,
@@ -224,23 +226,23 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
     const int step = L / 2, AL = ac * L;
     const long frames = (long)M * K;
     const long f0 = ((long)blockIdx.x * 4 + wave) * frames_per_wave;
-    float dg[ENC_MAXC], db[ENC_MAXC];
+    float dg[MC], db[MC];
 #pragma unroll
-    for (int i = 0; i < ENC_MAXC; ++i) { dg[i] = 0.f; db[i] = 0.f; }
-    // dU accumulators: this lane's channels x taps, kept in LDS rows private to the wave (ENC_MAXC * AL floats per lane is too
+    for (int i = 0; i < MC; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    // dU accumulators: this lane's channels x taps, kept in LDS rows private to the wave (MC * AL floats per lane is too
     // many registers for L = 40): [wave][l][n]
     extern __shared__ float sdU[];
     float* mine = sdU + (size_t)wave * AL * N;
     for (int i = lane; i < AL * N; i += 64) mine[i] = 0.f;
-    float gam[ENC_MAXC];
+    float gam[MC];
 #pragma unroll
-    for (int i = 0; i < ENC_MAXC; ++i) gam[i] = lane + 64 * i < N ? gamma[lane + 64 * i] : 0.f;
+    for (int i = 0; i < MC; ++i) gam[i] = lane + 64 * i < N ? gamma[lane + 64 * i] : 0.f;
     for (long fr = f0; fr < f0 + frames_per_wave && fr < frames; ++fr) {
         const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
-        float wv[ENC_MAXC], dy[ENC_MAXC];
+        float wv[MC], dy[MC];
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const int n = lane + 64 * i;
             wv[i] = n < N ? w[fr * N + n] : 0.f;
             dy[i] = n < N ? bf2f(dcln[fr * N + n]) : 0.f;
@@ -251,16 +253,16 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
         float var = q / N - mean * mean;
         var = var > 0.f ? var : 0.f;
         const float rs = 1.f / sqrtf(var + CTN_EPS);
-        float s1 = 0.f, s2 = 0.f, xh[ENC_MAXC];
+        float s1 = 0.f, s2 = 0.f, xh[MC];
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) {
+        for (int i = 0; i < MC; ++i) {
             xh[i] = (wv[i] - mean) * rs;
             if (lane + 64 * i < N) { s1 += gam[i] * dy[i]; s2 += gam[i] * dy[i] * xh[i]; dg[i] += dy[i] * xh[i]; db[i] += dy[i]; }
         }
         s1 = wave_sum(s1) / N; s2 = wave_sum(s2) / N;
-        float dpre[ENC_MAXC];
+        float dpre[MC];
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const int n = lane + 64 * i;
             float dwv = n < N ? (gam[i] * dy[i] - s1 - xh[i] * s2) * rs + dw_dec[fr * N + n] : 0.f;
             dpre[i] = wv[i] > 0.f ? dwv : 0.f;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
             for (int l = 0; l < L; ++l) {
                 const float xv = x[l];
 #pragma unroll
-                for (int i = 0; i < ENC_MAXC; ++i) {
+                for (int i = 0; i < MC; ++i) {
                     const int n = lane + 64 * i;
                     if (n < N) mine[(a * L + l) * N + n] += dpre[i] * xv;
                 }
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void ctn_encoder_bwd_kernel(const float* __res
     for (int turn = 0; turn < 4; ++turn) {          // the four waves one after the other: a fixed order (LDS atomics have the hardware's)
         if (wave == turn) {
 #pragma unroll
-            for (int i = 0; i < ENC_MAXC; ++i) {
+            for (int i = 0; i < MC; ++i) {
                 const int n = lane + 64 * i;
                 if (n < N) { sgb[n] += dg[i]; sgb[N + n] += db[i]; }
             }
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(256) void ctn_gln_bwd_apply_kernel(const bf16_raw* 
 //   sw[c][n] = w[n] relu(mlin[c*N + n]);  frame[c][l] = sum_n sw[c][n] V[l][n];  out[m][c][a][k*step + l'] += frame (2 adds per
 //   sample: fp32 addition of two terms commutes, so the atomics are deterministic; caller zeroes `out`)
 // ------------------------------------------------------------------------------------------------------------------
+template <int MC>        // channels per lane: N <= 64 MC (4: N <= 256, 8: N <= 512)
 __global__ __launch_bounds__(256) void ctn_decoder_fwd_kernel(const float* __restrict__ w, const bf16_raw* __restrict__ mlin,
                                                               const float* __restrict__ V /*[ac*L][N]*/, int M, int K, int N, int L, int ac,
                                                               int Cs, int T, float* __restrict__ out /*[M][Cs][ac][T]*/) {
@@ -1089,6 +1092,7 @@ __global__ __launch_bounds__(256) void ctn_decoder_fwd_mfma_kernel(const float* 
 }
 
 // gacc: dV [AL][N] (fp32 atomics, caller zeroes).  dmlin [M][K][Cs*N] bf16, dw_dec [M][K][N] fp32 (overwritten)
+template <int MC>        // channels per lane: N <= 64 MC (4: N <= 256, 8: N <= 512)
 __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                                               const bf16_raw* __restrict__ mlin, const float* __restrict__ V, int M, int K,
                                                               int N, int L, int ac, int Cs, int T, int frames_per_wave,
@@ -1110,9 +1114,9 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __res
     const long f0 = ((long)blockIdx.x * 4 + wave) * frames_per_wave;
     for (long fr = f0; fr < f0 + frames_per_wave && fr < frames; ++fr) {
         const int m = (int)(fr / K), k = (int)(fr - (long)m * K);
-        float dwacc[ENC_MAXC];
+        float dwacc[MC];
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) dwacc[i] = 0.f;
+        for (int i = 0; i < MC; ++i) dwacc[i] = 0.f;
         for (int c = 0; c < Cs; ++c) {
             for (int al = lane; al < AL; al += 64) {
                 const int a = al / L, l = al - a * L;
@@ -1123,7 +1127,7 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __res
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int i = 0; i < ENC_MAXC; ++i) {
+            for (int i = 0; i < MC; ++i) {
                 const int n = lane + 64 * i;
                 if (n >= N) continue;
                 const float wv = w[fr * N + n];
@@ -1144,7 +1148,7 @@ __global__ __launch_bounds__(256) void ctn_decoder_bwd_kernel(const float* __res
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #pragma unroll
-        for (int i = 0; i < ENC_MAXC; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const int n = lane + 64 * i;
             if (n < N) dw_dec[fr * N + n] = dwacc[i];
         }
@@ -1296,7 +1300,8 @@ extern "C" int sehip_ctn_encoder_fwd(const float* wav, const float* U, const flo
     }
     long g = ((long)M * K + 3) / 4;
     if (g > 2048) g = 2048;
-    ctn_encoder_fwd_kernel<<<(int)g, 256, lds, (hipStream_t)stream>>>(wav, U, gamma, beta, M, ac, T, K, N, L, w, (bf16_raw*)cln_bf16);
+    if (N <= 256) ctn_encoder_fwd_kernel<4><<<(int)g, 256, lds, (hipStream_t)stream>>>(wav, U, gamma, beta, M, ac, T, K, N, L, w, (bf16_raw*)cln_bf16);
+    else ctn_encoder_fwd_kernel<8><<<(int)g, 256, lds, (hipStream_t)stream>>>(wav, U, gamma, beta, M, ac, T, K, N, L, w, (bf16_raw*)cln_bf16);
     SEHIP_CHECK_LAUNCH("ctn_encoder_fwd");
     return 0;
 }
@@ -1320,9 +1325,12 @@ extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const voi
     SEHIP_REQUIRE(scratch != nullptr, "ctn_encoder_bwd: missing scratch buffer");
     const int K = (T - L) / (L / 2) + 1;
     const size_t lds = ((size_t)4 * N * ac * L + 2 * N) * sizeof(float);
-    SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_encoder_bwd: %zu bytes of LDS needed", lds);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_encoder_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     const long frames = (long)M * K;
     const int fpw = ctn_frames_per_wave(frames);
     const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
@@ -1351,7 +1359,12 @@ extern "C" int sehip_ctn_encoder_bwd(const float* wav, const float* w, const voi
     else if (AL == 40 && NC == 1) ENC_REG(40, 1);
     else if (AL == 16 && NC <= 2 && rlds <= 64 * 1024) ENC_REG(16, 2);
     else if (AL == 20 && NC <= 2 && rlds <= 64 * 1024) ENC_REG(20, 2);
-    else ctn_encoder_bwd_kernel<<<grid, 256, lds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch);
+    else if (AL == 16 && NC <= 8 && rlds <= 64 * 1024) ENC_REG(16, 8);        // (N = 512, L = 16: the Conv-TasNet paper's encoder)
+    else {
+        SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_encoder_bwd: %zu bytes of LDS needed", lds);
+        if (N <= 256) ctn_encoder_bwd_kernel<4><<<grid, 256, lds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch);
+        else ctn_encoder_bwd_kernel<8><<<grid, 256, lds, st>>>(wav, w, (const bf16_raw*)dcln_bf16, dw_dec, gamma, M, ac, T, K, N, L, fpw, scratch);
+    }
 #undef ENC_REG
     ctn_colsum_kernel<<<ctn_colsum_grid(grid, ncols), 256, 0, st>>>(scratch, grid, ncols, gacc);
     SEHIP_CHECK_LAUNCH("ctn_encoder_bwd");
@@ -1543,7 +1556,8 @@ extern "C" int sehip_ctn_decoder_fwd(const float* w, const void* mlin_bf16, cons
     }
     long g = ((long)M * K + 3) / 4;
     if (g > 2048) g = 2048;
-    ctn_decoder_fwd_kernel<<<(int)g, 256, lds, (hipStream_t)stream>>>(w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, out);
+    if (N <= 256) ctn_decoder_fwd_kernel<4><<<(int)g, 256, lds, (hipStream_t)stream>>>(w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, out);
+    else ctn_decoder_fwd_kernel<8><<<(int)g, 256, lds, (hipStream_t)stream>>>(w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, out);
     SEHIP_CHECK_LAUNCH("ctn_decoder_fwd");
     return 0;
 }
@@ -1554,9 +1568,13 @@ extern "C" int sehip_ctn_decoder_bwd(const float* dout, const float* w, const vo
     SEHIP_REQUIRE(N >= 8 && N <= 64 * ENC_MAXC, "ctn_decoder_bwd: bad N=%d", N);
     SEHIP_REQUIRE(scratch != nullptr, "ctn_decoder_bwd: missing scratch buffer");
     const size_t lds = ((size_t)5 * ac * L * N + 4 * ac * L) * sizeof(float);
-    SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_decoder_bwd: %zu bytes of LDS needed", lds);
+    // (lds: what the wave-per-frame kernel at the end of the chain below needs; the register kernels keep one copy of the basis)
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_decoder_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctn_decoder_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     const long frames = (long)M * K;
     const int fpw = ctn_frames_per_wave(frames);
     const int grid = (int)((frames + 4L * fpw - 1) / (4L * fpw));
@@ -1569,8 +1587,14 @@ extern "C" int sehip_ctn_decoder_bwd(const float* dout, const float* w, const vo
     else if (AL == 40 && NC == 1) DEC_REG(40, 1);
     else if (AL == 16 && NC <= 2 && rlds <= 64 * 1024) DEC_REG(16, 2);
     else if (AL == 20 && NC <= 2 && rlds <= 64 * 1024) DEC_REG(20, 2);
-    else ctn_decoder_bwd_kernel<<<grid, 256, lds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
-                                                        (bf16_raw*)dmlin_bf16, dw_dec, scratch);
+    else if (AL == 16 && NC <= 8 && rlds <= 64 * 1024) DEC_REG(16, 8);
+    else {
+        SEHIP_REQUIRE(lds <= 160 * 1024, "ctn_decoder_bwd: %zu bytes of LDS needed", lds);
+        if (N <= 256) ctn_decoder_bwd_kernel<4><<<grid, 256, lds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
+                                                                       (bf16_raw*)dmlin_bf16, dw_dec, scratch);
+        else ctn_decoder_bwd_kernel<8><<<grid, 256, lds, st>>>(dout, w, (const bf16_raw*)mlin_bf16, V, M, K, N, L, ac, Cs, T, fpw,
+                                                              (bf16_raw*)dmlin_bf16, dw_dec, scratch);
+    }
 #undef DEC_REG
     ctn_colsum_kernel<<<ctn_colsum_grid(grid, ncols), 256, 0, st>>>(scratch, grid, ncols, gacc);
     SEHIP_CHECK_LAUNCH("ctn_decoder_bwd");

@@ -40,7 +40,11 @@ class TasNetConfig:
             raise SehipError(f"sehip ConvTasNet: L={L} must be even")
         self.sources = list(sources)
         self.C = len(self.sources)
-        if N > 256 or 5 * audio_channels * L * N * 4 + 4 * audio_channels * L * 4 > 160 * 1024:
+        # (the codec's backward kernels -- csrc/tasnet.hip sehip_ctn_decoder_bwd: either a register kernel for this (ac * L, N) with one
+        #  copy of the basis in LDS, or the wave-per-frame kernel with five)
+        al = audio_channels * L
+        reg = (al == 40 and N <= 128) or (al in (16, 20, 40) and N <= 128 and al * N * 4 <= 64 * 1024) or (al == 16 and N <= 512)
+        if N > 512 or al * (N + 1) * 4 + 16 * N > 64 * 1024 or (not reg and (5 * al * N + 4 * al) * 4 > 160 * 1024):
             raise SehipError(f"sehip ConvTasNet: N={N}, L={L}, audio_channels={audio_channels}: the decoder's basis does not fit the LDS")
         self.N, self.L, self.B, self.H, self.P, self.X, self.R = N, L, B, H, P, X, R
         self.audio_channels = audio_channels
