@@ -98,6 +98,12 @@ int sehip_sisnr_pit_fwd(const float* est, const float* ref, int B, int S, int C,
 int sehip_sisnr_pit_bwd(const float* est, const float* ref, const float* rowstat, const int* perm, const float* upstream /*or NULL*/,
                         int B, int S, int C, int n, float* dest, void* stream);
 
+/* ---- phase-sensitive spectral approximation loss: src/loss.py:32-56 (`optim.loss: psa`; the Solver passes the mixture's spectrum as
+ *      the third argument, src/solver.py:480).  enh / tgt / mix: ncomplex (real, imaginary) pairs each;
+ *      loss = mean_i (|E_i| - |T_i| cos(tanh(Ti / (Tr + 1e-9)) - tanh(Mi / (Mr + 1e-9))))^2   (the reference's formula as it stands).
+ *      acc: one double of scratch.  Backward: the gradient w.r.t. enh only (elements with |E| = 0 get 0). */
+int sehip_psa_loss_fwd(const float* enh, const float* tgt, const float* mix, long ncomplex, double* acc, float* loss, void* stream);
+int sehip_psa_loss_bwd(const float* enh, const float* tgt, const float* mix, long ncomplex, const float* upstream, float* denh, void* stream);
 /* ---- l1 / mse with reduction 'mean' (torch.nn.functional.l1_loss / mse_loss in src/distrib.py:263-268); mode 0 = l1, 1 = mse */
 int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, int mode, double* acc_scratch, float* loss, void* stream);
 int sehip_pointwise_loss_bwd(const float* x, const float* y, long n, int mode, const float* upstream, float* dx, void* stream);

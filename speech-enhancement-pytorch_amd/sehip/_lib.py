@@ -55,6 +55,8 @@ _PROTOS = {
     "sehip_sisnr_bwd": [P, P, P, P, I, I, P, P],
     "sehip_sisnr_pit_fwd": [P, P, I, I, I, I, P, P, P, P, P],
     "sehip_sisnr_pit_bwd": [P, P, P, P, P, I, I, I, I, P, P],
+    "sehip_psa_loss_fwd": [P, P, P, L, P, P, P],
+    "sehip_psa_loss_bwd": [P, P, P, L, P, P, P],
     "sehip_pointwise_loss_fwd": [P, P, L, I, P, P, P],
     "sehip_pointwise_loss_bwd": [P, P, L, I, P, P, P],
     "sehip_grad_sumsq": [P, L, P, P],

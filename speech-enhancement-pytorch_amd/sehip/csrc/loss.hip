@@ -296,6 +296,70 @@ __global__ __launch_bounds__(256) void pointwise_loss_bwd_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// phase-sensitive spectral approximation (src/loss.py:32-56, `optim.loss: psa`, STFT-domain models; the Solver hands the mixture's
+// spectrum as the third argument, src/solver.py:480).  Per complex element (last axis = (real, imaginary)):
+//   d = |E| - |T| cos(tanh(Ti / (Tr + 1e-9)) - tanh(Mi / (Mr + 1e-9)));   loss = mean d^2
+// (sic: tanh of the ratio, not atan -- the reference's formula is restated, not corrected).  Backward w.r.t. the enhanced spectrum:
+// dE = upstream * 2 d / n * E / |E|; an element with |E| = 0 gets 0 (torch's sqrt backward gives NaN there: 0 * inf).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float psa_residual(float2 e, float2 t, float2 m, float& ae) {
+    const float am = tanhf(m.y / (m.x + 1e-9f)), at = tanhf(t.y / (t.x + 1e-9f));
+    ae = sqrtf(e.y * e.y + e.x * e.x);
+    return ae - sqrtf(t.y * t.y + t.x * t.x) * cosf(at - am);
+}
+
+__global__ __launch_bounds__(256) void psa_loss_fwd_kernel(const float2* __restrict__ enh, const float2* __restrict__ tgt,
+                                                           const float2* __restrict__ mix, long n, double* __restrict__ acc) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        float ae;
+        const float d = psa_residual(enh[i], tgt[i], mix[i], ae);
+        a += d * d;
+    }
+    a = block_sum<4>(a, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)a);
+}
+
+__global__ __launch_bounds__(256) void psa_loss_bwd_kernel(const float2* __restrict__ enh, const float2* __restrict__ tgt,
+                                                           const float2* __restrict__ mix, long n, const float* __restrict__ upstream,
+                                                           float2* __restrict__ denh) {
+    const float up = 2.f * (upstream ? upstream[0] : 1.f) / (float)n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const float2 e = enh[i];
+        float ae;
+        const float d = psa_residual(e, tgt[i], mix[i], ae);
+        const float k = ae > 0.f ? up * d / ae : 0.f;
+        denh[i] = make_float2(k * e.x, k * e.y);
+    }
+}
+
+extern "C" int sehip_psa_loss_fwd(const float* enh, const float* tgt, const float* mix, long ncomplex, double* acc, float* loss, void* stream) {
+    SEHIP_REQUIRE(ncomplex > 0 && enh && tgt && mix, "psa_loss_fwd: bad arguments (n=%ld)", ncomplex);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(double), st);
+    SEHIP_REQUIRE(e == hipSuccess, "psa_loss_fwd: memset failed: %s", hipGetErrorString(e));
+    int grid = cdiv(ncomplex, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    if (sehip_deterministic()) grid = 1;
+    psa_loss_fwd_kernel<<<grid, 256, 0, st>>>((const float2*)enh, (const float2*)tgt, (const float2*)mix, ncomplex, acc);
+    pointwise_loss_finalize_kernel<<<1, 1, 0, st>>>(acc, ncomplex, loss);
+    SEHIP_CHECK_LAUNCH("psa_loss_fwd");
+    return 0;
+}
+
+extern "C" int sehip_psa_loss_bwd(const float* enh, const float* tgt, const float* mix, long ncomplex, const float* upstream, float* denh,
+                                  void* stream) {
+    SEHIP_REQUIRE(ncomplex > 0 && enh && tgt && mix && denh, "psa_loss_bwd: bad arguments (n=%ld)", ncomplex);
+    int grid = cdiv(ncomplex, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    psa_loss_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float2*)enh, (const float2*)tgt, (const float2*)mix, ncomplex, upstream,
+                                                             (float2*)denh);
+    SEHIP_CHECK_LAUNCH("psa_loss_bwd");
+    return 0;
+}
+
 extern "C" int sehip_pointwise_loss_fwd(const float* x, const float* y, long n, int mode, double* acc, float* loss,
                                         void* stream) {
     SEHIP_REQUIRE(n > 0 && (mode == 0 || mode == 1), "pointwise_loss_fwd: bad arguments (n=%ld mode=%d)", n, mode);

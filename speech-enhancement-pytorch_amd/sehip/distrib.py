@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import SehipError
-from .loss import loss_sisdr, l1_loss, mse_loss
+from .loss import loss_sisdr, l1_loss, mse_loss, loss_phase_sensitive_spectral_approximation
 from .model.dccrn import DCCRN
 from .model.conv_tasnet import ConvTasNet
 from .model.dcunet import DCUnet
@@ -57,8 +57,8 @@ def get_loss_function(config, device="gpu"):
         return mse_loss
     if config.loss == "si-sdr":
         return loss_sisdr
-    if config.loss == "psa":
-        raise SehipError("loss 'psa' (phase-sensitive spectral approximation, STFT-domain models) has no HIP path yet")
+    if config.loss == "psa":      # src/distrib.py:270-271; the Solver passes the mixture as the third argument (Solver._loss)
+        return loss_phase_sensitive_spectral_approximation
     raise ValueError(f"Loss function {config.loss} cannot use...")
 
 

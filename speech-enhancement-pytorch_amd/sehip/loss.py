@@ -125,3 +125,34 @@ def mse_loss(inputs, targets):
     if inputs.shape != targets.shape:
         raise SehipError(f"mse_loss: shape mismatch {tuple(inputs.shape)} vs {tuple(targets.shape)}")
     return _PointwiseLoss.apply(inputs, targets, 1)
+
+
+class _PsaLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enh, tgt, mix):
+        from ._lib import call, ptr, stream, require_gpu
+        require_gpu(enh, "psa loss")
+        e, t, m = enh.contiguous().float(), tgt.contiguous().float(), mix.contiguous().float()
+        acc = torch.zeros(1, dtype=torch.float64, device=enh.device)
+        loss = torch.empty(1, device=enh.device)
+        call("sehip_psa_loss_fwd", ptr(e), ptr(t), ptr(m), e.numel() // 2, ptr(acc), ptr(loss), stream())
+        ctx.save_for_backward(e, t, m)
+        ctx.shape = enh.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import call, ptr, stream
+        e, t, m = ctx.saved_tensors
+        de = torch.empty_like(e)
+        call("sehip_psa_loss_bwd", ptr(e), ptr(t), ptr(m), e.numel() // 2, ptr(g.reshape(1).contiguous().float()), ptr(de), stream())
+        return de.view(ctx.shape), None, None
+
+
+def loss_phase_sensitive_spectral_approximation(enhance, target, mixture):
+    """src/loss.py:32-56 (`optim.loss: psa`): mean (|E| - |T| cos(tanh(Ti / (Tr + eps)) - tanh(Mi / (Mr + eps))))^2 over [..., 2] spectra;
+    the gradient flows into `enhance` only (target and mixture are data in the Solver, src/solver.py:480)."""
+    if not (enhance.shape == target.shape == mixture.shape) or enhance.shape[-1] != 2:
+        raise SehipError(f"psa loss: three [..., 2] tensors of one shape expected, got {tuple(enhance.shape)}, {tuple(target.shape)}, "
+                         f"{tuple(mixture.shape)}")
+    return _PsaLoss.apply(enhance, target, mixture)

@@ -310,6 +310,15 @@ class Solver(object):
             g = self._unit = torch.ones_like(loss)
         return g
 
+    def _loss(self, enhanced, sources, mixture):
+        """src/solver.py:476-480: `optim.loss: psa` takes the mixture's spectrum as a third argument (broadcast over the speakers when the
+        model separates); every other loss is loss(enhanced, sources)."""
+        if _cfg(self.config.optim, "loss", None) != "psa":
+            return self.loss_function(enhanced, sources)
+        if sources.dim() == mixture.dim() + 1:
+            mixture = mixture.unsqueeze(1).expand_as(sources)
+        return self.loss_function(enhanced, sources, mixture)
+
     def _train_step(self, mixture, sources):
         if not self.model.training:
             self.model.train()
@@ -322,7 +331,7 @@ class Solver(object):
             from .loss import pit_loss
             loss = pit_loss(enhanced, sources, self.loss_function)
         else:
-            loss = self.loss_function(enhanced, sources)
+            loss = self._loss(enhanced, sources, mixture)
         self.optimizer.zero_grad()
         fused = isinstance(self.optimizer, FlatOptimizer)
         works, early_guard = [], False
@@ -414,7 +423,7 @@ class Solver(object):
         fb, upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(fb):
             enhanced = self.model(mix)
-            loss = self.loss_function(enhanced, src)
+            loss = self._loss(enhanced, src, mix)
             self.optimizer.zero_grad()
             loss.backward()
             loss_out = loss.detach().clone()
@@ -473,7 +482,7 @@ class Solver(object):
                 self.model.eval()
                 with torch.no_grad():
                     enhanced = self.model(mixture)
-                    loss_t = self.loss_function(enhanced, sources)
+                    loss_t = self._loss(enhanced, sources, mixture)
                 pending.append((step, loss_t.detach().clone(), None))
             if (step + 1) % self.log_interval == 0:
                 flush()
