@@ -22,8 +22,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+# (win_len, win_inc) of the DCCRN constructor (src/model/dccrn.py:14-15): the defaults and three other frame geometries -- half-overlap,
+# a window as long as the transform, a short window
+GEOMETRIES = [(400, 100), (320, 160), (512, 128), (256, 64)]
+
+
+@pytest.mark.parametrize("WIN,HOP", GEOMETRIES)
 @pytest.mark.parametrize("b,n", [(2, 4000), (3, 32000), (1, 700)])
-def test_stft_fwd(dev, b, n):
+def test_stft_fwd(dev, b, n, WIN, HOP):
     from sehip import ops
     g = torch.Generator().manual_seed(1)
     wav = torch.randn(b, n, generator=g) * 0.3
@@ -37,9 +43,10 @@ def test_stft_fwd(dev, b, n):
     assert rel_err(enc.float().cpu(), ref_c[:, :, 1:]) < 4e-3  # bf16 storage
 
 
+@pytest.mark.parametrize("WIN,HOP", GEOMETRIES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("b,n", [(2, 4000), (2, 32000)])
-def test_istft_fwd_bwd(dev, mode, b, n):
+def test_istft_fwd_bwd(dev, mode, b, n, WIN, HOP):
     from sehip import ops
     g = torch.Generator().manual_seed(2)
     wav = torch.randn(b, n, generator=g) * 0.3

@@ -20,6 +20,9 @@ CASES = [
     (2, 4000, dict(kernel_num=[16, 16, 32, 32, 64, 64], length=4000, masking_mode="R")),
     (17, 2000, dict(kernel_num=[16, 16, 16, 32, 32, 32], length=2000)),         # more than one LSTM batch tile, ragged
     (1, 100, dict(kernel_num=[16, 16, 16, 16, 16, 16], length=100)),            # 4 frames (the reference pads by win-hop)
+    # other frame geometries of the constructor (win_len, win_inc; src/model/dccrn.py:14-15): half overlap, a window as long as the transform
+    (2, 4000, dict(kernel_num=[16, 16, 32, 32, 64, 64], length=4000, win_len=320, win_inc=160)),
+    (3, 5000, dict(kernel_num=[16, 16, 32, 32, 64, 64], length=5000, win_len=512, win_inc=128, win_type="hamming")),
 ]
 
 
