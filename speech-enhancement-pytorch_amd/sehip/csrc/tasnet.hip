@@ -1387,13 +1387,17 @@ extern "C" int sehip_ctn_dwconv_fwd(const void* h1, const float* slope1, const d
                                     const float* Wd, int P, int dilation, const float* slope2, int M, int K, int C, void* h2, double* stats2,
                                     void* stream) {
     if (int e = ctn_check("ctn_dwconv_fwd", M, K, C)) return e;
-    SEHIP_REQUIRE(P == 3, "ctn_dwconv_fwd: only kernel size P=3 is built (got %d)", P);
+    SEHIP_REQUIRE(P == 3 || P == 5 || P == 7, "ctn_dwconv_fwd: kernel size P must be 3, 5 or 7 (got %d)", P);
     const dim3 grid = ctn_grid(M, K, C);
     bool ok;
     const DetCtx dc = sehip_det_ctx((hipStream_t)stream, (size_t)grid.x * grid.y * 2, &ok);
     if (!ok) return -2;
-    ctn_dwconv_fwd_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h1, slope1, stats1, gamma, beta, Wd, dilation,
-                                                                   slope2, K, C, (bf16_raw*)h2, stats2, dc);
+#define CTN_DWF(P_) ctn_dwconv_fwd_kernel<P_><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_raw*)h1, slope1, stats1, gamma, beta, Wd, dilation, \
+                                                                            slope2, K, C, (bf16_raw*)h2, stats2, dc)
+    if (P == 3) CTN_DWF(3);
+    else if (P == 5) CTN_DWF(5);
+    else CTN_DWF(7);
+#undef CTN_DWF
     if (int e = sehip_det_finish((hipStream_t)stream, dc, (int)grid.y, (int)grid.x, 2, stats2, 2)) return e;
     SEHIP_CHECK_LAUNCH("ctn_dwconv_fwd");
     return 0;
@@ -1412,29 +1416,36 @@ extern "C" int sehip_ctn_gln_apply(const void* h, const float* slope, const doub
 // sehip_ctn_gln_bwd_scratch_floats(M, K, C) floats (the blocks' per-channel partial rows).
 extern "C" long sehip_ctn_gln_bwd_scratch_floats(int M, int K, int C) {
     const dim3 grid = ctn_reduce_grid(M, K, C);
-    return (long)grid.x * grid.y * (5L * C + 3);          // partial rows + three slope-gradient sums per workgroup
+    return (long)grid.x * grid.y * (9L * C + 3);          // partial rows of 2 + P <= 9 values per channel + three slope-gradient sums per workgroup
 }
 
 extern "C" int sehip_ctn_gln_bwd(const void* g, const void* h, const float* slope, const double* stats, const float* gamma, const float* beta,
                                  const float* Wd, int P, int dilation, int dw, int M, int K, int C, double* sums, float* gch, void* dh,
                                  float* dslope, float* scratch, void* stream) {
     if (int e = ctn_check("ctn_gln_bwd", M, K, C)) return e;
-    SEHIP_REQUIRE(!dw || P == 3, "ctn_gln_bwd: only kernel size P=3 is built (got %d)", P);
+    SEHIP_REQUIRE(!dw || P == 3 || P == 5 || P == 7, "ctn_gln_bwd: kernel size P must be 3, 5 or 7 (got %d)", P);
     SEHIP_REQUIRE((C >> 3) <= 256, "ctn_gln_bwd: too many channels");
     SEHIP_REQUIRE(scratch != nullptr, "ctn_gln_bwd: missing scratch buffer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = ctn_grid(M, K, C), rgrid = ctn_reduce_grid(M, K, C);
-    const int ncols = (2 + (dw ? 3 : 0)) * C, nrows = (int)(rgrid.x * rgrid.y);
+    const int ncols = (2 + (dw ? P : 0)) * C, nrows = (int)(rgrid.x * rgrid.y);
     const size_t lds = (size_t)ncols * sizeof(float);
     bool ok;
     const DetCtx dc = sehip_det_ctx(st, (size_t)rgrid.x * rgrid.y * 2, &ok);
     if (!ok) return -2;
     const int det = sehip_deterministic();
     if (dw) {
-        ctn_gln_bwd_reduce_kernel<3, true><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch, dc);
-        if (int e = sehip_det_finish(st, dc, (int)rgrid.y, (int)rgrid.x, 2, sums, 2)) return e;
-        ctn_gln_bwd_apply_kernel<3, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh, dslope,
-                                                                scratch, nrows, ncols, gch, det);
+#define CTN_GB(P_)                                                                                                                                                         \
+    do {                                                                                                                                                                   \
+        ctn_gln_bwd_reduce_kernel<P_, true><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch, dc); \
+        if (int e = sehip_det_finish(st, dc, (int)rgrid.y, (int)rgrid.x, 2, sums, 2)) return e;                                                                            \
+        ctn_gln_bwd_apply_kernel<P_, true><<<grid, 256, 0, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, Wd, dilation, sums, K, C, (bf16_raw*)dh,      \
+                                                                 dslope, scratch, nrows, ncols, gch, det);                                                                  \
+    } while (0)
+        if (P == 3) CTN_GB(3);
+        else if (P == 5) CTN_GB(5);
+        else CTN_GB(7);
+#undef CTN_GB
     } else {
         ctn_gln_bwd_reduce_kernel<3, false><<<rgrid, 256, lds, st>>>((const bf16_raw*)g, (const bf16_raw*)h, slope, stats, gamma, beta, Wd, dilation, K, C, sums, scratch, dc);
         if (int e = sehip_det_finish(st, dc, (int)rgrid.y, (int)rgrid.x, 2, sums, 2)) return e;

@@ -4,7 +4,7 @@ Same constructor arguments, same ``forward(mixture[M, ac, T]) -> [M, C, ac, T]``
 (``encoder.conv1d_U.weight``, ``separator.network.{0,1,2.r.x.net...,3}``, ``decoder.basis_signals.weight``), so the
 reference's checkpoints load here and vice versa.  Parameters are views into one flat fp32 buffer; forward / backward run the
 HIP kernels through the C ABI; a CPU tensor raises SehipError.  Built: the shipped options (skip=False, gLN, non-causal,
-relu or softmax mask), kernel size P=3, channel counts that are multiples of 8 (N up to 512: the paper's N = 512, L = 16 encoder
+relu or softmax mask), kernel size P = 3 / 5 / 7, channel counts that are multiples of 8 (N up to 512: the paper's N = 512, L = 16 encoder
 included; B, H up to 512).
 """
 import math

@@ -31,8 +31,8 @@ class TasNetConfig:
         if mask_nonlinear == "softmax" and len(sources) > 8:
             raise SehipError("sehip ConvTasNet: mask_nonlinear='softmax' is built for at most 8 sources")
         self.mask_nonlinear = mask_nonlinear
-        if P != 3:
-            raise SehipError("sehip ConvTasNet: only kernel size P=3 is built")
+        if P not in (3, 5, 7):
+            raise SehipError("sehip ConvTasNet: kernel size P must be 3, 5 or 7 (the sizes csrc/tasnet.hip instantiates)")
         for name, v in (("N", N), ("B", B), ("H", H)):
             if v % 8 or v < 8:
                 raise SehipError(f"sehip ConvTasNet: {name}={v} must be a multiple of 8")

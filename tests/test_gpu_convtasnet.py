@@ -191,6 +191,49 @@ def test_wide_encoder_vs_oracle(N, L):
     assert max(v for k, v in e.items() if k != "d score") < 2e-5 and e["d score"] < 1.8e-3, e
 
 
+@pytest.mark.parametrize("P", [5, 7])
+def test_wider_depthwise_kernels_vs_oracle(P):
+    """P = 5 / 7 (src/model/conv_tasnet.py:40, :352-402: the depthwise convolution's kernel size; csrc/tasnet.hip instantiates its stream
+    kernels for 3, 5 and 7) on a shallow separator (X = 3: dilations 1, 2, 4; R = 1): separated sources against the fp32 oracle, every
+    parameter gradient under a fixed upstream gradient, and block 0's streams op-locally in float64 from the HIP path's own h1 / h2."""
+    from sehip.model import ConvTasNet
+    kw = dict(N=64, L=16, B=64, H=128, P=P, X=3, R=1, audio_channels=1)
+    torch.manual_seed(35 + P)
+    model = ConvTasNet(sources=["None", "None"], **kw).cuda()
+    p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(36)
+    mix = 0.3 * torch.randn(3, 1, 3000, generator=g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    names = sorted(leaves)
+    ref = CT.convtasnet_forward(leaves, mix, C=2, **kw)
+    G = torch.randn(ref.shape, generator=g) / ref.numel() ** 0.5
+    est = model(mix.cuda())
+    assert rel_err(est.detach().cpu(), ref.detach()) < 1e-2
+    est.backward(G.cuda())
+    got = {k: v.grad.detach().cpu() for k, v in model.named_parameters()}
+    want = dict(zip(names, torch.autograd.grad((ref * G).sum(), [leaves[k] for k in names])))
+    num = sum(float(((got[k].double() - want[k].double()) ** 2).sum()) for k in names)
+    den = sum(float((want[k].double() ** 2).sum()) for k in names)
+    dw = {k: rel_err(got[k], want[k]) for k in names if k.endswith("3.net.0.weight")}
+    print(f"ConvTasNet P={P}: output rel {rel_err(est.detach().cpu(), ref.detach()):.3e}, global grad rel {(num / den) ** 0.5:.3e}, depthwise weights {dw}")
+    # (chain-level figures carry the separator's bf16 noise -- measured 4.1e-2 ... 4.3e-2 globally, 4.8e-2 ... 8.0e-2 for the small depthwise
+    #  tensors; the tight gate on the new instantiations is the op-local one below)
+    assert (num / den) ** 0.5 < 7e-2 and max(dw.values()) < 0.15
+    # block 2 (dilation 4) op-locally: h2 = depthwise(gLN(PReLU(h1))) and its weight gradient from the stored h1 and dh2 (SEHIP_CTN_KEEP_GRADS
+    # is off: the LAST block visited by the backward pass, block 0, still owns the shared du / dh2 buffers -- use block 0, dilation 1)
+    ws = model.workspace(3, 3000)
+    tr = lambda name: ws.bufs[name].t.float().cpu()[:, :, 0].transpose(1, 2).contiguous().double()
+    q = "separator.network.2.0.0.net."
+    lv = {k: p[q + k].double().clone().requires_grad_(True) for k in ("1.weight", "2.gamma", "2.beta", "3.net.0.weight")}
+    h1 = tr("h1_0")
+    n1 = CT.gln(F.prelu(h1, lv["1.weight"]), lv["2.gamma"], lv["2.beta"])
+    h2 = F.conv1d(n1, lv["3.net.0.weight"], padding=(P - 1) // 2, dilation=1, groups=h1.shape[1])
+    assert rel_err(tr("h2_0"), h2.detach()) < 1.8e-3                                  # one bf16 rounding of the stored tensor
+    gw = torch.autograd.grad((h2 * tr(ws.st.dh2_name(0))).sum(), [lv["3.net.0.weight"], lv["2.gamma"], lv["2.beta"], lv["1.weight"]])
+    for k, gref in zip(("3.net.0.weight", "2.gamma", "2.beta", "1.weight"), gw):
+        assert rel_err(got[q + k].double(), gref) < 2e-4, (k, rel_err(got[q + k].double(), gref))
+
+
 def test_full_width_model_vs_oracle():
     """N128 L40 B128 H256 P3 X7 R2, two speakers (the C4 network), 2 clips of 8000 samples.
     (1) forward + SI-SNR loss; (2) the backward pass under a FIXED upstream gradient G (loss = <est, G>): every parameter gradient
