@@ -506,7 +506,7 @@ int sehip_dcunet_tail_bwd(const float* dout, const float* spec, float* mask_ws, 
  *                    w [M][K][N] fp32 (mixture_w, kept for the decoder) and cln [M][K][N] bf16
  *      encoder_bwd : gacc += {dU [N][ac*L], dgamma [N], dbeta [N]} from dcln (bf16) and dw_dec (fp32, the decoder's share)
  *      gln_stats   : stats[m] += (sum, sum of squares) of PReLU(h[m]; slope)                                   (:465-487)
- *      dwconv_fwd  : h2 = depthwise dilated Conv1d(groups = C, P = 3, 'same') of gLN(PReLU(h1)) (:366-379); stats2 += PReLU(h2)
+ *      dwconv_fwd  : h2 = depthwise dilated Conv1d(groups = C, P = 3, 5 or 7, 'same') of gLN(PReLU(h1)) (:366-379); stats2 += PReLU(h2)
  *      gln_apply   : u = gLN(PReLU(h))
  *      gln_bwd     : gradient of y = gLN(PReLU(h)) [dw = 1: behind the depthwise conv, g = d h2]: dh, sums [M][2],
  *                    gch += {dgamma [C], dbeta [C] [, dWd [C][P]]}, dslope += d PReLU slope
