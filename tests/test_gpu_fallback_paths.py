@@ -87,7 +87,10 @@ def test_batchnorm_pass_variants_agree():
         return float((x["named"][n] - y["named"][n]).norm() / y["named"][n].norm())
 
     noise = {n: err(b, a, n) for n in names}
-    floor = 3e-2          # a different rounding of the batch statistics moves bf16 activations: a few times the atomics' own noise
+    # a different rounding of the batch statistics moves bf16 activations: a few times the atomics' own noise.  (Round 6: the floor was 3e-2 and
+    # the suite failed here ONCE in ~30 runs; measured over 8 x 3 comparisons on one box: the worst tensor is the 16-element decoder.4.1.Wri /
+    # .Br of the separate-passes variant at 2.0e-2 ... 2.5e-2 with a run-to-run noise of 3e-3 ... 7e-3 -- 0.8 of the old floor.)
+    floor = 6e-2
     for env in ({"SEHIP_NO_FUSE_STATS": "1", "SEHIP_NO_FUSE_FINALIZE": "1"}, {"SEHIP_NO_FUSE_STATS32": "1"}, {"SEHIP_FUSE_BWD_FINALIZE": "1"}):
         other = run(env)
         assert float((other["out"] - a["out"]).norm() / a["out"].norm()) < 1e-2, env
