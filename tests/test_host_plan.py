@@ -267,6 +267,26 @@ def test_module_schema_and_optimizer_state_on_cpu():
         distrib.get_model(utils.dict2obj({"name": "dcunet"}))
 
 
+@pytest.mark.parametrize("case,extra", [("hamming", dict(win_type="hamming")), ("realbn", dict(use_cbn=False)), ("rnn1", dict(rnn_layers=1)),
+                                        ("rnn3", dict(rnn_layers=3)), ("ru256", dict(rnn_units=256)), ("reallstm", dict(use_clstm=False))])
+def test_constructor_variants_keep_the_reference_parameter_order(case, extra):
+    """The module tree of every constructor variant against what the IMPORTED reference registered (tests/golden/dccrn_variants.npz keeps
+    its named_parameters() order and every gradient's shape): same names, same order, same shapes -- optimizer state indices and
+    checkpoints interchange.  CPU: the modules are built without a GPU."""
+    from sehip.model import DCCRN
+    from util import load_golden, json_entry
+    g = {k[len(case) + 1:]: v for k, v in load_golden("dccrn_variants.npz").items() if k.startswith(case + "/")}
+    names = json_entry(g, "grad_names_json")
+    m = DCCRN(kernel_num=[16, 16, 32, 32, 64, 64], length=4000, **extra)
+    mine = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+    assert [n for n, _ in mine] == list(names)
+    for n, shape in mine:
+        assert tuple(g["grad16/" + n].shape) == shape, n
+    for k in g:
+        if k.startswith("state_after/"):
+            assert k[len("state_after/"):] in m.state_dict(), k
+
+
 def test_fused_statistics_column_tiles():
     """The forward products that also accumulate the ComplexBatchNorm sums (sehip_gemm_desc.stats): every 128-column tile
     must hold [64 re | 64 im] of the same 64 complex channels, and the re-ordered product is still the reference's conv."""
